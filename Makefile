@@ -1,0 +1,42 @@
+# Top-level build: host library (g++), HIP library (hipcc, gfx950), C++ benchmark driver, oracle.
+#   make            -> everything
+#   make host hip oracle benchmark
+# Built artefacts stay in-tree (hisparse_amd/lib/, oracle/liboracle.so): they are git-ignored but
+# travel to the GPU box with the gpurun snapshot.
+ROOT      := $(abspath .)
+INC       := -I$(ROOT)/include
+LIBDIR    := $(ROOT)/hisparse_amd/lib
+CSRC      := $(ROOT)/hisparse_amd/csrc
+CXX       ?= g++
+HIPCC     ?= /opt/rocm/bin/hipcc
+CXXFLAGS  := -O3 -std=c++17 -fPIC -Wall -Wextra -pthread $(INC)
+HIPFLAGS  := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -ffp-contract=off -Wall $(INC)
+
+HOST_HDRS := $(wildcard include/hisparse/*.h) include/hisparse_host.h
+HIP_HDRS  := include/hisparse_hip.h $(wildcard $(CSRC)/*.h) include/hisparse/common.h
+
+.PHONY: all host hip oracle benchmark clean
+all: host hip oracle benchmark
+
+host: $(LIBDIR)/libhisparse_host.so
+hip: $(LIBDIR)/libhisparse_hip.so
+oracle: oracle/liboracle.so
+benchmark: $(LIBDIR)/benchmark
+
+$(LIBDIR):
+	mkdir -p $(LIBDIR)
+
+$(LIBDIR)/libhisparse_host.so: $(CSRC)/host_capi.cpp $(HOST_HDRS) | $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $< -lz
+
+$(LIBDIR)/libhisparse_hip.so: $(CSRC)/hs_api.cpp $(CSRC)/stream_tiles.cpp $(CSRC)/spmv_kernels.hip $(HIP_HDRS) | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/hs_api.cpp $(CSRC)/stream_tiles.cpp $(CSRC)/spmv_kernels.hip -pthread
+
+$(LIBDIR)/benchmark: $(CSRC)/benchmark.cpp $(HOST_HDRS) include/hisparse_hip.h $(LIBDIR)/libhisparse_hip.so | $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lhisparse_hip -lz -Wl,-rpath,'$$ORIGIN'
+
+oracle/liboracle.so: oracle/cpu_ref.c
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(LIBDIR) oracle/liboracle.so oracle/_ref
