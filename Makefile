@@ -29,8 +29,9 @@ $(LIBDIR):
 $(LIBDIR)/libhisparse_host.so: $(CSRC)/host_capi.cpp $(HOST_HDRS) | $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $< -lz
 
-$(LIBDIR)/libhisparse_hip.so: $(CSRC)/hs_api.cpp $(CSRC)/stream_tiles.cpp $(CSRC)/spmv_kernels.hip $(HIP_HDRS) | $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/hs_api.cpp $(CSRC)/stream_tiles.cpp $(CSRC)/spmv_kernels.hip -pthread
+HIP_SRCS  := $(CSRC)/hs_api.cpp $(CSRC)/tiles_capi.cpp $(CSRC)/stream_tiles.cpp $(CSRC)/spmv_kernels.hip
+$(LIBDIR)/libhisparse_hip.so: $(HIP_SRCS) $(HIP_HDRS) | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS) -pthread
 
 $(LIBDIR)/benchmark: $(CSRC)/benchmark.cpp $(HOST_HDRS) include/hisparse_hip.h $(LIBDIR)/libhisparse_hip.so | $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lhisparse_hip -lz -Wl,-rpath,'$$ORIGIN'

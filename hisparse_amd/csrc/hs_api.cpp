@@ -1,0 +1,401 @@
+// hs_api.cpp — implementation of the drop-in C-ABI (include/hisparse_hip.h) on the HIP runtime.
+//
+// The reference reaches its device through OpenCL/XRT objects created in sw/benchmark.cpp:228-298 and
+// launches five kernels per row partition (:318-338).  Here one context owns one HIP device, one
+// stream and the device-resident data; hs_run launches the whole SpMV (all row partitions) as
+//   fixed:  spmv_stream_kernel<fixed> -> finalize_fixed_kernel
+//   float:  hipMemsetAsync(y)          -> spmv_stream_kernel<float>
+// There is no CPU fallback anywhere in this file: without a usable gfx950 device every call fails.
+#include "hisparse_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "hisparse/common.h"
+#include "spmv_kernels.h"
+#include "stream_tiles.h"
+
+using hisparse::Geometry;
+using hisparse::dev::Piece;
+
+struct hs_context {
+    int device = -1;
+    int impl = 0;
+    Geometry geom;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int compute_units = 0;
+
+    bool matrix_loaded = false;
+    bool vector_loaded = false;
+    uint32_t num_rows = 0, num_cols = 0, row_parts = 0, col_parts = 0;
+    uint8_t* d_image = nullptr;
+    Piece* d_pieces = nullptr;
+    uint32_t* d_wg_first = nullptr;
+    uint32_t num_workgroups = 0;
+    uint32_t row_stride = 0;
+    uint32_t lds_bytes = 0;
+
+    uint32_t* d_x = nullptr;       // library-owned packed x
+    uint32_t* d_y = nullptr;       // library-owned packed y
+    uint64_t* d_accum = nullptr;   // fixed point: 64-bit row accumulators, zero between runs
+    const uint32_t* x_bound = nullptr;
+    uint32_t* y_bound = nullptr;
+    uint32_t x_capacity = 0;
+
+    hs_stats stats{};
+    std::string error;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr uint32_t kAccumSlackRows = 2048;  // a run's counter may step one stride past the last row before it ends
+
+int fail(hs_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->error = msg; else g_create_error = msg;
+    return code;
+}
+int hip_fail(hs_context* ctx, hipError_t e, const char* what) {
+    return fail(ctx, HS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HS_HIP(ctx, call)                                       \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call);  \
+    } while (0)
+
+void free_matrix(hs_context* c) {
+    if (c->d_image) (void)hipFree(c->d_image);
+    if (c->d_pieces) (void)hipFree(c->d_pieces);
+    if (c->d_wg_first) (void)hipFree(c->d_wg_first);
+    if (c->d_y) (void)hipFree(c->d_y);
+    if (c->d_accum) (void)hipFree(c->d_accum);
+    c->d_image = nullptr;
+    c->d_pieces = nullptr;
+    c->d_wg_first = nullptr;
+    c->d_y = nullptr;
+    c->d_accum = nullptr;
+    c->y_bound = nullptr;
+    c->matrix_loaded = false;
+}
+
+uint32_t* y_target(hs_context* c) { return c->y_bound ? c->y_bound : c->d_y; }
+const uint32_t* x_source(hs_context* c) { return c->x_bound ? c->x_bound : c->d_x; }
+
+int check_ready(hs_context* ctx) {
+    if (!ctx) return HS_ERR_BAD_ARG;
+    if (!ctx->matrix_loaded) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix has not been called");
+    if (!ctx->vector_loaded && !ctx->x_bound) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_vector has not been called");
+    return HS_OK;
+}
+
+hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
+    hisparse::dev::SpmvLaunch a;
+    a.image = c->d_image;
+    a.pieces = c->d_pieces;
+    a.wg_first = c->d_wg_first;
+    a.x = x_source(c);
+    a.accum = c->impl == HS_IMPL_FIXED ? static_cast<void*>(c->d_accum) : static_cast<void*>(y_target(c));
+    a.num_cols = c->num_cols;
+    a.tile_cols = uint32_t(c->geom.logical_vb);
+    a.row_stride = c->row_stride;
+    a.row_part_filter = filter;
+    a.num_workgroups = c->num_workgroups;
+    a.lds_bytes = c->lds_bytes;
+    return a;
+}
+
+// rows [lo, hi) of row partition j
+void partition_rows(const hs_context* c, uint32_t j, uint32_t& lo, uint32_t& hi) {
+    const uint64_t a = uint64_t(j) * c->geom.logical_ob;
+    const uint64_t b = std::min<uint64_t>(a + c->geom.logical_ob, c->num_rows);
+    lo = uint32_t(a);
+    hi = uint32_t(b);
+}
+
+// Enqueue one SpMV (filter < 0) or one row partition; optional events bracket the dominant kernel.
+int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1) {
+    uint32_t lo = 0, hi = c->num_rows;
+    if (filter >= 0) partition_rows(c, uint32_t(filter), lo, hi);
+    const bool is_float = c->impl != HS_IMPL_FIXED;
+    if (is_float) HS_HIP(c, hipMemsetAsync(y_target(c) + lo, 0, size_t(hi - lo) * 4, c->stream));
+    if (k0) HS_HIP(c, hipEventRecord(k0, c->stream));
+    HS_HIP(c, hisparse::dev::launch_spmv_stream(is_float, launch_args(c, filter), c->stream));
+    if (k1) HS_HIP(c, hipEventRecord(k1, c->stream));
+    if (!is_float) HS_HIP(c, hisparse::dev::launch_finalize_fixed(c->d_accum, y_target(c), lo, hi, c->stream));
+    return HS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hs_strerror(int code) {
+    switch (code) {
+        case HS_OK: return "ok";
+        case HS_ERR_BAD_ARG: return "bad argument";
+        case HS_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case HS_ERR_HIP: return "HIP runtime error";
+        case HS_ERR_BAD_MATRIX: return "channel buffers are not a valid CPSR image";
+        case HS_ERR_NOT_LOADED: return "matrix or vector not loaded";
+        case HS_ERR_UNSUPPORTED: return "unsupported configuration";
+        case HS_ERR_NO_MEMORY: return "out of memory";
+        default: return "unknown error";
+    }
+}
+
+const char* hs_last_error(const hs_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int hs_create(hs_context** out, int device_id, int impl, uint32_t ob_bank, uint32_t vb_bank) {
+    if (!out) return fail(nullptr, HS_ERR_BAD_ARG, "null context pointer");
+    *out = nullptr;
+    if (!hisparse::impl_valid(impl)) return fail(nullptr, HS_ERR_BAD_ARG, "impl must be 0 (fixed), 1 (float_pob) or 2 (float_stall)");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(nullptr, HS_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= count) return fail(nullptr, HS_ERR_BAD_ARG, "device_id out of range");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, HS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    hs_context* c = new (std::nothrow) hs_context;
+    if (!c) return fail(nullptr, HS_ERR_NO_MEMORY, "out of memory");
+    c->device = device_id;
+    c->impl = impl;
+    c->geom = hisparse::make_geometry(impl, ob_bank ? ob_bank : hisparse::impl_default_ob_bank(impl),
+                                      vb_bank ? vb_bank : hisparse::impl_default_vb_bank(impl));
+    c->compute_units = prop.multiProcessorCount;
+    if (c->geom.logical_ob > 0xffffffffull || c->geom.logical_vb > 0xffffffffull || c->geom.logical_ob % c->geom.row_divisor != 0) {
+        delete c;
+        return fail(nullptr, HS_ERR_BAD_ARG, "ob_bank must make 128*ob_bank a multiple of 128*interleave; bank sizes must fit 32 bits");
+    }
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete c;
+        return hip_fail(nullptr, e, "hipSetDevice/hipStreamCreate");
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return HS_OK;
+}
+
+int hs_destroy(hs_context* ctx) {
+    if (!ctx) return HS_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_matrix(ctx);
+    if (ctx->d_x) (void)hipFree(ctx->d_x);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return HS_OK;
+}
+
+int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], const uint64_t n_packets[HS_NUM_CHANNELS],
+                   uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions, uint32_t num_col_partitions) {
+    if (!ctx || !channel || !n_packets) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+    const Geometry& g = ctx->geom;
+    if (num_rows == 0 || num_cols == 0) return fail(ctx, HS_ERR_BAD_ARG, "empty matrix");
+    if (num_rows % g.row_divisor != 0 || num_cols % hisparse::PACK_SIZE != 0)
+        return fail(ctx, HS_ERR_BAD_ARG, "dimensions are not padded: rows must divide by " + std::to_string(g.row_divisor) +
+                                             " and columns by 8 (util_round_csr_matrix_dim)");
+    if (num_row_partitions != (num_rows + g.logical_ob - 1) / g.logical_ob || num_col_partitions != (num_cols + g.logical_vb - 1) / g.logical_vb)
+        return fail(ctx, HS_ERR_BAD_ARG, "partition counts do not match the dimensions and the bank sizes of this context");
+    const uint64_t tile_cols = std::min<uint64_t>(g.logical_vb, num_cols);
+    if (tile_cols > hisparse::dev::kMaxTileCols)
+        return fail(ctx, HS_ERR_UNSUPPORTED, "vector bank of " + std::to_string(g.vb_bank) + " words needs an x tile of " +
+                                                 std::to_string(tile_cols * 4) + " bytes; the LDS holds 163840");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_matrix(ctx);
+    const auto t0 = std::chrono::steady_clock::now();
+
+    const uint32_t lds_bytes = uint32_t((tile_cols * 4 + 15) / 16 * 16);
+    const uint32_t wg_per_cu = lds_bytes <= 80 * 1024 ? 2u : 1u;  // 1024-thread workgroups: at most 2 per CU
+    hisparse::dev::StreamTiles tiles;
+    std::string why;
+    try {
+        if (!hisparse::dev::build_stream_tiles(channel, n_packets, g, num_rows, num_cols, num_row_partitions, num_col_partitions,
+                                               uint32_t(ctx->compute_units) * wg_per_cu, tiles, why))
+            return fail(ctx, HS_ERR_BAD_MATRIX, why);
+    } catch (const std::bad_alloc&) {
+        return fail(ctx, HS_ERR_NO_MEMORY, "out of host memory while re-tiling the matrix");
+    }
+
+    HS_HIP(ctx, hisparse::dev::configure_spmv_kernels(lds_bytes));
+    const size_t image_bytes = std::max<size_t>(tiles.image.size(), 256);
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_image), image_bytes));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_pieces), std::max<size_t>(tiles.pieces.size(), 1) * sizeof(Piece)));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_wg_first), tiles.wg_first.size() * sizeof(uint32_t)));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
+    if (!tiles.image.empty()) HS_HIP(ctx, hipMemcpy(ctx->d_image, tiles.image.data(), tiles.image.size(), hipMemcpyHostToDevice));
+    if (!tiles.pieces.empty()) HS_HIP(ctx, hipMemcpy(ctx->d_pieces, tiles.pieces.data(), tiles.pieces.size() * sizeof(Piece), hipMemcpyHostToDevice));
+    HS_HIP(ctx, hipMemcpy(ctx->d_wg_first, tiles.wg_first.data(), tiles.wg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
+    if (ctx->impl == HS_IMPL_FIXED) {
+        const size_t n = size_t(num_rows) + kAccumSlackRows;
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_accum), n * 8));
+        HS_HIP(ctx, hipMemset(ctx->d_accum, 0, n * 8));
+    }
+    ctx->num_rows = num_rows;
+    ctx->num_cols = num_cols;
+    ctx->row_parts = num_row_partitions;
+    ctx->col_parts = num_col_partitions;
+    ctx->num_workgroups = tiles.num_workgroups;
+    ctx->row_stride = tiles.row_stride;
+    ctx->lds_bytes = lds_bytes;
+    ctx->matrix_loaded = true;
+
+    hs_stats& s = ctx->stats;
+    s = hs_stats{};
+    s.nnz = tiles.nnz;
+    for (int c = 0; c < HS_NUM_CHANNELS; ++c) s.cpsr_bytes += n_packets[c] * sizeof(hisparse::MatPkt);
+    s.stream_bytes = tiles.image.size();
+    s.stream_elements = tiles.elements;
+    s.num_pieces = uint32_t(tiles.pieces.size());
+    s.num_workgroups = tiles.num_workgroups;
+    s.lds_bytes = lds_bytes;
+    s.num_compute_units = uint32_t(ctx->compute_units);
+    s.load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return HS_OK;
+}
+
+int hs_load_vector(hs_context* ctx, const void* packed_x, uint32_t num_cols) {
+    if (!ctx || !packed_x) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+    if (ctx->matrix_loaded && num_cols != ctx->num_cols) return fail(ctx, HS_ERR_BAD_ARG, "vector length must equal the padded column count");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    if (num_cols > ctx->x_capacity) {
+        HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_x) (void)hipFree(ctx->d_x);
+        ctx->d_x = nullptr;
+        ctx->x_capacity = 0;
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_x), size_t(num_cols) * 4 + 64));
+        ctx->x_capacity = num_cols;
+    }
+    HS_HIP(ctx, hipMemcpyAsync(ctx->d_x, packed_x, size_t(num_cols) * 4, hipMemcpyHostToDevice, ctx->stream));
+    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller may reuse packed_x immediately
+    ctx->vector_loaded = true;
+    return HS_OK;
+}
+
+int hs_run(hs_context* ctx) {
+    int rc = check_ready(ctx);
+    if (rc != HS_OK) return rc;
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    return enqueue(ctx, -1, nullptr, nullptr);
+}
+
+int hs_run_partition(hs_context* ctx, uint32_t row_part_id, uint32_t part_len) {
+    int rc = check_ready(ctx);
+    if (rc != HS_OK) return rc;
+    if (row_part_id >= ctx->row_parts) return fail(ctx, HS_ERR_BAD_ARG, "row_part_id out of range");
+    uint32_t lo, hi;
+    partition_rows(ctx, row_part_id, lo, hi);
+    if (part_len != (hi - lo) / hisparse::NUM_HBM_CHANNELS)
+        return fail(ctx, HS_ERR_BAD_ARG, "part_len must be the partition's rows / 16 (sw/benchmark.cpp:301-322): expected " +
+                                             std::to_string((hi - lo) / hisparse::NUM_HBM_CHANNELS));
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    return enqueue(ctx, int32_t(row_part_id), nullptr, nullptr);
+}
+
+int hs_sync(hs_context* ctx) {
+    if (!ctx) return HS_ERR_BAD_ARG;
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HS_OK;
+}
+
+int hs_read_result(hs_context* ctx, void* packed_y, uint32_t num_rows) {
+    if (!ctx || !packed_y) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+    if (!ctx->matrix_loaded) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix has not been called");
+    if (num_rows != ctx->num_rows) return fail(ctx, HS_ERR_BAD_ARG, "result length must equal the padded row count");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_HIP(ctx, hipMemcpyAsync(packed_y, y_target(ctx), size_t(num_rows) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HS_OK;
+}
+
+int hs_set_stream(hs_context* ctx, void* hip_stream) {
+    if (!ctx) return HS_ERR_BAD_ARG;
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return HS_OK;
+}
+
+int hs_device_vector(hs_context* ctx, void** x_dev) {
+    if (!ctx || !x_dev) return HS_ERR_BAD_ARG;
+    if (!ctx->d_x) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_vector has not been called");
+    *x_dev = ctx->d_x;
+    return HS_OK;
+}
+
+int hs_device_result(hs_context* ctx, void** y_dev) {
+    if (!ctx || !y_dev) return HS_ERR_BAD_ARG;
+    if (!ctx->matrix_loaded) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix has not been called");
+    *y_dev = ctx->d_y;
+    return HS_OK;
+}
+
+int hs_bind_device_vector(hs_context* ctx, const void* x_dev) {
+    if (!ctx) return HS_ERR_BAD_ARG;
+    if (x_dev && (reinterpret_cast<uintptr_t>(x_dev) & 15u)) return fail(ctx, HS_ERR_BAD_ARG, "device vector must be 16-byte aligned");
+    ctx->x_bound = static_cast<const uint32_t*>(x_dev);
+    return HS_OK;
+}
+
+int hs_bind_device_result(hs_context* ctx, void* y_dev) {
+    if (!ctx) return HS_ERR_BAD_ARG;
+    if (y_dev && (reinterpret_cast<uintptr_t>(y_dev) & 3u)) return fail(ctx, HS_ERR_BAD_ARG, "device result must be 4-byte aligned");
+    ctx->y_bound = static_cast<uint32_t*>(y_dev);
+    return HS_OK;
+}
+
+int hs_get_stats(const hs_context* ctx, hs_stats* stats) {
+    if (!ctx || !stats) return HS_ERR_BAD_ARG;
+    *stats = ctx->stats;
+    return HS_OK;
+}
+
+int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* kernel_ms) {
+    int rc = check_ready(ctx);
+    if (rc != HS_OK) return rc;
+    if (warmup < 0 || runs <= 0) return fail(ctx, HS_ERR_BAD_ARG, "need warmup >= 0 and runs > 0");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < warmup; ++i)
+        if ((rc = enqueue(ctx, -1, nullptr, nullptr)) != HS_OK) return rc;
+    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipEvent_t begin, end;
+    HS_HIP(ctx, hipEventCreate(&begin));
+    HS_HIP(ctx, hipEventCreate(&end));
+    std::vector<hipEvent_t> k(kernel_ms ? size_t(runs) * 2 : 0);
+    for (auto& ev : k) HS_HIP(ctx, hipEventCreate(&ev));
+    HS_HIP(ctx, hipEventRecord(begin, ctx->stream));
+    for (int i = 0; i < runs; ++i)
+        if ((rc = enqueue(ctx, -1, kernel_ms ? k[size_t(i) * 2] : nullptr, kernel_ms ? k[size_t(i) * 2 + 1] : nullptr)) != HS_OK) return rc;
+    HS_HIP(ctx, hipEventRecord(end, ctx->stream));
+    HS_HIP(ctx, hipEventSynchronize(end));
+    float ms = 0.0f;
+    HS_HIP(ctx, hipEventElapsedTime(&ms, begin, end));
+    if (total_ms) *total_ms = ms;
+    if (kernel_ms) {
+        float sum = 0.0f;
+        for (int i = 0; i < runs; ++i) {
+            float one = 0.0f;
+            HS_HIP(ctx, hipEventElapsedTime(&one, k[size_t(i) * 2], k[size_t(i) * 2 + 1]));
+            sum += one;
+        }
+        *kernel_ms = sum;
+    }
+    for (auto& ev : k) (void)hipEventDestroy(ev);
+    (void)hipEventDestroy(begin);
+    (void)hipEventDestroy(end);
+    return HS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// stream_tiles.h — device-private re-tiling of a CPSR image for the gfx950 SpMV kernel.
+//
+// The FPGA consumes each HBM channel as 8 lock-step lane streams whose row index is a running sum of
+// in-band markers (spmv/libfpga/spmv_cluster.h:34-107; fp variant spmv-fp/libfpga/spmv_cluster.h:39-129):
+// 128 sequential streams per (row partition, column partition), each padded to the longest lane of its
+// channel (sw/data_formatter.h:421-428, sw/benchmark.cpp:148-163).  That is far too few, too
+// sequential and too unbalanced for 256 CUs.  What DOES carry over is the architecture:
+//
+//   FPGA (16 clusters)                                       MI355X (256 workgroups)
+//   -------------------------------------------------------  -------------------------------------------
+//   a cluster's 8 PEs own a fixed set of rows; their sums    a workgroup owns a contiguous ROW BLOCK
+//   live in on-chip output banks (pe.h:121-135)              (<= 4096 rows); the sums live in its LDS
+//   the current column partition of x sits in 8 on-chip      the current x SUB-TILE (<= 16384 columns)
+//   vector banks, double-buffered (vecbuf_access_unit.h)     sits in LDS, double-buffered
+//   the matrix streams past, one packet per cycle            the block's non-zeros stream past as
+//   (spmv_cluster.h:73-98)                                   coalesced 8-byte elements
+//
+// So at hs_load_matrix time the CPSR image is decoded ONCE on the host and re-cut:
+//   * rows are split into row blocks of roughly equal non-zero count (never across a row partition);
+//   * the non-zeros of a block are grouped into UNITS, one per x sub-tile that the block touches
+//     (a sub-tile is a <= 16384-column slice of one column partition);
+//   * a unit's elements are dealt to the 12 consumer wavefronts of the workgroup in chunks of 64,
+//     each wavefront's chunks forming one contiguous stream through all units of the block.
+// Element = { u32 value word, u32 (local_row << 16 | local_col) } = 8 bytes: markers, lane padding and
+// partition headers are gone, so the bytes read per SpMV equal the reference's "8 bytes per
+// non-zero" throughput definition (sw/benchmark.cpp:312-314) plus < 2 % chunk padding.
+#ifndef HISPARSE_STREAM_TILES_H_
+#define HISPARSE_STREAM_TILES_H_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "hisparse/common.h"
+
+namespace hisparse {
+namespace dev {
+
+constexpr uint32_t kWaveLanes = 64;
+constexpr uint32_t kWavesPerWorkgroup = 16;                   // 1024 threads: one workgroup per CU
+constexpr uint32_t kConsumerWaves = 12;                       // stream elements, gather x, accumulate rows
+constexpr uint32_t kLoaderWaves = kWavesPerWorkgroup - kConsumerWaves;  // refill the idle x buffer
+constexpr uint32_t kSubTileCols = 16384;                      // 64 KiB of x per buffer, two buffers
+constexpr uint32_t kMaxBlockRows = 4096;                      // 32 KiB of 64-bit row accumulators
+constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
+constexpr uint32_t kMaxLdsBytes = 160 * 1024;
+
+// Mirrored in the kernel source (read through scalar loads).
+struct Block {
+    uint32_t row0;          // first row (absolute, padded numbering)
+    uint32_t nrows;         // <= kMaxBlockRows; local row nrows is the scratch slot padding elements hit
+    uint32_t row_part;      // row partition (hs_run_partition filter)
+    uint32_t unit_begin;    // units [unit_begin, unit_end) in ascending sub-tile order
+    uint32_t unit_end;
+    uint32_t reserved;
+    uint64_t wave_offset[kConsumerWaves];   // byte offset of each consumer wavefront's stream in the image
+};
+struct Unit {
+    uint32_t col0;          // first absolute column of the x sub-tile
+    uint32_t ncols;         // multiple of 8, <= kSubTileCols
+    uint32_t end_step[kConsumerWaves];      // per wavefront: its stream position (in steps) after this unit
+};
+static_assert(sizeof(Block) == 24 + 8 * kConsumerWaves, "Block layout is shared with the device code");
+static_assert(sizeof(Unit) == 8 + 4 * kConsumerWaves, "Unit layout is shared with the device code");
+
+struct StreamTiles {
+    std::vector<uint8_t> image;          // element streams, uploaded verbatim
+    std::vector<Block> blocks;
+    std::vector<Unit> units;
+    std::vector<uint32_t> wg_first;      // workgroup g owns block_order[wg_first[g] .. wg_first[g+1])
+    std::vector<uint32_t> block_order;
+    uint32_t num_workgroups = 0;
+    uint32_t max_block_rows = 0;
+    uint64_t nnz = 0;
+    uint64_t elements = 0;               // element slots including chunk padding
+};
+
+// Decode + validate + re-tile.  `max_workgroups` = workgroups the device keeps resident (one per CU).
+// Returns false and sets `error` when the buffers are not a valid CPSR image for the geometry.
+bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
+                        const Geometry& geom, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
+                        uint32_t num_col_partitions, uint32_t max_workgroups, StreamTiles& out, std::string& error);
+
+}  // namespace dev
+}  // namespace hisparse
+
+#endif  // HISPARSE_STREAM_TILES_H_

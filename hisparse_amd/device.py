@@ -1,0 +1,206 @@
+"""hisparse_amd.device — ctypes binding of libhisparse_hip.so (include/hisparse_hip.h).
+
+`SpmvEngine` is the Python face of the drop-in boundary: the object a reference driver would hold in
+place of its cl::Context / cl::Kernel / cl::Buffer set (sw/benchmark.cpp:63-71,228-298).  Every
+method is one C-ABI call; there is no Python or CPU compute path here — if the HIP library or a
+gfx950 device is missing, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import host
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhisparse_hip.so")
+_lib = None
+
+EXPORTS = [
+    "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
+    "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_device_vector", "hs_device_result",
+    "hs_bind_device_vector", "hs_bind_device_result", "hs_get_stats", "hs_time_runs", "hs_tiles_build", "hs_tiles_info",
+    "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
+]
+
+
+class DeviceError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"hisparse_hip error {code}: {message}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("nnz", C.c_uint64), ("cpsr_bytes", C.c_uint64), ("stream_bytes", C.c_uint64), ("stream_elements", C.c_uint64),
+                ("num_pieces", C.c_uint32), ("num_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("num_compute_units", C.c_uint32), ("load_seconds", C.c_double)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+PIECE_DTYPE = np.dtype([("col_tile", "<u4"), ("row_part", "<u4"), ("steps", "<u4"), ("reserved", "<u4"), ("offset", "<u8")])
+
+
+def lib():
+    """Load libhisparse_hip.so.  Loading needs the ROCm runtime library but no GPU."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise DeviceError(-3, f"{_LIB_PATH} is missing: run `make hip` (or __graft_entry__.build()); there is no fallback path")
+        l = C.CDLL(_LIB_PATH)
+        vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+        l.hs_strerror.restype = C.c_char_p
+        l.hs_strerror.argtypes = [C.c_int]
+        l.hs_last_error.restype = C.c_char_p
+        l.hs_last_error.argtypes = [vp]
+        l.hs_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, u32, u32]
+        l.hs_destroy.argtypes = [vp]
+        l.hs_load_matrix.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), u32, u32, u32, u32]
+        l.hs_load_vector.argtypes = [vp, vp, u32]
+        l.hs_run.argtypes = [vp]
+        l.hs_run_partition.argtypes = [vp, u32, u32]
+        l.hs_sync.argtypes = [vp]
+        l.hs_read_result.argtypes = [vp, vp, u32]
+        l.hs_set_stream.argtypes = [vp, vp]
+        l.hs_device_vector.argtypes = [vp, C.POINTER(vp)]
+        l.hs_device_result.argtypes = [vp, C.POINTER(vp)]
+        l.hs_bind_device_vector.argtypes = [vp, vp]
+        l.hs_bind_device_result.argtypes = [vp, vp]
+        l.hs_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.hs_tiles_build.argtypes = [C.POINTER(vp), C.POINTER(u64), C.c_int, u32, u32, u32, u32, u32, u32, u32, C.POINTER(vp)]
+        l.hs_tiles_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
+        l.hs_tiles_copy.argtypes = [vp, vp, vp, vp]
+        l.hs_tiles_free.argtypes = [vp]
+        l.hs_tiles_free.restype = None
+        l.hs_tiles_last_error.restype = C.c_char_p
+        _lib = l
+    return _lib
+
+
+def _channel_arrays(packets):
+    """(void*[16], uint64[16]) for a host.ChannelPackets or a list of 16 (n,16) uint32 arrays."""
+    ptrs = (C.c_void_p * 16)()
+    counts = (C.c_uint64 * 16)()
+    keep = []
+    for c in range(16):
+        if isinstance(packets, host.ChannelPackets):
+            addr, n = packets.channel_ptr(c)
+        else:
+            a = np.ascontiguousarray(packets[c], dtype=np.uint32)
+            keep.append(a)
+            addr, n = a.ctypes.data, a.shape[0]
+        ptrs[c] = addr
+        counts[c] = n
+    return ptrs, counts, keep
+
+
+class SpmvEngine:
+    def __init__(self, impl, device_id=0, ob_bank=0, vb_bank=0):
+        self._h = C.c_void_p()
+        self.impl = host.impl_id(impl)
+        rc = lib().hs_create(C.byref(self._h), device_id, self.impl, ob_bank, vb_bank)
+        if rc != 0:
+            raise DeviceError(rc, lib().hs_last_error(None).decode())
+        self.num_rows = self.num_cols = 0
+        self.row_parts = self.col_parts = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DeviceError(rc, lib().hs_last_error(self._h).decode() or lib().hs_strerror(rc).decode())
+
+    def close(self):
+        if self._h:
+            lib().hs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the boundary -------------------------------------------------------------------------
+    def load_matrix(self, packets, num_rows=None, num_cols=None, num_row_partitions=None, num_col_partitions=None):
+        """packets: host.ChannelPackets (dims taken from it) or 16 raw (n,16) uint32 arrays + explicit dims."""
+        if isinstance(packets, host.ChannelPackets):
+            num_rows, num_cols = packets.num_rows, packets.num_cols
+            num_row_partitions, num_col_partitions = packets.num_row_partitions, packets.num_col_partitions
+        ptrs, counts, keep = _channel_arrays(packets)
+        self._check(lib().hs_load_matrix(self._h, ptrs, counts, num_rows, num_cols, num_row_partitions, num_col_partitions))
+        del keep
+        self.num_rows, self.num_cols = num_rows, num_cols
+        self.row_parts, self.col_parts = num_row_partitions, num_col_partitions
+
+    def load_vector(self, x_words):
+        x_words = np.ascontiguousarray(x_words, dtype=np.uint32)
+        self._check(lib().hs_load_vector(self._h, x_words.ctypes.data, x_words.size))
+
+    def run(self):
+        self._check(lib().hs_run(self._h))
+
+    def run_partition(self, row_part_id, part_len):
+        self._check(lib().hs_run_partition(self._h, row_part_id, part_len))
+
+    def sync(self):
+        self._check(lib().hs_sync(self._h))
+
+    def read_result(self):
+        y = np.empty(self.num_rows, dtype=np.uint32)
+        self._check(lib().hs_read_result(self._h, y.ctypes.data, y.size))
+        return y
+
+    # ---- zero-copy hooks ----------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        self._check(lib().hs_set_stream(self._h, C.c_void_p(hip_stream or None)))
+
+    def device_vector(self):
+        p = C.c_void_p()
+        self._check(lib().hs_device_vector(self._h, C.byref(p)))
+        return p.value
+
+    def device_result(self):
+        p = C.c_void_p()
+        self._check(lib().hs_device_result(self._h, C.byref(p)))
+        return p.value
+
+    def bind_device_vector(self, ptr):
+        self._check(lib().hs_bind_device_vector(self._h, C.c_void_p(ptr or None)))
+
+    def bind_device_result(self, ptr):
+        self._check(lib().hs_bind_device_result(self._h, C.c_void_p(ptr or None)))
+
+    # ---- measurement ----------------------------------------------------------------------------
+    def stats(self):
+        s = Stats()
+        self._check(lib().hs_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def time_runs(self, warmup, runs, kernel=True):
+        """(total_ms for `runs` SpMVs, summed duration of the dominant kernel over those runs or None)."""
+        total, kern = C.c_float(), C.c_float()
+        self._check(lib().hs_time_runs(self._h, warmup, runs, C.byref(total), C.byref(kern) if kernel else None))
+        return total.value, (kern.value if kernel else None)
+
+
+def build_tiles(packets, impl, ob_bank, vb_bank, num_rows, num_cols, num_row_partitions, num_col_partitions, max_workgroups):
+    """What hs_load_matrix would upload (no GPU involved): dict(image, pieces, wg_first, row_stride, nnz, elements)."""
+    l = lib()
+    ptrs, counts, keep = _channel_arrays(packets)
+    h = C.c_void_p()
+    rc = l.hs_tiles_build(ptrs, counts, host.impl_id(impl), ob_bank, vb_bank, num_rows, num_cols, num_row_partitions,
+                          num_col_partitions, max_workgroups, C.byref(h))
+    del keep
+    if rc != 0:
+        raise DeviceError(rc, l.hs_tiles_last_error().decode())
+    try:
+        nbytes, npieces, nwg, stride, nnz, elems = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+        l.hs_tiles_info(h, C.byref(nbytes), C.byref(npieces), C.byref(nwg), C.byref(stride), C.byref(nnz), C.byref(elems))
+        image = np.zeros(max(nbytes.value, 1), dtype=np.uint8)
+        pieces = np.zeros(max(npieces.value, 1), dtype=PIECE_DTYPE)
+        wg_first = np.zeros(nwg.value + 1, dtype=np.uint32)
+        l.hs_tiles_copy(h, image.ctypes.data, pieces.ctypes.data, wg_first.ctypes.data)
+        return dict(image=image[:nbytes.value], pieces=pieces[:npieces.value], wg_first=wg_first, num_workgroups=nwg.value,
+                    row_stride=stride.value, nnz=nnz.value, elements=elems.value)
+    finally:
+        l.hs_tiles_free(h)

@@ -1,0 +1,137 @@
+/*
+ * hisparse_hip.h — the drop-in boundary: C-ABI of libhisparse_hip.so (MI355X / gfx950).
+ *
+ * This library takes the place of the FPGA launch path of the reference.  What a reference driver
+ * hands to OpenCL/XRT — 16 matrix channel buffers, the packed vector, the packed result and five
+ * scalars — is what these entry points take, byte for byte:
+ *
+ *   reference (sw/benchmark.cpp, sw/host.cpp, spmv_csim/csim.cpp)             this library
+ *   ------------------------------------------------------------------------  -----------------------
+ *   cl::Context / cl::Program(xclbin) / 5 x cl::Kernel / queue  (:372-404)    hs_create
+ *   16 x CL_BUFFER_RDONLY + enqueueMigrateMemObjects            (:231-252,266-269)  hs_load_matrix
+ *   vector_buf + migrate                                        (:255-260,270-272)  hs_load_vector
+ *   per row partition: setArg(row_part_id, part_len) x4, 5 x enqueueTask, finish() (:318-338)
+ *                                                                             hs_run_partition
+ *   the whole `for row_part_id` loop of one SpMV                (:318-339)    hs_run (one launch)
+ *   queue.finish()                                              (:337)        hs_sync
+ *   enqueueMigrateMemObjects(result, D2H)                       (sw/host.cpp:370)   hs_read_result
+ *   csim: top_wrapper(m0..m15, x, y, row_part_id, part_len, num_col_partitions,
+ *                     num_partitions, num_cols)                 (csim.cpp:22-46)    hs_run_partition
+ *   OCL_CHECK / CHECK_ERR -> print + exit(EXIT_FAILURE)         (xcl2.hpp:40-46, benchmark.cpp:56-61)
+ *                                                                             negative return codes
+ *
+ * Ownership: the caller owns every host pointer it passes; hs_load_* copy what they need before
+ * returning.  The library owns all device memory until hs_destroy.  At load time the library builds
+ * private device-side structures from the CPSR buffers (see DESIGN.md "stream tiles"); the inputs
+ * themselves are never modified.
+ *
+ * Threading: one context per GPU; calls on one context must not overlap.  hs_run* are asynchronous
+ * on the context's HIP stream; hs_sync / hs_read_result wait for them.
+ *
+ * There is NO CPU fallback: every entry point that needs the GPU fails with HS_ERR_NO_DEVICE or
+ * HS_ERR_HIP when none is usable.
+ */
+#ifndef HISPARSE_HIP_H_
+#define HISPARSE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HS_NUM_CHANNELS 16 /* NUM_HBM_CHANNELS, spmv/libfpga/common.h:173-176 */
+
+enum {
+    HS_OK = 0,
+    HS_ERR_BAD_ARG = -1,      /* null pointer, unknown impl, dimension not padded ... */
+    HS_ERR_NO_DEVICE = -2,    /* no usable gfx950 device */
+    HS_ERR_HIP = -3,          /* a HIP runtime call failed; see hs_last_error */
+    HS_ERR_BAD_MATRIX = -4,   /* channel buffers are not a valid CPSR image for the given geometry */
+    HS_ERR_NOT_LOADED = -5,   /* run before hs_load_matrix / hs_load_vector */
+    HS_ERR_UNSUPPORTED = -6,  /* e.g. vector bank too large for the 160 KiB LDS tile */
+    HS_ERR_NO_MEMORY = -7,
+};
+
+/* numeric mode == the reference's IMPL make variable (sw/Makefile:2-12) */
+enum { HS_IMPL_FIXED = 0, HS_IMPL_FLOAT_POB = 1, HS_IMPL_FLOAT_STALL = 2 };
+
+typedef struct hs_context hs_context;
+
+typedef struct {
+    uint64_t nnz;               /* true non-zeros found in the CPSR image */
+    uint64_t cpsr_bytes;        /* bytes of the 16 channel buffers as handed in */
+    uint64_t stream_bytes;      /* bytes of the device-private stream tiles the kernel reads per SpMV */
+    uint64_t stream_elements;   /* element slots in the stream tiles (non-zeros + row-sets + padding) */
+    uint32_t num_pieces;        /* (workgroup, column tile) work pieces */
+    uint32_t num_workgroups;    /* grid size of the SpMV kernel */
+    uint32_t lds_bytes;         /* dynamic LDS per workgroup (the x tile) */
+    uint32_t num_compute_units; /* of the device */
+    double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
+} hs_stats;
+
+const char* hs_strerror(int code);
+/* message of the last failure on this context (or of the last failed hs_create when ctx is NULL) */
+const char* hs_last_error(const hs_context* ctx);
+
+/* Open device `device_id` (HIP ordinal) for one numeric mode and one bank geometry.
+ * ob_bank / vb_bank are OB_BANK_SIZE / VB_BANK_SIZE in words (0 = the shipped bitstream's value:
+ * 8192 (1024 for float_pob) and 4096).  They must equal the values the matrix was formatted with —
+ * the `<v> <o>` arguments of sw/benchmark.cpp:364-365 times 1024. */
+int hs_create(hs_context** ctx, int device_id, int impl, uint32_t ob_bank, uint32_t vb_bank);
+int hs_destroy(hs_context* ctx);
+
+/* channel[c] points to n_packets[c] 64-byte packets {u32 idx[8]; u32 val[8];} laid out as in
+ * SURVEY.md Appendix A.2 (headers + interleaved payload).  num_rows / num_cols are the PADDED
+ * dimensions.  Replaces any previously loaded matrix. */
+int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], const uint64_t n_packets[HS_NUM_CHANNELS],
+                   uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions, uint32_t num_col_partitions);
+
+/* packed_x: num_cols value words (PACKED_VAL_T[num_cols/8]) in natural order. */
+int hs_load_vector(hs_context* ctx, const void* packed_x, uint32_t num_cols);
+
+/* One full SpMV (every row partition) in one launch sequence; asynchronous. */
+int hs_run(hs_context* ctx);
+/* One row partition, with the reference's scalar arguments; part_len = rows per cluster
+ * (checked against the geometry).  Rows of other partitions keep their previous contents. */
+int hs_run_partition(hs_context* ctx, uint32_t row_part_id, uint32_t part_len);
+int hs_sync(hs_context* ctx);
+/* Waits, then copies num_rows value words (PACKED_VAL_T[num_rows/8]) to the host. */
+int hs_read_result(hs_context* ctx, void* packed_y, uint32_t num_rows);
+
+/* ---- zero-copy hooks for callers that already live on the GPU (PyTorch tensors, RCCL) ---------- */
+/* Run on a caller-owned hipStream_t instead of the context's private stream (NULL restores it). */
+int hs_set_stream(hs_context* ctx, void* hip_stream);
+/* Device addresses of the library's packed x (num_cols words) and packed y (num_rows words). */
+int hs_device_vector(hs_context* ctx, void** x_dev);
+int hs_device_result(hs_context* ctx, void** y_dev);
+/* Make the kernels read x from / write y to caller-owned device memory (NULL restores the library's). */
+int hs_bind_device_vector(hs_context* ctx, const void* x_dev);
+int hs_bind_device_result(hs_context* ctx, void* y_dev);
+
+/* ---- measurement ------------------------------------------------------------------------------- */
+int hs_get_stats(const hs_context* ctx, hs_stats* stats);
+/* `runs` back-to-back hs_run calls after `warmup` untimed ones, bracketed by HIP events on the
+ * stream the kernels are launched on.  total_ms: wall time of the `runs` SpMVs (events around the
+ * whole loop).  kernel_ms: sum over the runs of the duration of the dominant kernel
+ * (spmv_stream_*) alone, from per-launch event pairs.  Either output may be NULL. */
+int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* kernel_ms);
+
+/* ---- introspection of the load-time re-tiling (host only, no GPU needed; used by the tests) -------- */
+typedef struct hs_tiles hs_tiles;
+/* Builds exactly what hs_load_matrix would upload for a device wanting `max_workgroups` workgroups. */
+int hs_tiles_build(const void* const channel[HS_NUM_CHANNELS], const uint64_t n_packets[HS_NUM_CHANNELS], int impl, uint32_t ob_bank,
+                   uint32_t vb_bank, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
+                   uint32_t num_col_partitions, uint32_t max_workgroups, hs_tiles** out);
+int hs_tiles_info(const hs_tiles* t, uint64_t* image_bytes, uint32_t* num_pieces, uint32_t* num_workgroups, uint32_t* row_stride,
+                  uint64_t* nnz, uint64_t* elements);
+/* image: image_bytes; pieces: num_pieces x {u32 col_tile, row_part, steps, reserved; u64 offset}; wg_first: num_workgroups + 1 */
+int hs_tiles_copy(const hs_tiles* t, void* image, void* pieces, uint32_t* wg_first);
+void hs_tiles_free(hs_tiles* t);
+const char* hs_tiles_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HISPARSE_HIP_H_ */
