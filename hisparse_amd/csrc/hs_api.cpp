@@ -2,9 +2,8 @@
 //
 // The reference reaches its device through OpenCL/XRT objects created in sw/benchmark.cpp:228-298 and
 // launches five kernels per row partition (:318-338).  Here one context owns one HIP device, one
-// stream and the device-resident data; hs_run launches the whole SpMV (all row partitions) as
-//   fixed:  spmv_stream_kernel<fixed> -> finalize_fixed_kernel
-//   float:  hipMemsetAsync(y)          -> spmv_stream_kernel<float>
+// stream and the device-resident data; hs_run launches the whole SpMV (all row partitions) as ONE
+// kernel, spmv_rowblock_kernel<fixed|float>, which writes the packed y directly.
 // There is no CPU fallback anywhere in this file: without a usable gfx950 device every call fails.
 #include "hisparse_hip.h"
 
@@ -21,7 +20,8 @@
 #include "stream_tiles.h"
 
 using hisparse::Geometry;
-using hisparse::dev::Piece;
+using hisparse::dev::Block;
+using hisparse::dev::Unit;
 
 struct hs_context {
     int device = -1;
@@ -35,15 +35,15 @@ struct hs_context {
     bool vector_loaded = false;
     uint32_t num_rows = 0, num_cols = 0, row_parts = 0, col_parts = 0;
     uint8_t* d_image = nullptr;
-    Piece* d_pieces = nullptr;
+    Block* d_blocks = nullptr;
+    Unit* d_units = nullptr;
     uint32_t* d_wg_first = nullptr;
+    uint32_t* d_block_order = nullptr;
     uint32_t num_workgroups = 0;
-    uint32_t row_stride = 0;
     uint32_t lds_bytes = 0;
 
     uint32_t* d_x = nullptr;       // library-owned packed x
     uint32_t* d_y = nullptr;       // library-owned packed y
-    uint64_t* d_accum = nullptr;   // fixed point: 64-bit row accumulators, zero between runs
     const uint32_t* x_bound = nullptr;
     uint32_t* y_bound = nullptr;
     uint32_t x_capacity = 0;
@@ -56,7 +56,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-constexpr uint32_t kAccumSlackRows = 2048;  // a run's counter may step one stride past the last row before it ends
+constexpr size_t kImageSlackBytes = 4096;  // tail prefetches of an empty wavefront stream stay inside the allocation
 
 int fail(hs_context* ctx, int code, const std::string& msg) {
     if (ctx) ctx->error = msg; else g_create_error = msg;
@@ -73,15 +73,17 @@ int hip_fail(hs_context* ctx, hipError_t e, const char* what) {
 
 void free_matrix(hs_context* c) {
     if (c->d_image) (void)hipFree(c->d_image);
-    if (c->d_pieces) (void)hipFree(c->d_pieces);
+    if (c->d_blocks) (void)hipFree(c->d_blocks);
+    if (c->d_units) (void)hipFree(c->d_units);
     if (c->d_wg_first) (void)hipFree(c->d_wg_first);
+    if (c->d_block_order) (void)hipFree(c->d_block_order);
     if (c->d_y) (void)hipFree(c->d_y);
-    if (c->d_accum) (void)hipFree(c->d_accum);
     c->d_image = nullptr;
-    c->d_pieces = nullptr;
+    c->d_blocks = nullptr;
+    c->d_units = nullptr;
     c->d_wg_first = nullptr;
+    c->d_block_order = nullptr;
     c->d_y = nullptr;
-    c->d_accum = nullptr;
     c->y_bound = nullptr;
     c->matrix_loaded = false;
 }
@@ -99,13 +101,12 @@ int check_ready(hs_context* ctx) {
 hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     hisparse::dev::SpmvLaunch a;
     a.image = c->d_image;
-    a.pieces = c->d_pieces;
+    a.blocks = c->d_blocks;
+    a.units = c->d_units;
     a.wg_first = c->d_wg_first;
+    a.block_order = c->d_block_order;
     a.x = x_source(c);
-    a.accum = c->impl == HS_IMPL_FIXED ? static_cast<void*>(c->d_accum) : static_cast<void*>(y_target(c));
-    a.num_cols = c->num_cols;
-    a.tile_cols = uint32_t(c->geom.logical_vb);
-    a.row_stride = c->row_stride;
+    a.y = y_target(c);
     a.row_part_filter = filter;
     a.num_workgroups = c->num_workgroups;
     a.lds_bytes = c->lds_bytes;
@@ -120,16 +121,11 @@ void partition_rows(const hs_context* c, uint32_t j, uint32_t& lo, uint32_t& hi)
     hi = uint32_t(b);
 }
 
-// Enqueue one SpMV (filter < 0) or one row partition; optional events bracket the dominant kernel.
+// Enqueue one SpMV (filter < 0) or one row partition; optional events bracket the kernel.
 int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1) {
-    uint32_t lo = 0, hi = c->num_rows;
-    if (filter >= 0) partition_rows(c, uint32_t(filter), lo, hi);
-    const bool is_float = c->impl != HS_IMPL_FIXED;
-    if (is_float) HS_HIP(c, hipMemsetAsync(y_target(c) + lo, 0, size_t(hi - lo) * 4, c->stream));
     if (k0) HS_HIP(c, hipEventRecord(k0, c->stream));
-    HS_HIP(c, hisparse::dev::launch_spmv_stream(is_float, launch_args(c, filter), c->stream));
+    HS_HIP(c, hisparse::dev::launch_spmv(c->impl != HS_IMPL_FIXED, launch_args(c, filter), c->stream));
     if (k1) HS_HIP(c, hipEventRecord(k1, c->stream));
-    if (!is_float) HS_HIP(c, hisparse::dev::launch_finalize_fixed(c->d_accum, y_target(c), lo, hi, c->stream));
     return HS_OK;
 }
 
@@ -206,48 +202,42 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
                                              " and columns by 8 (util_round_csr_matrix_dim)");
     if (num_row_partitions != (num_rows + g.logical_ob - 1) / g.logical_ob || num_col_partitions != (num_cols + g.logical_vb - 1) / g.logical_vb)
         return fail(ctx, HS_ERR_BAD_ARG, "partition counts do not match the dimensions and the bank sizes of this context");
-    const uint64_t tile_cols = std::min<uint64_t>(g.logical_vb, num_cols);
-    if (tile_cols > hisparse::dev::kMaxTileCols)
-        return fail(ctx, HS_ERR_UNSUPPORTED, "vector bank of " + std::to_string(g.vb_bank) + " words needs an x tile of " +
-                                                 std::to_string(tile_cols * 4) + " bytes; the LDS holds 163840");
     HS_HIP(ctx, hipSetDevice(ctx->device));
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_matrix(ctx);
     const auto t0 = std::chrono::steady_clock::now();
 
-    const uint32_t lds_bytes = uint32_t((tile_cols * 4 + 15) / 16 * 16);
-    const uint32_t wg_per_cu = lds_bytes <= 80 * 1024 ? 2u : 1u;  // 1024-thread workgroups: at most 2 per CU
     hisparse::dev::StreamTiles tiles;
     std::string why;
     try {
+        // one 1024-thread workgroup per CU: the two x buffers alone take 128 KiB of the 160 KiB LDS
         if (!hisparse::dev::build_stream_tiles(channel, n_packets, g, num_rows, num_cols, num_row_partitions, num_col_partitions,
-                                               uint32_t(ctx->compute_units) * wg_per_cu, tiles, why))
+                                               uint32_t(ctx->compute_units), tiles, why))
             return fail(ctx, HS_ERR_BAD_MATRIX, why);
     } catch (const std::bad_alloc&) {
         return fail(ctx, HS_ERR_NO_MEMORY, "out of host memory while re-tiling the matrix");
     }
+    const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows);
+    if (lds_bytes > hisparse::dev::kMaxLdsBytes) return fail(ctx, HS_ERR_UNSUPPORTED, "row block does not fit the LDS");
 
     HS_HIP(ctx, hisparse::dev::configure_spmv_kernels(lds_bytes));
-    const size_t image_bytes = std::max<size_t>(tiles.image.size(), 256);
-    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_image), image_bytes));
-    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_pieces), std::max<size_t>(tiles.pieces.size(), 1) * sizeof(Piece)));
-    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_wg_first), tiles.wg_first.size() * sizeof(uint32_t)));
+    auto upload = [&](void** dst, const void* src, size_t bytes, size_t slack) -> hipError_t {
+        hipError_t e = hipMalloc(dst, std::max<size_t>(bytes + slack, 256));
+        if (e != hipSuccess || bytes == 0) return e;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_image), tiles.image.data(), tiles.image.size(), kImageSlackBytes));
+    HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_blocks), tiles.blocks.data(), tiles.blocks.size() * sizeof(Block), 0));
+    HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_units), tiles.units.data(), tiles.units.size() * sizeof(Unit), 0));
+    HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_wg_first), tiles.wg_first.data(), tiles.wg_first.size() * sizeof(uint32_t), 0));
+    HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_block_order), tiles.block_order.data(), tiles.block_order.size() * sizeof(uint32_t), 0));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
-    if (!tiles.image.empty()) HS_HIP(ctx, hipMemcpy(ctx->d_image, tiles.image.data(), tiles.image.size(), hipMemcpyHostToDevice));
-    if (!tiles.pieces.empty()) HS_HIP(ctx, hipMemcpy(ctx->d_pieces, tiles.pieces.data(), tiles.pieces.size() * sizeof(Piece), hipMemcpyHostToDevice));
-    HS_HIP(ctx, hipMemcpy(ctx->d_wg_first, tiles.wg_first.data(), tiles.wg_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
-    if (ctx->impl == HS_IMPL_FIXED) {
-        const size_t n = size_t(num_rows) + kAccumSlackRows;
-        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_accum), n * 8));
-        HS_HIP(ctx, hipMemset(ctx->d_accum, 0, n * 8));
-    }
     ctx->num_rows = num_rows;
     ctx->num_cols = num_cols;
     ctx->row_parts = num_row_partitions;
     ctx->col_parts = num_col_partitions;
     ctx->num_workgroups = tiles.num_workgroups;
-    ctx->row_stride = tiles.row_stride;
     ctx->lds_bytes = lds_bytes;
     ctx->matrix_loaded = true;
 
@@ -257,7 +247,8 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     for (int c = 0; c < HS_NUM_CHANNELS; ++c) s.cpsr_bytes += n_packets[c] * sizeof(hisparse::MatPkt);
     s.stream_bytes = tiles.image.size();
     s.stream_elements = tiles.elements;
-    s.num_pieces = uint32_t(tiles.pieces.size());
+    s.num_blocks = uint32_t(tiles.blocks.size());
+    s.num_units = uint32_t(tiles.units.size());
     s.num_workgroups = tiles.num_workgroups;
     s.lds_bytes = lds_bytes;
     s.num_compute_units = uint32_t(ctx->compute_units);

@@ -1,24 +1,29 @@
-// spmv_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the SpMV hot path.
+// spmv_kernels.hip — the gfx950 (MI355X, CDNA4) kernel of the SpMV hot path.
 //
 // Replaces the FPGA dataflow  spmv_vector_loader -> spmv_sk0/1/2 -> spmv_result_drain
 // (spmv/spmv_vector_loader.cpp:95-121, spmv/spmv_sk0.cpp:12-121, spmv/spmv_result_drain.cpp:10-126):
 //
-//   FPGA unit (reference)                                    here
-//   -------------------------------------------------------  ----------------------------------------------
-//   vector loader + 8 vector banks per cluster               one x tile (<= 160 KiB) per workgroup in LDS,
-//     (vecbuf_access_unit.h:66-72,126-128)                     loaded once per column partition
-//   CPSR_matrix_loader, 1 packet/cycle/channel               64-lane wavefronts, 16 B + 8 B coalesced loads
-//     (spmv_cluster.h:34-107)                                  from re-tiled streams (stream_tiles.h)
-//   shuffle 1 by col%8 + bank read (shuffle.h:380-468)       ds_read_b32 gather from the LDS tile
-//   shuffle 2 by row%8 + PE accumulate (pe.h:62-81)          per-lane running sum, flushed at end-of-row
-//   PE output banks, zeroed per row partition (pe.h:131-135) global accumulator, integer / fp32 atomics
-//   result packer + drain (spmv_result_drain.cpp:104-113)    natural-order y written by the finalize pass
+//   FPGA unit (reference)                                     here, per 1024-thread workgroup
+//   --------------------------------------------------------  --------------------------------------------------
+//   spmv_cluster: owns rows, PE output banks zeroed per        owns a row block; 64-bit (fixed) / fp32 (float) row
+//     launch, dumped at the end (pe.h:121-178)                   accumulators in LDS, zeroed per block, written once
+//   vector loader + vecbuf_access_unit: x partition in 8       4 LOADER wavefronts copy the next x sub-tile (64 KiB)
+//     banks, writer/reader alternate per partition               into the idle one of two LDS buffers while ...
+//     (vecbuf_access_unit.h:146-163)
+//   CPSR_matrix_loader: one 64-byte packet per cycle           ... 12 CONSUMER wavefronts stream coalesced 8-byte
+//     (spmv_cluster.h:73-98)                                      elements, 8 loads in flight per lane
+//   shuffle 1 by col%8 + bank read (shuffle.h, vecbuf :126)    ds_read_b32 gather from the LDS sub-tile
+//   shuffle 2 by row%8 + PE accumulate (pe.h:62-81)            ds_add_u64 / ds_add_f32 into the row accumulators
+//   result packer + drain, natural row order                   coalesced y store, AP_SAT clamp applied once
+//     (spmv_result_drain.cpp:104-113)
 //
-// Bandwidth-bound integer/fp32 gather work: no MFMA anywhere.
-// Numerics: fixed point = ap_ufixed<32,8,AP_RND,AP_SAT> products summed in u64 and clamped once
-// (bit-exact with the saturating PE because all terms are non-negative);
-// float = separate fp32 multiply and add (no FMA contraction: -ffp-contract=off), association differs
-// from the FPGA's arrival order, hence tolerance parity.
+// One barrier per (row block, x sub-tile) hands the freshly filled buffer to the consumers.
+// No global atomics, no second pass: y is complete when the kernel ends.  Bandwidth-bound
+// integer / fp32 gather work — no MFMA anywhere.
+// Numerics: fixed point = ap_ufixed<32,8,AP_RND,AP_SAT> products summed exactly in 64 bits and clamped
+// once (bit-exact with the saturating PE because every term is non-negative);
+// float = separate fp32 multiply and add (no FMA contraction: -ffp-contract=off); the order of the
+// adds differs from the FPGA's arrival order, hence tolerance parity.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -30,8 +35,10 @@ namespace dev {
 
 namespace {
 
-constexpr int kThreads = kRunsPerWorkgroup;   // 1024 = 16 wavefronts: one workgroup fills a CU's LDS with the x tile
-constexpr int kBatchGroups = kStepQuantum / kStepsPerGroup;  // groups (of 4 steps) loaded per prefetch batch
+constexpr int kThreads = kWaveLanes * kWavesPerWorkgroup;       // 1024
+constexpr int kConsumerThreads = kWaveLanes * kConsumerWaves;   // 768
+constexpr int kLoaderThreads = kThreads - kConsumerThreads;     // 256
+constexpr uint32_t kXBytes = kXBuffers * kSubTileCols * 4u;     // the ring of x buffers (128 KiB)
 
 // mat_val * vec_val narrowed to Q8.24: exact 64-bit product, + half LSB, >> 24, saturate (pe.h:64).
 __device__ __forceinline__ uint32_t q8_24_mul(uint32_t a, uint32_t b) {
@@ -41,177 +48,212 @@ __device__ __forceinline__ uint32_t q8_24_mul(uint32_t a, uint32_t b) {
 }
 
 template <bool kFloat>
-struct RowSum;
+struct Rows;
 template <>
-struct RowSum<false> {  // fixed point: exact integer sum of saturated products
-    using accum_t = unsigned long long;
-    uint64_t v = 0;
-    __device__ __forceinline__ void add(uint32_t mat, uint32_t vec, bool special) { v += q8_24_mul(special ? 0u : mat, vec); }
-    __device__ __forceinline__ bool nonzero() const { return v != 0; }
-    __device__ __forceinline__ void flush(accum_t* acc, uint32_t row) { atomicAdd(acc + row, static_cast<unsigned long long>(v)); }
-    __device__ __forceinline__ void clear() { v = 0; }
+struct Rows<false> {
+    using acc_t = unsigned long long;
+    static __device__ __forceinline__ void add(acc_t* ys, uint32_t row, uint32_t mat, uint32_t vec) {
+        atomicAdd(ys + row, static_cast<unsigned long long>(q8_24_mul(mat, vec)));   // ds_add_u64
+    }
+    static __device__ __forceinline__ uint32_t finish(acc_t s) { return s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s); }  // AP_SAT (pe.h:72)
 };
 template <>
-struct RowSum<true> {  // float: multiply then add, as the float PEs do (pe-pob.h:63-65, pe-stall.h:52,138)
-    using accum_t = float;
-    float v = 0.0f;
-    __device__ __forceinline__ void add(uint32_t mat, uint32_t vec, bool special) {
-        const float prod = __uint_as_float(mat) * __uint_as_float(vec);
-        v += special ? 0.0f : prod;
+struct Rows<true> {
+    using acc_t = float;
+    static __device__ __forceinline__ void add(acc_t* ys, uint32_t row, uint32_t mat, uint32_t vec) {
+        atomicAdd(ys + row, __uint_as_float(mat) * __uint_as_float(vec));           // ds_add_f32; multiply, then add (pe-pob.h:63-65)
     }
-    __device__ __forceinline__ bool nonzero() const { return v != 0.0f; }
-    __device__ __forceinline__ void flush(accum_t* acc, uint32_t row) { atomicAdd(acc + row, v); }
-    __device__ __forceinline__ void clear() { v = 0.0f; }
+    static __device__ __forceinline__ uint32_t finish(acc_t s) { return __float_as_uint(s); }
 };
 
-// One element: gather x from the LDS tile, accumulate, and on an end-of-row flag flush the row sum
-// and step the row counter (flagged non-zero: +stride; flagged special element = ROWSET: absolute row).
-// kAblate (profiling builds only, HISPARSE_ABLATE): bit 0 = no atomics, bit 1 = no LDS gather, bit 2 = no arithmetic.
-template <bool kFloat, int kAblate>
-__device__ __forceinline__ void consume(uint32_t col, uint32_t val, bool flagged, const uint32_t* xs, uint32_t col_clamp,
-                                        uint32_t stride, RowSum<kFloat>& sum, uint32_t& row,
-                                        typename RowSum<kFloat>::accum_t* accum) {
-    const bool special = col == kSpecialCol;
-    const uint32_t xv = (kAblate & 2) ? col : xs[min(col, col_clamp)];
-    if (kAblate & 4) { asm volatile("" ::"v"(xv), "v"(val)); } else { sum.add(val, xv, special); }
-    if (flagged) {
-        if (kAblate & 1) { asm volatile("" ::"v"(row)); } else if (sum.nonzero()) sum.flush(accum, row);
-        sum.clear();
-        row = special ? val : row + stride;
-    }
+// Copy one x sub-tile into an LDS buffer with kStride cooperating threads (t = 0 .. kStride-1).
+// Completely branch-free: out-of-range threads re-copy the last 16 bytes (same data to the same place), so all
+// kIters loads are in flight before the first LDS write and the L2 latency is paid once per sub-tile.
+template <int kIters, int kStride>
+__device__ __forceinline__ void fill_x(uint32_t* dst, const uint32_t* __restrict__ x, uint32_t col0, uint32_t ncols, uint32_t t) {
+    const uint4* src = reinterpret_cast<const uint4*>(x + col0);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    const uint32_t n4 = ncols / 4;   // >= 2: ncols is a positive multiple of 8
+    uint4 r[kIters];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) r[j] = src[min(t + j * kStride, n4 - 1)];
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) d[min(t + j * kStride, n4 - 1)] = r[j];
 }
 
-template <bool kFloat, int kAblate>
-__global__ __launch_bounds__(kThreads) void spmv_stream_kernel(const uint8_t* __restrict__ image, const Piece* __restrict__ pieces,
-                                                                const uint32_t* __restrict__ wg_first,
-                                                                const uint32_t* __restrict__ x,
-                                                                typename RowSum<kFloat>::accum_t* __restrict__ accum,
-                                                                uint32_t num_cols, uint32_t tile_cols, uint32_t stride,
-                                                                int32_t row_part_filter) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t xs[];
-    const uint32_t lane = threadIdx.x & (kWaveLanes - 1);
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWaveLanes);
-    // Workgroup b runs on XCD b % 8 (observed dispatch order); give each XCD a contiguous range of
-    // logical workgroups so the workgroups that share an x tile share an L2.  Speed only.
+// The loader wavefronts' refill: LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip).
+// The LDS destination of one instruction is wave-uniform base + lane * 16, which is exactly the linear sub-tile.
+// Always kDmaPerFill instructions per wavefront (columns past `ncols` re-read the sub-tile's last 16 bytes into LDS
+// words nobody reads), so the landing of a given refill can be awaited with a counted s_waitcnt.
+constexpr uint32_t kDmaCols = kWaveLanes * 4;                                  // 256 columns = 1 KiB per instruction
+constexpr uint32_t kDmaPerFill = kSubTileCols / kDmaCols / kLoaderWaves;       // 8 instructions per wavefront per refill
+__device__ __forceinline__ void dma_fill_x(uint32_t* dst, const uint32_t* __restrict__ x, uint32_t col0, uint32_t ncols, uint32_t w,
+                                           uint32_t lane) {
+#pragma unroll
+    for (uint32_t j = 0; j < kDmaPerFill; ++j) {
+        const uint32_t c = (w * kDmaPerFill + j) * kDmaCols;                   // wave-uniform first column of this instruction
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t*)(x + col0 + min(c + lane * 4, ncols - 4)),
+                                         (__attribute__((address_space(3))) uint32_t*)(dst + c), 16, 0, 0);
+    }
+}
+// "at most kFills refills are still in flight" (vmcnt retires in order; the loader wavefronts issue nothing else)
+template <int kFills>
+__device__ __forceinline__ void dma_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFills * kDmaPerFill) : "memory");
+}
+
+// The element stream is loaded with hand-placed instructions: hipcc's s_waitcnt placement degrades to vmcnt(0)
+// (a full drain per element) in the unit/barrier control flow below, which would serialise the HBM stream.
+// Rules kept here: exactly ONE stream_load per step and no other vector-memory instruction inside the consumer
+// loop, so "the load issued kDepth steps ago has landed" is exactly vmcnt(kDepth - 1) (vmcnt retires in order).
+// `nt`: every element is read exactly once per SpMV, so it should not displace x in the L2 (measured: -8 % kernel time).
+__device__ __forceinline__ void stream_load(uint64_t& dst, const void* addr) {
+    asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(dst) : "v"(addr) : "memory");
+}
+template <int kOutstanding>
+__device__ __forceinline__ void stream_wait(uint64_t& v) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(kOutstanding) : "memory");
+}
+
+// Workgroup barrier that orders LDS traffic only: the consumers' prefetched global loads stay in flight
+// across it (a plain __syncthreads() carries a generic release fence and would drain them).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// kDepth: element loads in flight per lane (kDepth x 512 B per wavefront).
+// kAblate (profiling builds only, HISPARSE_ABLATE): bit 0 = no LDS accumulate, bit 1 = no LDS gather,
+// bit 2 = no x sub-tile refill, bit 3 = no per-sub-tile barrier.  Any non-zero value gives wrong results.
+template <bool kFloat, int kAblate, int kDepth>
+__global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
+                                                                  const Unit* __restrict__ units, const uint32_t* __restrict__ wg_first,
+                                                                  const uint32_t* __restrict__ block_order, const uint32_t* __restrict__ x,
+                                                                  uint32_t* __restrict__ y, int32_t row_part_filter) {
+    using acc_t = typename Rows<kFloat>::acc_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint32_t* xs = reinterpret_cast<uint32_t*>(lds);             // [2][kSubTileCols]
+    acc_t* ys = reinterpret_cast<acc_t*>(lds + kXBytes);         // [nrows + 1]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWaveLanes - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWaveLanes);
+    const bool loader = wave >= kConsumerWaves;
+    // Workgroup b runs on XCD b % 8 (observed dispatch order): neighbouring logical workgroups (neighbouring row
+    // blocks, same x sub-tiles at about the same time) then share an L2.  Speed only, never correctness.
     uint32_t wg = blockIdx.x;
     if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 
-    uint32_t resident_tile = 0xffffffffu;
-    const uint32_t p_end = wg_first[wg + 1];
-    for (uint32_t p = wg_first[wg]; p < p_end; ++p) {
-        const Piece piece = pieces[p];
-        if (row_part_filter >= 0 && piece.row_part != static_cast<uint32_t>(row_part_filter)) continue;
-        const uint32_t cols_here = min(tile_cols, num_cols - piece.col_tile * tile_cols);
-        if (piece.col_tile != resident_tile) {
-            __syncthreads();  // everyone is done with the previous tile
-            const uint4* src = reinterpret_cast<const uint4*>(x + static_cast<size_t>(piece.col_tile) * tile_cols);
-            for (uint32_t i = threadIdx.x; i < cols_here / 4; i += kThreads) reinterpret_cast<uint4*>(xs)[i] = src[i];
-            __syncthreads();
-            resident_tile = piece.col_tile;
-        }
-        const uint32_t steps = piece.steps;
-        const uint8_t* chunk = image + piece.offset + static_cast<uint64_t>(wave) * (kChunkHeaderBytes + static_cast<uint64_t>(steps) * 8 +
-                                                                                    static_cast<uint64_t>(steps / kStepsPerGroup) * kGroupBytes);
-        uint32_t row = reinterpret_cast<const uint32_t*>(chunk)[lane];
-        const uint64_t* flags = reinterpret_cast<const uint64_t*>(chunk + kChunkHeaderBytes);
-        const uint8_t* groups = chunk + kChunkHeaderBytes + static_cast<uint64_t>(steps) * 8;
-        const uint32_t col_clamp = cols_here - 1;
-        const uint32_t batches = steps / (kStepsPerGroup * kBatchGroups);
+    const uint32_t q_end = wg_first[wg + 1];
+    for (uint32_t q = wg_first[wg]; q < q_end; ++q) {
+        const Block* blk = blocks + block_order[q];
+        if (row_part_filter >= 0 && blk->row_part != static_cast<uint32_t>(row_part_filter)) continue;
+        const uint32_t nrows = blk->nrows, row0 = blk->row0;
+        const Unit* unit = units + blk->unit_begin;
+        const uint32_t U = blk->unit_end - blk->unit_begin;
 
-        uint2 cnext[kBatchGroups];
-        uint4 vnext[kBatchGroups];
-#pragma unroll
-        for (int j = 0; j < kBatchGroups; ++j) {
-            cnext[j] = reinterpret_cast<const uint2*>(groups + j * kGroupBytes)[lane];
-            vnext[j] = reinterpret_cast<const uint4*>(groups + j * kGroupBytes + kGroupColsBytes)[lane];
-        }
-        RowSum<kFloat> sum;
-        for (uint32_t b = 0; b < batches; ++b) {
-            uint2 c[kBatchGroups];
-            uint4 v[kBatchGroups];
-#pragma unroll
-            for (int j = 0; j < kBatchGroups; ++j) { c[j] = cnext[j]; v[j] = vnext[j]; }
-            if (b + 1 < batches) {
-                const uint8_t* nxt = groups + static_cast<uint64_t>(b + 1) * kBatchGroups * kGroupBytes;
-#pragma unroll
-                for (int j = 0; j < kBatchGroups; ++j) {
-                    cnext[j] = reinterpret_cast<const uint2*>(nxt + j * kGroupBytes)[lane];
-                    vnext[j] = reinterpret_cast<const uint4*>(nxt + j * kGroupBytes + kGroupColsBytes)[lane];
+        for (uint32_t i = tid; i <= nrows; i += kThreads) ys[i] = 0;           // PE banks start at zero (pe.h:131-135)
+        if (U > 0) fill_x<kSubTileCols / 4 / kThreads, kThreads>(xs, x, unit[0].col0, unit[0].ncols, tid);
+        __syncthreads();
+
+        if (U > 0) {
+            if (loader) {
+                // ---- loader wavefronts: keep the ring of x buffers up to three sub-tiles ahead of the consumers ----
+                const uint32_t lw = wave - kConsumerWaves;
+                auto refill = [&](uint32_t v) {
+                    if (!(kAblate & 4)) dma_fill_x(xs + (v % kXBuffers) * kSubTileCols, x, unit[v].col0, unit[v].ncols, lw, lane);
+                };
+                uint32_t issued = 1;                                   // sub-tile 0 was copied synchronously above
+                while (issued < U && issued < kXBuffers - 1) refill(issued++);
+                for (uint32_t u = 0; u < U; ++u) {
+                    // buffer (u+3) % 4 last held sub-tile u-1, which every consumer left at the previous barrier
+                    if (issued < U) refill(issued++);
+                    // sub-tile u+1 must be resident before the consumers enter it (they do so after this barrier)
+                    const uint32_t younger = issued - min(issued, u + 2);   // refills issued after the one for u+1: 0..2
+                    if (younger >= 2) dma_wait<2>(); else if (younger == 1) dma_wait<1>(); else dma_wait<0>();
+                    if (!(kAblate & 8)) __builtin_amdgcn_s_barrier();
                 }
-            }
-            const uint64_t* f = flags + static_cast<uint64_t>(b) * kBatchGroups * kStepsPerGroup;
+            } else {
+                // ---- consumer wavefronts: stream elements, gather x, accumulate rows -----------------------------
+                const uint8_t* stream = image + blk->wave_offset[wave] + lane * 8u;
+                const uint32_t total = unit[U - 1].end_step[wave];
+                const uint32_t last = total ? total - 1 : 0;   // prefetches past the end re-read the last chunk (no branch)
+                uint64_t buf[kDepth];
 #pragma unroll
-            for (int j = 0; j < kBatchGroups; ++j) {
-                const uint64_t f0 = f[j * 4 + 0], f1 = f[j * 4 + 1], f2 = f[j * 4 + 2], f3 = f[j * 4 + 3];
-                consume<kFloat, kAblate>(c[j].x & 0xffffu, v[j].x, (f0 >> lane) & 1u, xs, col_clamp, stride, sum, row, accum);
-                consume<kFloat, kAblate>(c[j].x >> 16, v[j].y, (f1 >> lane) & 1u, xs, col_clamp, stride, sum, row, accum);
-                consume<kFloat, kAblate>(c[j].y & 0xffffu, v[j].z, (f2 >> lane) & 1u, xs, col_clamp, stride, sum, row, accum);
-                consume<kFloat, kAblate>(c[j].y >> 16, v[j].w, (f3 >> lane) & 1u, xs, col_clamp, stride, sum, row, accum);
+                for (int k = 0; k < kDepth; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kChunkBytes);
+                uint32_t u = 0, end = unit[0].end_step[wave];
+                const uint32_t* xb = xs;
+                for (uint32_t base = 0;; base += kDepth) {
+#pragma unroll
+                    for (int k = 0; k < kDepth; ++k) {
+                        const uint32_t s = base + k;
+                        while (s == end) {                 // this wavefront finished sub-tile u (possibly with no work in it)
+                            if (!(kAblate & 8)) lds_barrier();
+                            if (++u == U) goto block_done;
+                            end = unit[u].end_step[wave];
+                            xb = xs + (u % kXBuffers) * kSubTileCols;
+                        }
+                        stream_wait<kDepth - 1>(buf[k]);
+                        const uint32_t mat = static_cast<uint32_t>(buf[k]), cr = static_cast<uint32_t>(buf[k] >> 32);
+                        const uint32_t xv = (kAblate & 2) ? cr : xb[cr & 0xffffu];
+                        if (kAblate & 1) asm volatile("" ::"v"(xv), "v"(mat));
+                        else Rows<kFloat>::add(ys, cr >> 16, mat, xv);
+                        stream_load(buf[k], stream + static_cast<size_t>(min(s + kDepth, last)) * kChunkBytes);
+                    }
+                }
+            block_done:
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail prefetches must land before their registers are reused
             }
         }
-        if (!(kAblate & 1) && sum.nonzero()) sum.flush(accum, row);  // the run ended inside a row: hand the partial sum over
+        // every sub-tile barrier has passed: the accumulators are final
+        for (uint32_t i = tid; i < nrows; i += kThreads) y[row0 + i] = Rows<kFloat>::finish(ys[i]);
+        __syncthreads();   // before the next block re-zeroes the accumulators
     }
 }
 
-__global__ __launch_bounds__(256) void finalize_fixed_kernel(uint64_t* __restrict__ accum, uint32_t* __restrict__ y, uint32_t row_lo,
-                                                             uint32_t row_hi) {
-    const uint32_t r = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= row_hi) return;
-    const uint64_t s = accum[r];
-    accum[r] = 0;  // ready for the next SpMV (the PEs zero their banks at the start of every launch, pe.h:131-135)
-    y[r] = s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s);  // AP_SAT of the running sum (pe.h:72)
+template <bool kFloat, int kAblate, int kDepth>
+hipError_t configure_one(uint32_t lds_bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_rowblock_kernel<kFloat, kAblate, kDepth>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+}
+
+int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
 }
 
 }  // namespace
 
-template <bool kFloat, int kAblate>
-hipError_t configure_one(uint32_t lds_bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_stream_kernel<kFloat, kAblate>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+uint32_t spmv_lds_bytes(uint32_t max_block_rows) {
+    return kXBytes + (max_block_rows + 1) * 8u;
 }
 
-// Profiling aid: HISPARSE_ABLATE=<bits> launches a variant with parts of the work removed (results are wrong).
-int ablation() {
-    static const int v = [] { const char* e = std::getenv("HISPARSE_ABLATE"); return e ? std::atoi(e) : 0; }();
-    return v;
-}
+#define HS_FOR_EACH_VARIANT(X) \
+    X(true, 0, 8) X(false, 0, 8) X(false, 0, 16) X(false, 0, 4) X(false, 1, 8) X(false, 2, 8) X(false, 3, 8) X(false, 4, 8) X(false, 8, 8) X(false, 12, 8) X(false, 15, 8) X(false, 32, 8) X(false, 64, 8) X(false, 96, 8) X(false, 36, 8) X(false, 160, 8) X(false, 288, 8)
 
 hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
     hipError_t e;
-    if ((e = configure_one<false, 0>(lds_bytes)) != hipSuccess) return e;
-    if ((e = configure_one<true, 0>(lds_bytes)) != hipSuccess) return e;
-    if ((e = configure_one<false, 1>(lds_bytes)) != hipSuccess) return e;
-    if ((e = configure_one<false, 2>(lds_bytes)) != hipSuccess) return e;
-    if ((e = configure_one<false, 3>(lds_bytes)) != hipSuccess) return e;
-    if ((e = configure_one<false, 7>(lds_bytes)) != hipSuccess) return e;
+#define X(F, A, D) if ((e = configure_one<F, A, D>(lds_bytes)) != hipSuccess) return e;
+    HS_FOR_EACH_VARIANT(X)
+#undef X
     return hipSuccess;
 }
 
-hipError_t launch_spmv_stream(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
+hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.num_workgroups == 0) return hipSuccess;
     const dim3 grid(a.num_workgroups), block(kThreads);
-#define HS_LAUNCH(FLOAT, ABL, T)                                                                                          \
-    hipLaunchKernelGGL((spmv_stream_kernel<FLOAT, ABL>), grid, block, a.lds_bytes, stream, a.image, a.pieces, a.wg_first, a.x, \
-                       static_cast<T*>(a.accum), a.num_cols, a.tile_cols, a.row_stride, a.row_part_filter)
-    if (is_float) {
-        HS_LAUNCH(true, 0, float);
-    } else {
-        switch (ablation()) {
-            case 1: HS_LAUNCH(false, 1, unsigned long long); break;
-            case 2: HS_LAUNCH(false, 2, unsigned long long); break;
-            case 3: HS_LAUNCH(false, 3, unsigned long long); break;
-            case 7: HS_LAUNCH(false, 7, unsigned long long); break;
-            default: HS_LAUNCH(false, 0, unsigned long long); break;
-        }
+    // profiling aids: HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the prefetch depth
+    static const int ablate = env_int("HISPARSE_ABLATE", 0), depth = env_int("HISPARSE_DEPTH", 8);
+    bool launched = false;
+#define X(F, A, D)                                                                                                           \
+    if (!launched && is_float == F && (F || (ablate == A && depth == D))) {                                                  \
+        hipLaunchKernelGGL((spmv_rowblock_kernel<F, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \
+                           a.wg_first, a.block_order, a.x, a.y, a.row_part_filter);                                          \
+        launched = true;                                                                                                     \
     }
-#undef HS_LAUNCH
-    return hipGetLastError();
-}
-
-hipError_t launch_finalize_fixed(uint64_t* accum, uint32_t* y, uint32_t row_lo, uint32_t row_hi, hipStream_t stream) {
-    if (row_hi <= row_lo) return hipSuccess;
-    const uint32_t n = row_hi - row_lo;
-    hipLaunchKernelGGL(finalize_fixed_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, accum, y, row_lo, row_hi);
+    HS_FOR_EACH_VARIANT(X)
+#undef X
+    if (!launched) return hipErrorInvalidValue;   // unknown HISPARSE_ABLATE / HISPARSE_DEPTH combination
     return hipGetLastError();
 }
 

@@ -9,16 +9,16 @@
 //   FPGA (16 clusters)                                       MI355X (256 workgroups)
 //   -------------------------------------------------------  -------------------------------------------
 //   a cluster's 8 PEs own a fixed set of rows; their sums    a workgroup owns a contiguous ROW BLOCK
-//   live in on-chip output banks (pe.h:121-135)              (<= 4096 rows); the sums live in its LDS
-//   the current column partition of x sits in 8 on-chip      the current x SUB-TILE (<= 16384 columns)
-//   vector banks, double-buffered (vecbuf_access_unit.h)     sits in LDS, double-buffered
+//   live in on-chip output banks (pe.h:121-135)              (<= 4095 rows); the sums live in its LDS
+//   the current column partition of x sits in 8 on-chip      the current x SUB-TILE (<= 8192 columns) sits
+//   vector banks, double-buffered (vecbuf_access_unit.h)     in LDS, in a ring of four buffers
 //   the matrix streams past, one packet per cycle            the block's non-zeros stream past as
 //   (spmv_cluster.h:73-98)                                   coalesced 8-byte elements
 //
 // So at hs_load_matrix time the CPSR image is decoded ONCE on the host and re-cut:
 //   * rows are split into row blocks of roughly equal non-zero count (never across a row partition);
 //   * the non-zeros of a block are grouped into UNITS, one per x sub-tile that the block touches
-//     (a sub-tile is a <= 16384-column slice of one column partition);
+//     (a sub-tile is a <= 8192-column slice of one column partition);
 //   * a unit's elements are dealt to the 12 consumer wavefronts of the workgroup in chunks of 64,
 //     each wavefront's chunks forming one contiguous stream through all units of the block.
 // Element = { u32 value word, u32 (local_row << 16 | local_col) } = 8 bytes: markers, lane padding and
@@ -40,8 +40,9 @@ constexpr uint32_t kWaveLanes = 64;
 constexpr uint32_t kWavesPerWorkgroup = 16;                   // 1024 threads: one workgroup per CU
 constexpr uint32_t kConsumerWaves = 12;                       // stream elements, gather x, accumulate rows
 constexpr uint32_t kLoaderWaves = kWavesPerWorkgroup - kConsumerWaves;  // refill the idle x buffer
-constexpr uint32_t kSubTileCols = 16384;                      // 64 KiB of x per buffer, two buffers
-constexpr uint32_t kMaxBlockRows = 4096;                      // 32 KiB of 64-bit row accumulators
+constexpr uint32_t kSubTileCols = 8192;                       // 32 KiB of x per LDS buffer ...
+constexpr uint32_t kXBuffers = 4;                             // ... in a ring of four: refills run three sub-tiles ahead
+constexpr uint32_t kMaxBlockRows = 4095;                      // + 1 scratch slot = 32 KiB of 64-bit row accumulators
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 
@@ -50,7 +51,7 @@ struct Block {
     uint32_t row0;          // first row (absolute, padded numbering)
     uint32_t nrows;         // <= kMaxBlockRows; local row nrows is the scratch slot padding elements hit
     uint32_t row_part;      // row partition (hs_run_partition filter)
-    uint32_t unit_begin;    // units [unit_begin, unit_end) in ascending sub-tile order
+    uint32_t unit_begin;    // units [unit_begin, unit_end), consumed in this order
     uint32_t unit_end;
     uint32_t reserved;
     uint64_t wave_offset[kConsumerWaves];   // byte offset of each consumer wavefront's stream in the image

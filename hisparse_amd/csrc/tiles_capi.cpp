@@ -43,23 +43,26 @@ int hs_tiles_build(const void* const channel[HS_NUM_CHANNELS], const uint64_t n_
     return HS_OK;
 }
 
-int hs_tiles_info(const hs_tiles* h, uint64_t* image_bytes, uint32_t* num_pieces, uint32_t* num_workgroups, uint32_t* row_stride,
-                  uint64_t* nnz, uint64_t* elements) {
+int hs_tiles_info(const hs_tiles* h, uint64_t* image_bytes, uint32_t* num_blocks, uint32_t* num_units, uint32_t* num_workgroups,
+                  uint32_t* max_block_rows, uint64_t* nnz, uint64_t* elements) {
     if (!h) return HS_ERR_BAD_ARG;
     if (image_bytes) *image_bytes = h->t.image.size();
-    if (num_pieces) *num_pieces = uint32_t(h->t.pieces.size());
+    if (num_blocks) *num_blocks = uint32_t(h->t.blocks.size());
+    if (num_units) *num_units = uint32_t(h->t.units.size());
     if (num_workgroups) *num_workgroups = h->t.num_workgroups;
-    if (row_stride) *row_stride = h->t.row_stride;
+    if (max_block_rows) *max_block_rows = h->t.max_block_rows;
     if (nnz) *nnz = h->t.nnz;
     if (elements) *elements = h->t.elements;
     return HS_OK;
 }
 
-int hs_tiles_copy(const hs_tiles* h, void* image, void* pieces, uint32_t* wg_first) {
+int hs_tiles_copy(const hs_tiles* h, void* image, void* blocks, void* units, uint32_t* wg_first, uint32_t* block_order) {
     if (!h) return HS_ERR_BAD_ARG;
     if (image && !h->t.image.empty()) std::memcpy(image, h->t.image.data(), h->t.image.size());
-    if (pieces && !h->t.pieces.empty()) std::memcpy(pieces, h->t.pieces.data(), h->t.pieces.size() * sizeof(hisparse::dev::Piece));
+    if (blocks && !h->t.blocks.empty()) std::memcpy(blocks, h->t.blocks.data(), h->t.blocks.size() * sizeof(hisparse::dev::Block));
+    if (units && !h->t.units.empty()) std::memcpy(units, h->t.units.data(), h->t.units.size() * sizeof(hisparse::dev::Unit));
     if (wg_first) std::memcpy(wg_first, h->t.wg_first.data(), h->t.wg_first.size() * sizeof(uint32_t));
+    if (block_order && !h->t.block_order.empty()) std::memcpy(block_order, h->t.block_order.data(), h->t.block_order.size() * sizeof(uint32_t));
     return HS_OK;
 }
 

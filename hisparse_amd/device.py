@@ -31,14 +31,18 @@ class DeviceError(RuntimeError):
 
 class Stats(C.Structure):
     _fields_ = [("nnz", C.c_uint64), ("cpsr_bytes", C.c_uint64), ("stream_bytes", C.c_uint64), ("stream_elements", C.c_uint64),
-                ("num_pieces", C.c_uint32), ("num_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("num_blocks", C.c_uint32), ("num_units", C.c_uint32), ("num_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("num_compute_units", C.c_uint32), ("load_seconds", C.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
-PIECE_DTYPE = np.dtype([("col_tile", "<u4"), ("row_part", "<u4"), ("steps", "<u4"), ("reserved", "<u4"), ("offset", "<u8")])
+CONSUMER_WAVES = 12
+# device-side descriptors (hisparse_amd/csrc/stream_tiles.h)
+BLOCK_DTYPE = np.dtype([("row0", "<u4"), ("nrows", "<u4"), ("row_part", "<u4"), ("unit_begin", "<u4"), ("unit_end", "<u4"),
+                        ("reserved", "<u4"), ("wave_offset", "<u8", (CONSUMER_WAVES,))])
+UNIT_DTYPE = np.dtype([("col0", "<u4"), ("ncols", "<u4"), ("end_step", "<u4", (CONSUMER_WAVES,))])
 
 
 def lib():
@@ -69,8 +73,9 @@ def lib():
         l.hs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.hs_tiles_build.argtypes = [C.POINTER(vp), C.POINTER(u64), C.c_int, u32, u32, u32, u32, u32, u32, u32, C.POINTER(vp)]
-        l.hs_tiles_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
-        l.hs_tiles_copy.argtypes = [vp, vp, vp, vp]
+        l.hs_tiles_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64),
+                                    C.POINTER(u64)]
+        l.hs_tiles_copy.argtypes = [vp, vp, vp, vp, vp, vp]
         l.hs_tiles_free.argtypes = [vp]
         l.hs_tiles_free.restype = None
         l.hs_tiles_last_error.restype = C.c_char_p
@@ -184,7 +189,7 @@ class SpmvEngine:
 
 
 def build_tiles(packets, impl, ob_bank, vb_bank, num_rows, num_cols, num_row_partitions, num_col_partitions, max_workgroups):
-    """What hs_load_matrix would upload (no GPU involved): dict(image, pieces, wg_first, row_stride, nnz, elements)."""
+    """What hs_load_matrix would upload (no GPU involved): dict(image, blocks, units, wg_first, block_order, ...)."""
     l = lib()
     ptrs, counts, keep = _channel_arrays(packets)
     h = C.c_void_p()
@@ -194,13 +199,17 @@ def build_tiles(packets, impl, ob_bank, vb_bank, num_rows, num_cols, num_row_par
     if rc != 0:
         raise DeviceError(rc, l.hs_tiles_last_error().decode())
     try:
-        nbytes, npieces, nwg, stride, nnz, elems = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
-        l.hs_tiles_info(h, C.byref(nbytes), C.byref(npieces), C.byref(nwg), C.byref(stride), C.byref(nnz), C.byref(elems))
+        nbytes, nnz, elems = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        nblocks, nunits, nwg, maxrows = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        l.hs_tiles_info(h, C.byref(nbytes), C.byref(nblocks), C.byref(nunits), C.byref(nwg), C.byref(maxrows), C.byref(nnz), C.byref(elems))
         image = np.zeros(max(nbytes.value, 1), dtype=np.uint8)
-        pieces = np.zeros(max(npieces.value, 1), dtype=PIECE_DTYPE)
+        blocks = np.zeros(max(nblocks.value, 1), dtype=BLOCK_DTYPE)
+        units = np.zeros(max(nunits.value, 1), dtype=UNIT_DTYPE)
         wg_first = np.zeros(nwg.value + 1, dtype=np.uint32)
-        l.hs_tiles_copy(h, image.ctypes.data, pieces.ctypes.data, wg_first.ctypes.data)
-        return dict(image=image[:nbytes.value], pieces=pieces[:npieces.value], wg_first=wg_first, num_workgroups=nwg.value,
-                    row_stride=stride.value, nnz=nnz.value, elements=elems.value)
+        order = np.zeros(max(nblocks.value, 1), dtype=np.uint32)
+        l.hs_tiles_copy(h, image.ctypes.data, blocks.ctypes.data, units.ctypes.data, wg_first.ctypes.data, order.ctypes.data)
+        return dict(image=image[:nbytes.value], blocks=blocks[:nblocks.value], units=units[:nunits.value], wg_first=wg_first,
+                    block_order=order[:nblocks.value], num_workgroups=nwg.value, max_block_rows=maxrows.value, nnz=nnz.value,
+                    elements=elems.value)
     finally:
         l.hs_tiles_free(h)

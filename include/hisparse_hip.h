@@ -49,7 +49,7 @@ enum {
     HS_ERR_HIP = -3,          /* a HIP runtime call failed; see hs_last_error */
     HS_ERR_BAD_MATRIX = -4,   /* channel buffers are not a valid CPSR image for the given geometry */
     HS_ERR_NOT_LOADED = -5,   /* run before hs_load_matrix / hs_load_vector */
-    HS_ERR_UNSUPPORTED = -6,  /* e.g. vector bank too large for the 160 KiB LDS tile */
+    HS_ERR_UNSUPPORTED = -6,  /* configuration the device cannot hold */
     HS_ERR_NO_MEMORY = -7,
 };
 
@@ -61,11 +61,12 @@ typedef struct hs_context hs_context;
 typedef struct {
     uint64_t nnz;               /* true non-zeros found in the CPSR image */
     uint64_t cpsr_bytes;        /* bytes of the 16 channel buffers as handed in */
-    uint64_t stream_bytes;      /* bytes of the device-private stream tiles the kernel reads per SpMV */
-    uint64_t stream_elements;   /* element slots in the stream tiles (non-zeros + row-sets + padding) */
-    uint32_t num_pieces;        /* (workgroup, column tile) work pieces */
+    uint64_t stream_bytes;      /* bytes of the device-private element streams the kernel reads per SpMV */
+    uint64_t stream_elements;   /* 8-byte element slots in those streams (non-zeros + chunk padding) */
+    uint32_t num_blocks;        /* row blocks (each owned by one workgroup at a time) */
+    uint32_t num_units;         /* (row block, x sub-tile) units */
     uint32_t num_workgroups;    /* grid size of the SpMV kernel */
-    uint32_t lds_bytes;         /* dynamic LDS per workgroup (the x tile) */
+    uint32_t lds_bytes;         /* dynamic LDS per workgroup (two x sub-tile buffers + row accumulators) */
     uint32_t num_compute_units; /* of the device */
     double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
 } hs_stats;
@@ -113,8 +114,8 @@ int hs_bind_device_result(hs_context* ctx, void* y_dev);
 int hs_get_stats(const hs_context* ctx, hs_stats* stats);
 /* `runs` back-to-back hs_run calls after `warmup` untimed ones, bracketed by HIP events on the
  * stream the kernels are launched on.  total_ms: wall time of the `runs` SpMVs (events around the
- * whole loop).  kernel_ms: sum over the runs of the duration of the dominant kernel
- * (spmv_stream_*) alone, from per-launch event pairs.  Either output may be NULL. */
+ * whole loop).  kernel_ms: sum over the runs of the duration of the SpMV kernel
+ * (spmv_rowblock_kernel) alone, from per-launch event pairs.  Either output may be NULL. */
 int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* kernel_ms);
 
 /* ---- introspection of the load-time re-tiling (host only, no GPU needed; used by the tests) -------- */
@@ -123,10 +124,11 @@ typedef struct hs_tiles hs_tiles;
 int hs_tiles_build(const void* const channel[HS_NUM_CHANNELS], const uint64_t n_packets[HS_NUM_CHANNELS], int impl, uint32_t ob_bank,
                    uint32_t vb_bank, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
                    uint32_t num_col_partitions, uint32_t max_workgroups, hs_tiles** out);
-int hs_tiles_info(const hs_tiles* t, uint64_t* image_bytes, uint32_t* num_pieces, uint32_t* num_workgroups, uint32_t* row_stride,
-                  uint64_t* nnz, uint64_t* elements);
-/* image: image_bytes; pieces: num_pieces x {u32 col_tile, row_part, steps, reserved; u64 offset}; wg_first: num_workgroups + 1 */
-int hs_tiles_copy(const hs_tiles* t, void* image, void* pieces, uint32_t* wg_first);
+int hs_tiles_info(const hs_tiles* t, uint64_t* image_bytes, uint32_t* num_blocks, uint32_t* num_units, uint32_t* num_workgroups,
+                  uint32_t* max_block_rows, uint64_t* nnz, uint64_t* elements);
+/* image: image_bytes; blocks: num_blocks x 120 B; units: num_units x 56 B (layouts: hisparse_amd/csrc/stream_tiles.h);
+ * wg_first: num_workgroups + 1; block_order: num_blocks */
+int hs_tiles_copy(const hs_tiles* t, void* image, void* blocks, void* units, uint32_t* wg_first, uint32_t* block_order);
 void hs_tiles_free(hs_tiles* t);
 const char* hs_tiles_last_error(void);
 

@@ -15,5 +15,5 @@ eng.load_vector(host.pack_vector(0, x))
 runs = int(os.environ.get("RUNS", "50"))
 for k in range(2):
     tot, kern = eng.time_runs(5, runs)
-print("ablate", os.environ.get("HISPARSE_ABLATE", "0"), "ms/run %.4f kernel ms %.4f | algorithmic %.0f GB/s | stream %.0f GB/s" % (
+print("ablate", os.environ.get("HISPARSE_ABLATE", "0"), "depth", os.environ.get("HISPARSE_DEPTH", "8"), "ms/run %.4f kernel ms %.4f | algorithmic %.0f GB/s | stream %.0f GB/s" % (
     tot / runs, kern / runs, 8 * cp.nnz / (kern / runs * 1e-3) / 1e9, st["stream_bytes"] / (kern / runs * 1e-3) / 1e9))
