@@ -33,8 +33,8 @@ HIP_SRCS  := $(CSRC)/hs_api.cpp $(CSRC)/tiles_capi.cpp $(CSRC)/stream_tiles.cpp 
 $(LIBDIR)/libhisparse_hip.so: $(HIP_SRCS) $(HIP_HDRS) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS) -pthread
 
-$(LIBDIR)/benchmark: $(CSRC)/benchmark.cpp $(HOST_HDRS) include/hisparse_hip.h $(LIBDIR)/libhisparse_hip.so | $(LIBDIR)
-	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lhisparse_hip -lz -Wl,-rpath,'$$ORIGIN'
+$(LIBDIR)/benchmark: $(CSRC)/benchmark.cpp $(HOST_HDRS) include/hisparse_hip.h $(LIBDIR)/libhisparse_hip.so $(LIBDIR)/libhisparse_host.so | $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lhisparse_hip -lhisparse_host -lz -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 oracle/liboracle.so: oracle/cpu_ref.c
 	$(MAKE) -C oracle

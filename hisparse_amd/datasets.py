@@ -1,0 +1,66 @@
+"""hisparse_amd.datasets — the benchmark matrices of the reference, as seeded synthetic stand-ins.
+
+The reference's datasets (sw/bm.sh:3-17, paper Table 2) live in a Google-Drive archive that is not part
+of the checkout (datasets/download.sh; git-lfs blob missing) and there is no network here, so every
+named configuration below can be produced two ways:
+  * from the real `.npz` if the caller has it (`path=`), through the same loader the reference uses
+    (load_csr_matrix_from_float_npz, sw/data_loader.h:51-70);
+  * otherwise from a seeded generator of the same shape / non-zero count.
+Each entry also carries the numeric mode and bank sizes BASELINE.json's `configs` pair it with.
+"""
+from dataclasses import dataclass
+
+from . import host
+
+
+@dataclass(frozen=True)
+class Config:
+    name: str
+    impl: str            # fixed | float_pob | float_stall
+    rows: int
+    cols: int
+    kind: str            # generator kind (host.CSRMatrix.generate)
+    a: float             # powerlaw: target nnz;  uniform: nnz per row
+    b: float             # powerlaw: skew exponent; bernoulli: density
+    c: float             # value scale
+    seed: int
+    npz: str             # file name of the real dataset (sw/bm.sh:4-17)
+    skip_empty_rows: bool = True
+    note: str = ""
+
+
+# value scale: the reference overwrites every value with `1 / num_cols` (integer division => 0.0,
+# sw/benchmark.cpp:411); the stand-ins use non-degenerate values instead so that parity means something.
+CONFIGS = {
+    # BASELINE.json configs[0]: plumbing case
+    "csim_1k": Config("csim_1k", "fixed", 1000, 1000, "bernoulli", 0, 0.01, 0.5, 1, "", True,
+                      "1k x 1k, 1 % dense (values |N(0,0.5)| clipped by the unsigned fixed-point type)"),
+    # configs[1]: the north-star workload
+    "ogbl_ppa": Config("ogbl_ppa", "fixed", 576289, 576289, "powerlaw", 42463862, 0.35, 1.0, 42,
+                       "ogbl_ppa_576K_42M_csr_float32.npz"),
+    # configs[2]
+    "transformer_50": Config("transformer_50", "float_pob", 512, 33288, "bernoulli", 0, 0.5, 0.05, 50,
+                             "transformer_50_512_33288_csr_float32.npz"),
+    # configs[3]
+    "ogbn_products": Config("ogbn_products", "float_stall", 2449029, 2449029, "powerlaw", 123718280, 0.43, 1.0, 43,
+                            "ogbn_products_2M_124M_csr_float32.npz"),
+    # configs[4]
+    "mouse_gene": Config("mouse_gene", "fixed", 45101, 45101, "powerlaw", 28967291, 0.30, 0.1, 44,
+                         "mouse_gene_45K_29M_csr_float32.npz"),
+    # small relatives for tests / smoke
+    "ppa_small": Config("ppa_small", "fixed", 40000, 70000, "powerlaw", 1400000, 0.35, 1.0, 7, ""),
+    "nn_small": Config("nn_small", "float_pob", 512, 33288, "bernoulli", 0, 0.05, 0.05, 95, ""),
+}
+
+
+def load(name, path=None, scale=1.0):
+    """(Config, CSRMatrix).  `scale` < 1 shrinks rows, cols and nnz of a generated stand-in proportionally."""
+    cfg = CONFIGS[name]
+    if path:
+        return cfg, host.load_csr_matrix_from_float_npz(path)
+    rows, cols, a = cfg.rows, cfg.cols, cfg.a
+    if scale != 1.0:
+        rows, cols = max(128, int(rows * scale)), max(8, int(cols * scale))
+        if cfg.kind == "powerlaw":
+            a = max(1.0, a * scale)
+    return cfg, host.CSRMatrix.generate(cfg.kind, rows, cols, a=a, b=cfg.b, c=cfg.c, seed=cfg.seed)

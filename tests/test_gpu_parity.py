@@ -63,8 +63,13 @@ def test_baseline_config_1k(impl):
 
 @pytest.mark.parametrize("impl", IMPLS)
 def test_medium_default_banks(impl):
-    # 40k x 70k, three column partitions at the default 32768-column tile, ~1.4 M non-zeros
-    m = cases.random_csr(40000, 70000, 0.0005, 7, impl)
+    # 40k x 70k power-law stand-in, three column partitions at the default 32768-column tile, ~1.4 M non-zeros
+    csr = host.CSRMatrix.generate("powerlaw", 40000, 70000, a=1.4e6, b=0.35, c=1.0 if impl == 0 else 2.0, seed=7)
+    ip, ix, dv = csr.arrays()
+    if impl != 0:
+        dv = (dv - 1.0).astype(np.float32)   # signed values for the float modes
+    import scipy.sparse as sp
+    m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(40000, 70000))
     v, o = host.default_banks(impl)
     cp, _, _ = _run_case(impl, m, vb=v, ob=o, skip=True, seed=7)
     assert cp.num_col_partitions == 3

@@ -1,0 +1,51 @@
+"""Summarise the rocprofv3 outputs of tools/profile_hbm.sh (rocpd sqlite databases) into text + hbm_traffic.json."""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+out = sys.argv[1]
+KERNEL = "spmv_rowblock_kernel"
+summary = {"kernel": KERNEL}
+
+
+def db(sub):
+    hits = glob.glob(os.path.join(out, sub, "**", "*.db"), recursive=True)
+    return sqlite3.connect(hits[0]) if hits else None
+
+
+d = db("stats")
+if d:
+    print("== rocprofv3 --kernel-trace --stats (top_kernels; durations in us) ==")
+    for name, calls, total, avg, pct in d.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+        print(f"{name[:100]:100s} calls {calls:5d} total_us {total:12.3f} avg_us {avg:10.3f} pct {pct:6.2f}")
+        if KERNEL in name:
+            summary["kernel_avg_us"] = avg
+            summary["kernel_calls"] = calls
+    row = d.execute(f"select vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels where name like '%{KERNEL}%' limit 1").fetchone()
+    if row:
+        summary["launch"] = dict(zip(["vgpr", "agpr", "sgpr", "lds_bytes", "scratch", "grid_x", "workgroup_x"], row))
+        print("launch:", summary["launch"])
+for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    d = db(sub)
+    if not d:
+        continue
+    vals = sorted(v for (v,) in d.execute(f"select value from counters_collection where counter_name = '{counter}' and kernel_name like '%{KERNEL}%'"))
+    if vals:
+        summary[counter + "_KiB_median"] = vals[len(vals) // 2]
+        summary[counter + "_KiB_min"] = vals[0]
+        summary[counter + "_KiB_max"] = vals[-1]
+        print(f"== --pmc {counter}: {len(vals)} launches, median {vals[len(vals)//2]:.1f} KiB (min {vals[0]:.1f}, max {vals[-1]:.1f}) ==")
+if "FETCH_SIZE_KiB_median" in summary:
+    # MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read
+    # (it tallies 128-byte requests at 64 bytes) -> double it.  WRITE_SIZE is uncalibrated there; it is small here (y only).
+    read_b = summary["FETCH_SIZE_KiB_median"] * 1024 * 2
+    write_b = summary.get("WRITE_SIZE_KiB_median", 0.0) * 1024
+    summary["hbm_read_bytes_per_launch_corrected"] = read_b
+    summary["hbm_write_bytes_per_launch"] = write_b
+    summary["hbm_bytes_per_launch"] = read_b + write_b
+    summary["correction"] = "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of wide streaming reads), WRITE_SIZE KiB x 1024 as reported"
+print(json.dumps(summary, indent=1))
+with open(os.path.join(out, "hbm_traffic.json"), "w") as f:
+    json.dump(summary, f, indent=1)
