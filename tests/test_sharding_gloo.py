@@ -1,0 +1,92 @@
+"""Row-slab sharding across ranks (hisparse_amd/sharding.py) with a real process group: world_size 2, gloo, CPU.
+Each rank formats its own slab with the product host library, computes its y slab with the oracle (no GPU here),
+and the slabs are all-gathered the way bench.py gathers them over RCCL.  The assembled y must equal the y of the
+unsharded matrix."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, impl, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from hisparse_amd import host, sharding
+    from oracle import oracle as orc
+    import cases
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    granule = 128 * (8 if impl == 2 else 1)
+    m = cases.random_csr(5000, 400, 0.02, 77, impl)            # same seeded matrix on every rank
+    x = cases.random_x(400, 77, impl)
+    bounds = sharding.split_rows_by_nnz(m.indptr, world, granule)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    ip, ix, dv = sharding.slab_arrays(m.indptr, m.indices, m.data, lo, hi)
+    csr = host.CSRMatrix.from_arrays(hi - lo, 400, ip, ix, dv)
+    cp = host.format_matrix(csr, impl, vb_bank=16, ob_bank=8, skip_empty_rows=True)
+    xw = host.pack_vector(impl, np.concatenate([x, np.zeros(cp.num_cols - 400, dtype=np.float32)]))
+    y = orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                 cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+    rows_all = [None] * world
+    dist.all_gather_object(rows_all, (hi - lo, cp.num_rows))
+    chunk = max(p for _, p in rows_all)
+    mine = torch.zeros(chunk, dtype=torch.int32)
+    mine[:cp.num_rows] = torch.from_numpy(y.view(np.int32))
+    gathered = torch.zeros(chunk * world, dtype=torch.int32)
+    dist.all_gather_into_tensor(gathered, mine)
+    if rank == 0:
+        layout = (chunk, [(i * chunk, r) for i, (r, _) in enumerate(rows_all)])
+        np.save(out_path, sharding.assemble(gathered.numpy().view(np.uint32), layout))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("impl", [0, 2])
+def test_two_rank_row_slabs_reassemble(tmp_path, impl):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hisparse_amd import host
+    from oracle import oracle as orc
+    import cases
+
+    out = str(tmp_path / "y.npy")
+    mp.spawn(_worker, args=(2, _free_port(), impl, out), nprocs=2, join=True)
+    got = np.load(out)
+    m = cases.random_csr(5000, 400, 0.02, 77, impl)
+    csr = host.CSRMatrix.from_scipy(m)
+    cp = host.format_matrix(csr, impl, vb_bank=16, ob_bank=8, skip_empty_rows=True)
+    xw = host.pack_vector(impl, np.concatenate([cases.random_x(400, 77, impl), np.zeros(cp.num_cols - 400, dtype=np.float32)]))
+    want = orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                    cp.num_col_partitions, cp.ob_bank, cp.vb_bank)[:5000]
+    assert got.shape == (5000,)
+    if impl == 0:
+        assert np.array_equal(got, want)
+    else:
+        assert cases.float_close(got, want)
+
+
+def test_split_rows_by_nnz_properties():
+    from hisparse_amd import sharding
+    rng = np.random.default_rng(0)
+    deg = rng.zipf(1.7, size=20000).clip(max=5000)
+    indptr = np.concatenate([[0], np.cumsum(deg)])
+    for parts in (1, 2, 4, 8):
+        b = sharding.split_rows_by_nnz(indptr, parts, 128)
+        assert b[0] == 0 and b[-1] == 20000 and len(b) == parts + 1 and all(x <= y for x, y in zip(b, b[1:]))
+        assert all(v % 128 == 0 for v in b[1:-1])
+        loads = [indptr[b[i + 1]] - indptr[b[i]] for i in range(parts)]
+        assert max(loads) <= indptr[-1] / parts * 1.25 + 5000 * 128
+    chunk, spans = sharding.gather_layout([300, 129, 0], 128)
+    assert chunk == 384 and spans == [(0, 300), (384, 129), (768, 0)]

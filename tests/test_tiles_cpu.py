@@ -1,0 +1,121 @@
+"""Load-time re-tiling (hisparse_amd/csrc/stream_tiles.cpp) checked without a GPU: the image hs_load_matrix would
+upload is walked by a numpy emulation of the kernel (tests/tile_emulator.py) and compared with the oracle."""
+import numpy as np
+import pytest
+
+from hisparse_amd import device, host
+from oracle import oracle as orc
+
+import cases
+import tile_emulator
+
+
+def build(cp, impl, workgroups):
+    return device.build_tiles(cp, impl, cp.ob_bank, cp.vb_bank, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                              cp.num_col_partitions, workgroups)
+
+
+def oracle_y(cp, impl, xw):
+    return orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                    cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("skip", [False, True])
+@pytest.mark.parametrize("rows,cols,density,vb,ob,wgs", [(300, 50, 0.05, 2, 8, 4), (3000, 700, 0.02, 16, 8, 7), (1000, 1000, 0.01, 4096, 8192, 256)])
+def test_emulated_kernel_matches_oracle(impl, skip, rows, cols, density, vb, ob, wgs):
+    if impl == 1 and ob == 8192:
+        ob = 1024
+    m = cases.random_csr(rows, cols, density, 5, impl)
+    _, cp = cases.formatted(m, impl, vb, ob, skip)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 5, impl))
+    tiles = build(cp, impl, wgs)
+    assert tiles["nnz"] == m.nnz
+    got = tile_emulator.run(tiles, impl, xw, cp.num_rows)
+    want = oracle_y(cp, impl, xw)
+    if impl == 0:
+        assert np.array_equal(got, want)
+    else:
+        assert cases.float_close(got, want)
+
+
+def test_structure_invariants():
+    csr = host.CSRMatrix.generate("powerlaw", 30000, 50000, a=600000, b=0.4, c=1.0, seed=3)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+    t = build(cp, 0, 64)
+    blocks, units = t["blocks"], t["units"]
+    # blocks tile the rows exactly, in order, within the LDS budget, never across a row partition
+    assert blocks["row0"][0] == 0 and (blocks["row0"][1:] == blocks["row0"][:-1] + blocks["nrows"][:-1]).all()
+    assert blocks["row0"][-1] + blocks["nrows"][-1] == cp.num_rows
+    assert blocks["nrows"].max() <= 4095 and t["max_block_rows"] == blocks["nrows"].max()
+    # every block is owned by exactly one workgroup
+    assert sorted(t["block_order"].tolist()) == list(range(len(blocks)))
+    assert t["wg_first"][0] == 0 and t["wg_first"][-1] == len(blocks) and t["num_workgroups"] <= 64
+    # sub-tiles: multiple-of-8 widths inside one column partition, wave streams monotone
+    assert (units["ncols"] % 8 == 0).all() and (units["ncols"] <= 8192).all() and (units["ncols"] > 0).all()
+    assert ((units["col0"] // 32768) == ((units["col0"] + units["ncols"] - 1) // 32768)).all()
+    for b in blocks[:5]:
+        es = units["end_step"][b["unit_begin"]:b["unit_end"]]
+        assert (np.diff(es, axis=0) >= 0).all()
+    # bytes: 8 per element slot, padding below 64 slots per unit
+    assert len(t["image"]) == t["elements"] * 8
+    assert 0 <= t["elements"] - t["nnz"] < 64 * len(units)
+    # balance: no workgroup carries more than ~1.5x the mean (power-law rows, 64 groups)
+    loads = []
+    for g in range(t["num_workgroups"]):
+        bs = t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]
+        loads.append(sum(int(units["end_step"][blocks[b]["unit_end"] - 1].sum()) if blocks[b]["unit_end"] > blocks[b]["unit_begin"] else 0 for b in bs))
+    assert max(loads) < 1.5 * (sum(loads) / len(loads)) + 64
+
+
+def test_many_row_partitions_and_partition_filter():
+    # float_pob-style small output banks: several row partitions, run one at a time like hs_run_partition
+    m = cases.random_csr(2500, 300, 0.03, 21, 0)
+    _, cp = cases.formatted(m, 0, 4, 1, True)
+    assert cp.num_row_partitions > 3
+    xw = host.pack_vector(0, cases.random_x(cp.num_cols, 21, 0))
+    t = build(cp, 0, 16)
+    full = tile_emulator.run(t, 0, xw, cp.num_rows)
+    y = np.zeros(cp.num_rows, dtype=np.uint32)
+    for j in range(cp.num_row_partitions):
+        y = tile_emulator.run(t, 0, xw, cp.num_rows, row_part_filter=j, y_init=y)
+    assert np.array_equal(y, full) and np.array_equal(full, oracle_y(cp, 0, xw))
+
+
+def corrupt(cp, fn):
+    chans = [cp.channel(c) for c in range(16)]
+    fn(chans)
+    return chans
+
+
+def test_malformed_images_are_rejected():
+    m = cases.random_csr(600, 80, 0.05, 2, 0)
+    _, cp = cases.formatted(m, 0, 4, 2, True)
+    args = (0, cp.ob_bank, cp.vb_bank, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, 8)
+
+    def col_out_of_range(ch):
+        payload = cp.num_partitions * 2
+        rows, lanes = np.nonzero(ch[0][payload:, :8] != 0xFFFFFFFF)
+        ch[0][payload + rows[0], lanes[0]] = 40          # partition-local column beyond the 32-column partition
+    with pytest.raises(device.DeviceError) as e:
+        device.build_tiles(corrupt(cp, col_out_of_range), *args)
+    assert e.value.code == -4 and "column" in str(e.value)
+
+    def truncated(ch):
+        ch[3] = ch[3][: cp.num_partitions * 2 + 1]
+    with pytest.raises(device.DeviceError) as e:
+        device.build_tiles(corrupt(cp, truncated), *args)
+    assert e.value.code == -4
+
+    def huge_marker(ch):
+        payload = cp.num_partitions * 2
+        rows, lanes = np.nonzero(ch[1][payload:, :8] == 0xFFFFFFFF)
+        ch[1][payload + rows[0], 8 + lanes[0]] = 200 << 24   # skip 200 rounds: the next non-zero of that lane leaves the partition
+    with pytest.raises(device.DeviceError) as e:
+        device.build_tiles(corrupt(cp, huge_marker), *args)
+    assert e.value.code == -4 and "row" in str(e.value)
+
+    def short_headers(ch):
+        ch[0] = ch[0][:1]
+    with pytest.raises(device.DeviceError):
+        device.build_tiles(corrupt(cp, short_headers), *args)
