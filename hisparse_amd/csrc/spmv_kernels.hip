@@ -51,20 +51,29 @@ template <bool kFloat>
 struct Rows;
 template <>
 struct Rows<false> {
-    using acc_t = unsigned long long;
-    static __device__ __forceinline__ void add(acc_t* ys, uint32_t row, uint32_t mat, uint32_t vec) {
-        atomicAdd(ys + row, static_cast<unsigned long long>(q8_24_mul(mat, vec)));   // ds_add_u64
-    }
+    using acc_t = unsigned long long;   // LDS accumulator
+    using prod_t = unsigned long long;
+    static __device__ __forceinline__ prod_t product(uint32_t mat, uint32_t vec) { return q8_24_mul(mat, vec); }
+    static __device__ __forceinline__ void add(acc_t* ys, uint32_t row, prod_t p) { atomicAdd(ys + row, p); }   // ds_add_u64
     static __device__ __forceinline__ uint32_t finish(acc_t s) { return s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s); }  // AP_SAT (pe.h:72)
 };
 template <>
 struct Rows<true> {
     using acc_t = float;
-    static __device__ __forceinline__ void add(acc_t* ys, uint32_t row, uint32_t mat, uint32_t vec) {
-        atomicAdd(ys + row, __uint_as_float(mat) * __uint_as_float(vec));           // ds_add_f32; multiply, then add (pe-pob.h:63-65)
-    }
+    using prod_t = float;
+    // multiply, then add: two roundings like the float PEs (pe-pob.h:63-65, pe-stall.h:52,138)
+    static __device__ __forceinline__ prod_t product(uint32_t mat, uint32_t vec) { return __uint_as_float(mat) * __uint_as_float(vec); }
+    static __device__ __forceinline__ void add(acc_t* ys, uint32_t row, prod_t p) { atomicAdd(ys + row, p); }   // ds_add_f32
     static __device__ __forceinline__ uint32_t finish(acc_t s) { return __float_as_uint(s); }
 };
+
+// Sum over the 64 lanes of a wavefront (result valid in every lane).
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWaveLanes);
+    return v;
+}
 
 // Copy one x sub-tile into an LDS buffer with kStride cooperating threads (t = 0 .. kStride-1).
 // Completely branch-free: out-of-range threads re-copy the last 16 bytes (same data to the same place), so all
@@ -123,6 +132,57 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// The consumer side of one row block: stream this wavefront's chunks through all sub-tiles of the block.
+// kDense: the block has few, long rows and its chunks are row-sorted (Block::flags & kBlockDenseRows).
+template <bool kFloat, int kAblate, int kDepth, bool kDense>
+__device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit* __restrict__ unit, uint32_t U, uint32_t wave, uint32_t lane,
+                                              const uint32_t* xs, typename Rows<kFloat>::acc_t* ys) {
+    const uint32_t total = unit[U - 1].end_step[wave];
+    const uint32_t last = total ? total - 1 : 0;   // prefetches past the end re-read the last chunk (no branch)
+    uint64_t buf[kDepth];
+#pragma unroll
+    for (int k = 0; k < kDepth; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kChunkBytes);
+    uint32_t u = 0, end = unit[0].end_step[wave];
+    const uint32_t* xb = xs;
+    for (uint32_t base = 0;; base += kDepth) {
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) {
+            const uint32_t s = base + k;
+            while (s == end) {                 // this wavefront finished sub-tile u (possibly with no work in it)
+                if (!(kAblate & 8)) lds_barrier();
+                if (++u == U) goto block_done;
+                end = unit[u].end_step[wave];
+                xb = xs + (u % kXBuffers) * kSubTileCols;
+            }
+            stream_wait<kDepth - 1>(buf[k]);
+            const uint32_t mat = static_cast<uint32_t>(buf[k]), cr = static_cast<uint32_t>(buf[k] >> 32);
+            const uint32_t xv = (kAblate & 2) ? cr : xb[cr & 0xffffu];
+            if (kAblate & 1) {
+                asm volatile("" ::"v"(xv), "v"(mat));
+            } else {
+                const typename Rows<kFloat>::prod_t prod = Rows<kFloat>::product(mat, xv);
+                const uint32_t row = cr >> 16;
+                if (kDense) {
+                    // chunks are row-sorted, so the whole wavefront is usually on ONE accumulator: add the 64 products in
+                    // registers instead of issuing a 64-way conflicting LDS atomic
+                    const uint32_t row0 = __builtin_amdgcn_readfirstlane(row);
+                    if (__ballot(row == row0) == ~0ull) {
+                        const typename Rows<kFloat>::prod_t sum = wave_sum(prod);
+                        if (lane == 0) Rows<kFloat>::add(ys, row0, sum);
+                    } else {
+                        Rows<kFloat>::add(ys, row, prod);
+                    }
+                } else {
+                    Rows<kFloat>::add(ys, row, prod);
+                }
+            }
+            stream_load(buf[k], stream + static_cast<size_t>(min(s + kDepth, last)) * kChunkBytes);
+        }
+    }
+block_done:
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail prefetches must land before their registers are reused
+}
+
 // kDepth: element loads in flight per lane (kDepth x 512 B per wavefront).
 // kAblate (profiling builds only, HISPARSE_ABLATE): bit 0 = no LDS accumulate, bit 1 = no LDS gather,
 // bit 2 = no x sub-tile refill, bit 3 = no per-sub-tile barrier.  Any non-zero value gives wrong results.
@@ -176,33 +236,8 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
             } else {
                 // ---- consumer wavefronts: stream elements, gather x, accumulate rows -----------------------------
                 const uint8_t* stream = image + blk->wave_offset[wave] + lane * 8u;
-                const uint32_t total = unit[U - 1].end_step[wave];
-                const uint32_t last = total ? total - 1 : 0;   // prefetches past the end re-read the last chunk (no branch)
-                uint64_t buf[kDepth];
-#pragma unroll
-                for (int k = 0; k < kDepth; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kChunkBytes);
-                uint32_t u = 0, end = unit[0].end_step[wave];
-                const uint32_t* xb = xs;
-                for (uint32_t base = 0;; base += kDepth) {
-#pragma unroll
-                    for (int k = 0; k < kDepth; ++k) {
-                        const uint32_t s = base + k;
-                        while (s == end) {                 // this wavefront finished sub-tile u (possibly with no work in it)
-                            if (!(kAblate & 8)) lds_barrier();
-                            if (++u == U) goto block_done;
-                            end = unit[u].end_step[wave];
-                            xb = xs + (u % kXBuffers) * kSubTileCols;
-                        }
-                        stream_wait<kDepth - 1>(buf[k]);
-                        const uint32_t mat = static_cast<uint32_t>(buf[k]), cr = static_cast<uint32_t>(buf[k] >> 32);
-                        const uint32_t xv = (kAblate & 2) ? cr : xb[cr & 0xffffu];
-                        if (kAblate & 1) asm volatile("" ::"v"(xv), "v"(mat));
-                        else Rows<kFloat>::add(ys, cr >> 16, mat, xv);
-                        stream_load(buf[k], stream + static_cast<size_t>(min(s + kDepth, last)) * kChunkBytes);
-                    }
-                }
-            block_done:
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail prefetches must land before their registers are reused
+                if (blk->flags & kBlockDenseRows) consume_block<kFloat, kAblate, kDepth, true>(stream, unit, U, wave, lane, xs, ys);
+                else consume_block<kFloat, kAblate, kDepth, false>(stream, unit, U, wave, lane, xs, ys);
             }
         }
         // every sub-tile barrier has passed: the accumulators are final

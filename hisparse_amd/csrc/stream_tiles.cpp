@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -115,6 +116,8 @@ struct UnitPlan {           // host-side companion of a device Unit
     uint64_t n = 0;         // real elements
     uint32_t chunks = 0;    // ceil(n / 64)
     uint32_t base = 0;      // chunk counter of the block at the unit's first chunk
+    bool dense = false;     // row-sorted, linear dealing (Block::flags & kBlockDenseRows)
+    size_t row_cursor = 0;  // dense: index of this unit's per-row cursors in `dense_cnt`
     uint32_t start_step[kConsumerWaves];
 };
 
@@ -193,6 +196,20 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         out.max_block_rows = std::max(out.max_block_rows, out.blocks[b].nrows);
     }
 
+    // dense-row blocks additionally count per (sub-tile, row): their units are stored sorted by row
+    std::vector<size_t> dense_base(NB, SIZE_MAX);
+    size_t dense_total = 0;
+    for (uint32_t b = 0; b < NB; ++b)
+        if (out.blocks[b].nrows <= kDenseBlockRows && block_nnz[b] >= 64ull * out.blocks[b].nrows) {
+            out.blocks[b].flags |= kBlockDenseRows;
+            dense_base[b] = dense_total;
+            dense_total += size_t(CP) * S * out.blocks[b].nrows;
+        }
+    std::vector<uint32_t> dense_cnt(dense_total, 0);
+    auto dense_slot = [&](uint32_t b, uint32_t cp, uint32_t s, uint32_t local_row) {
+        return dense_base[b] + (size_t(cp) * S + s) * out.blocks[b].nrows + local_row;
+    };
+
     // ---- pass 1: elements per (block, column partition, sub-tile, source channel) -------------------
     const size_t slots_per_block = size_t(CP) * S * NUM_HBM_CHANNELS;
     std::vector<uint32_t> cnt(size_t(NB) * slots_per_block, 0);
@@ -201,7 +218,9 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     parallel_for(res1.size(), [&](size_t w) {
         const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP), rp = uint32_t(w / NUM_HBM_CHANNELS / CP);
         res1[w] = walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t) {
-            cnt[slot(block_of_row[row], cp, col / L.sub_width, pc)]++;
+            const uint32_t b = block_of_row[row], s = col / L.sub_width;
+            cnt[slot(b, cp, s, pc)]++;
+            if (dense_base[b] != SIZE_MAX) dense_cnt[dense_slot(b, cp, s, row - out.blocks[b].row0)]++;   // a row belongs to one channel: no race
         });
     });
     for (const auto& r : res1)
@@ -236,6 +255,16 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 up.n = n;
                 up.chunks = uint32_t((n + kWaveLanes - 1) / kWaveLanes);
                 up.base = chunk_counter;
+                if (dense_base[b] != SIZE_MAX) {   // per-row counts -> exclusive offsets (the fill pass bumps them)
+                    up.dense = true;
+                    up.row_cursor = dense_slot(b, cp, s, 0);
+                    uint32_t acc = 0;
+                    for (uint32_t r = 0; r < blk.nrows; ++r) {
+                        const uint32_t c = dense_cnt[up.row_cursor + r];
+                        dense_cnt[up.row_cursor + r] = acc;
+                        acc += c;
+                    }
+                }
                 Unit u{};
                 u.col0 = uint32_t(uint64_t(cp) * geom.logical_vb + uint64_t(s) * L.sub_width);
                 u.ncols = std::min<uint32_t>(L.sub_width, L.cols_in_part(cp) - s * L.sub_width);
@@ -281,10 +310,11 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     // ---- pass 2: scatter the elements into the wavefront streams -------------------------------------------
     out.image.assign(image_bytes, 0);
     uint8_t* image = out.image.data();
-    // slot (chunk c, lane l) of a unit holds element l * chunks + c: neighbouring lanes get elements far apart in
-    // the (row-ordered) unit, which keeps same-row LDS atomics out of one instruction.
+    // normal units: slot (chunk c, lane l) holds element l * chunks + c (neighbouring lanes far apart in the unit);
+    // dense-row units: element i sits in chunk i / 64, lane i % 64 of the row-sorted unit.
     auto element_address = [&](const Block& blk, const UnitPlan& up, uint64_t i) -> uint8_t* {
-        const uint32_t lane = uint32_t(i / up.chunks), c = uint32_t(i % up.chunks);
+        const uint32_t lane = up.dense ? uint32_t(i % kWaveLanes) : uint32_t(i / up.chunks);
+        const uint32_t c = up.dense ? uint32_t(i / kWaveLanes) : uint32_t(i % up.chunks);
         const uint32_t g = up.base + c, w = g % kConsumerWaves;
         const uint32_t first = up.base + (w + kConsumerWaves - up.base % kConsumerWaves) % kConsumerWaves;  // first chunk of wave w in this unit
         const uint32_t step = up.start_step[w] + (g - first) / kConsumerWaves;
@@ -296,7 +326,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             const uint32_t b = block_of_row[row], s = col / L.sub_width;
             const Block& blk = out.blocks[b];
             const UnitPlan& up = plans[unit_of[(size_t(b) * CP + cp) * S + s]];
-            const uint64_t i = cnt[slot(b, cp, s, pc)]++;
+            const uint64_t i = up.dense ? dense_cnt[up.row_cursor + (row - blk.row0)]++ : cnt[slot(b, cp, s, pc)]++;
             uint32_t* e = reinterpret_cast<uint32_t*>(element_address(blk, up, i));
             e[0] = val;
             e[1] = ((row - blk.row0) << 16) | (col - s * L.sub_width);

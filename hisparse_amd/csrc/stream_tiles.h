@@ -20,7 +20,11 @@
 //   * the non-zeros of a block are grouped into UNITS, one per x sub-tile that the block touches
 //     (a sub-tile is a <= 8192-column slice of one column partition);
 //   * a unit's elements are dealt to the 12 consumer wavefronts of the workgroup in chunks of 64,
-//     each wavefront's chunks forming one contiguous stream through all units of the block.
+//     each wavefront's chunks forming one contiguous stream through all units of the block.  Normally
+//     lane l of chunk c takes element l*chunks + c (neighbouring lanes far apart: no same-row LDS
+//     atomics in one instruction).  Blocks of <= 32 rows (pruned-NN layers: 512 rows x 16 K non-zeros)
+//     would put all 64 lanes on the same one or two accumulators; there the unit is sorted by row and
+//     dealt linearly, so a chunk almost always holds ONE row and the wavefront adds it up in registers.
 // Element = { u32 value word, u32 (local_row << 16 | local_col) } = 8 bytes: markers, lane padding and
 // partition headers are gone, so the bytes read per SpMV equal the reference's "8 bytes per
 // non-zero" throughput definition (sw/benchmark.cpp:312-314) plus < 2 % chunk padding.
@@ -45,6 +49,8 @@ constexpr uint32_t kXBuffers = 4;                             // ... in a ring o
 constexpr uint32_t kMaxBlockRows = 4095;                      // + 1 scratch slot = 32 KiB of 64-bit row accumulators
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
+constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
+constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit
 
 // Mirrored in the kernel source (read through scalar loads).
 struct Block {
@@ -53,7 +59,7 @@ struct Block {
     uint32_t row_part;      // row partition (hs_run_partition filter)
     uint32_t unit_begin;    // units [unit_begin, unit_end), consumed in this order
     uint32_t unit_end;
-    uint32_t reserved;
+    uint32_t flags;         // kBlockDenseRows: few long rows; chunks are row-sorted and mostly hold ONE row
     uint64_t wave_offset[kConsumerWaves];   // byte offset of each consumer wavefront's stream in the image
 };
 struct Unit {

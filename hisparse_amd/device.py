@@ -41,7 +41,7 @@ class Stats(C.Structure):
 CONSUMER_WAVES = 12
 # device-side descriptors (hisparse_amd/csrc/stream_tiles.h)
 BLOCK_DTYPE = np.dtype([("row0", "<u4"), ("nrows", "<u4"), ("row_part", "<u4"), ("unit_begin", "<u4"), ("unit_end", "<u4"),
-                        ("reserved", "<u4"), ("wave_offset", "<u8", (CONSUMER_WAVES,))])
+                        ("flags", "<u4"), ("wave_offset", "<u8", (CONSUMER_WAVES,))])
 UNIT_DTYPE = np.dtype([("col0", "<u4"), ("ncols", "<u4"), ("end_step", "<u4", (CONSUMER_WAVES,))])
 
 

@@ -75,6 +75,19 @@ def test_medium_default_banks(impl):
     assert cp.num_col_partitions == 3
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+def test_dense_row_blocks(impl):
+    # pruned-NN shape: few rows, thousands of non-zeros each => row blocks of 1-2 rows, the dense-row (wave-combine) layout
+    csr = host.CSRMatrix.generate("bernoulli", 64, 20000, b=0.3, c=0.05, seed=3)
+    ip, ix, dv = csr.arrays()
+    if impl == 0:
+        dv = np.abs(dv)
+    import scipy.sparse as sp
+    m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(64, 20000))
+    v, o = host.default_banks(impl)
+    _run_case(impl, m, vb=v, ob=o, skip=True, seed=13)
+
+
 def test_fixed_rounding_and_saturation():
     # values/x chosen so products need AP_RND and rows overflow AP_SAT (sum >= 256 => 0xffffffff)
     rng = np.random.default_rng(3)
