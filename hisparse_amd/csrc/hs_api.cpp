@@ -41,6 +41,9 @@ struct hs_context {
     uint32_t* d_block_order = nullptr;
     uint32_t num_workgroups = 0;
     uint32_t lds_bytes = 0;
+    uint32_t col_slices = 1;
+    uint32_t ring_buffers = 4;
+    uint32_t* d_partial = nullptr;  // col_slices > 1: per-slice partial results, col_slices x num_rows words
 
     uint32_t* d_x = nullptr;       // library-owned packed x
     uint32_t* d_y = nullptr;       // library-owned packed y
@@ -78,6 +81,8 @@ void free_matrix(hs_context* c) {
     if (c->d_wg_first) (void)hipFree(c->d_wg_first);
     if (c->d_block_order) (void)hipFree(c->d_block_order);
     if (c->d_y) (void)hipFree(c->d_y);
+    if (c->d_partial) (void)hipFree(c->d_partial);
+    c->d_partial = nullptr;
     c->d_image = nullptr;
     c->d_blocks = nullptr;
     c->d_units = nullptr;
@@ -106,8 +111,9 @@ hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     a.wg_first = c->d_wg_first;
     a.block_order = c->d_block_order;
     a.x = x_source(c);
-    a.y = y_target(c);
+    a.out = c->col_slices > 1 ? c->d_partial : y_target(c);
     a.row_part_filter = filter;
+    a.ring_buffers = c->ring_buffers;
     a.num_workgroups = c->num_workgroups;
     a.lds_bytes = c->lds_bytes;
     return a;
@@ -126,6 +132,11 @@ int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1) {
     if (k0) HS_HIP(c, hipEventRecord(k0, c->stream));
     HS_HIP(c, hisparse::dev::launch_spmv(c->impl != HS_IMPL_FIXED, launch_args(c, filter), c->stream));
     if (k1) HS_HIP(c, hipEventRecord(k1, c->stream));
+    if (c->col_slices > 1) {
+        uint32_t lo = 0, hi = c->num_rows;
+        if (filter >= 0) partition_rows(c, uint32_t(filter), lo, hi);
+        HS_HIP(c, hisparse::dev::launch_combine_slices(c->impl != HS_IMPL_FIXED, c->d_partial, y_target(c), c->num_rows, c->col_slices, lo, hi, c->stream));
+    }
     return HS_OK;
 }
 
@@ -217,7 +228,7 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     } catch (const std::bad_alloc&) {
         return fail(ctx, HS_ERR_NO_MEMORY, "out of host memory while re-tiling the matrix");
     }
-    const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows);
+    const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers);
     if (lds_bytes > hisparse::dev::kMaxLdsBytes) return fail(ctx, HS_ERR_UNSUPPORTED, "row block does not fit the LDS");
 
     HS_HIP(ctx, hisparse::dev::configure_spmv_kernels(lds_bytes));
@@ -233,12 +244,15 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_block_order), tiles.block_order.data(), tiles.block_order.size() * sizeof(uint32_t), 0));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
+    if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
     ctx->num_rows = num_rows;
     ctx->num_cols = num_cols;
     ctx->row_parts = num_row_partitions;
     ctx->col_parts = num_col_partitions;
     ctx->num_workgroups = tiles.num_workgroups;
     ctx->lds_bytes = lds_bytes;
+    ctx->col_slices = tiles.col_slices;
+    ctx->ring_buffers = tiles.ring_buffers;
     ctx->matrix_loaded = true;
 
     hs_stats& s = ctx->stats;
@@ -249,6 +263,8 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     s.stream_elements = tiles.elements;
     s.num_blocks = uint32_t(tiles.blocks.size());
     s.num_units = uint32_t(tiles.units.size());
+    s.col_slices = tiles.col_slices;
+    s.ring_buffers = tiles.ring_buffers;
     s.num_workgroups = tiles.num_workgroups;
     s.lds_bytes = lds_bytes;
     s.num_compute_units = uint32_t(ctx->compute_units);

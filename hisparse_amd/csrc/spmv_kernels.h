@@ -18,18 +18,22 @@ struct SpmvLaunch {
     const uint32_t* wg_first;     // num_workgroups + 1 entries into block_order
     const uint32_t* block_order;
     const uint32_t* x;            // packed vector words, num_cols
-    uint32_t* y;                  // packed result words, num_rows
+    uint32_t* out;                // packed result words: y itself (one column slice) or slices x num_rows partials
     int32_t row_part_filter;      // -1: every row partition
+    uint32_t ring_buffers;        // x sub-tile buffers in the LDS ring (2..4)
     uint32_t num_workgroups;
     uint32_t lds_bytes;
 };
 
-// Dynamic LDS a launch needs for blocks of at most `max_block_rows` rows.
-uint32_t spmv_lds_bytes(uint32_t max_block_rows);
+// Dynamic LDS a launch needs for blocks of at most `max_block_rows` rows and a ring of `ring_buffers` x buffers.
+uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers);
 // One-time per device: allow the kernels to use up to `lds_bytes` of dynamic LDS.
 hipError_t configure_spmv_kernels(uint32_t lds_bytes);
 // The SpMV kernel: row-owner workgroups, x sub-tiles double-buffered in LDS, no global atomics.
 hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream);
+// Column-sliced matrices only: y[r] = (saturating / fp32) sum of the `slices` partial vectors, rows [row_lo, row_hi).
+hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_t* y, uint32_t num_rows, uint32_t slices, uint32_t row_lo,
+                                 uint32_t row_hi, hipStream_t stream);
 
 }  // namespace dev
 }  // namespace hisparse

@@ -38,7 +38,7 @@ namespace {
 constexpr int kThreads = kWaveLanes * kWavesPerWorkgroup;       // 1024
 constexpr int kConsumerThreads = kWaveLanes * kConsumerWaves;   // 768
 constexpr int kLoaderThreads = kThreads - kConsumerThreads;     // 256
-constexpr uint32_t kXBytes = kXBuffers * kSubTileCols * 4u;     // the ring of x buffers (128 KiB)
+constexpr uint32_t kBufBytes = kSubTileCols * 4u;               // one x buffer of the LDS ring (32 KiB)
 
 // mat_val * vec_val narrowed to Q8.24: exact 64-bit product, + half LSB, >> 24, saturate (pe.h:64).
 __device__ __forceinline__ uint32_t q8_24_mul(uint32_t a, uint32_t b) {
@@ -136,13 +136,13 @@ __device__ __forceinline__ void lds_barrier() {
 // kDense: the block has few, long rows and its chunks are row-sorted (Block::flags & kBlockDenseRows).
 template <bool kFloat, int kAblate, int kDepth, bool kDense>
 __device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit* __restrict__ unit, uint32_t U, uint32_t wave, uint32_t lane,
-                                              const uint32_t* xs, typename Rows<kFloat>::acc_t* ys) {
+                                              const uint32_t* xs, uint32_t ring, typename Rows<kFloat>::acc_t* ys) {
     const uint32_t total = unit[U - 1].end_step[wave];
     const uint32_t last = total ? total - 1 : 0;   // prefetches past the end re-read the last chunk (no branch)
     uint64_t buf[kDepth];
 #pragma unroll
     for (int k = 0; k < kDepth; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kChunkBytes);
-    uint32_t u = 0, end = unit[0].end_step[wave];
+    uint32_t u = 0, slot = 0, end = unit[0].end_step[wave];   // slot = u % ring
     const uint32_t* xb = xs;
     for (uint32_t base = 0;; base += kDepth) {
 #pragma unroll
@@ -152,7 +152,8 @@ __device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit*
                 if (!(kAblate & 8)) lds_barrier();
                 if (++u == U) goto block_done;
                 end = unit[u].end_step[wave];
-                xb = xs + (u % kXBuffers) * kSubTileCols;
+                slot = slot + 1 == ring ? 0 : slot + 1;
+                xb = xs + slot * kSubTileCols;
             }
             stream_wait<kDepth - 1>(buf[k]);
             const uint32_t mat = static_cast<uint32_t>(buf[k]), cr = static_cast<uint32_t>(buf[k] >> 32);
@@ -190,11 +191,11 @@ template <bool kFloat, int kAblate, int kDepth>
 __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const Unit* __restrict__ units, const uint32_t* __restrict__ wg_first,
                                                                   const uint32_t* __restrict__ block_order, const uint32_t* __restrict__ x,
-                                                                  uint32_t* __restrict__ y, int32_t row_part_filter) {
+                                                                  uint32_t* __restrict__ out, int32_t row_part_filter, uint32_t ring) {
     using acc_t = typename Rows<kFloat>::acc_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint32_t* xs = reinterpret_cast<uint32_t*>(lds);             // [2][kSubTileCols]
-    acc_t* ys = reinterpret_cast<acc_t*>(lds + kXBytes);         // [nrows + 1]
+    uint32_t* xs = reinterpret_cast<uint32_t*>(lds);             // [ring][kSubTileCols]
+    acc_t* ys = reinterpret_cast<acc_t*>(lds + ring * kBufBytes); // [nrows + 1]
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWaveLanes - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWaveLanes);
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
     for (uint32_t q = wg_first[wg]; q < q_end; ++q) {
         const Block* blk = blocks + block_order[q];
         if (row_part_filter >= 0 && blk->row_part != static_cast<uint32_t>(row_part_filter)) continue;
-        const uint32_t nrows = blk->nrows, row0 = blk->row0;
+        const uint32_t nrows = blk->nrows, out0 = blk->out_offset;
         const Unit* unit = units + blk->unit_begin;
         const uint32_t U = blk->unit_end - blk->unit_begin;
 
@@ -220,29 +221,50 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
             if (loader) {
                 // ---- loader wavefronts: keep the ring of x buffers up to three sub-tiles ahead of the consumers ----
                 const uint32_t lw = wave - kConsumerWaves;
+                uint32_t fill_slot = 1 == ring ? 0 : 1;                // ring slot of the next refill (sub-tile v lives in slot v % ring)
                 auto refill = [&](uint32_t v) {
-                    if (!(kAblate & 4)) dma_fill_x(xs + (v % kXBuffers) * kSubTileCols, x, unit[v].col0, unit[v].ncols, lw, lane);
+                    if (!(kAblate & 4)) dma_fill_x(xs + fill_slot * kSubTileCols, x, unit[v].col0, unit[v].ncols, lw, lane);
+                    fill_slot = fill_slot + 1 == ring ? 0 : fill_slot + 1;
                 };
                 uint32_t issued = 1;                                   // sub-tile 0 was copied synchronously above
-                while (issued < U && issued < kXBuffers - 1) refill(issued++);
+                while (issued < U && issued < ring - 1) refill(issued++);
                 for (uint32_t u = 0; u < U; ++u) {
-                    // buffer (u+3) % 4 last held sub-tile u-1, which every consumer left at the previous barrier
+                    // slot (u + ring - 1) % ring last held sub-tile u-1, which every consumer left at the previous barrier
                     if (issued < U) refill(issued++);
                     // sub-tile u+1 must be resident before the consumers enter it (they do so after this barrier)
-                    const uint32_t younger = issued - min(issued, u + 2);   // refills issued after the one for u+1: 0..2
+                    const uint32_t younger = issued - min(issued, u + 2);   // refills issued after the one for u+1: 0..ring-2
                     if (younger >= 2) dma_wait<2>(); else if (younger == 1) dma_wait<1>(); else dma_wait<0>();
                     if (!(kAblate & 8)) __builtin_amdgcn_s_barrier();
                 }
             } else {
                 // ---- consumer wavefronts: stream elements, gather x, accumulate rows -----------------------------
                 const uint8_t* stream = image + blk->wave_offset[wave] + lane * 8u;
-                if (blk->flags & kBlockDenseRows) consume_block<kFloat, kAblate, kDepth, true>(stream, unit, U, wave, lane, xs, ys);
-                else consume_block<kFloat, kAblate, kDepth, false>(stream, unit, U, wave, lane, xs, ys);
+                if (blk->flags & kBlockDenseRows) consume_block<kFloat, kAblate, kDepth, true>(stream, unit, U, wave, lane, xs, ring, ys);
+                else consume_block<kFloat, kAblate, kDepth, false>(stream, unit, U, wave, lane, xs, ring, ys);
             }
         }
         // every sub-tile barrier has passed: the accumulators are final
-        for (uint32_t i = tid; i < nrows; i += kThreads) y[row0 + i] = Rows<kFloat>::finish(ys[i]);
+        for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = Rows<kFloat>::finish(ys[i]);
         __syncthreads();   // before the next block re-zeroes the accumulators
+    }
+}
+
+// Column-sliced matrices: y[r] = sum over slices of the per-slice partial results.  Fixed point: each partial is
+// already clamped to 2^32-1 and min(sum, MAX) == min(sum of min(part, MAX), MAX) for non-negative parts, so the
+// result is still exactly the saturating sum of the PE (pe.h:72).
+template <bool kFloat>
+__global__ __launch_bounds__(256) void combine_slices_kernel(const uint32_t* __restrict__ partial, uint32_t* __restrict__ y,
+                                                             uint32_t num_rows, uint32_t slices, uint32_t row_lo, uint32_t row_hi) {
+    const uint32_t r = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= row_hi) return;
+    if (kFloat) {
+        float s = 0.0f;
+        for (uint32_t k = 0; k < slices; ++k) s += __uint_as_float(partial[static_cast<size_t>(k) * num_rows + r]);
+        y[r] = __float_as_uint(s);
+    } else {
+        uint64_t s = 0;
+        for (uint32_t k = 0; k < slices; ++k) s += partial[static_cast<size_t>(k) * num_rows + r];
+        y[r] = s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s);
     }
 }
 
@@ -259,12 +281,12 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
-uint32_t spmv_lds_bytes(uint32_t max_block_rows) {
-    return kXBytes + (max_block_rows + 1) * 8u;
+uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers) {
+    return ring_buffers * kBufBytes + (max_block_rows + 1) * 8u;
 }
 
 #define HS_FOR_EACH_VARIANT(X) \
-    X(true, 0, 8) X(false, 0, 8) X(false, 0, 16) X(false, 0, 4) X(false, 1, 8) X(false, 2, 8) X(false, 3, 8) X(false, 4, 8) X(false, 8, 8) X(false, 12, 8) X(false, 15, 8) X(false, 32, 8) X(false, 64, 8) X(false, 96, 8) X(false, 36, 8) X(false, 160, 8) X(false, 288, 8)
+    X(true, 0, 8) X(false, 0, 8) X(false, 0, 16) X(false, 3, 8) X(false, 4, 8) X(false, 8, 8) X(false, 15, 8)
 
 hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
     hipError_t e;
@@ -283,12 +305,21 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(F, A, D)                                                                                                           \
     if (!launched && is_float == F && (F || (ablate == A && depth == D))) {                                                  \
         hipLaunchKernelGGL((spmv_rowblock_kernel<F, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \
-                           a.wg_first, a.block_order, a.x, a.y, a.row_part_filter);                                          \
+                           a.wg_first, a.block_order, a.x, a.out, a.row_part_filter, a.ring_buffers);                         \
         launched = true;                                                                                                     \
     }
     HS_FOR_EACH_VARIANT(X)
 #undef X
     if (!launched) return hipErrorInvalidValue;   // unknown HISPARSE_ABLATE / HISPARSE_DEPTH combination
+    return hipGetLastError();
+}
+
+hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_t* y, uint32_t num_rows, uint32_t slices, uint32_t row_lo,
+                                 uint32_t row_hi, hipStream_t stream) {
+    if (row_hi <= row_lo) return hipSuccess;
+    const dim3 grid((row_hi - row_lo + 255) / 256), block(256);
+    if (is_float) hipLaunchKernelGGL(combine_slices_kernel<true>, grid, block, 0, stream, partial, y, num_rows, slices, row_lo, row_hi);
+    else hipLaunchKernelGGL(combine_slices_kernel<false>, grid, block, 0, stream, partial, y, num_rows, slices, row_lo, row_hi);
     return hipGetLastError();
 }
 

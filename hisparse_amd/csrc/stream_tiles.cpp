@@ -160,59 +160,78 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         out.nnz += r.nnz;
     }
 
-    // ---- row blocks: equal non-zero count, <= kMaxBlockRows rows, never across a row partition -------
+    // ---- column slices: trade x broadcast (every workgroup pulls its slice of x through its CU at ~120 GB/s) against
+    //      the combine pass (one more small kernel reading `slices` partial vectors) --------------------------------
     const uint32_t G = std::max<uint32_t>(1, max_workgroups);
-    const uint64_t want_blocks = std::max<uint64_t>(1, std::min<uint64_t>(G, out.nnz / 4096));
-    const uint64_t target = std::max<uint64_t>(1, (out.nnz + want_blocks - 1) / want_blocks);
-    std::vector<uint64_t> block_nnz;
+    uint32_t slices = 1;
+    {
+        const char* force = std::getenv("HISPARSE_COL_SLICES");
+        double best = 1e30;
+        for (uint32_t cs = 1; cs <= kMaxColSlices; cs *= 2) {
+            if (force && uint32_t(std::atoi(force)) != cs) continue;
+            if (cs > 1 && uint64_t(CP) * S < cs) continue;                                    // fewer sub-tiles than slices
+            const uint32_t cap = cs > 1 ? kMaxSlicedBlockRows : kMaxBlockRows;
+            const uint64_t ranges_est = std::max<uint64_t>((G + cs - 1) / cs, (uint64_t(num_rows) + cap - 1) / cap);
+            // every row range pulls all of x (split over its slices) through the CUs that own it
+            const double fill_us = double(ranges_est) * double(num_cols) * 4.0 / double(G) / 120e3;   // bytes / (120 GB/s) in us
+            const double combine_us = cs > 1 ? 3.5 + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
+            if (fill_us + combine_us < best) { best = fill_us + combine_us; slices = cs; }
+        }
+    }
+    out.col_slices = slices;
+    const uint32_t max_rows = slices > 1 ? kMaxSlicedBlockRows : kMaxBlockRows;
+
+    // ---- row ranges: equal non-zero count, <= max_rows rows, never across a row partition ---------------------------
+    struct Range { uint32_t row0, nrows, row_part; };
+    std::vector<Range> ranges;
+    std::vector<uint64_t> range_nnz;
+    const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint32_t>(1, G / slices), out.nnz / 4096));
+    const uint64_t target = std::max<uint64_t>(1, (out.nnz + want_ranges - 1) / want_ranges);
     for (uint32_t rp = 0; rp < RP; ++rp) {
         const uint32_t lo = uint32_t(uint64_t(rp) * geom.logical_ob), hi = lo + L.rows_in_part(rp);
         uint32_t r0 = lo;
         uint64_t acc = 0;
         for (uint32_t r = lo; r < hi; ++r) {
-            // close the block BEFORE a row that would overshoot the target by more than the block undershoots now
+            // close the range BEFORE a row that would overshoot the target by more than the range undershoots now
             const uint64_t with = acc + row_nnz[r];
-            if (r > r0 && (r - r0 == kMaxBlockRows || (with > target && with - target > target - std::min(acc, target)))) {
-                Block b{};
-                b.row0 = r0; b.nrows = r - r0; b.row_part = rp;
-                out.blocks.push_back(b);
-                block_nnz.push_back(acc);
+            if (r > r0 && (r - r0 == max_rows || (with > target && with - target > target - std::min(acc, target)))) {
+                ranges.push_back(Range{r0, r - r0, rp});
+                range_nnz.push_back(acc);
                 r0 = r;
                 acc = 0;
             }
             acc += row_nnz[r];
         }
         if (hi > r0) {
-            Block b{};
-            b.row0 = r0; b.nrows = hi - r0; b.row_part = rp;
-            out.blocks.push_back(b);
-            block_nnz.push_back(acc);
+            ranges.push_back(Range{r0, hi - r0, rp});
+            range_nnz.push_back(acc);
         }
     }
-    const uint32_t NB = uint32_t(out.blocks.size());
-    std::vector<uint32_t> block_of_row(num_rows);
-    for (uint32_t b = 0; b < NB; ++b) {
-        std::fill(block_of_row.begin() + out.blocks[b].row0, block_of_row.begin() + out.blocks[b].row0 + out.blocks[b].nrows, b);
-        out.max_block_rows = std::max(out.max_block_rows, out.blocks[b].nrows);
+    const uint32_t NR = uint32_t(ranges.size());
+    std::vector<uint32_t> block_of_row(num_rows);   // row -> row range
+    for (uint32_t b = 0; b < NR; ++b) {
+        std::fill(block_of_row.begin() + ranges[b].row0, block_of_row.begin() + ranges[b].row0 + ranges[b].nrows, b);
+        out.max_block_rows = std::max(out.max_block_rows, ranges[b].nrows);
     }
+    const uint32_t ring_fit = (kMaxLdsBytes - (out.max_block_rows + 1) * 8u) / (kSubTileCols * 4u);
+    out.ring_buffers = std::max(kMinXBuffers, std::min(kMaxXBuffers, ring_fit));
 
     // dense-row blocks additionally count per (sub-tile, row): their units are stored sorted by row
-    std::vector<size_t> dense_base(NB, SIZE_MAX);
+    std::vector<size_t> dense_base(NR, SIZE_MAX);
     size_t dense_total = 0;
-    for (uint32_t b = 0; b < NB; ++b)
-        if (out.blocks[b].nrows <= kDenseBlockRows && block_nnz[b] >= 64ull * out.blocks[b].nrows) {
-            out.blocks[b].flags |= kBlockDenseRows;
+    for (uint32_t b = 0; b < NR; ++b)
+        if (ranges[b].nrows <= kDenseBlockRows && range_nnz[b] >= 64ull * ranges[b].nrows) {
             dense_base[b] = dense_total;
-            dense_total += size_t(CP) * S * out.blocks[b].nrows;
+            dense_total += size_t(CP) * S * ranges[b].nrows;
         }
     std::vector<uint32_t> dense_cnt(dense_total, 0);
     auto dense_slot = [&](uint32_t b, uint32_t cp, uint32_t s, uint32_t local_row) {
-        return dense_base[b] + (size_t(cp) * S + s) * out.blocks[b].nrows + local_row;
+        return dense_base[b] + (size_t(cp) * S + s) * ranges[b].nrows + local_row;
     };
 
     // ---- pass 1: elements per (block, column partition, sub-tile, source channel) -------------------
     const size_t slots_per_block = size_t(CP) * S * NUM_HBM_CHANNELS;
-    std::vector<uint32_t> cnt(size_t(NB) * slots_per_block, 0);
+    std::vector<uint32_t> cnt(size_t(NR) * slots_per_block, 0);
     auto slot = [&](uint32_t b, uint32_t cp, uint32_t s, uint32_t pc) { return size_t(b) * slots_per_block + (size_t(cp) * S + s) * NUM_HBM_CHANNELS + pc; };
     std::vector<WalkResult> res1(size_t(RP) * CP * NUM_HBM_CHANNELS);
     parallel_for(res1.size(), [&](size_t w) {
@@ -220,7 +239,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         res1[w] = walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t) {
             const uint32_t b = block_of_row[row], s = col / L.sub_width;
             cnt[slot(b, cp, s, pc)]++;
-            if (dense_base[b] != SIZE_MAX) dense_cnt[dense_slot(b, cp, s, row - out.blocks[b].row0)]++;   // a row belongs to one channel: no race
+            if (dense_base[b] != SIZE_MAX) dense_cnt[dense_slot(b, cp, s, row - ranges[b].row0)]++;   // a row belongs to one channel: no race
         });
     });
     for (const auto& r : res1)
@@ -229,20 +248,28 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     // ---- plan units and wavefront streams ---------------------------------------------------------------
     const bool rotate = [] { const char* e = std::getenv("HISPARSE_ROTATE"); return e ? std::atoi(e) != 0 : false; }();
     std::vector<UnitPlan> plans;
-    std::vector<uint32_t> unit_of(size_t(NB) * CP * S, 0xffffffffu);  // (block, cp, s) -> unit index
+    std::vector<uint32_t> unit_of(size_t(NR) * CP * S, 0xffffffffu);  // (row range, cp, s) -> unit index
+    std::vector<uint64_t> block_nnz;
     uint64_t image_bytes = 0;
-    for (uint32_t b = 0; b < NB; ++b) {
-        Block& blk = out.blocks[b];
-        blk.unit_begin = uint32_t(out.units.size());
-        uint32_t pos[kConsumerWaves] = {0};   // stream position of every wavefront, in steps
-        uint32_t chunk_counter = 0;
-        // HISPARSE_ROTATE=1 (experiment, off by default: measured neutral) starts every block at a different sub-tile so
-        // the workgroups of one XCD pull different parts of x out of their shared L2 at any one time.
-        const uint32_t slots = CP * S;
-        const uint32_t rot = rotate ? uint32_t((uint64_t(b) * 0x9e3779b1u) % slots) : 0u;
-        for (uint32_t k = 0; k < slots; ++k) {
-            {
-                const uint32_t cp = ((k + rot) % slots) / S, s = ((k + rot) % slots) % S;
+    const uint32_t sub_tiles = CP * S;
+    for (uint32_t b = 0; b < NR; ++b) {
+        for (uint32_t slice = 0; slice < slices; ++slice) {   // device block index = b * slices + slice
+            Block blk{};
+            blk.row0 = ranges[b].row0;
+            blk.nrows = ranges[b].nrows;
+            blk.row_part = ranges[b].row_part;
+            blk.flags = dense_base[b] != SIZE_MAX ? kBlockDenseRows : 0u;
+            blk.out_offset = slices > 1 ? slice * num_rows + ranges[b].row0 : ranges[b].row0;
+            blk.unit_begin = uint32_t(out.units.size());
+            uint32_t pos[kConsumerWaves] = {0};   // stream position of every wavefront, in steps
+            uint32_t chunk_counter = 0;
+            uint64_t elems = 0;
+            // HISPARSE_ROTATE=1 (experiment, off by default: measured neutral) starts every block at a different sub-tile
+            const uint32_t rot = rotate ? uint32_t((uint64_t(b) * 0x9e3779b1u) % sub_tiles) : 0u;
+            for (uint32_t k0 = 0; k0 < sub_tiles; ++k0) {
+                const uint32_t k = (k0 + rot) % sub_tiles;
+                if (k % slices != slice) continue;                    // sub-tiles are dealt round-robin to the column slices
+                const uint32_t cp = k / S, s = k % S;
                 uint64_t n = 0;
                 for (uint32_t pc = 0; pc < NUM_HBM_CHANNELS; ++pc) {   // counts -> exclusive offsets inside the unit
                     const uint32_t c = cnt[slot(b, cp, s, pc)];
@@ -276,14 +303,18 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 out.units.push_back(u);
                 plans.push_back(up);
                 out.elements += uint64_t(up.chunks) * kWaveLanes;
+                elems += n;
             }
-        }
-        blk.unit_end = uint32_t(out.units.size());
-        for (uint32_t w = 0; w < kConsumerWaves; ++w) {
-            blk.wave_offset[w] = image_bytes;
-            image_bytes += uint64_t(pos[w]) * kChunkBytes;
+            blk.unit_end = uint32_t(out.units.size());
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+                blk.wave_offset[w] = image_bytes;
+                image_bytes += uint64_t(pos[w]) * kChunkBytes;
+            }
+            out.blocks.push_back(blk);
+            block_nnz.push_back(elems);
         }
     }
+    const uint32_t NB = uint32_t(out.blocks.size());
 
     // ---- workgroups: longest-processing-time assignment of blocks ------------------------------------------
     {
@@ -324,7 +355,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP), rp = uint32_t(w / NUM_HBM_CHANNELS / CP);
         walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t val) {
             const uint32_t b = block_of_row[row], s = col / L.sub_width;
-            const Block& blk = out.blocks[b];
+            const Block& blk = out.blocks[size_t(b) * slices + (cp * S + s) % slices];
             const UnitPlan& up = plans[unit_of[(size_t(b) * CP + cp) * S + s]];
             const uint64_t i = up.dense ? dense_cnt[up.row_cursor + (row - blk.row0)]++ : cnt[slot(b, cp, s, pc)]++;
             uint32_t* e = reinterpret_cast<uint32_t*>(element_address(blk, up, i));

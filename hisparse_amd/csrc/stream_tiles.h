@@ -19,6 +19,10 @@
 //   * rows are split into row blocks of roughly equal non-zero count (never across a row partition);
 //   * the non-zeros of a block are grouped into UNITS, one per x sub-tile that the block touches
 //     (a sub-tile is a <= 8192-column slice of one column partition);
+//   * when x is large relative to the work per workgroup, the columns are additionally cut into 2-8
+//     COLUMN SLICES (sub-tiles dealt round-robin): a block is then (row range, slice), row ranges get
+//     proportionally longer, every workgroup pulls only 1/slices of x through its CU, and a small
+//     combine pass adds the per-slice partial results (saturating sums compose: DESIGN.md §4);
 //   * a unit's elements are dealt to the 12 consumer wavefronts of the workgroup in chunks of 64,
 //     each wavefront's chunks forming one contiguous stream through all units of the block.  Normally
 //     lane l of chunk c takes element l*chunks + c (neighbouring lanes far apart: no same-row LDS
@@ -45,8 +49,11 @@ constexpr uint32_t kWavesPerWorkgroup = 16;                   // 1024 threads: o
 constexpr uint32_t kConsumerWaves = 12;                       // stream elements, gather x, accumulate rows
 constexpr uint32_t kLoaderWaves = kWavesPerWorkgroup - kConsumerWaves;  // refill the idle x buffer
 constexpr uint32_t kSubTileCols = 8192;                       // 32 KiB of x per LDS buffer ...
-constexpr uint32_t kXBuffers = 4;                             // ... in a ring of four: refills run three sub-tiles ahead
-constexpr uint32_t kMaxBlockRows = 4095;                      // + 1 scratch slot = 32 KiB of 64-bit row accumulators
+constexpr uint32_t kMaxXBuffers = 4;                          // ... in a ring of up to four: refills run up to three sub-tiles ahead
+constexpr uint32_t kMinXBuffers = 2;
+constexpr uint32_t kMaxBlockRows = 4095;                      // one column slice: + 1 scratch slot = 32 KiB of 64-bit accumulators, ring of 4
+constexpr uint32_t kMaxSlicedBlockRows = 12287;               // several column slices: 96 KiB of accumulators, ring of 2
+constexpr uint32_t kMaxColSlices = 8;
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
@@ -60,6 +67,8 @@ struct Block {
     uint32_t unit_begin;    // units [unit_begin, unit_end), consumed in this order
     uint32_t unit_end;
     uint32_t flags;         // kBlockDenseRows: few long rows; chunks are row-sorted and mostly hold ONE row
+    uint32_t out_offset;    // word offset of the block's first row in the output: y (one slice) or the per-slice partials
+    uint32_t reserved;
     uint64_t wave_offset[kConsumerWaves];   // byte offset of each consumer wavefront's stream in the image
 };
 struct Unit {
@@ -67,7 +76,7 @@ struct Unit {
     uint32_t ncols;         // multiple of 8, <= kSubTileCols
     uint32_t end_step[kConsumerWaves];      // per wavefront: its stream position (in steps) after this unit
 };
-static_assert(sizeof(Block) == 24 + 8 * kConsumerWaves, "Block layout is shared with the device code");
+static_assert(sizeof(Block) == 32 + 8 * kConsumerWaves, "Block layout is shared with the device code");
 static_assert(sizeof(Unit) == 8 + 4 * kConsumerWaves, "Unit layout is shared with the device code");
 
 struct StreamTiles {
@@ -78,6 +87,8 @@ struct StreamTiles {
     std::vector<uint32_t> block_order;
     uint32_t num_workgroups = 0;
     uint32_t max_block_rows = 0;
+    uint32_t col_slices = 1;             // > 1: blocks write per-slice partial results, a combine pass adds them
+    uint32_t ring_buffers = kMaxXBuffers;
     uint64_t nnz = 0;
     uint64_t elements = 0;               // element slots including chunk padding
 };

@@ -68,6 +68,8 @@ typedef struct {
     uint32_t num_workgroups;    /* grid size of the SpMV kernel */
     uint32_t lds_bytes;         /* dynamic LDS per workgroup (two x sub-tile buffers + row accumulators) */
     uint32_t num_compute_units; /* of the device */
+    uint32_t col_slices;        /* column slices (1 = none; > 1 adds the small combine pass) */
+    uint32_t ring_buffers;      /* x sub-tile buffers in the LDS ring */
     double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
 } hs_stats;
 
@@ -125,8 +127,8 @@ int hs_tiles_build(const void* const channel[HS_NUM_CHANNELS], const uint64_t n_
                    uint32_t vb_bank, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
                    uint32_t num_col_partitions, uint32_t max_workgroups, hs_tiles** out);
 int hs_tiles_info(const hs_tiles* t, uint64_t* image_bytes, uint32_t* num_blocks, uint32_t* num_units, uint32_t* num_workgroups,
-                  uint32_t* max_block_rows, uint64_t* nnz, uint64_t* elements);
-/* image: image_bytes; blocks: num_blocks x 120 B; units: num_units x 56 B (layouts: hisparse_amd/csrc/stream_tiles.h);
+                  uint32_t* max_block_rows, uint64_t* nnz, uint64_t* elements, uint32_t* col_slices, uint32_t* ring_buffers);
+/* image: image_bytes; blocks: num_blocks x 128 B; units: num_units x 56 B (layouts: hisparse_amd/csrc/stream_tiles.h);
  * wg_first: num_workgroups + 1; block_order: num_blocks */
 int hs_tiles_copy(const hs_tiles* t, void* image, void* blocks, void* units, uint32_t* wg_first, uint32_t* block_order);
 void hs_tiles_free(hs_tiles* t);

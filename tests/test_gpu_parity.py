@@ -88,6 +88,21 @@ def test_dense_row_blocks(impl):
     _run_case(impl, m, vb=v, ob=o, skip=True, seed=13)
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("slices", [2, 4, 8])
+def test_column_slices(impl, slices, monkeypatch):
+    # force the 2-D (row range x column slice) decomposition + combine pass on a matrix small enough for the oracle
+    monkeypatch.setenv("HISPARSE_COL_SLICES", str(slices))
+    csr = host.CSRMatrix.generate("powerlaw", 30000, 70000, a=900000, b=0.4, c=1.0 if impl == 0 else 2.0, seed=17)
+    ip, ix, dv = csr.arrays()
+    if impl != 0:
+        dv = (dv - 1.0).astype(np.float32)
+    import scipy.sparse as sp
+    m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(30000, 70000))
+    v, o = host.default_banks(impl)
+    _run_case(impl, m, vb=v, ob=o, skip=True, seed=17)
+
+
 def test_fixed_rounding_and_saturation():
     # values/x chosen so products need AP_RND and rows overflow AP_SAT (sum >= 256 => 0xffffffff)
     rng = np.random.default_rng(3)

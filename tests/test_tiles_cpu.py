@@ -45,8 +45,10 @@ def test_structure_invariants():
     t = build(cp, 0, 64)
     blocks, units = t["blocks"], t["units"]
     # blocks tile the rows exactly, in order, within the LDS budget, never across a row partition
+    assert t["col_slices"] == 1 and t["ring_buffers"] == 4
     assert blocks["row0"][0] == 0 and (blocks["row0"][1:] == blocks["row0"][:-1] + blocks["nrows"][:-1]).all()
     assert blocks["row0"][-1] + blocks["nrows"][-1] == cp.num_rows
+    assert (blocks["out_offset"] == blocks["row0"]).all()
     assert blocks["nrows"].max() <= 4095 and t["max_block_rows"] == blocks["nrows"].max()
     # every block is owned by exactly one workgroup
     assert sorted(t["block_order"].tolist()) == list(range(len(blocks)))
@@ -66,6 +68,29 @@ def test_structure_invariants():
         bs = t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]
         loads.append(sum(int(units["end_step"][blocks[b]["unit_end"] - 1].sum()) if blocks[b]["unit_end"] > blocks[b]["unit_begin"] else 0 for b in bs))
     assert max(loads) < 1.5 * (sum(loads) / len(loads)) + 64
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("slices", [2, 4])
+def test_column_slices(impl, slices, monkeypatch):
+    # 2-D decomposition: (row range x column slice) blocks writing per-slice partials + combine pass
+    monkeypatch.setenv("HISPARSE_COL_SLICES", str(slices))
+    csr = host.CSRMatrix.generate("powerlaw", 20000, 60000, a=300000, b=0.4, c=1.0 if impl == 0 else 2.0, seed=11)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 3, impl))
+    t = build(cp, impl, 32)
+    assert t["col_slices"] == slices and t["nnz"] == cp.nnz
+    blocks, units = t["blocks"], t["units"]
+    assert len(blocks) % slices == 0 and blocks["nrows"].max() <= 12287
+    # the slices of one row range own disjoint sub-tiles: sub-tile index mod slices == slice
+    for b in range(0, len(blocks), slices):
+        for k in range(slices):
+            u = units[blocks[b + k]["unit_begin"]:blocks[b + k]["unit_end"]]
+            assert ((u["col0"] // 8192) % slices == k).all()
+            assert blocks[b + k]["out_offset"] == k * cp.num_rows + blocks[b]["row0"]
+    got = tile_emulator.run(t, impl, xw, cp.num_rows)
+    want = oracle_y(cp, impl, xw)
+    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
 
 
 def test_many_row_partitions_and_partition_filter():

@@ -19,6 +19,9 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
     is_float = impl != 0
     image, blocks, units = tiles["image"], tiles["blocks"], tiles["units"]
     y = np.zeros(num_rows, dtype=np.uint32) if y_init is None else y_init.copy()
+    slices = int(tiles.get("col_slices", 1))
+    out = y if slices == 1 else np.zeros(slices * num_rows, dtype=np.uint32)   # per-slice partial results
+    touched = np.zeros(num_rows, dtype=bool)
     done = np.zeros(len(blocks), dtype=bool)
     for g in range(tiles["num_workgroups"]):
         for q in range(tiles["wg_first"][g], tiles["wg_first"][g + 1]):
@@ -28,8 +31,11 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
             blk = blocks[b]
             if row_part_filter >= 0 and int(blk["row_part"]) != row_part_filter:
                 continue
-            nrows, row0 = int(blk["nrows"]), int(blk["row0"])
-            assert nrows <= 4095
+            nrows, row0, out0 = int(blk["nrows"]), int(blk["row0"]), int(blk["out_offset"])
+            assert nrows <= (4095 if slices == 1 else 12287)
+            assert out0 % num_rows == row0 and out0 // num_rows < slices
+            assert (4 if slices == 1 else 2) <= tiles["ring_buffers"] <= 4 or slices > 1
+            touched[row0: row0 + nrows] = True
             ys = np.zeros(nrows + 1, dtype=np.float32 if is_float else np.uint64)
             pos = [0] * CONSUMERS
             for u in range(int(blk["unit_begin"]), int(blk["unit_end"])):
@@ -52,8 +58,17 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
                             np.add.at(ys, row, _q_mul(val, xv))
                     pos[w] = end
             if is_float:
-                y[row0: row0 + nrows] = ys[:nrows].view(np.uint32)
+                out[out0: out0 + nrows] = ys[:nrows].view(np.uint32)
             else:
-                y[row0: row0 + nrows] = np.minimum(ys[:nrows], np.uint64(0xFFFFFFFF)).astype(np.uint32)
+                out[out0: out0 + nrows] = np.minimum(ys[:nrows], np.uint64(0xFFFFFFFF)).astype(np.uint32)
     assert done.all()
+    if slices > 1:   # combine_slices_kernel
+        parts = out.reshape(slices, num_rows)[:, touched]
+        if is_float:
+            acc = np.zeros(parts.shape[1], dtype=np.float32)
+            for k in range(slices):
+                acc = (acc + parts[k].view(np.float32)).astype(np.float32)
+            y[touched] = acc.view(np.uint32)
+        else:
+            y[touched] = np.minimum(parts.astype(np.uint64).sum(axis=0), np.uint64(0xFFFFFFFF)).astype(np.uint32)
     return y
