@@ -46,7 +46,7 @@ namespace dev {
 
 constexpr uint32_t kWaveLanes = 64;
 constexpr uint32_t kWavesPerWorkgroup = 16;                   // 1024 threads: one workgroup per CU
-constexpr uint32_t kConsumerWaves = 12;                       // stream elements, gather x, accumulate rows
+constexpr uint32_t kConsumerWaves = 14;                       // stream elements, gather x, accumulate rows
 constexpr uint32_t kLoaderWaves = kWavesPerWorkgroup - kConsumerWaves;  // refill the idle x buffer
 constexpr uint32_t kSubTileCols = 8192;                       // 32 KiB of x per LDS buffer ...
 constexpr uint32_t kMaxXBuffers = 4;                          // ... in a ring of up to four: refills run up to three sub-tiles ahead

@@ -38,7 +38,7 @@ class Stats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
-CONSUMER_WAVES = 12
+CONSUMER_WAVES = 14
 # device-side descriptors (hisparse_amd/csrc/stream_tiles.h)
 BLOCK_DTYPE = np.dtype([("row0", "<u4"), ("nrows", "<u4"), ("row_part", "<u4"), ("unit_begin", "<u4"), ("unit_end", "<u4"),
                         ("flags", "<u4"), ("out_offset", "<u4"), ("reserved", "<u4"), ("wave_offset", "<u8", (CONSUMER_WAVES,))])

@@ -5,7 +5,7 @@ kernel's element semantics against the oracle without a GPU.  Never imported by 
 """
 import numpy as np
 
-WAVE, CONSUMERS, CHUNK_BYTES, SUB_TILE = 64, 12, 512, 8192
+WAVE, CONSUMERS, CHUNK_BYTES, SUB_TILE = 64, 14, 512, 8192
 
 
 def _q_mul(a, b):
