@@ -130,30 +130,46 @@ def main():
 
     # ---- distributed plumbing: y slab inside an all-gather buffer -------------------------------------
     gather = dist_mode and not args.no_gather
-    y_chunk = gathered = None
+    y_chunks = gathered = None
+    pending = [None, None]
     if dist_mode:
         rows_all = [None] * world
         dist.all_gather_object(rows_all, packets.num_rows)
         chunk = max(rows_all)
-        y_chunk = torch.zeros(chunk, dtype=torch.int32, device=f"cuda:{local_rank}")
-        gathered = torch.zeros(chunk * world, dtype=torch.int32, device=f"cuda:{local_rank}")
-        eng.bind_device_result(y_chunk.data_ptr())
+        dev = f"cuda:{local_rank}"
+        # two y slabs / gather buffers: the all-gather of step k runs on RCCL's stream while step k+1 computes
+        y_chunks = [torch.zeros(chunk, dtype=torch.int32, device=dev) for _ in range(2)]
+        gathered = [torch.zeros(chunk * world, dtype=torch.int32, device=dev) for _ in range(2)]
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    step_no = [0]
 
     def step():
+        if not dist_mode:
+            eng.run()
+            return
+        cur = step_no[0] & 1
+        step_no[0] += 1
+        if pending[cur] is not None:
+            pending[cur].wait()              # the gather that read this slab two steps ago (stream-level wait, no host sync)
+            pending[cur] = None
+        eng.bind_device_result(y_chunks[cur].data_ptr())
         eng.run()
         if gather:
-            dist.all_gather_into_tensor(gathered, y_chunk)
+            pending[cur] = dist.all_gather_into_tensor(gathered[cur], y_chunks[cur], async_op=True)
 
     def sync():
-        eng.sync()
         if dist_mode:
+            for i in (0, 1):
+                if pending[i] is not None:
+                    pending[i].wait()
+                    pending[i] = None
             torch.cuda.synchronize()
+        eng.sync()
 
     # ---- correctness of what is about to be timed (and the CPU baseline) --------------------------------
     step()
     sync()
-    y_gpu = eng.read_result() if not dist_mode else y_chunk[:packets.num_rows].cpu().numpy().view(np.uint32)
+    y_gpu = eng.read_result() if not dist_mode else y_chunks[0][:packets.num_rows].cpu().numpy().view(np.uint32)
     cpu_baseline = None
     parity = "unchecked"
     if rank == 0 and not args.no_cpu_baseline:

@@ -142,6 +142,9 @@ __device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit*
     uint64_t buf[kDepth];
 #pragma unroll
     for (int k = 0; k < kDepth; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kChunkBytes);
+    constexpr uint32_t kNoRow = 0xffffffffu;
+    uint32_t run_row = kNoRow;                      // kDense: row whose products are being summed in registers
+    typename Rows<kFloat>::prod_t run_sum = 0;      // kDense: this lane's share of that sum
     uint32_t u = 0, slot = 0, end = unit[0].end_step[wave];   // slot = u % ring
     const uint32_t* xb = xs;
     for (uint32_t base = 0;; base += kDepth) {
@@ -149,6 +152,11 @@ __device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit*
         for (int k = 0; k < kDepth; ++k) {
             const uint32_t s = base + k;
             while (s == end) {                 // this wavefront finished sub-tile u (possibly with no work in it)
+                if (kDense && u + 1 == U && run_row != kNoRow) {   // last sub-tile: hand the register sum over before the final barrier
+                    const typename Rows<kFloat>::prod_t sum = wave_sum(run_sum);
+                    if (lane == 0) Rows<kFloat>::add(ys, run_row, sum);
+                    run_row = kNoRow;
+                }
                 if (!(kAblate & 8)) lds_barrier();
                 if (++u == U) goto block_done;
                 end = unit[u].end_step[wave];
@@ -164,14 +172,21 @@ __device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit*
                 const typename Rows<kFloat>::prod_t prod = Rows<kFloat>::product(mat, xv);
                 const uint32_t row = cr >> 16;
                 if (kDense) {
-                    // chunks are row-sorted, so the whole wavefront is usually on ONE accumulator: add the 64 products in
-                    // registers instead of issuing a 64-way conflicting LDS atomic
+                    // Chunks are row-sorted, so the whole wavefront is usually on ONE row, and stays on it for many chunks:
+                    // keep a per-lane running sum in registers while the row does not change and touch the LDS accumulator
+                    // only when it does (one wave_sum + one ds_add per row per wavefront instead of a 64-way conflicting
+                    // atomic per chunk).
                     const uint32_t row0 = __builtin_amdgcn_readfirstlane(row);
-                    if (__ballot(row == row0) == ~0ull) {
-                        const typename Rows<kFloat>::prod_t sum = wave_sum(prod);
-                        if (lane == 0) Rows<kFloat>::add(ys, row0, sum);
+                    const bool uniform = __ballot(row == row0) == ~0ull;
+                    if (uniform && row0 == run_row) {
+                        run_sum += prod;
                     } else {
-                        Rows<kFloat>::add(ys, row, prod);
+                        if (run_row != kNoRow) {
+                            const typename Rows<kFloat>::prod_t sum = wave_sum(run_sum);
+                            if (lane == 0) Rows<kFloat>::add(ys, run_row, sum);
+                        }
+                        if (uniform) { run_row = row0; run_sum = prod; }
+                        else { run_row = kNoRow; run_sum = 0; Rows<kFloat>::add(ys, row, prod); }   // chunk straddles rows
                     }
                 } else {
                     Rows<kFloat>::add(ys, row, prod);

@@ -139,6 +139,27 @@ def test_run_partition_matches_run():
     assert np.array_equal(full, stepped)
 
 
+def test_run_partition_with_column_slices(monkeypatch):
+    # per-partition stepping must also combine only that partition's rows when the matrix is column-sliced
+    monkeypatch.setenv("HISPARSE_COL_SLICES", "2")
+    impl = 1
+    m = cases.random_csr(2500, 300, 0.03, 23, impl)
+    csr, cp = cases.formatted(m, impl, 4, 1, True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 23, impl))
+    want = orc.spmv(impl, [cp.channel(c) for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, 1, 4)
+    eng = device.SpmvEngine(impl, ob_bank=1, vb_bank=4)
+    eng.load_matrix(cp)
+    assert eng.stats()["col_slices"] == 2
+    eng.load_vector(xw)
+    for j in reversed(range(cp.num_row_partitions)):
+        eng.run_partition(j, cp.part_len(j))
+    stepped = eng.read_result()
+    eng.run()
+    full = eng.read_result()
+    eng.close()
+    assert cases.float_close(stepped, want) and cases.float_close(full, want)
+
+
 def test_empty_rows_and_empty_matrix_rows():
     # rows with no entries at all, an all-empty column partition, and skip counts > 1
     import scipy.sparse as sp
