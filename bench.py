@@ -140,7 +140,12 @@ def main():
         # two y slabs / gather buffers: the all-gather of step k runs on RCCL's stream while step k+1 computes
         y_chunks = [torch.zeros(chunk, dtype=torch.int32, device=dev) for _ in range(2)]
         gathered = [torch.zeros(chunk * world, dtype=torch.int32, device=dev) for _ in range(2)]
-        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        # one explicit (non-default) stream for both the SpMV kernels and the point RCCL synchronises against: the legacy
+        # default stream has handle 0, which hs_set_stream reads as "use the library's private stream"
+        main_stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(main_stream)
+        torch.cuda.synchronize()
+        eng.set_stream(main_stream.cuda_stream)
     step_no = [0]
 
     def step():
@@ -170,6 +175,11 @@ def main():
     step()
     sync()
     y_gpu = eng.read_result() if not dist_mode else y_chunks[0][:packets.num_rows].cpu().numpy().view(np.uint32)
+    if gather:   # the gathered buffer must hold this rank's slab at its offset (kernel -> RCCL ordering on the shared stream)
+        mine = gathered[0][rank * y_chunks[0].numel(): rank * y_chunks[0].numel() + packets.num_rows].cpu().numpy().view(np.uint32)
+        if not np.array_equal(mine, y_gpu):
+            print(json.dumps({"error": "all-gathered y differs from the local slab", "rank": rank}))
+            sys.exit(1)
     cpu_baseline = None
     parity = "unchecked"
     if rank == 0 and not args.no_cpu_baseline:
@@ -230,6 +240,7 @@ def main():
     if dist_mode:
         dist.barrier()
 
+    out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = 8.0 * total_nnz / (elapsed / args.steps) / 1e9
@@ -255,10 +266,19 @@ def main():
             "parity_vs_oracle": parity,
             "preprocess_s": {"format_csr2cpsr": round(t_fmt, 3), "device_load_retile": round(stats["load_seconds"], 3)},
         }
-        print(json.dumps(out), flush=True)
     eng.close()
     if dist_mode:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to the C stdout buffer; flush it first so that the JSON line is the LAST line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

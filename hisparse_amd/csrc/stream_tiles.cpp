@@ -185,7 +185,11 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     struct Range { uint32_t row0, nrows, row_part; };
     std::vector<Range> ranges;
     std::vector<uint64_t> range_nnz;
-    const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint32_t>(1, G / slices), out.nnz / 4096));
+    // as many ranges as workgroup slots (G / slices), or the next multiple of that when the LDS row cap forces more, so that
+    // every workgroup ends up with the same number of blocks
+    const uint64_t per_round = std::max<uint32_t>(1, G / slices);
+    const uint64_t rounds = std::max<uint64_t>(1, ((uint64_t(num_rows) + max_rows - 1) / max_rows + per_round - 1) / per_round);
+    const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(per_round * rounds, out.nnz / 4096));
     const uint64_t target = std::max<uint64_t>(1, (out.nnz + want_ranges - 1) / want_ranges);
     for (uint32_t rp = 0; rp < RP; ++rp) {
         const uint32_t lo = uint32_t(uint64_t(rp) * geom.logical_ob), hi = lo + L.rows_in_part(rp);
