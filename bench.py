@@ -202,6 +202,21 @@ def main():
         cpu_baseline = {"value": round(8.0 * nnz / t_cpu / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
                         "sample": f"{reps} full SpMV(s) of the same matrix through oracle/cpu_ref.c (csim-equivalent restatement, 1 thread), {t_cpu*1e3:.1f} ms each",
                         "gops": round(2.0 * nnz / t_cpu / 1e9, 4), "host_cpus": os.cpu_count()}
+        # context only: plain float32 CSR loop (compute_ref, csim.cpp:143-158) with OpenMP over every host core
+        try:
+            ip, ix, dv = csr.arrays()
+            xf = np.ascontiguousarray(x, dtype=np.float32)
+            yref = np.zeros(packets.num_rows, dtype=np.float32)
+            orc.compute_ref_parallel(packets.num_rows, ip, ix, dv, xf, out=yref)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                orc.compute_ref_parallel(packets.num_rows, ip, ix, dv, xf, out=yref)
+            t_omp = (time.perf_counter() - t0) / 5
+            cpu_baseline["csr_openmp_all_cores"] = {"value": round(8.0 * nnz / t_omp / 1e9, 3), "unit": "GB/s", "cores": os.cpu_count(),
+                                                    "gops": round(2.0 * nnz / t_omp / 1e9, 3), "sample": f"5 float32 CSR SpMVs, {t_omp*1e3:.2f} ms each"}
+            del ip, ix, dv
+        except Exception as e:  # the context number must never break the bench line
+            log(rank, f"csr_openmp baseline skipped: {e}")
         log(rank, f"oracle: {t_cpu*1e3:.1f} ms per SpMV on 1 core; GPU result {parity}")
         if parity == "MISMATCH":
             print(json.dumps({"error": "GPU result does not match the oracle", "config": args.config}))

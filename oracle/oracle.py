@@ -39,6 +39,8 @@ def lib():
         l.oracle_spmv.argtypes = [C.c_int, vpp, u32p, u32p, u32, u32, u32, u32, u32, u32]
         l.oracle_compute_ref.argtypes = [u32, u32p, u32p, f32p, f32p, f32p]
         l.oracle_compute_ref.restype = None
+        l.oracle_compute_ref_parallel.argtypes = [u32, u32p, u32p, f32p, f32p, f32p]
+        l.oracle_compute_ref_parallel.restype = None
         l.oracle_verify.argtypes = [f32p, f32p, C.c_uint64]
         l.oracle_verify.restype = C.c_int64
         _lib = l
@@ -128,6 +130,13 @@ def compute_ref(num_rows, indptr, indices, data, x):
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.zeros(num_rows, dtype=np.float32)
     lib().oracle_compute_ref(num_rows, _u32p(indptr), _u32p(indices), _f32p(data), _f32p(x), _f32p(y))
+    return y
+
+
+def compute_ref_parallel(num_rows, indptr, indices, data, x, out=None):
+    """OpenMP version of compute_ref over all host cores (CPU-baseline context only)."""
+    y = np.zeros(num_rows, dtype=np.float32) if out is None else out
+    lib().oracle_compute_ref_parallel(num_rows, _u32p(indptr), _u32p(indices), _f32p(data), _f32p(x), _f32p(y))
     return y
 
 

@@ -172,3 +172,37 @@ def test_empty_rows_and_empty_matrix_rows():
     for impl in IMPLS:
         _run_case(impl, m, vb=4, ob=8, skip=True, seed=5)
         _run_case(impl, m, vb=4, ob=8, skip=False, seed=5)
+
+
+def test_marker_skip_count_limit_matches_oracle():
+    # fixed mode, >= 256 skipped rounds: the reference's 8-bit skip count saturates; reproduced, see tests/test_tiles_cpu.py
+    from test_tiles_cpu import marker_limit_matrix
+    m, _ = marker_limit_matrix()
+    for impl in (0, 2):
+        v, o = host.default_banks(impl)
+        _run_case(impl, m, vb=v, ob=o, skip=True, seed=1)
+
+
+def test_csim_large_sparse_known_answer():
+    # spmv_csim/csim.cpp:468-479 at full size: uniform 100 000 x 100 000, 10 ones per row, x = glibc rand() % 2 after the
+    # 128 + 1024 draws of the two earlier cases; expected y = exact integer row sums (compute_ref) -- all three modes
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    for _ in range(128 + 1024):
+        libc.rand()
+    draws = np.array([libc.rand() % 2 for _ in range(100000)], dtype=np.float32)
+    for impl in IMPLS:
+        csr = host.CSRMatrix.generate("uniform", 100000, 100000, a=10)
+        cp = host.format_matrix(csr, impl, skip_empty_rows=False)
+        x = np.zeros(cp.num_cols, dtype=np.float32)
+        x[:100000] = draws
+        eng = device.SpmvEngine(impl)
+        eng.load_matrix(cp)
+        eng.load_vector(host.pack_vector(impl, x))
+        eng.run()
+        y = host.unpack_result(impl, eng.read_result())
+        eng.close()
+        ip, ix, dv = csr.arrays()
+        ref = orc.compute_ref(cp.num_rows, ip, ix, dv, x)
+        assert orc.verify(ref, y) == -1 and np.array_equal(y, ref)

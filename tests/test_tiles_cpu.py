@@ -144,3 +144,26 @@ def test_malformed_images_are_rejected():
         ch[0] = ch[0][:1]
     with pytest.raises(device.DeviceError):
         device.build_tiles(corrupt(cp, short_headers), *args)
+
+
+def marker_limit_matrix():
+    import scipy.sparse as sp
+    rows = 128 * 400
+    r = np.array([5, 5 + 128 * 300, 5 + 128 * 350])          # one lane stream; 299 empty rounds between the first two rows
+    return sp.csr_matrix((np.array([1.0, 2.0, 3.0], dtype=np.float32), (r, np.array([3, 4, 5]))), shape=(rows, 64)), r
+
+
+def test_marker_skip_count_limit_is_reproduced_not_fixed():
+    """SURVEY.md Appendix B.7 / spmv/libfpga/spmv_cluster.h:81-82: in fixed mode the skip count travels in the 8 integer
+    bits of a Q8.24 word, so a jump of >= 256 rounds saturates to 255 and the FPGA accumulates the following rows 45 rounds
+    too early.  The boundary is the reference's, so the product reproduces that exactly (oracle == product); the float
+    modes carry the count as a raw integer and are right."""
+    m, r = marker_limit_matrix()
+    for impl, landed in ((0, [5, 5 + 128 * 255, 5 + 128 * 305]), (1, r.tolist())):
+        csr = host.CSRMatrix.from_scipy(m)
+        cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+        xw = host.pack_vector(impl, np.ones(cp.num_cols, dtype=np.float32))
+        want = oracle_y(cp, impl, xw)
+        got = tile_emulator.run(build(cp, impl, 8), impl, xw, cp.num_rows)
+        assert np.array_equal(got, want)
+        assert np.nonzero(orc.unpack_result(impl, want))[0].tolist() == landed
