@@ -201,7 +201,7 @@ def main():
             parity = "within 1e-4" if np.allclose(y_gpu.view(np.float32), y_cpu.view(np.float32), rtol=1e-4, atol=1e-4) else "MISMATCH"
         cpu_baseline = {"value": round(8.0 * nnz / t_cpu / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
                         "sample": f"{reps} full SpMV(s) of the same matrix through oracle/cpu_ref.c (csim-equivalent restatement, 1 thread), {t_cpu*1e3:.1f} ms each",
-                        "gops": round(2.0 * nnz / t_cpu / 1e9, 4), "host_cpus": os.cpu_count()}
+                        "gops": round(2.0 * nnz / t_cpu / 1e9, 4), "host_cpus": orc.usable_cores()}
         # context only: plain float32 CSR loop (compute_ref, csim.cpp:143-158) with OpenMP over every host core
         try:
             ip, ix, dv = csr.arrays()
@@ -212,7 +212,7 @@ def main():
             for _ in range(5):
                 orc.compute_ref_parallel(packets.num_rows, ip, ix, dv, xf, out=yref)
             t_omp = (time.perf_counter() - t0) / 5
-            cpu_baseline["csr_openmp_all_cores"] = {"value": round(8.0 * nnz / t_omp / 1e9, 3), "unit": "GB/s", "cores": os.cpu_count(),
+            cpu_baseline["csr_openmp_all_cores"] = {"value": round(8.0 * nnz / t_omp / 1e9, 3), "unit": "GB/s", "cores": orc.usable_cores(),
                                                     "gops": round(2.0 * nnz / t_omp / 1e9, 3), "sample": f"5 float32 CSR SpMVs, {t_omp*1e3:.2f} ms each"}
             del ip, ix, dv
         except Exception as e:  # the context number must never break the bench line

@@ -235,8 +235,8 @@ int64_t oracle_verify(const float* reference, const float* kernel, uint64_t n) {
 /* The same float32 CSR loop spread over all host cores (rows are independent): the "honest CPU SpMV" context number of
  * BASELINE.md §3 (baseline C).  Only bench.py's cpu_baseline leg calls it. */
 void oracle_compute_ref_parallel(uint32_t num_rows, const uint32_t* indptr, const uint32_t* indices, const float* data,
-                                 const float* x, float* y) {
-#pragma omp parallel for schedule(dynamic, 1024)
+                                 const float* x, float* y, int threads) {
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads > 0 ? threads : 1)
     for (int64_t r = 0; r < (int64_t)num_rows; ++r) {
         float acc = 0.0f;
         for (uint32_t e = indptr[r]; e < indptr[r + 1]; ++e) acc += data[e] * x[indices[e]];

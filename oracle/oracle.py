@@ -39,7 +39,7 @@ def lib():
         l.oracle_spmv.argtypes = [C.c_int, vpp, u32p, u32p, u32, u32, u32, u32, u32, u32]
         l.oracle_compute_ref.argtypes = [u32, u32p, u32p, f32p, f32p, f32p]
         l.oracle_compute_ref.restype = None
-        l.oracle_compute_ref_parallel.argtypes = [u32, u32p, u32p, f32p, f32p, f32p]
+        l.oracle_compute_ref_parallel.argtypes = [u32, u32p, u32p, f32p, f32p, f32p, C.c_int]
         l.oracle_compute_ref_parallel.restype = None
         l.oracle_verify.argtypes = [f32p, f32p, C.c_uint64]
         l.oracle_verify.restype = C.c_int64
@@ -133,10 +133,17 @@ def compute_ref(num_rows, indptr, indices, data, x):
     return y
 
 
-def compute_ref_parallel(num_rows, indptr, indices, data, x, out=None):
-    """OpenMP version of compute_ref over all host cores (CPU-baseline context only)."""
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def compute_ref_parallel(num_rows, indptr, indices, data, x, out=None, threads=None):
+    """OpenMP version of compute_ref over the usable host cores (CPU-baseline context only)."""
     y = np.zeros(num_rows, dtype=np.float32) if out is None else out
-    lib().oracle_compute_ref_parallel(num_rows, _u32p(indptr), _u32p(indices), _f32p(data), _f32p(x), _f32p(y))
+    lib().oracle_compute_ref_parallel(num_rows, _u32p(indptr), _u32p(indices), _f32p(data), _f32p(x), _f32p(y), threads or usable_cores())
     return y
 
 
