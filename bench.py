@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--npz", default=None, help="real dataset file instead of the seeded stand-in")
     ap.add_argument("--impl", default=None, help="override the config's numeric mode")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather", choices=["final", "step", "off"], default="final",
+                    help="N > 1: all-gather the y slabs once after the timed SpMVs (default), after every SpMV (overlapped), or never")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for one GPU")
@@ -129,7 +130,10 @@ def main():
               f"generate {t_gen:.2f}s format {t_fmt:.2f}s device-load {stats['load_seconds']:.2f}s, CPSR {stats['cpsr_bytes']/1e6:.0f} MB -> stream {stats['stream_bytes']/1e6:.0f} MB")
 
     # ---- distributed plumbing: y slab inside an all-gather buffer -------------------------------------
-    gather = dist_mode and not args.no_gather
+    # `final`: one all-gather of the y slabs after the K timed SpMVs (inside the timed region) -- the path itself has no
+    # exchange step: rows are independent and the reference leaves y in device memory.  `step`: gather after every SpMV
+    # (iterative-solver pattern, y_k feeds x_k+1), double-buffered so that the gather of step k overlaps the SpMV of k+1.
+    gather = args.gather if dist_mode else "off"
     y_chunks = gathered = None
     pending = [None, None]
     if dist_mode:
@@ -137,7 +141,6 @@ def main():
         dist.all_gather_object(rows_all, packets.num_rows)
         chunk = max(rows_all)
         dev = f"cuda:{local_rank}"
-        # two y slabs / gather buffers: the all-gather of step k runs on RCCL's stream while step k+1 computes
         y_chunks = [torch.zeros(chunk, dtype=torch.int32, device=dev) for _ in range(2)]
         gathered = [torch.zeros(chunk * world, dtype=torch.int32, device=dev) for _ in range(2)]
         # one explicit (non-default) stream for both the SpMV kernels and the point RCCL synchronises against: the legacy
@@ -146,10 +149,11 @@ def main():
         torch.cuda.set_stream(main_stream)
         torch.cuda.synchronize()
         eng.set_stream(main_stream.cuda_stream)
+        eng.bind_device_result(y_chunks[0].data_ptr())
     step_no = [0]
 
     def step():
-        if not dist_mode:
+        if gather != "step":
             eng.run()
             return
         cur = step_no[0] & 1
@@ -159,8 +163,11 @@ def main():
             pending[cur] = None
         eng.bind_device_result(y_chunks[cur].data_ptr())
         eng.run()
-        if gather:
-            pending[cur] = dist.all_gather_into_tensor(gathered[cur], y_chunks[cur], async_op=True)
+        pending[cur] = dist.all_gather_into_tensor(gathered[cur], y_chunks[cur], async_op=True)
+
+    def final_gather():
+        if gather == "final":
+            dist.all_gather_into_tensor(gathered[0], y_chunks[0])
 
     def sync():
         if dist_mode:
@@ -173,9 +180,10 @@ def main():
 
     # ---- correctness of what is about to be timed (and the CPU baseline) --------------------------------
     step()
+    final_gather()
     sync()
     y_gpu = eng.read_result() if not dist_mode else y_chunks[0][:packets.num_rows].cpu().numpy().view(np.uint32)
-    if gather:   # the gathered buffer must hold this rank's slab at its offset (kernel -> RCCL ordering on the shared stream)
+    if gather != "off":   # the gathered buffer must hold this rank's slab at its offset (kernel -> RCCL ordering on the shared stream)
         mine = gathered[0][rank * y_chunks[0].numel(): rank * y_chunks[0].numel() + packets.num_rows].cpu().numpy().view(np.uint32)
         if not np.array_equal(mine, y_gpu):
             print(json.dumps({"error": "all-gathered y differs from the local slab", "rank": rank}))
@@ -232,6 +240,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    final_gather()
     sync()
     if dist_mode:
         torch.cuda.synchronize()
@@ -269,7 +278,7 @@ def main():
             "config": {"workload": f"{args.config}, {['fixed', 'float_pob', 'float_stall'][impl]} IMPL, v={packets.vb_bank} o={packets.ob_bank}",
                        "rows": true_rows, "cols": packets.num_cols, "nnz_per_gpu": int(nnz), "nnz_total": int(total_nnz),
                        "partitions": f"{packets.num_row_partitions}x{packets.num_col_partitions}",
-                       "parallelism": f"row-slab x{n_gpus}" + (" + all_gather(y) over RCCL" if gather and n_gpus > 1 else "")},
+                       "parallelism": f"row-slab x{n_gpus}" + ({"final": " + one final all_gather(y) over RCCL", "step": " + all_gather(y) over RCCL every step (overlapped)", "off": ""}[gather] if n_gpus > 1 else "")},
             "gops": round(2.0 * total_nnz / (elapsed / args.steps) / 1e9, 2),
             "gibps_reference_formula": round(8.0 * total_nnz / 2 ** 30 / (elapsed / args.steps), 2),
             "hbm_roofline_fraction_whole_job": round(value / (HBM_PEAK_GBS * n_gpus), 4),

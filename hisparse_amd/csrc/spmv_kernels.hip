@@ -199,6 +199,87 @@ block_done:
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail prefetches must land before their registers are reused
 }
 
+// GATHER mode (x too large for LDS staging to pay): the same streams, but x is read per element straight from
+// L2 / Infinity Cache.  Two software pipelines share vmcnt, both hand-counted: element loads run kDepth = 8 steps ahead,
+// the x gather of an element is issued kGather = 4 steps before it is consumed.  Issue order per step s:
+//   wait G(s) -> multiply-accumulate -> L(s+8) -> wait L(s+4) -> G(s+4)
+// so G(s) has exactly 2*(4-1) = 6 younger operations when it is awaited and L(s+4) has 8 (the prologue is peeled with
+// its own exact counts).  No x ring, no loaders, no barriers: a unit boundary only changes the column base.
+__device__ __forceinline__ void gather_load(uint32_t& dst, uint32_t byte_offset, const uint32_t* base) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_offset), "s"(base) : "memory");
+}
+template <int kOutstanding>
+__device__ __forceinline__ void gather_wait(uint32_t& v) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(kOutstanding) : "memory");
+}
+
+template <bool kFloat>
+__device__ __forceinline__ void consume_block_gather(const uint8_t* stream, const Unit* __restrict__ unit, uint32_t U, uint32_t wave,
+                                                     uint32_t lane, const uint32_t* __restrict__ x, typename Rows<kFloat>::acc_t* ys) {
+    constexpr int kDepth = 8, kGather = 4;
+    const uint32_t total = unit[U - 1].end_step[wave];
+    if (total == 0) return;
+    const uint32_t last = total - 1;
+    uint64_t buf[kDepth];
+    uint32_t xg[kGather];
+    // column base of the element whose gather is issued next (position p = s + kGather)
+    uint32_t ug = 0, endg = unit[0].end_step[wave], col0g = unit[0].col0;
+    auto issue_gather = [&](uint32_t p, uint64_t& element, uint32_t& dst) {
+        while (p == endg && ug + 1 < U) { ++ug; endg = unit[ug].end_step[wave]; col0g = unit[ug].col0; }
+        gather_load(dst, (col0g + (static_cast<uint32_t>(element >> 32) & 0xffffu)) * 4u, x);
+    };
+#pragma unroll
+    for (int k = 0; k < kGather; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kChunkBytes);
+    // peeled prologue: virtual steps -4 .. -1 issue L(4..7) and G(0..3) with the exact number of younger operations
+    stream_load(buf[4], stream + static_cast<size_t>(min(4u, last)) * kChunkBytes); stream_wait<4>(buf[0]); issue_gather(0, buf[0], xg[0]);
+    stream_load(buf[5], stream + static_cast<size_t>(min(5u, last)) * kChunkBytes); stream_wait<5>(buf[1]); issue_gather(1, buf[1], xg[1]);
+    stream_load(buf[6], stream + static_cast<size_t>(min(6u, last)) * kChunkBytes); stream_wait<6>(buf[2]); issue_gather(2, buf[2], xg[2]);
+    stream_load(buf[7], stream + static_cast<size_t>(min(7u, last)) * kChunkBytes); stream_wait<7>(buf[3]); issue_gather(3, buf[3], xg[3]);
+    for (uint32_t base = 0; base < total; base += kDepth) {
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) {
+            const uint32_t s = base + k;
+            if (s >= total) break;                               // wave-uniform
+            gather_wait<2 * (kGather - 1)>(xg[k % kGather]);
+            const uint32_t mat = static_cast<uint32_t>(buf[k]), cr = static_cast<uint32_t>(buf[k] >> 32);
+            Rows<kFloat>::add(ys, cr >> 16, Rows<kFloat>::product(mat, xg[k % kGather]));
+            stream_load(buf[k], stream + static_cast<size_t>(min(s + kDepth, last)) * kChunkBytes);
+            stream_wait<2 * kGather>(buf[(k + kGather) % kDepth]);
+            issue_gather(min(s + kGather, last), buf[(k + kGather) % kDepth], xg[k % kGather]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail prefetches and gathers must land before their registers are reused
+}
+
+template <bool kFloat>
+__global__ __launch_bounds__(kThreads) void spmv_gather_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
+                                                                const Unit* __restrict__ units, const uint32_t* __restrict__ wg_first,
+                                                                const uint32_t* __restrict__ block_order, const uint32_t* __restrict__ x,
+                                                                uint32_t* __restrict__ out, int32_t row_part_filter) {
+    using acc_t = typename Rows<kFloat>::acc_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    acc_t* ys = reinterpret_cast<acc_t*>(lds);                   // [nrows + 1]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWaveLanes - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWaveLanes);
+    uint32_t wg = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t q_end = wg_first[wg + 1];
+    for (uint32_t q = wg_first[wg]; q < q_end; ++q) {
+        const Block* blk = blocks + block_order[q];
+        if (row_part_filter >= 0 && blk->row_part != static_cast<uint32_t>(row_part_filter)) continue;
+        const uint32_t nrows = blk->nrows, out0 = blk->out_offset;
+        const uint32_t U = blk->unit_end - blk->unit_begin;
+        for (uint32_t i = tid; i <= nrows; i += kThreads) ys[i] = 0;
+        __syncthreads();
+        if (U > 0 && wave < kConsumerWaves)
+            consume_block_gather<kFloat>(image + blk->wave_offset[wave] + lane * 8u, units + blk->unit_begin, U, wave, lane, x, ys);
+        __syncthreads();
+        for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = Rows<kFloat>::finish(ys[i]);
+        __syncthreads();
+    }
+}
+
 // kDepth: element loads in flight per lane (kDepth x 512 B per wavefront).
 // kAblate (profiling builds only, HISPARSE_ABLATE): bit 0 = no LDS accumulate, bit 1 = no LDS gather,
 // bit 2 = no x sub-tile refill, bit 3 = no per-sub-tile barrier.  Any non-zero value gives wrong results.
@@ -305,6 +386,10 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers) {
 
 hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
     hipError_t e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_gather_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 static_cast<int>(lds_bytes))) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_gather_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 static_cast<int>(lds_bytes))) != hipSuccess) return e;
 #define X(F, A, D) if ((e = configure_one<F, A, D>(lds_bytes)) != hipSuccess) return e;
     HS_FOR_EACH_VARIANT(X)
 #undef X
@@ -314,6 +399,13 @@ hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
 hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.num_workgroups == 0) return hipSuccess;
     const dim3 grid(a.num_workgroups), block(kThreads);
+    if (a.ring_buffers == 0) {   // gather mode
+        if (is_float) hipLaunchKernelGGL(spmv_gather_kernel<true>, grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.wg_first,
+                                         a.block_order, a.x, a.out, a.row_part_filter);
+        else hipLaunchKernelGGL(spmv_gather_kernel<false>, grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.wg_first,
+                                a.block_order, a.x, a.out, a.row_part_filter);
+        return hipGetLastError();
+    }
     // profiling aids: HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the prefetch depth
     static const int ablate = env_int("HISPARSE_ABLATE", 0), depth = env_int("HISPARSE_DEPTH", 8);
     bool launched = false;

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <string>
 #include <thread>
 
 namespace hisparse {
@@ -178,8 +179,22 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             if (fill_us + combine_us < best) { best = fill_us + combine_us; slices = cs; }
         }
     }
+    // gather mode: with the best LDS plan, how many non-zeros would one (row range, sub-tile) unit hold?
+    {
+        const uint32_t cap = slices > 1 ? kMaxSlicedBlockRows : kMaxBlockRows;
+        const uint64_t ranges_est = std::max<uint64_t>((G + slices - 1) / slices, (uint64_t(num_rows) + cap - 1) / cap);
+        const double per_unit = double(out.nnz) / (double(ranges_est) * double(CP) * double(S));
+        const char* mode = std::getenv("HISPARSE_XMODE");
+        // Measured on MI355X: uncoalesced 4-byte gathers run at ~0.8 lanes/clk/CU (ogbl-ppa 218 us vs 62 us with LDS
+        // staging; ogbn-products 907 us vs 780-880 us), so gather mode never wins today.  It stays selectable
+        // (HISPARSE_XMODE=gather) as the tested fallback for matrices whose units are tiny; `per_unit` is what a
+        // future heuristic would look at.
+        (void)per_unit;
+        out.gather_x = mode && std::string(mode) == "gather";
+        if (out.gather_x) slices = 1;
+    }
     out.col_slices = slices;
-    const uint32_t max_rows = slices > 1 ? kMaxSlicedBlockRows : kMaxBlockRows;
+    const uint32_t max_rows = out.gather_x ? kMaxGatherBlockRows : (slices > 1 ? kMaxSlicedBlockRows : kMaxBlockRows);
 
     // ---- row ranges: equal non-zero count, <= max_rows rows, never across a row partition ---------------------------
     struct Range { uint32_t row0, nrows, row_part; };
@@ -218,7 +233,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         out.max_block_rows = std::max(out.max_block_rows, ranges[b].nrows);
     }
     const uint32_t ring_fit = (kMaxLdsBytes - (out.max_block_rows + 1) * 8u) / (kSubTileCols * 4u);
-    out.ring_buffers = std::max(kMinXBuffers, std::min(kMaxXBuffers, ring_fit));
+    out.ring_buffers = out.gather_x ? 0u : std::max(kMinXBuffers, std::min(kMaxXBuffers, ring_fit));
 
     // dense-row blocks additionally count per (sub-tile, row): their units are stored sorted by row
     std::vector<size_t> dense_base(NR, SIZE_MAX);

@@ -23,6 +23,10 @@
 //     COLUMN SLICES (sub-tiles dealt round-robin): a block is then (row range, slice), row ranges get
 //     proportionally longer, every workgroup pulls only 1/slices of x through its CU, and a small
 //     combine pass adds the per-slice partial results (saturating sums compose: DESIGN.md §4);
+//   * when x is so large that even then a (row range, sub-tile) unit would hold only a few hundred
+//     non-zeros (ogbn-products: 2.4 M columns), staging sub-tiles in LDS stops paying; the same streams
+//     are then consumed in GATHER mode: no x ring, no loaders, no barriers, x read per element from
+//     L2 / Infinity Cache;
 //   * a unit's elements are dealt to the 12 consumer wavefronts of the workgroup in chunks of 64,
 //     each wavefront's chunks forming one contiguous stream through all units of the block.  Normally
 //     lane l of chunk c takes element l*chunks + c (neighbouring lanes far apart: no same-row LDS
@@ -54,6 +58,8 @@ constexpr uint32_t kMinXBuffers = 2;
 constexpr uint32_t kMaxBlockRows = 4095;                      // one column slice: + 1 scratch slot = 32 KiB of 64-bit accumulators, ring of 4
 constexpr uint32_t kMaxSlicedBlockRows = 12287;               // several column slices: 96 KiB of accumulators, ring of 2
 constexpr uint32_t kMaxColSlices = 8;
+constexpr uint32_t kMaxGatherBlockRows = 16383;               // gather mode: the LDS holds row accumulators only
+constexpr uint32_t kGatherUnitElements = 3000;                // below this many non-zeros per (row range, sub-tile) staging x in LDS does not pay
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
@@ -88,7 +94,8 @@ struct StreamTiles {
     uint32_t num_workgroups = 0;
     uint32_t max_block_rows = 0;
     uint32_t col_slices = 1;             // > 1: blocks write per-slice partial results, a combine pass adds them
-    uint32_t ring_buffers = kMaxXBuffers;
+    uint32_t ring_buffers = kMaxXBuffers; // 0 in gather mode
+    bool gather_x = false;               // x is gathered straight from L2 / Infinity Cache instead of staged in LDS
     uint64_t nnz = 0;
     uint64_t elements = 0;               // element slots including chunk padding
 };

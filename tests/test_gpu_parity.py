@@ -103,6 +103,22 @@ def test_column_slices(impl, slices, monkeypatch):
     _run_case(impl, m, vb=v, ob=o, skip=True, seed=17)
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+def test_gather_mode(impl, monkeypatch):
+    # force the large-x path (x gathered from L2 per element, two hand-counted load pipelines) on an oracle-sized matrix
+    monkeypatch.setenv("HISPARSE_XMODE", "gather")
+    csr = host.CSRMatrix.generate("powerlaw", 50000, 90000, a=1200000, b=0.4, c=1.0 if impl == 0 else 2.0, seed=19)
+    ip, ix, dv = csr.arrays()
+    if impl != 0:
+        dv = (dv - 1.0).astype(np.float32)
+    import scipy.sparse as sp
+    m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(50000, 90000))
+    v, o = host.default_banks(impl)
+    _run_case(impl, m, vb=v, ob=o, skip=True, seed=19)
+    # tiny matrix: wavefronts with fewer chunks than the pipeline depth, and wavefronts with none at all
+    _run_case(impl, cases.random_csr(300, 200, 0.05, 3, impl), vb=v, ob=o, skip=True, seed=3)
+
+
 def test_fixed_rounding_and_saturation():
     # values/x chosen so products need AP_RND and rows overflow AP_SAT (sum >= 256 => 0xffffffff)
     rng = np.random.default_rng(3)

@@ -93,6 +93,20 @@ def test_column_slices(impl, slices, monkeypatch):
     assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
 
 
+@pytest.mark.parametrize("impl", [0, 2])
+def test_gather_mode_layout(impl, monkeypatch):
+    # matrices whose x is too large for LDS staging: same streams, longer row ranges, no x ring
+    monkeypatch.setenv("HISPARSE_XMODE", "gather")
+    csr = host.CSRMatrix.generate("powerlaw", 60000, 90000, a=500000, b=0.4, c=1.0 if impl == 0 else 2.0, seed=5)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 4, impl))
+    t = build(cp, impl, 8)
+    assert t["ring_buffers"] == 0 and t["col_slices"] == 1 and t["blocks"]["nrows"].max() <= 16383
+    got = tile_emulator.run(t, impl, xw, cp.num_rows)
+    want = oracle_y(cp, impl, xw)
+    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+
+
 def test_many_row_partitions_and_partition_filter():
     # float_pob-style small output banks: several row partitions, run one at a time like hs_run_partition
     m = cases.random_csr(2500, 300, 0.03, 21, 0)

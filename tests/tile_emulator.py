@@ -32,9 +32,10 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
             if row_part_filter >= 0 and int(blk["row_part"]) != row_part_filter:
                 continue
             nrows, row0, out0 = int(blk["nrows"]), int(blk["row0"]), int(blk["out_offset"])
-            assert nrows <= (4095 if slices == 1 else 12287)
+            gather = tiles["ring_buffers"] == 0            # gather mode: no x ring, only row accumulators in LDS
+            assert nrows <= (16383 if gather else 4095 if slices == 1 else 12287)
             assert out0 % num_rows == row0 and out0 // num_rows < slices
-            assert (4 if slices == 1 else 2) <= tiles["ring_buffers"] <= 4 or slices > 1
+            assert gather or 2 <= tiles["ring_buffers"] <= 4
             touched[row0: row0 + nrows] = True
             ys = np.zeros(nrows + 1, dtype=np.float32 if is_float else np.uint64)
             pos = [0] * CONSUMERS
