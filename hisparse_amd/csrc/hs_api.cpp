@@ -59,7 +59,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-constexpr size_t kImageSlackBytes = 4096;  // tail prefetches of an empty wavefront stream stay inside the allocation
+constexpr size_t kImageSlackBytes = 16384;  // the clamped prefetches of a wavefront without chunks (offset w * 512 past a short block) stay inside the allocation
 
 int fail(hs_context* ctx, int code, const std::string& msg) {
     if (ctx) ctx->error = msg; else g_create_error = msg;

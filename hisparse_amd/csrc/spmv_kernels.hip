@@ -141,11 +141,12 @@ __device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit*
     const uint32_t last = total ? total - 1 : 0;   // prefetches past the end re-read the last chunk (no branch)
     uint64_t buf[kDepth];
 #pragma unroll
-    for (int k = 0; k < kDepth; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kChunkBytes);
+    for (int k = 0; k < kDepth; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kWaveStrideBytes);
     constexpr uint32_t kNoRow = 0xffffffffu;
     uint32_t run_row = kNoRow;                      // kDense: row whose products are being summed in registers
     typename Rows<kFloat>::prod_t run_sum = 0;      // kDense: this lane's share of that sum
     uint32_t u = 0, slot = 0, end = unit[0].end_step[wave];   // slot = u % ring
+    if (kAblate & 64) { u = U - 1; end = total; }                // profiling: one unit per block
     const uint32_t* xb = xs;
     for (uint32_t base = 0;; base += kDepth) {
 #pragma unroll
@@ -192,7 +193,7 @@ __device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit*
                     Rows<kFloat>::add(ys, row, prod);
                 }
             }
-            stream_load(buf[k], stream + static_cast<size_t>(min(s + kDepth, last)) * kChunkBytes);
+            stream_load(buf[k], stream + static_cast<size_t>(min(s + kDepth, last)) * kWaveStrideBytes);
         }
     }
 block_done:
@@ -229,12 +230,12 @@ __device__ __forceinline__ void consume_block_gather(const uint8_t* stream, cons
         gather_load(dst, (col0g + (static_cast<uint32_t>(element >> 32) & 0xffffu)) * 4u, x);
     };
 #pragma unroll
-    for (int k = 0; k < kGather; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kChunkBytes);
+    for (int k = 0; k < kGather; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kWaveStrideBytes);
     // peeled prologue: virtual steps -4 .. -1 issue L(4..7) and G(0..3) with the exact number of younger operations
-    stream_load(buf[4], stream + static_cast<size_t>(min(4u, last)) * kChunkBytes); stream_wait<4>(buf[0]); issue_gather(0, buf[0], xg[0]);
-    stream_load(buf[5], stream + static_cast<size_t>(min(5u, last)) * kChunkBytes); stream_wait<5>(buf[1]); issue_gather(1, buf[1], xg[1]);
-    stream_load(buf[6], stream + static_cast<size_t>(min(6u, last)) * kChunkBytes); stream_wait<6>(buf[2]); issue_gather(2, buf[2], xg[2]);
-    stream_load(buf[7], stream + static_cast<size_t>(min(7u, last)) * kChunkBytes); stream_wait<7>(buf[3]); issue_gather(3, buf[3], xg[3]);
+    stream_load(buf[4], stream + static_cast<size_t>(min(4u, last)) * kWaveStrideBytes); stream_wait<4>(buf[0]); issue_gather(0, buf[0], xg[0]);
+    stream_load(buf[5], stream + static_cast<size_t>(min(5u, last)) * kWaveStrideBytes); stream_wait<5>(buf[1]); issue_gather(1, buf[1], xg[1]);
+    stream_load(buf[6], stream + static_cast<size_t>(min(6u, last)) * kWaveStrideBytes); stream_wait<6>(buf[2]); issue_gather(2, buf[2], xg[2]);
+    stream_load(buf[7], stream + static_cast<size_t>(min(7u, last)) * kWaveStrideBytes); stream_wait<7>(buf[3]); issue_gather(3, buf[3], xg[3]);
     for (uint32_t base = 0; base < total; base += kDepth) {
 #pragma unroll
         for (int k = 0; k < kDepth; ++k) {
@@ -243,7 +244,7 @@ __device__ __forceinline__ void consume_block_gather(const uint8_t* stream, cons
             gather_wait<2 * (kGather - 1)>(xg[k % kGather]);
             const uint32_t mat = static_cast<uint32_t>(buf[k]), cr = static_cast<uint32_t>(buf[k] >> 32);
             Rows<kFloat>::add(ys, cr >> 16, Rows<kFloat>::product(mat, xg[k % kGather]));
-            stream_load(buf[k], stream + static_cast<size_t>(min(s + kDepth, last)) * kChunkBytes);
+            stream_load(buf[k], stream + static_cast<size_t>(min(s + kDepth, last)) * kWaveStrideBytes);
             stream_wait<2 * kGather>(buf[(k + kGather) % kDepth]);
             issue_gather(min(s + kGather, last), buf[(k + kGather) % kDepth], xg[k % kGather]);
         }
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(kThreads) void spmv_gather_kernel(const uint8_t* __
 
 // kDepth: element loads in flight per lane (kDepth x 512 B per wavefront).
 // kAblate (profiling builds only, HISPARSE_ABLATE): bit 0 = no LDS accumulate, bit 1 = no LDS gather,
-// bit 2 = no x sub-tile refill, bit 3 = no per-sub-tile barrier.  Any non-zero value gives wrong results.
+// bit 2 = no x sub-tile refill, bit 3 = no per-sub-tile barrier, bit 4 = no block prologue (zero + first sub-tile),
+// bit 5 = no result store, bit 6 = ignore unit boundaries.  Any non-zero value gives wrong results.
 template <bool kFloat, int kAblate, int kDepth>
 __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const Unit* __restrict__ units, const uint32_t* __restrict__ wg_first,
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
     if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 
     const uint32_t q_end = wg_first[wg + 1];
+    bool first_block = true;
     for (uint32_t q = wg_first[wg]; q < q_end; ++q) {
         const Block* blk = blocks + block_order[q];
         if (row_part_filter >= 0 && blk->row_part != static_cast<uint32_t>(row_part_filter)) continue;
@@ -309,8 +312,10 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
         const Unit* unit = units + blk->unit_begin;
         const uint32_t U = blk->unit_end - blk->unit_begin;
 
-        for (uint32_t i = tid; i <= nrows; i += kThreads) ys[i] = 0;           // PE banks start at zero (pe.h:131-135)
-        if (U > 0) fill_x<kSubTileCols / 4 / kThreads, kThreads>(xs, x, unit[0].col0, unit[0].ncols, tid);
+        if (!first_block) __syncthreads();   // the previous block's result store has read the accumulators
+        first_block = false;
+        if (!(kAblate & 16)) for (uint32_t i = tid; i <= nrows; i += kThreads) ys[i] = 0;           // PE banks start at zero (pe.h:131-135)
+        if (U > 0 && !(kAblate & 16)) fill_x<kSubTileCols / 4 / kThreads, kThreads>(xs, x, unit[0].col0, unit[0].ncols, tid);
         __syncthreads();
 
         if (U > 0) {
@@ -340,8 +345,8 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
             }
         }
         // every sub-tile barrier has passed: the accumulators are final
-        for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = Rows<kFloat>::finish(ys[i]);
-        __syncthreads();   // before the next block re-zeroes the accumulators
+        // (no barrier after the store: the last block's stores drain while the workgroup retires)
+        if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = Rows<kFloat>::finish(ys[i]);
     }
 }
 
@@ -382,7 +387,7 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers) {
 }
 
 #define HS_FOR_EACH_VARIANT(X) \
-    X(true, 0, 8) X(false, 0, 8) X(false, 0, 16) X(false, 3, 8) X(false, 4, 8) X(false, 8, 8) X(false, 15, 8)
+    X(true, 0, 8) X(false, 0, 8) X(false, 0, 16) X(false, 3, 8) X(false, 4, 8) X(false, 8, 8) X(false, 15, 8) X(false, 79, 8) X(false, 127, 8) X(false, 31, 8) X(false, 47, 8)
 
 hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
     hipError_t e;

@@ -325,10 +325,12 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 elems += n;
             }
             blk.unit_end = uint32_t(out.units.size());
-            for (uint32_t w = 0; w < kConsumerWaves; ++w) {
-                blk.wave_offset[w] = image_bytes;
-                image_bytes += uint64_t(pos[w]) * kChunkBytes;
-            }
+            // chunks are stored in dealing order (global chunk g of the block at g * 512 bytes; wavefront w consumes
+            // g = w, w + 14, w + 28, ...): the 14 wavefronts of a workgroup sweep ONE contiguous region together instead of
+            // 14 separate ones (3584 independent sequential streams chip-wide thrash the DRAM row buffers: measured 5.5 vs
+            // 7.0 TB/s for a plain streaming read)
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) blk.wave_offset[w] = image_bytes + uint64_t(w) * kChunkBytes;
+            image_bytes += uint64_t(chunk_counter) * kChunkBytes;
             out.blocks.push_back(blk);
             block_nnz.push_back(elems);
         }
@@ -368,7 +370,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         const uint32_t g = up.base + c, w = g % kConsumerWaves;
         const uint32_t first = up.base + (w + kConsumerWaves - up.base % kConsumerWaves) % kConsumerWaves;  // first chunk of wave w in this unit
         const uint32_t step = up.start_step[w] + (g - first) / kConsumerWaves;
-        return image + blk.wave_offset[w] + uint64_t(step) * kChunkBytes + lane * 8;
+        return image + blk.wave_offset[w] + uint64_t(step) * kWaveStrideBytes + lane * 8;
     };
     parallel_for(res1.size(), [&](size_t w) {
         const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP), rp = uint32_t(w / NUM_HBM_CHANNELS / CP);

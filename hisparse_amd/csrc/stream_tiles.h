@@ -28,7 +28,7 @@
 //     are then consumed in GATHER mode: no x ring, no loaders, no barriers, x read per element from
 //     L2 / Infinity Cache;
 //   * a unit's elements are dealt to the 12 consumer wavefronts of the workgroup in chunks of 64,
-//     each wavefront's chunks forming one contiguous stream through all units of the block.  Normally
+//     the chunks of a block stored in dealing order so that the workgroup sweeps one contiguous region.  Normally
 //     lane l of chunk c takes element l*chunks + c (neighbouring lanes far apart: no same-row LDS
 //     atomics in one instruction).  Blocks of <= 32 rows (pruned-NN layers: 512 rows x 16 K non-zeros)
 //     would put all 64 lanes on the same one or two accumulators; there the unit is sorted by row and
@@ -61,6 +61,7 @@ constexpr uint32_t kMaxColSlices = 8;
 constexpr uint32_t kMaxGatherBlockRows = 16383;               // gather mode: the LDS holds row accumulators only
 constexpr uint32_t kGatherUnitElements = 3000;                // below this many non-zeros per (row range, sub-tile) staging x in LDS does not pay
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
+constexpr uint32_t kWaveStrideBytes = kChunkBytes * kConsumerWaves;   // chunks of the 14 wavefronts are interleaved in memory
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit
@@ -75,7 +76,7 @@ struct Block {
     uint32_t flags;         // kBlockDenseRows: few long rows; chunks are row-sorted and mostly hold ONE row
     uint32_t out_offset;    // word offset of the block's first row in the output: y (one slice) or the per-slice partials
     uint32_t reserved;
-    uint64_t wave_offset[kConsumerWaves];   // byte offset of each consumer wavefront's stream in the image
+    uint64_t wave_offset[kConsumerWaves];   // byte offset of each consumer wavefront's first chunk; its next is kWaveStrideBytes on
 };
 struct Unit {
     uint32_t col0;          // first absolute column of the x sub-tile

@@ -48,7 +48,7 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
                     end = int(unit["end_step"][w])
                     base = int(blk["wave_offset"][w])
                     for s in range(pos[w], end):
-                        chunk = image[base + s * CHUNK_BYTES: base + (s + 1) * CHUNK_BYTES].view(np.uint32).reshape(WAVE, 2)
+                        chunk = image[base + s * CHUNK_BYTES * CONSUMERS: base + s * CHUNK_BYTES * CONSUMERS + CHUNK_BYTES].view(np.uint32).reshape(WAVE, 2)
                         val, cr = chunk[:, 0], chunk[:, 1]
                         col, row = (cr & 0xFFFF).astype(np.int64), (cr >> 16).astype(np.int64)
                         assert (col < ncols).all() and (row <= nrows).all()
