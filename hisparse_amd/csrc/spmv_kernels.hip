@@ -140,6 +140,11 @@ __device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit*
     const uint32_t total = unit[U - 1].end_step[wave];
     const uint32_t last = total ? total - 1 : 0;   // prefetches past the end re-read the last chunk (no branch)
     uint64_t buf[kDepth];
+    // The loader branch of the kernel leaves "LDS-DMA may be pending" in hipcc's wait-count bookkeeping, and that state
+    // reaches this loop around the block loop: every LDS store on a conditional path below (the dense-row hand-over)
+    // would then get its own s_waitcnt vmcnt(0) and drain the prefetch ring.  A consumer wavefront never has LDS-DMA in
+    // flight, so say so once, up front, where nothing is in flight yet.
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), lgkmcnt/expcnt untouched
 #pragma unroll
     for (int k = 0; k < kDepth; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kWaveStrideBytes);
     constexpr uint32_t kNoRow = 0xffffffffu;
