@@ -20,7 +20,8 @@ struct SpmvLaunch {
     const uint32_t* x;            // packed vector words, num_cols
     uint32_t* out;                // packed result words: y itself (one column slice) or slices x num_rows partials
     int32_t row_part_filter;      // -1: every row partition
-    uint32_t ring_buffers;        // x sub-tile buffers in the LDS ring (2..4); 0 = gather mode (x read from L2 per element)
+    uint32_t ring_buffers;        // x sub-tile buffers in the LDS ring (2..4)
+    bool delta;                   // stream format of `image`: DELTA records, otherwise PAIRS chunks (stream_tiles.h)
     uint32_t num_workgroups;
     uint32_t lds_bytes;
 };

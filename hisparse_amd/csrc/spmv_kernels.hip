@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <utility>
 
 #include "spmv_kernels.h"
 
@@ -37,14 +38,18 @@ namespace {
 
 constexpr int kThreads = kWaveLanes * kWavesPerWorkgroup;       // 1024
 constexpr int kConsumerThreads = kWaveLanes * kConsumerWaves;   // 768
-constexpr int kLoaderThreads = kThreads - kConsumerThreads;     // 256
 constexpr uint32_t kBufBytes = kSubTileCols * 4u;               // one x buffer of the LDS ring (32 KiB)
 
 // mat_val * vec_val narrowed to Q8.24: exact 64-bit product, + half LSB, >> 24, saturate (pe.h:64).
 __device__ __forceinline__ uint32_t q8_24_mul(uint32_t a, uint32_t b) {
-    const uint64_t wide = static_cast<uint64_t>(a) * b;
-    const uint64_t r = (wide >> 24) + ((wide >> 23) & 1u);
-    return r > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(r);
+    // min((a*b + 2^23) >> 24, 2^32-1): the rounding constant rides in the multiply-add (a*b + 2^23 < 2^64), the shift
+    // is one v_alignbit on the 64-bit register pair, and "result >= 2^32" is "top byte of the high word != 0".
+    const uint64_t wide = static_cast<uint64_t>(a) * b + 0x800000ull;
+    uint32_t hi = static_cast<uint32_t>(wide >> 32);
+    const uint32_t lo = static_cast<uint32_t>(wide);
+    asm("" : "+v"(hi));   // keeps hipcc from re-deriving the overflow test from a second, unrounded 64-bit multiply
+    const uint32_t r = __builtin_amdgcn_alignbit(hi, lo, 24);
+    return (hi >> 24) ? 0xffffffffu : r;
 }
 
 template <bool kFloat>
@@ -113,15 +118,57 @@ __device__ __forceinline__ void dma_wait() {
 
 // The element stream is loaded with hand-placed instructions: hipcc's s_waitcnt placement degrades to vmcnt(0)
 // (a full drain per element) in the unit/barrier control flow below, which would serialise the HBM stream.
-// Rules kept here: exactly ONE stream_load per step and no other vector-memory instruction inside the consumer
-// loop, so "the load issued kDepth steps ago has landed" is exactly vmcnt(kDepth - 1) (vmcnt retires in order).
-// `nt`: every element is read exactly once per SpMV, so it should not displace x in the L2 (measured: -8 % kernel time).
-__device__ __forceinline__ void stream_load(uint64_t& dst, const void* addr) {
-    asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(dst) : "v"(addr) : "memory");
-}
-template <int kOutstanding>
-__device__ __forceinline__ void stream_wait(uint64_t& v) {
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(kOutstanding) : "memory");
+// Rules kept here:
+//   * exactly ONE issue<K>() per step and no other vector-memory instruction inside the consumer loop, so "the step
+//     issued kDepth steps ago has landed" is exactly a counted s_waitcnt vmcnt (vmcnt retires in order);
+//   * data in flight lives in ACCUMULATOR registers (a0..a31), which hipcc never allocates in this kernel, and only
+//     becomes a compiler-visible value inside take<K>(), AFTER the wait.  With ordinary asm outputs the compiler is free
+//     to copy a load's destination register before the wait (it did: a v_mov of not-yet-landed data, one record in a
+//     few million wrong);
+//   * the stream base is a loop-invariant SGPR pair, the per-step address a 32-bit vector offset (no 64-bit vector
+//     address arithmetic per step); s_nop 4 keeps 5 wait states between any scalar write of the base and its use;
+//   * `nt`: every element is read exactly once per SpMV, so it should not displace x in the L2 (measured: -8 %).
+#define HS_RING_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", \
+                      "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"
+constexpr int kMaxDepth = 16;
+
+template <bool kDelta>
+struct Ring;
+template <>
+struct Ring<false> {   // PAIRS: one dwordx2 per lane and step
+    static constexpr uint32_t kLaneBytes = 8;
+    template <int K>
+    static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %2, %3 nt" ::"n"(2 * K), "n"(2 * K + 1), "v"(byte_off + lane_off), "s"(base)
+                     : "memory", HS_RING_AGPRS);
+    }
+    template <int K, int kDepth>
+    static __device__ __forceinline__ void take(uint32_t& value, uint32_t& where) {
+        asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]"
+                     : "=v"(value), "=v"(where) : "n"(2 * K), "n"(2 * K + 1), "n"(kDepth - 1) : "memory");
+    }
+};
+template <>
+struct Ring<true> {    // DELTA: the value dword and the 16-bit gap of this lane
+    static constexpr uint32_t kLaneBytes = 4;
+    template <int K>
+    static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
+        asm volatile("s_nop 4\n\tglobal_load_dword a[%0], %2, %4 nt\n\tglobal_load_ushort a[%1], %3, %4 offset:256 nt" ::"n"(K),
+                     "n"(K + kMaxDepth), "v"(byte_off + lane_off), "v"(byte_off + lane_off / 2), "s"(base)
+                     : "memory", HS_RING_AGPRS);
+    }
+    template <int K, int kDepth>
+    static __device__ __forceinline__ void take(uint32_t& value, uint32_t& gap) {
+        asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]"
+                     : "=v"(value), "=v"(gap) : "n"(K), "n"(K + kMaxDepth), "n"(2 * (kDepth - 1)) : "memory");
+    }
+};
+// a pointer the compiler must keep in a scalar register pair
+__device__ __forceinline__ const uint8_t* scalar_pointer(const uint8_t* p) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));   // (the builtin returns int:
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a));         //  no sign extension, please)
+    return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
 // Workgroup barrier that orders LDS traffic only: the consumers' prefetched global loads stay in flight
@@ -132,173 +179,155 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// The consumer side of one row block: stream this wavefront's chunks through all sub-tiles of the block.
-// kDense: the block has few, long rows and its chunks are row-sorted (Block::flags & kBlockDenseRows).
-template <bool kFloat, int kAblate, int kDepth, bool kDense>
-__device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit* __restrict__ unit, uint32_t U, uint32_t wave, uint32_t lane,
-                                              const uint32_t* xs, uint32_t ring, typename Rows<kFloat>::acc_t* ys) {
-    const uint32_t total = unit[U - 1].end_step[wave];
-    const uint32_t last = total ? total - 1 : 0;   // prefetches past the end re-read the last chunk (no branch)
-    uint64_t buf[kDepth];
-    // The loader branch of the kernel leaves "LDS-DMA may be pending" in hipcc's wait-count bookkeeping, and that state
-    // reaches this loop around the block loop: every LDS store on a conditional path below (the dense-row hand-over)
-    // would then get its own s_waitcnt vmcnt(0) and drain the prefetch ring.  A consumer wavefront never has LDS-DMA in
-    // flight, so say so once, up front, where nothing is in flight yet.
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), lgkmcnt/expcnt untouched
-#pragma unroll
-    for (int k = 0; k < kDepth; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kWaveStrideBytes);
-    constexpr uint32_t kNoRow = 0xffffffffu;
-    uint32_t run_row = kNoRow;                      // kDense: row whose products are being summed in registers
-    typename Rows<kFloat>::prod_t run_sum = 0;      // kDense: this lane's share of that sum
-    uint32_t u = 0, slot = 0, end = unit[0].end_step[wave];   // slot = u % ring
-    if (kAblate & 64) { u = U - 1; end = total; }                // profiling: one unit per block
-    const uint32_t* xb = xs;
-    for (uint32_t base = 0;; base += kDepth) {
-#pragma unroll
-        for (int k = 0; k < kDepth; ++k) {
-            const uint32_t s = base + k;
-            while (s == end) {                 // this wavefront finished sub-tile u (possibly with no work in it)
-                if (kDense && u + 1 == U && run_row != kNoRow) {   // last sub-tile: hand the register sum over before the final barrier
-                    const typename Rows<kFloat>::prod_t sum = wave_sum(run_sum);
-                    if (lane == 0) Rows<kFloat>::add(ys, run_row, sum);
-                    run_row = kNoRow;
-                }
-                if (!(kAblate & 8)) lds_barrier();
-                if (++u == U) goto block_done;
-                end = unit[u].end_step[wave];
-                slot = slot + 1 == ring ? 0 : slot + 1;
-                xb = xs + slot * kSubTileCols;
-            }
-            stream_wait<kDepth - 1>(buf[k]);
-            const uint32_t mat = static_cast<uint32_t>(buf[k]), cr = static_cast<uint32_t>(buf[k] >> 32);
-            const uint32_t xv = (kAblate & 2) ? cr : xb[cr & 0xffffu];
-            if (kAblate & 1) {
-                asm volatile("" ::"v"(xv), "v"(mat));
-            } else {
-                const typename Rows<kFloat>::prod_t prod = Rows<kFloat>::product(mat, xv);
-                const uint32_t row = cr >> 16;
-                if (kDense) {
-                    // Chunks are row-sorted, so the whole wavefront is usually on ONE row, and stays on it for many chunks:
-                    // keep a per-lane running sum in registers while the row does not change and touch the LDS accumulator
-                    // only when it does (one wave_sum + one ds_add per row per wavefront instead of a 64-way conflicting
-                    // atomic per chunk).
-                    const uint32_t row0 = __builtin_amdgcn_readfirstlane(row);
-                    const bool uniform = __ballot(row == row0) == ~0ull;
-                    if (uniform && row0 == run_row) {
-                        run_sum += prod;
-                    } else {
-                        if (run_row != kNoRow) {
-                            const typename Rows<kFloat>::prod_t sum = wave_sum(run_sum);
-                            if (lane == 0) Rows<kFloat>::add(ys, run_row, sum);
-                        }
-                        if (uniform) { run_row = row0; run_sum = prod; }
-                        else { run_row = kNoRow; run_sum = 0; Rows<kFloat>::add(ys, row, prod); }   // chunk straddles rows
-                    }
-                } else {
-                    Rows<kFloat>::add(ys, row, prod);
-                }
-            }
-            stream_load(buf[k], stream + static_cast<size_t>(min(s + kDepth, last)) * kWaveStrideBytes);
-        }
-    }
-block_done:
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail prefetches must land before their registers are reused
-}
-
-// GATHER mode (x too large for LDS staging to pay): the same streams, but x is read per element straight from
-// L2 / Infinity Cache.  Two software pipelines share vmcnt, both hand-counted: element loads run kDepth = 8 steps ahead,
-// the x gather of an element is issued kGather = 4 steps before it is consumed.  Issue order per step s:
-//   wait G(s) -> multiply-accumulate -> L(s+8) -> wait L(s+4) -> G(s+4)
-// so G(s) has exactly 2*(4-1) = 6 younger operations when it is awaited and L(s+4) has 8 (the prologue is peeled with
-// its own exact counts).  No x ring, no loaders, no barriers: a unit boundary only changes the column base.
-__device__ __forceinline__ void gather_load(uint32_t& dst, uint32_t byte_offset, const uint32_t* base) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_offset), "s"(base) : "memory");
-}
-template <int kOutstanding>
-__device__ __forceinline__ void gather_wait(uint32_t& v) {
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(kOutstanding) : "memory");
-}
-
+// ---- the consumer side of one row block: stream this wavefront's chunks / records through all sub-tiles of the block ----
 template <bool kFloat>
-__device__ __forceinline__ void consume_block_gather(const uint8_t* stream, const Unit* __restrict__ unit, uint32_t U, uint32_t wave,
-                                                     uint32_t lane, const uint32_t* __restrict__ x, typename Rows<kFloat>::acc_t* ys) {
-    constexpr int kDepth = 8, kGather = 4;
-    const uint32_t total = unit[U - 1].end_step[wave];
-    if (total == 0) return;
-    const uint32_t last = total - 1;
-    uint64_t buf[kDepth];
-    uint32_t xg[kGather];
-    // column base of the element whose gather is issued next (position p = s + kGather)
-    uint32_t ug = 0, endg = unit[0].end_step[wave], col0g = unit[0].col0;
-    auto issue_gather = [&](uint32_t p, uint64_t& element, uint32_t& dst) {
-        while (p == endg && ug + 1 < U) { ++ug; endg = unit[ug].end_step[wave]; col0g = unit[ug].col0; }
-        gather_load(dst, (col0g + (static_cast<uint32_t>(element >> 32) & 0xffffu)) * 4u, x);
-    };
-#pragma unroll
-    for (int k = 0; k < kGather; ++k) stream_load(buf[k], stream + static_cast<size_t>(min(static_cast<uint32_t>(k), last)) * kWaveStrideBytes);
-    // peeled prologue: virtual steps -4 .. -1 issue L(4..7) and G(0..3) with the exact number of younger operations
-    stream_load(buf[4], stream + static_cast<size_t>(min(4u, last)) * kWaveStrideBytes); stream_wait<4>(buf[0]); issue_gather(0, buf[0], xg[0]);
-    stream_load(buf[5], stream + static_cast<size_t>(min(5u, last)) * kWaveStrideBytes); stream_wait<5>(buf[1]); issue_gather(1, buf[1], xg[1]);
-    stream_load(buf[6], stream + static_cast<size_t>(min(6u, last)) * kWaveStrideBytes); stream_wait<6>(buf[2]); issue_gather(2, buf[2], xg[2]);
-    stream_load(buf[7], stream + static_cast<size_t>(min(7u, last)) * kWaveStrideBytes); stream_wait<7>(buf[3]); issue_gather(3, buf[3], xg[3]);
-    for (uint32_t base = 0; base < total; base += kDepth) {
-#pragma unroll
-        for (int k = 0; k < kDepth; ++k) {
-            const uint32_t s = base + k;
-            if (s >= total) break;                               // wave-uniform
-            gather_wait<2 * (kGather - 1)>(xg[k % kGather]);
-            const uint32_t mat = static_cast<uint32_t>(buf[k]), cr = static_cast<uint32_t>(buf[k] >> 32);
-            Rows<kFloat>::add(ys, cr >> 16, Rows<kFloat>::product(mat, xg[k % kGather]));
-            stream_load(buf[k], stream + static_cast<size_t>(min(s + kDepth, last)) * kWaveStrideBytes);
-            stream_wait<2 * kGather>(buf[(k + kGather) % kDepth]);
-            issue_gather(min(s + kGather, last), buf[(k + kGather) % kDepth], xg[k % kGather]);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail prefetches and gathers must land before their registers are reused
-}
-
-template <bool kFloat>
-__global__ __launch_bounds__(kThreads) void spmv_gather_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
-                                                                const Unit* __restrict__ units, const uint32_t* __restrict__ wg_first,
-                                                                const uint32_t* __restrict__ block_order, const uint32_t* __restrict__ x,
-                                                                uint32_t* __restrict__ out, int32_t row_part_filter) {
+struct Consumer {
     using acc_t = typename Rows<kFloat>::acc_t;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    acc_t* ys = reinterpret_cast<acc_t*>(lds);                   // [nrows + 1]
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & (kWaveLanes - 1);
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWaveLanes);
-    uint32_t wg = blockIdx.x;
-    if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const uint32_t q_end = wg_first[wg + 1];
-    for (uint32_t q = wg_first[wg]; q < q_end; ++q) {
-        const Block* blk = blocks + block_order[q];
-        if (row_part_filter >= 0 && blk->row_part != static_cast<uint32_t>(row_part_filter)) continue;
-        const uint32_t nrows = blk->nrows, out0 = blk->out_offset;
-        const uint32_t U = blk->unit_end - blk->unit_begin;
-        for (uint32_t i = tid; i <= nrows; i += kThreads) ys[i] = 0;
-        __syncthreads();
-        if (U > 0 && wave < kConsumerWaves)
-            consume_block_gather<kFloat>(image + blk->wave_offset[wave] + lane * 8u, units + blk->unit_begin, U, wave, lane, x, ys);
-        __syncthreads();
-        for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = Rows<kFloat>::finish(ys[i]);
-        __syncthreads();
+    using prod_t = typename Rows<kFloat>::prod_t;
+    static constexpr uint32_t kNoRow = 0xffffffffu;
+    const uint8_t* stream;     // scalar_pointer: first chunk / record of this wavefront in the block
+    const Unit* unit;
+    uint32_t U, wave, lane, lane_off, ring, nrows, last;
+    const uint32_t* xs;
+    acc_t* ys;
+    uint32_t u = 0, slot = 0, end = 0, base = 0;
+    const uint32_t* xb;
+    uint32_t pos = 0;          // DELTA: this lane's position in the current sub-tile
+    bool head = true;          // DELTA: the next record of this wavefront is a head record
+    uint32_t run_row = kNoRow; // PAIRS dense rows: row whose products are being summed in registers ...
+    prod_t run_sum = 0;        // ... and this lane's share of that sum
+};
+
+// One step (slot K of the ring).  Returns false when the block is finished.
+// kDelta: DELTA format, otherwise PAIRS; kDense (PAIRS only): the block has few, long rows (Block::flags & kBlockDenseRows).
+template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense, int K>
+__device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
+    using R = Rows<kFloat>;
+    constexpr uint32_t kStride = kDelta ? kRecordBytes : kWaveStrideBytes;
+    const uint32_t s = c.base + K;
+    while (s == c.end) {               // this wavefront finished sub-tile u (possibly with no work in it)
+        if (!kDelta && kDense && c.u + 1 == c.U && c.run_row != Consumer<kFloat>::kNoRow) {   // last sub-tile: hand the register sum over
+            const typename R::prod_t sum = wave_sum(c.run_sum);
+            if (c.lane == 0) R::add(c.ys, c.run_row, sum);
+            c.run_row = Consumer<kFloat>::kNoRow;
+        }
+        if (!(kAblate & 8)) lds_barrier();
+        if (++c.u == c.U) return false;
+        c.end = c.unit[c.u].end_step[c.wave];
+        c.slot = c.slot + 1 == c.ring ? 0 : c.slot + 1;
+        c.xb = c.xs + c.slot * kSubTileCols;
+        c.head = true;
     }
+    uint32_t mat, aux;                 // value word; PAIRS: row << 16 | col, DELTA: gap
+    Ring<kDelta>::template take<K, kDepth>(mat, aux);
+    if (kDelta) {
+        // A lane owns a run of consecutive slots of the position-sorted unit.  The head record of every (unit, wavefront)
+        // gives each lane its absolute start position (local_row * 8192 + local_col); every following record carries one
+        // value word and one 16-bit gap per lane.  No per-lane branch: a bridge slot (gap 0xffff, value 0) advances 65535
+        // and adds 0 at a valid row of the block; fixed-point padding is (gap 0, value 0); float padding is a bridge whose
+        // row is clamped to the spare accumulator ys[nrows] (0 * x could be NaN for a non-finite x, so float bridge slots
+        // add a literal 0).
+        if (c.head) {                  // wave-uniform
+            c.pos = mat;
+            c.head = false;
+        } else {
+            c.pos += aux;
+            uint32_t row = c.pos / kSubTileCols;
+            const uint32_t col = c.pos % kSubTileCols;
+            if (kAblate & 1) {
+                asm volatile("" ::"v"(row), "v"(mat));
+            } else {
+                const uint32_t xv = (kAblate & 2) ? col : c.xb[col];
+                typename R::prod_t prod = R::product(mat, xv);
+                if (kFloat) {
+                    if (aux == kBridgeGap) prod = 0;
+                    row = min(row, c.nrows);
+                }
+                R::add(c.ys, row, prod);
+            }
+        }
+    } else {
+        const uint32_t xv = (kAblate & 2) ? aux : c.xb[aux & 0xffffu];
+        if (kAblate & 1) {
+            asm volatile("" ::"v"(xv), "v"(mat));
+        } else {
+            const typename R::prod_t prod = R::product(mat, xv);
+            const uint32_t row = aux >> 16;
+            if (kDense) {
+                // Chunks are row-sorted, so the whole wavefront is usually on ONE row, and stays on it for many chunks:
+                // keep a per-lane running sum in registers while the row does not change and touch the LDS accumulator
+                // only when it does (one wave_sum + one ds_add per row per wavefront instead of a 64-way conflicting
+                // atomic per chunk).
+                const uint32_t row0 = __builtin_amdgcn_readfirstlane(row);
+                const bool uniform = __ballot(row == row0) == ~0ull;
+                if (uniform && row0 == c.run_row) {
+                    c.run_sum += prod;
+                } else {
+                    if (c.run_row != Consumer<kFloat>::kNoRow) {
+                        const typename R::prod_t sum = wave_sum(c.run_sum);
+                        if (c.lane == 0) R::add(c.ys, c.run_row, sum);
+                    }
+                    if (uniform) { c.run_row = row0; c.run_sum = prod; }
+                    else { c.run_row = Consumer<kFloat>::kNoRow; c.run_sum = 0; R::add(c.ys, row, prod); }   // chunk straddles rows
+                }
+            } else {
+                R::add(c.ys, row, prod);
+            }
+        }
+    }
+    Ring<kDelta>::template issue<K>(c.stream, min(s + kDepth, c.last) * kStride, c.lane_off);
+    return true;
+}
+
+template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense, int... Ks>
+__device__ __forceinline__ bool consume_round(Consumer<kFloat>& c, std::integer_sequence<int, Ks...>) {
+    return (consume_step<kFloat, kDelta, kAblate, kDepth, kDense, Ks>(c) && ...);
+}
+template <bool kDelta, int... Ks>
+__device__ __forceinline__ void prime_ring(const uint8_t* stream, uint32_t last, uint32_t stride, uint32_t lane_off, std::integer_sequence<int, Ks...>) {
+    (Ring<kDelta>::template issue<Ks>(stream, min(static_cast<uint32_t>(Ks), last) * stride, lane_off), ...);
+}
+
+template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense>
+__device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit* __restrict__ unit, uint32_t U, uint32_t wave, uint32_t lane,
+                                              const uint32_t* xs, uint32_t ring, typename Rows<kFloat>::acc_t* ys, uint32_t nrows) {
+    static_assert(kDepth <= kMaxDepth, "the ring lives in a0..a31");
+    constexpr uint32_t kStride = kDelta ? kRecordBytes : kWaveStrideBytes;
+    const uint32_t total = unit[U - 1].end_step[wave];
+    Consumer<kFloat> c;
+    c.stream = scalar_pointer(stream);
+    c.unit = unit; c.U = U; c.wave = wave; c.lane = lane; c.ring = ring; c.nrows = nrows;
+    c.lane_off = lane * Ring<kDelta>::kLaneBytes;
+    c.last = total ? total - 1 : 0;    // prefetches past the end re-read the last chunk / record (no branch)
+    c.xs = xs; c.xb = xs; c.ys = ys;
+    c.end = unit[0].end_step[wave];
+    if (kAblate & 64) { c.u = U - 1; c.end = total; }   // profiling: one unit per block
+    // The loader branch of the kernel leaves "LDS-DMA may be pending" in hipcc's wait-count bookkeeping, and that state
+    // reaches this loop around the block loop: every LDS store on a conditional path below would then get its own
+    // s_waitcnt vmcnt(0) and drain the prefetch ring.  A consumer wavefront never has LDS-DMA in flight, so say so once,
+    // up front, where nothing is in flight yet.
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), lgkmcnt/expcnt untouched
+    prime_ring<kDelta>(c.stream, c.last, kStride, c.lane_off, std::make_integer_sequence<int, kDepth>());
+    for (;; c.base += kDepth)
+        if (!consume_round<kFloat, kDelta, kAblate, kDepth, kDense>(c, std::make_integer_sequence<int, kDepth>())) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory", HS_RING_AGPRS);   // the clamped tail prefetches must land before the ring is reused
 }
 
 // kDepth: element loads in flight per lane (kDepth x 512 B per wavefront).
 // kAblate (profiling builds only, HISPARSE_ABLATE): bit 0 = no LDS accumulate, bit 1 = no LDS gather,
 // bit 2 = no x sub-tile refill, bit 3 = no per-sub-tile barrier, bit 4 = no block prologue (zero + first sub-tile),
 // bit 5 = no result store, bit 6 = ignore unit boundaries.  Any non-zero value gives wrong results.
-template <bool kFloat, int kAblate, int kDepth>
+// kDelta: the image is in the DELTA stream format (stream_tiles.h), otherwise PAIRS.
+template <bool kFloat, bool kDelta, int kAblate, int kDepth>
 __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const Unit* __restrict__ units, const uint32_t* __restrict__ wg_first,
                                                                   const uint32_t* __restrict__ block_order, const uint32_t* __restrict__ x,
-                                                                  uint32_t* __restrict__ out, int32_t row_part_filter, uint32_t ring) {
+                                                                  uint32_t* __restrict__ out, int32_t row_part_filter, uint32_t ring,
+                                                                  uint32_t x_base) {
     using acc_t = typename Rows<kFloat>::acc_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint32_t* xs = reinterpret_cast<uint32_t*>(lds);             // [ring][kSubTileCols]
-    acc_t* ys = reinterpret_cast<acc_t*>(lds + ring * kBufBytes); // [nrows + 1]
+    acc_t* ys = reinterpret_cast<acc_t*>(lds);                    // [nrows + 1] at LDS address 0: row addresses need no base add
+    uint32_t* xs = reinterpret_cast<uint32_t*>(lds + x_base);     // [ring][kSubTileCols]
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWaveLanes - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWaveLanes);
@@ -344,9 +373,9 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 }
             } else {
                 // ---- consumer wavefronts: stream elements, gather x, accumulate rows -----------------------------
-                const uint8_t* stream = image + blk->wave_offset[wave] + lane * 8u;
-                if (blk->flags & kBlockDenseRows) consume_block<kFloat, kAblate, kDepth, true>(stream, unit, U, wave, lane, xs, ring, ys);
-                else consume_block<kFloat, kAblate, kDepth, false>(stream, unit, U, wave, lane, xs, ring, ys);
+                const uint8_t* stream = image + blk->wave_offset[wave];
+                if (!kDelta && (blk->flags & kBlockDenseRows)) consume_block<kFloat, false, kAblate, kDepth, true>(stream, unit, U, wave, lane, xs, ring, ys, nrows);
+                else consume_block<kFloat, kDelta, kAblate, kDepth, false>(stream, unit, U, wave, lane, xs, ring, ys, nrows);
             }
         }
         // every sub-tile barrier has passed: the accumulators are final
@@ -374,9 +403,9 @@ __global__ __launch_bounds__(256) void combine_slices_kernel(const uint32_t* __r
     }
 }
 
-template <bool kFloat, int kAblate, int kDepth>
+template <bool kFloat, bool kDelta, int kAblate, int kDepth>
 hipError_t configure_one(uint32_t lds_bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_rowblock_kernel<kFloat, kAblate, kDepth>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_rowblock_kernel<kFloat, kDelta, kAblate, kDepth>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
 }
 
@@ -387,20 +416,24 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
+// LDS plan: 64-bit (fixed) / 32-bit (float, upper half unused) row accumulators first, then the ring of x buffers.
+static uint32_t accumulator_bytes(uint32_t max_block_rows) { return ((max_block_rows + 1) * 8u + 15u) & ~15u; }
+
 uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers) {
-    return ring_buffers * kBufBytes + (max_block_rows + 1) * 8u;
+    return accumulator_bytes(max_block_rows) + ring_buffers * kBufBytes;
 }
 
-#define HS_FOR_EACH_VARIANT(X) \
-    X(true, 0, 8) X(false, 0, 8) X(false, 0, 16) X(false, 3, 8) X(false, 4, 8) X(false, 8, 8) X(false, 15, 8) X(false, 79, 8) X(false, 127, 8) X(false, 31, 8) X(false, 47, 8)
+// (float, delta, ablate, depth): the product variants first, then the profiling builds (fixed point only)
+#define HS_FOR_EACH_VARIANT(X)                                                                                   \
+    X(true, false, 0, 8) X(true, true, 0, 8) X(false, false, 0, 8) X(false, true, 0, 8)                           \
+    X(false, false, 0, 16) X(false, true, 0, 16) X(false, false, 3, 8) X(false, true, 3, 8)                       \
+    X(false, false, 15, 8) X(false, true, 15, 8) X(false, false, 31, 8) X(false, true, 31, 8)                     \
+    X(false, false, 47, 8) X(false, true, 47, 8) X(false, false, 79, 8) X(false, true, 79, 8)                     \
+    X(false, false, 127, 8) X(false, true, 127, 8)
 
 hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
     hipError_t e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_gather_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 static_cast<int>(lds_bytes))) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_gather_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 static_cast<int>(lds_bytes))) != hipSuccess) return e;
-#define X(F, A, D) if ((e = configure_one<F, A, D>(lds_bytes)) != hipSuccess) return e;
+#define X(F, T, A, D) if ((e = configure_one<F, T, A, D>(lds_bytes)) != hipSuccess) return e;
     HS_FOR_EACH_VARIANT(X)
 #undef X
     return hipSuccess;
@@ -409,21 +442,15 @@ hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
 hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.num_workgroups == 0) return hipSuccess;
     const dim3 grid(a.num_workgroups), block(kThreads);
-    if (a.ring_buffers == 0) {   // gather mode
-        if (is_float) hipLaunchKernelGGL(spmv_gather_kernel<true>, grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.wg_first,
-                                         a.block_order, a.x, a.out, a.row_part_filter);
-        else hipLaunchKernelGGL(spmv_gather_kernel<false>, grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.wg_first,
-                                a.block_order, a.x, a.out, a.row_part_filter);
-        return hipGetLastError();
-    }
+    const uint32_t x_base = a.lds_bytes - a.ring_buffers * kBufBytes;
     // profiling aids: HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the prefetch depth
     static const int ablate = env_int("HISPARSE_ABLATE", 0), depth = env_int("HISPARSE_DEPTH", 8);
     bool launched = false;
-#define X(F, A, D)                                                                                                           \
-    if (!launched && is_float == F && (F || (ablate == A && depth == D))) {                                                  \
-        hipLaunchKernelGGL((spmv_rowblock_kernel<F, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \
-                           a.wg_first, a.block_order, a.x, a.out, a.row_part_filter, a.ring_buffers);                         \
-        launched = true;                                                                                                     \
+#define X(F, T, A, D)                                                                                                           \
+    if (!launched && is_float == F && a.delta == T && (F || (ablate == A && depth == D))) {                                     \
+        hipLaunchKernelGGL((spmv_rowblock_kernel<F, T, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \
+                           a.wg_first, a.block_order, a.x, a.out, a.row_part_filter, a.ring_buffers, x_base);                   \
+        launched = true;                                                                                                        \
     }
     HS_FOR_EACH_VARIANT(X)
 #undef X

@@ -114,12 +114,17 @@ WalkResult walk_channel_partition(const Layout& L, const MatPkt* buf, uint64_t n
 }
 
 struct UnitPlan {           // host-side companion of a device Unit
-    uint64_t n = 0;         // real elements
+    uint32_t n = 0;         // real elements
+    uint64_t scratch = 0;   // index of the unit's first element in the position-sorted scratch list
+    // PAIRS
     uint32_t chunks = 0;    // ceil(n / 64)
     uint32_t base = 0;      // chunk counter of the block at the unit's first chunk
-    bool dense = false;     // row-sorted, linear dealing (Block::flags & kBlockDenseRows)
-    size_t row_cursor = 0;  // dense: index of this unit's per-row cursors in `dense_cnt`
-    uint32_t start_step[kConsumerWaves];
+    uint32_t start_step[kConsumerWaves];   // chunk index of the unit's first chunk in wavefront w's stream
+    // DELTA
+    uint64_t slots = 0;     // elements + bridge slots
+    uint32_t run_len[kConsumerWaves];      // slots per lane of wavefront w in this unit
+    uint64_t first_slot[kConsumerWaves];   // first slot of lane 0 of wavefront w
+    uint32_t start_record[kConsumerWaves]; // record index of the unit's head record in wavefront w's stream
 };
 
 }  // namespace
@@ -179,22 +184,21 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             if (fill_us + combine_us < best) { best = fill_us + combine_us; slices = cs; }
         }
     }
-    // gather mode: with the best LDS plan, how many non-zeros would one (row range, sub-tile) unit hold?
-    {
-        const uint32_t cap = slices > 1 ? kMaxSlicedBlockRows : kMaxBlockRows;
-        const uint64_t ranges_est = std::max<uint64_t>((G + slices - 1) / slices, (uint64_t(num_rows) + cap - 1) / cap);
-        const double per_unit = double(out.nnz) / (double(ranges_est) * double(CP) * double(S));
-        const char* mode = std::getenv("HISPARSE_XMODE");
-        // Measured on MI355X: uncoalesced 4-byte gathers run at ~0.8 lanes/clk/CU (ogbl-ppa 218 us vs 62 us with LDS
-        // staging; ogbn-products 907 us vs 780-880 us), so gather mode never wins today.  It stays selectable
-        // (HISPARSE_XMODE=gather) as the tested fallback for matrices whose units are tiny; `per_unit` is what a
-        // future heuristic would look at.
-        (void)per_unit;
-        out.gather_x = mode && std::string(mode) == "gather";
-        if (out.gather_x) slices = 1;
-    }
     out.col_slices = slices;
-    const uint32_t max_rows = out.gather_x ? kMaxGatherBlockRows : (slices > 1 ? kMaxSlicedBlockRows : kMaxBlockRows);
+    const uint32_t max_rows = slices > 1 ? kMaxSlicedBlockRows : kMaxBlockRows;
+
+    // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse ---------------------
+    {
+        const double mean_gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 0.0;
+        out.format = (mean_gap >= kDeltaMinMeanGap && mean_gap <= kDeltaMaxMeanGap) ? kFormatDelta : kFormatPairs;
+        if (const char* force = std::getenv("HISPARSE_STREAM_FORMAT")) {
+            const std::string f(force);
+            if (f == "pairs") out.format = kFormatPairs;
+            else if (f == "delta") out.format = kFormatDelta;
+            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs or delta"; return false; }
+        }
+    }
+    const bool delta = out.format == kFormatDelta;
 
     // ---- row ranges: equal non-zero count, <= max_rows rows, never across a row partition ---------------------------
     struct Range { uint32_t row0, nrows, row_part; };
@@ -233,60 +237,37 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         out.max_block_rows = std::max(out.max_block_rows, ranges[b].nrows);
     }
     const uint32_t ring_fit = (kMaxLdsBytes - (out.max_block_rows + 1) * 8u) / (kSubTileCols * 4u);
-    out.ring_buffers = out.gather_x ? 0u : std::max(kMinXBuffers, std::min(kMaxXBuffers, ring_fit));
+    out.ring_buffers = std::max(kMinXBuffers, std::min(kMaxXBuffers, ring_fit));
 
-    // dense-row blocks additionally count per (sub-tile, row): their units are stored sorted by row
-    std::vector<size_t> dense_base(NR, SIZE_MAX);
-    size_t dense_total = 0;
-    for (uint32_t b = 0; b < NR; ++b)
-        if (ranges[b].nrows <= kDenseBlockRows && range_nnz[b] >= 64ull * ranges[b].nrows) {
-            dense_base[b] = dense_total;
-            dense_total += size_t(CP) * S * ranges[b].nrows;
-        }
-    std::vector<uint32_t> dense_cnt(dense_total, 0);
-    auto dense_slot = [&](uint32_t b, uint32_t cp, uint32_t s, uint32_t local_row) {
-        return dense_base[b] + (size_t(cp) * S + s) * ranges[b].nrows + local_row;
-    };
-
-    // ---- pass 1: elements per (block, column partition, sub-tile, source channel) -------------------
-    const size_t slots_per_block = size_t(CP) * S * NUM_HBM_CHANNELS;
-    std::vector<uint32_t> cnt(size_t(NR) * slots_per_block, 0);
-    auto slot = [&](uint32_t b, uint32_t cp, uint32_t s, uint32_t pc) { return size_t(b) * slots_per_block + (size_t(cp) * S + s) * NUM_HBM_CHANNELS + pc; };
+    // ---- pass 1: elements per (row range, column partition, sub-tile, source channel) -------------------
+    const size_t slots_per_range = size_t(CP) * S * NUM_HBM_CHANNELS;
+    std::vector<uint32_t> cnt(size_t(NR) * slots_per_range, 0);
+    auto slot = [&](uint32_t b, uint32_t cp, uint32_t s, uint32_t pc) { return size_t(b) * slots_per_range + (size_t(cp) * S + s) * NUM_HBM_CHANNELS + pc; };
     std::vector<WalkResult> res1(size_t(RP) * CP * NUM_HBM_CHANNELS);
     parallel_for(res1.size(), [&](size_t w) {
         const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP), rp = uint32_t(w / NUM_HBM_CHANNELS / CP);
         res1[w] = walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t) {
-            const uint32_t b = block_of_row[row], s = col / L.sub_width;
-            cnt[slot(b, cp, s, pc)]++;
-            if (dense_base[b] != SIZE_MAX) dense_cnt[dense_slot(b, cp, s, row - ranges[b].row0)]++;   // a row belongs to one channel: no race
+            cnt[slot(block_of_row[row], cp, col / L.sub_width, pc)]++;
         });
     });
     for (const auto& r : res1)
         if (!r.ok) { error = r.error; return false; }
 
-    // ---- plan units and wavefront streams ---------------------------------------------------------------
-    const bool rotate = [] { const char* e = std::getenv("HISPARSE_ROTATE"); return e ? std::atoi(e) != 0 : false; }();
+    // ---- enumerate blocks (row range x column slice) and their units; counts -> offsets into a scratch element list ----
     std::vector<UnitPlan> plans;
     std::vector<uint32_t> unit_of(size_t(NR) * CP * S, 0xffffffffu);  // (row range, cp, s) -> unit index
-    std::vector<uint64_t> block_nnz;
-    uint64_t image_bytes = 0;
     const uint32_t sub_tiles = CP * S;
+    uint64_t scratch_elems = 0;
     for (uint32_t b = 0; b < NR; ++b) {
         for (uint32_t slice = 0; slice < slices; ++slice) {   // device block index = b * slices + slice
             Block blk{};
             blk.row0 = ranges[b].row0;
             blk.nrows = ranges[b].nrows;
             blk.row_part = ranges[b].row_part;
-            blk.flags = dense_base[b] != SIZE_MAX ? kBlockDenseRows : 0u;
+            blk.flags = (!delta && ranges[b].nrows <= kDenseBlockRows && range_nnz[b] >= 64ull * ranges[b].nrows) ? kBlockDenseRows : 0u;
             blk.out_offset = slices > 1 ? slice * num_rows + ranges[b].row0 : ranges[b].row0;
             blk.unit_begin = uint32_t(out.units.size());
-            uint32_t pos[kConsumerWaves] = {0};   // stream position of every wavefront, in steps
-            uint32_t chunk_counter = 0;
-            uint64_t elems = 0;
-            // HISPARSE_ROTATE=1 (experiment, off by default: measured neutral) starts every block at a different sub-tile
-            const uint32_t rot = rotate ? uint32_t((uint64_t(b) * 0x9e3779b1u) % sub_tiles) : 0u;
-            for (uint32_t k0 = 0; k0 < sub_tiles; ++k0) {
-                const uint32_t k = (k0 + rot) % sub_tiles;
+            for (uint32_t k = 0; k < sub_tiles; ++k) {
                 if (k % slices != slice) continue;                    // sub-tiles are dealt round-robin to the column slices
                 const uint32_t cp = k / S, s = k % S;
                 uint64_t n = 0;
@@ -296,46 +277,92 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                     n += c;
                 }
                 if (n == 0) continue;
-                if (n > 0xffffffffull) { error = "unit too large"; return false; }
+                if (n > 0x7fffffffull) { error = "unit too large"; return false; }
                 UnitPlan up;
-                up.n = n;
-                up.chunks = uint32_t((n + kWaveLanes - 1) / kWaveLanes);
-                up.base = chunk_counter;
-                if (dense_base[b] != SIZE_MAX) {   // per-row counts -> exclusive offsets (the fill pass bumps them)
-                    up.dense = true;
-                    up.row_cursor = dense_slot(b, cp, s, 0);
-                    uint32_t acc = 0;
-                    for (uint32_t r = 0; r < blk.nrows; ++r) {
-                        const uint32_t c = dense_cnt[up.row_cursor + r];
-                        dense_cnt[up.row_cursor + r] = acc;
-                        acc += c;
-                    }
-                }
+                up.n = uint32_t(n);
+                up.scratch = scratch_elems;
+                scratch_elems += n;
                 Unit u{};
                 u.col0 = uint32_t(uint64_t(cp) * geom.logical_vb + uint64_t(s) * L.sub_width);
                 u.ncols = std::min<uint32_t>(L.sub_width, L.cols_in_part(cp) - s * L.sub_width);
-                for (uint32_t w = 0; w < kConsumerWaves; ++w) up.start_step[w] = pos[w];
-                for (uint32_t c = 0; c < up.chunks; ++c) pos[(chunk_counter + c) % kConsumerWaves]++;
-                chunk_counter += up.chunks;
-                for (uint32_t w = 0; w < kConsumerWaves; ++w) u.end_step[w] = pos[w];
                 unit_of[(size_t(b) * CP + cp) * S + s] = uint32_t(out.units.size());
                 out.units.push_back(u);
                 plans.push_back(up);
-                out.elements += uint64_t(up.chunks) * kWaveLanes;
-                elems += n;
             }
             blk.unit_end = uint32_t(out.units.size());
-            // chunks are stored in dealing order (global chunk g of the block at g * 512 bytes; wavefront w consumes
-            // g = w, w + 14, w + 28, ...): the 14 wavefronts of a workgroup sweep ONE contiguous region together instead of
-            // 14 separate ones (3584 independent sequential streams chip-wide thrash the DRAM row buffers: measured 5.5 vs
-            // 7.0 TB/s for a plain streaming read)
-            for (uint32_t w = 0; w < kConsumerWaves; ++w) blk.wave_offset[w] = image_bytes + uint64_t(w) * kChunkBytes;
-            image_bytes += uint64_t(chunk_counter) * kChunkBytes;
             out.blocks.push_back(blk);
-            block_nnz.push_back(elems);
         }
     }
     const uint32_t NB = uint32_t(out.blocks.size());
+    const uint32_t NU = uint32_t(out.units.size());
+
+    // ---- pass 2: collect every unit's elements as (position, value), position = local_row * 8192 + local_col -------
+    std::vector<uint64_t> scratch(scratch_elems);   // high word position, low word value: sorts by position
+    parallel_for(res1.size(), [&](size_t w) {
+        const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP), rp = uint32_t(w / NUM_HBM_CHANNELS / CP);
+        walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t val) {
+            const uint32_t b = block_of_row[row], s = col / L.sub_width;
+            const UnitPlan& up = plans[unit_of[(size_t(b) * CP + cp) * S + s]];
+            const uint32_t pos = (row - ranges[b].row0) * kSubTileCols + (col - s * L.sub_width);
+            scratch[up.scratch + cnt[slot(b, cp, s, pc)]++] = (uint64_t(pos) << 32) | val;
+        });
+    });
+    std::vector<uint32_t>().swap(cnt);
+
+    // ---- per unit: sort by position; DELTA: count slots (elements + bridges for gaps that do not fit 16 bits) -------
+    parallel_for(NU, [&](size_t u) {
+        UnitPlan& up = plans[u];
+        uint64_t* e = scratch.data() + up.scratch;
+        std::sort(e, e + up.n);
+        uint64_t slots = up.n;
+        for (uint32_t i = 1; delta && i < up.n; ++i) {
+            const uint64_t d = (e[i] >> 32) - (e[i - 1] >> 32);
+            if (d > kMaxGap) slots += (d - kMaxGap + kBridgeAdvance - 1) / kBridgeAdvance;
+        }
+        up.slots = slots;
+    });
+
+    // ---- per block: deal every unit's 64-slot chunks to the consumer wavefronts round-robin; lay out the streams -------
+    std::vector<uint64_t> block_nnz(NB, 0);
+    uint64_t image_bytes = 0;
+    for (uint32_t bi = 0; bi < NB; ++bi) {
+        Block& blk = out.blocks[bi];
+        uint32_t pos[kConsumerWaves] = {0};   // chunk / record position of every wavefront in its stream
+        uint32_t chunk_counter = 0;
+        for (uint32_t u = blk.unit_begin; u < blk.unit_end; ++u) {
+            UnitPlan& up = plans[u];
+            if (up.slots > 0x7fffffffull) { error = "unit too large"; return false; }
+            const uint32_t chunks = uint32_t((up.slots + kWaveLanes - 1) / kWaveLanes);
+            uint32_t run[kConsumerWaves] = {0};
+            for (uint32_t c = 0; c < chunks; ++c) run[(chunk_counter + c) % kConsumerWaves]++;
+            up.chunks = chunks;
+            up.base = chunk_counter;
+            chunk_counter += chunks;
+            uint64_t first = 0;
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+                up.run_len[w] = run[w];
+                up.first_slot[w] = first;
+                first += uint64_t(run[w]) * kWaveLanes;
+                up.start_step[w] = up.start_record[w] = pos[w];
+                // DELTA: one head record (absolute positions) in front of the wavefront's records of this unit
+                pos[w] += delta ? (run[w] ? run[w] + 1 : 0) : run[w];
+                out.units[u].end_step[w] = pos[w];
+            }
+            out.elements += uint64_t(chunks) * kWaveLanes;
+            block_nnz[bi] += up.n;
+        }
+        if (delta) {
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+                blk.wave_offset[w] = image_bytes;
+                image_bytes += uint64_t(pos[w]) * kRecordBytes;
+            }
+        } else {
+            // chunks are stored in dealing order (global chunk g of the block at g * 512 bytes; wavefront w consumes
+            // g = w, w + 14, w + 28, ...): the 14 wavefronts of a workgroup sweep ONE contiguous region together
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) blk.wave_offset[w] = image_bytes + uint64_t(w) * kChunkBytes;
+            image_bytes += uint64_t(chunk_counter) * kChunkBytes;
+        }
+    }
 
     // ---- workgroups: longest-processing-time assignment of blocks ------------------------------------------
     {
@@ -359,40 +386,73 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         out.wg_first[groups] = uint32_t(out.block_order.size());
     }
 
-    // ---- pass 2: scatter the elements into the wavefront streams -------------------------------------------
     out.image.assign(image_bytes, 0);
     uint8_t* image = out.image.data();
-    // normal units: slot (chunk c, lane l) holds element l * chunks + c (neighbouring lanes far apart in the unit);
-    // dense-row units: element i sits in chunk i / 64, lane i % 64 of the row-sorted unit.
-    auto element_address = [&](const Block& blk, const UnitPlan& up, uint64_t i) -> uint8_t* {
-        const uint32_t lane = up.dense ? uint32_t(i % kWaveLanes) : uint32_t(i / up.chunks);
-        const uint32_t c = up.dense ? uint32_t(i / kWaveLanes) : uint32_t(i % up.chunks);
-        const uint32_t g = up.base + c, w = g % kConsumerWaves;
-        const uint32_t first = up.base + (w + kConsumerWaves - up.base % kConsumerWaves) % kConsumerWaves;  // first chunk of wave w in this unit
-        const uint32_t step = up.start_step[w] + (g - first) / kConsumerWaves;
-        return image + blk.wave_offset[w] + uint64_t(step) * kWaveStrideBytes + lane * 8;
-    };
-    parallel_for(res1.size(), [&](size_t w) {
-        const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP), rp = uint32_t(w / NUM_HBM_CHANNELS / CP);
-        walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t val) {
-            const uint32_t b = block_of_row[row], s = col / L.sub_width;
-            const Block& blk = out.blocks[size_t(b) * slices + (cp * S + s) % slices];
-            const UnitPlan& up = plans[unit_of[(size_t(b) * CP + cp) * S + s]];
-            const uint64_t i = up.dense ? dense_cnt[up.row_cursor + (row - blk.row0)]++ : cnt[slot(b, cp, s, pc)]++;
-            uint32_t* e = reinterpret_cast<uint32_t*>(element_address(blk, up, i));
-            e[0] = val;
-            e[1] = ((row - blk.row0) << 16) | (col - s * L.sub_width);
-        });
-    });
-    // padding slots: zero value aimed at the block's scratch row
-    parallel_for(NB, [&](size_t b) {
-        const Block& blk = out.blocks[b];
-        for (uint32_t u = blk.unit_begin; u < blk.unit_end; ++u) {
+    std::vector<uint32_t> block_of_unit(NU);
+    for (uint32_t bi = 0; bi < NB; ++bi)
+        for (uint32_t u = out.blocks[bi].unit_begin; u < out.blocks[bi].unit_end; ++u) block_of_unit[u] = bi;
+
+    if (!delta) {
+        // ---- PAIRS: normal units: slot (chunk c, lane l) holds sorted element l * chunks + c (neighbouring lanes far
+        //      apart in the unit); dense-row units: element i sits in chunk i / 64, lane i % 64 ------------------------------
+        parallel_for(NU, [&](size_t u) {
             const UnitPlan& up = plans[u];
-            for (uint64_t i = up.n; i < uint64_t(up.chunks) * kWaveLanes; ++i) {
-                uint32_t* e = reinterpret_cast<uint32_t*>(element_address(blk, up, i));
-                e[0] = 0;
-                e[1] = blk.nrows << 16;
+            const Block& blk = out.blocks[block_of_unit[u]];
+            const bool dense = blk.flags & kBlockDenseRows;
+            const uint64_t* e = scratch.data() + up.scratch;
+            const uint64_t total = uint64_t(up.chunks) * kWaveLanes;
+            for (uint64_t i = 0; i < total; ++i) {
+                const uint32_t lane = dense ? uint32_t(i % kWaveLanes) : uint32_t(i / up.chunks);
+                const uint32_t c = dense ? uint32_t(i / kWaveLanes) : uint32_t(i % up.chunks);
+                const uint32_t g = up.base + c, w = g % kConsumerWaves;
+                const uint32_t first = up.base + (w + kConsumerWaves - up.base % kConsumerWaves) % kConsumerWaves;  // first chunk of wave w in this unit
+                const uint32_t step = up.start_step[w] + (g - first) / kConsumerWaves;
+                uint32_t* slot = reinterpret_cast<uint32_t*>(image + blk.wave_offset[w] + uint64_t(step) * kWaveStrideBytes + lane * 8);
+                if (i < up.n) {
+                    const uint32_t pos = uint32_t(e[i] >> 32);
+                    slot[0] = uint32_t(e[i]);
+                    slot[1] = ((pos / kSubTileCols) << 16) | (pos % kSubTileCols);
+                } else {            // padding: zero value aimed at the block's scratch row
+                    slot[0] = 0;
+                    slot[1] = blk.nrows << 16;
+                }
+            }
+        });
+        return true;
+    }
+
+    // ---- DELTA: lane l of wavefront w owns run_len[w] consecutive slots of the sorted unit --------------------------------
+    parallel_for(NU, [&](size_t u) {
+        const UnitPlan& up = plans[u];
+        const Block& blk = out.blocks[block_of_unit[u]];
+        const uint64_t* e = scratch.data() + up.scratch;
+        // expand to the slot sequence: gap (16 bit, 0xffff = bridge: advance 65535, no element), value, position after the slot
+        std::vector<uint16_t> gap(up.slots);
+        std::vector<uint32_t> val(up.slots), after(up.slots);
+        uint64_t k = 0;
+        uint32_t at = uint32_t(e[0] >> 32);
+        for (uint32_t i = 0; i < up.n; ++i) {
+            uint64_t d = (e[i] >> 32) - at;
+            while (d > kMaxGap) { at += kBridgeAdvance; d -= kBridgeAdvance; gap[k] = kBridgeGap; val[k] = 0; after[k] = at; ++k; }
+            at += uint32_t(d);
+            gap[k] = uint16_t(d); val[k] = uint32_t(e[i]); after[k] = at; ++k;
+        }
+        const uint16_t pad_gap = geom.impl == IMPL_FIXED ? 0 : kBridgeGap;
+        const uint32_t scratch_pos = blk.nrows * kSubTileCols;   // local row nrows = the scratch accumulator
+        for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+            if (!up.run_len[w]) continue;
+            uint8_t* rec = image + blk.wave_offset[w] + uint64_t(up.start_record[w]) * kRecordBytes;
+            uint32_t* head = reinterpret_cast<uint32_t*>(rec);
+            for (uint32_t l = 0; l < kWaveLanes; ++l) {
+                const uint64_t s0 = up.first_slot[w] + uint64_t(l) * up.run_len[w];
+                // position BEFORE the run's first slot; slot 0 carries gap 0 from the first element's own position
+                head[l] = s0 >= up.slots ? scratch_pos : (s0 == 0 ? uint32_t(e[0] >> 32) : after[s0 - 1]);
+                for (uint32_t j = 0; j < up.run_len[w]; ++j) {
+                    uint8_t* r = rec + uint64_t(j + 1) * kRecordBytes;
+                    const uint64_t si = s0 + j;
+                    reinterpret_cast<uint32_t*>(r)[l] = si < up.slots ? val[si] : 0u;
+                    reinterpret_cast<uint16_t*>(r + kWaveLanes * 4)[l] = si < up.slots ? gap[si] : pad_gap;   // padding: see consume_block
+                }
             }
         }
     });

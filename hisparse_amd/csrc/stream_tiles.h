@@ -13,7 +13,7 @@
 //   the current column partition of x sits in 8 on-chip      the current x SUB-TILE (<= 8192 columns) sits
 //   vector banks, double-buffered (vecbuf_access_unit.h)     in LDS, in a ring of four buffers
 //   the matrix streams past, one packet per cycle            the block's non-zeros stream past as
-//   (spmv_cluster.h:73-98)                                   coalesced 8-byte elements
+//   (spmv_cluster.h:73-98)                                   coalesced 8- or 6-byte elements
 //
 // So at hs_load_matrix time the CPSR image is decoded ONCE on the host and re-cut:
 //   * rows are split into row blocks of roughly equal non-zero count (never across a row partition);
@@ -23,19 +23,31 @@
 //     COLUMN SLICES (sub-tiles dealt round-robin): a block is then (row range, slice), row ranges get
 //     proportionally longer, every workgroup pulls only 1/slices of x through its CU, and a small
 //     combine pass adds the per-slice partial results (saturating sums compose: DESIGN.md §4);
-//   * when x is so large that even then a (row range, sub-tile) unit would hold only a few hundred
-//     non-zeros (ogbn-products: 2.4 M columns), staging sub-tiles in LDS stops paying; the same streams
-//     are then consumed in GATHER mode: no x ring, no loaders, no barriers, x read per element from
-//     L2 / Infinity Cache;
-//   * a unit's elements are dealt to the 12 consumer wavefronts of the workgroup in chunks of 64,
-//     the chunks of a block stored in dealing order so that the workgroup sweeps one contiguous region.  Normally
-//     lane l of chunk c takes element l*chunks + c (neighbouring lanes far apart: no same-row LDS
-//     atomics in one instruction).  Blocks of <= 32 rows (pruned-NN layers: 512 rows x 16 K non-zeros)
-//     would put all 64 lanes on the same one or two accumulators; there the unit is sorted by row and
-//     dealt linearly, so a chunk almost always holds ONE row and the wavefront adds it up in registers.
-// Element = { u32 value word, u32 (local_row << 16 | local_col) } = 8 bytes: markers, lane padding and
-// partition headers are gone, so the bytes read per SpMV equal the reference's "8 bytes per
-// non-zero" throughput definition (sw/benchmark.cpp:312-314) plus < 2 % chunk padding.
+//   * a unit's elements are sorted by position (local_row * 8192 + local_col) and dealt to the 14 consumer
+//     wavefronts of the workgroup in chunks of 64 slots, in one of two STREAM FORMATS chosen per matrix:
+//
+//     PAIRS (8 bytes per element): element = { u32 value word, u32 (local_row << 16 | local_col) }, one
+//       512-byte chunk per wavefront step, the chunks of a block stored in dealing order so that the
+//       workgroup sweeps one contiguous region.  Normally lane l of chunk c takes element l*chunks + c
+//       (neighbouring lanes far apart: no same-row LDS atomics in one instruction).  Blocks of <= 32 rows
+//       (pruned-NN layers: 512 rows x 16 K non-zeros) would put all 64 lanes on the same one or two
+//       accumulators; there the unit is dealt linearly, so a chunk almost always holds ONE row and the
+//       wavefront adds it up in registers.  Bytes read per SpMV = the reference's "8 bytes per non-zero"
+//       throughput definition (sw/benchmark.cpp:312-314) plus < 2 % chunk padding.
+//
+//     DELTA (6 bytes per slot): lane l of wavefront w owns run_len consecutive slots of the sorted unit.
+//       A 384-byte record = 64 x u32 value words followed by 64 x u16 GAPS: the distance from the lane's
+//       previous position.  Every (unit, wavefront) starts with a HEAD record whose value words are the
+//       lanes' absolute start positions.  Gap 0xffff = BRIDGE: no element, advance 65535 (value word 0);
+//       it carries a lane across distances that do not fit 16 bits and pads the float formats' tails
+//       (fixed-point tails are padded with gap 0 / value 0).  Each wavefront's records are contiguous.
+//       On ogbl-ppa this is 6.6 bytes per non-zero all in (heads, bridges, padding) instead of 8.03.
+//
+//     DELTA needs units that are sparse (lanes of one instruction on different rows) but not so sparse that
+//     every other gap needs a bridge: it is chosen when the mean position gap rows*cols/nnz lies in
+//     [kDeltaMinMeanGap, kDeltaMaxMeanGap]; HISPARSE_STREAM_FORMAT=pairs|delta overrides (tests run both).
+//
+// Markers, lane padding and partition headers of the CPSR image are gone in both formats.
 #ifndef HISPARSE_STREAM_TILES_H_
 #define HISPARSE_STREAM_TILES_H_
 
@@ -58,10 +70,17 @@ constexpr uint32_t kMinXBuffers = 2;
 constexpr uint32_t kMaxBlockRows = 4095;                      // one column slice: + 1 scratch slot = 32 KiB of 64-bit accumulators, ring of 4
 constexpr uint32_t kMaxSlicedBlockRows = 12287;               // several column slices: 96 KiB of accumulators, ring of 2
 constexpr uint32_t kMaxColSlices = 8;
-constexpr uint32_t kMaxGatherBlockRows = 16383;               // gather mode: the LDS holds row accumulators only
-constexpr uint32_t kGatherUnitElements = 3000;                // below this many non-zeros per (row range, sub-tile) staging x in LDS does not pay
+// PAIRS format
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
 constexpr uint32_t kWaveStrideBytes = kChunkBytes * kConsumerWaves;   // chunks of the 14 wavefronts are interleaved in memory
+// DELTA format
+constexpr uint32_t kRecordBytes = kWaveLanes * (4 + 2);       // one wavefront step: 64 x u32 value words, then 64 x u16 gaps
+constexpr uint32_t kMaxGap = 0xfffeu;                         // largest position gap an element slot can carry
+constexpr uint32_t kBridgeGap = 0xffffu;                      // gap code of a slot without element ...
+constexpr uint32_t kBridgeAdvance = 0xffffu;                  // ... which advances the position by this much
+constexpr double kDeltaMinMeanGap = 2048.0;                   // denser: lanes of one instruction collide on rows, PAIRS wins (measured)
+constexpr double kDeltaMaxMeanGap = 20000.0;                  // sparser: > 4 % of the gaps need bridges
+enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1 };
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit
@@ -73,15 +92,16 @@ struct Block {
     uint32_t row_part;      // row partition (hs_run_partition filter)
     uint32_t unit_begin;    // units [unit_begin, unit_end), consumed in this order
     uint32_t unit_end;
-    uint32_t flags;         // kBlockDenseRows: few long rows; chunks are row-sorted and mostly hold ONE row
+    uint32_t flags;         // kBlockDenseRows (PAIRS only): few long rows; chunks are dealt linearly and mostly hold ONE row
     uint32_t out_offset;    // word offset of the block's first row in the output: y (one slice) or the per-slice partials
     uint32_t reserved;
-    uint64_t wave_offset[kConsumerWaves];   // byte offset of each consumer wavefront's first chunk; its next is kWaveStrideBytes on
+    uint64_t wave_offset[kConsumerWaves];   // byte offset of each consumer wavefront's first chunk (PAIRS: its next is kWaveStrideBytes on)
+                                            // or of its contiguous record stream (DELTA)
 };
 struct Unit {
     uint32_t col0;          // first absolute column of the x sub-tile
     uint32_t ncols;         // multiple of 8, <= kSubTileCols
-    uint32_t end_step[kConsumerWaves];      // per wavefront: its stream position (in steps) after this unit
+    uint32_t end_step[kConsumerWaves];      // per wavefront: its stream position (in chunks / records, heads included) after this unit
 };
 static_assert(sizeof(Block) == 32 + 8 * kConsumerWaves, "Block layout is shared with the device code");
 static_assert(sizeof(Unit) == 8 + 4 * kConsumerWaves, "Unit layout is shared with the device code");
@@ -95,10 +115,10 @@ struct StreamTiles {
     uint32_t num_workgroups = 0;
     uint32_t max_block_rows = 0;
     uint32_t col_slices = 1;             // > 1: blocks write per-slice partial results, a combine pass adds them
-    uint32_t ring_buffers = kMaxXBuffers; // 0 in gather mode
-    bool gather_x = false;               // x is gathered straight from L2 / Infinity Cache instead of staged in LDS
+    uint32_t ring_buffers = kMaxXBuffers;
+    StreamFormat format = kFormatPairs;
     uint64_t nnz = 0;
-    uint64_t elements = 0;               // element slots including chunk padding
+    uint64_t elements = 0;               // element slots including bridges and chunk padding (DELTA head records not counted)
 };
 
 // Decode + validate + re-tile.  `max_workgroups` = workgroups the device keeps resident (one per CU).

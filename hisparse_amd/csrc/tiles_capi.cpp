@@ -44,7 +44,8 @@ int hs_tiles_build(const void* const channel[HS_NUM_CHANNELS], const uint64_t n_
 }
 
 int hs_tiles_info(const hs_tiles* h, uint64_t* image_bytes, uint32_t* num_blocks, uint32_t* num_units, uint32_t* num_workgroups,
-                  uint32_t* max_block_rows, uint64_t* nnz, uint64_t* elements, uint32_t* col_slices, uint32_t* ring_buffers) {
+                  uint32_t* max_block_rows, uint64_t* nnz, uint64_t* elements, uint32_t* col_slices, uint32_t* ring_buffers,
+                  uint32_t* stream_format) {
     if (!h) return HS_ERR_BAD_ARG;
     if (image_bytes) *image_bytes = h->t.image.size();
     if (num_blocks) *num_blocks = uint32_t(h->t.blocks.size());
@@ -55,6 +56,7 @@ int hs_tiles_info(const hs_tiles* h, uint64_t* image_bytes, uint32_t* num_blocks
     if (elements) *elements = h->t.elements;
     if (col_slices) *col_slices = h->t.col_slices;
     if (ring_buffers) *ring_buffers = h->t.ring_buffers;
+    if (stream_format) *stream_format = h->t.format;
     return HS_OK;
 }
 

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import host
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhisparse_hip.so")
+_LIB_PATH = os.environ.get("HISPARSE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhisparse_hip.so")
 _lib = None
 
 EXPORTS = [
@@ -32,12 +32,14 @@ class DeviceError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("nnz", C.c_uint64), ("cpsr_bytes", C.c_uint64), ("stream_bytes", C.c_uint64), ("stream_elements", C.c_uint64),
                 ("num_blocks", C.c_uint32), ("num_units", C.c_uint32), ("num_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32),
-                ("num_compute_units", C.c_uint32), ("col_slices", C.c_uint32), ("ring_buffers", C.c_uint32), ("load_seconds", C.c_double)]
+                ("num_compute_units", C.c_uint32), ("col_slices", C.c_uint32), ("ring_buffers", C.c_uint32), ("stream_format", C.c_uint32),
+                ("load_seconds", C.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+STREAM_FORMATS = ("pairs", "delta")   # HS_STREAM_PAIRS / HS_STREAM_DELTA
 CONSUMER_WAVES = 14
 # device-side descriptors (hisparse_amd/csrc/stream_tiles.h)
 BLOCK_DTYPE = np.dtype([("row0", "<u4"), ("nrows", "<u4"), ("row_part", "<u4"), ("unit_begin", "<u4"), ("unit_end", "<u4"),
@@ -74,7 +76,7 @@ def lib():
         l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.hs_tiles_build.argtypes = [C.POINTER(vp), C.POINTER(u64), C.c_int, u32, u32, u32, u32, u32, u32, u32, C.POINTER(vp)]
         l.hs_tiles_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64),
-                                    C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
+                                    C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
         l.hs_tiles_copy.argtypes = [vp, vp, vp, vp, vp, vp]
         l.hs_tiles_free.argtypes = [vp]
         l.hs_tiles_free.restype = None
@@ -200,9 +202,9 @@ def build_tiles(packets, impl, ob_bank, vb_bank, num_rows, num_cols, num_row_par
         raise DeviceError(rc, l.hs_tiles_last_error().decode())
     try:
         nbytes, nnz, elems = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        nblocks, nunits, nwg, maxrows, slices, ring = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        nblocks, nunits, nwg, maxrows, slices, ring, fmt = (C.c_uint32() for _ in range(7))
         l.hs_tiles_info(h, C.byref(nbytes), C.byref(nblocks), C.byref(nunits), C.byref(nwg), C.byref(maxrows), C.byref(nnz), C.byref(elems),
-                        C.byref(slices), C.byref(ring))
+                        C.byref(slices), C.byref(ring), C.byref(fmt))
         image = np.zeros(max(nbytes.value, 1), dtype=np.uint8)
         blocks = np.zeros(max(nblocks.value, 1), dtype=BLOCK_DTYPE)
         units = np.zeros(max(nunits.value, 1), dtype=UNIT_DTYPE)
@@ -211,6 +213,7 @@ def build_tiles(packets, impl, ob_bank, vb_bank, num_rows, num_cols, num_row_par
         l.hs_tiles_copy(h, image.ctypes.data, blocks.ctypes.data, units.ctypes.data, wg_first.ctypes.data, order.ctypes.data)
         return dict(image=image[:nbytes.value], blocks=blocks[:nblocks.value], units=units[:nunits.value], wg_first=wg_first,
                     block_order=order[:nblocks.value], num_workgroups=nwg.value, max_block_rows=maxrows.value, nnz=nnz.value,
-                    elements=elems.value, col_slices=slices.value, ring_buffers=ring.value)
+                    elements=elems.value, col_slices=slices.value, ring_buffers=ring.value,
+                    format=STREAM_FORMATS[fmt.value])
     finally:
         l.hs_tiles_free(h)

@@ -56,13 +56,16 @@ enum {
 /* numeric mode == the reference's IMPL make variable (sw/Makefile:2-12) */
 enum { HS_IMPL_FIXED = 0, HS_IMPL_FLOAT_POB = 1, HS_IMPL_FLOAT_STALL = 2 };
 
+/* device-private stream formats (hisparse_amd/csrc/stream_tiles.h) */
+enum { HS_STREAM_PAIRS = 0, HS_STREAM_DELTA = 1 };
+
 typedef struct hs_context hs_context;
 
 typedef struct {
     uint64_t nnz;               /* true non-zeros found in the CPSR image */
     uint64_t cpsr_bytes;        /* bytes of the 16 channel buffers as handed in */
     uint64_t stream_bytes;      /* bytes of the device-private element streams the kernel reads per SpMV */
-    uint64_t stream_elements;   /* 8-byte element slots in those streams (non-zeros + chunk padding) */
+    uint64_t stream_elements;   /* element slots in those streams (non-zeros + bridges + chunk padding) */
     uint32_t num_blocks;        /* row blocks (each owned by one workgroup at a time) */
     uint32_t num_units;         /* (row block, x sub-tile) units */
     uint32_t num_workgroups;    /* grid size of the SpMV kernel */
@@ -70,6 +73,7 @@ typedef struct {
     uint32_t num_compute_units; /* of the device */
     uint32_t col_slices;        /* column slices (1 = none; > 1 adds the small combine pass) */
     uint32_t ring_buffers;      /* x sub-tile buffers in the LDS ring */
+    uint32_t stream_format;     /* HS_STREAM_PAIRS (8 B per element) or HS_STREAM_DELTA (6 B per slot), chosen per matrix */
     double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
 } hs_stats;
 
@@ -127,7 +131,8 @@ int hs_tiles_build(const void* const channel[HS_NUM_CHANNELS], const uint64_t n_
                    uint32_t vb_bank, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
                    uint32_t num_col_partitions, uint32_t max_workgroups, hs_tiles** out);
 int hs_tiles_info(const hs_tiles* t, uint64_t* image_bytes, uint32_t* num_blocks, uint32_t* num_units, uint32_t* num_workgroups,
-                  uint32_t* max_block_rows, uint64_t* nnz, uint64_t* elements, uint32_t* col_slices, uint32_t* ring_buffers);
+                  uint32_t* max_block_rows, uint64_t* nnz, uint64_t* elements, uint32_t* col_slices, uint32_t* ring_buffers,
+                  uint32_t* stream_format);
 /* image: image_bytes; blocks: num_blocks x 128 B; units: num_units x 56 B (layouts: hisparse_amd/csrc/stream_tiles.h);
  * wg_first: num_workgroups + 1; block_order: num_blocks */
 int hs_tiles_copy(const hs_tiles* t, void* image, void* blocks, void* units, uint32_t* wg_first, uint32_t* block_order);

@@ -3,6 +3,8 @@
 Bit-exact for the fixed-point mode; float modes within 1e-4 relative + 1e-4 absolute (north_star:
 1e-4 rel-err; the reference's own verify uses 1e-4 absolute, spmv_csim/csim.cpp:162,172).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,13 @@ import cases
 pytestmark = pytest.mark.gpu
 
 IMPLS = [0, 1, 2]
+
+
+@pytest.fixture(autouse=True, params=["pairs", "delta"])
+def stream_format(request, monkeypatch):
+    # every parity test runs once per device stream format (hisparse_amd/csrc/stream_tiles.h)
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", request.param)
+    return request.param
 
 
 def _run_case(impl, m, vb, ob, skip, seed):
@@ -33,6 +42,7 @@ def _run_case(impl, m, vb, ob, skip, seed):
     stats = eng.stats()
     eng.close()
     assert stats["nnz"] == m.nnz
+    assert device.STREAM_FORMATS[stats["stream_format"]] == os.environ["HISPARSE_STREAM_FORMAT"]
     if impl == 0:
         assert np.array_equal(got, want), f"fixed-point mismatch at {np.nonzero(got != want)[0][:8]}"
         assert np.array_equal(again, want)
@@ -103,19 +113,28 @@ def test_column_slices(impl, slices, monkeypatch):
     _run_case(impl, m, vb=v, ob=o, skip=True, seed=17)
 
 
+def test_repeated_runs_stay_exact():
+    # soak: the hand-counted waits of the stream ring must hold on every launch, not just most (a compiler-inserted
+    # register copy ahead of a wait once made one record in a few million wrong, on some launches only)
+    csr = host.CSRMatrix.generate("powerlaw", 150000, 150000, a=6000000, b=0.35, c=1.0, seed=23)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+    xw = host.pack_vector(0, cases.random_x(cp.num_cols, 23, 0))
+    want = orc.spmv(0, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                    cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+    eng = device.SpmvEngine(0)
+    eng.load_matrix(cp)
+    eng.load_vector(xw)
+    for i in range(40):
+        eng.run()
+        got = eng.read_result()
+        assert np.array_equal(got, want), f"run {i}: {int((got != want).sum())} rows differ"
+    eng.close()
+
+
 @pytest.mark.parametrize("impl", IMPLS)
-def test_gather_mode(impl, monkeypatch):
-    # force the large-x path (x gathered from L2 per element, two hand-counted load pipelines) on an oracle-sized matrix
-    monkeypatch.setenv("HISPARSE_XMODE", "gather")
-    csr = host.CSRMatrix.generate("powerlaw", 50000, 90000, a=1200000, b=0.4, c=1.0 if impl == 0 else 2.0, seed=19)
-    ip, ix, dv = csr.arrays()
-    if impl != 0:
-        dv = (dv - 1.0).astype(np.float32)
-    import scipy.sparse as sp
-    m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(50000, 90000))
+def test_tiny_matrix(impl):
+    # wavefronts with fewer records than the pipeline depth, and wavefronts with none at all
     v, o = host.default_banks(impl)
-    _run_case(impl, m, vb=v, ob=o, skip=True, seed=19)
-    # tiny matrix: wavefronts with fewer chunks than the pipeline depth, and wavefronts with none at all
     _run_case(impl, cases.random_csr(300, 200, 0.05, 3, impl), vb=v, ob=o, skip=True, seed=3)
 
 

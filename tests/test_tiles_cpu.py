@@ -10,6 +10,13 @@ import cases
 import tile_emulator
 
 
+@pytest.fixture(autouse=True, params=["pairs", "delta"])
+def stream_format(request, monkeypatch):
+    # every test of this module runs once per device stream format (stream_tiles.h)
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", request.param)
+    return request.param
+
+
 def build(cp, impl, workgroups):
     return device.build_tiles(cp, impl, cp.ob_bank, cp.vb_bank, cp.num_rows, cp.num_cols, cp.num_row_partitions,
                               cp.num_col_partitions, workgroups)
@@ -39,7 +46,7 @@ def test_emulated_kernel_matches_oracle(impl, skip, rows, cols, density, vb, ob,
         assert cases.float_close(got, want)
 
 
-def test_structure_invariants():
+def test_structure_invariants(stream_format):
     csr = host.CSRMatrix.generate("powerlaw", 30000, 50000, a=600000, b=0.4, c=1.0, seed=3)
     cp = host.format_matrix(csr, 0, skip_empty_rows=True)
     t = build(cp, 0, 64)
@@ -59,9 +66,17 @@ def test_structure_invariants():
     for b in blocks[:5]:
         es = units["end_step"][b["unit_begin"]:b["unit_end"]]
         assert (np.diff(es, axis=0) >= 0).all()
-    # bytes: 8 per element slot, padding below 64 slots per unit
-    assert len(t["image"]) == t["elements"] * 8
-    assert 0 <= t["elements"] - t["nnz"] < 64 * len(units)
+    assert t["format"] == stream_format and t["elements"] >= t["nnz"]
+    if stream_format == "pairs":
+        # bytes: 8 per element slot, padding below 64 slots per unit
+        assert len(t["image"]) == t["elements"] * 8
+        assert t["elements"] - t["nnz"] < 64 * len(units)
+    else:
+        # bytes: 384 per record = 64 x (u32 value + u16 gap); one head record per (unit, wavefront) that has work
+        records = sum(int(units["end_step"][b["unit_end"] - 1].sum()) for b in blocks if b["unit_end"] > b["unit_begin"])
+        assert len(t["image"]) == records * 384
+        heads = records - t["elements"] // 64
+        assert 0 < heads <= 14 * len(units)
     # balance: no workgroup carries more than ~1.5x the mean (power-law rows, 64 groups)
     loads = []
     for g in range(t["num_workgroups"]):
@@ -93,18 +108,33 @@ def test_column_slices(impl, slices, monkeypatch):
     assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
 
 
-@pytest.mark.parametrize("impl", [0, 2])
-def test_gather_mode_layout(impl, monkeypatch):
-    # matrices whose x is too large for LDS staging: same streams, longer row ranges, no x ring
-    monkeypatch.setenv("HISPARSE_XMODE", "gather")
-    csr = host.CSRMatrix.generate("powerlaw", 60000, 90000, a=500000, b=0.4, c=1.0 if impl == 0 else 2.0, seed=5)
-    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
-    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 4, impl))
-    t = build(cp, impl, 8)
-    assert t["ring_buffers"] == 0 and t["col_slices"] == 1 and t["blocks"]["nrows"].max() <= 16383
-    got = tile_emulator.run(t, impl, xw, cp.num_rows)
-    want = oracle_y(cp, impl, xw)
-    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+def test_format_choice(monkeypatch):
+    # unforced: DELTA for sparse-but-not-hyper-sparse matrices (mean position gap rows*cols/nnz in [2048, 20000]), else PAIRS
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    for rows, cols, nnz, want in [(20000, 60000, 150000, "delta"), (3000, 3000, 90000, "pairs"), (60000, 90000, 100000, "pairs")]:
+        csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=nnz, b=0.0, c=1.0, seed=2)
+        cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+        gap = cp.num_rows * cp.num_cols / cp.nnz
+        assert (2048 <= gap <= 20000) == (want == "delta"), gap
+        assert build(cp, 0, 16)["format"] == want
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "bogus")
+    with pytest.raises(device.DeviceError):
+        build(cp, 0, 16)
+
+
+def test_delta_bridges(stream_format):
+    # a hyper-sparse unit: most gaps exceed 16 bits and need bridge slots; rows near the end of a 12287-row block
+    if stream_format != "delta":
+        pytest.skip("bridges exist in the DELTA format only")
+    for impl in (0, 2):
+        csr = host.CSRMatrix.generate("powerlaw", 30000, 40000, a=15000, b=0.0, c=1.0 if impl == 0 else 2.0, seed=8)
+        cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+        xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 9, impl))
+        t = build(cp, impl, 4)
+        assert t["elements"] > 1.3 * t["nnz"]            # bridges are there
+        got = tile_emulator.run(t, impl, xw, cp.num_rows)
+        want = oracle_y(cp, impl, xw)
+        assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
 
 
 def test_many_row_partitions_and_partition_filter():

@@ -1,11 +1,14 @@
 """tests/tile_emulator.py — numpy walk over a row-block stream image, unit for unit what spmv_rowblock_kernel does.
 
 Test infrastructure: lets the CPU-only suite check the load-time re-tiling (stream_tiles.cpp) and the
-kernel's element semantics against the oracle without a GPU.  Never imported by the product.
+kernel's element semantics against the oracle without a GPU, for both stream formats.  Never imported by the product.
 """
 import numpy as np
 
-WAVE, CONSUMERS, CHUNK_BYTES, SUB_TILE = 64, 14, 512, 8192
+WAVE, CONSUMERS, SUB_TILE = 64, 14, 8192
+CHUNK_BYTES = 512            # PAIRS: 64 x {u32 value, u32 row << 16 | col}
+RECORD_BYTES = 384           # DELTA: 64 x u32 value, then 64 x u16 gap
+BRIDGE = 0xFFFF
 
 
 def _q_mul(a, b):
@@ -14,15 +17,84 @@ def _q_mul(a, b):
     return np.minimum(r, np.uint64(0xFFFFFFFF))
 
 
+def _accumulate(ys, is_float, row, val, xv):
+    if is_float:
+        np.add.at(ys, row, (val.view(np.float32) * xv.view(np.float32)).astype(np.float32))
+    else:
+        np.add.at(ys, row, _q_mul(val, xv))
+
+
+def _block_pairs(image, blk, units, x_words, ys, is_float):
+    nrows = int(blk["nrows"])
+    step = [0] * CONSUMERS
+    for u in range(int(blk["unit_begin"]), int(blk["unit_end"])):
+        unit = units[u]
+        col0, ncols = int(unit["col0"]), int(unit["ncols"])
+        xt = x_words[col0: col0 + ncols]
+        for w in range(CONSUMERS):
+            end = int(unit["end_step"][w])
+            base = int(blk["wave_offset"][w])
+            for s in range(step[w], end):
+                at = base + s * CHUNK_BYTES * CONSUMERS
+                chunk = image[at: at + CHUNK_BYTES].view(np.uint32).reshape(WAVE, 2)
+                val, cr = chunk[:, 0], chunk[:, 1]
+                col, row = (cr & 0xFFFF).astype(np.int64), (cr >> 16).astype(np.int64)
+                assert (col < ncols).all() and (row <= nrows).all()
+                assert (val[row == nrows] == 0).all()                 # padding aims a zero at the spare accumulator
+                _accumulate(ys, is_float, row, val, xt[col])
+            step[w] = end
+
+
+def _block_delta(image, blk, units, x_words, ys, is_float):
+    nrows = int(blk["nrows"])
+    step = [0] * CONSUMERS
+    for u in range(int(blk["unit_begin"]), int(blk["unit_end"])):
+        unit = units[u]
+        col0, ncols = int(unit["col0"]), int(unit["ncols"])
+        xt = np.zeros(SUB_TILE, dtype=np.uint32)                        # the LDS buffer: stale words past ncols
+        xt[:ncols] = x_words[col0: col0 + ncols]
+        for w in range(CONSUMERS):
+            end = int(unit["end_step"][w])
+            base = int(blk["wave_offset"][w])
+            assert end >= step[w] and end != step[w] + 1              # a (unit, wavefront) has no records, or head + >= 1
+            pos = None
+            for s in range(step[w], end):
+                rec = image[base + s * RECORD_BYTES: base + (s + 1) * RECORD_BYTES]
+                val = rec[:WAVE * 4].view(np.uint32)
+                gap = rec[WAVE * 4:].view(np.uint16).astype(np.int64)
+                if pos is None:                                         # head record: absolute start position per lane
+                    pos = val.astype(np.int64)
+                    assert (pos <= nrows * SUB_TILE).all()
+                    continue
+                pos = (pos + gap) & 0xFFFFFFFF                          # u32 arithmetic like the kernel
+                row, col = pos >> 13, pos & (SUB_TILE - 1)
+                live = gap != BRIDGE
+                if is_float:
+                    # bridge slots add a literal zero at min(row, nrows); live slots must be real positions
+                    assert (row[live] < nrows).all() and (col[live] < ncols).all()
+                    _accumulate(ys, True, row[live], val[live], xt[col[live]])
+                else:
+                    # no live test in the fixed-point kernel: every slot multiplies; dead slots carry value 0 and must
+                    # still aim at an accumulator of the block (or the spare one)
+                    assert (row <= nrows).all() and (val[~live] == 0).all()
+                    real = live & (val != 0)
+                    assert (row[real] < nrows).all() and (col[real] < ncols).all()
+                    _accumulate(ys, False, row, val, xt[col])
+            step[w] = end
+
+
 def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
     """Returns packed y words.  tiles: dict from hisparse_amd.device.build_tiles."""
     is_float = impl != 0
     image, blocks, units = tiles["image"], tiles["blocks"], tiles["units"]
+    delta = tiles["format"] == "delta"
     y = np.zeros(num_rows, dtype=np.uint32) if y_init is None else y_init.copy()
     slices = int(tiles.get("col_slices", 1))
     out = y if slices == 1 else np.zeros(slices * num_rows, dtype=np.uint32)   # per-slice partial results
     touched = np.zeros(num_rows, dtype=bool)
     done = np.zeros(len(blocks), dtype=bool)
+    assert 2 <= tiles["ring_buffers"] <= 4
+    assert (units["ncols"] % 8 == 0).all() and (units["ncols"] > 0).all() and (units["ncols"] <= SUB_TILE).all()
     for g in range(tiles["num_workgroups"]):
         for q in range(tiles["wg_first"][g], tiles["wg_first"][g + 1]):
             b = int(tiles["block_order"][q])
@@ -32,32 +104,11 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
             if row_part_filter >= 0 and int(blk["row_part"]) != row_part_filter:
                 continue
             nrows, row0, out0 = int(blk["nrows"]), int(blk["row0"]), int(blk["out_offset"])
-            gather = tiles["ring_buffers"] == 0            # gather mode: no x ring, only row accumulators in LDS
-            assert nrows <= (16383 if gather else 4095 if slices == 1 else 12287)
+            assert nrows <= (4095 if slices == 1 else 12287)
             assert out0 % num_rows == row0 and out0 // num_rows < slices
-            assert gather or 2 <= tiles["ring_buffers"] <= 4
             touched[row0: row0 + nrows] = True
             ys = np.zeros(nrows + 1, dtype=np.float32 if is_float else np.uint64)
-            pos = [0] * CONSUMERS
-            for u in range(int(blk["unit_begin"]), int(blk["unit_end"])):
-                unit = units[u]
-                col0, ncols = int(unit["col0"]), int(unit["ncols"])
-                assert ncols % 8 == 0 and 0 < ncols <= SUB_TILE
-                xt = x_words[col0: col0 + ncols]
-                for w in range(CONSUMERS):
-                    end = int(unit["end_step"][w])
-                    base = int(blk["wave_offset"][w])
-                    for s in range(pos[w], end):
-                        chunk = image[base + s * CHUNK_BYTES * CONSUMERS: base + s * CHUNK_BYTES * CONSUMERS + CHUNK_BYTES].view(np.uint32).reshape(WAVE, 2)
-                        val, cr = chunk[:, 0], chunk[:, 1]
-                        col, row = (cr & 0xFFFF).astype(np.int64), (cr >> 16).astype(np.int64)
-                        assert (col < ncols).all() and (row <= nrows).all()
-                        xv = xt[col]
-                        if is_float:
-                            np.add.at(ys, row, (val.view(np.float32) * xv.view(np.float32)).astype(np.float32))
-                        else:
-                            np.add.at(ys, row, _q_mul(val, xv))
-                    pos[w] = end
+            (_block_delta if delta else _block_pairs)(image, blk, units, x_words, ys, is_float)
             if is_float:
                 out[out0: out0 + nrows] = ys[:nrows].view(np.uint32)
             else:
