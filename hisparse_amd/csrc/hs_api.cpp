@@ -37,8 +37,6 @@ struct hs_context {
     uint8_t* d_image = nullptr;
     Block* d_blocks = nullptr;
     Unit* d_units = nullptr;
-    uint32_t* d_wg_first = nullptr;
-    uint32_t* d_block_order = nullptr;
     uint32_t num_workgroups = 0;
     uint32_t lds_bytes = 0;
     uint32_t col_slices = 1;
@@ -79,16 +77,12 @@ void free_matrix(hs_context* c) {
     if (c->d_image) (void)hipFree(c->d_image);
     if (c->d_blocks) (void)hipFree(c->d_blocks);
     if (c->d_units) (void)hipFree(c->d_units);
-    if (c->d_wg_first) (void)hipFree(c->d_wg_first);
-    if (c->d_block_order) (void)hipFree(c->d_block_order);
     if (c->d_y) (void)hipFree(c->d_y);
     if (c->d_partial) (void)hipFree(c->d_partial);
     c->d_partial = nullptr;
     c->d_image = nullptr;
     c->d_blocks = nullptr;
     c->d_units = nullptr;
-    c->d_wg_first = nullptr;
-    c->d_block_order = nullptr;
     c->d_y = nullptr;
     c->y_bound = nullptr;
     c->matrix_loaded = false;
@@ -109,8 +103,6 @@ hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     a.image = c->d_image;
     a.blocks = c->d_blocks;
     a.units = c->d_units;
-    a.wg_first = c->d_wg_first;
-    a.block_order = c->d_block_order;
     a.x = x_source(c);
     a.out = c->col_slices > 1 ? c->d_partial : y_target(c);
     a.row_part_filter = filter;
@@ -242,8 +234,6 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_image), tiles.image.data(), tiles.image.size(), kImageSlackBytes));
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_blocks), tiles.blocks.data(), tiles.blocks.size() * sizeof(Block), 0));
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_units), tiles.units.data(), tiles.units.size() * sizeof(Unit), 0));
-    HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_wg_first), tiles.wg_first.data(), tiles.wg_first.size() * sizeof(uint32_t), 0));
-    HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_block_order), tiles.block_order.data(), tiles.block_order.size() * sizeof(uint32_t), 0));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
     if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));

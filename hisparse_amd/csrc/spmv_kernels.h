@@ -13,10 +13,8 @@ namespace dev {
 
 struct SpmvLaunch {
     const uint8_t* image;         // element streams
-    const Block* blocks;
+    const Block* blocks;          // workgroup g starts at blocks[g] and follows Block::next
     const Unit* units;
-    const uint32_t* wg_first;     // num_workgroups + 1 entries into block_order
-    const uint32_t* block_order;
     const uint32_t* x;            // packed vector words, num_cols
     uint32_t* out;                // packed result words: y itself (one column slice) or slices x num_rows partials
     int32_t row_part_filter;      // -1: every row partition

@@ -37,7 +37,6 @@ namespace dev {
 namespace {
 
 constexpr int kThreads = kWaveLanes * kWavesPerWorkgroup;       // 1024
-constexpr int kConsumerThreads = kWaveLanes * kConsumerWaves;   // 768
 constexpr uint32_t kBufBytes = kSubTileCols * 4u;               // one x buffer of the LDS ring (32 KiB)
 
 // mat_val * vec_val narrowed to Q8.24: exact 64-bit product, + half LSB, >> 24, saturate (pe.h:64).
@@ -163,12 +162,21 @@ struct Ring<true> {    // DELTA: the value dword and the 16-bit gap of this lane
                      : "=v"(value), "=v"(gap) : "n"(K), "n"(K + kMaxDepth), "n"(2 * (kDepth - 1)) : "memory");
     }
 };
+// One dword through the scalar cache, whatever hipcc thinks of the pointer's provenance: after the ring's inline asm
+// ("memory" clobbers) it no longer proves unit data invariant and falls back to a VECTOR load of the uniform address,
+// which both costs a vmcnt(0) drain of the ring and sits in the counted-wait window.  Blocking (rare paths only).
+__device__ __forceinline__ uint32_t scalar_load(const uint32_t* p);
 // a pointer the compiler must keep in a scalar register pair
 __device__ __forceinline__ const uint8_t* scalar_pointer(const uint8_t* p) {
     const uint64_t a = reinterpret_cast<uint64_t>(p);
     const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));   // (the builtin returns int:
     const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a));         //  no sign extension, please)
     return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+__device__ __forceinline__ uint32_t scalar_load(const uint32_t* p) {
+    uint32_t v;
+    asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(scalar_pointer(reinterpret_cast<const uint8_t*>(p))) : "memory");
+    return v;
 }
 
 // Workgroup barrier that orders LDS traffic only: the consumers' prefetched global loads stay in flight
@@ -213,7 +221,7 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
         }
         if (!(kAblate & 8)) lds_barrier();
         if (++c.u == c.U) return false;
-        c.end = c.unit[c.u].end_step[c.wave];
+        c.end = scalar_load(&c.unit[c.u].end_step[c.wave]);
         c.slot = c.slot + 1 == c.ring ? 0 : c.slot + 1;
         c.xb = c.xs + c.slot * kSubTileCols;
         c.head = true;
@@ -288,26 +296,31 @@ __device__ __forceinline__ void prime_ring(const uint8_t* stream, uint32_t last,
     (Ring<kDelta>::template issue<Ks>(stream, min(static_cast<uint32_t>(Ks), last) * stride, lane_off), ...);
 }
 
-template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense>
-__device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit* __restrict__ unit, uint32_t U, uint32_t wave, uint32_t lane,
-                                              const uint32_t* xs, uint32_t ring, typename Rows<kFloat>::acc_t* ys, uint32_t nrows) {
+// Before the block's prologue: set the wavefront's consumer up and put the first kDepth loads in flight, so that the HBM
+// latency of the stream overlaps the accumulator zeroing and the first x sub-tile copy.
+template <bool kFloat, bool kDelta, int kDepth>
+__device__ __forceinline__ void consumer_begin(Consumer<kFloat>& c, const uint8_t* stream, const Unit* __restrict__ unit, uint32_t U, uint32_t wave,
+                                               uint32_t lane, const uint32_t* xs, uint32_t ring, typename Rows<kFloat>::acc_t* ys, uint32_t nrows,
+                                               uint32_t total, uint32_t first_end) {
     static_assert(kDepth <= kMaxDepth, "the ring lives in a0..a31");
     constexpr uint32_t kStride = kDelta ? kRecordBytes : kWaveStrideBytes;
-    const uint32_t total = unit[U - 1].end_step[wave];
-    Consumer<kFloat> c;
     c.stream = scalar_pointer(stream);
     c.unit = unit; c.U = U; c.wave = wave; c.lane = lane; c.ring = ring; c.nrows = nrows;
     c.lane_off = lane * Ring<kDelta>::kLaneBytes;
     c.last = total ? total - 1 : 0;    // prefetches past the end re-read the last chunk / record (no branch)
     c.xs = xs; c.xb = xs; c.ys = ys;
-    c.end = unit[0].end_step[wave];
-    if (kAblate & 64) { c.u = U - 1; c.end = total; }   // profiling: one unit per block
-    // The loader branch of the kernel leaves "LDS-DMA may be pending" in hipcc's wait-count bookkeeping, and that state
-    // reaches this loop around the block loop: every LDS store on a conditional path below would then get its own
-    // s_waitcnt vmcnt(0) and drain the prefetch ring.  A consumer wavefront never has LDS-DMA in flight, so say so once,
-    // up front, where nothing is in flight yet.
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), lgkmcnt/expcnt untouched
+    c.end = first_end;
     prime_ring<kDelta>(c.stream, c.last, kStride, c.lane_off, std::make_integer_sequence<int, kDepth>());
+}
+
+template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense>
+__device__ __forceinline__ void consumer_run(Consumer<kFloat>& c) {
+    // The loader branch of the kernel leaves "LDS-DMA may be pending" in hipcc's wait-count bookkeeping, and that state
+    // reaches this loop around the block loop and through the shared prologue: every LDS store on a conditional path below
+    // would then get its own s_waitcnt vmcnt(0) and drain the prefetch ring.  A consumer wavefront never has LDS-DMA in
+    // flight, so say so once, here, where it costs nothing: the prologue's x copy has just waited for vmcnt(0) anyway.
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), lgkmcnt/expcnt untouched
+    if (kAblate & 64) { c.u = c.U - 1; c.end = c.last + 1; }   // profiling: one unit per block
     for (;; c.base += kDepth)
         if (!consume_round<kFloat, kDelta, kAblate, kDepth, kDense>(c, std::make_integer_sequence<int, kDepth>())) break;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory", HS_RING_AGPRS);   // the clamped tail prefetches must land before the ring is reused
@@ -320,8 +333,7 @@ __device__ __forceinline__ void consume_block(const uint8_t* stream, const Unit*
 // kDelta: the image is in the DELTA stream format (stream_tiles.h), otherwise PAIRS.
 template <bool kFloat, bool kDelta, int kAblate, int kDepth>
 __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
-                                                                  const Unit* __restrict__ units, const uint32_t* __restrict__ wg_first,
-                                                                  const uint32_t* __restrict__ block_order, const uint32_t* __restrict__ x,
+                                                                  const Unit* __restrict__ units, const uint32_t* __restrict__ x,
                                                                   uint32_t* __restrict__ out, int32_t row_part_filter, uint32_t ring,
                                                                   uint32_t x_base) {
     using acc_t = typename Rows<kFloat>::acc_t;
@@ -337,19 +349,28 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
     uint32_t wg = blockIdx.x;
     if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 
-    const uint32_t q_end = wg_first[wg + 1];
+    // The workgroup's first block is blocks[wg]; further ones are chained through Block::next (0 = none).  Everything a
+    // consumer wavefront needs before its first stream load sits in the Block itself: ONE dependent load per block.
     bool first_block = true;
-    for (uint32_t q = wg_first[wg]; q < q_end; ++q) {
-        const Block* blk = blocks + block_order[q];
-        if (row_part_filter >= 0 && blk->row_part != static_cast<uint32_t>(row_part_filter)) continue;
+    for (uint32_t bi = wg, next = 0;; bi = next) {
+        const Block* blk = blocks + bi;
+        next = blk->next;
+        if (row_part_filter >= 0 && blk->row_part != static_cast<uint32_t>(row_part_filter)) {
+            if (!next) break;
+            continue;
+        }
         const uint32_t nrows = blk->nrows, out0 = blk->out_offset;
         const Unit* unit = units + blk->unit_begin;
         const uint32_t U = blk->unit_end - blk->unit_begin;
 
-        if (!first_block) __syncthreads();   // the previous block's result store has read the accumulators
+        if (!first_block) __syncthreads();   // the previous block's result store has read the accumulators (and has drained)
         first_block = false;
+        Consumer<kFloat> c;
+        if (!loader && U > 0)
+            consumer_begin<kFloat, kDelta, kDepth>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave],
+                                                   blk->first_end[wave]);
         if (!(kAblate & 16)) for (uint32_t i = tid; i <= nrows; i += kThreads) ys[i] = 0;           // PE banks start at zero (pe.h:131-135)
-        if (U > 0 && !(kAblate & 16)) fill_x<kSubTileCols / 4 / kThreads, kThreads>(xs, x, unit[0].col0, unit[0].ncols, tid);
+        if (U > 0 && !(kAblate & 16)) fill_x<kSubTileCols / 4 / kThreads, kThreads>(xs, x, blk->first_col0, blk->first_ncols, tid);
         __syncthreads();
 
         if (U > 0) {
@@ -373,14 +394,14 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 }
             } else {
                 // ---- consumer wavefronts: stream elements, gather x, accumulate rows -----------------------------
-                const uint8_t* stream = image + blk->wave_offset[wave];
-                if (!kDelta && (blk->flags & kBlockDenseRows)) consume_block<kFloat, false, kAblate, kDepth, true>(stream, unit, U, wave, lane, xs, ring, ys, nrows);
-                else consume_block<kFloat, kDelta, kAblate, kDepth, false>(stream, unit, U, wave, lane, xs, ring, ys, nrows);
+                if (!kDelta && (blk->flags & kBlockDenseRows)) consumer_run<kFloat, false, kAblate, kDepth, true>(c);
+                else consumer_run<kFloat, kDelta, kAblate, kDepth, false>(c);
             }
         }
         // every sub-tile barrier has passed: the accumulators are final
         // (no barrier after the store: the last block's stores drain while the workgroup retires)
         if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = Rows<kFloat>::finish(ys[i]);
+        if (!next) break;
     }
 }
 
@@ -449,7 +470,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(F, T, A, D)                                                                                                           \
     if (!launched && is_float == F && a.delta == T && (F || (ablate == A && depth == D))) {                                     \
         hipLaunchKernelGGL((spmv_rowblock_kernel<F, T, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \
-                           a.wg_first, a.block_order, a.x, a.out, a.row_part_filter, a.ring_buffers, x_base);                   \
+                           a.x, a.out, a.row_part_filter, a.ring_buffers, x_base);                   \
         launched = true;                                                                                                        \
     }
     HS_FOR_EACH_VARIANT(X)

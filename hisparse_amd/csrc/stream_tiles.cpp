@@ -365,26 +365,56 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     }
 
     // ---- workgroups: longest-processing-time assignment of blocks ------------------------------------------
+    std::vector<std::vector<uint32_t>> mine;
     {
         const uint32_t groups = std::min<uint32_t>(G, std::max<uint32_t>(1, NB));
         out.num_workgroups = groups;
         std::vector<uint32_t> order(NB);
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return block_nnz[a] > block_nnz[b]; });
-        std::vector<std::vector<uint32_t>> mine(groups);
+        mine.resize(groups);
         std::vector<uint64_t> load(groups, 0);
         for (uint32_t b : order) {
             uint32_t best = uint32_t(std::min_element(load.begin(), load.end()) - load.begin());
             mine[best].push_back(b);
             load[best] += block_nnz[b] + 1024;   // every block also costs a fixed prologue/epilogue
         }
+    }
+    // Final block order: the first block of workgroup g sits at blocks[g] (ONE dependent load before the kernel's first
+    // stream load), further blocks of a workgroup are chained through Block::next.  Also fills the copies of unit data.
+    auto finish_blocks = [&]() {
+        const uint32_t groups = out.num_workgroups;
+        for (Block& blk : out.blocks) {
+            if (blk.unit_end > blk.unit_begin) {
+                for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+                    blk.total_steps[w] = out.units[blk.unit_end - 1].end_step[w];
+                    blk.first_end[w] = out.units[blk.unit_begin].end_step[w];
+                }
+                blk.first_col0 = out.units[blk.unit_begin].col0;
+                blk.first_ncols = out.units[blk.unit_begin].ncols;
+            }
+        }
+        std::vector<uint32_t> new_index(NB, 0);
+        uint32_t tail = 0;
+        for (uint32_t g = 0; g < groups; ++g) tail += mine[g].empty() ? 0u : 1u;   // == groups unless NB == 0
+        uint32_t heads = 0;
+        for (uint32_t g = 0; g < groups; ++g)
+            for (size_t k = 0; k < mine[g].size(); ++k) new_index[mine[g][k]] = k == 0 ? heads++ : tail++;
+        std::vector<Block> moved(NB);
         out.wg_first.assign(groups + 1, 0);
+        out.block_order.clear();
         for (uint32_t g = 0; g < groups; ++g) {
             out.wg_first[g] = uint32_t(out.block_order.size());
-            out.block_order.insert(out.block_order.end(), mine[g].begin(), mine[g].end());
+            for (size_t k = 0; k < mine[g].size(); ++k) {
+                Block blk = out.blocks[mine[g][k]];
+                blk.next = k + 1 < mine[g].size() ? new_index[mine[g][k + 1]] : 0u;
+                moved[new_index[mine[g][k]]] = blk;
+                out.block_order.push_back(new_index[mine[g][k]]);
+            }
         }
         out.wg_first[groups] = uint32_t(out.block_order.size());
-    }
+        out.blocks.swap(moved);
+    };
 
     out.image.assign(image_bytes, 0);
     uint8_t* image = out.image.data();
@@ -418,6 +448,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 }
             }
         });
+        finish_blocks();
         return true;
     }
 
@@ -456,6 +487,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             }
         }
     });
+    finish_blocks();
     return true;
 }
 

@@ -94,24 +94,29 @@ struct Block {
     uint32_t unit_end;
     uint32_t flags;         // kBlockDenseRows (PAIRS only): few long rows; chunks are dealt linearly and mostly hold ONE row
     uint32_t out_offset;    // word offset of the block's first row in the output: y (one slice) or the per-slice partials
-    uint32_t reserved;
+    uint32_t next;          // index of the next block of the same workgroup, 0 = none (workgroup g starts at blocks[g])
     uint64_t wave_offset[kConsumerWaves];   // byte offset of each consumer wavefront's first chunk (PAIRS: its next is kWaveStrideBytes on)
                                             // or of its contiguous record stream (DELTA)
+    // copies of what the kernel would otherwise fetch through two more dependent loads before its first stream load
+    uint32_t total_steps[kConsumerWaves];   // == units[unit_end - 1].end_step
+    uint32_t first_end[kConsumerWaves];     // == units[unit_begin].end_step
+    uint32_t first_col0, first_ncols;       // == units[unit_begin].col0 / .ncols (0 / 0 for a block without units)
+    uint32_t pad[14];
 };
 struct Unit {
     uint32_t col0;          // first absolute column of the x sub-tile
     uint32_t ncols;         // multiple of 8, <= kSubTileCols
     uint32_t end_step[kConsumerWaves];      // per wavefront: its stream position (in chunks / records, heads included) after this unit
 };
-static_assert(sizeof(Block) == 32 + 8 * kConsumerWaves, "Block layout is shared with the device code");
+static_assert(sizeof(Block) == 320, "Block layout is shared with the device code");
 static_assert(sizeof(Unit) == 8 + 4 * kConsumerWaves, "Unit layout is shared with the device code");
 
 struct StreamTiles {
     std::vector<uint8_t> image;          // element streams, uploaded verbatim
     std::vector<Block> blocks;
     std::vector<Unit> units;
-    std::vector<uint32_t> wg_first;      // workgroup g owns block_order[wg_first[g] .. wg_first[g+1])
-    std::vector<uint32_t> block_order;
+    std::vector<uint32_t> wg_first;      // workgroup g owns block_order[wg_first[g] .. wg_first[g+1]), in this order: a host-side
+    std::vector<uint32_t> block_order;   // description (tests, statistics); the kernel follows blocks[g] -> Block::next
     uint32_t num_workgroups = 0;
     uint32_t max_block_rows = 0;
     uint32_t col_slices = 1;             // > 1: blocks write per-slice partial results, a combine pass adds them

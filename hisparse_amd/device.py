@@ -43,7 +43,9 @@ STREAM_FORMATS = ("pairs", "delta")   # HS_STREAM_PAIRS / HS_STREAM_DELTA
 CONSUMER_WAVES = 14
 # device-side descriptors (hisparse_amd/csrc/stream_tiles.h)
 BLOCK_DTYPE = np.dtype([("row0", "<u4"), ("nrows", "<u4"), ("row_part", "<u4"), ("unit_begin", "<u4"), ("unit_end", "<u4"),
-                        ("flags", "<u4"), ("out_offset", "<u4"), ("reserved", "<u4"), ("wave_offset", "<u8", (CONSUMER_WAVES,))])
+                        ("flags", "<u4"), ("out_offset", "<u4"), ("next", "<u4"), ("wave_offset", "<u8", (CONSUMER_WAVES,)),
+                        ("total_steps", "<u4", (CONSUMER_WAVES,)), ("first_end", "<u4", (CONSUMER_WAVES,)), ("first_col0", "<u4"),
+                        ("first_ncols", "<u4"), ("pad", "<u4", (14,))])
 UNIT_DTYPE = np.dtype([("col0", "<u4"), ("ncols", "<u4"), ("end_step", "<u4", (CONSUMER_WAVES,))])
 
 

@@ -133,7 +133,7 @@ int hs_tiles_build(const void* const channel[HS_NUM_CHANNELS], const uint64_t n_
 int hs_tiles_info(const hs_tiles* t, uint64_t* image_bytes, uint32_t* num_blocks, uint32_t* num_units, uint32_t* num_workgroups,
                   uint32_t* max_block_rows, uint64_t* nnz, uint64_t* elements, uint32_t* col_slices, uint32_t* ring_buffers,
                   uint32_t* stream_format);
-/* image: image_bytes; blocks: num_blocks x 128 B; units: num_units x 56 B (layouts: hisparse_amd/csrc/stream_tiles.h);
+/* image: image_bytes; blocks: num_blocks x 320 B; units: num_units x 64 B (layouts: hisparse_amd/csrc/stream_tiles.h);
  * wg_first: num_workgroups + 1; block_order: num_blocks */
 int hs_tiles_copy(const hs_tiles* t, void* image, void* blocks, void* units, uint32_t* wg_first, uint32_t* block_order);
 void hs_tiles_free(hs_tiles* t);

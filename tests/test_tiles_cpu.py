@@ -50,8 +50,18 @@ def test_structure_invariants(stream_format):
     csr = host.CSRMatrix.generate("powerlaw", 30000, 50000, a=600000, b=0.4, c=1.0, seed=3)
     cp = host.format_matrix(csr, 0, skip_empty_rows=True)
     t = build(cp, 0, 64)
-    blocks, units = t["blocks"], t["units"]
-    # blocks tile the rows exactly, in order, within the LDS budget, never across a row partition
+    units = t["units"]
+    # the kernel's walk: workgroup g starts at blocks[g] and follows `next`; same blocks as the host-side wg_first/block_order
+    for g in range(t["num_workgroups"]):
+        chain, b = [], g
+        while True:
+            chain.append(b)
+            b = int(t["blocks"][b]["next"])
+            if b == 0:
+                break
+        assert chain == t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]].tolist()
+    blocks = t["blocks"][np.argsort(t["blocks"]["row0"], kind="stable")]
+    # blocks tile the rows exactly, within the LDS budget, never across a row partition
     assert t["col_slices"] == 1 and t["ring_buffers"] == 4
     assert blocks["row0"][0] == 0 and (blocks["row0"][1:] == blocks["row0"][:-1] + blocks["nrows"][:-1]).all()
     assert blocks["row0"][-1] + blocks["nrows"][-1] == cp.num_rows
@@ -66,6 +76,7 @@ def test_structure_invariants(stream_format):
     for b in blocks[:5]:
         es = units["end_step"][b["unit_begin"]:b["unit_end"]]
         assert (np.diff(es, axis=0) >= 0).all()
+        assert (b["total_steps"] == es[-1]).all() and (b["first_end"] == es[0]).all() and b["first_col0"] == units["col0"][b["unit_begin"]] and b["first_ncols"] == units["ncols"][b["unit_begin"]]
     assert t["format"] == stream_format and t["elements"] >= t["nnz"]
     if stream_format == "pairs":
         # bytes: 8 per element slot, padding below 64 slots per unit
@@ -95,7 +106,8 @@ def test_column_slices(impl, slices, monkeypatch):
     xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 3, impl))
     t = build(cp, impl, 32)
     assert t["col_slices"] == slices and t["nnz"] == cp.nnz
-    blocks, units = t["blocks"], t["units"]
+    units = t["units"]
+    blocks = t["blocks"][np.lexsort((t["blocks"]["out_offset"], t["blocks"]["row0"]))]   # row range major, slice minor
     assert len(blocks) % slices == 0 and blocks["nrows"].max() <= 12287
     # the slices of one row range own disjoint sub-tiles: sub-tile index mod slices == slice
     for b in range(0, len(blocks), slices):

@@ -1,0 +1,20 @@
+"""Kernel-time probe on any named config: python tools/probe_cfg.py <config> (HISPARSE_* env selects variants)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hisparse_amd import host, device, datasets
+
+name = sys.argv[1]
+cfg, csr = datasets.load(name)
+impl = host.impl_id(cfg.impl)
+cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+eng = device.SpmvEngine(impl)
+eng.load_matrix(cp)
+x = np.random.default_rng(0).uniform(0, 2, cp.num_cols).astype(np.float32)
+eng.load_vector(host.pack_vector(impl, x))
+runs = int(os.environ.get("RUNS", "50"))
+best = 1e9
+for k in range(3):
+    tot, kern = eng.time_runs(5, runs)
+    best = min(best, kern / runs)
+print("%-16s %s kernel us %.1f (best of 3 x %d)" % (name, os.environ.get("TAG", ""), best * 1e3, runs))
