@@ -51,6 +51,12 @@ __device__ __forceinline__ uint32_t q8_24_mul(uint32_t a, uint32_t b) {
     return (hi >> 24) ? 0xffffffffu : r;
 }
 
+// Matrix descriptors (blocks, units) never change while the kernel runs: reading them through the CONSTANT address
+// space makes every uniform read a scalar-cache load, whatever hipcc can or cannot prove after the inline asm below
+// (through a plain pointer it fell back to VECTOR loads of the uniform address: a vmcnt(0) drain per unit boundary).
+typedef const __attribute__((address_space(4))) Unit* UnitTable;
+typedef const __attribute__((address_space(4))) Block* BlockTable;
+
 template <bool kFloat>
 struct Rows;
 template <>
@@ -63,12 +69,13 @@ struct Rows<false> {
 };
 template <>
 struct Rows<true> {
-    using acc_t = float;
+    using acc_t = double;    // LDS accumulator: ds_add_f64 is ~9x faster than ds_add_f32 here (stream_tiles.h)
     using prod_t = float;
-    // multiply, then add: two roundings like the float PEs (pe-pob.h:63-65, pe-stall.h:52,138)
+    // multiply in float like the float PEs (pe-pob.h:63-65, pe-stall.h:52,138); the products are then summed in double
+    // and rounded to float once per row (and per column slice) -- closer to the exact sum than the PEs' float running sum
     static __device__ __forceinline__ prod_t product(uint32_t mat, uint32_t vec) { return __uint_as_float(mat) * __uint_as_float(vec); }
-    static __device__ __forceinline__ void add(acc_t* ys, uint32_t row, prod_t p) { atomicAdd(ys + row, p); }   // ds_add_f32
-    static __device__ __forceinline__ uint32_t finish(acc_t s) { return __float_as_uint(s); }
+    static __device__ __forceinline__ void add(acc_t* ys, uint32_t row, prod_t p) { atomicAdd(ys + row, static_cast<double>(p)); }   // ds_add_f64
+    static __device__ __forceinline__ uint32_t finish(acc_t s) { return __float_as_uint(static_cast<float>(s)); }
 };
 
 // Sum over the 64 lanes of a wavefront (result valid in every lane).
@@ -162,21 +169,12 @@ struct Ring<true> {    // DELTA: the value dword and the 16-bit gap of this lane
                      : "=v"(value), "=v"(gap) : "n"(K), "n"(K + kMaxDepth), "n"(2 * (kDepth - 1)) : "memory");
     }
 };
-// One dword through the scalar cache, whatever hipcc thinks of the pointer's provenance: after the ring's inline asm
-// ("memory" clobbers) it no longer proves unit data invariant and falls back to a VECTOR load of the uniform address,
-// which both costs a vmcnt(0) drain of the ring and sits in the counted-wait window.  Blocking (rare paths only).
-__device__ __forceinline__ uint32_t scalar_load(const uint32_t* p);
 // a pointer the compiler must keep in a scalar register pair
 __device__ __forceinline__ const uint8_t* scalar_pointer(const uint8_t* p) {
     const uint64_t a = reinterpret_cast<uint64_t>(p);
     const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));   // (the builtin returns int:
     const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a));         //  no sign extension, please)
     return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
-}
-__device__ __forceinline__ uint32_t scalar_load(const uint32_t* p) {
-    uint32_t v;
-    asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(scalar_pointer(reinterpret_cast<const uint8_t*>(p))) : "memory");
-    return v;
 }
 
 // Workgroup barrier that orders LDS traffic only: the consumers' prefetched global loads stay in flight
@@ -194,7 +192,7 @@ struct Consumer {
     using prod_t = typename Rows<kFloat>::prod_t;
     static constexpr uint32_t kNoRow = 0xffffffffu;
     const uint8_t* stream;     // scalar_pointer: first chunk / record of this wavefront in the block
-    const Unit* unit;
+    UnitTable unit;
     uint32_t U, wave, lane, lane_off, ring, nrows, last;
     const uint32_t* xs;
     acc_t* ys;
@@ -221,7 +219,7 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
         }
         if (!(kAblate & 8)) lds_barrier();
         if (++c.u == c.U) return false;
-        c.end = scalar_load(&c.unit[c.u].end_step[c.wave]);
+        c.end = c.unit[c.u].end_step[c.wave];
         c.slot = c.slot + 1 == c.ring ? 0 : c.slot + 1;
         c.xb = c.xs + c.slot * kSubTileCols;
         c.head = true;
@@ -299,7 +297,7 @@ __device__ __forceinline__ void prime_ring(const uint8_t* stream, uint32_t last,
 // Before the block's prologue: set the wavefront's consumer up and put the first kDepth loads in flight, so that the HBM
 // latency of the stream overlaps the accumulator zeroing and the first x sub-tile copy.
 template <bool kFloat, bool kDelta, int kDepth>
-__device__ __forceinline__ void consumer_begin(Consumer<kFloat>& c, const uint8_t* stream, const Unit* __restrict__ unit, uint32_t U, uint32_t wave,
+__device__ __forceinline__ void consumer_begin(Consumer<kFloat>& c, const uint8_t* stream, UnitTable unit, uint32_t U, uint32_t wave,
                                                uint32_t lane, const uint32_t* xs, uint32_t ring, typename Rows<kFloat>::acc_t* ys, uint32_t nrows,
                                                uint32_t total, uint32_t first_end) {
     static_assert(kDepth <= kMaxDepth, "the ring lives in a0..a31");
@@ -353,14 +351,14 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
     // consumer wavefront needs before its first stream load sits in the Block itself: ONE dependent load per block.
     bool first_block = true;
     for (uint32_t bi = wg, next = 0;; bi = next) {
-        const Block* blk = blocks + bi;
+        const BlockTable blk = (BlockTable)(blocks + bi);
         next = blk->next;
         if (row_part_filter >= 0 && blk->row_part != static_cast<uint32_t>(row_part_filter)) {
             if (!next) break;
             continue;
         }
         const uint32_t nrows = blk->nrows, out0 = blk->out_offset;
-        const Unit* unit = units + blk->unit_begin;
+        const UnitTable unit = (UnitTable)(units + blk->unit_begin);
         const uint32_t U = blk->unit_end - blk->unit_begin;
 
         if (!first_block) __syncthreads();   // the previous block's result store has read the accumulators (and has drained)
@@ -378,8 +376,16 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 // ---- loader wavefronts: keep the ring of x buffers up to three sub-tiles ahead of the consumers ----
                 const uint32_t lw = wave - kConsumerWaves;
                 uint32_t fill_slot = 1 == ring ? 0 : 1;                // ring slot of the next refill (sub-tile v lives in slot v % ring)
+                // Unit descriptors are 64 bytes apart and cold (they stream from HBM once per SpMV): the descriptor of the
+                // refill after next is fetched while this one is in flight, so its miss latency is off the per-unit path
+                // (hyper-sparse matrices have hundreds of short units per block: 1 us each used to add up to 300 us).
+                uint32_t col0_next = U > 1 ? unit[1].col0 : 0, ncols_next = U > 1 ? unit[1].ncols : 8;
                 auto refill = [&](uint32_t v) {
-                    if (!(kAblate & 4)) dma_fill_x(xs + fill_slot * kSubTileCols, x, unit[v].col0, unit[v].ncols, lw, lane);
+                    const uint32_t col0 = col0_next, ncols = ncols_next;
+                    const uint32_t ahead = min(v + 1, U - 1);
+                    col0_next = unit[ahead].col0;
+                    ncols_next = unit[ahead].ncols;
+                    if (!(kAblate & 4)) dma_fill_x(xs + fill_slot * kSubTileCols, x, col0, ncols, lw, lane);
                     fill_slot = fill_slot + 1 == ring ? 0 : fill_slot + 1;
                 };
                 uint32_t issued = 1;                                   // sub-tile 0 was copied synchronously above
@@ -437,20 +443,19 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
-// LDS plan: 64-bit (fixed) / 32-bit (float, upper half unused) row accumulators first, then the ring of x buffers.
-static uint32_t accumulator_bytes(uint32_t max_block_rows) { return ((max_block_rows + 1) * 8u + 15u) & ~15u; }
-
+// LDS plan: 64-bit row accumulators first (integer sums / double sums), then the ring of x buffers.
 uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers) {
-    return accumulator_bytes(max_block_rows) + ring_buffers * kBufBytes;
+    return (((max_block_rows + 1) * kAccumulatorBytes + 15u) & ~15u) + ring_buffers * kBufBytes;
 }
 
 // (float, delta, ablate, depth): the product variants first, then the profiling builds (fixed point only)
 #define HS_FOR_EACH_VARIANT(X)                                                                                   \
     X(true, false, 0, 8) X(true, true, 0, 8) X(false, false, 0, 8) X(false, true, 0, 8)                           \
     X(false, false, 0, 16) X(false, true, 0, 16) X(false, false, 3, 8) X(false, true, 3, 8)                       \
-    X(false, false, 15, 8) X(false, true, 15, 8) X(false, false, 31, 8) X(false, true, 31, 8)                     \
+    X(false, false, 4, 8) X(false, true, 4, 8) X(false, false, 8, 8) X(false, true, 8, 8) X(false, false, 15, 8) X(false, true, 15, 8) X(false, false, 31, 8) X(false, true, 31, 8)                     \
     X(false, false, 47, 8) X(false, true, 47, 8) X(false, false, 79, 8) X(false, true, 79, 8)                     \
-    X(false, false, 127, 8) X(false, true, 127, 8)
+    X(false, false, 127, 8) X(false, true, 127, 8)                                                                 \
+    X(true, false, 3, 8) X(true, false, 4, 8) X(true, false, 8, 8) X(true, false, 15, 8) X(true, false, 127, 8)
 
 hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
     hipError_t e;
@@ -468,7 +473,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     static const int ablate = env_int("HISPARSE_ABLATE", 0), depth = env_int("HISPARSE_DEPTH", 8);
     bool launched = false;
 #define X(F, T, A, D)                                                                                                           \
-    if (!launched && is_float == F && a.delta == T && (F || (ablate == A && depth == D))) {                                     \
+    if (!launched && is_float == F && a.delta == T && ablate == A && depth == D) {                                     \
         hipLaunchKernelGGL((spmv_rowblock_kernel<F, T, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \
                            a.x, a.out, a.row_part_filter, a.ring_buffers, x_base);                   \
         launched = true;                                                                                                        \

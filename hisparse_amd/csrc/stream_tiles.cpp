@@ -142,6 +142,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     L.sub_width = uint32_t(std::min<uint64_t>(kSubTileCols, geom.logical_vb));
     L.subs_per_cp = uint32_t((geom.logical_vb + L.sub_width - 1) / L.sub_width);
     const uint32_t F = L.F, CP = num_col_partitions, RP = num_row_partitions, S = L.subs_per_cp;
+    const bool is_float = geom.impl != IMPL_FIXED;
     const uint64_t header_pkts = uint64_t(RP) * CP * (1 + F);
     for (uint32_t c = 0; c < NUM_HBM_CHANNELS; ++c) {
         if (!channel[c] && n_packets[c]) { error = "null channel buffer"; return false; }
@@ -176,7 +177,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         for (uint32_t cs = 1; cs <= kMaxColSlices; cs *= 2) {
             if (force && uint32_t(std::atoi(force)) != cs) continue;
             if (cs > 1 && uint64_t(CP) * S < cs) continue;                                    // fewer sub-tiles than slices
-            const uint32_t cap = cs > 1 ? kMaxSlicedBlockRows : kMaxBlockRows;
+            const uint32_t cap = max_block_rows(cs > 1);
             const uint64_t ranges_est = std::max<uint64_t>((G + cs - 1) / cs, (uint64_t(num_rows) + cap - 1) / cap);
             // every row range pulls all of x (split over its slices) through the CUs that own it
             const double fill_us = double(ranges_est) * double(num_cols) * 4.0 / double(G) / 120e3;   // bytes / (120 GB/s) in us
@@ -185,7 +186,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         }
     }
     out.col_slices = slices;
-    const uint32_t max_rows = slices > 1 ? kMaxSlicedBlockRows : kMaxBlockRows;
+    uint32_t max_rows = max_block_rows(slices > 1);
+    if (const char* e = std::getenv("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(e)));   // experiments
 
     // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse ---------------------
     {
@@ -236,7 +238,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         std::fill(block_of_row.begin() + ranges[b].row0, block_of_row.begin() + ranges[b].row0 + ranges[b].nrows, b);
         out.max_block_rows = std::max(out.max_block_rows, ranges[b].nrows);
     }
-    const uint32_t ring_fit = (kMaxLdsBytes - (out.max_block_rows + 1) * 8u) / (kSubTileCols * 4u);
+    const uint32_t ring_fit = (kMaxLdsBytes - (out.max_block_rows + 1) * kAccumulatorBytes - 16u) / (kSubTileCols * 4u);
     out.ring_buffers = std::max(kMinXBuffers, std::min(kMaxXBuffers, ring_fit));
 
     // ---- pass 1: elements per (row range, column partition, sub-tile, source channel) -------------------
@@ -468,7 +470,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             at += uint32_t(d);
             gap[k] = uint16_t(d); val[k] = uint32_t(e[i]); after[k] = at; ++k;
         }
-        const uint16_t pad_gap = geom.impl == IMPL_FIXED ? 0 : kBridgeGap;
+        const uint16_t pad_gap = is_float ? kBridgeGap : 0;
         const uint32_t scratch_pos = blk.nrows * kSubTileCols;   // local row nrows = the scratch accumulator
         for (uint32_t w = 0; w < kConsumerWaves; ++w) {
             if (!up.run_len[w]) continue;

@@ -67,8 +67,12 @@ constexpr uint32_t kLoaderWaves = kWavesPerWorkgroup - kConsumerWaves;  // refil
 constexpr uint32_t kSubTileCols = 8192;                       // 32 KiB of x per LDS buffer ...
 constexpr uint32_t kMaxXBuffers = 4;                          // ... in a ring of up to four: refills run up to three sub-tiles ahead
 constexpr uint32_t kMinXBuffers = 2;
-constexpr uint32_t kMaxBlockRows = 4095;                      // one column slice: + 1 scratch slot = 32 KiB of 64-bit accumulators, ring of 4
-constexpr uint32_t kMaxSlicedBlockRows = 12287;               // several column slices: 96 KiB of accumulators, ring of 2
+// Rows per block: + 1 spare slot, 8-byte accumulators in both numeric modes (fixed point: 64-bit integer sums; float:
+// DOUBLE sums of the float products, because LDS float atomics are slow on this part: measured 0.33 lanes/clk/CU for
+// ds_add_f32 against 3.0 for ds_add_f64 and 5.6 for ds_add_u64, tools/lds_atomic_bench.hip).
+//   one column slice:      32 KiB of accumulators, ring of 4;   several column slices: 96 KiB of accumulators, ring of 2
+constexpr uint32_t kAccumulatorBytes = 8;
+constexpr uint32_t max_block_rows(bool sliced) { return (sliced ? 96u : 32u) * 1024u / kAccumulatorBytes - 1u; }
 constexpr uint32_t kMaxColSlices = 8;
 // PAIRS format
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
@@ -88,7 +92,7 @@ constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bi
 // Mirrored in the kernel source (read through scalar loads).
 struct Block {
     uint32_t row0;          // first row (absolute, padded numbering)
-    uint32_t nrows;         // <= kMaxBlockRows; local row nrows is the scratch slot padding elements hit
+    uint32_t nrows;         // <= max_block_rows(); local row nrows is the spare accumulator padding elements hit
     uint32_t row_part;      // row partition (hs_run_partition filter)
     uint32_t unit_begin;    // units [unit_begin, unit_end), consumed in this order
     uint32_t unit_end;

@@ -19,7 +19,7 @@ def _q_mul(a, b):
 
 def _accumulate(ys, is_float, row, val, xv):
     if is_float:
-        np.add.at(ys, row, (val.view(np.float32) * xv.view(np.float32)).astype(np.float32))
+        np.add.at(ys, row, (val.view(np.float32) * xv.view(np.float32)).astype(np.float32).astype(np.float64))
     else:
         np.add.at(ys, row, _q_mul(val, xv))
 
@@ -104,13 +104,13 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
             if row_part_filter >= 0 and int(blk["row_part"]) != row_part_filter:
                 continue
             nrows, row0, out0 = int(blk["nrows"]), int(blk["row0"]), int(blk["out_offset"])
-            assert nrows <= (4095 if slices == 1 else 12287)
+            assert nrows <= (32 if slices == 1 else 96) * 1024 // 8 - 1     # LDS plan of the kernel: 8-byte accumulators
             assert out0 % num_rows == row0 and out0 // num_rows < slices
             touched[row0: row0 + nrows] = True
-            ys = np.zeros(nrows + 1, dtype=np.float32 if is_float else np.uint64)
+            ys = np.zeros(nrows + 1, dtype=np.float64 if is_float else np.uint64)     # double sums of float products
             (_block_delta if delta else _block_pairs)(image, blk, units, x_words, ys, is_float)
             if is_float:
-                out[out0: out0 + nrows] = ys[:nrows].view(np.uint32)
+                out[out0: out0 + nrows] = ys[:nrows].astype(np.float32).view(np.uint32)
             else:
                 out[out0: out0 + nrows] = np.minimum(ys[:nrows], np.uint64(0xFFFFFFFF)).astype(np.uint32)
     assert done.all()

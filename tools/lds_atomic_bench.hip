@@ -1,0 +1,43 @@
+// tools/lds_atomic_bench.hip — throughput of LDS atomic adds by type, 16 wavefronts per CU, pseudo-random rows
+// (what the row accumulators of spmv_rowblock_kernel see in sparse blocks).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+template <typename T> __device__ __forceinline__ void lds_add(T* p, T v) { atomicAdd(p, v); }
+
+template <typename T, int kRows>
+__global__ __launch_bounds__(1024) void k(uint32_t iters, T* sink) {
+    __shared__ T acc[kRows];
+    for (uint32_t i = threadIdx.x; i < kRows; i += 1024) acc[i] = T(0);
+    __syncthreads();
+    uint32_t h = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    for (uint32_t i = 0; i < iters; ++i) {
+        h = h * 1664525u + 1013904223u;
+        lds_add(&acc[(h >> 8) % kRows], T(1));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sink[blockIdx.x] = acc[0];
+}
+
+template <typename T>
+void run(const char* name) {
+    T* sink; hipMalloc(&sink, 256 * sizeof(T));
+    const uint32_t iters = 2000;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((k<T, 8192>), dim3(256), dim3(1024), 0, 0, iters, sink);
+    hipEventRecord(a);
+    hipLaunchKernelGGL((k<T, 8192>), dim3(256), dim3(1024), 0, 0, iters, sink);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double per_cu = double(iters) * 1024;   // atomics per CU
+    printf("%-10s %8.1f us  %6.2f ns per wave-instruction (64 lanes)  %5.2f lanes/clk/CU @2.4GHz\n", name, ms * 1e3, ms * 1e6 / (per_cu / 64), per_cu / (ms * 1e-3 * 2.4e9));
+}
+
+int main() {
+    run<unsigned int>("u32");
+    run<unsigned long long>("u64");
+    run<float>("f32");
+    run<double>("f64");
+    return 0;
+}

@@ -1,4 +1,6 @@
-"""Kernel-time probe on any named config: python tools/probe_cfg.py <config> (HISPARSE_* env selects variants)."""
+"""Kernel-time probe on any named config: python tools/probe_cfg.py <config> [impl]  (HISPARSE_* env selects variants;
+an explicit impl (fixed|float_pob|float_stall) runs the config's matrix in another numeric mode, e.g. to use the
+fixed-point-only HISPARSE_ABLATE builds on a float config)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,10 +8,11 @@ from hisparse_amd import host, device, datasets
 
 name = sys.argv[1]
 cfg, csr = datasets.load(name)
-impl = host.impl_id(cfg.impl)
+impl = host.impl_id(sys.argv[2] if len(sys.argv) > 2 else cfg.impl)
 cp = host.format_matrix(csr, impl, skip_empty_rows=True)
 eng = device.SpmvEngine(impl)
 eng.load_matrix(cp)
+st = eng.stats()
 x = np.random.default_rng(0).uniform(0, 2, cp.num_cols).astype(np.float32)
 eng.load_vector(host.pack_vector(impl, x))
 runs = int(os.environ.get("RUNS", "50"))
@@ -17,4 +20,6 @@ best = 1e9
 for k in range(3):
     tot, kern = eng.time_runs(5, runs)
     best = min(best, kern / runs)
-print("%-16s %s kernel us %.1f (best of 3 x %d)" % (name, os.environ.get("TAG", ""), best * 1e3, runs))
+print("%-16s %-28s kernel us %8.1f (best of 3 x %d) | %s slices %d ring %d blocks %d units %d | ablate %s" % (
+    name, os.environ.get("TAG", ""), best * 1e3, runs, device.STREAM_FORMATS[st["stream_format"]], st["col_slices"], st["ring_buffers"],
+    st["num_blocks"], st["num_units"], os.environ.get("HISPARSE_ABLATE", "0")))
