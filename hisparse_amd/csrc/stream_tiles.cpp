@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -167,27 +168,49 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         out.nnz += r.nnz;
     }
 
-    // ---- column slices: trade x broadcast (every workgroup pulls its slice of x through its CU at ~120 GB/s) against
-    //      the combine pass (one more small kernel reading `slices` partial vectors) --------------------------------
+    // ---- tile plan: column slices x (rows per block, x ring depth) ------------------------------------------------
+    // More column slices = longer row ranges = less x pulled through every CU, at the price of the combine pass; fewer
+    // rows per block = deeper x ring = refill latency hidden even when a (row range, sub-tile) unit holds only a few
+    // thousand non-zeros (hyper-sparse matrices).  Cost model in microseconds, constants measured on MI355X:
+    //   x volume through one CU at ~120 GB/s; a refill takes ~0.8 us to land, ring-1 of them overlap, a unit's stream
+    //   time (~25 GB/s per CU) hides the rest; ~8 us of prologue + epilogue per block; the combine kernel.
     const uint32_t G = std::max<uint32_t>(1, max_workgroups);
-    uint32_t slices = 1;
+    uint32_t slices = 1, max_rows = max_block_rows(false);
     {
-        const char* force = std::getenv("HISPARSE_COL_SLICES");
+        const char* force_slices = std::getenv("HISPARSE_COL_SLICES");
+        const char* force_rows = std::getenv("HISPARSE_MAX_ROWS");   // experiments
+        struct Shape { uint32_t cap, ring; };
+        const Shape sliced[2] = {{max_block_rows(true), 2}, {(kMaxLdsBytes - 3 * kSubTileCols * 4) / kAccumulatorBytes - 1, 3}};   // 12287 / 8191 rows
+        const Shape whole[1] = {{max_block_rows(false), kMaxXBuffers}};                                       // 4095 rows, ring 4
+        const double sub_tiles = double(CP) * S;
         double best = 1e30;
         for (uint32_t cs = 1; cs <= kMaxColSlices; cs *= 2) {
-            if (force && uint32_t(std::atoi(force)) != cs) continue;
+            if (force_slices && uint32_t(std::atoi(force_slices)) != cs) continue;
             if (cs > 1 && uint64_t(CP) * S < cs) continue;                                    // fewer sub-tiles than slices
-            const uint32_t cap = max_block_rows(cs > 1);
-            const uint64_t ranges_est = std::max<uint64_t>((G + cs - 1) / cs, (uint64_t(num_rows) + cap - 1) / cap);
-            // every row range pulls all of x (split over its slices) through the CUs that own it
-            const double fill_us = double(ranges_est) * double(num_cols) * 4.0 / double(G) / 120e3;   // bytes / (120 GB/s) in us
-            const double combine_us = cs > 1 ? 3.5 + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
-            if (fill_us + combine_us < best) { best = fill_us + combine_us; slices = cs; }
+            for (const Shape& shape : cs > 1 ? std::vector<Shape>(sliced, sliced + 2) : std::vector<Shape>(whole, whole + 1)) {
+                uint32_t cap = shape.cap, ring = shape.ring;
+                if (force_rows) {
+                    cap = std::min<uint32_t>(cap, std::max(1, std::atoi(force_rows)));
+                    ring = std::max(kMinXBuffers, std::min(kMaxXBuffers, (kMaxLdsBytes - (cap + 1) * kAccumulatorBytes) / (kSubTileCols * 4u)));
+                }
+                const uint64_t per_round = std::max<uint32_t>(1, G / cs);
+                const uint64_t need = (uint64_t(num_rows) + cap - 1) / cap;
+                const double ranges = double(per_round * std::max<uint64_t>(1, (need + per_round - 1) / per_round));
+                const double blocks_per_wg = ranges * cs / G;
+                const double units_per_wg = std::max(1.0, ranges * sub_tiles / G);
+                const double unit_stream_us = double(out.nnz) * 8.0 / (units_per_wg * G) / 25e3;
+                const double volume_us = ranges * double(num_cols) * 4.0 / G / 120e3;
+                const double latency_us = units_per_wg * std::max(0.0, 0.8 / (ring - 1) - unit_stream_us);
+                const double combine_us = cs > 1 ? 3.5 + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
+                const double cost = volume_us + latency_us + 8.0 * blocks_per_wg + combine_us;
+                if (std::getenv("HISPARSE_PLAN_DEBUG"))
+                    std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f blocks/wg %.1f combine %.1f => %.1f us\n", cs, cap, ring, ranges,
+                                 volume_us, latency_us, blocks_per_wg, combine_us, cost);
+                if (cost < best) { best = cost; slices = cs; max_rows = cap; }
+            }
         }
     }
     out.col_slices = slices;
-    uint32_t max_rows = max_block_rows(slices > 1);
-    if (const char* e = std::getenv("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(e)));   // experiments
 
     // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse ---------------------
     {
@@ -238,7 +261,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         std::fill(block_of_row.begin() + ranges[b].row0, block_of_row.begin() + ranges[b].row0 + ranges[b].nrows, b);
         out.max_block_rows = std::max(out.max_block_rows, ranges[b].nrows);
     }
-    const uint32_t ring_fit = (kMaxLdsBytes - (out.max_block_rows + 1) * kAccumulatorBytes - 16u) / (kSubTileCols * 4u);
+    const uint32_t ring_fit = (kMaxLdsBytes - (((out.max_block_rows + 1) * kAccumulatorBytes + 15u) & ~15u)) / (kSubTileCols * 4u);
     out.ring_buffers = std::max(kMinXBuffers, std::min(kMaxXBuffers, ring_fit));
 
     // ---- pass 1: elements per (row range, column partition, sub-tile, source channel) -------------------
