@@ -55,8 +55,8 @@ def read_traffic(kernel_launch_bytes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="ogbl_ppa")
     ap.add_argument("--npz", default=None, help="real dataset file instead of the seeded stand-in")
     ap.add_argument("--impl", default=None, help="override the config's numeric mode")
@@ -210,6 +210,18 @@ def main():
         cpu_baseline = {"value": round(8.0 * nnz / t_cpu / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
                         "sample": f"{reps} full SpMV(s) of the same matrix through oracle/cpu_ref.c (csim-equivalent restatement, 1 thread), {t_cpu*1e3:.1f} ms each",
                         "gops": round(2.0 * nnz / t_cpu / 1e9, 4), "host_cpus": orc.usable_cores()}
+        # context only: the same restatement with one host thread per cluster (the 16 clusters are independent)
+        try:
+            threads = min(16, orc.usable_cores())
+            t0 = time.perf_counter()
+            y_par = orc.spmv_per_channel_threads(impl, chans, xw, packets.num_rows, packets.num_cols, packets.num_row_partitions,
+                                                 packets.num_col_partitions, packets.ob_bank, packets.vb_bank, threads=threads)
+            t_par = time.perf_counter() - t0
+            if np.array_equal(y_par, y_cpu):
+                cpu_baseline["cpsr_one_thread_per_cluster"] = {"value": round(8.0 * nnz / t_par / 1e9, 3), "unit": "GB/s", "cores": threads,
+                                                               "gops": round(2.0 * nnz / t_par / 1e9, 3), "sample": f"1 SpMV, {t_par*1e3:.1f} ms"}
+        except Exception as e:
+            log(rank, f"per-cluster-thread baseline skipped: {e}")
         # context only: plain float32 CSR loop (compute_ref, csim.cpp:143-158) with OpenMP over every host core
         try:
             ip, ix, dv = csr.arrays()

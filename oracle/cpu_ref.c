@@ -88,9 +88,9 @@ static unsigned interleave_of(int impl) { return impl == IMPL_FLOAT_STALL ? 8u :
  *   part_len    rows per cluster in this row partition (`rows_per_c_in_partition`)
  *   ob_bank/vb_bank  OB_BANK_SIZE / VB_BANK_SIZE the "bitstream" was built with (runtime here)
  */
-int oracle_top_wrapper(int impl, const void* const ch[C], const uint32_t* x, uint32_t* y, uint32_t row_part_id,
-                       uint32_t part_len, uint32_t num_col_partitions, uint32_t num_partitions, uint32_t num_cols,
-                       uint32_t ob_bank, uint32_t vb_bank) {
+static int top_wrapper_threads(int impl, const void* const ch[C], const uint32_t* x, uint32_t* y, uint32_t row_part_id,
+                               uint32_t part_len, uint32_t num_col_partitions, uint32_t num_partitions, uint32_t num_cols,
+                               uint32_t ob_bank, uint32_t vb_bank, int threads) {
     if (impl < IMPL_FIXED || impl > IMPL_FLOAT_STALL || !ch || !x || !y || ob_bank == 0 || vb_bank == 0) return ORACLE_BAD_ARG;
     if (part_len % P != 0) return ORACLE_BAD_ARG;
     const unsigned F = interleave_of(impl);
@@ -102,13 +102,23 @@ int oracle_top_wrapper(int impl, const void* const ch[C], const uint32_t* x, uin
     const uint32_t vl_parts = (uint32_t)((num_cols + logical_vb - 1) / logical_vb);
     const unsigned nbuf = impl == IMPL_FLOAT_POB ? POB_DEPTH : 1u;
 
-    uint32_t* bank = (uint32_t*)malloc((size_t)P * vb_bank * sizeof(uint32_t));          /* 8 vector banks */
-    uint32_t* ob = (uint32_t*)malloc((size_t)nbuf * P * (used ? used : 1) * sizeof(uint32_t)); /* 8 output banks (x7 for pob) */
-    if (!bank || !ob) { free(bank); free(ob); return ORACLE_NO_MEMORY; }
-    memset(bank, 0, (size_t)P * vb_bank * sizeof(uint32_t));
-    int rc = ORACLE_OK;
-
-    for (unsigned pc = 0; pc < C && rc == ORACLE_OK; ++pc) { /* 16 clusters, spmv_sk0.cpp:43-114 */
+    int status = ORACLE_OK;
+    /* The 16 clusters share nothing but x (read) and write disjoint y packets (spmv_sk0/1/2 run them concurrently on
+       the FPGA): `threads` > 1 gives every cluster its own banks and its own host thread -- CPU baseline (B) of SURVEY
+       section 8(d); threads == 1 is the csim order. */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 1 ? threads : 1)
+    for (int pci = 0; pci < (int)C; ++pci) { /* 16 clusters, spmv_sk0.cpp:43-114 */
+        const unsigned pc = (unsigned)pci;
+        int rc = ORACLE_OK;
+        uint32_t* bank = (uint32_t*)malloc((size_t)P * vb_bank * sizeof(uint32_t));          /* 8 vector banks */
+        uint32_t* ob = (uint32_t*)malloc((size_t)nbuf * P * (used ? used : 1) * sizeof(uint32_t)); /* 8 output banks (x7 for pob) */
+        if (!bank || !ob) {
+            free(bank); free(ob);
+#pragma omp critical
+            status = ORACLE_NO_MEMORY;
+            continue;
+        }
+        memset(bank, 0, (size_t)P * vb_bank * sizeof(uint32_t));
         const mat_pkt_t* m = (const mat_pkt_t*)ch[pc];
         /* pe.h:131-135 (pe-pob.h:124-130): zero the used part of the output banks */
         memset(ob, 0, (size_t)nbuf * P * (used ? used : 1) * sizeof(uint32_t));
@@ -175,7 +185,12 @@ int oracle_top_wrapper(int impl, const void* const ch[C], const uint32_t* x, uin
                 }
             }
         }
-        if (rc != ORACLE_OK) break;
+        if (rc != ORACLE_OK) {
+            free(bank); free(ob);
+#pragma omp critical
+            status = rc;
+            continue;
+        }
         /* -- PE dump -> result packer -> axis_merge -> result drain ------------------------------
            packet n of cluster pc lands at y packet row_part*LOGICAL_OB/8 + n*16 + pc
            (spmv_result_drain.cpp:36,43-113 with the 4/6/6 round robin; stream_utils.h:46-62). */
@@ -191,24 +206,42 @@ int oracle_top_wrapper(int impl, const void* const ch[C], const uint32_t* x, uin
                 }
             }
         }
+        free(bank);
+        free(ob);
     }
-    free(bank);
-    free(ob);
-    return rc;
+    return status;
+}
+
+int oracle_top_wrapper(int impl, const void* const ch[C], const uint32_t* x, uint32_t* y, uint32_t row_part_id,
+                       uint32_t part_len, uint32_t num_col_partitions, uint32_t num_partitions, uint32_t num_cols,
+                       uint32_t ob_bank, uint32_t vb_bank) {
+    return top_wrapper_threads(impl, ch, x, y, row_part_id, part_len, num_col_partitions, num_partitions, num_cols, ob_bank, vb_bank, 1);
 }
 
 /* All row partitions, the way every driver loops them (sw/benchmark.cpp:301-338, csim.cpp:329-365). */
-int oracle_spmv(int impl, const void* const ch[C], const uint32_t* x, uint32_t* y, uint32_t num_rows, uint32_t num_cols,
-                uint32_t num_row_partitions, uint32_t num_col_partitions, uint32_t ob_bank, uint32_t vb_bank) {
+static int spmv_threads(int impl, const void* const ch[C], const uint32_t* x, uint32_t* y, uint32_t num_rows, uint32_t num_cols,
+                        uint32_t num_row_partitions, uint32_t num_col_partitions, uint32_t ob_bank, uint32_t vb_bank, int threads) {
     const uint64_t logical_ob = (uint64_t)ob_bank * P * C;
     uint32_t last = (uint32_t)(num_rows % logical_ob == 0 ? logical_ob / C : (num_rows % logical_ob) / C);
     for (uint32_t rp = 0; rp < num_row_partitions; ++rp) {
         uint32_t part_len = rp == num_row_partitions - 1 ? last : (uint32_t)(logical_ob / C);
-        int rc = oracle_top_wrapper(impl, ch, x, y, rp, part_len, num_col_partitions, num_row_partitions * num_col_partitions,
-                                    num_cols, ob_bank, vb_bank);
+        int rc = top_wrapper_threads(impl, ch, x, y, rp, part_len, num_col_partitions, num_row_partitions * num_col_partitions,
+                                     num_cols, ob_bank, vb_bank, threads);
         if (rc != ORACLE_OK) return rc;
     }
     return ORACLE_OK;
+}
+
+int oracle_spmv(int impl, const void* const ch[C], const uint32_t* x, uint32_t* y, uint32_t num_rows, uint32_t num_cols,
+                uint32_t num_row_partitions, uint32_t num_col_partitions, uint32_t ob_bank, uint32_t vb_bank) {
+    return spmv_threads(impl, ch, x, y, num_rows, num_cols, num_row_partitions, num_col_partitions, ob_bank, vb_bank, 1);
+}
+
+/* Same result, one host thread per cluster (at most 16 are useful).  Only bench.py's cpu_baseline leg calls it. */
+int oracle_spmv_per_channel_threads(int impl, const void* const ch[C], const uint32_t* x, uint32_t* y, uint32_t num_rows,
+                                    uint32_t num_cols, uint32_t num_row_partitions, uint32_t num_col_partitions, uint32_t ob_bank,
+                                    uint32_t vb_bank, int threads) {
+    return spmv_threads(impl, ch, x, y, num_rows, num_cols, num_row_partitions, num_col_partitions, ob_bank, vb_bank, threads);
 }
 
 /* compute_ref (csim.cpp:143-158): float32 CSR loop, accumulation in float, in CSR order. */

@@ -37,6 +37,7 @@ def lib():
         l.oracle_q_add.restype = u32
         l.oracle_top_wrapper.argtypes = [C.c_int, vpp, u32p, u32p, u32, u32, u32, u32, u32, u32, u32]
         l.oracle_spmv.argtypes = [C.c_int, vpp, u32p, u32p, u32, u32, u32, u32, u32, u32]
+        l.oracle_spmv_per_channel_threads.argtypes = [C.c_int, vpp, u32p, u32p, u32, u32, u32, u32, u32, u32, C.c_int]
         l.oracle_compute_ref.argtypes = [u32, u32p, u32p, f32p, f32p, f32p]
         l.oracle_compute_ref.restype = None
         l.oracle_compute_ref_parallel.argtypes = [u32, u32p, u32p, f32p, f32p, f32p, C.c_int]
@@ -105,6 +106,22 @@ def spmv(impl, channels, x_words, num_rows, num_cols, num_row_partitions, num_co
     ptrs, keep = _channel_ptrs(channels)
     rc = lib().oracle_spmv(impl, ptrs, _u32p(x_words), _u32p(y), num_rows, num_cols, num_row_partitions,
                            num_col_partitions, ob_bank, vb_bank)
+    del keep
+    if rc != 0:
+        raise OracleError(f"oracle_spmv failed: {ERRORS.get(rc, rc)}")
+    return y
+
+
+def spmv_per_channel_threads(impl, channels, x_words, num_rows, num_cols, num_row_partitions, num_col_partitions, ob_bank, vb_bank,
+                             threads=16):
+    """oracle_spmv with one host thread per cluster (same result; CPU-baseline context only)."""
+    x_words = np.ascontiguousarray(x_words, dtype=np.uint32)
+    if x_words.size != num_cols:
+        raise OracleError("x must have num_cols (padded) words")
+    y = np.zeros(num_rows, dtype=np.uint32)
+    ptrs, keep = _channel_ptrs(channels)
+    rc = lib().oracle_spmv_per_channel_threads(impl, ptrs, _u32p(x_words), _u32p(y), num_rows, num_cols, num_row_partitions,
+                                               num_col_partitions, ob_bank, vb_bank, threads)
     del keep
     if rc != 0:
         raise OracleError(f"oracle_spmv failed: {ERRORS.get(rc, rc)}")

@@ -51,3 +51,16 @@ def test_csim_synthetic_cases(impl, kind, rows, cols, per_row, skip):
     assert orc.verify(ref, got) == -1                                 # csim's own acceptance test
     assert np.array_equal(got, ref)                                   # and in fact exact: integer sums <= 128 / 10
     assert np.array_equal(ref[:rows], np.round(ref[:rows])) and (got[rows:] == 0).all()
+
+
+def test_per_cluster_threads_equal_sequential():
+    # the cpu_baseline variant with one host thread per cluster must be the same function
+    import cases
+    from hisparse_amd import host
+    for impl in (0, 1, 2):
+        m = cases.random_csr(1500, 400, 0.04, 31, impl)
+        _, cp = cases.formatted(m, impl, 4, 8 if impl == 2 else 1, True)
+        xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 31, impl))
+        chans = [cp.channel(c) for c in range(16)]
+        args = (cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+        assert np.array_equal(orc.spmv(impl, chans, xw, *args), orc.spmv_per_channel_threads(impl, chans, xw, *args, threads=4))
