@@ -227,13 +227,19 @@ def main():
             ip, ix, dv = csr.arrays()
             xf = np.ascontiguousarray(x, dtype=np.float32)
             yref = np.zeros(packets.num_rows, dtype=np.float32)
-            orc.compute_ref_parallel(packets.num_rows, ip, ix, dv, xf, out=yref)
-            t0 = time.perf_counter()
-            for _ in range(5):
-                orc.compute_ref_parallel(packets.num_rows, ip, ix, dv, xf, out=yref)
-            t_omp = (time.perf_counter() - t0) / 5
-            cpu_baseline["csr_openmp_all_cores"] = {"value": round(8.0 * nnz / t_omp / 1e9, 3), "unit": "GB/s", "cores": orc.usable_cores(),
-                                                    "gops": round(2.0 * nnz / t_omp / 1e9, 3), "sample": f"5 float32 CSR SpMVs, {t_omp*1e3:.2f} ms each"}
+            best = None
+            for threads in sorted({min(16, orc.usable_cores()), min(64, orc.usable_cores()), orc.usable_cores()}):   # cgroup quotas make "all" a bad guess
+                orc.compute_ref_parallel(packets.num_rows, ip, ix, dv, xf, out=yref, threads=threads)
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    orc.compute_ref_parallel(packets.num_rows, ip, ix, dv, xf, out=yref, threads=threads)
+                t_omp = (time.perf_counter() - t0) / 5
+                if best is None or t_omp < best[0]:
+                    best = (t_omp, threads)
+            t_omp, threads = best
+            cpu_baseline["csr_openmp_best_thread_count"] = {"value": round(8.0 * nnz / t_omp / 1e9, 3), "unit": "GB/s", "cores": threads,
+                                                            "gops": round(2.0 * nnz / t_omp / 1e9, 3),
+                                                            "sample": f"5 float32 CSR SpMVs, {t_omp*1e3:.2f} ms each (best of 16 / 64 / all host threads)"}
             del ip, ix, dv
         except Exception as e:  # the context number must never break the bench line
             log(rank, f"csr_openmp baseline skipped: {e}")
