@@ -175,6 +175,12 @@ int hsf_csr_fill(hsf_csr* m, float value) {
     return HSF_OK;
 }
 
+int hsf_csr_normalize_by_outdegree(hsf_csr* m) {
+    if (!m) return fail(HSF_BAD_ARG, "null handle");
+    spmv::io::util_normalize_csr_matrix_by_outdegree(m->m);
+    return HSF_OK;
+}
+
 void hsf_csr_free(hsf_csr* m) { delete m; }
 
 int hsf_csr_generate(const char* kind, uint32_t num_rows, uint32_t num_cols, double a, double b, double c, uint64_t seed,

@@ -34,6 +34,9 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream);
 hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_t* y, uint32_t num_rows, uint32_t slices, uint32_t row_lo,
                                  uint32_t row_hi, hipStream_t stream);
 
+// Iterative callers: x[i] = scale (*) y[i] (+) shift, i < n, in Q8.24 (AP_RND, AP_SAT) or fp32 arithmetic.
+hipError_t launch_feedback(bool is_float, const uint32_t* y, uint32_t* x, uint32_t n, uint32_t scale, uint32_t shift, hipStream_t stream);
+
 }  // namespace dev
 }  // namespace hisparse
 

@@ -430,6 +430,21 @@ __global__ __launch_bounds__(256) void combine_slices_kernel(const uint32_t* __r
     }
 }
 
+// Iterative callers: x[i] = scale (*) y[i] (+) shift in the numeric mode's own arithmetic (hisparse_hip.h, hs_feedback).
+template <bool kFloat>
+__global__ __launch_bounds__(256) void feedback_kernel(const uint32_t* __restrict__ y, uint32_t* __restrict__ x, uint32_t n, uint32_t scale,
+                                                       uint32_t shift) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (kFloat) {
+        const float p = __uint_as_float(scale) * __uint_as_float(y[i]);   // -ffp-contract=off: multiply, then add
+        x[i] = __float_as_uint(p + __uint_as_float(shift));
+    } else {
+        const uint64_t s = static_cast<uint64_t>(q8_24_mul(scale, y[i])) + shift;
+        x[i] = s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s);
+    }
+}
+
 template <bool kFloat, bool kDelta, int kAblate, int kDepth>
 hipError_t configure_one(uint32_t lds_bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_rowblock_kernel<kFloat, kDelta, kAblate, kDepth>),
@@ -490,6 +505,14 @@ hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_
     const dim3 grid((row_hi - row_lo + 255) / 256), block(256);
     if (is_float) hipLaunchKernelGGL(combine_slices_kernel<true>, grid, block, 0, stream, partial, y, num_rows, slices, row_lo, row_hi);
     else hipLaunchKernelGGL(combine_slices_kernel<false>, grid, block, 0, stream, partial, y, num_rows, slices, row_lo, row_hi);
+    return hipGetLastError();
+}
+
+hipError_t launch_feedback(bool is_float, const uint32_t* y, uint32_t* x, uint32_t n, uint32_t scale, uint32_t shift, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const dim3 grid((n + 255) / 256), block(256);
+    if (is_float) hipLaunchKernelGGL(feedback_kernel<true>, grid, block, 0, stream, y, x, n, scale, shift);
+    else hipLaunchKernelGGL(feedback_kernel<false>, grid, block, 0, stream, y, x, n, scale, shift);
     return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
     "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_device_vector", "hs_device_result",
-    "hs_bind_device_vector", "hs_bind_device_result", "hs_get_stats", "hs_time_runs", "hs_tiles_build", "hs_tiles_info",
+    "hs_bind_device_vector", "hs_bind_device_result", "hs_feedback", "hs_iterate", "hs_get_stats", "hs_time_runs", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
 
@@ -74,6 +74,8 @@ def lib():
         l.hs_device_result.argtypes = [vp, C.POINTER(vp)]
         l.hs_bind_device_vector.argtypes = [vp, vp]
         l.hs_bind_device_result.argtypes = [vp, vp]
+        l.hs_feedback.argtypes = [vp, u32, u32]
+        l.hs_iterate.argtypes = [vp, u32, u32, u32]
         l.hs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.hs_tiles_build.argtypes = [C.POINTER(vp), C.POINTER(u64), C.c_int, u32, u32, u32, u32, u32, u32, u32, C.POINTER(vp)]
@@ -184,6 +186,14 @@ class SpmvEngine:
         s = Stats()
         self._check(lib().hs_get_stats(self._h, C.byref(s)))
         return s.as_dict()
+
+    def feedback(self, scale_word, shift_word):
+        """x[i] = scale (*) y[i] (+) shift on the device (extension for iterative callers; words from host.pack_vector)."""
+        self._check(lib().hs_feedback(self._h, int(scale_word), int(shift_word)))
+
+    def iterate(self, iterations, scale_word, shift_word):
+        """`iterations` x { run; feedback }, replayed from one captured hipGraph."""
+        self._check(lib().hs_iterate(self._h, int(iterations), int(scale_word), int(shift_word)))
 
     def time_runs(self, warmup, runs, kernel=True):
         """(total_ms for `runs` SpMVs, summed duration of the dominant kernel over those runs or None)."""

@@ -49,6 +49,7 @@ def lib():
         l.hsf_csr_dims.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
         l.hsf_csr_copy.argtypes = [vp, u32p, u32p, f32p]
         l.hsf_csr_fill.argtypes = [vp, C.c_float]
+        l.hsf_csr_normalize_by_outdegree.argtypes = [vp]
         l.hsf_csr_free.argtypes = [vp]
         l.hsf_csr_free.restype = None
         l.hsf_csr_generate.argtypes = [C.c_char_p, u32, u32, C.c_double, C.c_double, C.c_double, u64, C.POINTER(vp)]
@@ -140,6 +141,10 @@ class CSRMatrix:
 
     def fill(self, value):
         _check(lib().hsf_csr_fill(self._h, float(value)))
+
+    def normalize_by_outdegree(self):
+        """util_normalize_csr_matrix_by_outdegree (sw/data_formatter.h:33-47)."""
+        _check(lib().hsf_csr_normalize_by_outdegree(self._h))
 
 
 def load_csr_matrix_from_float_npz(path):

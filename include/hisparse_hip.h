@@ -116,6 +116,19 @@ int hs_device_result(hs_context* ctx, void** y_dev);
 int hs_bind_device_vector(hs_context* ctx, const void* x_dev);
 int hs_bind_device_result(hs_context* ctx, void* y_dev);
 
+/* ---- iterative callers (EXTENSION: no reference counterpart) --------------
+ * The reference's drivers run one SpMV and read y back; an iterative caller (PageRank: sw/data_formatter.h:33-47
+ * normalises the matrix for it) would feed y back into x over PCIe.  On the GPU the feedback stays in HBM:
+ *   hs_feedback: x[i] = scale (*) y[i] (+) shift for i < min(num_rows, num_cols), in the context's arithmetic
+ *     (Q8.24 multiply with AP_RND/AP_SAT then saturating add; or one fp32 multiply, then one fp32 add);
+ *     the remaining words of x keep their value.  scale / shift are value words (hsf_pack_vector of one float).
+ *     Writes the context's vector -- also when it was bound with hs_bind_device_vector.
+ *   hs_iterate: `iterations` x { hs_run; hs_feedback } enqueued from one call (HISPARSE_ITERATE_GRAPH=1: replayed from
+ *     captured hipGraphs of 32 iterations -- measured no faster on ROCm 7.2, see hs_api.cpp).  Asynchronous; y holds the
+ *     last SpMV's result. */
+int hs_feedback(hs_context* ctx, uint32_t scale_word, uint32_t shift_word);
+int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32_t shift_word);
+
 /* ---- measurement ------------------------------------------------------------------------------- */
 int hs_get_stats(const hs_context* ctx, hs_stats* stats);
 /* `runs` back-to-back hs_run calls after `warmup` untimed ones, bracketed by HIP events on the

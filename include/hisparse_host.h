@@ -51,6 +51,8 @@ int hsf_csr_dims(const hsf_csr* m, uint32_t* num_rows, uint32_t* num_cols, uint6
 int hsf_csr_copy(const hsf_csr* m, uint32_t* indptr, uint32_t* indices, float* data);
 /* overwrite all values with one constant (the drivers' `x = 1 / num_cols`, sw/benchmark.cpp:411) */
 int hsf_csr_fill(hsf_csr* m, float value);
+/* util_normalize_csr_matrix_by_outdegree (sw/data_formatter.h:33-47): value := 1 / (non-zeros in the value's column) */
+int hsf_csr_normalize_by_outdegree(hsf_csr* m);
 void hsf_csr_free(hsf_csr* m);
 
 /* ---- synthetic stand-ins for the absent datasets -------------------------------- */

@@ -241,3 +241,53 @@ def test_csim_large_sparse_known_answer():
         ip, ix, dv = csr.arrays()
         ref = orc.compute_ref(cp.num_rows, ip, ix, dv, x)
         assert orc.verify(ref, y) == -1 and np.array_equal(y, ref)
+
+
+def _feedback_reference(impl, y_words, x_words, scale, shift):
+    n = min(len(y_words), len(x_words))
+    out = x_words.copy()
+    if impl == 0:
+        wide = y_words[:n].astype(object) * int(scale) + (1 << 23)          # exact integers
+        prod = np.array([min(int(w) >> 24, 0xFFFFFFFF) for w in wide], dtype=object)
+        out[:n] = np.array([min(int(p) + int(shift), 0xFFFFFFFF) for p in prod], dtype=np.uint32)
+    else:
+        s, b = np.uint32(scale).view(np.float32), np.uint32(shift).view(np.float32)
+        out[:n] = ((s * y_words[:n].view(np.float32)).astype(np.float32) + b).astype(np.float32).view(np.uint32)
+    return out
+
+
+@pytest.mark.parametrize("graph", ["0", "1"])
+@pytest.mark.parametrize("impl", IMPLS)
+def test_pagerank_iterations(impl, graph, monkeypatch):
+    monkeypatch.setenv("HISPARSE_ITERATE_GRAPH", graph)   # plain launches / captured hipGraphs of 32 iterations
+    # iterative caller (hisparse_hip.h extension): PageRank over util_normalize_csr_matrix_by_outdegree, x fed back on
+    # the device through one replayed hipGraph, against the same loop on the CPU (oracle SpMV + exact update arithmetic)
+    n, iters, damping = 3000, 40, 0.85
+    csr = host.CSRMatrix.generate("powerlaw", n, n, a=45000, b=0.3, c=1.0, seed=41)
+    csr.normalize_by_outdegree()
+    v, o = host.default_banks(impl)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    scale = int(host.pack_vector(impl, np.array([damping], dtype=np.float32))[0])
+    shift = int(host.pack_vector(impl, np.array([(1.0 - damping) / n], dtype=np.float32))[0])
+    x0 = host.pack_vector(impl, np.full(cp.num_cols, 1.0 / n, dtype=np.float32))
+    chans = [cp.channel(c) for c in range(16)]
+    x, y = x0.copy(), None
+    for _ in range(iters):
+        y = orc.spmv(impl, chans, x, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+        x = _feedback_reference(impl, y, x, scale, shift)
+    eng = device.SpmvEngine(impl, ob_bank=cp.ob_bank, vb_bank=cp.vb_bank)
+    eng.load_matrix(cp)
+    eng.load_vector(x0)
+    eng.iterate(iters, scale, shift)
+    got_y = eng.read_result()
+    # one more explicit step through the non-graph entry points must continue the same sequence
+    eng.run()
+    eng.feedback(scale, shift)
+    got_y2 = eng.read_result()
+    eng.close()
+    y2 = orc.spmv(impl, chans, x, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+    if impl == 0:
+        assert np.array_equal(got_y, y) and np.array_equal(got_y2, y2)
+        assert got_y[:n].astype(np.float64).sum() / 2 ** 24 > 0.5       # ranks still carry mass (not all rounded away)
+    else:
+        assert cases.float_close(got_y, y) and cases.float_close(got_y2, y2)

@@ -90,3 +90,13 @@ def test_generators_are_deterministic_and_sorted():
     ip, ix, dv = host.CSRMatrix.generate("uniform", 1000, 1024, a=10).arrays()
     assert ip[-1] == 10000 and (dv == 1.0).all()
     assert np.array_equal(ix[:10], (102 * np.arange(10) + 0) % 1024) and np.array_equal(ix[10:20], (102 * np.arange(10) + 1) % 1024)
+
+
+def test_normalize_by_outdegree():
+    # util_normalize_csr_matrix_by_outdegree (sw/data_formatter.h:33-47): value = 1 / (non-zeros in the value's column)
+    csr = host.CSRMatrix.generate("powerlaw", 500, 400, a=6000, b=0.3, c=1.0, seed=5)
+    ip, ix, _ = csr.arrays()
+    csr.normalize_by_outdegree()
+    _, _, dv = csr.arrays()
+    counts = np.bincount(ix, minlength=400)
+    assert np.array_equal(dv, (1.0 / counts[ix]).astype(np.float32))
