@@ -66,6 +66,9 @@ struct Rows<false> {
     static __device__ __forceinline__ prod_t product(uint32_t mat, uint32_t vec) { return q8_24_mul(mat, vec); }
     static __device__ __forceinline__ void add(acc_t* ys, uint32_t row, prod_t p) { atomicAdd(ys + row, p); }   // ds_add_u64
     static __device__ __forceinline__ uint32_t finish(acc_t s) { return s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s); }  // AP_SAT (pe.h:72)
+    using sum_t = unsigned long long;   // a lane's private sum over a row run
+    static __device__ __forceinline__ sum_t widen(prod_t p) { return p; }
+    static __device__ __forceinline__ void add_sum(acc_t* ys, uint32_t row, sum_t v) { atomicAdd(ys + row, v); }
 };
 template <>
 struct Rows<true> {
@@ -76,6 +79,9 @@ struct Rows<true> {
     static __device__ __forceinline__ prod_t product(uint32_t mat, uint32_t vec) { return __uint_as_float(mat) * __uint_as_float(vec); }
     static __device__ __forceinline__ void add(acc_t* ys, uint32_t row, prod_t p) { atomicAdd(ys + row, static_cast<double>(p)); }   // ds_add_f64
     static __device__ __forceinline__ uint32_t finish(acc_t s) { return __float_as_uint(static_cast<float>(s)); }
+    using sum_t = double;               // a lane's private sum over a row run
+    static __device__ __forceinline__ sum_t widen(prod_t p) { return static_cast<double>(p); }
+    static __device__ __forceinline__ void add_sum(acc_t* ys, uint32_t row, sum_t v) { atomicAdd(ys + row, v); }
 };
 
 // Sum over the 64 lanes of a wavefront (result valid in every lane).
@@ -202,10 +208,13 @@ struct Consumer {
     bool head = true;          // DELTA: the next record of this wavefront is a head record
     uint32_t run_row = kNoRow; // PAIRS dense rows: row whose products are being summed in registers ...
     prod_t run_sum = 0;        // ... and this lane's share of that sum
+    uint32_t lane_row = 0;     // DELTA dense rows: the row this LANE is on (its run of consecutive elements rarely leaves it) ...
+    typename Rows<kFloat>::sum_t lane_sum = 0;   // ... and the lane's private sum on it, flushed to LDS when the row changes
 };
 
 // One step (slot K of the ring).  Returns false when the block is finished.
-// kDelta: DELTA format, otherwise PAIRS; kDense (PAIRS only): the block has few, long rows (Block::flags & kBlockDenseRows).
+// kDelta: DELTA format, otherwise PAIRS; kDense: the block's rows are long (Block::flags & kBlockDenseRows): products are
+// summed in registers first (PAIRS: by the whole wavefront on one row; DELTA: by every lane along its own run).
 template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense, int K>
 __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
     using R = Rows<kFloat>;
@@ -216,6 +225,11 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
             const typename R::prod_t sum = wave_sum(c.run_sum);
             if (c.lane == 0) R::add(c.ys, c.run_row, sum);
             c.run_row = Consumer<kFloat>::kNoRow;
+        }
+        if (kDelta && kDense) {        // every lane hands its private row sum over before the sub-tile changes
+            R::add_sum(c.ys, c.lane_row, c.lane_sum);
+            c.lane_row = c.nrows;      // the spare accumulator: the next flush of an idle lane adds 0 there
+            c.lane_sum = 0;
         }
         if (!(kAblate & 8)) lds_barrier();
         if (++c.u == c.U) return false;
@@ -249,7 +263,18 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
                     if (aux == kBridgeGap) prod = 0;
                     row = min(row, c.nrows);
                 }
-                R::add(c.ys, row, prod);
+                if (kDense) {
+                    // Dense rows: a lane's run of consecutive sorted elements stays on one row for many steps (and the lanes
+                    // of one instruction would collide on the few rows there are): sum in a register, touch LDS on row changes.
+                    if (row != c.lane_row) {       // per lane (exec-masked)
+                        R::add_sum(c.ys, c.lane_row, c.lane_sum);
+                        c.lane_row = row;
+                        c.lane_sum = 0;
+                    }
+                    c.lane_sum += R::widen(prod);
+                } else {
+                    R::add(c.ys, row, prod);
+                }
             }
         }
     } else {
@@ -308,6 +333,7 @@ __device__ __forceinline__ void consumer_begin(Consumer<kFloat>& c, const uint8_
     c.last = total ? total - 1 : 0;    // prefetches past the end re-read the last chunk / record (no branch)
     c.xs = xs; c.xb = xs; c.ys = ys;
     c.end = first_end;
+    c.lane_row = nrows;
     prime_ring<kDelta>(c.stream, c.last, kStride, c.lane_off, std::make_integer_sequence<int, kDepth>());
 }
 
@@ -400,7 +426,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 }
             } else {
                 // ---- consumer wavefronts: stream elements, gather x, accumulate rows -----------------------------
-                if (!kDelta && (blk->flags & kBlockDenseRows)) consumer_run<kFloat, false, kAblate, kDepth, true>(c);
+                if (blk->flags & kBlockDenseRows) consumer_run<kFloat, kDelta, kAblate, kDepth, true>(c);
                 else consumer_run<kFloat, kDelta, kAblate, kDepth, false>(c);
             }
         }

@@ -214,7 +214,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
 
     // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse ---------------------
     {
-        const double mean_gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 0.0;
+        const double mean_gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 1e30;
         out.format = (mean_gap >= kDeltaMinMeanGap && mean_gap <= kDeltaMaxMeanGap) ? kFormatDelta : kFormatPairs;
         if (const char* force = std::getenv("HISPARSE_STREAM_FORMAT")) {
             const std::string f(force);
@@ -289,7 +289,13 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             blk.row0 = ranges[b].row0;
             blk.nrows = ranges[b].nrows;
             blk.row_part = ranges[b].row_part;
-            blk.flags = (!delta && ranges[b].nrows <= kDenseBlockRows && range_nnz[b] >= 64ull * ranges[b].nrows) ? kBlockDenseRows : 0u;
+            if (delta) {   // long rows: position gaps well inside a row (HISPARSE_ROW_RUNS=0|1 forces, for the tests)
+                const double gap = range_nnz[b] ? double(ranges[b].nrows) * double(num_cols) / double(range_nnz[b]) : 1e30;
+                const char* force = std::getenv("HISPARSE_ROW_RUNS");
+                blk.flags = (force ? std::atoi(force) != 0 : gap < kDenseMeanGap) ? kBlockDenseRows : 0u;
+            } else {
+                blk.flags = (ranges[b].nrows <= kDenseBlockRows && range_nnz[b] >= 64ull * ranges[b].nrows) ? kBlockDenseRows : 0u;
+            }
             blk.out_offset = slices > 1 ? slice * num_rows + ranges[b].row0 : ranges[b].row0;
             blk.unit_begin = uint32_t(out.units.size());
             for (uint32_t k = 0; k < sub_tiles; ++k) {

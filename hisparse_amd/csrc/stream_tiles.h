@@ -43,9 +43,13 @@
 //       (fixed-point tails are padded with gap 0 / value 0).  Each wavefront's records are contiguous.
 //       On ogbl-ppa this is 6.6 bytes per non-zero all in (heads, bridges, padding) instead of 8.03.
 //
-//     DELTA needs units that are sparse (lanes of one instruction on different rows) but not so sparse that
-//     every other gap needs a bridge: it is chosen when the mean position gap rows*cols/nnz lies in
-//     [kDeltaMinMeanGap, kDeltaMaxMeanGap]; HISPARSE_STREAM_FORMAT=pairs|delta overrides (tests run both).
+//     DELTA is chosen when the mean position gap rows*cols/nnz lies in [kDeltaMinMeanGap, kDeltaMaxMeanGap]:
+//     denser matrices run faster in PAIRS (fewer instructions per element once the stream is no longer the
+//     bound), hyper-sparse ones would need a bridge for every other gap.  Inside a DELTA matrix, blocks whose
+//     rows are long (heavy rows of a power-law graph; block gap < kDenseMeanGap) are flagged kBlockDenseRows:
+//     there every lane sums its run in a register and touches its LDS accumulator only when its row changes
+//     (otherwise the lanes of one instruction collide on the few rows there are: 56 vs 48 us on mouse_gene).
+//     HISPARSE_STREAM_FORMAT=pairs|delta overrides (the parity tests run both on every case).
 //
 // Markers, lane padding and partition headers of the CPSR image are gone in both formats.
 #ifndef HISPARSE_STREAM_TILES_H_
@@ -82,8 +86,9 @@ constexpr uint32_t kRecordBytes = kWaveLanes * (4 + 2);       // one wavefront s
 constexpr uint32_t kMaxGap = 0xfffeu;                         // largest position gap an element slot can carry
 constexpr uint32_t kBridgeGap = 0xffffu;                      // gap code of a slot without element ...
 constexpr uint32_t kBridgeAdvance = 0xffffu;                  // ... which advances the position by this much
-constexpr double kDeltaMinMeanGap = 2048.0;                   // denser: lanes of one instruction collide on rows, PAIRS wins (measured)
-constexpr double kDeltaMaxMeanGap = 20000.0;                  // sparser: > 4 % of the gaps need bridges
+constexpr double kDeltaMinMeanGap = 2048.0;                   // denser matrices: PAIRS wins (measured: mouse_gene 43.6 vs 48.0 us, transformer-50 18.6 vs 24.4)
+constexpr double kDeltaMaxMeanGap = 20000.0;                  // sparser matrices: > 4 % of the gaps need bridges, PAIRS wins
+constexpr double kDenseMeanGap = 2048.0;                      // DELTA blocks denser than this sum per lane in registers (kBlockDenseRows)
 enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1 };
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
@@ -96,7 +101,8 @@ struct Block {
     uint32_t row_part;      // row partition (hs_run_partition filter)
     uint32_t unit_begin;    // units [unit_begin, unit_end), consumed in this order
     uint32_t unit_end;
-    uint32_t flags;         // kBlockDenseRows (PAIRS only): few long rows; chunks are dealt linearly and mostly hold ONE row
+    uint32_t flags;         // kBlockDenseRows: long rows.  PAIRS: chunks are dealt linearly and mostly hold ONE row (wavefront-wide
+                            // register sums); DELTA: every lane sums its own run in a register until its row changes
     uint32_t out_offset;    // word offset of the block's first row in the output: y (one slice) or the per-slice partials
     uint32_t next;          // index of the next block of the same workgroup, 0 = none (workgroup g starts at blocks[g])
     uint64_t wave_offset[kConsumerWaves];   // byte offset of each consumer wavefront's first chunk (PAIRS: its next is kWaveStrideBytes on)

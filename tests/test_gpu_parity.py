@@ -18,10 +18,13 @@ pytestmark = pytest.mark.gpu
 IMPLS = [0, 1, 2]
 
 
-@pytest.fixture(autouse=True, params=["pairs", "delta"])
+@pytest.fixture(autouse=True, params=["pairs", "delta", "delta-lane-sums", "delta-no-lane-sums"])
 def stream_format(request, monkeypatch):
-    # every parity test runs once per device stream format (hisparse_amd/csrc/stream_tiles.h)
-    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", request.param)
+    # every parity test runs once per device stream format (hisparse_amd/csrc/stream_tiles.h); DELTA additionally with the
+    # per-lane register sums of long-row blocks forced on and off (by default the block's density decides)
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", request.param.split("-")[0])
+    if request.param.endswith("-lane-sums"):
+        monkeypatch.setenv("HISPARSE_ROW_RUNS", "0" if "-no-" in request.param else "1")
     return request.param
 
 
@@ -129,6 +132,20 @@ def test_repeated_runs_stay_exact():
         got = eng.read_result()
         assert np.array_equal(got, want), f"run {i}: {int((got != want).sum())} rows differ"
     eng.close()
+
+
+@pytest.mark.parametrize("impl", [0, 2])
+def test_heavy_rows_inside_a_sparse_matrix(impl):
+    # power-law head: a few blocks of very long rows (DELTA: per-lane register sums; PAIRS: dense-row chunks where rows <= 32)
+    # next to a sparse bulk, in one matrix
+    csr = host.CSRMatrix.generate("powerlaw", 30000, 60000, a=600000, b=0.8, c=1.0 if impl == 0 else 2.0, seed=3)
+    ip, ix, dv = csr.arrays()
+    if impl != 0:
+        dv = (dv - 1.0).astype(np.float32)
+    import scipy.sparse as sp
+    m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(30000, 60000))
+    v, o = host.default_banks(impl)
+    _run_case(impl, m, vb=v, ob=o, skip=True, seed=29)
 
 
 @pytest.mark.parametrize("impl", IMPLS)

@@ -129,6 +129,13 @@ def test_format_choice(monkeypatch):
         gap = cp.num_rows * cp.num_cols / cp.nnz
         assert (2048 <= gap <= 20000) == (want == "delta"), gap
         assert build(cp, 0, 16)["format"] == want
+    # inside a DELTA matrix, blocks of heavy rows are flagged for per-lane register sums, the sparse bulk is not
+    csr = host.CSRMatrix.generate("powerlaw", 30000, 60000, a=600000, b=0.8, c=1.0, seed=3)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+    t = build(cp, 0, 64)
+    flags = t["blocks"]["flags"] & 1
+    assert t["format"] == "delta" and flags.any() and not flags.all()
+    assert t["blocks"]["nrows"][flags == 1].max() < t["blocks"]["nrows"][flags == 0].min()
     monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "bogus")
     with pytest.raises(device.DeviceError):
         build(cp, 0, 16)
