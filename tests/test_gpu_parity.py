@@ -308,3 +308,45 @@ def test_pagerank_iterations(impl, graph, monkeypatch):
         assert got_y[:n].astype(np.float64).sum() / 2 ** 24 > 0.5       # ranks still carry mass (not all rounded away)
     else:
         assert cases.float_close(got_y, y) and cases.float_close(got_y2, y2)
+
+
+@pytest.mark.parametrize("name", ["ogbl_ppa", "transformer_50", "ogbn_products", "mouse_gene"])
+def test_full_size_exact_known_answer(name, stream_format, monkeypatch):
+    # BASELINE.json's configurations at FULL size (stand-in generators of hisparse_amd/datasets.py), with inputs that make the
+    # answer independent of summation order and rounding, so it must match an integer CSR product bit for bit in every
+    # numeric mode: all matrix values 2^-10, x in {0, 1, 2, 3}  =>  y[r] = 2^-10 * (sum of the selected x), exact in Q8.24
+    # (no product needs rounding, no row reaches 256) and in fp32 (every partial sum is a multiple of 2^-10 below 2^14).
+    if stream_format != "pairs":
+        pytest.skip("one pass over the big matrices, in the format the library picks by itself")
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    import scipy.sparse as sp
+    from hisparse_amd import datasets
+    cfg, csr = datasets.load(name)
+    impl = host.impl_id(cfg.impl)
+    csr.fill(2.0 ** -10)
+    ip, ix, _ = csr.arrays()
+    rows, cols = csr.num_rows, csr.num_cols
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    x_int = np.random.default_rng(77).integers(0, 4, cp.num_cols).astype(np.int64)
+    pattern = sp.csr_matrix((np.ones(len(ix), dtype=np.int64), ix.astype(np.int64), ip.astype(np.int64)), shape=(rows, cols))
+    sums = pattern @ x_int[:cols]                                    # exact integers
+    assert sums.max() < (1 << 17)                                    # < 256 * 2^10 / ... : far from saturation and from 2^24
+    want = np.zeros(cp.num_rows, dtype=np.uint32)
+    if impl == 0:
+        want[:rows] = (sums << 14).astype(np.uint32)                 # 2^-10 * s in Q8.24 = s * 2^14 LSB
+    else:
+        want[:rows] = (sums.astype(np.float64) / 1024.0).astype(np.float32).view(np.uint32)
+    eng = device.SpmvEngine(impl)
+    eng.load_matrix(cp)
+    eng.load_vector(host.pack_vector(impl, x_int.astype(np.float32)))
+    eng.run()
+    got = eng.read_result()
+    # the same through the reference's partition-by-partition launch sequence
+    for j in range(cp.num_row_partitions):
+        eng.run_partition(j, cp.part_len(j))
+    again = eng.read_result()
+    stats = eng.stats()
+    eng.close()
+    assert stats["nnz"] == len(ix)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} rows differ"
+    assert np.array_equal(again, want)
