@@ -382,6 +382,9 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             out.elements += uint64_t(chunks) * kWaveLanes;
             block_nnz[bi] += up.n;
         }
+        // the kernel addresses a wavefront's stream with a 32-bit byte offset from Block::wave_offset
+        for (uint32_t w = 0; w < kConsumerWaves; ++w)
+            if (uint64_t(pos[w]) * (delta ? kRecordBytes : kWaveStrideBytes) >= (1ull << 32)) { error = "row block stream exceeds 4 GiB"; return false; }
         if (delta) {
             for (uint32_t w = 0; w < kConsumerWaves; ++w) {
                 blk.wave_offset[w] = image_bytes;

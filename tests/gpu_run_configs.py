@@ -1,7 +1,7 @@
-"""Run BASELINE.json's configs on one GPU: parity against the oracle + kernel timing.  usage: run_configs.py [names...]"""
+"""Run BASELINE.json's configs on one GPU: parity against the oracle + kernel timing.  usage: python tests/gpu_run_configs.py [names...]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 from hisparse_amd import datasets, device, host
 from oracle import oracle as orc
 

@@ -1,7 +1,7 @@
 """Diagnostic: ogbl-ppa stand-in, x as in bench.py; repeated single runs compared against the oracle."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 from hisparse_amd import host, device, datasets
 from oracle import oracle as orc
 
