@@ -148,6 +148,23 @@ def test_heavy_rows_inside_a_sparse_matrix(impl):
     _run_case(impl, m, vb=v, ob=o, skip=True, seed=29)
 
 
+def test_random_shapes_and_banks():
+    # seeded fuzz over shapes, densities, bank sizes (hence partition counts), skip_empty_rows and numeric modes
+    rng = np.random.default_rng(20240607)
+    for case in range(36):
+        impl = int(rng.integers(0, 3))
+        rows = int(rng.integers(1, 6000))
+        cols = int(rng.integers(1, 6000))
+        density = float(rng.choice([0.0005, 0.003, 0.02, 0.15]))
+        vb = int(rng.choice([1, 2, 16, 64, 4096]))
+        ob = int(rng.choice([1, 2, 8, 64])) * (8 if impl == 2 else 1)
+        skip = bool(rng.integers(0, 2))
+        try:
+            _run_case(impl, cases.random_csr(rows, cols, density, 100 + case, impl), vb=vb, ob=ob, skip=skip, seed=200 + case)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: impl {impl} {rows}x{cols} density {density} vb {vb} ob {ob} skip {skip}: {e}")
+
+
 @pytest.mark.parametrize("impl", IMPLS)
 def test_tiny_matrix(impl):
     # wavefronts with fewer records than the pipeline depth, and wavefronts with none at all
