@@ -5,25 +5,28 @@
 //
 //   FPGA unit (reference)                                     here, per 1024-thread workgroup
 //   --------------------------------------------------------  --------------------------------------------------
-//   spmv_cluster: owns rows, PE output banks zeroed per        owns a row block; 64-bit (fixed) / fp32 (float) row
-//     launch, dumped at the end (pe.h:121-178)                   accumulators in LDS, zeroed per block, written once
-//   vector loader + vecbuf_access_unit: x partition in 8       4 LOADER wavefronts copy the next x sub-tile (64 KiB)
-//     banks, writer/reader alternate per partition               into the idle one of two LDS buffers while ...
+//   spmv_cluster: owns rows, PE output banks zeroed per        owns a row block; 64-bit row accumulators in LDS (integer
+//     launch, dumped at the end (pe.h:121-178)                   sums / double sums of the fp32 products), zeroed per
+//                                                                block, written once
+//   vector loader + vecbuf_access_unit: x partition in 8       2 LOADER wavefronts refill a ring of 2-4 x sub-tile buffers
+//     banks, writer/reader alternate per partition               (32 KiB each) with LDS-DMA, up to 3 sub-tiles ahead, while ...
 //     (vecbuf_access_unit.h:146-163)
-//   CPSR_matrix_loader: one 64-byte packet per cycle           ... 12 CONSUMER wavefronts stream coalesced 8-byte
-//     (spmv_cluster.h:73-98)                                      elements, 8 loads in flight per lane
+//   CPSR_matrix_loader: one 64-byte packet per cycle           ... 14 CONSUMER wavefronts stream coalesced 8-byte (PAIRS) or
+//     (spmv_cluster.h:73-98)                                      6-byte (DELTA) elements, 8 steps in flight per wavefront,
+//                                                                parked in accumulator registers until a counted wait
 //   shuffle 1 by col%8 + bank read (shuffle.h, vecbuf :126)    ds_read_b32 gather from the LDS sub-tile
-//   shuffle 2 by row%8 + PE accumulate (pe.h:62-81)            ds_add_u64 / ds_add_f32 into the row accumulators
-//   result packer + drain, natural row order                   coalesced y store, AP_SAT clamp applied once
+//   shuffle 2 by row%8 + PE accumulate (pe.h:62-81)            ds_add_u64 / ds_add_f64 into the row accumulators
+//   result packer + drain, natural row order                   coalesced y store, AP_SAT clamp / fp32 rounding applied once
 //     (spmv_result_drain.cpp:104-113)
 //
 // One barrier per (row block, x sub-tile) hands the freshly filled buffer to the consumers.
-// No global atomics, no second pass: y is complete when the kernel ends.  Bandwidth-bound
-// integer / fp32 gather work — no MFMA anywhere.
+// No global atomics: y is complete when the kernel ends, or -- for column-sliced matrices -- after the small
+// combine_slices_kernel that adds the per-slice partial results.  Bandwidth-bound integer / fp32 gather work: no MFMA.
 // Numerics: fixed point = ap_ufixed<32,8,AP_RND,AP_SAT> products summed exactly in 64 bits and clamped
-// once (bit-exact with the saturating PE because every term is non-negative, SURVEY.md §8a-T1);
-// float = separate fp32 multiply and add (no FMA contraction: -ffp-contract=off); the order of the
-// adds differs from the FPGA's arrival order, hence tolerance parity.
+// once (bit-exact with the saturating PE because every term is non-negative, SURVEY.md section 8a-T1);
+// float = one fp32 multiply per product (no FMA contraction: -ffp-contract=off), summed in double and rounded to fp32
+// once per row and column slice; the order of the adds differs from the FPGA's arrival order anyway, hence tolerance parity.
+// Data layout and the two stream formats: stream_tiles.h.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
