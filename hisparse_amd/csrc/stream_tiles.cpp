@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,16 @@ namespace hisparse {
 namespace dev {
 
 namespace {
+
+struct PhaseTimer {   // HISPARSE_PLAN_DEBUG=1: wall time of the load-time passes
+    const bool on = std::getenv("HISPARSE_PLAN_DEBUG") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (on) std::fprintf(stderr, "re-tile %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
 template <typename Fn>
 void parallel_for(size_t n, Fn fn) {
@@ -152,6 +163,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     out = StreamTiles();
     auto chan = [&](uint32_t pc) { return static_cast<const MatPkt*>(channel[pc]); };
 
+    PhaseTimer timer;
     // ---- pass 0: non-zeros per row (rows of different physical channels are disjoint) ------------
     std::vector<uint32_t> row_nnz(num_rows, 0);
     std::vector<WalkResult> res0(size_t(RP) * NUM_HBM_CHANNELS);
@@ -168,6 +180,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         out.nnz += r.nnz;
     }
 
+    timer.lap("pass 0 (row counts)");
     // ---- tile plan: column slices x (rows per block, x ring depth) ------------------------------------------------
     // More column slices = longer row ranges = less x pulled through every CU, at the price of the combine pass; fewer
     // rows per block = deeper x ring = refill latency hidden even when a (row range, sub-tile) unit holds only a few
@@ -264,6 +277,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     const uint32_t ring_fit = (kMaxLdsBytes - (((out.max_block_rows + 1) * kAccumulatorBytes + 15u) & ~15u)) / (kSubTileCols * 4u);
     out.ring_buffers = std::max(kMinXBuffers, std::min(kMaxXBuffers, ring_fit));
 
+    timer.lap("plan + row ranges");
     // ---- pass 1: elements per (row range, column partition, sub-tile, source channel) -------------------
     const size_t slots_per_range = size_t(CP) * S * NUM_HBM_CHANNELS;
     std::vector<uint32_t> cnt(size_t(NR) * slots_per_range, 0);
@@ -278,6 +292,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     for (const auto& r : res1)
         if (!r.ok) { error = r.error; return false; }
 
+    timer.lap("pass 1 (unit counts)");
     // ---- enumerate blocks (row range x column slice) and their units; counts -> offsets into a scratch element list ----
     std::vector<UnitPlan> plans;
     std::vector<uint32_t> unit_of(size_t(NR) * CP * S, 0xffffffffu);  // (row range, cp, s) -> unit index
@@ -327,6 +342,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     const uint32_t NB = uint32_t(out.blocks.size());
     const uint32_t NU = uint32_t(out.units.size());
 
+    timer.lap("enumerate blocks + units");
     // ---- pass 2: collect every unit's elements as (position, value), position = local_row * 8192 + local_col -------
     std::vector<uint64_t> scratch(scratch_elems);   // high word position, low word value: sorts by position
     parallel_for(res1.size(), [&](size_t w) {
@@ -340,6 +356,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     });
     std::vector<uint32_t>().swap(cnt);
 
+    timer.lap("pass 2 (scatter)");
     // ---- per unit: sort by position; DELTA: count slots (elements + bridges for gaps that do not fit 16 bits) -------
     parallel_for(NU, [&](size_t u) {
         UnitPlan& up = plans[u];
@@ -353,6 +370,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         up.slots = slots;
     });
 
+    timer.lap("sort units");
     // ---- per block: deal every unit's 64-slot chunks to the consumer wavefronts round-robin; lay out the streams -------
     std::vector<uint64_t> block_nnz(NB, 0);
     uint64_t image_bytes = 0;
@@ -450,6 +468,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         out.blocks.swap(moved);
     };
 
+    timer.lap("stream layout + workgroups");
     out.image.assign(image_bytes, 0);
     uint8_t* image = out.image.data();
     std::vector<uint32_t> block_of_unit(NU);
@@ -483,6 +502,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             }
         });
         finish_blocks();
+        timer.lap("emit PAIRS");
         return true;
     }
 
@@ -522,6 +542,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         }
     });
     finish_blocks();
+    timer.lap("emit DELTA");
     return true;
 }
 
