@@ -49,6 +49,7 @@ struct hs_context {
     const uint32_t* x_bound = nullptr;
     uint32_t* y_bound = nullptr;
     uint32_t x_capacity = 0;
+    uint32_t x_len = 0;            // words of the vector last given to hs_load_vector
 
     hs_stats stats{};
     std::string error;
@@ -95,6 +96,8 @@ int check_ready(hs_context* ctx) {
     if (!ctx) return HS_ERR_BAD_ARG;
     if (!ctx->matrix_loaded) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix has not been called");
     if (!ctx->vector_loaded && !ctx->x_bound) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_vector has not been called");
+    if (!ctx->x_bound && ctx->x_len != ctx->num_cols)
+        return fail(ctx, HS_ERR_NOT_LOADED, "the loaded vector does not have this matrix's padded column count: call hs_load_vector again");
     return HS_OK;
 }
 
@@ -281,6 +284,7 @@ int hs_load_vector(hs_context* ctx, const void* packed_x, uint32_t num_cols) {
     HS_HIP(ctx, hipMemcpyAsync(ctx->d_x, packed_x, size_t(num_cols) * 4, hipMemcpyHostToDevice, ctx->stream));
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller may reuse packed_x immediately
     ctx->vector_loaded = true;
+    ctx->x_len = num_cols;
     return HS_OK;
 }
 

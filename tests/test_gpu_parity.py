@@ -148,6 +148,28 @@ def test_heavy_rows_inside_a_sparse_matrix(impl):
     _run_case(impl, m, vb=v, ob=o, skip=True, seed=29)
 
 
+def test_context_reuse():
+    # one context, several matrices in a row (column-sliced and not, different sizes): no state of the previous matrix survives,
+    # and a vector left over from a differently sized matrix is refused instead of being read out of bounds
+    eng = device.SpmvEngine(0)
+    last_cols = None
+    for k, (rows, cols, nnz) in enumerate([(30000, 70000, 900000), (900, 500, 9000), (60000, 40000, 400000)]):
+        csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=nnz, b=0.4, c=1.0, seed=50 + k)
+        cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+        xw = host.pack_vector(0, cases.random_x(cp.num_cols, 60 + k, 0))
+        eng.load_matrix(cp)
+        if last_cols is not None and last_cols != cp.num_cols:
+            with pytest.raises(device.DeviceError):
+                eng.run()
+        eng.load_vector(xw)
+        eng.run()
+        want = orc.spmv(0, [cp.channel(c) for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                        cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+        assert np.array_equal(eng.read_result(), want)
+        last_cols = cp.num_cols
+    eng.close()
+
+
 def test_random_shapes_and_banks():
     # seeded fuzz over shapes, densities, bank sizes (hence partition counts), skip_empty_rows and numeric modes
     rng = np.random.default_rng(20240607)
