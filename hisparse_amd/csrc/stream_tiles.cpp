@@ -298,8 +298,29 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     std::vector<uint32_t> unit_of(size_t(NR) * CP * S, 0xffffffffu);  // (row range, cp, s) -> unit index
     const uint32_t sub_tiles = CP * S;
     uint64_t scratch_elems = 0;
+    std::vector<uint64_t> tile_nnz(sub_tiles);
+    std::vector<uint32_t> slice_of(sub_tiles), by_weight(sub_tiles);
     for (uint32_t b = 0; b < NR; ++b) {
-        for (uint32_t slice = 0; slice < slices; ++slice) {   // device block index = b * slices + slice
+        // Column slices of this row range: its sub-tiles are dealt to the slices heaviest first, each to the lightest slice
+        // so far.  (Round-robin by index left the slices of a power-law graph 7 % apart -- the columns of sub-tile 0 are
+        // the popular ones in EVERY row range -- and with one block per workgroup the slowest block is the kernel time.)
+        for (uint32_t k = 0; k < sub_tiles; ++k) {
+            tile_nnz[k] = 0;
+            for (uint32_t pc = 0; pc < NUM_HBM_CHANNELS; ++pc) tile_nnz[k] += cnt[slot(b, k / S, k % S, pc)];
+        }
+        std::iota(by_weight.begin(), by_weight.end(), 0u);
+        std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t x, uint32_t y) { return tile_nnz[x] > tile_nnz[y]; });
+        uint64_t slice_load[kMaxColSlices] = {0};
+        uint32_t slice_tiles[kMaxColSlices] = {0};
+        for (uint32_t k : by_weight) {
+            uint32_t best = 0;
+            for (uint32_t c = 1; c < slices; ++c)
+                if (slice_load[c] < slice_load[best] || (slice_load[c] == slice_load[best] && slice_tiles[c] < slice_tiles[best])) best = c;
+            slice_of[k] = best;
+            slice_load[best] += tile_nnz[k];
+            slice_tiles[best] += 1;     // empty sub-tiles still spread evenly (they cost nothing, but keep the rule simple)
+        }
+        for (uint32_t slice = 0; slice < slices; ++slice) {   // device block index (before finish_blocks) = b * slices + slice
             Block blk{};
             blk.row0 = ranges[b].row0;
             blk.nrows = ranges[b].nrows;
@@ -314,7 +335,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             blk.out_offset = slices > 1 ? slice * num_rows + ranges[b].row0 : ranges[b].row0;
             blk.unit_begin = uint32_t(out.units.size());
             for (uint32_t k = 0; k < sub_tiles; ++k) {
-                if (k % slices != slice) continue;                    // sub-tiles are dealt round-robin to the column slices
+                if (slice_of[k] != slice) continue;
                 const uint32_t cp = k / S, s = k % S;
                 uint64_t n = 0;
                 for (uint32_t pc = 0; pc < NUM_HBM_CHANNELS; ++pc) {   // counts -> exclusive offsets inside the unit
@@ -372,7 +393,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
 
     timer.lap("sort units");
     // ---- per block: deal every unit's 64-slot chunks to the consumer wavefronts round-robin; lay out the streams -------
-    std::vector<uint64_t> block_nnz(NB, 0);
+    std::vector<uint64_t> block_nnz(NB, 0);   // weight of a block for the workgroup assignment
     uint64_t image_bytes = 0;
     for (uint32_t bi = 0; bi < NB; ++bi) {
         Block& blk = out.blocks[bi];
@@ -398,8 +419,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 out.units[u].end_step[w] = pos[w];
             }
             out.elements += uint64_t(chunks) * kWaveLanes;
-            block_nnz[bi] += up.n;
         }
+        for (uint32_t w = 0; w < kConsumerWaves; ++w) block_nnz[bi] += pos[w];   // the block's weight: wavefront steps, heads included
         // the kernel addresses a wavefront's stream with a 32-bit byte offset from Block::wave_offset
         for (uint32_t w = 0; w < kConsumerWaves; ++w)
             if (uint64_t(pos[w]) * (delta ? kRecordBytes : kWaveStrideBytes) >= (1ull << 32)) { error = "row block stream exceeds 4 GiB"; return false; }
@@ -426,10 +447,19 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return block_nnz[a] > block_nnz[b]; });
         mine.resize(groups);
         std::vector<uint64_t> load(groups, 0);
+        std::vector<std::vector<uint32_t>> by_rank(groups);
         for (uint32_t b : order) {
             uint32_t best = uint32_t(std::min_element(load.begin(), load.end()) - load.begin());
-            mine[best].push_back(b);
-            load[best] += block_nnz[b] + 1024;   // every block also costs a fixed prologue/epilogue
+            by_rank[best].push_back(b);
+            load[best] += block_nnz[b] + 16;   // every block also costs a fixed prologue/epilogue (in steps)
+        }
+        // Group i (i-th heaviest first block) becomes workgroup (i % 8) * groups/8 + i / 8: the kernel runs logical
+        // workgroups [x * groups/8, (x+1) * groups/8) on XCD x, so every XCD -- its L2 and its share of the fabric to HBM --
+        // gets the same mix of heavy and light blocks (measured before: XCDs 0-3 held every 2913-step block, 6-7 only
+        // 2755-step ones, and finished 2 us apart).
+        for (uint32_t i = 0; i < groups; ++i) {
+            const uint32_t g = groups % 8 == 0 ? (i % 8) * (groups / 8) + i / 8 : i;
+            mine[g].swap(by_rank[i]);
         }
     }
     // Final block order: the first block of workgroup g sits at blocks[g] (ONE dependent load before the kernel's first

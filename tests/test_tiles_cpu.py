@@ -109,12 +109,17 @@ def test_column_slices(impl, slices, monkeypatch):
     units = t["units"]
     blocks = t["blocks"][np.lexsort((t["blocks"]["out_offset"], t["blocks"]["row0"]))]   # row range major, slice minor
     assert len(blocks) % slices == 0 and blocks["nrows"].max() <= 12287
-    # the slices of one row range own disjoint sub-tiles: sub-tile index mod slices == slice
+    # the slices of one row range own disjoint sub-tiles, every touched sub-tile exactly once, and carry about the same work
     for b in range(0, len(blocks), slices):
+        seen, loads = [], []
         for k in range(slices):
-            u = units[blocks[b + k]["unit_begin"]:blocks[b + k]["unit_end"]]
-            assert ((u["col0"] // 8192) % slices == k).all()
-            assert blocks[b + k]["out_offset"] == k * cp.num_rows + blocks[b]["row0"]
+            blk = blocks[b + k]
+            u = units[blk["unit_begin"]:blk["unit_end"]]
+            seen += (u["col0"] // 8192).tolist()
+            loads.append(int(u["end_step"][-1].sum()) if len(u) else 0)
+            assert blk["out_offset"] == k * cp.num_rows + blocks[b]["row0"] and blk["row0"] == blocks[b]["row0"]
+        assert len(seen) == len(set(seen))
+        assert max(loads) <= 1.25 * (sum(loads) / slices) + 14
     got = tile_emulator.run(t, impl, xw, cp.num_rows)
     want = oracle_y(cp, impl, xw)
     assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
