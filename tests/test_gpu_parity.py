@@ -148,6 +148,20 @@ def test_heavy_rows_inside_a_sparse_matrix(impl):
     _run_case(impl, m, vb=v, ob=o, skip=True, seed=29)
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+def test_hyper_sparse_bridges(impl, stream_format):
+    # most position gaps exceed 16 bits: DELTA needs bridge slots (fixed point: zero-value elements that advance 65535;
+    # float: dead slots whose row is clamped), PAIRS just pads; rows near the end of tall blocks
+    csr = host.CSRMatrix.generate("powerlaw", 30000, 40000, a=15000, b=0.0, c=1.0 if impl == 0 else 2.0, seed=8)
+    ip, ix, dv = csr.arrays()
+    if impl != 0:
+        dv = (dv - 1.0).astype(np.float32)
+    import scipy.sparse as sp
+    m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(30000, 40000))
+    v, o = host.default_banks(impl)
+    _run_case(impl, m, vb=v, ob=o, skip=True, seed=8)
+
+
 def test_context_reuse():
     # one context, several matrices in a row (column-sliced and not, different sizes): no state of the previous matrix survives,
     # and a vector left over from a differently sized matrix is refused instead of being read out of bounds
