@@ -37,6 +37,7 @@ struct hs_context {
     uint8_t* d_image = nullptr;
     Block* d_blocks = nullptr;
     Unit* d_units = nullptr;
+    uint32_t* d_part_heads = nullptr;
     uint32_t num_workgroups = 0;
     uint32_t lds_bytes = 0;
     uint32_t col_slices = 1;
@@ -78,6 +79,8 @@ void free_matrix(hs_context* c) {
     if (c->d_image) (void)hipFree(c->d_image);
     if (c->d_blocks) (void)hipFree(c->d_blocks);
     if (c->d_units) (void)hipFree(c->d_units);
+    if (c->d_part_heads) (void)hipFree(c->d_part_heads);
+    c->d_part_heads = nullptr;
     if (c->d_y) (void)hipFree(c->d_y);
     if (c->d_partial) (void)hipFree(c->d_partial);
     c->d_partial = nullptr;
@@ -106,6 +109,7 @@ hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     a.image = c->d_image;
     a.blocks = c->d_blocks;
     a.units = c->d_units;
+    a.part_heads = c->d_part_heads;
     a.x = x_source(c);
     a.out = c->col_slices > 1 ? c->d_partial : y_target(c);
     a.row_part_filter = filter;
@@ -237,6 +241,7 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_image), tiles.image.data(), tiles.image.size(), kImageSlackBytes));
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_blocks), tiles.blocks.data(), tiles.blocks.size() * sizeof(Block), 0));
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_units), tiles.units.data(), tiles.units.size() * sizeof(Unit), 0));
+    HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_part_heads), tiles.part_heads.data(), tiles.part_heads.size() * sizeof(uint32_t), 0));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
     if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));

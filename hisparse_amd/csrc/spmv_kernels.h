@@ -15,6 +15,7 @@ struct SpmvLaunch {
     const uint8_t* image;         // element streams
     const Block* blocks;          // workgroup g starts at blocks[g] and follows Block::next
     const Unit* units;
+    const uint32_t* part_heads;   // [row partition][workgroup] first block or kNoBlock (only read when row_part_filter >= 0)
     const uint32_t* x;            // packed vector words, num_cols
     uint32_t* out;                // packed result words: y itself (one column slice) or slices x num_rows partials
     int32_t row_part_filter;      // -1: every row partition

@@ -362,7 +362,7 @@ template <bool kFloat, bool kDelta, int kAblate, int kDepth>
 __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const Unit* __restrict__ units, const uint32_t* __restrict__ x,
                                                                   uint32_t* __restrict__ out, int32_t row_part_filter, uint32_t ring,
-                                                                  uint32_t x_base) {
+                                                                  uint32_t x_base, const uint32_t* __restrict__ part_heads) {
     using acc_t = typename Rows<kFloat>::acc_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     acc_t* ys = reinterpret_cast<acc_t*>(lds);                    // [nrows + 1] at LDS address 0: row addresses need no base add
@@ -378,14 +378,17 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
 
     // The workgroup's first block is blocks[wg]; further ones are chained through Block::next (0 = none).  Everything a
     // consumer wavefront needs before its first stream load sits in the Block itself: ONE dependent load per block.
+    // hs_run_partition: only the blocks of one row partition -- the workgroup's chain is ordered by partition, part_heads says
+    // where this partition's stretch begins and kBlockLastOfPartition where it ends.
+    uint32_t bi = wg;
+    if (row_part_filter >= 0) {
+        bi = ((const __attribute__((address_space(4))) uint32_t*)part_heads)[static_cast<uint32_t>(row_part_filter) * gridDim.x + wg];
+        if (bi == kNoBlock) return;
+    }
     bool first_block = true;
-    for (uint32_t bi = wg, next = 0;; bi = next) {
+    for (uint32_t next = 0;; bi = next) {
         const BlockTable blk = (BlockTable)(blocks + bi);
-        next = blk->next;
-        if (row_part_filter >= 0 && blk->row_part != static_cast<uint32_t>(row_part_filter)) {
-            if (!next) break;
-            continue;
-        }
+        next = (row_part_filter >= 0 && (blk->flags & kBlockLastOfPartition)) ? 0u : blk->next;
         const uint32_t nrows = blk->nrows, out0 = blk->out_offset;
         const UnitTable unit = (UnitTable)(units + blk->unit_begin);
         const uint32_t U = blk->unit_end - blk->unit_begin;
@@ -519,7 +522,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(F, T, A, D)                                                                                                           \
     if (!launched && is_float == F && a.delta == T && ablate == A && depth == D) {                                     \
         hipLaunchKernelGGL((spmv_rowblock_kernel<F, T, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \
-                           a.x, a.out, a.row_part_filter, a.ring_buffers, x_base);                   \
+                           a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                   \
         launched = true;                                                                                                        \
     }
     HS_FOR_EACH_VARIANT(X)

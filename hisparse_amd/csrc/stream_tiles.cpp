@@ -442,16 +442,26 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     {
         const uint32_t groups = std::min<uint32_t>(G, std::max<uint32_t>(1, NB));
         out.num_workgroups = groups;
-        std::vector<uint32_t> order(NB);
-        std::iota(order.begin(), order.end(), 0u);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return block_nnz[a] > block_nnz[b]; });
         mine.resize(groups);
-        std::vector<uint64_t> load(groups, 0);
+        std::vector<uint64_t> load(groups, 0), part_load(groups, 0);
         std::vector<std::vector<uint32_t>> by_rank(groups);
-        for (uint32_t b : order) {
-            uint32_t best = uint32_t(std::min_element(load.begin(), load.end()) - load.begin());
-            by_rank[best].push_back(b);
-            load[best] += block_nnz[b] + 16;   // every block also costs a fixed prologue/epilogue (in steps)
+        // Row partition by row partition (a launch of hs_run_partition runs ONE of them and wants it spread over all
+        // workgroups), heaviest block first, each to the workgroup with the least work in this partition -- ties to the one
+        // with the least work overall, so that the partitions' leftovers do not pile up on the same workgroups.
+        for (uint32_t rp = 0; rp < RP; ++rp) {
+            std::vector<uint32_t> order;
+            for (uint32_t b = 0; b < NB; ++b)
+                if (out.blocks[b].row_part == rp) order.push_back(b);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return block_nnz[a] > block_nnz[b]; });
+            std::fill(part_load.begin(), part_load.end(), 0);
+            for (uint32_t b : order) {
+                uint32_t best = 0;
+                for (uint32_t g = 1; g < groups; ++g)
+                    if (part_load[g] < part_load[best] || (part_load[g] == part_load[best] && load[g] < load[best])) best = g;
+                by_rank[best].push_back(b);
+                part_load[best] += block_nnz[b] + 16;   // every block also costs a fixed prologue/epilogue (in steps)
+                load[best] += block_nnz[b] + 16;
+            }
         }
         // Group i (i-th heaviest first block) becomes workgroup (i % 8) * groups/8 + i / 8: the kernel runs logical
         // workgroups [x * groups/8, (x+1) * groups/8) on XCD x, so every XCD -- its L2 and its share of the fabric to HBM --
@@ -485,11 +495,16 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         std::vector<Block> moved(NB);
         out.wg_first.assign(groups + 1, 0);
         out.block_order.clear();
+        out.part_heads.assign(size_t(RP) * groups, kNoBlock);
         for (uint32_t g = 0; g < groups; ++g) {
             out.wg_first[g] = uint32_t(out.block_order.size());
             for (size_t k = 0; k < mine[g].size(); ++k) {
                 Block blk = out.blocks[mine[g][k]];
+                const bool last_of_part = k + 1 == mine[g].size() || out.blocks[mine[g][k + 1]].row_part != blk.row_part;
+                const bool first_of_part = k == 0 || out.blocks[mine[g][k - 1]].row_part != blk.row_part;
                 blk.next = k + 1 < mine[g].size() ? new_index[mine[g][k + 1]] : 0u;
+                if (last_of_part) blk.flags |= kBlockLastOfPartition;
+                if (first_of_part) out.part_heads[size_t(blk.row_part) * groups + g] = new_index[mine[g][k]];
                 moved[new_index[mine[g][k]]] = blk;
                 out.block_order.push_back(new_index[mine[g][k]]);
             }

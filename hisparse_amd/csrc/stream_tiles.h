@@ -93,6 +93,8 @@ enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1 };
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit
+constexpr uint32_t kBlockLastOfPartition = 2u;                // Block::flags bit: the workgroup's last block of this row partition
+constexpr uint32_t kNoBlock = 0xffffffffu;
 
 // Mirrored in the kernel source (read through scalar loads).
 struct Block {
@@ -127,6 +129,8 @@ struct StreamTiles {
     std::vector<Unit> units;
     std::vector<uint32_t> wg_first;      // workgroup g owns block_order[wg_first[g] .. wg_first[g+1]), in this order: a host-side
     std::vector<uint32_t> block_order;   // description (tests, statistics); the kernel follows blocks[g] -> Block::next
+    std::vector<uint32_t> part_heads;    // [row partition][workgroup]: first block of that workgroup in that partition or kNoBlock
+                                         // (hs_run_partition starts there and stops at kBlockLastOfPartition)
     uint32_t num_workgroups = 0;
     uint32_t max_block_rows = 0;
     uint32_t col_slices = 1;             // > 1: blocks write per-slice partial results, a combine pass adds them

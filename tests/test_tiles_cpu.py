@@ -168,6 +168,17 @@ def test_many_row_partitions_and_partition_filter():
     assert cp.num_row_partitions > 3
     xw = host.pack_vector(0, cases.random_x(cp.num_cols, 21, 0))
     t = build(cp, 0, 16)
+    # a workgroup's chain visits the row partitions in order, every partition's stretch ends with the last-of-partition flag,
+    # and each partition is spread over the workgroups (block counts per workgroup differ by at most one)
+    for g in range(t["num_workgroups"]):
+        chain = t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]
+        parts = t["blocks"]["row_part"][chain]
+        assert (np.diff(parts.astype(np.int64)) >= 0).all()
+        last = (t["blocks"]["flags"][chain] & 2) != 0
+        assert np.array_equal(last, np.append(parts[1:] != parts[:-1], True))
+    for p in range(cp.num_row_partitions):
+        per_wg = [int((t["blocks"]["row_part"][t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]] == p).sum()) for g in range(t["num_workgroups"])]
+        assert max(per_wg) - min(per_wg) <= 1
     full = tile_emulator.run(t, 0, xw, cp.num_rows)
     y = np.zeros(cp.num_rows, dtype=np.uint32)
     for j in range(cp.num_row_partitions):
