@@ -222,7 +222,7 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     hisparse::dev::StreamTiles tiles;
     std::string why;
     try {
-        // one 1024-thread workgroup per CU: the two x buffers alone take 128 KiB of the 160 KiB LDS
+        // one 1024-thread workgroup per CU: its row accumulators and x ring fill the 160 KiB LDS
         if (!hisparse::dev::build_stream_tiles(channel, n_packets, g, num_rows, num_cols, num_row_partitions, num_col_partitions,
                                                uint32_t(ctx->compute_units), tiles, why))
             return fail(ctx, HS_ERR_BAD_MATRIX, why);
