@@ -128,15 +128,23 @@ void partition_rows(const hs_context* c, uint32_t j, uint32_t& lo, uint32_t& hi)
     hi = uint32_t(b);
 }
 
-// Enqueue one SpMV (filter < 0) or one row partition; optional events bracket the kernel.
-int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1) {
+// Enqueue one SpMV (filter < 0) or one row partition; optional events bracket the kernel.  `feedback` (hs_iterate): also
+// x = scale (*) y (+) shift afterwards -- folded into the combine launch of a column-sliced matrix, its own launch otherwise.
+struct Feedback { uint32_t scale, shift; };
+int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1, const Feedback* feedback = nullptr) {
     if (k0) HS_HIP(c, hipEventRecord(k0, c->stream));
     HS_HIP(c, hisparse::dev::launch_spmv(c->impl != HS_IMPL_FIXED, launch_args(c, filter), c->stream));
     if (k1) HS_HIP(c, hipEventRecord(k1, c->stream));
+    const bool is_float = c->impl != HS_IMPL_FIXED;
+    uint32_t* x = const_cast<uint32_t*>(x_source(c));
+    const uint32_t n_fb = std::min(c->num_rows, c->num_cols);
     if (c->col_slices > 1) {
         uint32_t lo = 0, hi = c->num_rows;
         if (filter >= 0) partition_rows(c, uint32_t(filter), lo, hi);
-        HS_HIP(c, hisparse::dev::launch_combine_slices(c->impl != HS_IMPL_FIXED, c->d_partial, y_target(c), c->num_rows, c->col_slices, lo, hi, c->stream));
+        HS_HIP(c, hisparse::dev::launch_combine_slices(is_float, c->d_partial, y_target(c), c->num_rows, c->col_slices, lo, hi, c->stream,
+                                                       feedback ? x : nullptr, n_fb, feedback ? feedback->scale : 0, feedback ? feedback->shift : 0));
+    } else if (feedback) {
+        HS_HIP(c, hisparse::dev::launch_feedback(is_float, y_target(c), x, n_fb, feedback->scale, feedback->shift, c->stream));
     }
     return HS_OK;
 }
@@ -327,10 +335,8 @@ int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32
     if (rc != HS_OK) return rc;
     if (iterations == 0) return HS_OK;
     HS_HIP(ctx, hipSetDevice(ctx->device));
-    auto one_iteration = [&]() -> int {
-        int r = enqueue(ctx, -1, nullptr, nullptr);
-        return r != HS_OK ? r : hs_feedback(ctx, scale_word, shift_word);
-    };
+    const Feedback feedback{scale_word, shift_word};
+    auto one_iteration = [&]() -> int { return enqueue(ctx, -1, nullptr, nullptr, &feedback); };
     // One iteration = 2-3 small launches, enqueued from this C loop far faster than the GPU retires them, so plain
     // stream-ordered launches are the default.  HISPARSE_ITERATE_GRAPH=1 captures chunks of 32 iterations into one
     // hipGraph and replays them instead; measured on ROCm 7.2 that is no faster (1k x 1k: 8.4 vs 8.6 us per iteration)

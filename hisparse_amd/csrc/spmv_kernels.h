@@ -31,9 +31,11 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers);
 hipError_t configure_spmv_kernels(uint32_t lds_bytes);
 // The SpMV kernel: row-owner workgroups, x sub-tiles double-buffered in LDS, no global atomics.
 hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream);
-// Column-sliced matrices only: y[r] = (saturating / fp32) sum of the `slices` partial vectors, rows [row_lo, row_hi).
+// Column-sliced matrices only: y[r] = (saturating / fp32) sum of the `slices` partial vectors, rows [row_lo, row_hi);
+// with x_fb also x_fb[r] = scale (*) y[r] (+) shift for r < n_fb (hs_iterate's feedback folded into the same launch).
 hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_t* y, uint32_t num_rows, uint32_t slices, uint32_t row_lo,
-                                 uint32_t row_hi, hipStream_t stream);
+                                 uint32_t row_hi, hipStream_t stream, uint32_t* x_fb = nullptr, uint32_t n_fb = 0, uint32_t scale = 0,
+                                 uint32_t shift = 0);
 
 // Iterative callers: x[i] = scale (*) y[i] (+) shift, i < n, in Q8.24 (AP_RND, AP_SAT) or fp32 arithmetic.
 hipError_t launch_feedback(bool is_float, const uint32_t* y, uint32_t* x, uint32_t n, uint32_t scale, uint32_t shift, hipStream_t stream);

@@ -446,35 +446,43 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
 // Column-sliced matrices: y[r] = sum over slices of the per-slice partial results.  Fixed point: each partial is
 // already clamped to 2^32-1 and min(sum, MAX) == min(sum of min(part, MAX), MAX) for non-negative parts, so the
 // result is still exactly the saturating sum of the PE (pe.h:72).
+// Iterative callers: scale (*) y (+) shift in the numeric mode's own arithmetic (hisparse_hip.h, hs_feedback).
+template <bool kFloat>
+__device__ __forceinline__ uint32_t feedback_word(uint32_t y, uint32_t scale, uint32_t shift) {
+    if (kFloat) {
+        const float p = __uint_as_float(scale) * __uint_as_float(y);   // -ffp-contract=off: multiply, then add
+        return __float_as_uint(p + __uint_as_float(shift));
+    }
+    const uint64_t s = static_cast<uint64_t>(q8_24_mul(scale, y)) + shift;
+    return s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s);
+}
+
+// x_fb != nullptr: also feeds the combined rows below n_fb back into x (one launch less per iteration of hs_iterate).
 template <bool kFloat>
 __global__ __launch_bounds__(256) void combine_slices_kernel(const uint32_t* __restrict__ partial, uint32_t* __restrict__ y,
-                                                             uint32_t num_rows, uint32_t slices, uint32_t row_lo, uint32_t row_hi) {
+                                                             uint32_t num_rows, uint32_t slices, uint32_t row_lo, uint32_t row_hi,
+                                                             uint32_t* __restrict__ x_fb, uint32_t n_fb, uint32_t scale, uint32_t shift) {
     const uint32_t r = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= row_hi) return;
+    uint32_t word;
     if (kFloat) {
         float s = 0.0f;
         for (uint32_t k = 0; k < slices; ++k) s += __uint_as_float(partial[static_cast<size_t>(k) * num_rows + r]);
-        y[r] = __float_as_uint(s);
+        word = __float_as_uint(s);
     } else {
         uint64_t s = 0;
         for (uint32_t k = 0; k < slices; ++k) s += partial[static_cast<size_t>(k) * num_rows + r];
-        y[r] = s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s);
+        word = s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s);
     }
+    y[r] = word;
+    if (x_fb && r < n_fb) x_fb[r] = feedback_word<kFloat>(word, scale, shift);
 }
 
-// Iterative callers: x[i] = scale (*) y[i] (+) shift in the numeric mode's own arithmetic (hisparse_hip.h, hs_feedback).
 template <bool kFloat>
 __global__ __launch_bounds__(256) void feedback_kernel(const uint32_t* __restrict__ y, uint32_t* __restrict__ x, uint32_t n, uint32_t scale,
                                                        uint32_t shift) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (kFloat) {
-        const float p = __uint_as_float(scale) * __uint_as_float(y[i]);   // -ffp-contract=off: multiply, then add
-        x[i] = __float_as_uint(p + __uint_as_float(shift));
-    } else {
-        const uint64_t s = static_cast<uint64_t>(q8_24_mul(scale, y[i])) + shift;
-        x[i] = s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s);
-    }
+    if (i < n) x[i] = feedback_word<kFloat>(y[i], scale, shift);
 }
 
 template <bool kFloat, bool kDelta, int kAblate, int kDepth>
@@ -532,11 +540,11 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 }
 
 hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_t* y, uint32_t num_rows, uint32_t slices, uint32_t row_lo,
-                                 uint32_t row_hi, hipStream_t stream) {
+                                 uint32_t row_hi, hipStream_t stream, uint32_t* x_fb, uint32_t n_fb, uint32_t scale, uint32_t shift) {
     if (row_hi <= row_lo) return hipSuccess;
     const dim3 grid((row_hi - row_lo + 255) / 256), block(256);
-    if (is_float) hipLaunchKernelGGL(combine_slices_kernel<true>, grid, block, 0, stream, partial, y, num_rows, slices, row_lo, row_hi);
-    else hipLaunchKernelGGL(combine_slices_kernel<false>, grid, block, 0, stream, partial, y, num_rows, slices, row_lo, row_hi);
+    if (is_float) hipLaunchKernelGGL(combine_slices_kernel<true>, grid, block, 0, stream, partial, y, num_rows, slices, row_lo, row_hi, x_fb, n_fb, scale, shift);
+    else hipLaunchKernelGGL(combine_slices_kernel<false>, grid, block, 0, stream, partial, y, num_rows, slices, row_lo, row_hi, x_fb, n_fb, scale, shift);
     return hipGetLastError();
 }
 

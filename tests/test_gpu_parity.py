@@ -326,14 +326,16 @@ def _feedback_reference(impl, y_words, x_words, scale, shift):
     return out
 
 
+@pytest.mark.parametrize("slices", ["1", "2"])
 @pytest.mark.parametrize("graph", ["0", "1"])
 @pytest.mark.parametrize("impl", IMPLS)
-def test_pagerank_iterations(impl, graph, monkeypatch):
+def test_pagerank_iterations(impl, graph, slices, monkeypatch):
     monkeypatch.setenv("HISPARSE_ITERATE_GRAPH", graph)   # plain launches / captured hipGraphs of 32 iterations
+    monkeypatch.setenv("HISPARSE_COL_SLICES", slices)     # 2: the feedback rides in the slice-combine launch
     # iterative caller (hisparse_hip.h extension): PageRank over util_normalize_csr_matrix_by_outdegree, x fed back on
     # the device through one replayed hipGraph, against the same loop on the CPU (oracle SpMV + exact update arithmetic)
-    n, iters, damping = 3000, 40, 0.85
-    csr = host.CSRMatrix.generate("powerlaw", n, n, a=45000, b=0.3, c=1.0, seed=41)
+    n, iters, damping = 20000, 40, 0.85
+    csr = host.CSRMatrix.generate("powerlaw", n, n, a=300000, b=0.3, c=1.0, seed=41)
     csr.normalize_by_outdegree()
     v, o = host.default_banks(impl)
     cp = host.format_matrix(csr, impl, skip_empty_rows=True)
