@@ -294,7 +294,7 @@ def main():
         value = 8.0 * total_nnz / (elapsed / args.steps) / 1e9
         achieved = 8.0 * nnz / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "spmv_data_throughput (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346)",
+            "metric": "SpMV GBPS (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346; GOPS and % of the HBM roofline alongside)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "spin_up_steps": SPIN_UP_STEPS,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": args.scaling if n_gpus > 1 else "weak",
             "vs_baseline": None, "dtype": "u32 Q8.24 fixed point (u64 accumulate)" if impl == host.IMPL_FIXED else "f32",
