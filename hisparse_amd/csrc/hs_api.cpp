@@ -417,7 +417,7 @@ int hs_bind_device_vector(hs_context* ctx, const void* x_dev) {
 
 int hs_bind_device_result(hs_context* ctx, void* y_dev) {
     if (!ctx) return HS_ERR_BAD_ARG;
-    if (y_dev && (reinterpret_cast<uintptr_t>(y_dev) & 3u)) return fail(ctx, HS_ERR_BAD_ARG, "device result must be 4-byte aligned");
+    if (y_dev && (reinterpret_cast<uintptr_t>(y_dev) & 15u)) return fail(ctx, HS_ERR_BAD_ARG, "device result must be 16-byte aligned");
     ctx->y_bound = static_cast<uint32_t*>(y_dev);
     return HS_OK;
 }

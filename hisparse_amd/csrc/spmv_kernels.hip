@@ -436,8 +436,17 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 else consumer_run<kFloat, kDelta, kAblate, kDepth, false>(c);
             }
         }
-        // every sub-tile barrier has passed: the accumulators are final
-        // (no barrier after the store: the last block's stores drain while the workgroup retires)
+        // Every sub-tile barrier has passed -- but LDS atomics WITHOUT return value can still be queued behind it: with heavy
+        // same-address conflicts (dense rows in the plain DELTA path, ds_add_f64) the s_waitcnt lgkmcnt(0) in front of the barrier
+        // did not cover them and the accumulators were read too early (40 % of the launches of a 15 %-dense float matrix lost one
+        // record's worth of products; found by tests/gpu_fuzz_soak.py).  LDS executes one wavefront's instructions in order, so a
+        // RETURNING atomic on the spare accumulator, awaited, proves that everything this wavefront queued before it is done.
+        if (!loader) {
+            const acc_t flushed = atomicAdd(ys + nrows, static_cast<acc_t>(0));
+            asm volatile("" ::"v"(flushed));
+        }
+        __syncthreads();
+        // the accumulators are final (no barrier after the store: the last block's stores drain while the workgroup retires)
         if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = Rows<kFloat>::finish(ys[i]);
         if (!next) break;
     }
@@ -458,24 +467,33 @@ __device__ __forceinline__ uint32_t feedback_word(uint32_t y, uint32_t scale, ui
 }
 
 // x_fb != nullptr: also feeds the combined rows below n_fb back into x (one launch less per iteration of hs_iterate).
+// Four rows per thread (row counts, partition bounds and n_fb are multiples of 8): 16-byte loads and stores.
 template <bool kFloat>
 __global__ __launch_bounds__(256) void combine_slices_kernel(const uint32_t* __restrict__ partial, uint32_t* __restrict__ y,
                                                              uint32_t num_rows, uint32_t slices, uint32_t row_lo, uint32_t row_hi,
                                                              uint32_t* __restrict__ x_fb, uint32_t n_fb, uint32_t scale, uint32_t shift) {
-    const uint32_t r = row_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = row_lo + (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
     if (r >= row_hi) return;
-    uint32_t word;
+    uint32_t word[4];
     if (kFloat) {
-        float s = 0.0f;
-        for (uint32_t k = 0; k < slices; ++k) s += __uint_as_float(partial[static_cast<size_t>(k) * num_rows + r]);
-        word = __float_as_uint(s);
+        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (uint32_t k = 0; k < slices; ++k) {
+            const uint4 p = *reinterpret_cast<const uint4*>(partial + static_cast<size_t>(k) * num_rows + r);
+            s[0] += __uint_as_float(p.x); s[1] += __uint_as_float(p.y); s[2] += __uint_as_float(p.z); s[3] += __uint_as_float(p.w);
+        }
+        for (int j = 0; j < 4; ++j) word[j] = __float_as_uint(s[j]);
     } else {
-        uint64_t s = 0;
-        for (uint32_t k = 0; k < slices; ++k) s += partial[static_cast<size_t>(k) * num_rows + r];
-        word = s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s);
+        uint64_t s[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; k < slices; ++k) {
+            const uint4 p = *reinterpret_cast<const uint4*>(partial + static_cast<size_t>(k) * num_rows + r);
+            s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
+        }
+        for (int j = 0; j < 4; ++j) word[j] = s[j] > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s[j]);
     }
-    y[r] = word;
-    if (x_fb && r < n_fb) x_fb[r] = feedback_word<kFloat>(word, scale, shift);
+    *reinterpret_cast<uint4*>(y + r) = make_uint4(word[0], word[1], word[2], word[3]);
+    if (x_fb && r < n_fb)
+        *reinterpret_cast<uint4*>(x_fb + r) = make_uint4(feedback_word<kFloat>(word[0], scale, shift), feedback_word<kFloat>(word[1], scale, shift),
+                                                         feedback_word<kFloat>(word[2], scale, shift), feedback_word<kFloat>(word[3], scale, shift));
 }
 
 template <bool kFloat>
@@ -542,7 +560,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_t* y, uint32_t num_rows, uint32_t slices, uint32_t row_lo,
                                  uint32_t row_hi, hipStream_t stream, uint32_t* x_fb, uint32_t n_fb, uint32_t scale, uint32_t shift) {
     if (row_hi <= row_lo) return hipSuccess;
-    const dim3 grid((row_hi - row_lo + 255) / 256), block(256);
+    const dim3 grid((row_hi - row_lo + 1023) / 1024), block(256);   // four rows per thread
     if (is_float) hipLaunchKernelGGL(combine_slices_kernel<true>, grid, block, 0, stream, partial, y, num_rows, slices, row_lo, row_hi, x_fb, n_fb, scale, shift);
     else hipLaunchKernelGGL(combine_slices_kernel<false>, grid, block, 0, stream, partial, y, num_rows, slices, row_lo, row_hi, x_fb, n_fb, scale, shift);
     return hipGetLastError();

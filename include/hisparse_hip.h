@@ -112,7 +112,7 @@ int hs_set_stream(hs_context* ctx, void* hip_stream);
 /* Device addresses of the library's packed x (num_cols words) and packed y (num_rows words). */
 int hs_device_vector(hs_context* ctx, void** x_dev);
 int hs_device_result(hs_context* ctx, void** y_dev);
-/* Make the kernels read x from / write y to caller-owned device memory (NULL restores the library's). */
+/* Make the kernels read x from / write y to caller-owned device memory, 16-byte aligned (NULL restores the library's). */
 int hs_bind_device_vector(hs_context* ctx, const void* x_dev);
 int hs_bind_device_result(hs_context* ctx, void* y_dev);
 

@@ -1,0 +1,53 @@
+"""Long seeded fuzz on one GPU: random shapes / densities / bank sizes / numeric modes / stream formats, every result compared
+with the oracle; prints the parameters of any failing case.  usage: python tests/gpu_fuzz_soak.py [cases] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from hisparse_amd import device, host
+from oracle import oracle as orc
+import cases
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+fails = 0
+t0 = time.time()
+for case in range(n_cases):
+    impl = int(rng.integers(0, 3))
+    rows = int(rng.integers(1, 6000)); cols = int(rng.integers(1, 6000))
+    density = float(rng.choice([0.0005, 0.003, 0.02, 0.15]))
+    vb = int(rng.choice([1, 2, 16, 64, 4096])); ob = int(rng.choice([1, 2, 8, 64])) * (8 if impl == 2 else 1)
+    skip = bool(rng.integers(0, 2))
+    fmt = str(rng.choice(["pairs", "delta"])); runs = str(rng.choice(["", "0", "1"])); slices = str(rng.choice(["", "", "2", "4"]))
+    os.environ["HISPARSE_STREAM_FORMAT"] = fmt
+    for k, v in (("HISPARSE_ROW_RUNS", runs), ("HISPARSE_COL_SLICES", slices)):
+        if v: os.environ[k] = v
+        else: os.environ.pop(k, None)
+    seed = int(rng.integers(0, 1 << 30))
+    m = cases.random_csr(rows, cols, density, seed, impl)
+    _, cp = cases.formatted(m, impl, vb, ob, skip)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, seed, impl))
+    want = orc.spmv(impl, [cp.channel(c) for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+    try:
+        eng = device.SpmvEngine(impl, ob_bank=cp.ob_bank, vb_bank=cp.vb_bank)
+        eng.load_matrix(cp)
+    except device.DeviceError as e:
+        if "fewer" in str(e) or "plan" in str(e):
+            continue
+        raise
+    eng.load_vector(xw)
+    bad_runs = []
+    for r in range(4):
+        eng.run()
+        got = eng.read_result()
+        ok = np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+        if not ok:
+            bad = np.nonzero(got != want)[0] if impl == 0 else np.nonzero(~np.isclose(got.view(np.float32), want.view(np.float32), rtol=1e-4, atol=1e-4))[0]
+            bad_runs.append((r, len(bad), bad[:6].tolist()))
+    st = eng.stats()
+    eng.close()
+    if bad_runs:
+        fails += 1
+        print(f"FAIL case {case}: impl {impl} {rows}x{cols} density {density} vb {vb} ob {ob} skip {skip} fmt {fmt} runs '{runs}' slices '{slices}' seed {seed} "
+              f"blocks {st['num_blocks']} units {st['num_units']} cs {st['col_slices']} ring {st['ring_buffers']}: {bad_runs}", flush=True)
+print(f"{n_cases} cases, {fails} failing, {time.time() - t0:.0f} s")

@@ -162,6 +162,27 @@ def test_hyper_sparse_bridges(impl, stream_format):
     _run_case(impl, m, vb=v, ob=o, skip=True, seed=8)
 
 
+@pytest.mark.parametrize("impl", [1, 2])
+def test_conflicting_lds_atomics_are_complete_before_the_store(impl, monkeypatch):
+    # regression (found by tests/gpu_fuzz_soak.py): a 15 %-dense float matrix in the DELTA format WITHOUT per-lane sums makes
+    # many lanes of one ds_add_f64 hit the same accumulator; such no-return atomics were still queued when the accumulators
+    # were stored, and ~40 % of the launches lost one record's worth of products.  Every launch must be right.
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "delta")
+    monkeypatch.setenv("HISPARSE_ROW_RUNS", "0")
+    m = cases.random_csr(3004, 1423, 0.15, 543808340, impl)
+    _, cp = cases.formatted(m, impl, 64, 16 if impl == 2 else 2, False)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 543808340, impl))
+    want = orc.spmv(impl, [cp.channel(c) for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions,
+                    cp.ob_bank, cp.vb_bank)
+    eng = device.SpmvEngine(impl, ob_bank=cp.ob_bank, vb_bank=cp.vb_bank)
+    eng.load_matrix(cp)
+    eng.load_vector(xw)
+    for i in range(40):
+        eng.run()
+        assert cases.float_close(eng.read_result(), want), f"launch {i}"
+    eng.close()
+
+
 def test_context_reuse():
     # one context, several matrices in a row (column-sliced and not, different sizes): no state of the previous matrix survives,
     # and a vector left over from a differently sized matrix is refused instead of being read out of bounds
