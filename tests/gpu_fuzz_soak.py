@@ -1,5 +1,5 @@
 """Long seeded fuzz on one GPU: random shapes / densities / bank sizes / numeric modes / stream formats, every result compared
-with the oracle; prints the parameters of any failing case.  usage: python tests/gpu_fuzz_soak.py [cases] [seed]"""
+with the oracle; prints the parameters of any failing case.  usage: [FUZZ_PROFILE=dense|large] python tests/gpu_fuzz_soak.py [cases] [seed]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,8 +14,15 @@ fails = 0
 t0 = time.time()
 for case in range(n_cases):
     impl = int(rng.integers(0, 3))
-    rows = int(rng.integers(1, 6000)); cols = int(rng.integers(1, 6000))
-    density = float(rng.choice([0.0005, 0.003, 0.02, 0.15]))
+    if os.environ.get("FUZZ_PROFILE") == "dense":      # few long rows: heavy same-accumulator traffic
+        rows = int(rng.integers(1, 2000)); cols = int(rng.integers(64, 5000))
+        density = float(rng.choice([0.1, 0.3, 0.6]))
+    elif os.environ.get("FUZZ_PROFILE") == "large":    # several row blocks per workgroup, column slices, bridges
+        rows = int(rng.integers(20000, 120000)); cols = int(rng.integers(20000, 120000))
+        density = float(rng.choice([0.00002, 0.0001, 0.0005]))
+    else:
+        rows = int(rng.integers(1, 6000)); cols = int(rng.integers(1, 6000))
+        density = float(rng.choice([0.0005, 0.003, 0.02, 0.15]))
     vb = int(rng.choice([1, 2, 16, 64, 4096])); ob = int(rng.choice([1, 2, 8, 64])) * (8 if impl == 2 else 1)
     skip = bool(rng.integers(0, 2))
     fmt = str(rng.choice(["pairs", "delta"])); runs = str(rng.choice(["", "0", "1"])); slices = str(rng.choice(["", "", "2", "4"]))
@@ -24,8 +31,14 @@ for case in range(n_cases):
         if v: os.environ[k] = v
         else: os.environ.pop(k, None)
     seed = int(rng.integers(0, 1 << 30))
-    m = cases.random_csr(rows, cols, density, seed, impl)
-    _, cp = cases.formatted(m, impl, vb, ob, skip)
+    if os.environ.get("FUZZ_PROFILE") == "large":      # the C++ generator: scipy.sparse.random takes minutes at this size
+        vb, ob = host.default_banks(impl)
+        csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=max(1.0, rows * cols * density), b=float(rng.choice([0.0, 0.35, 0.7])),
+                                      c=1.0 if impl == 0 else 2.0, seed=seed)
+        cp = host.format_matrix(csr, impl, vb_bank=vb, ob_bank=ob, skip_empty_rows=skip)
+    else:
+        m = cases.random_csr(rows, cols, density, seed, impl)
+        _, cp = cases.formatted(m, impl, vb, ob, skip)
     xw = host.pack_vector(impl, cases.random_x(cp.num_cols, seed, impl))
     want = orc.spmv(impl, [cp.channel(c) for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
     try:
