@@ -2,6 +2,7 @@
 with the oracle; prints the parameters of any failing case.  usage: [FUZZ_PROFILE=dense|large] python tests/gpu_fuzz_soak.py [cases] [seed]"""
 import os, sys, time
 import numpy as np
+import scipy.sparse as sp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from hisparse_amd import device, host
@@ -35,6 +36,8 @@ for case in range(n_cases):
         vb, ob = host.default_banks(impl)
         csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=max(1.0, rows * cols * density), b=float(rng.choice([0.0, 0.35, 0.7])),
                                       c=1.0 if impl == 0 else 2.0, seed=seed)
+        ip, ix, dv = csr.arrays()
+        m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(rows, cols))
         cp = host.format_matrix(csr, impl, vb_bank=vb, ob_bank=ob, skip_empty_rows=skip)
     else:
         m = cases.random_csr(rows, cols, density, seed, impl)
@@ -54,6 +57,12 @@ for case in range(n_cases):
         eng.run()
         got = eng.read_result()
         ok = np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+        if not ok and impl != 0:
+            # csim's fp32 running sum is itself off by more than 1e-4 on long rows with cancellation: when the GPU (double sums)
+            # agrees with the exact float64 product, the disagreement is the oracle's rounding, not a device error
+            exact = np.zeros(cp.num_rows)
+            exact[:rows] = m.astype(np.float64) @ xw.view(np.float32)[:cols].astype(np.float64)
+            ok = np.allclose(got.view(np.float32).astype(np.float64), exact, rtol=1e-4, atol=1e-4)
         if not ok:
             bad = np.nonzero(got != want)[0] if impl == 0 else np.nonzero(~np.isclose(got.view(np.float32), want.view(np.float32), rtol=1e-4, atol=1e-4))[0]
             bad_runs.append((r, len(bad), bad[:6].tolist()))
