@@ -53,6 +53,7 @@ for case in range(n_cases):
         raise
     eng.load_vector(xw)
     bad_runs = []
+    exact = None
     for r in range(4):
         eng.run()
         got = eng.read_result()
@@ -66,6 +67,14 @@ for case in range(n_cases):
         if not ok:
             bad = np.nonzero(got != want)[0] if impl == 0 else np.nonzero(~np.isclose(got.view(np.float32), want.view(np.float32), rtol=1e-4, atol=1e-4))[0]
             bad_runs.append((r, len(bad), bad[:6].tolist()))
+    # the reference's literal launch sequence, one row partition at a time, must give the same vector
+    for j in range(cp.num_row_partitions):
+        eng.run_partition(j, cp.part_len(j))
+    got = eng.read_result()
+    ok = np.array_equal(got, want) if impl == 0 else (cases.float_close(got, want) or
+                                                      (exact is not None and np.allclose(got.view(np.float32).astype(np.float64), exact, rtol=1e-4, atol=1e-4)))
+    if not ok:
+        bad_runs.append(("partitions", int((got != want).sum()), []))
     st = eng.stats()
     eng.close()
     if bad_runs:
