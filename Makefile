@@ -33,8 +33,9 @@ HIP_SRCS  := $(CSRC)/hs_api.cpp $(CSRC)/tiles_capi.cpp $(CSRC)/stream_tiles.cpp 
 $(LIBDIR)/libhisparse_hip.so: $(HIP_SRCS) $(HIP_HDRS) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS) -pthread
 
+# host-only translation unit, built with hipcc for the HIP runtime and RCCL headers (multi-GPU path: one context per device, ncclAllGather of y)
 $(LIBDIR)/benchmark: $(CSRC)/benchmark.cpp $(HOST_HDRS) include/hisparse_hip.h $(LIBDIR)/libhisparse_hip.so $(LIBDIR)/libhisparse_host.so | $(LIBDIR)
-	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lhisparse_hip -lhisparse_host -lz -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+	$(HIPCC) -O3 -std=c++17 -Wall -pthread $(INC) -o $@ $< -L$(LIBDIR) -lhisparse_hip -lhisparse_host -lz -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 oracle/liboracle.so: oracle/cpu_ref.c
 	$(MAKE) -C oracle

@@ -6,16 +6,33 @@
 // (sw/benchmark.cpp:80-87,311-346; formulas restated in 64-bit).
 //
 //   reference:  ./benchmark <hw-xclbin> <dataset> <v> <o>           (:355-365)
-//   here:       ./benchmark <impl>      <dataset> <v> <o> [device]
+//   here:       ./benchmark <impl>      <dataset> <v> <o> [device] [options]
 // The bitstream argument selected the numeric mode (one xclbin per IMPL, sw/Makefile:2-12); here the mode is
 // named directly: fixed | float_pob | float_stall.  <dataset> is a scipy .npz, or synth:<kind>:<rows>:<cols>:<a>:<b>:<c>:<seed>
 // for the generators of libhisparse_host (hsf_csr_generate).  <v>/<o> are the bank sizes in K words.
+//
+// Options (none of them exists in the reference; defaults reproduce round 1's behaviour):
+//   --values literal|intent|keep   literal: every value := `1 / num_cols` in INTEGER arithmetic = 0.0, exactly what
+//                                  sw/benchmark.cpp:411 does (timing parity; y is all zeros); intent (default for .npz):
+//                                  1.0f / num_cols; keep (default for synth:): the data set's own values
+//   --partition-loop               time the reference's literal launch loop: one hs_run_partition + hs_sync (= finish())
+//                                  per row partition (:318-338) instead of one launch for the whole SpMV
+//   --runs K                       NUM_RUNS (default 50, :29)
+//   --dump-x FILE / --dump-y FILE  raw little-endian u32 value words of the packed x / y (for the parity test)
+//   --gpus N [--no-gather]         shard the matrix by row slabs (hisparse/row_sharding.h) over devices 0..N-1 of this node:
+//                                  one hs_context per device, this one host thread issuing to the N streams, and one
+//                                  ncclAllGather (RCCL over xGMI) of the y slabs per SpMV; both the compute-only and the
+//                                  compute + gather times are reported
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
-#include <random>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -23,12 +40,25 @@
 #include "hisparse/channel_packets.h"
 #include "hisparse/data_formatter.h"
 #include "hisparse/data_loader.h"
+#include "hisparse/row_sharding.h"
 #include "hisparse_hip.h"
 #include "hisparse_host.h"
 
 namespace {
 
-const unsigned NUM_RUNS = 50;  // sw/benchmark.cpp:29
+struct Options {
+    int impl = -1;
+    std::string dataset;
+    unsigned vb_bank_size = 0, ob_bank_size = 0;
+    int device = 0;
+    unsigned runs = 50;  // NUM_RUNS, sw/benchmark.cpp:29
+    std::string values;  // literal | intent | keep ("" = default for the dataset kind)
+    bool partition_loop = false;
+    std::string dump_x, dump_y;
+    int gpus = 1;
+    bool gather = true;
+    bool sharded = false;   // take the multi-GPU path even with one GPU (exercises RCCL on a single-GPU box)
+};
 
 struct benchmark_result {
     double preprocess_time_s;
@@ -49,6 +79,16 @@ void check(int rc, hs_context* ctx, const char* what) {
     std::printf("HS Error at %s: %s (%s)\n", what, hs_strerror(rc), hs_last_error(ctx));
     std::exit(EXIT_FAILURE);
 }
+void hip_check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return;
+    std::printf("HIP Error at %s: %s\n", what, hipGetErrorString(e));
+    std::exit(EXIT_FAILURE);
+}
+void nccl_check(ncclResult_t r, const char* what) {
+    if (r == ncclSuccess) return;
+    std::printf("RCCL Error at %s: %s\n", what, ncclGetErrorString(r));
+    std::exit(EXIT_FAILURE);
+}
 
 int parse_impl(const std::string& s) {
     if (s == "fixed") return hisparse::IMPL_FIXED;
@@ -57,37 +97,80 @@ int parse_impl(const std::string& s) {
     return -1;
 }
 
-benchmark_result spmv_benchmark(int impl, unsigned vb_bank_size, unsigned ob_bank_size, int device,
-                                spmv::io::CSRMatrix<float>& ext_matrix, bool skip_empty_rows) {
+void dump_words(const std::string& path, const std::vector<uint32_t>& words) {
+    if (path.empty()) return;
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(words.data()), std::streamsize(words.size() * 4));
+    if (!f) {
+        std::cout << "ERROR : cannot write " << path << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+}
+
+void fill_result(benchmark_result& res, double nnz, double ms) {
+    res.spmv_time_ms = ms;
+    res.throughput_GBPS = nnz * 8.0 / 1024.0 / 1024.0 / 1024.0 / (ms / 1000.0);  // GiB/s, as the reference prints
+    res.throughput_GOPS = 2.0 * nnz / 1e6 / ms;
+}
+
+// x = rand() % 2 like the reference (benchmark.cpp:205-212; rand() is never seeded: glibc's default sequence), packed
+// by the value type's converting constructor
+std::vector<uint32_t> make_vector(int impl, uint32_t num_cols) {
+    std::vector<float> vector_f(num_cols);
+    for (auto& v : vector_f) v = float(std::rand() % 2);
+    std::vector<uint32_t> vector(num_cols);
+    hisparse::pack_vector(impl, vector_f.data(), vector_f.size(), vector.data());
+    return vector;
+}
+
+struct DeviceSlab {   // one device's share of the matrix
+    hs_context* ctx = nullptr;
+    hisparse::ChannelPackets packets;
+};
+
+void load_slab(DeviceSlab& s, const Options& o, int device, const std::vector<uint32_t>& vector) {
+    check(hs_create(&s.ctx, device, o.impl, o.ob_bank_size, o.vb_bank_size), nullptr, "hs_create");
+    const void* ch[HS_NUM_CHANNELS];
+    uint64_t n[HS_NUM_CHANNELS];
+    for (unsigned c = 0; c < HS_NUM_CHANNELS; ++c) {
+        ch[c] = s.packets.channel[c].data();
+        n[c] = s.packets.channel[c].size();
+    }
+    check(hs_load_matrix(s.ctx, ch, n, s.packets.num_rows, s.packets.num_cols, s.packets.num_row_partitions, s.packets.num_col_partitions), s.ctx,
+          "hs_load_matrix");
+    check(hs_load_vector(s.ctx, vector.data(), s.packets.num_cols), s.ctx, "hs_load_vector");
+}
+
+void run_once(DeviceSlab& s, bool partition_loop) {
+    if (!partition_loop) {
+        check(hs_run(s.ctx), s.ctx, "hs_run");    // every row partition (benchmark.cpp:318-339) in one launch
+        return;
+    }
+    for (uint32_t j = 0; j < s.packets.num_row_partitions; ++j) {   // the reference's loop, literally (:318-338)
+        check(hs_run_partition(s.ctx, j, s.packets.part_len(j)), s.ctx, "hs_run_partition");
+        check(hs_sync(s.ctx), s.ctx, "hs_sync");  // queue.finish()
+    }
+}
+
+benchmark_result spmv_benchmark(const Options& o, spmv::io::CSRMatrix<float>& ext_matrix, bool skip_empty_rows) {
     using clock = std::chrono::steady_clock;
     benchmark_result res{};
     std::cout << "INFO : Test started" << std::endl;
     const auto t0 = clock::now();
-    hisparse::Geometry g = hisparse::make_geometry(impl, ob_bank_size, vb_bank_size);
-    hisparse::ChannelPackets packets = hisparse::format_matrix(ext_matrix, g, skip_empty_rows);
+    hisparse::Geometry g = hisparse::make_geometry(o.impl, o.ob_bank_size, o.vb_bank_size);
+    DeviceSlab s;
+    s.packets = hisparse::format_matrix(ext_matrix, g, skip_empty_rows);
+    const hisparse::ChannelPackets& packets = s.packets;
     const auto t1 = clock::now();
     res.preprocess_time_s = std::chrono::duration<double>(t1 - t0).count();
     std::cout << "INFO : Matrix loading/preprocessing complete!" << std::endl;
     std::cout << "  row_partitions: " << packets.num_row_partitions << std::endl;
     std::cout << "  col_partitions: " << packets.num_col_partitions << std::endl;
 
-    // x = rand() % 2 like the reference (benchmark.cpp:205-212), packed by the value type's converting constructor
-    std::vector<float> vector_f(packets.num_cols);
-    for (auto& v : vector_f) v = float(std::rand() % 2);
-    std::vector<uint32_t> vector(packets.num_cols), result(packets.num_rows, 0);
-    hisparse::pack_vector(impl, vector_f.data(), vector_f.size(), vector.data());
+    std::vector<uint32_t> vector = make_vector(o.impl, packets.num_cols), result(packets.num_rows, 0);
     std::cout << "INFO : Input/result initialization complete!" << std::endl;
-
-    hs_context* ctx = nullptr;
-    check(hs_create(&ctx, device, impl, ob_bank_size, vb_bank_size), nullptr, "hs_create");
-    const void* ch[HS_NUM_CHANNELS];
-    uint64_t n[HS_NUM_CHANNELS];
-    for (unsigned c = 0; c < HS_NUM_CHANNELS; ++c) {
-        ch[c] = packets.channel[c].data();
-        n[c] = packets.channel[c].size();
-    }
-    check(hs_load_matrix(ctx, ch, n, packets.num_rows, packets.num_cols, packets.num_row_partitions, packets.num_col_partitions), ctx, "hs_load_matrix");
-    check(hs_load_vector(ctx, vector.data(), packets.num_cols), ctx, "hs_load_vector");
+    load_slab(s, o, o.device, vector);
+    hs_context* ctx = s.ctx;
     std::cout << "INFO : Host -> Device data transfer complete!" << std::endl;
     hs_stats st;
     hs_get_stats(ctx, &st);
@@ -95,53 +178,196 @@ benchmark_result spmv_benchmark(int impl, unsigned vb_bank_size, unsigned ob_ban
               << st.num_workgroups << " workgroups, stream " << st.stream_bytes / 1e6 << " MB" << std::endl;
 
     std::cout << "INFO : Invoking kernel:" << std::endl;
-    for (int i = 0; i < 5; ++i) check(hs_run(ctx), ctx, "hs_run");  // untimed warm-ups (the reference has none)
+    for (int i = 0; i < 5; ++i) run_once(s, o.partition_loop);  // untimed warm-ups (the reference has none)
     check(hs_sync(ctx), ctx, "hs_sync");
     double total_ms = 0;
-    for (unsigned i = 0; i < NUM_RUNS; ++i) {
+    for (unsigned i = 0; i < o.runs; ++i) {
         const auto a = clock::now();
-        check(hs_run(ctx), ctx, "hs_run");    // every row partition (benchmark.cpp:318-339) in one launch
+        run_once(s, o.partition_loop);
         check(hs_sync(ctx), ctx, "hs_sync");  // queue.finish()
         total_ms += std::chrono::duration<double, std::milli>(clock::now() - a).count();
     }
     const double nnz = double(packets.nnz);
-    res.spmv_time_ms = total_ms / NUM_RUNS;
-    res.throughput_GBPS = nnz * 8.0 / 1024.0 / 1024.0 / 1024.0 / (res.spmv_time_ms / 1000.0);  // GiB/s, as the reference prints
-    res.throughput_GOPS = 2.0 * nnz / 1e6 / res.spmv_time_ms;
+    fill_result(res, nnz, total_ms / o.runs);
     float ev_ms = 0, k_ms = 0;
-    check(hs_time_runs(ctx, 0, int(NUM_RUNS), &ev_ms, &k_ms), ctx, "hs_time_runs");
-    std::cout << "  device-side: " << ev_ms / NUM_RUNS << " ms per SpMV back-to-back, kernel alone " << k_ms / NUM_RUNS << " ms = "
-              << nnz * 8.0 / (k_ms / NUM_RUNS * 1e-3) / 1e9 << " GB/s = " << nnz * 8.0 / (k_ms / NUM_RUNS * 1e-3) / 8e12 * 100
+    check(hs_time_runs(ctx, 0, int(o.runs), &ev_ms, &k_ms), ctx, "hs_time_runs");
+    std::cout << "  device-side: " << ev_ms / o.runs << " ms per SpMV back-to-back, kernel alone " << k_ms / o.runs << " ms = "
+              << nnz * 8.0 / (k_ms / o.runs * 1e-3) / 1e9 << " GB/s = " << nnz * 8.0 / (k_ms / o.runs * 1e-3) / 8e12 * 100
               << " % of the 8 TB/s HBM roofline" << std::endl;
     check(hs_read_result(ctx, result.data(), packets.num_rows), ctx, "hs_read_result");
+    dump_words(o.dump_x, vector);
+    dump_words(o.dump_y, result);
     hs_destroy(ctx);
     return res;
+}
+
+// ---- one matrix over N GPUs of this node: row slabs, one thread, N streams, one ncclAllGather of y per SpMV ------------------
+benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<float>& ext_matrix, bool skip_empty_rows) {
+    using clock = std::chrono::steady_clock;
+    benchmark_result res{};
+    const int N = o.gpus;
+    int visible = 0;
+    hip_check(hipGetDeviceCount(&visible), "hipGetDeviceCount");
+    if (N > visible) {
+        std::cout << "ERROR : --gpus " << N << " but only " << visible << " device(s) visible" << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+    std::cout << "INFO : Test started (" << N << " GPUs, row slabs)" << std::endl;
+    const auto t0 = clock::now();
+    hisparse::Geometry g = hisparse::make_geometry(o.impl, o.ob_bank_size, o.vb_bank_size);
+    const uint32_t true_rows = ext_matrix.num_rows;
+    const uint32_t padded_cols = hisparse::padded_rows(ext_matrix.num_cols, hisparse::PACK_SIZE);
+    const std::vector<uint32_t> bounds = hisparse::split_rows_by_nnz(ext_matrix.adj_indptr, uint32_t(N), g.row_divisor);
+    std::vector<DeviceSlab> slab(N);
+    uint64_t nnz_total = 0;
+    uint32_t chunk = 0;   // padded rows of the tallest slab = the all-gather count per rank
+    for (int d = 0; d < N; ++d) {
+        if (bounds[d + 1] == bounds[d]) {
+            std::cout << "ERROR : the matrix has fewer than " << N << " x " << g.row_divisor << " rows: slab " << d << " is empty" << std::endl;
+            std::exit(EXIT_FAILURE);
+        }
+        spmv::io::CSRMatrix<float> part = hisparse::row_slab(ext_matrix, bounds[d], bounds[d + 1]);
+        slab[d].packets = hisparse::format_matrix(part, g, skip_empty_rows);
+        nnz_total += slab[d].packets.nnz;
+        chunk = std::max(chunk, slab[d].packets.num_rows);
+        std::cout << "  slab " << d << ": rows [" << bounds[d] << ", " << bounds[d + 1] << "), nnz " << slab[d].packets.nnz << ", "
+                  << slab[d].packets.num_row_partitions << " x " << slab[d].packets.num_col_partitions << " partitions" << std::endl;
+    }
+    res.preprocess_time_s = std::chrono::duration<double>(clock::now() - t0).count();
+    std::cout << "INFO : Matrix loading/preprocessing complete!" << std::endl;
+
+    std::vector<uint32_t> vector = make_vector(o.impl, padded_cols);
+    std::cout << "INFO : Input/result initialization complete!" << std::endl;
+    std::vector<int> devlist(N);
+    std::vector<hipStream_t> stream(N);
+    std::vector<uint32_t*> gathered(N, nullptr);   // per device: N chunks; the device's own slab is written in place at chunk d
+    std::vector<ncclComm_t> comm(N);
+    for (int d = 0; d < N; ++d) devlist[d] = d;
+    nccl_check(ncclCommInitAll(comm.data(), N, devlist.data()), "ncclCommInitAll");
+    for (int d = 0; d < N; ++d) {
+        hip_check(hipSetDevice(d), "hipSetDevice");
+        hip_check(hipStreamCreateWithFlags(&stream[d], hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&gathered[d]), size_t(chunk) * N * 4), "hipMalloc");
+        hip_check(hipMemset(gathered[d], 0, size_t(chunk) * N * 4), "hipMemset");
+        load_slab(slab[d], o, d, vector);
+        check(hs_set_stream(slab[d].ctx, stream[d]), slab[d].ctx, "hs_set_stream");
+        check(hs_bind_device_result(slab[d].ctx, gathered[d] + size_t(d) * chunk), slab[d].ctx, "hs_bind_device_result");
+    }
+    std::cout << "INFO : Host -> Device data transfer complete!" << std::endl;
+
+    auto spmv_all = [&]() {
+        for (int d = 0; d < N; ++d) run_once(slab[d], false);
+    };
+    auto gather_all = [&]() {   // in place: sendbuff = recvbuff + rank * count
+        nccl_check(ncclGroupStart(), "ncclGroupStart");
+        for (int d = 0; d < N; ++d)
+            nccl_check(ncclAllGather(gathered[d] + size_t(d) * chunk, gathered[d], chunk, ncclUint32, comm[d], stream[d]), "ncclAllGather");
+        nccl_check(ncclGroupEnd(), "ncclGroupEnd");
+    };
+    auto sync_all = [&]() {
+        for (int d = 0; d < N; ++d) {
+            hip_check(hipSetDevice(d), "hipSetDevice");
+            hip_check(hipStreamSynchronize(stream[d]), "hipStreamSynchronize");
+        }
+    };
+    auto timed = [&](bool with_gather) {
+        for (int i = 0; i < 5; ++i) { spmv_all(); if (with_gather) gather_all(); }
+        sync_all();
+        const auto a = clock::now();
+        for (unsigned i = 0; i < o.runs; ++i) { spmv_all(); if (with_gather) gather_all(); }
+        sync_all();
+        return std::chrono::duration<double, std::milli>(clock::now() - a).count() / o.runs;
+    };
+    std::cout << "INFO : Invoking kernel:" << std::endl;
+    const double compute_ms = timed(false);
+    benchmark_result compute_only = res;
+    fill_result(compute_only, double(nnz_total), compute_ms);
+    std::cout << "  compute only (y left sharded, like the reference leaves it in HBM): " << compute_only << std::endl;
+    if (o.gather) {
+        const double both_ms = timed(true);
+        fill_result(res, double(nnz_total), both_ms);
+        std::cout << "  compute + one all-gather of y per SpMV (RCCL, " << chunk * 4.0 / 1e3 << " kB per rank): " << res << std::endl;
+        std::cout << "  all-gather cost per SpMV: " << (both_ms - compute_ms) * 1e3 << " us" << std::endl;
+    } else {
+        res = compute_only;
+    }
+    std::cout << "  fraction of " << N << " x 8 TB/s HBM roofline: " << double(nnz_total) * 8.0 / (res.spmv_time_ms * 1e-3) / (8e12 * N) * 100 << " %" << std::endl;
+
+    // y in natural row order from device 0's gathered buffer (or slab by slab without the gather)
+    spmv_all();
+    if (o.gather) gather_all();
+    sync_all();
+    std::vector<uint32_t> result(true_rows, 0), tmp(chunk);
+    for (int d = 0; d < N; ++d) {
+        const int src = o.gather ? 0 : d;
+        hip_check(hipSetDevice(src), "hipSetDevice");
+        hip_check(hipMemcpy(tmp.data(), gathered[src] + size_t(d) * chunk, size_t(chunk) * 4, hipMemcpyDeviceToHost), "hipMemcpy");
+        std::copy(tmp.begin(), tmp.begin() + (bounds[d + 1] - bounds[d]), result.begin() + bounds[d]);
+    }
+    dump_words(o.dump_x, vector);
+    dump_words(o.dump_y, result);
+    for (int d = 0; d < N; ++d) {
+        hip_check(hipSetDevice(d), "hipSetDevice");
+        check(hs_set_stream(slab[d].ctx, nullptr), slab[d].ctx, "hs_set_stream");
+        hs_destroy(slab[d].ctx);
+        ncclCommDestroy(comm[d]);
+        hip_check(hipFree(gathered[d]), "hipFree");
+        hip_check(hipStreamDestroy(stream[d]), "hipStreamDestroy");
+    }
+    return res;
+}
+
+bool parse_args(int argc, char** argv, Options& o) {
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&](const char* name) -> std::string {
+            if (i + 1 >= argc) { std::cout << "ERROR : " << name << " needs a value" << std::endl; std::exit(1); }
+            return argv[++i];
+        };
+        if (a == "--values") o.values = need("--values");
+        else if (a == "--partition-loop") o.partition_loop = true;
+        else if (a == "--runs") o.runs = unsigned(std::max(1, std::atoi(need("--runs").c_str())));
+        else if (a == "--dump-x") o.dump_x = need("--dump-x");
+        else if (a == "--dump-y") o.dump_y = need("--dump-y");
+        else if (a == "--gpus") o.gpus = std::max(1, std::atoi(need("--gpus").c_str()));
+        else if (a == "--no-gather") o.gather = false;
+        else if (a == "--sharded") o.sharded = true;
+        else if (a == "--device") o.device = std::atoi(need("--device").c_str());
+        else if (a.rfind("--", 0) == 0) { std::cout << "ERROR : unknown option " << a << std::endl; return false; }
+        else pos.push_back(a);
+    }
+    if (pos.size() != 4 && pos.size() != 5) return false;
+    o.impl = parse_impl(pos[0]);
+    o.dataset = pos[1];
+    o.vb_bank_size = unsigned(std::atoi(pos[2].c_str())) * 1024;  // benchmark.cpp:364-365
+    o.ob_bank_size = unsigned(std::atoi(pos[3].c_str())) * 1024;
+    if (pos.size() == 5) o.device = std::atoi(pos[4].c_str());
+    if (o.impl < 0) { std::cout << "ERROR : unknown implementation " << pos[0] << std::endl; std::exit(1); }
+    if (!o.values.empty() && o.values != "literal" && o.values != "intent" && o.values != "keep") {
+        std::cout << "ERROR : --values must be literal, intent or keep" << std::endl;
+        std::exit(1);
+    }
+    return true;
 }
 
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc != 5 && argc != 6) {
-        std::cout << "Usage: " << argv[0] << " <fixed|float_pob|float_stall> <dataset.npz | synth:kind:rows:cols:a:b:c:seed> <v> <o> [device]" << std::endl;
+    Options o;
+    if (!parse_args(argc, argv, o)) {
+        std::cout << "Usage: " << argv[0] << " <fixed|float_pob|float_stall> <dataset.npz | synth:kind:rows:cols:a:b:c:seed> <v> <o> [device]"
+                  << " [--values literal|intent|keep] [--partition-loop] [--runs K] [--dump-x FILE] [--dump-y FILE] [--gpus N [--no-gather] [--sharded]]" << std::endl;
         return 0;
     }
-    const int impl = parse_impl(argv[1]);
-    if (impl < 0) {
-        std::cout << "ERROR : unknown implementation " << argv[1] << std::endl;
-        return 1;
-    }
-    const std::string dataset = argv[2];
-    const unsigned vb_bank_size = unsigned(std::atoi(argv[3])) * 1024;  // benchmark.cpp:364-365
-    const unsigned ob_bank_size = unsigned(std::atoi(argv[4])) * 1024;
-    const int device = argc == 6 ? std::atoi(argv[5]) : 0;
-
-    std::cout << "------ Running benchmark on " << dataset << std::endl;
+    std::cout << "------ Running benchmark on " << o.dataset << std::endl;
     spmv::io::CSRMatrix<float> mat_f;
+    const bool synthetic = o.dataset.rfind("synth:", 0) == 0;
     try {
-        if (dataset.rfind("synth:", 0) == 0) {
+        if (synthetic) {
             // synth:kind:rows:cols:a:b:c:seed -> the seeded generators of libhisparse_host (hsf_csr_generate)
             std::vector<std::string> f;
-            std::stringstream ss(dataset);
+            std::stringstream ss(o.dataset);
             for (std::string tok; std::getline(ss, tok, ':');) f.push_back(tok);
             if (f.size() != 8) { std::cout << "ERROR : expected synth:kind:rows:cols:a:b:c:seed" << std::endl; return 1; }
             hsf_csr* h = nullptr;
@@ -157,19 +383,23 @@ int main(int argc, char** argv) {
             mat_f.adj_data.resize(nnz);
             hsf_csr_copy(h, mat_f.adj_indptr.data(), mat_f.adj_indices.data(), mat_f.adj_data.data());
             hsf_csr_free(h);
-            std::cout << spmv_benchmark(impl, vb_bank_size, ob_bank_size, device, mat_f, true) << std::endl;
-            std::cout << "===== Benchmark Finished =====" << std::endl;
-            return 0;
+        } else {
+            mat_f = spmv::io::load_csr_matrix_from_float_npz(o.dataset);
         }
-        mat_f = spmv::io::load_csr_matrix_from_float_npz(dataset);
     } catch (const std::exception& e) {
         std::cout << "ERROR : " << e.what() << std::endl;
         return 1;
     }
-    // The reference sets every value to `1 / num_cols`, which is integer division and yields 0.0 (benchmark.cpp:411);
-    // the intent, a small non-degenerate constant, is used here so that the result is worth reading back.
-    for (auto& v : mat_f.adj_data) v = 1.0f / float(mat_f.num_cols);
-    std::cout << spmv_benchmark(impl, vb_bank_size, ob_bank_size, device, mat_f, true) << std::endl;
+    const std::string values = !o.values.empty() ? o.values : (synthetic ? "keep" : "intent");
+    if (values == "literal") {
+        // `x = 1 / mat_f.num_cols` with both operands integers (sw/benchmark.cpp:411): 0 for every matrix wider than one column
+        const float v = float(1 / std::max<uint32_t>(1, mat_f.num_cols));
+        for (auto& x : mat_f.adj_data) x = v;
+    } else if (values == "intent") {
+        // the intent of that line, a small non-degenerate constant, so that the result is worth reading back
+        for (auto& x : mat_f.adj_data) x = 1.0f / float(mat_f.num_cols);
+    }
+    std::cout << (o.gpus > 1 || o.sharded ? spmv_benchmark_multi(o, mat_f, true) : spmv_benchmark(o, mat_f, true)) << std::endl;
     std::cout << "===== Benchmark Finished =====" << std::endl;
     return 0;
 }

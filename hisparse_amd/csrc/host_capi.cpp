@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -14,6 +15,7 @@
 #include "hisparse/common.h"
 #include "hisparse/data_formatter.h"
 #include "hisparse/data_loader.h"
+#include "hisparse/row_sharding.h"
 
 using spmv::io::CSRMatrix;
 
@@ -122,9 +124,9 @@ const char* hsf_last_error(void) { return g_error.c_str(); }
 int hsf_csr_load_npz(const char* path, hsf_csr** out) {
     if (!path || !out) return fail(HSF_BAD_ARG, "null argument");
     try {
-        hsf_csr* h = new hsf_csr;
+        std::unique_ptr<hsf_csr> h(new hsf_csr);
         h->m = spmv::io::load_csr_matrix_from_float_npz(path);
-        *out = h;
+        *out = h.release();
         return HSF_OK;
     } catch (const std::bad_alloc&) {
         return fail(HSF_NO_MEMORY, "out of memory");
@@ -188,7 +190,7 @@ int hsf_csr_generate(const char* kind, uint32_t num_rows, uint32_t num_cols, dou
     if (!kind || !out || num_rows == 0 || num_cols == 0) return fail(HSF_BAD_ARG, "bad generator arguments");
     const std::string k(kind);
     return guarded([&]() {
-        hsf_csr* h = new hsf_csr;
+        std::unique_ptr<hsf_csr> h(new hsf_csr);   // released only on success: a throwing generator must not leak it
         CSRMatrix<float>& m = h->m;
         m.num_rows = num_rows;
         m.num_cols = num_cols;
@@ -199,13 +201,13 @@ int hsf_csr_generate(const char* kind, uint32_t num_rows, uint32_t num_cols, dou
         } else if (k == "uniform") {
             // column of the j-th non-zero of row i = (floor(cols / nnz_per_row) * j + i) % cols, value 1
             const uint32_t per_row = uint32_t(a);
-            if (per_row == 0 || per_row > num_cols) { delete h; return fail(HSF_BAD_ARG, "uniform: bad nnz_per_row"); }
+            if (per_row == 0 || per_row > num_cols) { return fail(HSF_BAD_ARG, "uniform: bad nnz_per_row"); }
             const uint32_t step = num_cols / per_row;
             build_rows_parallel(m, [&](uint32_t i, std::vector<uint32_t>& cols, std::vector<float>& vals) {
                 for (uint32_t j = 0; j < per_row; ++j) { cols.push_back(uint32_t((uint64_t(step) * j + i) % num_cols)); vals.push_back(1.0f); }
             });
         } else if (k == "bernoulli") {
-            if (!(b > 0.0 && b <= 1.0)) { delete h; return fail(HSF_BAD_ARG, "bernoulli: density must be in (0,1]"); }
+            if (!(b > 0.0 && b <= 1.0)) { return fail(HSF_BAD_ARG, "bernoulli: density must be in (0,1]"); }
             build_rows_parallel(m, [&](uint32_t i, std::vector<uint32_t>& cols, std::vector<float>& vals) {
                 Rng rng(mix(seed, i));
                 for (uint32_t j = 0; j < num_cols; ++j)
@@ -213,7 +215,7 @@ int hsf_csr_generate(const char* kind, uint32_t num_rows, uint32_t num_cols, dou
             });
         } else if (k == "powerlaw") {
             const double target = a, beta = b;
-            if (!(target > 0) || !(beta >= 0.0 && beta < 1.0)) { delete h; return fail(HSF_BAD_ARG, "powerlaw: need nnz > 0 and 0 <= beta < 1"); }
+            if (!(target > 0) || !(beta >= 0.0 && beta < 1.0)) { return fail(HSF_BAD_ARG, "powerlaw: need nnz > 0 and 0 <= beta < 1"); }
             // node weight w(rank) = (rank+1)^-beta; rank = bijective scramble of the id so hubs are spread out
             const uint64_t row_mul = coprime_multiplier(num_rows, 0x9e3779b1ull + seed * 7919u);
             const uint64_t col_mul = coprime_multiplier(num_cols, 0x85ebca6bull + seed * 104729u);
@@ -243,10 +245,9 @@ int hsf_csr_generate(const char* kind, uint32_t num_rows, uint32_t num_cols, dou
                 for (uint32_t col : pick) { cols.push_back(col); vals.push_back(float(rng.uniform() * c)); }
             });
         } else {
-            delete h;
             return fail(HSF_BAD_ARG, "unknown generator kind: " + k);
         }
-        *out = h;
+        *out = h.release();
         return int(HSF_OK);
     });
 }
@@ -311,6 +312,16 @@ int hsf_unpack_result(int impl, const uint32_t* words, uint64_t n, float* y) {
     if (!hisparse::impl_valid(impl) || (n && (!y || !words))) return fail(HSF_BAD_ARG, "bad argument");
     hisparse::unpack_result(impl, words, n, y);
     return HSF_OK;
+}
+
+int hsf_split_rows_by_nnz(const uint32_t* indptr, uint32_t num_rows, uint32_t parts, uint32_t granule, uint32_t* bounds) {
+    if (!indptr || !bounds || parts == 0 || granule == 0) return fail(HSF_BAD_ARG, "bad argument");
+    return guarded([&]() {
+        const std::vector<uint32_t> ip(indptr, indptr + size_t(num_rows) + 1);
+        const std::vector<uint32_t> b = hisparse::split_rows_by_nnz(ip, parts, granule);
+        std::copy(b.begin(), b.end(), bounds);
+        return int(HSF_OK);
+    });
 }
 
 }  // extern "C"

@@ -204,7 +204,10 @@ int hs_create(hs_context** out, int device_id, int impl, uint32_t ob_bank, uint3
 int hs_destroy(hs_context* ctx) {
     if (!ctx) return HS_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    // only the library's own stream is known to be alive here; a caller-owned stream (hs_set_stream) must have been
+    // synchronised by its owner before the context is destroyed (hisparse_hip.h)
+    if (ctx->stream == ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    else (void)hipDeviceSynchronize();
     free_matrix(ctx);
     if (ctx->d_x) (void)hipFree(ctx->d_x);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -240,7 +243,9 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers);
     if (lds_bytes > hisparse::dev::kMaxLdsBytes) return fail(ctx, HS_ERR_UNSUPPORTED, "row block does not fit the LDS");
 
-    HS_HIP(ctx, hisparse::dev::configure_spmv_kernels(lds_bytes));
+    // the dynamic-LDS cap is a property of the FUNCTION, not of this context: always raise it to the full 160 KiB, so that a
+    // second context with a smaller matrix on the same device cannot lower it under a first one's launches
+    HS_HIP(ctx, hisparse::dev::configure_spmv_kernels(hisparse::dev::kMaxLdsBytes));
     auto upload = [&](void** dst, const void* src, size_t bytes, size_t slack) -> hipError_t {
         hipError_t e = hipMalloc(dst, std::max<size_t>(bytes + slack, 256));
         if (e != hipSuccess || bytes == 0) return e;
@@ -389,7 +394,10 @@ int hs_read_result(hs_context* ctx, void* packed_y, uint32_t num_rows) {
 int hs_set_stream(hs_context* ctx, void* hip_stream) {
     if (!ctx) return HS_ERR_BAD_ARG;
     HS_HIP(ctx, hipSetDevice(ctx->device));
-    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // work already enqueued must not be overtaken by work on the new stream; a caller-owned stream may be gone by now,
+    // so only the library's own stream is synchronised by handle
+    if (ctx->stream == ctx->own_stream) HS_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
+    else HS_HIP(ctx, hipDeviceSynchronize());
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return HS_OK;
 }
@@ -436,11 +444,14 @@ int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* 
     for (int i = 0; i < warmup; ++i)
         if ((rc = enqueue(ctx, -1, nullptr, nullptr)) != HS_OK) return rc;
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    hipEvent_t begin, end;
-    HS_HIP(ctx, hipEventCreate(&begin));
-    HS_HIP(ctx, hipEventCreate(&end));
-    std::vector<hipEvent_t> k(kernel_ms ? size_t(runs) * 2 : 0);
-    for (auto& ev : k) HS_HIP(ctx, hipEventCreate(&ev));
+    struct Events {   // destroyed on every return path
+        std::vector<hipEvent_t> ev;
+        ~Events() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+    } events;
+    events.ev.assign(2 + (kernel_ms ? size_t(runs) * 2 : 0), nullptr);
+    for (auto& ev : events.ev) HS_HIP(ctx, hipEventCreate(&ev));
+    const hipEvent_t begin = events.ev[0], end = events.ev[1];
+    hipEvent_t* k = events.ev.data() + 2;
     HS_HIP(ctx, hipEventRecord(begin, ctx->stream));
     for (int i = 0; i < runs; ++i)
         if ((rc = enqueue(ctx, -1, kernel_ms ? k[size_t(i) * 2] : nullptr, kernel_ms ? k[size_t(i) * 2 + 1] : nullptr)) != HS_OK) return rc;
@@ -458,9 +469,6 @@ int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* 
         }
         *kernel_ms = sum;
     }
-    for (auto& ev : k) (void)hipEventDestroy(ev);
-    (void)hipEventDestroy(begin);
-    (void)hipEventDestroy(end);
     return HS_OK;
 }
 

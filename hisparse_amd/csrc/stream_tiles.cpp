@@ -223,6 +223,10 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             }
         }
     }
+    if (uint64_t(slices) * num_rows > 0xffffffffull) {   // Block::out_offset = slice * num_rows + row0 is a 32-bit word offset
+        while (slices > 1 && uint64_t(slices) * num_rows > 0xffffffffull) slices /= 2;
+        max_rows = slices > 1 ? max_block_rows(true) : max_block_rows(false);
+    }
     out.col_slices = slices;
 
     // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse ---------------------

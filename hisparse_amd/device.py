@@ -131,6 +131,13 @@ class SpmvEngine:
         except Exception:
             pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     # ---- the boundary -------------------------------------------------------------------------
     def load_matrix(self, packets, num_rows=None, num_cols=None, num_row_partitions=None, num_col_partitions=None):
         """packets: host.ChannelPackets (dims taken from it) or 16 raw (n,16) uint32 arrays + explicit dims."""

@@ -61,6 +61,7 @@ def lib():
         l.hsf_matrix_free.restype = None
         l.hsf_pack_vector.argtypes = [C.c_int, f32p, u64, u32p]
         l.hsf_unpack_result.argtypes = [C.c_int, u32p, u64, f32p]
+        l.hsf_split_rows_by_nnz.argtypes = [u32p, u32, u32, u32, u32p]
         _lib = l
     return _lib
 
@@ -210,3 +211,11 @@ def unpack_result(impl, words):
     y = np.empty(words.size, dtype=np.float32)
     _check(lib().hsf_unpack_result(impl_id(impl), _u32p(words), words.size, _f32p(y)))
     return y
+
+
+def split_rows_by_nnz_native(indptr, parts, granule):
+    """The C++ routine the `benchmark --gpus N` driver uses (include/hisparse/row_sharding.h); sharding.py is its Python twin."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.uint32)
+    bounds = np.zeros(parts + 1, dtype=np.uint32)
+    _check(lib().hsf_split_rows_by_nnz(_u32p(indptr), indptr.size - 1, parts, granule, _u32p(bounds)))
+    return [int(b) for b in bounds]

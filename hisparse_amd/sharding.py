@@ -12,19 +12,31 @@ import numpy as np
 
 
 def split_rows_by_nnz(indptr, parts, granule):
-    """Row boundaries [b_0=0, ..., b_parts=rows] balancing non-zeros, interior ones multiples of `granule`."""
+    """Row boundaries [b_0=0, ..., b_parts=rows] balancing non-zeros, interior ones multiples of `granule`.
+
+    Every slab gets at least one granule of rows when the matrix has that many (a slab without rows cannot be loaded:
+    hs_load_matrix refuses an empty matrix), so a few very heavy rows cannot starve the ranks behind them; with fewer
+    than parts * granule rows the trailing slabs are empty (lo == hi) and the caller skips them (`nonempty`)."""
     indptr = np.asarray(indptr, dtype=np.int64)
     rows = indptr.size - 1
     nnz = int(indptr[-1])
+    granules = (rows + granule - 1) // granule          # the last granule may be short
     bounds = [0]
     for p in range(1, parts):
         target = nnz * p / parts
         r = int(np.searchsorted(indptr, target, side="left"))
-        r = int(round(r / granule)) * granule
-        r = min(max(r, bounds[-1]), rows)
-        bounds.append(r)
+        g = (2 * r + granule) // (2 * granule)             # nearest granule boundary, halves up (same rule as row_sharding.h)
+        lo_g = bounds[-1] // granule + 1                 # at least one granule for slab p-1 ...
+        hi_g = granules - (parts - p)                    # ... and one for every slab still to come
+        g = min(max(g, lo_g), hi_g) if hi_g >= lo_g else min(bounds[-1] // granule + 1, granules)
+        bounds.append(min(g * granule, rows))
     bounds.append(rows)
     return bounds
+
+
+def nonempty(bounds):
+    """[(slab index, lo, hi)] of the slabs that hold rows."""
+    return [(i, bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1) if bounds[i + 1] > bounds[i]]
 
 
 def slab_arrays(indptr, indices, data, lo, hi):

@@ -54,6 +54,14 @@ inline DataT marker_word(uint32_t n) {
     }
 }
 
+// Largest row advance ONE marker can carry.  float streams hold the raw integer; a Q8.24 word holds it in its 8 integer
+// bits, which is all the decoder reads (spmv_cluster.h:81-82): n >= 256 would saturate to 0xffffffff and decode as 255,
+// silently landing every later row of that lane stream too early (SURVEY.md Appendix B.7 -- the reference has no check).
+template <typename DataT>
+constexpr uint32_t marker_limit() {
+    return std::is_same<DataT, float>::value ? 0xffffffffu : 255u;
+}
+
 inline unsigned format_threads() {
     if (const char* e = std::getenv("HISPARSE_FORMAT_THREADS")) {
         int v = std::atoi(e);
@@ -130,6 +138,10 @@ void util_pad_marker_end_of_row_no_skip_empty_rows(std::vector<DataT>& adj_data,
 // Markers only after non-empty rows, except that the first `interleave_stride` rows (the head of
 // every lane stream) always get one.  The marker's count n = 1 + number of empty rows that directly
 // follow in the same residue class (row, row+stride, row+2*stride, ...), so the decoder can jump.
+// An advance beyond what one marker word can carry (detail::marker_limit: 255 in fixed point) is emitted as a CHAIN of
+// markers (255, 255, ..., remainder): every decoder -- the reference's included -- adds consecutive markers up, so the
+// image stays valid where the reference's own formatter writes a saturated count and corrupts the row numbering.
+// Byte-identical to the reference wherever the reference is itself correct (advance <= 255).
 template <typename DataT>
 void util_pad_marker_end_of_row_skip_empty_rows(std::vector<DataT>& adj_data, std::vector<uint32_t>& adj_indices,
                                                 std::vector<uint32_t>& adj_indptr, uint32_t idx_marker,
@@ -148,8 +160,9 @@ void util_pad_marker_end_of_row_skip_empty_rows(std::vector<DataT>& adj_data, st
             if (r < interleave_stride) break;
         }
     }
+    constexpr uint32_t limit = detail::marker_limit<DataT>();
     size_t kept = 0;
-    for (size_t r = 0; r < rows; ++r) kept += gets_marker[r];
+    for (size_t r = 0; r < rows; ++r) kept += gets_marker[r] ? (size_t(advance[r]) + limit - 1) / limit : 0;
     std::vector<DataT> data_out;
     std::vector<uint32_t> idx_out;
     data_out.reserve(adj_data.size() + kept);
@@ -159,8 +172,12 @@ void util_pad_marker_end_of_row_skip_empty_rows(std::vector<DataT>& adj_data, st
         if (gets_marker[r]) {
             data_out.insert(data_out.end(), adj_data.begin() + adj_indptr[r], adj_data.begin() + adj_indptr[r + 1]);
             idx_out.insert(idx_out.end(), adj_indices.begin() + adj_indptr[r], adj_indices.begin() + adj_indptr[r + 1]);
-            data_out.push_back(detail::marker_word<DataT>(advance[r]));
-            idx_out.push_back(idx_marker);
+            for (uint32_t left = advance[r]; left != 0;) {
+                const uint32_t n = std::min(left, limit);
+                data_out.push_back(detail::marker_word<DataT>(n));
+                idx_out.push_back(idx_marker);
+                left -= n;
+            }
         }
         new_indptr[r + 1] = uint32_t(data_out.size());
     }

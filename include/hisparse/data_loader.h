@@ -56,18 +56,34 @@ inline CSRMatrix<float> load_csr_matrix_from_float_npz(std::string csr_float_npz
     const auto& indices = members["indices"];
     const auto& indptr = members["indptr"];
     if (shape.count() != 2) throw std::runtime_error("npz: shape must have 2 entries");
+    if (shape.kind() == 'f' || indices.kind() == 'f' || indptr.kind() == 'f') throw std::runtime_error("npz: shape / indices / indptr must be integer arrays");
+    const int64_t rows64 = shape.as_int(0), cols64 = shape.as_int(1);
+    if (rows64 < 0 || cols64 < 0 || rows64 > 0xffffffffll || cols64 > 0xffffffffll) throw std::runtime_error("npz: shape outside the 32-bit index range");
     CSRMatrix<float> m;
-    m.num_rows = uint32_t(shape.as_int(0));
-    m.num_cols = uint32_t(shape.as_int(1));
+    m.num_rows = uint32_t(rows64);
+    m.num_cols = uint32_t(cols64);
     const uint64_t nnz = data.count();
+    if (nnz > 0xffffffffull) throw std::runtime_error("npz: more than 2^32-1 non-zeros (32-bit indptr, sw/data_loader.h:24)");
     if (indices.count() != nnz || indptr.count() != uint64_t(m.num_rows) + 1)
         throw std::runtime_error("npz: inconsistent CSR array lengths");
     m.adj_data.resize(nnz);
     m.adj_indices.resize(nnz);
     m.adj_indptr.resize(indptr.count());
     for (uint64_t i = 0; i < nnz; ++i) m.adj_data[i] = data.as_float(i);
-    for (uint64_t i = 0; i < nnz; ++i) m.adj_indices[i] = uint32_t(indices.as_int(i));
-    for (uint64_t i = 0; i < indptr.count(); ++i) m.adj_indptr[i] = uint32_t(indptr.as_int(i));
+    // The formatter indexes per-partition tables by column and per-row tables by indptr (util_convert_csr_to_dds): a
+    // corrupt archive must be refused here, with the same rules hsf_csr_from_arrays applies to caller-provided arrays.
+    for (uint64_t i = 0; i < nnz; ++i) {
+        const int64_t c = indices.as_int(i);
+        if (c < 0 || c >= cols64) throw std::runtime_error("npz: column index out of range");
+        m.adj_indices[i] = uint32_t(c);
+    }
+    int64_t prev = 0;
+    for (uint64_t i = 0; i < indptr.count(); ++i) {
+        const int64_t v = indptr.as_int(i);
+        if (v < prev || uint64_t(v) > nnz || (i == 0 && v != 0)) throw std::runtime_error("npz: indptr must start at 0, be non-decreasing and stay within nnz");
+        m.adj_indptr[i] = uint32_t(v);
+        prev = v;
+    }
     if (m.adj_indptr.back() != nnz) throw std::runtime_error("npz: indptr does not end at nnz");
     return m;
 }

@@ -33,9 +33,12 @@ struct Array {
     std::vector<uint8_t> bytes;  // raw little-endian payload
     size_t word_size() const { return descr.size() >= 3 ? size_t(std::stoul(descr.substr(2))) : 0; }
     char kind() const { return descr.size() >= 2 ? descr[1] : '?'; }
-    uint64_t count() const {
+    uint64_t count() const {   // saturates instead of wrapping (a hostile header cannot make count() * word_size() look small)
         uint64_t n = 1;
-        for (uint64_t s : shape) n *= s;
+        for (uint64_t s : shape) {
+            if (s != 0 && n > (uint64_t(1) << 60) / s) return uint64_t(1) << 60;
+            n *= s;
+        }
         return n;
     }
     // element i widened to 64-bit integer (for i4/u4/i8/u8 payloads)
@@ -105,10 +108,19 @@ inline std::string dict_value(const std::string& hdr, const std::string& key) {
     size_t k = hdr.find("'" + key + "'");
     if (k == std::string::npos) throw std::runtime_error("npy: header lacks " + key);
     size_t c = hdr.find(':', k);
+    if (c == std::string::npos) throw std::runtime_error("npy: malformed header near " + key);
     size_t b = hdr.find_first_not_of(" ", c + 1);
-    if (hdr[b] == '\'') { size_t e = hdr.find('\'', b + 1); return hdr.substr(b + 1, e - b - 1); }
-    if (hdr[b] == '(') { size_t e = hdr.find(')', b); return hdr.substr(b, e - b + 1); }
-    size_t e = hdr.find_first_of(",}", b);
+    if (b == std::string::npos) throw std::runtime_error("npy: malformed header near " + key);
+    size_t e;
+    if (hdr[b] == '\'') {
+        if ((e = hdr.find('\'', b + 1)) == std::string::npos) throw std::runtime_error("npy: unterminated string in header");
+        return hdr.substr(b + 1, e - b - 1);
+    }
+    if (hdr[b] == '(') {
+        if ((e = hdr.find(')', b)) == std::string::npos) throw std::runtime_error("npy: unterminated tuple in header");
+        return hdr.substr(b, e - b + 1);
+    }
+    if ((e = hdr.find_first_of(",}", b)) == std::string::npos) throw std::runtime_error("npy: malformed header near " + key);
     return hdr.substr(b, e - b);
 }
 
@@ -120,7 +132,7 @@ inline Array parse_npy(const uint8_t* p, uint64_t n) {
     unsigned major = p[6];
     uint64_t hlen, hoff;
     if (major == 1) { hlen = rd16(p + 8); hoff = 10; } else { hlen = rd32(p + 8); hoff = 12; }
-    if (hoff + hlen > n) throw std::runtime_error("npy: truncated header");
+    if (hlen > n || hoff + hlen > n) throw std::runtime_error("npy: truncated header");
     std::string hdr(reinterpret_cast<const char*>(p + hoff), hlen);
     Array a;
     a.descr = dict_value(hdr, "descr");
@@ -133,6 +145,7 @@ inline Array parse_npy(const uint8_t* p, uint64_t n) {
         if (shp[i] >= '0' && shp[i] <= '9') {
             size_t j = i;
             while (j < shp.size() && shp[j] >= '0' && shp[j] <= '9') ++j;
+            if (j - i > 18) throw std::runtime_error("npy: dimension too large");
             a.shape.push_back(std::stoull(shp.substr(i, j - i)));
             i = j;
         } else {
@@ -142,8 +155,9 @@ inline Array parse_npy(const uint8_t* p, uint64_t n) {
     size_t ws = a.word_size();
     if ((a.kind() != 'f' && a.kind() != 'i' && a.kind() != 'u') || (ws != 4 && ws != 8))
         throw std::runtime_error("npy: unsupported dtype " + a.descr);
-    uint64_t need = a.count() * ws;
-    if (hoff + hlen + need > n) throw std::runtime_error("npy: truncated payload");
+    const uint64_t room = n - hoff - hlen;
+    if (a.count() > room / ws) throw std::runtime_error("npy: truncated payload");
+    const uint64_t need = a.count() * ws;
     a.bytes.assign(p + hoff + hlen, p + hoff + hlen + need);
     return a;
 }
@@ -164,35 +178,44 @@ inline std::map<std::string, Array> load(const std::string& path) {
     if (entries == 0xffff || cd_off == 0xffffffffu) {  // zip64 end-of-central-directory
         if (eocd < 20 || rd32(&z[eocd - 20]) != 0x07064b50u) throw std::runtime_error("npz: zip64 locator missing");
         uint64_t e64 = rd64(&z[eocd - 20 + 8]);
-        if (e64 + 56 > n || rd32(&z[e64]) != 0x06064b50u) throw std::runtime_error("npz: bad zip64 EOCD");
+        if (e64 > n || n - e64 < 56 || rd32(&z[e64]) != 0x06064b50u) throw std::runtime_error("npz: bad zip64 EOCD");
         entries = rd64(&z[e64 + 32]);
         cd_off = rd64(&z[e64 + 48]);
     }
     std::map<std::string, Array> out;
     uint64_t p = cd_off;
     for (uint64_t e = 0; e < entries; ++e) {
-        if (p + 46 > n || rd32(&z[p]) != 0x02014b50u) throw std::runtime_error("npz: bad central directory");
+        if (p > n || n - p < 46 || rd32(&z[p]) != 0x02014b50u) throw std::runtime_error("npz: bad central directory");
         unsigned method = rd16(&z[p + 10]);
         uint64_t csize = rd32(&z[p + 20]), usize = rd32(&z[p + 24]);
         unsigned nlen = rd16(&z[p + 28]), xlen = rd16(&z[p + 30]), clen = rd16(&z[p + 32]);
         uint64_t lho = rd32(&z[p + 42]);
+        if (p + 46 + uint64_t(nlen) + xlen + clen > n) throw std::runtime_error("npz: central directory entry exceeds file");
         std::string name(reinterpret_cast<const char*>(&z[p + 46]), nlen);
         // zip64 extra field (id 0x0001): present values appear in the order usize, csize, offset
         uint64_t x = p + 46 + nlen, xend = x + xlen;
         while (x + 4 <= xend) {
             unsigned id = rd16(&z[x]), sz = rd16(&z[x + 2]);
+            if (x + 4 + sz > xend) throw std::runtime_error("npz: extra field exceeds its record");
             if (id == 0x0001) {
                 uint64_t q = x + 4;
-                if (usize == 0xffffffffu) { usize = rd64(&z[q]); q += 8; }
-                if (csize == 0xffffffffu) { csize = rd64(&z[q]); q += 8; }
-                if (lho == 0xffffffffu) { lho = rd64(&z[q]); q += 8; }
+                const uint64_t qend = x + 4 + sz;
+                auto take64 = [&](uint64_t& v) {
+                    if (q + 8 > qend) throw std::runtime_error("npz: zip64 extra field too short");
+                    v = rd64(&z[q]);
+                    q += 8;
+                };
+                if (usize == 0xffffffffu) take64(usize);
+                if (csize == 0xffffffffu) take64(csize);
+                if (lho == 0xffffffffu) take64(lho);
             }
             x += 4 + sz;
         }
-        p += 46 + nlen + xlen + clen;
-        if (lho + 30 > n || rd32(&z[lho]) != 0x04034b50u) throw std::runtime_error("npz: bad local header");
-        uint64_t data = lho + 30 + rd16(&z[lho + 26]) + rd16(&z[lho + 28]);
-        if (data + csize > n) throw std::runtime_error("npz: member exceeds file");
+        p += 46 + uint64_t(nlen) + xlen + clen;
+        if (lho > n || n - lho < 30 || rd32(&z[lho]) != 0x04034b50u) throw std::runtime_error("npz: bad local header");
+        const uint64_t data = lho + 30 + rd16(&z[lho + 26]) + rd16(&z[lho + 28]);
+        if (data > n || csize > n - data) throw std::runtime_error("npz: member exceeds file");
+        if (usize > (uint64_t(1) << 40)) throw std::runtime_error("npz: member larger than 1 TiB");
         std::vector<uint8_t> raw;
         const uint8_t* src = &z[data];
         if (method == 8) { raw = inflate_raw(src, csize, usize); src = raw.data(); }

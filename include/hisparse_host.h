@@ -79,6 +79,10 @@ void hsf_matrix_free(hsf_matrix* m);
 int hsf_pack_vector(int impl, const float* x, uint64_t n, uint32_t* words);
 int hsf_unpack_result(int impl, const uint32_t* words, uint64_t n, float* y);
 
+/* ---- multi-GPU row slabs (hisparse/row_sharding.h; the C++ benchmark's --gpus N uses the same routine) ----------- */
+/* bounds[0..parts]: row boundaries balancing non-zeros, interior ones multiples of `granule` (128 * interleave). */
+int hsf_split_rows_by_nnz(const uint32_t* indptr, uint32_t num_rows, uint32_t parts, uint32_t granule, uint32_t* bounds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,122 @@
+"""The C++ `benchmark` entry (hisparse_amd/csrc/benchmark.cpp = the reference's sw/benchmark.cpp on the HIP C-ABI), run as
+a process: result line format (sw/benchmark.cpp:80-87), the reference-literal `1 / num_cols` value mode (:411), the
+literal per-partition launch loop (:318-338), y dumped and checked against the oracle, and the row-sharded RCCL path."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from hisparse_amd import host
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCHMARK = os.path.join(ROOT, "hisparse_amd", "lib", "benchmark")
+RESULT_LINE = re.compile(r"^\{Preprocessing: (\S+) s \| SpMV: (\S+) ms \| (\S+) GBPS \| (\S+) GOPS \}$", re.M)
+
+
+def run(*args, timeout=300):
+    return subprocess.run([BENCHMARK, *map(str, args)], capture_output=True, text=True, timeout=timeout)
+
+
+def glibc_rand_mod2(n):
+    """The reference never seeds rand() (sw/benchmark.cpp:206): glibc's default sequence (seed 1)."""
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    return np.array([libc.rand() % 2 for _ in range(n)], dtype=np.float32)
+
+
+def test_usage_and_argument_errors_need_no_gpu():
+    assert os.access(BENCHMARK, os.X_OK)
+    r = run()
+    assert r.returncode == 0 and r.stdout.startswith("Usage:")          # like the reference: usage, exit 0 (:357-361)
+    r = run("double", "x.npz", 4, 8)
+    assert r.returncode == 1 and "unknown implementation" in r.stdout
+    r = run("fixed", "/nonexistent/file.npz", 4, 8)
+    assert r.returncode == 1 and "ERROR" in r.stdout
+
+
+def _matrix(tmp_path, impl, rows=3000, cols=1500, density=0.01, seed=11):
+    rng = np.random.default_rng(seed)
+    m = sp.random(rows, cols, density=density, random_state=np.random.RandomState(seed), format="csr", dtype=np.float32)
+    m.data = (rng.uniform(0.0, 2.0, m.nnz) if impl == 0 else rng.normal(size=m.nnz)).astype(np.float32)
+    m.sort_indices()
+    path = tmp_path / "m.npz"
+    sp.save_npz(path, m)
+    return m, str(path)
+
+
+def _oracle_y(m, impl, vb, ob, x_words):
+    csr = host.CSRMatrix.from_scipy(m)
+    cp = host.format_matrix(csr, impl, vb_bank=vb, ob_bank=ob, skip_empty_rows=True)
+    assert x_words.size == cp.num_cols
+    return cp, orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], x_words, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                        cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl_name,impl,v,o", [("fixed", 0, 4, 8), ("float_pob", 1, 4, 1), ("float_stall", 2, 4, 8)])
+def test_result_line_and_dumped_y_match_oracle(tmp_path, impl_name, impl, v, o):
+    m, path = _matrix(tmp_path, impl)
+    xf, yf = tmp_path / "x.bin", tmp_path / "y.bin"
+    r = run(impl_name, path, v, o, "--values", "keep", "--dump-x", xf, "--dump-y", yf)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "===== Benchmark Finished =====" in r.stdout
+    hit = RESULT_LINE.search(r.stdout)
+    assert hit, r.stdout
+    pre_s, ms, gbps, gops = map(float, hit.groups())
+    assert pre_s > 0 and ms > 0
+    assert gbps == pytest.approx(m.nnz * 8 / 2 ** 30 / (ms / 1e3), rel=1e-3)      # GiB/s of 8 B per non-zero (:312-314,344-346)
+    assert gops == pytest.approx(2 * m.nnz / 1e6 / ms, rel=1e-3)
+    x = np.fromfile(xf, dtype=np.uint32)
+    y = np.fromfile(yf, dtype=np.uint32)
+    assert np.array_equal(orc.unpack_result(impl, x), glibc_rand_mod2(x.size))    # x = rand() % 2, unseeded (:205-212)
+    cp, want = _oracle_y(m, impl, v * 1024, o * 1024, x)
+    assert y.size == cp.num_rows
+    if impl == 0:
+        assert np.array_equal(y, want)
+    else:
+        assert np.allclose(y.view(np.float32), want.view(np.float32), rtol=1e-4, atol=1e-4)
+    assert np.any(y != 0)
+
+
+@pytest.mark.gpu
+def test_reference_literal_values_and_partition_loop(tmp_path):
+    # 3000 rows with o = 1K words per bank -> LOGICAL_OB 131072: one partition; use a tall matrix and tiny banks instead
+    m, path = _matrix(tmp_path, 0, rows=300000, cols=512, density=0.002, seed=5)
+    yf = tmp_path / "y.bin"
+    r = run("fixed", path, 4, 1, "--values", "literal", "--dump-y", yf)           # `1 / num_cols` == 0 (:411): y is all zeros
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert RESULT_LINE.search(r.stdout)
+    y = np.fromfile(yf, dtype=np.uint32)
+    assert y.size == 300032 and not y.any()
+    # the literal launch loop: 3 row partitions of 131072 rows, one hs_run_partition + finish each; same y as one launch
+    xa, ya, xb, yb = (tmp_path / n for n in ("xa", "ya", "xb", "yb"))
+    ra = run("fixed", path, 4, 1, "--values", "keep", "--dump-x", xa, "--dump-y", ya)
+    rb = run("fixed", path, 4, 1, "--values", "keep", "--partition-loop", "--dump-x", xb, "--dump-y", yb)
+    assert ra.returncode == 0 and rb.returncode == 0, ra.stdout + rb.stdout
+    assert "row_partitions: 3" in rb.stdout
+    assert np.array_equal(np.fromfile(xa, dtype=np.uint32), np.fromfile(xb, dtype=np.uint32))
+    assert np.array_equal(np.fromfile(ya, dtype=np.uint32), np.fromfile(yb, dtype=np.uint32))
+    cp, want = _oracle_y(m, 0, 4096, 1024, np.fromfile(xa, dtype=np.uint32))
+    assert np.array_equal(np.fromfile(ya, dtype=np.uint32), want)
+
+
+@pytest.mark.gpu
+def test_row_sharded_rccl_path_on_one_gpu(tmp_path):
+    """`--gpus N` = one context per device + ncclAllGather of the y slabs.  A single-GPU box can only run N = 1, which
+    still goes through the slab split, hs_bind_device_result into the gather buffer and the RCCL call."""
+    m, path = _matrix(tmp_path, 0, rows=20000, cols=3000, density=0.004, seed=9)
+    xf, yf = tmp_path / "x.bin", tmp_path / "y.bin"
+    r = run("fixed", path, 4, 8, "--values", "keep", "--gpus", 1, "--sharded", "--dump-x", xf, "--dump-y", yf)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "compute only" in r.stdout and "all-gather" in r.stdout and RESULT_LINE.search(r.stdout)
+    x = np.fromfile(xf, dtype=np.uint32)
+    cp, want = _oracle_y(m, 0, 4096, 8192, x)
+    y = np.fromfile(yf, dtype=np.uint32)
+    assert y.size == 20000 and np.array_equal(y, want[:20000])
+    r = run("fixed", path, 4, 8, "--gpus", 64)
+    assert r.returncode != 0 and "device(s) visible" in r.stdout

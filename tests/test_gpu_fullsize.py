@@ -1,0 +1,125 @@
+"""BASELINE.json's configurations at FULL size with RANDOM values, HIP path against the oracle -- and config 5's 8-way row
+split on the HIP path.  (tests/test_gpu_parity.py::test_full_size_exact_known_answer covers the same matrices with
+order-free inputs; this file is the one that can see a rounding or float-accumulation defect at scale.)
+
+Contracts:
+  fixed        bit-exact with oracle/cpu_ref.c (= csim's top_wrapper on Q8.24 words).
+  float_*      north_star: "within 1e-4 rel-err of csim", read as SURVEY.md section 8d states it:
+                   |y - y_csim| <= 1e-4 * max(1, |y_csim|)          (asserted)
+               csim's own verify (spmv_csim/csim.cpp:160-184) is ABSOLUTE 1e-4 on values of order 1; the maximum absolute
+               error is reported (printed and attached to the test's user properties) and asserted only where csim's
+               inputs are of that order (|y| <= 1).  The float sums here are double accumulations rounded once, i.e.
+               closer to the exact product than csim's fp32 running sum; the error against the exact float64 product is
+               reported alongside.
+"""
+import numpy as np
+import pytest
+
+from hisparse_amd import datasets, device, host, sharding
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(cp, impl, xw):
+    return orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                    cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+
+
+def _random_x(impl, n, seed):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(0.0, 2.0, n).astype(np.float32) if impl == 0 else rng.normal(size=n).astype(np.float32)
+
+
+def _float_report(got_words, want_words, exact):
+    got, want = got_words.view(np.float32).astype(np.float64), want_words.view(np.float32).astype(np.float64)
+    err = np.abs(got - want)
+    bound = 1e-4 * np.maximum(1.0, np.abs(want))
+    return {
+        "max_abs_err_vs_csim": float(err.max()),
+        "max_rel_err_vs_csim": float((err / np.maximum(1.0, np.abs(want))).max()),
+        "rows_over_bound": int((err > bound).sum()),
+        "max_abs_y": float(np.abs(want).max()),
+        "max_abs_err_gpu_vs_float64": float(np.abs(got[:exact.size] - exact).max()),
+        "max_abs_err_csim_vs_float64": float(np.abs(want[:exact.size] - exact).max()),
+        "rows_over_csim_abs_1e-4": int((err > 1e-4).sum()),
+    }
+
+
+@pytest.mark.parametrize("name", ["ogbl_ppa", "transformer_50", "ogbn_products", "mouse_gene"])
+def test_full_size_random_values_vs_oracle(name, record_property):
+    import scipy.sparse as sp
+    cfg, csr = datasets.load(name)
+    impl = host.impl_id(cfg.impl)
+    rows, cols = csr.num_rows, csr.num_cols
+    ip, ix, dv = csr.arrays()
+    cp = host.format_matrix(csr, impl, skip_empty_rows=cfg.skip_empty_rows)
+    x = _random_x(impl, cp.num_cols, 20260928)
+    xw = host.pack_vector(impl, x)
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix(cp)
+        eng.load_vector(xw)
+        eng.run()
+        got = eng.read_result()
+        for j in range(cp.num_row_partitions):      # and through the reference's partition-by-partition launch loop
+            eng.run_partition(j, cp.part_len(j))
+        again = eng.read_result()
+        assert eng.stats()["nnz"] == len(ix)
+    want = _oracle(cp, impl, xw)
+    if impl == 0:
+        assert np.array_equal(got, want), f"{int((got != want).sum())} of {got.size} rows differ from the oracle"
+        assert np.array_equal(again, want)
+        record_property("parity", "bit-exact")
+        record_property("saturated_rows", int((want == 0xFFFFFFFF).sum()))
+        return
+    exact = sp.csr_matrix((dv.astype(np.float64), ix.astype(np.int64), ip.astype(np.int64)), shape=(rows, cols)) @ x[:cols].astype(np.float64)
+    rep = _float_report(got, want, exact)
+    print(f"\n{name}/{cfg.impl}: {rep}")
+    for k, v in rep.items():
+        record_property(k, v)
+    assert rep["rows_over_bound"] == 0, rep
+    assert np.array_equal(again.view(np.float32)[rows:], np.zeros(cp.num_rows - rows, dtype=np.float32))   # padded rows stay 0
+    rep2 = _float_report(again, want, exact)
+    assert rep2["rows_over_bound"] == 0, rep2
+    if rep["max_abs_y"] <= 1.0:                      # csim's absolute check, where its premise (values of order 1) holds
+        assert rep["rows_over_csim_abs_1e-4"] == 0, rep
+
+
+def test_config5_mouse_gene_8way_row_split_on_hip(record_property):
+    """BASELINE.json configs[4]: mouse_gene row-partitioned 8 ways (sw/benchmark.cpp:318-338 and sw/data_formatter.h:494,
+    500-511 are the reference's grounds for treating row partitions as independent).  The 8 slabs of sharding.
+    split_rows_by_nnz run one after the other through the HIP path on this one GPU (exactly what each rank of
+    `bench.py --gpus 8` runs); the assembled y must be bit-identical to the oracle on the UNSHARDED matrix."""
+    cfg, csr = datasets.load("mouse_gene")
+    impl = host.impl_id(cfg.impl)
+    assert impl == 0
+    rows, cols = csr.num_rows, csr.num_cols
+    ip, ix, dv = csr.arrays()
+    x = _random_x(impl, (cols + 7) // 8 * 8, 5)
+    xw = host.pack_vector(impl, x)
+    bounds = sharding.split_rows_by_nnz(ip, 8, 128)
+    assert bounds[0] == 0 and bounds[-1] == rows and all(b % 128 == 0 for b in bounds[1:-1])
+    slabs = sharding.nonempty(bounds)
+    assert len(slabs) == 8
+    nnz_per_slab = [int(ip[hi] - ip[lo]) for _, lo, hi in slabs]
+    assert max(nnz_per_slab) < 1.25 * (len(ix) / 8), nnz_per_slab     # balanced by non-zeros, not by rows
+    padded = [sharding.padded_rows(hi - lo, 128) for _, lo, hi in slabs]
+    layout = sharding.gather_layout([hi - lo for _, lo, hi in slabs], 128)
+    chunk = layout[0]
+    gathered = np.zeros(chunk * 8, dtype=np.uint32)                    # what all_gather_into_tensor would fill
+    with device.SpmvEngine(impl) as eng:                               # one context re-used for the 8 slabs
+        for k, (i, lo, hi) in enumerate(slabs):
+            sip, six, sdv = sharding.slab_arrays(ip, ix, dv, lo, hi)
+            slab = host.CSRMatrix.from_arrays(hi - lo, cols, sip, six, sdv)
+            cp = host.format_matrix(slab, impl, skip_empty_rows=True)
+            assert cp.num_rows == padded[k] and cp.num_cols == xw.size
+            eng.load_matrix(cp)
+            eng.load_vector(xw)
+            eng.run()
+            gathered[k * chunk: k * chunk + cp.num_rows] = eng.read_result()
+    y = sharding.assemble(gathered, layout)
+    assert y.size == rows
+    full = host.format_matrix(csr, impl, skip_empty_rows=True)
+    want = _oracle(full, impl, xw)
+    assert np.array_equal(y, want[:rows]), f"{int((y != want[:rows]).sum())} rows differ"
+    record_property("slab_nnz", nnz_per_slab)

@@ -300,8 +300,8 @@ def test_empty_rows_and_empty_matrix_rows():
         _run_case(impl, m, vb=4, ob=8, skip=False, seed=5)
 
 
-def test_marker_skip_count_limit_matches_oracle():
-    # fixed mode, >= 256 skipped rounds: the reference's 8-bit skip count saturates; reproduced, see tests/test_tiles_cpu.py
+def test_marker_skip_count_beyond_255():
+    # fixed mode, >= 256 skipped rounds: the product's formatter chains markers (tests/test_tiles_cpu.py), rows land where they belong
     from test_tiles_cpu import marker_limit_matrix
     m, _ = marker_limit_matrix()
     for impl in (0, 2):

@@ -90,3 +90,24 @@ def test_split_rows_by_nnz_properties():
         assert max(loads) <= indptr[-1] / parts * 1.25 + 5000 * 128
     chunk, spans = sharding.gather_layout([300, 129, 0], 128)
     assert chunk == 384 and spans == [(0, 300), (384, 129), (768, 0)]
+
+
+def test_cpp_and_python_row_splits_agree():
+    """include/hisparse/row_sharding.h (the C++ benchmark's --gpus N) and hisparse_amd/sharding.py cut the same slabs."""
+    from hisparse_amd import host, sharding
+    rng = np.random.default_rng(3)
+    for trial in range(60):
+        rows = int(rng.integers(1, 9000))
+        deg = rng.integers(0, 40, rows)
+        if trial % 3 == 0:
+            deg[rng.integers(0, rows, 3)] += 20000          # a few very heavy rows
+        indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.uint32)
+        for parts in (1, 2, 3, 8):
+            for granule in (128, 1024):
+                want = sharding.split_rows_by_nnz(indptr, parts, granule)
+                got = host.split_rows_by_nnz_native(indptr, parts, granule)
+                assert got == want, (rows, parts, granule)
+                assert got[0] == 0 and got[-1] == rows and all(a <= b for a, b in zip(got, got[1:]))
+                assert all(b % granule == 0 for b in got[1:-1] if b != rows)
+                if rows >= parts * granule:
+                    assert all(b > a for a, b in zip(got, got[1:]))      # nobody is left without rows

@@ -232,17 +232,31 @@ def marker_limit_matrix():
     return sp.csr_matrix((np.array([1.0, 2.0, 3.0], dtype=np.float32), (r, np.array([3, 4, 5]))), shape=(rows, 64)), r
 
 
-def test_marker_skip_count_limit_is_reproduced_not_fixed():
+def test_marker_skip_count_beyond_255_is_chained():
     """SURVEY.md Appendix B.7 / spmv/libfpga/spmv_cluster.h:81-82: in fixed mode the skip count travels in the 8 integer
-    bits of a Q8.24 word, so a jump of >= 256 rounds saturates to 255 and the FPGA accumulates the following rows 45 rounds
-    too early.  The boundary is the reference's, so the product reproduces that exactly (oracle == product); the float
-    modes carry the count as a raw integer and are right."""
+    bits of a Q8.24 word.  The reference's formatter writes a jump of >= 256 rounds as ONE saturated word, which every
+    decoder (its own included) reads as 255: the following rows land 45 rounds too early, silently.  The product's
+    formatter emits a chain of markers (255 + 45) instead -- decoders add consecutive markers up -- so the image is valid
+    and y lands on the right rows; the float modes carry the count as a raw integer and need no chain."""
     m, r = marker_limit_matrix()
-    for impl, landed in ((0, [5, 5 + 128 * 255, 5 + 128 * 305]), (1, r.tolist())):
+    for impl in (0, 1):
         csr = host.CSRMatrix.from_scipy(m)
         cp = host.format_matrix(csr, impl, skip_empty_rows=True)
         xw = host.pack_vector(impl, np.ones(cp.num_cols, dtype=np.float32))
         want = oracle_y(cp, impl, xw)
         got = tile_emulator.run(build(cp, impl, 8), impl, xw, cp.num_rows)
         assert np.array_equal(got, want)
-        assert np.nonzero(orc.unpack_result(impl, want))[0].tolist() == landed
+        assert np.nonzero(orc.unpack_result(impl, want))[0].tolist() == r.tolist()
+        assert orc.unpack_result(impl, want)[r].tolist() == [1.0, 2.0, 3.0]
+
+
+def test_reference_formatter_marker_limit_quirk_is_documented():
+    """The same matrix through the ORACLE's restatement of the reference formatter (saturating marker word): the oracle's
+    decoder puts rows 2 and 3 of the lane stream 45 rounds early.  This pins what the reference does; the product does not
+    reproduce it (previous test)."""
+    from oracle import cpsr_format as of
+    m, r = marker_limit_matrix()
+    ref, rows, cols, rp, cpn = of.format_matrix(0, m.shape[0], m.shape[1], m.data, m.indices, m.indptr, 8192, 4096, True)
+    xw = host.pack_vector(0, np.ones(cols, dtype=np.float32))
+    y = orc.spmv(0, ref, xw, rows, cols, rp, cpn, 8192, 4096)
+    assert np.nonzero(orc.unpack_result(0, y))[0].tolist() == [5, 5 + 128 * 255, 5 + 128 * 305]
