@@ -1,0 +1,230 @@
+// bitmap_tiles.cpp — CPSR image -> BITMAP rows (stream_tiles.h "BITMAP format"; kernel: spmv_bitmap.hip).
+//
+// For dense-row matrices the 8 bytes per non-zero the FPGA streams (value + column index, spmv/libfpga/common.h:44-50) are
+// mostly index: at 50 % density a bit per column position says the same in 1/16 of the space.  The CPSR image is decoded once
+// (tiles_common.h: the same walk as the other formats), the rows are put back into column order, and every (row, 64-column
+// group) becomes a 64-bit occupancy mask plus its compacted values.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "tiles_common.h"
+
+namespace hisparse {
+namespace dev {
+
+using namespace detail;
+
+bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
+                        const std::vector<uint32_t>& row_nnz, uint32_t max_workgroups, StreamTiles& out, std::string& error) {
+    const uint32_t num_rows = L.num_rows, num_cols = L.num_cols, RP = L.row_parts, CP = L.col_parts;
+    const uint32_t G = std::max<uint32_t>(1, max_workgroups);
+    // a mask per 64 columns of every row: only sensible for dense rows; when the format is FORCED onto a big sparse matrix
+    // (tests) the element streams take over beyond 1 GiB of masks
+    if (double(num_rows) * double((num_cols + kBitmapGroupCols - 1) / kBitmapGroupCols) * 8.0 > double(1ull << 30)) {
+        error = "bitmap: more than 1 GiB of masks";
+        return false;
+    }
+    auto chan = [&](uint32_t pc) { return static_cast<const MatPkt*>(channel[pc]); };
+    PhaseTimer timer;
+
+    // ---- rows back in CSR form: (absolute column, value word) per row ------------------------------------------------------
+    std::vector<uint64_t> row_ptr(size_t(num_rows) + 1, 0);
+    for (uint32_t r = 0; r < num_rows; ++r) row_ptr[r + 1] = row_ptr[r] + row_nnz[r];
+    const uint64_t nnz = row_ptr[num_rows];
+    std::vector<uint64_t> elems(nnz);                       // column << 32 | value word: sorts by column
+    {
+        std::vector<uint32_t> cursor(num_rows, 0);
+        std::vector<WalkResult> res(size_t(RP) * NUM_HBM_CHANNELS);
+        // rows of different physical channels are disjoint, and one task takes the column partitions of its rows in ascending
+        // order: a row's elements arrive in the order the CSR input had them (sw/data_formatter.h:256-313 keeps it)
+        parallel_for(res.size(), [&](size_t w) {
+            const uint32_t rp = uint32_t(w / NUM_HBM_CHANNELS), pc = uint32_t(w % NUM_HBM_CHANNELS);
+            for (uint32_t cp = 0; cp < CP && res[w].ok; ++cp) {
+                const uint64_t col_base = uint64_t(cp) * L.g->logical_vb;
+                WalkResult r = walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t val) {
+                    elems[row_ptr[row] + cursor[row]++] = ((col_base + col) << 32) | val;
+                });
+                if (!r.ok) res[w] = r;
+            }
+        });
+        for (const auto& r : res)
+            if (!r.ok) { error = r.error; return false; }
+    }
+    // column order inside a row (the reference does not require sorted CSR input); a column that occurs twice in a row cannot be
+    // a bit in a mask -> the caller falls back to the element-stream formats
+    std::atomic<bool> duplicates(false);
+    parallel_for((num_rows + 1023) / 1024, [&](size_t chunk) {
+        for (uint32_t r = uint32_t(chunk) * 1024; r < std::min<uint64_t>(num_rows, (chunk + 1) * 1024); ++r) {
+            uint64_t* e = elems.data() + row_ptr[r];
+            const uint32_t n = row_nnz[r];
+            bool sorted = true;
+            for (uint32_t i = 1; i < n && sorted; ++i) sorted = (e[i] >> 32) > (e[i - 1] >> 32);
+            if (sorted) continue;
+            std::stable_sort(e, e + n, [](uint64_t a, uint64_t b) { return (a >> 32) < (b >> 32); });
+            for (uint32_t i = 1; i < n; ++i)
+                if ((e[i] >> 32) == (e[i - 1] >> 32)) duplicates = true;
+        }
+    });
+    if (duplicates) { error = "bitmap: duplicate column in a row"; out.format = kFormatPairs; return false; }
+    timer.lap("bitmap: rows in column order");
+
+    // ---- plan: column slices only when there are fewer rows than workgroups; row ranges of equal non-zero count --------------
+    const uint32_t GR = (num_cols + kBitmapGroupCols - 1) / kBitmapGroupCols;     // groups per row
+    uint32_t slices = 1;
+    if (const char* force = std::getenv("HISPARSE_COL_SLICES")) slices = std::max(1, std::atoi(force));
+    else while (slices * 2 <= kMaxColSlices && uint64_t(num_rows) * slices * 2 <= G) slices *= 2;
+    slices = std::min<uint32_t>(std::min<uint32_t>(slices, kMaxColSlices), GR);
+    while (slices > 1 && uint64_t(slices) * num_rows > 0xffffffffull) slices /= 2;
+    uint32_t max_rows = kBitmapMaxBlockRows;
+    if (const char* force = std::getenv("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force)));
+    const uint64_t per_round = std::max<uint32_t>(1, G / slices);
+    const uint64_t rounds = std::max<uint64_t>(1, ((uint64_t(num_rows) + max_rows - 1) / max_rows + per_round - 1) / per_round);
+    const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(per_round * rounds, std::max<uint64_t>(1, nnz / 1024)));
+    const uint64_t target = std::max<uint64_t>(1, (nnz + want_ranges - 1) / want_ranges);
+    std::vector<RowRange> ranges;
+    std::vector<uint64_t> range_nnz;
+    build_row_ranges(L, row_nnz, target, max_rows, ranges, range_nnz);
+    const uint32_t NR = uint32_t(ranges.size());
+    const uint32_t NB = NR * slices;
+
+    // ---- blocks: layout of masks + values, wavefront runs -------------------------------------------------------------------
+    out.nnz = nnz;
+    out.elements = nnz;
+    out.format = kFormatBitmap;
+    out.col_slices = slices;
+    out.ring_buffers = 0;
+    out.blocks.assign(NB, Block{});
+    out.units.assign(size_t(NB) * kBitmapWaves, Unit{});
+    std::vector<uint64_t> block_nnz(NB, 0), block_base(NB + 1, 0), block_weight(NB, 0);
+    // non-zeros of every block (row range x slice of groups)
+    parallel_for(NB, [&](size_t bi) {
+        const RowRange& rg = ranges[bi / slices];
+        const uint32_t k = uint32_t(bi % slices);
+        const uint64_t c0 = uint64_t(k) * GR / slices * kBitmapGroupCols, c1 = uint64_t(k + 1) * GR / slices * kBitmapGroupCols;
+        uint64_t n = 0;
+        for (uint32_t r = rg.row0; r < rg.row0 + rg.nrows; ++r) {
+            const uint64_t* e = elems.data() + row_ptr[r];
+            const uint64_t* lo = std::lower_bound(e, e + row_nnz[r], c0 << 32);
+            const uint64_t* hi = std::lower_bound(e, e + row_nnz[r], c1 << 32);
+            n += uint64_t(hi - lo);
+        }
+        block_nnz[bi] = n;
+    });
+    // A row is cut into `pieces` runs of (almost) equal group count -- one per wavefront when the block has few rows, one run per
+    // row otherwise -- and every run's masks are followed by zero masks up to a multiple of 8 plus two whole batches: the kernel
+    // fetches masks eight at a time and issues up to two batches past the end of a run, which then find "no column set".
+    auto pieces_of = [](uint32_t nrows) { return nrows * 2 <= kBitmapWaves ? kBitmapWaves / nrows : 1u; };
+    auto padded = [](uint32_t steps) { return (steps + 7u) / 8u * 8u + 16u; };
+    auto cut = [](uint32_t GS, uint32_t pieces, uint32_t j) { return uint32_t(uint64_t(j) * GS / pieces); };
+    auto row_stride = [&](uint32_t GS, uint32_t pieces) {
+        uint32_t n = 0;
+        for (uint32_t j = 0; j < pieces; ++j) n += padded(cut(GS, pieces, j + 1) - cut(GS, pieces, j));
+        return n;
+    };
+    for (uint32_t bi = 0; bi < NB; ++bi) {
+        const RowRange& rg = ranges[bi / slices];
+        const uint32_t k = bi % slices;
+        const uint32_t gs0 = uint32_t(uint64_t(k) * GR / slices), gs1 = uint32_t(uint64_t(k + 1) * GR / slices);
+        const uint64_t masks = uint64_t(rg.nrows) * row_stride(gs1 - gs0, pieces_of(rg.nrows));
+        // [masks: 8 bytes each][values: 4 bytes each, padded to 8]
+        block_base[bi + 1] = block_base[bi] + masks * 8 + ((block_nnz[bi] + 1) & ~uint64_t(1)) * 4;
+        block_weight[bi] = uint64_t(rg.nrows) * (gs1 - gs0) / kBitmapWaves + 1;          // wavefront steps
+        out.max_block_rows = std::max(out.max_block_rows, rg.nrows);
+    }
+    if (block_base[NB] / 4 >= (1ull << 40)) { error = "matrix too large for the bitmap image"; return false; }
+    out.image.assign(block_base[NB], 0);
+    timer.lap("bitmap: plan");
+
+    parallel_for(NB, [&](size_t bi) {
+        const RowRange& rg = ranges[bi / slices];
+        const uint32_t k = uint32_t(bi % slices);
+        const uint32_t gs0 = uint32_t(uint64_t(k) * GR / slices), gs1 = uint32_t(uint64_t(k + 1) * GR / slices), GS = gs1 - gs0;
+        const uint64_t c0 = uint64_t(gs0) * kBitmapGroupCols;
+        Block& blk = out.blocks[bi];
+        blk.row0 = rg.row0;
+        blk.nrows = rg.nrows;
+        blk.row_part = rg.row_part;
+        blk.flags = 0;
+        blk.out_offset = slices > 1 ? k * num_rows + rg.row0 : rg.row0;
+        blk.unit_begin = uint32_t(bi * kBitmapWaves);
+        blk.unit_end = blk.unit_begin + kBitmapWaves;
+        blk.first_col0 = uint32_t(c0);
+        blk.first_ncols = GS;
+        const uint32_t pieces = pieces_of(rg.nrows), stride = row_stride(GS, pieces);
+        std::vector<uint32_t> piece_of(GS), piece_at(pieces + 1, 0);          // group -> piece; piece -> offset inside the row's masks
+        for (uint32_t j = 0; j < pieces; ++j) {
+            for (uint32_t g = cut(GS, pieces, j); g < cut(GS, pieces, j + 1); ++g) piece_of[g] = j;
+            piece_at[j + 1] = piece_at[j] + padded(cut(GS, pieces, j + 1) - cut(GS, pieces, j));
+        }
+        auto mask_index = [&](uint32_t lr, uint32_t g) { return uint64_t(lr) * stride + piece_at[piece_of[g]] + (g - cut(GS, pieces, piece_of[g])); };
+        uint64_t* mask = reinterpret_cast<uint64_t*>(out.image.data() + block_base[bi]);
+        uint32_t* value = reinterpret_cast<uint32_t*>(out.image.data() + block_base[bi] + uint64_t(rg.nrows) * stride * 8);
+        const uint64_t mask_word0 = block_base[bi] / 8, value_word0 = (block_base[bi] + uint64_t(rg.nrows) * stride * 8) / 4;
+        // masks + compacted values in (row, group) order; value_at[r] = values of the block before local row r
+        std::vector<uint64_t> value_at(size_t(rg.nrows) + 1, 0);
+        uint64_t at = 0;
+        for (uint32_t lr = 0; lr < rg.nrows; ++lr) {
+            value_at[lr] = at;
+            const uint64_t* e = elems.data() + row_ptr[rg.row0 + lr];
+            const uint32_t n = row_nnz[rg.row0 + lr];
+            const uint64_t* p = std::lower_bound(e, e + n, c0 << 32);
+            const uint64_t c1 = uint64_t(gs1) * kBitmapGroupCols;
+            for (; p < e + n && (*p >> 32) < c1; ++p) {
+                const uint64_t rel = (*p >> 32) - c0;
+                mask[mask_index(lr, uint32_t(rel / kBitmapGroupCols))] |= 1ull << (rel % kBitmapGroupCols);
+                value[at++] = uint32_t(*p);
+            }
+        }
+        value_at[rg.nrows] = at;
+        // wavefront runs.  Few rows: every row is cut into floor(16 / nrows) runs of equal group count.  Many rows: contiguous whole
+        // rows per wavefront, balanced by steps-plus-non-zeros.
+        WaveSeg* seg = reinterpret_cast<WaveSeg*>(out.units.data() + blk.unit_begin);
+        auto set_seg = [&](uint32_t w, uint32_t r0, uint32_t r1, uint32_t g0, uint32_t g1) {
+            WaveSeg& s = seg[w];
+            s.row_begin = r0; s.row_end = r1; s.g_begin = g0; s.g_end = g1;
+            uint64_t v = value_word0 + value_at[std::min(r0, rg.nrows)];
+            if (r1 == r0 + 1 && g0 > 0)        // partial row: values of the groups in front of g0
+                for (uint32_t g = 0; g < g0; ++g) v += uint64_t(__builtin_popcountll(mask[mask_index(r0, g)]));
+            const uint64_t mw = mask_word0 + (r0 < rg.nrows ? mask_index(r0, r1 == r0 + 1 && g0 < GS ? g0 : 0) : 0);
+            s.value_lo = uint32_t(v); s.value_hi = uint32_t(v >> 32);
+            s.mask_lo = uint32_t(mw); s.mask_hi = uint32_t(mw >> 32);
+        };
+        if (pieces > 1) {
+            uint32_t w = 0;
+            for (uint32_t lr = 0; lr < rg.nrows; ++lr)
+                for (uint32_t j = 0; j < pieces; ++j, ++w) set_seg(w, lr, lr + 1, cut(GS, pieces, j), cut(GS, pieces, j + 1));
+            for (; w < kBitmapWaves; ++w) set_seg(w, rg.nrows, rg.nrows, 0, 0);      // idle wavefronts
+        } else {
+            // cost of a row = its steps + its non-zeros / 16 (issue slots vs. bytes); cut the prefix sum into 16 equal parts
+            std::vector<uint64_t> cost(size_t(rg.nrows) + 1, 0);
+            for (uint32_t lr = 0; lr < rg.nrows; ++lr) cost[lr + 1] = cost[lr] + GS + (value_at[lr + 1] - value_at[lr]) / 16;
+            uint32_t r0 = 0;
+            for (uint32_t w = 0; w < kBitmapWaves; ++w) {
+                const uint64_t goal = cost[rg.nrows] * (w + 1) / kBitmapWaves;
+                uint32_t r1 = uint32_t(std::lower_bound(cost.begin() + r0, cost.end(), goal) - cost.begin());
+                r1 = w + 1 == kBitmapWaves ? rg.nrows : std::min(std::max(r1, r0), rg.nrows);
+                // a whole-row run must not be mistaken for a partial one: one row = [0, GS) of that row, which is the same thing
+                set_seg(w, r0, r1, 0, GS);
+                r0 = r1;
+            }
+        }
+    });
+    timer.lap("bitmap: emit");
+
+    std::vector<std::vector<uint32_t>> mine;
+    assign_workgroups(out, block_weight, G, RP, mine);
+    chain_blocks(out, mine, RP);
+    // the kernel finds the runs of block i at units[16 i ..] without reading the block first: store them in final block order
+    std::vector<Unit> moved(out.units.size());
+    for (uint32_t i = 0; i < NB; ++i) {
+        std::copy(out.units.begin() + out.blocks[i].unit_begin, out.units.begin() + out.blocks[i].unit_end, moved.begin() + size_t(i) * kBitmapWaves);
+        out.blocks[i].unit_begin = i * kBitmapWaves;
+        out.blocks[i].unit_end = (i + 1) * kBitmapWaves;
+    }
+    out.units.swap(moved);
+    return true;
+}
+
+}  // namespace dev
+}  // namespace hisparse

@@ -42,7 +42,7 @@ struct hs_context {
     uint32_t lds_bytes = 0;
     uint32_t col_slices = 1;
     uint32_t ring_buffers = 4;
-    bool delta = false;            // stream format of d_image
+    uint32_t format = 0;           // StreamFormat of d_image
     uint32_t* d_partial = nullptr;  // col_slices > 1: per-slice partial results, col_slices x num_rows words
 
     uint32_t* d_x = nullptr;       // library-owned packed x
@@ -114,7 +114,8 @@ hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     a.out = c->col_slices > 1 ? c->d_partial : y_target(c);
     a.row_part_filter = filter;
     a.ring_buffers = c->ring_buffers;
-    a.delta = c->delta;
+    a.format = c->format;
+    a.num_cols = c->num_cols;
     a.num_workgroups = c->num_workgroups;
     a.lds_bytes = c->lds_bytes;
     return a;
@@ -266,7 +267,7 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     ctx->lds_bytes = lds_bytes;
     ctx->col_slices = tiles.col_slices;
     ctx->ring_buffers = tiles.ring_buffers;
-    ctx->delta = tiles.format == hisparse::dev::kFormatDelta;
+    ctx->format = tiles.format;
     ctx->matrix_loaded = true;
 
     hs_stats& s = ctx->stats;

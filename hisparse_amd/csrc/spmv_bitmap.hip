@@ -1,0 +1,266 @@
+// spmv_bitmap.hip — the gfx950 SpMV kernel for dense-row matrices in the BITMAP format (stream_tiles.h, bitmap_tiles.cpp).
+//
+// Same architecture as spmv_kernels.hip -- a workgroup owns rows, their sums live in its LDS, y is written once -- but for
+// rows that are dense enough (>= 1/8 of the columns set; the pruned-NN layers of sw/bm.sh:21-27) the FPGA's two gather
+// stages have nothing left to do:
+//   CPSR_matrix_loader (spmv_cluster.h:73-98)       a wavefront step = one 64-column GROUP of one row: a 64-bit occupancy mask
+//     streams {value, column} pairs                  + the values of the set columns, compacted (4 B + 1 bit per position, not 8 B)
+//   vecbuf_access_unit + shuffle 1 (x[col] gather)   x[64 g + lane]: a coalesced 256-byte read straight from L2 -- no x sub-tiles
+//                                                    in LDS, no gather, no per-sub-tile barrier
+//   shuffle 2 + PE accumulate (pe.h:62-81)           per-lane register sums along the wavefront's run of groups, ONE wavefront-wide
+//                                                    sum and ONE LDS add per (wavefront, row)
+//   result packer + drain                            coalesced store, AP_SAT clamp / fp32 rounding once (column-sliced blocks write
+//                                                    partials, combine_slices_kernel adds them)
+// Lane l of a step takes column 64 g + l: its value sits at (values before this group) + (set bits below l) = a scalar running
+// offset + v_mbcnt(mask).  All loads are BUFFER loads: a lane whose bit is clear gets an out-of-range offset and the hardware
+// returns 0 without touching memory, the x read of the last (partial) group is range-checked the same way, and so are mask reads
+// past the end of a run -- the whole inner loop is branch-free straight-line code, which is what lets hipcc count its own
+// s_waitcnt vmcnt (16 loads of the next batch stay in flight while a batch is consumed).
+// Numerics identical to spmv_kernels.hip: Q8.24 products rounded/saturated one by one and summed exactly in 64 bits; float
+// products (one fp32 multiply, no FMA) summed in double, rounded once per row and column slice.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "spmv_device.h"
+#include "spmv_kernels.h"
+
+namespace hisparse {
+namespace dev {
+
+namespace {
+
+constexpr int kBmThreads = kWaveLanes * kBitmapWaves;   // 1024
+constexpr int kBatch = 8;                               // steps per batch: 16 loads issued back to back
+constexpr uint32_t kInvalidOffset = 0x80000000u;        // beyond any num_records below: the load returns 0 (no memory access)
+constexpr uint32_t kRsrcFlags = 0x00020000u;            // raw 32-bit buffer, gfx9 family
+
+typedef const __attribute__((address_space(4))) WaveSeg* WaveSegTable;
+
+template <bool kFloat>
+struct Batch {
+    uint32_t v[kBatch], xv[kBatch];
+    uint64_t m[kBatch];        // wave-uniform (SGPR pairs)
+};
+
+// One wavefront, one row: groups [0, steps) of the run that starts at mask `mp`, value `vp`, column `col0`.  Returns the lane's sum.
+// kAblate (profiling builds, HISPARSE_ABLATE): bit 0 = no value loads, bit 1 = no x loads, bit 2 = no arithmetic (wrong results);
+// 64 = timeline, 256 = nt cache policy on the value loads (correct results)
+template <bool kFloat, int kAblate>
+__device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uint64_t* mp, const uint32_t*& vp, const uint32_t* x, uint32_t num_cols,
+                                                                       uint32_t col0, uint32_t steps, uint32_t lane, uint64_t* stamps = nullptr) {
+    using R = Rows<kFloat>;
+    typename R::sum_t acc = 0;
+    // values: this run's compacted values; offset = running scalar byte offset + 4 * (set bits below the lane)
+    const auto vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(vp), 0, 0x7fffffffu, kRsrcFlags);
+    // x: a fresh descriptor per batch whose base is the batch's first column and whose length is what is left of the vector
+    // (scalar arithmetic only): the per-step lane offsets are then eight loop-invariant registers, and the last group of a row,
+    // which may hang over the end of x, is still range-checked
+    uint32_t xk[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) xk[k] = (lane + k * kBitmapGroupCols) * 4u;
+    uint32_t voff = 0;                                   // bytes into the run's values (scalar)
+    // masks: one dword per lane = 32 masks per vector load, four vectors (128 steps) ahead -- a vector requested only one
+    // superbatch before it is needed would expose the memory latency once per superbatch.  Reads past the run's own masks find the
+    // zero masks the image pads every run with (bitmap_tiles.cpp), or 0 from the range check: no tail code anywhere.
+    // (Fetching the masks through the scalar cache instead -- s_load_dwordx16 = one batch, no v_readlane -- was tried: the
+    // scalar loads must be requested a batch ahead with hand-placed waits, and hipcc copies the destination registers of an asm
+    // load before the wait; not worth reserving registers for, the loop is bound by the latency chain in front of it, not by issue.)
+    const auto mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(mp), 0, steps * 8u, kRsrcFlags);
+    uint32_t moff = lane * 4u;
+    uint32_t mcur = __builtin_amdgcn_raw_buffer_load_b32(mr, moff, 0, 0);
+    uint32_t m1 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 256u, 0, 0);
+    uint32_t m2 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 512u, 0, 0);
+    uint32_t m3 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 768u, 0, 0);
+    // batch bb (8 steps, 16 loads); its masks are dwords (bb % 4) * 16 .. + 15 of the current mask vector.  The lane select of
+    // v_readlane is a scalar register, so ONE copy of this code serves every batch and the kernel stays a few KiB (every launch
+    // starts with a cold instruction cache).
+    auto issue = [&](Batch<kFloat>& b, uint32_t bb) {
+        const uint32_t sel = (bb & 3u) * (2 * kBatch);
+        const uint32_t xc = min(col0 + bb * (kBatch * kBitmapGroupCols), num_cols);      // first column of the batch (scalar)
+        const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(x + xc), 0, (num_cols - xc) * 4u, kRsrcFlags);
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const uint32_t lo = __builtin_amdgcn_readlane(mcur, sel + 2 * k), hi = __builtin_amdgcn_readlane(mcur, sel + 2 * k + 1);
+            b.m[k] = (static_cast<uint64_t>(hi) << 32) | lo;
+            // EVERY lane loads values[running offset + set bits below it]: for a lane whose own bit is clear that is the value of
+            // the next set column (or the first value of the next step) -- same cache lines, no extra traffic, and consume() never
+            // looks at it.  Cheaper than steering those lanes to an out-of-range offset (two more vector instructions per step).
+            const uint32_t off = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0)) * 4u;
+            b.v[k] = (kAblate & 1) ? off : __builtin_amdgcn_raw_buffer_load_b32(vr, off, voff, (kAblate & 256) ? 2 : 0);
+            b.xv[k] = (kAblate & 2) ? lo : __builtin_amdgcn_raw_buffer_load_b32(xr, xk[k], 0, 0);
+            voff += static_cast<uint32_t>(__builtin_popcountll(b.m[k])) * 4u;
+        }
+    };
+    // Only the lanes whose bit is set take part; in float mode the eight products of a batch are added up in fp32 first and join
+    // the double sum once per batch (one conversion + one double add instead of eight).
+    auto consume = [&](const Batch<kFloat>& b) {
+        typename R::prod_t part = 0;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            if (kAblate & 4) { acc += static_cast<typename R::sum_t>(b.v[k] ^ b.xv[k]); continue; }
+            if (__builtin_amdgcn_inverse_ballot_w64(b.m[k])) {
+                if (kFloat) part += R::product(b.v[k], b.xv[k]);
+                else acc += R::widen(R::product(b.v[k], b.xv[k]));
+            }
+        }
+        if (kFloat) acc += R::widen(part);
+    };
+    // Two batches: 16 loads of the next one are in flight while a batch is consumed.  Three in flight measured SLOWER (16.6 ->
+    // 17.7 us on transformer-50), and so did the nt policy on the value loads (-> 17.6 us: the 36 MB image lives in the 256 MiB
+    // Infinity Cache between launches); the timeline (tools/bitmap_timeline.py) shows the run itself streaming at ~5.5 TB/s and
+    // ~7 us of the kernel's life spent in front of it (dispatch ramp, descriptor -> masks -> first values: three dependent round
+    // trips) and behind it (wavefronts finish 6 us apart, the last one holds the barrier).
+    Batch<kFloat> A, B;
+    auto rotate_masks = [&](uint32_t bb) {
+        if ((bb & 3u) == 0) {            // batch bb opens a new mask vector (wave-uniform branch)
+            mcur = m1; m1 = m2; m2 = m3;
+            moff += 256u;
+            m3 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 768u, 0, 0);
+        }
+    };
+    issue(A, 0);
+    if (kAblate & 64) {   // timeline build: [2] = the first masks have arrived (issue() has used them)
+        uint64_t t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(voff));
+        if (lane == 0) stamps[2] = t;
+    }
+    issue(B, 1);
+    for (uint32_t bb = 0; bb * kBatch < steps; bb += 2) {
+        consume(A);
+        if ((kAblate & 64) && bb == 0) {   // [3] = the first batch of values and x has arrived and been consumed
+            uint64_t t;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(acc));
+            if (lane == 0) stamps[3] = t;
+        }
+        rotate_masks(bb + 2);
+        issue(A, bb + 2);                // batches past the end find all-zero masks: no memory traffic
+        consume(B);
+        rotate_masks(bb + 3);
+        issue(B, bb + 3);
+    }
+    vp += voff / 4u;
+    return acc;
+}
+
+template <bool kFloat, int kAblate>
+__global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
+                                                                const Unit* __restrict__ units, const uint32_t* __restrict__ x, uint32_t num_cols,
+                                                                uint32_t* __restrict__ out, int32_t row_part_filter,
+                                                                const uint32_t* __restrict__ part_heads, uint64_t* __restrict__ timeline) {
+    using R = Rows<kFloat>;
+    using acc_t = typename R::acc_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    acc_t* ys = reinterpret_cast<acc_t*>(lds);                    // [nrows + 1]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWaveLanes - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWaveLanes);
+    // timeline build (kAblate & 64): eight 100 MHz timestamps per wavefront: 0 entry, 1 descriptors read, 2 first masks in,
+    // 3 first batch consumed, 4 run finished, 5 row sums in LDS, 6 after the barrier, 7 results stored
+    uint64_t* stamps = (kAblate & 64) ? timeline + (static_cast<size_t>(blockIdx.x) * kBitmapWaves + wave) * 8 : nullptr;
+    auto stamp = [&](int i, uint32_t dep) {
+        if (!(kAblate & 64)) return;
+        uint64_t t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(dep));
+        if (lane == 0) stamps[i] = t;
+    };
+    stamp(0, wave);
+    uint32_t wg = blockIdx.x;                                     // same XCD-aware remap as spmv_rowblock_kernel
+    if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    uint32_t bi = wg;
+    if (row_part_filter >= 0) {
+        bi = ((const __attribute__((address_space(4))) uint32_t*)part_heads)[static_cast<uint32_t>(row_part_filter) * gridDim.x + wg];
+        if (bi == kNoBlock) return;
+    }
+    bool first_block = true;
+    for (uint32_t next = 0;; bi = next) {
+        const BlockTable blk = (BlockTable)(blocks + bi);
+        next = (row_part_filter >= 0 && (blk->flags & kBlockLastOfPartition)) ? 0u : blk->next;
+        const uint32_t nrows = blk->nrows, out0 = blk->out_offset;
+        // the block's 16 wavefront runs sit at units[16 bi ..] (the builder stores them in final block order): descriptor and run
+        // are fetched side by side, one dependent round trip before the first mask load instead of two
+        const WaveSegTable seg = (WaveSegTable)(units + static_cast<size_t>(bi) * kBitmapWaves) + wave;
+        const uint32_t row_begin = seg->row_begin, row_end = seg->row_end, g_begin = seg->g_begin, steps = seg->g_end - seg->g_begin;
+        const uint64_t* mp = reinterpret_cast<const uint64_t*>(image) + ((static_cast<uint64_t>(seg->mask_hi) << 32) | seg->mask_lo);
+        const uint32_t* vp = reinterpret_cast<const uint32_t*>(image) + ((static_cast<uint64_t>(seg->value_hi) << 32) | seg->value_lo);
+        const uint32_t col0 = blk->first_col0 + g_begin * kBitmapGroupCols;
+        stamp(1, col0 + steps + nrows);
+
+        if (!first_block) __syncthreads();   // the previous block's result store has read the accumulators
+        first_block = false;
+        for (uint32_t i = tid; i <= nrows; i += kBmThreads) ys[i] = 0;           // PE banks start at zero (pe.h:131-135)
+        __syncthreads();
+        for (uint32_t r = row_begin; r < row_end; ++r) {
+            const typename R::sum_t mine = (kAblate & 8) ? typename R::sum_t(steps) : bitmap_row_run<kFloat, kAblate>(mp, vp, x, num_cols, col0, steps, lane, stamps);
+            if (kAblate & 64) { uint64_t t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(mine)); if (lane == 0) stamps[4] = t; }
+            mp += (steps + 7u) / 8u * 8u + 16u;     // the run's masks + its zero padding (bitmap_tiles.cpp)
+            if (kAblate & 16) { asm volatile("" ::"v"(mine)); continue; }
+            const typename R::sum_t total = wave_sum(mine);
+            if (lane == 0) R::add_sum(ys, r, total);
+        }
+        // no-return LDS atomics can outlive s_waitcnt lgkmcnt(0) (spmv_kernels.hip): a RETURNING atomic per wavefront, awaited
+        const acc_t flushed = atomicAdd(ys + nrows, static_cast<acc_t>(0));
+        asm volatile("" ::"v"(flushed));
+        stamp(5, nrows);
+        __syncthreads();
+        stamp(6, nrows);
+        for (uint32_t i = tid; i < nrows; i += kBmThreads) out[out0 + i] = R::finish(ys[i]);
+        if (kAblate & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(7, nrows); }
+        if (!next) break;
+    }
+}
+
+#define HS_FOR_EACH_BITMAP_VARIANT(X) X(false, 0) X(true, 0) X(true, 1) X(true, 2) X(true, 3) X(true, 4) X(true, 7) X(true, 15) X(true, 31) X(true, 23) X(true, 64) X(true, 256)
+
+int bitmap_env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+
+}  // namespace
+
+hipError_t configure_bitmap_kernels(uint32_t lds_bytes) {
+    hipError_t e;
+#define X(F, A) \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_bitmap_kernel<F, A>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != hipSuccess) return e;
+    HS_FOR_EACH_BITMAP_VARIANT(X)
+#undef X
+    return hipSuccess;
+}
+
+hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
+    if (a.num_workgroups == 0) return hipSuccess;
+    const dim3 grid(a.num_workgroups), block(kBmThreads);
+    static const int ablate = bitmap_env_int("HISPARSE_ABLATE", 0);
+    // timeline build: HISPARSE_ABLATE=64 HISPARSE_TIMELINE_OUT=file -> every launch is synchronised and its per-wavefront
+    // timestamps (workgroups x 16 x 8 u64, 100 MHz) overwrite the file (tools/bitmap_timeline.py reads it)
+    static uint64_t* timeline = nullptr;
+    if ((ablate & 64) && !timeline) (void)hipMalloc(reinterpret_cast<void**>(&timeline), size_t(4096) * kBitmapWaves * 8 * sizeof(uint64_t));
+    bool launched = false;
+#define X(F, A)                                                                                                                                  \
+    if (!launched && is_float == F && ablate == A) {                                                                                             \
+        hipLaunchKernelGGL((spmv_bitmap_kernel<F, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.num_cols, a.out,     \
+                           a.row_part_filter, a.part_heads, timeline);                                                                           \
+        launched = true;                                                                                                                         \
+    }
+    HS_FOR_EACH_BITMAP_VARIANT(X)
+#undef X
+    if (!launched) return hipErrorInvalidValue;
+    if ((ablate & 64) && timeline && a.num_workgroups <= 4096) {
+        if (const char* path = std::getenv("HISPARSE_TIMELINE_OUT")) {
+            (void)hipStreamSynchronize(stream);
+            std::vector<uint64_t> host(size_t(a.num_workgroups) * kBitmapWaves * 8);
+            (void)hipMemcpy(host.data(), timeline, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+            if (FILE* f = std::fopen(path, "wb")) {
+                std::fwrite(host.data(), sizeof(uint64_t), host.size(), f);
+                std::fclose(f);
+            }
+        }
+    }
+    return hipGetLastError();
+}
+
+}  // namespace dev
+}  // namespace hisparse

@@ -20,7 +20,8 @@ struct SpmvLaunch {
     uint32_t* out;                // packed result words: y itself (one column slice) or slices x num_rows partials
     int32_t row_part_filter;      // -1: every row partition
     uint32_t ring_buffers;        // x sub-tile buffers in the LDS ring (2..4)
-    bool delta;                   // stream format of `image`: DELTA records, otherwise PAIRS chunks (stream_tiles.h)
+    uint32_t format;              // StreamFormat of `image` (stream_tiles.h): PAIRS chunks, DELTA records or BITMAP rows
+    uint32_t num_cols;            // length of x in words (BITMAP: the x reads of a row's last group are range-checked against it)
     uint32_t num_workgroups;
     uint32_t lds_bytes;
 };
@@ -31,6 +32,9 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers);
 hipError_t configure_spmv_kernels(uint32_t lds_bytes);
 // The SpMV kernel: row-owner workgroups, x sub-tiles double-buffered in LDS, no global atomics.
 hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream);
+// BITMAP images (spmv_bitmap.hip); launch_spmv forwards to it when a.format == kFormatBitmap.
+hipError_t configure_bitmap_kernels(uint32_t lds_bytes);
+hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream);
 // Column-sliced matrices only: y[r] = (saturating / fp32) sum of the `slices` partial vectors, rows [row_lo, row_hi);
 // with x_fb also x_fb[r] = scale (*) y[r] (+) shift for r < n_fb (hs_iterate's feedback folded into the same launch).
 hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_t* y, uint32_t num_rows, uint32_t slices, uint32_t row_lo,

@@ -7,6 +7,7 @@
 // with the row <-> (channel, lane, round) mapping of sw/data_formatter.h:410,432 and the result drain
 // order of spmv/spmv_result_drain.cpp:36,104-113 (net effect: natural row order in y).
 #include "stream_tiles.h"
+#include "tiles_common.h"
 
 #include <algorithm>
 #include <atomic>
@@ -24,106 +25,7 @@ namespace dev {
 
 namespace {
 
-struct PhaseTimer {   // HISPARSE_PLAN_DEBUG=1: wall time of the load-time passes
-    const bool on = std::getenv("HISPARSE_PLAN_DEBUG") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void lap(const char* what) {
-        const auto now = std::chrono::steady_clock::now();
-        if (on) std::fprintf(stderr, "re-tile %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-        t = now;
-    }
-};
-
-template <typename Fn>
-void parallel_for(size_t n, Fn fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    unsigned threads = unsigned(std::min<size_t>(hw ? hw : 1u, n));
-    if (threads <= 1) {
-        for (size_t i = 0; i < n; ++i) fn(i);
-        return;
-    }
-    std::atomic<size_t> next(0);
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < threads; ++t)
-        pool.emplace_back([&]() {
-            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
-        });
-    for (auto& th : pool) th.join();
-}
-
-struct Layout {
-    const Geometry* g;
-    uint32_t num_rows, num_cols, row_parts, col_parts, F;
-    uint32_t sub_width;     // columns per x sub-tile
-    uint32_t subs_per_cp;   // sub-tiles per column partition
-    uint32_t rows_in_part(uint32_t rp) const {
-        uint64_t lo = uint64_t(rp) * g->logical_ob;
-        return uint32_t(std::min<uint64_t>(g->logical_ob, num_rows - lo));
-    }
-    uint32_t cols_in_part(uint32_t cp) const {
-        uint64_t lo = uint64_t(cp) * g->logical_vb;
-        return uint32_t(std::min<uint64_t>(g->logical_vb, num_cols - lo));
-    }
-};
-
-struct WalkResult {
-    bool ok = true;
-    std::string error;
-    uint64_t nnz = 0;
-};
-
-// Visit every non-zero of physical channel `pc` in partition (rp, cp): visit(absolute_row, partition_local_col, value_word).
-template <typename Visit>
-WalkResult walk_channel_partition(const Layout& L, const MatPkt* buf, uint64_t n_pkts, uint32_t pc, uint32_t rp, uint32_t cp,
-                                  Visit visit) {
-    WalkResult res;
-    const uint32_t F = L.F;
-    const uint32_t parts = L.row_parts * L.col_parts;
-    const uint64_t pid = uint64_t(rp) * L.col_parts + cp;     // j outer, i inner (sw/benchmark.cpp:142-143)
-    const uint64_t header = pid * (1 + F);
-    const uint64_t payload_base = uint64_t(parts) * (1 + F);  // spmv_cluster.h:41 / fp :46
-    auto fail = [&](const std::string& what) {
-        res.ok = false;
-        res.error = "channel " + std::to_string(pc) + ", row partition " + std::to_string(rp) + ", column partition " +
-                    std::to_string(cp) + ": " + what;
-        return res;
-    };
-    if (header + 1 + F > n_pkts) return fail("partition header lies outside the channel buffer");
-    const uint64_t start = buf[header].indices.data[0];        // already multiplied by F (benchmark.cpp:178-179)
-    const uint64_t stride = uint64_t(PACK_SIZE) * NUM_HBM_CHANNELS * F;  // rows between two rows of one lane stream
-    const uint64_t row_base = uint64_t(rp) * L.g->logical_ob;
-    const uint64_t row_limit = row_base + L.rows_in_part(rp);
-    const uint32_t col_limit = L.cols_in_part(cp);
-    const bool fixed = L.g->impl == IMPL_FIXED;
-
-    for (uint32_t f = 0; f < F; ++f) {
-        const PackedWord& lens = buf[header + 1 + f].indices;
-        uint32_t longest = 0;
-        for (uint32_t k = 0; k < PACK_SIZE; ++k) longest = std::max(longest, lens.data[k]);
-        if (longest && payload_base + start + uint64_t(longest - 1) * F + f >= n_pkts)
-            return fail("payload runs past the end of the channel buffer");
-        const uint32_t vc = pc + f * NUM_HBM_CHANNELS;         // benchmark.cpp:146
-        uint64_t row[PACK_SIZE];
-        for (uint32_t k = 0; k < PACK_SIZE; ++k) row[k] = row_base + uint64_t(vc) * PACK_SIZE + k;  // round 0, data_formatter.h:410
-        const MatPkt* pkt = buf + payload_base + start + f;
-        for (uint32_t p = 0; p < longest; ++p, pkt += F) {
-            for (uint32_t k = 0; k < PACK_SIZE; ++k) {
-                if (p >= lens.data[k]) continue;               // lane exhausted: zero padding
-                const uint32_t col = pkt->indices.data[k], val = pkt->vals.data[k];
-                if (col == IDX_MARKER) {
-                    // fixed: integer part of the Q8.24 word (spmv_cluster.h:82); float: raw bits (fp :104)
-                    row[k] += uint64_t(fixed ? (val >> 24) : val) * stride;
-                } else {
-                    if (col >= col_limit) return fail("column index " + std::to_string(col) + " outside the column partition");
-                    if (row[k] >= row_limit) return fail("decoded row outside the row partition (marker count wrapped?)");
-                    visit(uint32_t(row[k]), col, val);
-                    ++res.nnz;
-                }
-            }
-        }
-    }
-    return res;
-}
+using namespace detail;
 
 struct UnitPlan {           // host-side companion of a device Unit
     uint32_t n = 0;         // real elements
@@ -181,6 +83,27 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     }
 
     timer.lap("pass 0 (row counts)");
+    // ---- dense-row matrices (pruned-NN layers): BITMAP rows, their own builder and kernel (stream_tiles.h) --------------
+    {
+        // density of the rows that hold anything (padding rows and empty rows cost a mask per group and nothing else -- as long as
+        // all masks together stay below a quarter of the 8 bytes per non-zero they replace)
+        uint64_t live_rows = 0;
+        for (uint32_t r = 0; r < num_rows; ++r) live_rows += row_nnz[r] != 0;
+        const double density = live_rows ? double(out.nnz) / (double(live_rows) * double(num_cols)) : 0.0;
+        const double mask_bytes = double(num_rows) * double((num_cols + kBitmapGroupCols - 1) / kBitmapGroupCols) * 8.0;
+        bool bitmap = density >= kBitmapMinDensity && num_cols >= kBitmapMinCols && mask_bytes <= 2.0 * double(out.nnz);
+        if (const char* force = std::getenv("HISPARSE_STREAM_FORMAT")) {
+            const std::string f(force);
+            if (f == "bitmap") bitmap = true;
+            else if (f == "pairs" || f == "delta") bitmap = false;
+            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta or bitmap"; return false; }
+        }
+        if (bitmap) {
+            if (build_bitmap_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error)) return true;
+            if (error.rfind("bitmap:", 0) != 0) return false;     // a real decode error
+            error.clear();                                       // not representable as a bitmap (duplicate entries): element streams
+        }
+    }
     // ---- tile plan: column slices x (rows per block, x ring depth) ------------------------------------------------
     // More column slices = longer row ranges = less x pulled through every CU, at the price of the combine pass; fewer
     // rows per block = deeper x ring = refill latency hidden even when a (row range, sub-tile) unit holds only a few
@@ -237,13 +160,14 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             const std::string f(force);
             if (f == "pairs") out.format = kFormatPairs;
             else if (f == "delta") out.format = kFormatDelta;
-            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs or delta"; return false; }
+            else if (f == "bitmap") {}   // was tried above and is not representable (duplicate entries): automatic choice
+            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta or bitmap"; return false; }
         }
     }
     const bool delta = out.format == kFormatDelta;
 
     // ---- row ranges: equal non-zero count, <= max_rows rows, never across a row partition ---------------------------
-    struct Range { uint32_t row0, nrows, row_part; };
+    using Range = RowRange;
     std::vector<Range> ranges;
     std::vector<uint64_t> range_nnz;
     // as many ranges as workgroup slots (G / slices), or the next multiple of that when the LDS row cap forces more, so that
@@ -252,26 +176,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     const uint64_t rounds = std::max<uint64_t>(1, ((uint64_t(num_rows) + max_rows - 1) / max_rows + per_round - 1) / per_round);
     const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(per_round * rounds, out.nnz / 4096));
     const uint64_t target = std::max<uint64_t>(1, (out.nnz + want_ranges - 1) / want_ranges);
-    for (uint32_t rp = 0; rp < RP; ++rp) {
-        const uint32_t lo = uint32_t(uint64_t(rp) * geom.logical_ob), hi = lo + L.rows_in_part(rp);
-        uint32_t r0 = lo;
-        uint64_t acc = 0;
-        for (uint32_t r = lo; r < hi; ++r) {
-            // close the range BEFORE a row that would overshoot the target by more than the range undershoots now
-            const uint64_t with = acc + row_nnz[r];
-            if (r > r0 && (r - r0 == max_rows || (with > target && with - target > target - std::min(acc, target)))) {
-                ranges.push_back(Range{r0, r - r0, rp});
-                range_nnz.push_back(acc);
-                r0 = r;
-                acc = 0;
-            }
-            acc += row_nnz[r];
-        }
-        if (hi > r0) {
-            ranges.push_back(Range{r0, hi - r0, rp});
-            range_nnz.push_back(acc);
-        }
-    }
+    build_row_ranges(L, row_nnz, target, max_rows, ranges, range_nnz);
     const uint32_t NR = uint32_t(ranges.size());
     std::vector<uint32_t> block_of_row(num_rows);   // row -> row range
     for (uint32_t b = 0; b < NR; ++b) {
@@ -441,45 +346,11 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         }
     }
 
-    // ---- workgroups: longest-processing-time assignment of blocks ------------------------------------------
+    // ---- workgroups: longest-processing-time assignment of blocks (tiles_common.h) ------------------------------
     std::vector<std::vector<uint32_t>> mine;
-    {
-        const uint32_t groups = std::min<uint32_t>(G, std::max<uint32_t>(1, NB));
-        out.num_workgroups = groups;
-        mine.resize(groups);
-        std::vector<uint64_t> load(groups, 0), part_load(groups, 0);
-        std::vector<std::vector<uint32_t>> by_rank(groups);
-        // Row partition by row partition (a launch of hs_run_partition runs ONE of them and wants it spread over all
-        // workgroups), heaviest block first, each to the workgroup with the least work in this partition -- ties to the one
-        // with the least work overall, so that the partitions' leftovers do not pile up on the same workgroups.
-        for (uint32_t rp = 0; rp < RP; ++rp) {
-            std::vector<uint32_t> order;
-            for (uint32_t b = 0; b < NB; ++b)
-                if (out.blocks[b].row_part == rp) order.push_back(b);
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return block_nnz[a] > block_nnz[b]; });
-            std::fill(part_load.begin(), part_load.end(), 0);
-            for (uint32_t b : order) {
-                uint32_t best = 0;
-                for (uint32_t g = 1; g < groups; ++g)
-                    if (part_load[g] < part_load[best] || (part_load[g] == part_load[best] && load[g] < load[best])) best = g;
-                by_rank[best].push_back(b);
-                part_load[best] += block_nnz[b] + 16;   // every block also costs a fixed prologue/epilogue (in steps)
-                load[best] += block_nnz[b] + 16;
-            }
-        }
-        // Group i (i-th heaviest first block) becomes workgroup (i % 8) * groups/8 + i / 8: the kernel runs logical
-        // workgroups [x * groups/8, (x+1) * groups/8) on XCD x, so every XCD -- its L2 and its share of the fabric to HBM --
-        // gets the same mix of heavy and light blocks (measured before: XCDs 0-3 held every 2913-step block, 6-7 only
-        // 2755-step ones, and finished 2 us apart).
-        for (uint32_t i = 0; i < groups; ++i) {
-            const uint32_t g = groups % 8 == 0 ? (i % 8) * (groups / 8) + i / 8 : i;
-            mine[g].swap(by_rank[i]);
-        }
-    }
-    // Final block order: the first block of workgroup g sits at blocks[g] (ONE dependent load before the kernel's first
-    // stream load), further blocks of a workgroup are chained through Block::next.  Also fills the copies of unit data.
+    assign_workgroups(out, block_nnz, G, RP, mine);
+    // Final block order (chain_blocks) after the copies of unit data the kernel wants inside the Block have been filled in.
     auto finish_blocks = [&]() {
-        const uint32_t groups = out.num_workgroups;
         for (Block& blk : out.blocks) {
             if (blk.unit_end > blk.unit_begin) {
                 for (uint32_t w = 0; w < kConsumerWaves; ++w) {
@@ -490,31 +361,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 blk.first_ncols = out.units[blk.unit_begin].ncols;
             }
         }
-        std::vector<uint32_t> new_index(NB, 0);
-        uint32_t tail = 0;
-        for (uint32_t g = 0; g < groups; ++g) tail += mine[g].empty() ? 0u : 1u;   // == groups unless NB == 0
-        uint32_t heads = 0;
-        for (uint32_t g = 0; g < groups; ++g)
-            for (size_t k = 0; k < mine[g].size(); ++k) new_index[mine[g][k]] = k == 0 ? heads++ : tail++;
-        std::vector<Block> moved(NB);
-        out.wg_first.assign(groups + 1, 0);
-        out.block_order.clear();
-        out.part_heads.assign(size_t(RP) * groups, kNoBlock);
-        for (uint32_t g = 0; g < groups; ++g) {
-            out.wg_first[g] = uint32_t(out.block_order.size());
-            for (size_t k = 0; k < mine[g].size(); ++k) {
-                Block blk = out.blocks[mine[g][k]];
-                const bool last_of_part = k + 1 == mine[g].size() || out.blocks[mine[g][k + 1]].row_part != blk.row_part;
-                const bool first_of_part = k == 0 || out.blocks[mine[g][k - 1]].row_part != blk.row_part;
-                blk.next = k + 1 < mine[g].size() ? new_index[mine[g][k + 1]] : 0u;
-                if (last_of_part) blk.flags |= kBlockLastOfPartition;
-                if (first_of_part) out.part_heads[size_t(blk.row_part) * groups + g] = new_index[mine[g][k]];
-                moved[new_index[mine[g][k]]] = blk;
-                out.block_order.push_back(new_index[mine[g][k]]);
-            }
-        }
-        out.wg_first[groups] = uint32_t(out.block_order.size());
-        out.blocks.swap(moved);
+        chain_blocks(out, mine, RP);
     };
 
     timer.lap("stream layout + workgroups");

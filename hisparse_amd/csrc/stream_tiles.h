@@ -89,7 +89,20 @@ constexpr uint32_t kBridgeAdvance = 0xffffu;                  // ... which advan
 constexpr double kDeltaMinMeanGap = 2048.0;                   // denser matrices: PAIRS wins (measured: mouse_gene 43.6 vs 48.0 us, transformer-50 18.6 vs 24.4)
 constexpr double kDeltaMaxMeanGap = 20000.0;                  // sparser matrices: > 4 % of the gaps need bridges, PAIRS wins
 constexpr double kDenseMeanGap = 2048.0;                      // DELTA blocks denser than this sum per lane in registers (kBlockDenseRows)
-enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1 };
+enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1, kFormatBitmap = 2 };
+// BITMAP format (dense-row matrices, e.g. the pruned-NN layers of sw/bm.sh:21-27: 512 rows x 33 K columns, half of them set):
+// a row is cut into GROUPS of 64 consecutive columns; per (row, group) the image holds one 64-bit occupancy mask and the
+// values of the set columns, compacted, in column order.  4 bytes + 1 bit per column position instead of 8 bytes per non-zero
+// (4.25 B per non-zero at 50 % density), and x is read LINEARLY (x[64 g + lane], coalesced, straight from L2): no x sub-tiles,
+// no LDS gather, no per-sub-tile barriers.  A workgroup owns whole rows (or, for matrices with fewer rows than CUs, a column
+// slice of them); each of its 16 wavefronts streams a contiguous run of groups, sums per lane in registers and adds one
+// wavefront-wide sum per row to the row's LDS accumulator.  kernel: spmv_bitmap.hip; builder: bitmap_tiles.cpp.
+constexpr double kBitmapMinDensity = 0.125;                   // below: < 8 of 64 lanes busy per step, PAIRS / DELTA win
+constexpr uint32_t kBitmapMinCols = 2048;                     // shorter rows: a wavefront's run per row is too short to pipeline
+constexpr uint32_t kBitmapGroupCols = 64;                     // one wavefront step
+constexpr uint32_t kBitmapWaves = 16;                         // all 16 wavefronts of the workgroup stream (no loader wavefronts)
+constexpr uint32_t kBitmapMaxBlockRows = 8191;                // 64 KiB of 8-byte row accumulators
+constexpr uint32_t kBitmapMaskBatch = 32;                     // masks fetched per vector load (one dword per lane)
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit
@@ -120,6 +133,17 @@ struct Unit {
     uint32_t ncols;         // multiple of 8, <= kSubTileCols
     uint32_t end_step[kConsumerWaves];      // per wavefront: its stream position (in chunks / records, heads included) after this unit
 };
+// BITMAP images re-use the two tables: a Block describes (row range x column slice) -- row0, nrows, row_part, flags, out_offset, next as
+// above, first_col0 = first column of the slice, first_ncols = groups per row in the slice -- and its units [unit_begin, unit_end)
+// are kBitmapWaves WaveSeg entries (same 64 bytes as a Unit), one per wavefront:
+struct WaveSeg {
+    uint32_t row_begin, row_end;   // local rows [row_begin, row_end) of the block; row_end - row_begin == 1: the groups [g_begin, g_end)
+    uint32_t g_begin, g_end;       //   of that row (relative to the slice), otherwise WHOLE rows (g_begin = 0, g_end = groups per row)
+    uint32_t value_lo, value_hi;   // word offset (from the image start) of the first compacted value of the wavefront's run
+    uint32_t mask_lo, mask_hi;     // 8-byte offset (from the image start) of the first mask of the run; masks and values of a
+    uint32_t pad[8];               //   block are stored in (row, group) order, so a run is contiguous in both
+};
+static_assert(sizeof(WaveSeg) == 64, "WaveSeg overlays Unit");
 static_assert(sizeof(Block) == 320, "Block layout is shared with the device code");
 static_assert(sizeof(Unit) == 8 + 4 * kConsumerWaves, "Unit layout is shared with the device code");
 

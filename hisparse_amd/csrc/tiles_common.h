@@ -1,0 +1,232 @@
+// tiles_common.h — pieces shared by the load-time builders (stream_tiles.cpp: PAIRS / DELTA element streams,
+// bitmap_tiles.cpp: BITMAP rows): the CPSR walk, the thread pool, workgroup assignment and block chaining.
+//
+// The decode follows the reference's loader in MEANING (header layout, per-lane lengths, marker = row
+// advance, interleaved virtual channels):
+//   spmv/libfpga/spmv_cluster.h:41-98        fixed point, INTERLEAVE_FACTOR 1
+//   spmv-fp/libfpga/spmv_cluster.h:46-117    float, INTERLEAVE_FACTOR 1 or 8
+// with the row <-> (channel, lane, round) mapping of sw/data_formatter.h:410,432.
+#ifndef HISPARSE_TILES_COMMON_H_
+#define HISPARSE_TILES_COMMON_H_
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "stream_tiles.h"
+
+namespace hisparse {
+namespace dev {
+namespace detail {
+
+struct PhaseTimer {   // HISPARSE_PLAN_DEBUG=1: wall time of the load-time passes
+    const bool on = std::getenv("HISPARSE_PLAN_DEBUG") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (on) std::fprintf(stderr, "re-tile %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
+template <typename Fn>
+void parallel_for(size_t n, Fn fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned threads = unsigned(std::min<size_t>(hw ? hw : 1u, n));
+    if (threads <= 1) {
+        for (size_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<size_t> next(0);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&]() {
+            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+        });
+    for (auto& th : pool) th.join();
+}
+
+struct Layout {
+    const Geometry* g;
+    uint32_t num_rows, num_cols, row_parts, col_parts, F;
+    uint32_t sub_width;     // columns per x sub-tile
+    uint32_t subs_per_cp;   // sub-tiles per column partition
+    uint32_t rows_in_part(uint32_t rp) const {
+        uint64_t lo = uint64_t(rp) * g->logical_ob;
+        return uint32_t(std::min<uint64_t>(g->logical_ob, num_rows - lo));
+    }
+    uint32_t cols_in_part(uint32_t cp) const {
+        uint64_t lo = uint64_t(cp) * g->logical_vb;
+        return uint32_t(std::min<uint64_t>(g->logical_vb, num_cols - lo));
+    }
+};
+
+struct WalkResult {
+    bool ok = true;
+    std::string error;
+    uint64_t nnz = 0;
+};
+
+// Visit every non-zero of physical channel `pc` in partition (rp, cp): visit(absolute_row, partition_local_col, value_word).
+template <typename Visit>
+WalkResult walk_channel_partition(const Layout& L, const MatPkt* buf, uint64_t n_pkts, uint32_t pc, uint32_t rp, uint32_t cp,
+                                  Visit visit) {
+    WalkResult res;
+    const uint32_t F = L.F;
+    const uint32_t parts = L.row_parts * L.col_parts;
+    const uint64_t pid = uint64_t(rp) * L.col_parts + cp;     // j outer, i inner (sw/benchmark.cpp:142-143)
+    const uint64_t header = pid * (1 + F);
+    const uint64_t payload_base = uint64_t(parts) * (1 + F);  // spmv_cluster.h:41 / fp :46
+    auto fail = [&](const std::string& what) {
+        res.ok = false;
+        res.error = "channel " + std::to_string(pc) + ", row partition " + std::to_string(rp) + ", column partition " +
+                    std::to_string(cp) + ": " + what;
+        return res;
+    };
+    if (header + 1 + F > n_pkts) return fail("partition header lies outside the channel buffer");
+    const uint64_t start = buf[header].indices.data[0];        // already multiplied by F (benchmark.cpp:178-179)
+    const uint64_t stride = uint64_t(PACK_SIZE) * NUM_HBM_CHANNELS * F;  // rows between two rows of one lane stream
+    const uint64_t row_base = uint64_t(rp) * L.g->logical_ob;
+    const uint64_t row_limit = row_base + L.rows_in_part(rp);
+    const uint32_t col_limit = L.cols_in_part(cp);
+    const bool fixed = L.g->impl == IMPL_FIXED;
+
+    for (uint32_t f = 0; f < F; ++f) {
+        const PackedWord& lens = buf[header + 1 + f].indices;
+        uint32_t longest = 0;
+        for (uint32_t k = 0; k < PACK_SIZE; ++k) longest = std::max(longest, lens.data[k]);
+        if (longest && payload_base + start + uint64_t(longest - 1) * F + f >= n_pkts)
+            return fail("payload runs past the end of the channel buffer");
+        const uint32_t vc = pc + f * NUM_HBM_CHANNELS;         // benchmark.cpp:146
+        uint64_t row[PACK_SIZE];
+        for (uint32_t k = 0; k < PACK_SIZE; ++k) row[k] = row_base + uint64_t(vc) * PACK_SIZE + k;  // round 0, data_formatter.h:410
+        const MatPkt* pkt = buf + payload_base + start + f;
+        for (uint32_t p = 0; p < longest; ++p, pkt += F) {
+            for (uint32_t k = 0; k < PACK_SIZE; ++k) {
+                if (p >= lens.data[k]) continue;               // lane exhausted: zero padding
+                const uint32_t col = pkt->indices.data[k], val = pkt->vals.data[k];
+                if (col == IDX_MARKER) {
+                    // fixed: integer part of the Q8.24 word (spmv_cluster.h:82); float: raw bits (fp :104)
+                    row[k] += uint64_t(fixed ? (val >> 24) : val) * stride;
+                } else {
+                    if (col >= col_limit) return fail("column index " + std::to_string(col) + " outside the column partition");
+                    if (row[k] >= row_limit) return fail("decoded row outside the row partition (marker count wrapped?)");
+                    visit(uint32_t(row[k]), col, val);
+                    ++res.nnz;
+                }
+            }
+        }
+    }
+    return res;
+}
+
+
+struct RowRange { uint32_t row0, nrows, row_part; };
+
+// Workgroups: longest-processing-time assignment of blocks, row partition by row partition (a launch of hs_run_partition
+// runs ONE of them and wants it spread over all workgroups), heaviest block first, each to the workgroup with the least
+// work in this partition -- ties to the one with the least work overall, so that the partitions' leftovers do not pile up
+// on the same workgroups.  Group i (i-th heaviest first block) becomes workgroup (i % 8) * groups/8 + i / 8: the kernels run
+// logical workgroups [x * groups/8, (x+1) * groups/8) on XCD x, so every XCD -- its L2 and its share of the fabric to HBM --
+// gets the same mix of heavy and light blocks.  Sets out.num_workgroups; mine[g] = blocks of workgroup g in execution order.
+inline void assign_workgroups(StreamTiles& out, const std::vector<uint64_t>& block_weight, uint32_t max_workgroups, uint32_t row_parts,
+                              std::vector<std::vector<uint32_t>>& mine) {
+    const uint32_t NB = uint32_t(out.blocks.size());
+    const uint32_t groups = std::min<uint32_t>(std::max<uint32_t>(1, max_workgroups), std::max<uint32_t>(1, NB));
+    out.num_workgroups = groups;
+    mine.assign(groups, {});
+    std::vector<uint64_t> load(groups, 0), part_load(groups, 0);
+    std::vector<std::vector<uint32_t>> by_rank(groups);
+    for (uint32_t rp = 0; rp < row_parts; ++rp) {
+        std::vector<uint32_t> order;
+        for (uint32_t b = 0; b < NB; ++b)
+            if (out.blocks[b].row_part == rp) order.push_back(b);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return block_weight[a] > block_weight[b]; });
+        std::fill(part_load.begin(), part_load.end(), 0);
+        for (uint32_t b : order) {
+            uint32_t best = 0;
+            for (uint32_t g = 1; g < groups; ++g)
+                if (part_load[g] < part_load[best] || (part_load[g] == part_load[best] && load[g] < load[best])) best = g;
+            by_rank[best].push_back(b);
+            part_load[best] += block_weight[b] + 16;   // every block also costs a fixed prologue/epilogue (in steps)
+            load[best] += block_weight[b] + 16;
+        }
+    }
+    for (uint32_t i = 0; i < groups; ++i) {
+        const uint32_t g = groups % 8 == 0 ? (i % 8) * (groups / 8) + i / 8 : i;
+        mine[g].swap(by_rank[i]);
+    }
+}
+
+// Final block order: the first block of workgroup g sits at blocks[g] (ONE dependent load before the kernel's first
+// stream load), further blocks of a workgroup are chained through Block::next.  Fills wg_first / block_order / part_heads.
+inline void chain_blocks(StreamTiles& out, const std::vector<std::vector<uint32_t>>& mine, uint32_t row_parts) {
+    const uint32_t groups = out.num_workgroups, NB = uint32_t(out.blocks.size());
+    std::vector<uint32_t> new_index(NB, 0);
+    uint32_t tail = 0;
+    for (uint32_t g = 0; g < groups; ++g) tail += mine[g].empty() ? 0u : 1u;   // == groups unless NB == 0
+    uint32_t heads = 0;
+    for (uint32_t g = 0; g < groups; ++g)
+        for (size_t k = 0; k < mine[g].size(); ++k) new_index[mine[g][k]] = k == 0 ? heads++ : tail++;
+    std::vector<Block> moved(NB);
+    out.wg_first.assign(groups + 1, 0);
+    out.block_order.clear();
+    out.part_heads.assign(size_t(row_parts) * groups, kNoBlock);
+    for (uint32_t g = 0; g < groups; ++g) {
+        out.wg_first[g] = uint32_t(out.block_order.size());
+        for (size_t k = 0; k < mine[g].size(); ++k) {
+            Block blk = out.blocks[mine[g][k]];
+            const bool last_of_part = k + 1 == mine[g].size() || out.blocks[mine[g][k + 1]].row_part != blk.row_part;
+            const bool first_of_part = k == 0 || out.blocks[mine[g][k - 1]].row_part != blk.row_part;
+            blk.next = k + 1 < mine[g].size() ? new_index[mine[g][k + 1]] : 0u;
+            if (last_of_part) blk.flags |= kBlockLastOfPartition;
+            if (first_of_part) out.part_heads[size_t(blk.row_part) * groups + g] = new_index[mine[g][k]];
+            moved[new_index[mine[g][k]]] = blk;
+            out.block_order.push_back(new_index[mine[g][k]]);
+        }
+    }
+    out.wg_first[groups] = uint32_t(out.block_order.size());
+    out.blocks.swap(moved);
+}
+
+// Row ranges of roughly `target` non-zeros each, at most max_rows rows, never across a row partition.
+inline void build_row_ranges(const Layout& L, const std::vector<uint32_t>& row_nnz, uint64_t target, uint32_t max_rows,
+                             std::vector<RowRange>& ranges, std::vector<uint64_t>& range_nnz) {
+    for (uint32_t rp = 0; rp < L.row_parts; ++rp) {
+        const uint32_t lo = uint32_t(uint64_t(rp) * L.g->logical_ob), hi = lo + L.rows_in_part(rp);
+        uint32_t r0 = lo;
+        uint64_t acc = 0;
+        for (uint32_t r = lo; r < hi; ++r) {
+            // close the range BEFORE a row that would overshoot the target by more than the range undershoots now
+            const uint64_t with = acc + row_nnz[r];
+            if (r > r0 && (r - r0 == max_rows || (with > target && with - target > target - std::min(acc, target)))) {
+                ranges.push_back(RowRange{r0, r - r0, rp});
+                range_nnz.push_back(acc);
+                r0 = r;
+                acc = 0;
+            }
+            acc += row_nnz[r];
+        }
+        if (hi > r0) {
+            ranges.push_back(RowRange{r0, hi - r0, rp});
+            range_nnz.push_back(acc);
+        }
+    }
+}
+
+}  // namespace detail
+
+// bitmap_tiles.cpp: the BITMAP builder (called by build_stream_tiles once the format is chosen; `row_nnz` from its pass 0)
+bool build_bitmap_tiles(const detail::Layout& L, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
+                        const std::vector<uint32_t>& row_nnz, uint32_t max_workgroups, StreamTiles& out, std::string& error);
+
+}  // namespace dev
+}  // namespace hisparse
+
+#endif  // HISPARSE_TILES_COMMON_H_

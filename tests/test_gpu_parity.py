@@ -18,10 +18,11 @@ pytestmark = pytest.mark.gpu
 IMPLS = [0, 1, 2]
 
 
-@pytest.fixture(autouse=True, params=["pairs", "delta", "delta-lane-sums", "delta-no-lane-sums"])
+@pytest.fixture(autouse=True, params=["pairs", "delta", "delta-lane-sums", "delta-no-lane-sums", "bitmap"])
 def stream_format(request, monkeypatch):
     # every parity test runs once per device stream format (hisparse_amd/csrc/stream_tiles.h); DELTA additionally with the
-    # per-lane register sums of long-row blocks forced on and off (by default the block's density decides)
+    # per-lane register sums of long-row blocks forced on and off (by default the block's density decides); BITMAP (normally
+    # chosen for dense rows only) forced onto every matrix small enough for a mask per 64 columns of every row
     monkeypatch.setenv("HISPARSE_STREAM_FORMAT", request.param.split("-")[0])
     if request.param.endswith("-lane-sums"):
         monkeypatch.setenv("HISPARSE_ROW_RUNS", "0" if "-no-" in request.param else "1")
@@ -45,7 +46,9 @@ def _run_case(impl, m, vb, ob, skip, seed):
     stats = eng.stats()
     eng.close()
     assert stats["nnz"] == m.nnz
-    assert device.STREAM_FORMATS[stats["stream_format"]] == os.environ["HISPARSE_STREAM_FORMAT"]
+    forced = os.environ["HISPARSE_STREAM_FORMAT"]
+    if forced != "bitmap" or cp.num_rows * ((cp.num_cols + 63) // 64) * 8 <= (1 << 30):    # a forced bitmap gives way above 1 GiB of masks
+        assert device.STREAM_FORMATS[stats["stream_format"]] == forced
     if impl == 0:
         assert np.array_equal(got, want), f"fixed-point mismatch at {np.nonzero(got != want)[0][:8]}"
         assert np.array_equal(again, want)
@@ -426,3 +429,43 @@ def test_full_size_exact_known_answer(name, stream_format, monkeypatch):
     assert stats["nnz"] == len(ix)
     assert np.array_equal(got, want), f"{int((got != want).sum())} rows differ"
     assert np.array_equal(again, want)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("rows,cols,density", [(512, 33288, 0.5), (40, 9000, 0.3), (3000, 2500, 0.2), (129, 2049, 0.9), (20000, 4096, 0.15)])
+def test_dense_rows_pick_bitmap(impl, rows, cols, density, stream_format, monkeypatch):
+    """Pruned-NN shaped matrices (sw/bm.sh:21-27) choose the BITMAP format unforced: whole-run, partition-by-partition and
+    repeated launches against the oracle."""
+    if stream_format != "pairs":
+        pytest.skip("format chosen by the library here; one pass")
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    m = cases.random_csr(rows, cols, density, 17, impl)
+    if impl != 0:
+        m.data *= np.float32(0.05)       # pruned-NN weights (datasets.py: N(0, 0.05)): the ORACLE's fp32 running sum of 16 K unit-sized
+                                         # terms would itself be further than 1e-4 from the exact product (DESIGN.md section 4)
+    v, o = host.default_banks(impl)
+    if rows == 20000:
+        o = 16 if impl != 2 else 16      # several row partitions: 20000 rows over LOGICAL_OB = 2048
+    csr, cp = cases.formatted(m, impl, v, o, True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 17, impl))
+    want = orc.spmv(impl, [cp.channel(c) for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions,
+                    cp.ob_bank, cp.vb_bank)
+    with device.SpmvEngine(impl, ob_bank=cp.ob_bank, vb_bank=cp.vb_bank) as eng:
+        eng.load_matrix(cp)
+        eng.load_vector(xw)
+        st = eng.stats()
+        assert st["nnz"] == m.nnz
+        # rows padded to 1024 (float_stall) can leave so many empty rows that their masks outweigh the saving: element streams then
+        expect_bitmap = cp.num_rows * ((cp.num_cols + 63) // 64) * 8 <= 2 * m.nnz
+        assert (device.STREAM_FORMATS[st["stream_format"]] == "bitmap") == expect_bitmap
+        if expect_bitmap:
+            assert st["stream_bytes"] < 0.8 * 8 * m.nnz + (1 << 20)
+        results = []
+        for _ in range(3):
+            eng.run()
+            results.append(eng.read_result())
+        for j in range(cp.num_row_partitions):
+            eng.run_partition(j, cp.part_len(j))
+        results.append(eng.read_result())
+    for got in results:
+        assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)

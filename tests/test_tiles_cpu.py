@@ -1,5 +1,7 @@
 """Load-time re-tiling (hisparse_amd/csrc/stream_tiles.cpp) checked without a GPU: the image hs_load_matrix would
 upload is walked by a numpy emulation of the kernel (tests/tile_emulator.py) and compared with the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,7 +12,7 @@ import cases
 import tile_emulator
 
 
-@pytest.fixture(autouse=True, params=["pairs", "delta"])
+@pytest.fixture(autouse=True, params=["pairs", "delta", "bitmap"])
 def stream_format(request, monkeypatch):
     # every test of this module runs once per device stream format (stream_tiles.h)
     monkeypatch.setenv("HISPARSE_STREAM_FORMAT", request.param)
@@ -47,6 +49,8 @@ def test_emulated_kernel_matches_oracle(impl, skip, rows, cols, density, vb, ob,
 
 
 def test_structure_invariants(stream_format):
+    if stream_format == "bitmap":
+        pytest.skip("element-stream structure; BITMAP has its own test below")
     csr = host.CSRMatrix.generate("powerlaw", 30000, 50000, a=600000, b=0.4, c=1.0, seed=3)
     cp = host.format_matrix(csr, 0, skip_empty_rows=True)
     t = build(cp, 0, 64)
@@ -100,6 +104,8 @@ def test_structure_invariants(stream_format):
 @pytest.mark.parametrize("slices", [2, 4])
 def test_column_slices(impl, slices, monkeypatch):
     # 2-D decomposition: (row range x column slice) blocks writing per-slice partials + combine pass
+    if os.environ.get("HISPARSE_STREAM_FORMAT") == "bitmap":
+        pytest.skip("sub-tile slices; BITMAP slices are covered by test_bitmap_structure_and_parity")
     monkeypatch.setenv("HISPARSE_COL_SLICES", str(slices))
     csr = host.CSRMatrix.generate("powerlaw", 20000, 60000, a=300000, b=0.4, c=1.0 if impl == 0 else 2.0, seed=11)
     cp = host.format_matrix(csr, impl, skip_empty_rows=True)
@@ -260,3 +266,70 @@ def test_reference_formatter_marker_limit_quirk_is_documented():
     xw = host.pack_vector(0, np.ones(cols, dtype=np.float32))
     y = orc.spmv(0, ref, xw, rows, cols, rp, cpn, 8192, 4096)
     assert np.nonzero(orc.unpack_result(0, y))[0].tolist() == [5, 5 + 128 * 255, 5 + 128 * 305]
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("rows,cols,density,wgs", [(512, 4200, 0.5, 256), (40, 9000, 0.3, 64), (3000, 2500, 0.2, 16), (129, 2049, 0.9, 8)])
+def test_bitmap_structure_and_parity(impl, rows, cols, density, wgs, monkeypatch):
+    """Dense-row matrices pick the BITMAP format by themselves; image = one 64-bit mask per (row, 64-column group) + the compacted
+    values; every (row, group) belongs to exactly one wavefront run (checked inside the emulator); y matches the oracle."""
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    m = cases.random_csr(rows, cols, density, 31, impl)
+    ob = 1024 if impl == 1 else 8192
+    _, cp = cases.formatted(m, impl, 4096, ob, True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 31, impl))
+    t = build(cp, impl, wgs)
+    assert t["format"] == "bitmap" and t["nnz"] == m.nnz and t["elements"] == m.nnz
+    blocks, slices = t["blocks"], t["col_slices"]
+    groups = (cp.num_cols + 63) // 64
+    # fewer rows than workgroups: the columns are cut into slices so that every workgroup has a block
+    assert slices == max(1, min(8, 1 << int(np.floor(np.log2(max(1, wgs // cp.num_rows))))))
+    assert len(t["units"]) == 16 * len(blocks) and (blocks["unit_end"] - blocks["unit_begin"] == 16).all()
+    # masks: rows x groups x 8 bytes in total (every row belongs to `slices` blocks that split its groups) + zero padding of
+    # at most 23 masks per wavefront run; values: 4 bytes, padded to 8 per block
+    mask_bytes = int((blocks["nrows"].astype(np.int64) * blocks["first_ncols"]).sum()) * 8
+    assert mask_bytes == cp.num_rows * groups * 8
+    runs = int(np.where(blocks["nrows"] * 2 <= 16, blocks["nrows"] * (16 // np.maximum(blocks["nrows"], 1)), blocks["nrows"]).sum())
+    assert mask_bytes + 4 * m.nnz + 16 * 8 * runs <= len(t["image"]) <= mask_bytes + 4 * m.nnz + 4 * len(blocks) + 23 * 8 * runs
+    assert len(t["image"]) < 0.75 * 8 * m.nnz + 23 * 8 * runs      # the point of the format: well under 8 bytes per non-zero
+    assert blocks["nrows"].max() <= 8191 and t["max_block_rows"] == blocks["nrows"].max()
+    for b in blocks:
+        assert b["out_offset"] % cp.num_rows == b["row0"] and b["first_col0"] % 64 == 0
+    got = tile_emulator.run(t, impl, xw, cp.num_rows)
+    want = oracle_y(cp, impl, xw)
+    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+
+
+def test_bitmap_choice_unsorted_rows_and_duplicates(monkeypatch):
+    import scipy.sparse as sp
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    # below 1/8 density or with short rows the element streams stay
+    for rows, cols, density, want in [(256, 4096, 0.10, False), (256, 1024, 0.5, False), (256, 4096, 0.13, True)]:
+        m = cases.random_csr(rows, cols, density, 4, 0)
+        _, cp = cases.formatted(m, 0, 4096, 8192, True)
+        assert (build(cp, 0, 16)["format"] == "bitmap") == want
+    # CSR input with unsorted columns inside the rows (legal for the reference): the bitmap builder sorts them
+    rng = np.random.default_rng(6)
+    m = cases.random_csr(200, 3000, 0.3, 6, 0)
+    for r in range(m.shape[0]):
+        a, b = m.indptr[r], m.indptr[r + 1]
+        perm = rng.permutation(b - a)
+        m.indices[a:b], m.data[a:b] = m.indices[a:b][perm], m.data[a:b][perm]
+    csr = host.CSRMatrix.from_arrays(200, 3000, m.indptr.astype(np.uint32), m.indices.astype(np.uint32), m.data)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+    xw = host.pack_vector(0, cases.random_x(cp.num_cols, 6, 0))
+    t = build(cp, 0, 16)
+    assert t["format"] == "bitmap"
+    assert np.array_equal(tile_emulator.run(t, 0, xw, cp.num_rows), oracle_y(cp, 0, xw))
+    # the same column twice in a row cannot be one bit: the element streams take over, result still right
+    ip = np.array([0, 3] + [3] * 127, dtype=np.uint32)
+    ix = np.array([5, 5, 9], dtype=np.uint32)
+    dv = np.array([1.0, 2.0, 4.0], dtype=np.float32)
+    csr = host.CSRMatrix.from_arrays(128, 4096, ip, ix, dv)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "bitmap")
+    xw = host.pack_vector(0, np.ones(cp.num_cols, dtype=np.float32))
+    t = build(cp, 0, 4)
+    assert t["format"] != "bitmap"
+    y = tile_emulator.run(t, 0, xw, cp.num_rows)
+    assert orc.unpack_result(0, y)[0] == 7.0 and np.array_equal(y, oracle_y(cp, 0, xw))

@@ -83,18 +83,56 @@ def _block_delta(image, blk, units, x_words, ys, is_float):
             step[w] = end
 
 
+WAVESEG_DTYPE = np.dtype([("row_begin", "<u4"), ("row_end", "<u4"), ("g_begin", "<u4"), ("g_end", "<u4"), ("value", "<u8"), ("mask", "<u8"),
+                          ("pad", "<u4", (8,))])
+BITMAP_WAVES, GROUP = 16, 64
+
+
+def _block_bitmap(image, blk, units, x_words, ys, is_float):
+    """spmv_bitmap_kernel: every wavefront walks its run of (row, 64-column group) steps; mask bit l = column 64 g + l is set,
+    its value is the next compacted one."""
+    nrows, col0, gs = int(blk["nrows"]), int(blk["first_col0"]), int(blk["first_ncols"])
+    assert int(blk["unit_end"]) - int(blk["unit_begin"]) == BITMAP_WAVES
+    segs = units[int(blk["unit_begin"]): int(blk["unit_end"])].view(WAVESEG_DTYPE).reshape(-1)
+    masks = image[: image.size // 8 * 8].view(np.uint64)
+    values = image[: image.size // 4 * 4].view(np.uint32)
+    covered = np.zeros((nrows, gs), dtype=np.int32)
+    for w in range(BITMAP_WAVES):
+        sg = segs[w]
+        r0, r1, g0, g1 = int(sg["row_begin"]), int(sg["row_end"]), int(sg["g_begin"]), int(sg["g_end"])
+        assert r0 <= r1 <= nrows and g0 <= g1 <= gs
+        assert r1 - r0 <= 1 or (g0 == 0 and g1 == gs)                 # several rows: whole rows only
+        mp, vp = int(sg["mask"]), int(sg["value"])
+        for r in range(r0, r1):
+            covered[r, g0:g1] += 1
+            m = masks[mp: mp + (g1 - g0)]
+            stride = (g1 - g0 + 7) // 8 * 8 + 16                         # zero masks up to a multiple of 8, plus two batches
+            assert not masks[mp + (g1 - g0): mp + stride].any()
+            mp += stride
+            bits = np.unpackbits(m.view(np.uint8).reshape(-1, 8), axis=1, bitorder="little").astype(bool)    # [group, lane]
+            n = int(bits.sum())
+            g, lane = np.nonzero(bits)
+            col = col0 + (g0 + g) * GROUP + lane
+            assert (col < x_words.size).all()
+            _accumulate(ys, is_float, np.full(n, r, dtype=np.int64), values[vp: vp + n], x_words[col])
+            vp += n
+    assert (covered == 1).all()                                       # every (row, group) of the block belongs to exactly one wavefront
+
+
 def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
     """Returns packed y words.  tiles: dict from hisparse_amd.device.build_tiles."""
     is_float = impl != 0
     image, blocks, units = tiles["image"], tiles["blocks"], tiles["units"]
     delta = tiles["format"] == "delta"
+    bitmap = tiles["format"] == "bitmap"
     y = np.zeros(num_rows, dtype=np.uint32) if y_init is None else y_init.copy()
     slices = int(tiles.get("col_slices", 1))
     out = y if slices == 1 else np.zeros(slices * num_rows, dtype=np.uint32)   # per-slice partial results
     touched = np.zeros(num_rows, dtype=bool)
     done = np.zeros(len(blocks), dtype=bool)
-    assert 2 <= tiles["ring_buffers"] <= 4
-    assert (units["ncols"] % 8 == 0).all() and (units["ncols"] > 0).all() and (units["ncols"] <= SUB_TILE).all()
+    if not bitmap:
+        assert 2 <= tiles["ring_buffers"] <= 4
+        assert (units["ncols"] % 8 == 0).all() and (units["ncols"] > 0).all() and (units["ncols"] <= SUB_TILE).all()
     for g in range(tiles["num_workgroups"]):
         for q in range(tiles["wg_first"][g], tiles["wg_first"][g + 1]):
             b = int(tiles["block_order"][q])
@@ -104,11 +142,11 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
             if row_part_filter >= 0 and int(blk["row_part"]) != row_part_filter:
                 continue
             nrows, row0, out0 = int(blk["nrows"]), int(blk["row0"]), int(blk["out_offset"])
-            assert nrows <= (32 if slices == 1 else 96) * 1024 // 8 - 1     # LDS plan of the kernel: 8-byte accumulators
+            assert nrows <= (8191 if bitmap else (32 if slices == 1 else 96) * 1024 // 8 - 1)   # LDS plan of the kernels: 8-byte accumulators
             assert out0 % num_rows == row0 and out0 // num_rows < slices
             touched[row0: row0 + nrows] = True
             ys = np.zeros(nrows + 1, dtype=np.float64 if is_float else np.uint64)     # double sums of float products
-            (_block_delta if delta else _block_pairs)(image, blk, units, x_words, ys, is_float)
+            (_block_bitmap if bitmap else _block_delta if delta else _block_pairs)(image, blk, units, x_words, ys, is_float)
             if is_float:
                 out[out0: out0 + nrows] = ys[:nrows].astype(np.float32).view(np.uint32)
             else:
