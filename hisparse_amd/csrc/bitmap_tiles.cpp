@@ -81,10 +81,9 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     const uint64_t per_round = std::max<uint32_t>(1, G / slices);
     const uint64_t rounds = std::max<uint64_t>(1, ((uint64_t(num_rows) + max_rows - 1) / max_rows + per_round - 1) / per_round);
     const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(per_round * rounds, std::max<uint64_t>(1, nnz / 1024)));
-    const uint64_t target = std::max<uint64_t>(1, (nnz + want_ranges - 1) / want_ranges);
     std::vector<RowRange> ranges;
     std::vector<uint64_t> range_nnz;
-    build_row_ranges(L, row_nnz, target, max_rows, ranges, range_nnz);
+    build_row_ranges_at_most(L, row_nnz, nnz, want_ranges, max_rows, ranges, range_nnz);
     const uint32_t NR = uint32_t(ranges.size());
     const uint32_t NB = NR * slices;
 

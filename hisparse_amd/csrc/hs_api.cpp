@@ -241,7 +241,7 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     } catch (const std::bad_alloc&) {
         return fail(ctx, HS_ERR_NO_MEMORY, "out of host memory while re-tiling the matrix");
     }
-    const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers);
+    const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers, tiles.format);
     if (lds_bytes > hisparse::dev::kMaxLdsBytes) return fail(ctx, HS_ERR_UNSUPPORTED, "row block does not fit the LDS");
 
     // the dynamic-LDS cap is a property of the FUNCTION, not of this context: always raise it to the full 160 KiB, so that a

@@ -27,7 +27,7 @@ struct SpmvLaunch {
 };
 
 // Dynamic LDS a launch needs for blocks of at most `max_block_rows` rows and a ring of `ring_buffers` x buffers.
-uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers);
+uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t format = kFormatPairs);
 // One-time per device: allow the kernels to use up to `lds_bytes` of dynamic LDS.
 hipError_t configure_spmv_kernels(uint32_t lds_bytes);
 // The SpMV kernel: row-owner workgroups, x sub-tiles double-buffered in LDS, no global atomics.

@@ -29,8 +29,10 @@
 // Data layout and the two stream formats: stream_tiles.h.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <utility>
+#include <vector>
 
 #include "spmv_kernels.h"
 #include "spmv_device.h"
@@ -73,10 +75,24 @@ __device__ __forceinline__ void dma_fill_x(uint32_t* dst, const uint32_t* __rest
                                          (__attribute__((address_space(3))) uint32_t*)(dst + c), 16, 0, 0);
     }
 }
-// "at most kFills refills are still in flight" (vmcnt retires in order; the loader wavefronts issue nothing else)
-template <int kFills>
+// "at most kFills refills are still in flight" (vmcnt retires in order; the loader wavefronts issue nothing else -- except, with
+// kTouch, the kTouchPerFill prefetch loads that follow every refill)
+constexpr uint32_t kTouchPerFill = kSubTileCols * 4u / 128u / (kLoaderWaves * kWaveLanes);   // one dword per 128-byte line: 2 per lane
+template <int kFills, bool kTouch = false>
 __device__ __forceinline__ void dma_wait() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFills * kDmaPerFill) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFills * (kDmaPerFill + (kTouch ? kTouchPerFill : 0u)) + (kTouch ? kTouchPerFill : 0u)) : "memory");
+}
+// Pull a sub-tile of x into this XCD's L2 ahead of its refill: the row blocks of an XCD walk the sub-tiles in the same order at
+// about the same time, so without this every refill of every workgroup is an L2 MISS at the same moment (x, 9.8 MB on
+// ogbn-products, does not stay in a 4 MiB L2), and with a ring of two buffers the refill latency is on the critical path.
+__device__ __forceinline__ void touch_x(const uint32_t* __restrict__ x, uint32_t col0, uint32_t ncols, uint32_t w, uint32_t lane) {
+#pragma unroll
+    for (uint32_t j = 0; j < kTouchPerFill; ++j) {
+        const uint32_t c = ((w * kTouchPerFill + j) * kWaveLanes + lane) * 32u;            // one word per 128 bytes
+        // the data goes to an accumulator register (loader wavefronts use none, and hipcc allocates none in this kernel): a VGPR
+        // output would be handed to something else by the compiler while the load is still in flight
+        asm volatile("global_load_dword a0, %0, off" ::"v"(x + col0 + min(c, ncols - 1)) : "memory", "a0");
+    }
 }
 
 // The element stream is loaded with hand-placed instructions: hipcc's s_waitcnt placement degrades to vmcnt(0)
@@ -109,6 +125,14 @@ struct Ring<false> {   // PAIRS: one dwordx2 per lane and step
     static __device__ __forceinline__ void take(uint32_t& value, uint32_t& where) {
         asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]"
                      : "=v"(value), "=v"(where) : "n"(2 * K), "n"(2 * K + 1), "n"(kDepth - 1) : "memory");
+    }
+    // steps K and K + 1 together (neither slot has been re-issued yet: kDepth - 2 younger loads may stay in flight)
+    template <int K, int kDepth>
+    static __device__ __forceinline__ void take2(uint32_t& value0, uint32_t& where0, uint32_t& value1, uint32_t& where1) {
+        asm volatile("s_waitcnt vmcnt(%8)\n\tv_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\t"
+                     "v_accvgpr_read_b32 %3, a[%7]"
+                     : "=v"(value0), "=v"(where0), "=v"(value1), "=v"(where1)
+                     : "n"(2 * K), "n"(2 * K + 1), "n"(2 * K + 2), "n"(2 * K + 3), "n"(kDepth - 2) : "memory");
     }
 };
 template <>
@@ -161,7 +185,13 @@ struct Consumer {
     prod_t run_sum = 0;        // ... and this lane's share of that sum
     uint32_t lane_row = 0;     // DELTA dense rows: the row this LANE is on (its run of consecutive elements rarely leaves it) ...
     typename Rows<kFloat>::sum_t lane_sum = 0;   // ... and the lane's private sum on it, flushed to LDS when the row changes
+    float own_sum = 0;         // OWNER: the lane's fp32 sum on lane_row (accumulators are floats, touched by this wavefront only)
+    uint32_t spare = 0;        // OWNER: the wavefront's own spare accumulator (local row nrows + wave)
+    uint64_t t_flush = 0, t_barrier = 0;   // OWNER profiling build (kAblate & 256): clocks spent in end-of-unit flushes / at unit barriers
 };
+
+// OWNER profiling build: where a wavefront's time goes (HISPARSE_ABLATE=256, tools/owner_profile.py); 8 u64 per wavefront
+__device__ uint64_t* g_owner_profile = nullptr;
 
 // One step (slot K of the ring).  Returns false when the block is finished.
 // kDelta: DELTA format, otherwise PAIRS; kDense: the block's rows are long (Block::flags & kBlockDenseRows): products are
@@ -261,6 +291,134 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
     return true;
 }
 
+// ---- OWNER format (stream_tiles.h): float accumulators without atomics ----------------------------------------------------------
+// The wavefront owns its rows: nobody else reads or writes ys32[row] for the rows in its stream, and LDS executes one wavefront's
+// instructions in order, so a plain read-modify-write is safe as long as the lanes of ONE instruction hold distinct rows.  The
+// builder deals a (unit, wavefront) share -- sorted by (row, column) -- to the lanes in consecutive runs, so rows are
+// non-decreasing from lane to lane.  A lane sums while its row stays the same and writes when it changes: two lanes flushing in
+// the same step flush different rows (the lower lane's old row is below its new row, which is at most the higher lane's first
+// row).  Only at the end of a unit, when every lane hands its last row over, can neighbours hold the same row: one segmented
+// wavefront reduction first.
+__device__ __forceinline__ void owner_flush(float* ys32, uint32_t row, float sum) {
+    float a = ys32[row];
+    a += sum;
+    ys32[row] = a;
+}
+__device__ __forceinline__ void owner_end_of_unit(Consumer<true>& c) {
+    float* ys32 = reinterpret_cast<float*>(c.ys);
+    const uint32_t row = c.lane_row;
+    float sum = c.own_sum;
+    const bool live = row != c.spare;                           // lanes that saw only padding have nothing to hand over
+    const uint32_t above = __shfl_down(row, 1, kWaveLanes);
+    const bool same_above = live && c.lane + 1 < kWaveLanes && above == row;
+    if (__ballot(same_above) == 0) {                            // the usual case in a hyper-sparse unit: all rows distinct
+        if (live) owner_flush(ys32, row, sum);
+    } else {
+        // equal rows are contiguous lanes: suffix sums inside every run of equal rows, the run's first lane writes
+#pragma unroll
+        for (uint32_t d = 1; d < kWaveLanes; d <<= 1) {
+            const float s2 = __shfl_down(sum, d, kWaveLanes);
+            const uint32_t r2 = __shfl_down(row, d, kWaveLanes);
+            if (c.lane + d < kWaveLanes && r2 == row) sum += s2;
+        }
+        const uint32_t below = __shfl_up(row, 1, kWaveLanes);
+        if (live && (c.lane == 0 || below != row)) owner_flush(ys32, row, sum);
+    }
+    c.lane_row = c.spare;
+    c.own_sum = 0;
+}
+
+template <int kAblate, int kDepth, int K>
+__device__ __forceinline__ bool consume_step_owner(Consumer<true>& c) {
+    const uint32_t s = c.base + K;
+    while (s == c.end) {               // this wavefront finished sub-tile u (possibly with no work in it)
+        if (kAblate & 256) {
+            const uint64_t t0 = __builtin_readcyclecounter();
+            owner_end_of_unit(c);
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the flush has executed
+            const uint64_t t1 = __builtin_readcyclecounter();
+            lds_barrier();
+            const uint64_t t2 = __builtin_readcyclecounter();
+            c.t_flush += t1 - t0;
+            c.t_barrier += t2 - t1;
+        } else {
+        if (!(kAblate & 1)) owner_end_of_unit(c);
+        if (!(kAblate & 8)) lds_barrier();
+        }
+        if (++c.u == c.U) return false;
+        c.end = c.unit[c.u].end_step[c.wave];
+        c.slot = c.slot + 1 == c.ring ? 0 : c.slot + 1;
+        c.xb = c.xs + c.slot * kSubTileCols;
+    }
+    uint32_t mat, where;               // value word; local_row << 13 | local_col
+    Ring<false>::template take<K, kDepth>(mat, where);
+    const uint32_t row = where >> kOwnerColBits, col = where & (kSubTileCols - 1u);
+    if (kAblate & 1) {
+        const uint32_t xv = (kAblate & 2) ? where : c.xb[col];
+        asm volatile("" ::"v"(xv), "v"(mat), "v"(row));
+    } else {
+        // The accumulator of the row the lane is LEAVING and the x word of the element it has just taken are independent:
+        // both LDS reads go out back to back and their latencies overlap (one LDS round trip per step instead of two).
+        float* ys32 = reinterpret_cast<float*>(c.ys);
+        const bool leaving = row != c.lane_row;     // per lane; the very first step of a unit leaves the spare accumulator (adds 0)
+        float old = 0.0f;
+        if (leaving) old = ys32[c.lane_row];
+        const uint32_t xv = (kAblate & 2) ? where : c.xb[col];
+        const float prod = __uint_as_float(mat) * __uint_as_float(xv);     // one fp32 multiply, like the float PEs (pe-stall.h:52)
+        if (leaving) {
+            ys32[c.lane_row] = old + c.own_sum;
+            c.lane_row = row;
+            c.own_sum = 0;
+        }
+        c.own_sum += prod;
+    }
+    Ring<false>::template issue<K>(c.stream, min(s + kDepth, c.last) * kChunkBytes, c.lane_off);
+    return true;
+}
+// Two steps of the same unit at once: the two x words and the accumulators of the (up to two) rows the lane leaves are four
+// independent LDS reads -- one round trip for two steps.  (The row entered at step K can be left at step K + 1; its accumulator is
+// not written by step K, whose write goes to the row left THERE, and no other lane's write of this pair can hit it: a higher lane
+// leaves rows >= this lane's last row, which this lane never leaves, a lower lane leaves rows below this lane's first row.)
+template <int kAblate, int kDepth, int K>
+__device__ __forceinline__ bool consume_pair_owner(Consumer<true>& c) {
+    const uint32_t s = c.base + K;
+    if ((kAblate & 1) || s == c.end || s + 1 == c.end) {     // a unit ends at or inside the pair: one step at a time
+        if (!consume_step_owner<kAblate, kDepth, K>(c)) return false;
+        return consume_step_owner<kAblate, kDepth, K + 1>(c);
+    }
+    uint32_t mat0, where0, mat1, where1;
+    Ring<false>::template take2<K, kDepth>(mat0, where0, mat1, where1);
+    const uint32_t row0 = where0 >> kOwnerColBits, col0 = where0 & (kSubTileCols - 1u);
+    const uint32_t row1 = where1 >> kOwnerColBits, col1 = where1 & (kSubTileCols - 1u);
+    float* ys32 = reinterpret_cast<float*>(c.ys);
+    const bool leaving0 = row0 != c.lane_row, leaving1 = row1 != row0;
+    float old0 = 0.0f, old1 = 0.0f;
+    if (leaving0) old0 = ys32[c.lane_row];
+    if (leaving1) old1 = ys32[row0];
+    const uint32_t xv0 = (kAblate & 2) ? where0 : c.xb[col0];
+    const uint32_t xv1 = (kAblate & 2) ? where1 : c.xb[col1];
+    const float prod0 = __uint_as_float(mat0) * __uint_as_float(xv0), prod1 = __uint_as_float(mat1) * __uint_as_float(xv1);
+    if (leaving0) {
+        ys32[c.lane_row] = old0 + c.own_sum;
+        c.own_sum = 0;
+    }
+    c.own_sum += prod0;
+    if (leaving1) {
+        ys32[row0] = old1 + c.own_sum;
+        c.own_sum = 0;
+    }
+    c.own_sum += prod1;
+    c.lane_row = row1;
+    Ring<false>::template issue<K>(c.stream, min(s + kDepth, c.last) * kChunkBytes, c.lane_off);
+    Ring<false>::template issue<K + 1>(c.stream, min(s + 1 + kDepth, c.last) * kChunkBytes, c.lane_off);
+    return true;
+}
+template <int kAblate, int kDepth, int... Ks>
+__device__ __forceinline__ bool consume_round_owner(Consumer<true>& c, std::integer_sequence<int, Ks...>) {
+    static_assert(kDepth % 2 == 0, "steps are taken in pairs");
+    return ((Ks % 2 != 0 || consume_pair_owner<kAblate, kDepth, Ks>(c)) && ...);
+}
+
 template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense, int... Ks>
 __device__ __forceinline__ bool consume_round(Consumer<kFloat>& c, std::integer_sequence<int, Ks...>) {
     return (consume_step<kFloat, kDelta, kAblate, kDepth, kDense, Ks>(c) && ...);
@@ -272,23 +430,24 @@ __device__ __forceinline__ void prime_ring(const uint8_t* stream, uint32_t last,
 
 // Before the block's prologue: set the wavefront's consumer up and put the first kDepth loads in flight, so that the HBM
 // latency of the stream overlaps the accumulator zeroing and the first x sub-tile copy.
-template <bool kFloat, bool kDelta, int kDepth>
+template <bool kFloat, bool kDelta, int kDepth, bool kOwner = false>
 __device__ __forceinline__ void consumer_begin(Consumer<kFloat>& c, const uint8_t* stream, UnitTable unit, uint32_t U, uint32_t wave,
                                                uint32_t lane, const uint32_t* xs, uint32_t ring, typename Rows<kFloat>::acc_t* ys, uint32_t nrows,
                                                uint32_t total, uint32_t first_end) {
     static_assert(kDepth <= kMaxDepth, "the ring lives in a0..a31");
-    constexpr uint32_t kStride = kDelta ? kRecordBytes : kWaveStrideBytes;
+    constexpr uint32_t kStride = kDelta ? kRecordBytes : kOwner ? kChunkBytes : kWaveStrideBytes;
     c.stream = scalar_pointer(stream);
     c.unit = unit; c.U = U; c.wave = wave; c.lane = lane; c.ring = ring; c.nrows = nrows;
     c.lane_off = lane * Ring<kDelta>::kLaneBytes;
     c.last = total ? total - 1 : 0;    // prefetches past the end re-read the last chunk / record (no branch)
     c.xs = xs; c.xb = xs; c.ys = ys;
     c.end = first_end;
-    c.lane_row = nrows;
+    c.lane_row = kOwner ? nrows + wave : nrows;
+    c.spare = nrows + wave;
     prime_ring<kDelta>(c.stream, c.last, kStride, c.lane_off, std::make_integer_sequence<int, kDepth>());
 }
 
-template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense>
+template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense, bool kOwner = false>
 __device__ __forceinline__ void consumer_run(Consumer<kFloat>& c) {
     // The loader branch of the kernel leaves "LDS-DMA may be pending" in hipcc's wait-count bookkeeping, and that state
     // reaches this loop around the block loop and through the shared prologue: every LDS store on a conditional path below
@@ -296,9 +455,23 @@ __device__ __forceinline__ void consumer_run(Consumer<kFloat>& c) {
     // flight, so say so once, here, where it costs nothing: the prologue's x copy has just waited for vmcnt(0) anyway.
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), lgkmcnt/expcnt untouched
     if (kAblate & 64) { c.u = c.U - 1; c.end = c.last + 1; }   // profiling: one unit per block
-    for (;; c.base += kDepth)
-        if (!consume_round<kFloat, kDelta, kAblate, kDepth, kDense>(c, std::make_integer_sequence<int, kDepth>())) break;
+    const uint64_t t_begin = (kOwner && (kAblate & 256)) ? __builtin_readcyclecounter() : 0;
+    for (;; c.base += kDepth) {
+        if constexpr (kOwner) {
+            if (!consume_round_owner<kAblate, kDepth>(c, std::make_integer_sequence<int, kDepth>())) break;
+        } else {
+            if (!consume_round<kFloat, kDelta, kAblate, kDepth, kDense>(c, std::make_integer_sequence<int, kDepth>())) break;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory", HS_RING_AGPRS);   // the clamped tail prefetches must land before the ring is reused
+    if (kOwner && (kAblate & 256) && c.lane == 0 && g_owner_profile) {
+        uint64_t* p = g_owner_profile + (static_cast<size_t>(blockIdx.x) * kWavesPerWorkgroup + c.wave) * 8;
+        p[0] += __builtin_readcyclecounter() - t_begin;   // the wavefront's whole consumer phase
+        p[1] += c.t_flush;
+        p[2] += c.t_barrier;
+        p[3] += c.U;
+        p[4] += c.last + 1;                               // steps
+    }
 }
 
 // kDepth: element loads in flight per lane (kDepth x 512 B per wavefront).
@@ -306,7 +479,8 @@ __device__ __forceinline__ void consumer_run(Consumer<kFloat>& c) {
 // bit 2 = no x sub-tile refill, bit 3 = no per-sub-tile barrier, bit 4 = no block prologue (zero + first sub-tile),
 // bit 5 = no result store, bit 6 = ignore unit boundaries.  Any non-zero value gives wrong results.
 // kDelta: the image is in the DELTA stream format (stream_tiles.h), otherwise PAIRS.
-template <bool kFloat, bool kDelta, int kAblate, int kDepth>
+// kOwner: the image is in the OWNER format (float only): 4-byte float accumulators, nrows + 14 of them.
+template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kOwner = false>
 __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const Unit* __restrict__ units, const uint32_t* __restrict__ x,
                                                                   uint32_t* __restrict__ out, int32_t row_part_filter, uint32_t ring,
@@ -345,8 +519,11 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
         first_block = false;
         Consumer<kFloat> c;
         if (!loader && U > 0)
-            consumer_begin<kFloat, kDelta, kDepth>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave],
-                                                   blk->first_end[wave]);
+            consumer_begin<kFloat, kDelta, kDepth, kOwner>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave],
+                                                           blk->first_end[wave]);
+        if (kOwner) {
+            if (!(kAblate & 16)) for (uint32_t i = tid; i < nrows + kConsumerWaves; i += kThreads) reinterpret_cast<float*>(ys)[i] = 0.0f;
+        } else
         if (!(kAblate & 16)) for (uint32_t i = tid; i <= nrows; i += kThreads) ys[i] = 0;           // PE banks start at zero (pe.h:131-135)
         if (U > 0 && !(kAblate & 16)) fill_x<kSubTileCols / 4 / kThreads, kThreads>(xs, x, blk->first_col0, blk->first_ncols, tid);
         __syncthreads();
@@ -360,27 +537,49 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 // refill after next is fetched while this one is in flight, so its miss latency is off the per-unit path
                 // (hyper-sparse matrices have hundreds of short units per block: 1 us each used to add up to 300 us).
                 uint32_t col0_next = U > 1 ? unit[1].col0 : 0, ncols_next = U > 1 ? unit[1].ncols : 8;
+                uint32_t col0_after = U > 2 ? unit[2].col0 : col0_next, ncols_after = U > 2 ? unit[2].ncols : ncols_next;   // kOwner: two ahead
                 auto refill = [&](uint32_t v) {
                     const uint32_t col0 = col0_next, ncols = ncols_next;
-                    const uint32_t ahead = min(v + 1, U - 1);
-                    col0_next = unit[ahead].col0;
-                    ncols_next = unit[ahead].ncols;
+                    if (kOwner) {
+                        col0_next = col0_after;
+                        ncols_next = ncols_after;
+                        const uint32_t ahead = min(v + 2, U - 1);
+                        col0_after = unit[ahead].col0;
+                        ncols_after = unit[ahead].ncols;
+                    } else {
+                        const uint32_t ahead = min(v + 1, U - 1);
+                        col0_next = unit[ahead].col0;
+                        ncols_next = unit[ahead].ncols;
+                    }
                     if (!(kAblate & 4)) dma_fill_x(xs + fill_slot * kSubTileCols, x, col0, ncols, lw, lane);
                     fill_slot = fill_slot + 1 == ring ? 0 : fill_slot + 1;
                 };
                 uint32_t issued = 1;                                   // sub-tile 0 was copied synchronously above
                 while (issued < U && issued < ring - 1) refill(issued++);
+                uint64_t t_wait = 0, t_bar = 0;
+                const uint64_t t_begin = (kOwner && (kAblate & 256)) ? __builtin_readcyclecounter() : 0;
                 for (uint32_t u = 0; u < U; ++u) {
                     // slot (u + ring - 1) % ring last held sub-tile u-1, which every consumer left at the previous barrier
                     if (issued < U) refill(issued++);
                     // sub-tile u+1 must be resident before the consumers enter it (they do so after this barrier)
                     const uint32_t younger = issued - min(issued, u + 2);   // refills issued after the one for u+1: 0..ring-2
+                    const uint64_t t0 = (kOwner && (kAblate & 256)) ? __builtin_readcyclecounter() : 0;
                     if (younger >= 2) dma_wait<2>(); else if (younger == 1) dma_wait<1>(); else dma_wait<0>();
+                    const uint64_t t1 = (kOwner && (kAblate & 256)) ? __builtin_readcyclecounter() : 0;
                     if (!(kAblate & 8)) __builtin_amdgcn_s_barrier();
+                    if (kOwner && (kAblate & 256)) { const uint64_t t2 = __builtin_readcyclecounter(); t_wait += t1 - t0; t_bar += t2 - t1; }
+                }
+                if (kOwner && (kAblate & 256) && lane == 0 && g_owner_profile) {
+                    uint64_t* p = g_owner_profile + (static_cast<size_t>(blockIdx.x) * kWavesPerWorkgroup + wave) * 8;
+                    p[0] += __builtin_readcyclecounter() - t_begin;
+                    p[1] += t_wait;                                    // waiting for a refill to land
+                    p[2] += t_bar;                                     // waiting for the consumers at the unit barrier
+                    p[3] += U;
                 }
             } else {
                 // ---- consumer wavefronts: stream elements, gather x, accumulate rows -----------------------------
-                if (blk->flags & kBlockDenseRows) consumer_run<kFloat, kDelta, kAblate, kDepth, true>(c);
+                if constexpr (kOwner) consumer_run<kFloat, kDelta, kAblate, kDepth, false, true>(c);
+                else if (blk->flags & kBlockDenseRows) consumer_run<kFloat, kDelta, kAblate, kDepth, true>(c);
                 else consumer_run<kFloat, kDelta, kAblate, kDepth, false>(c);
             }
         }
@@ -389,6 +588,17 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
         // did not cover them and the accumulators were read too early (40 % of the launches of a 15 %-dense float matrix lost one
         // record's worth of products; found by tests/gpu_fuzz_soak.py).  LDS executes one wavefront's instructions in order, so a
         // RETURNING atomic on the spare accumulator, awaited, proves that everything this wavefront queued before it is done.
+        if (kOwner) {
+            // plain LDS writes: a read of the wavefront's own spare accumulator, awaited, comes back after every write it queued
+            if (!loader) {
+                const float flushed = reinterpret_cast<volatile float*>(ys)[nrows + wave];
+                asm volatile("" ::"v"(flushed));
+            }
+            __syncthreads();
+            if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = __float_as_uint(reinterpret_cast<float*>(ys)[i]);
+            if (!next) break;
+            continue;
+        }
         if (!loader) {
             const acc_t flushed = atomicAdd(ys + nrows, static_cast<acc_t>(0));
             asm volatile("" ::"v"(flushed));
@@ -451,9 +661,9 @@ __global__ __launch_bounds__(256) void feedback_kernel(const uint32_t* __restric
     if (i < n) x[i] = feedback_word<kFloat>(y[i], scale, shift);
 }
 
-template <bool kFloat, bool kDelta, int kAblate, int kDepth>
+template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kOwner = false>
 hipError_t configure_one(uint32_t lds_bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_rowblock_kernel<kFloat, kDelta, kAblate, kDepth>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_rowblock_kernel<kFloat, kDelta, kAblate, kDepth, kOwner>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
 }
 
@@ -464,10 +674,15 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
-// LDS plan: 64-bit row accumulators first (integer sums / double sums), then the ring of x buffers.
-uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers) {
-    return (((max_block_rows + 1) * kAccumulatorBytes + 15u) & ~15u) + ring_buffers * kBufBytes;
+// LDS plan: row accumulators first (64-bit integer sums / double sums + 1 spare; OWNER: floats + one spare per consumer
+// wavefront), then the ring of x buffers.
+uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t format) {
+    const uint32_t acc = format == kFormatOwner ? (max_block_rows + kConsumerWaves) * kOwnerAccumulatorBytes : (max_block_rows + 1) * kAccumulatorBytes;
+    return ((acc + 15u) & ~15u) + ring_buffers * kBufBytes;
 }
+
+// OWNER variants (float only): ablate values as for the other formats
+#define HS_FOR_EACH_OWNER_VARIANT(X) X(0) X(1) X(2) X(3) X(4) X(7) X(8) X(11) X(12) X(15) X(127) X(256)
 
 // (float, delta, ablate, depth): the product variants first, then the profiling builds (fixed point only)
 #define HS_FOR_EACH_VARIANT(X)                                                                                   \
@@ -483,6 +698,11 @@ hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
 #define X(F, T, A, D) if ((e = configure_one<F, T, A, D>(lds_bytes)) != hipSuccess) return e;
     HS_FOR_EACH_VARIANT(X)
 #undef X
+#define X(A) if ((e = configure_one<true, false, A, 8, true>(lds_bytes)) != hipSuccess) return e;
+    HS_FOR_EACH_OWNER_VARIANT(X)
+#undef X
+    if ((e = configure_one<true, false, 0, 16, true>(lds_bytes)) != hipSuccess) return e;
+    if ((e = configure_one<true, false, 0, 12, true>(lds_bytes)) != hipSuccess) return e;
     return configure_bitmap_kernels(lds_bytes);
 }
 
@@ -495,6 +715,49 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     // profiling aids: HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the prefetch depth
     static const int ablate = env_int("HISPARSE_ABLATE", 0), depth = env_int("HISPARSE_DEPTH", 8);
     bool launched = false;
+    if (a.format == kFormatOwner) {
+        if (!is_float) return hipErrorInvalidValue;
+        // profiling build: HISPARSE_ABLATE=256 HISPARSE_TIMELINE_OUT=file -> per-wavefront clock totals, accumulated over the
+        // launches, rewritten after every launch (tools/owner_profile.py)
+        static uint64_t* profile = nullptr;
+        if (ablate == 256 && !profile) {
+            (void)hipMalloc(reinterpret_cast<void**>(&profile), size_t(4096) * kWavesPerWorkgroup * 8 * sizeof(uint64_t));
+            (void)hipMemset(profile, 0, size_t(4096) * kWavesPerWorkgroup * 8 * sizeof(uint64_t));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_owner_profile), &profile, sizeof(profile));
+        }
+#define X(A)                                                                                                                      \
+    if (!launched && ablate == A) {                                                                                               \
+        hipLaunchKernelGGL((spmv_rowblock_kernel<true, false, A, 8, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks,  \
+                           a.units, a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                        \
+        launched = true;                                                                                                          \
+    }
+        if (depth == 8) {
+        HS_FOR_EACH_OWNER_VARIANT(X)
+        }
+#undef X
+        if (!launched && ablate == 0 && depth == 16) {
+            hipLaunchKernelGGL((spmv_rowblock_kernel<true, false, 0, 16, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out,
+                               a.row_part_filter, a.ring_buffers, x_base, a.part_heads);
+            launched = true;
+        }
+        if (!launched && ablate == 0 && depth == 12) {
+            hipLaunchKernelGGL((spmv_rowblock_kernel<true, false, 0, 12, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out,
+                               a.row_part_filter, a.ring_buffers, x_base, a.part_heads);
+            launched = true;
+        }
+        if (ablate == 256 && profile && a.num_workgroups <= 4096) {
+            if (const char* path = std::getenv("HISPARSE_TIMELINE_OUT")) {
+                (void)hipStreamSynchronize(stream);
+                std::vector<uint64_t> host(size_t(a.num_workgroups) * kWavesPerWorkgroup * 8);
+                (void)hipMemcpy(host.data(), profile, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+                if (FILE* f = std::fopen(path, "wb")) {
+                    std::fwrite(host.data(), sizeof(uint64_t), host.size(), f);
+                    std::fclose(f);
+                }
+            }
+        }
+        return launched ? hipGetLastError() : hipErrorInvalidValue;
+    }
 #define X(F, T, A, D)                                                                                                           \
     if (!launched && is_float == F && delta == T && ablate == A && depth == D) {                                     \
         hipLaunchKernelGGL((spmv_rowblock_kernel<F, T, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \

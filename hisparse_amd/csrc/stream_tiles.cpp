@@ -39,6 +39,8 @@ struct UnitPlan {           // host-side companion of a device Unit
     uint32_t run_len[kConsumerWaves];      // slots per lane of wavefront w in this unit
     uint64_t first_slot[kConsumerWaves];   // first slot of lane 0 of wavefront w
     uint32_t start_record[kConsumerWaves]; // record index of the unit's head record in wavefront w's stream
+    // OWNER
+    uint32_t own_begin[kConsumerWaves + 1]; // wavefront w owns sorted elements [own_begin[w], own_begin[w + 1]) of the unit
 };
 
 }  // namespace
@@ -96,7 +98,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             const std::string f(force);
             if (f == "bitmap") bitmap = true;
             else if (f == "pairs" || f == "delta") bitmap = false;
-            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta or bitmap"; return false; }
+            else if (f == "owner") bitmap = false;
+            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner or bitmap"; return false; }
         }
         if (bitmap) {
             if (build_bitmap_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error)) return true;
@@ -104,6 +107,24 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             error.clear();                                       // not representable as a bitmap (duplicate entries): element streams
         }
     }
+    // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse; hyper-sparse float matrices: OWNER --
+    {
+        const double mean_gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 1e30;
+        out.format = (mean_gap >= kDeltaMinMeanGap && mean_gap <= kDeltaMaxMeanGap) ? kFormatDelta : kFormatPairs;
+        if (is_float && mean_gap > kOwnerMinMeanGap && out.nnz >= 4096) out.format = kFormatOwner;
+        if (const char* force = std::getenv("HISPARSE_STREAM_FORMAT")) {
+            const std::string f(force);
+            if (f == "pairs") out.format = kFormatPairs;
+            else if (f == "delta") out.format = kFormatDelta;
+            else if (f == "owner") out.format = is_float ? kFormatOwner : kFormatPairs;   // float accumulators only
+            else if (f == "bitmap") {}   // was tried above and is not representable (duplicate entries): automatic choice
+            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner or bitmap"; return false; }
+        }
+    }
+    const bool delta = out.format == kFormatDelta, owner = out.format == kFormatOwner;
+    const uint32_t acc_bytes = owner ? kOwnerAccumulatorBytes : kAccumulatorBytes;
+    const uint32_t spare_rows = owner ? kConsumerWaves : 1u;     // accumulators behind the block's rows that padding elements aim at
+
     // ---- tile plan: column slices x (rows per block, x ring depth) ------------------------------------------------
     // More column slices = longer row ranges = less x pulled through every CU, at the price of the combine pass; fewer
     // rows per block = deeper x ring = refill latency hidden even when a (row range, sub-tile) unit holds only a few
@@ -116,18 +137,20 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         const char* force_slices = std::getenv("HISPARSE_COL_SLICES");
         const char* force_rows = std::getenv("HISPARSE_MAX_ROWS");   // experiments
         struct Shape { uint32_t cap, ring; };
-        const Shape sliced[2] = {{max_block_rows(true), 2}, {(kMaxLdsBytes - 3 * kSubTileCols * 4) / kAccumulatorBytes - 1, 3}};   // 12287 / 8191 rows
+        // OWNER: 4-byte accumulators -> 24561 rows with a ring of 2, 16369 with a ring of 3, sliced or not
+        const Shape sliced[2] = {{owner ? owner_max_block_rows(2) : max_block_rows(true), 2},
+                                 {owner ? owner_max_block_rows(3) : (kMaxLdsBytes - 3 * kSubTileCols * 4) / kAccumulatorBytes - 1, 3}};   // 12287 / 8191 rows
         const Shape whole[1] = {{max_block_rows(false), kMaxXBuffers}};                                       // 4095 rows, ring 4
         const double sub_tiles = double(CP) * S;
         double best = 1e30;
         for (uint32_t cs = 1; cs <= kMaxColSlices; cs *= 2) {
             if (force_slices && uint32_t(std::atoi(force_slices)) != cs) continue;
             if (cs > 1 && uint64_t(CP) * S < cs) continue;                                    // fewer sub-tiles than slices
-            for (const Shape& shape : cs > 1 ? std::vector<Shape>(sliced, sliced + 2) : std::vector<Shape>(whole, whole + 1)) {
+            for (const Shape& shape : (cs > 1 || owner) ? std::vector<Shape>(sliced, sliced + 2) : std::vector<Shape>(whole, whole + 1)) {
                 uint32_t cap = shape.cap, ring = shape.ring;
                 if (force_rows) {
                     cap = std::min<uint32_t>(cap, std::max(1, std::atoi(force_rows)));
-                    ring = std::max(kMinXBuffers, std::min(kMaxXBuffers, (kMaxLdsBytes - (cap + 1) * kAccumulatorBytes) / (kSubTileCols * 4u)));
+                    ring = std::max(kMinXBuffers, std::min(kMaxXBuffers, (kMaxLdsBytes - (cap + spare_rows) * acc_bytes) / (kSubTileCols * 4u)));
                 }
                 const uint64_t per_round = std::max<uint32_t>(1, G / cs);
                 const uint64_t need = (uint64_t(num_rows) + cap - 1) / cap;
@@ -148,23 +171,9 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     }
     if (uint64_t(slices) * num_rows > 0xffffffffull) {   // Block::out_offset = slice * num_rows + row0 is a 32-bit word offset
         while (slices > 1 && uint64_t(slices) * num_rows > 0xffffffffull) slices /= 2;
-        max_rows = slices > 1 ? max_block_rows(true) : max_block_rows(false);
+        max_rows = owner ? owner_max_block_rows(2) : slices > 1 ? max_block_rows(true) : max_block_rows(false);
     }
     out.col_slices = slices;
-
-    // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse ---------------------
-    {
-        const double mean_gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 1e30;
-        out.format = (mean_gap >= kDeltaMinMeanGap && mean_gap <= kDeltaMaxMeanGap) ? kFormatDelta : kFormatPairs;
-        if (const char* force = std::getenv("HISPARSE_STREAM_FORMAT")) {
-            const std::string f(force);
-            if (f == "pairs") out.format = kFormatPairs;
-            else if (f == "delta") out.format = kFormatDelta;
-            else if (f == "bitmap") {}   // was tried above and is not representable (duplicate entries): automatic choice
-            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta or bitmap"; return false; }
-        }
-    }
-    const bool delta = out.format == kFormatDelta;
 
     // ---- row ranges: equal non-zero count, <= max_rows rows, never across a row partition ---------------------------
     using Range = RowRange;
@@ -175,16 +184,33 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     const uint64_t per_round = std::max<uint32_t>(1, G / slices);
     const uint64_t rounds = std::max<uint64_t>(1, ((uint64_t(num_rows) + max_rows - 1) / max_rows + per_round - 1) / per_round);
     const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(per_round * rounds, out.nnz / 4096));
-    const uint64_t target = std::max<uint64_t>(1, (out.nnz + want_ranges - 1) / want_ranges);
-    build_row_ranges(L, row_nnz, target, max_rows, ranges, range_nnz);
+    build_row_ranges_at_most(L, row_nnz, out.nnz, want_ranges, max_rows, ranges, range_nnz);
     const uint32_t NR = uint32_t(ranges.size());
     std::vector<uint32_t> block_of_row(num_rows);   // row -> row range
     for (uint32_t b = 0; b < NR; ++b) {
         std::fill(block_of_row.begin() + ranges[b].row0, block_of_row.begin() + ranges[b].row0 + ranges[b].nrows, b);
         out.max_block_rows = std::max(out.max_block_rows, ranges[b].nrows);
     }
-    const uint32_t ring_fit = (kMaxLdsBytes - (((out.max_block_rows + 1) * kAccumulatorBytes + 15u) & ~15u)) / (kSubTileCols * 4u);
+    const uint32_t ring_fit = (kMaxLdsBytes - (((out.max_block_rows + spare_rows) * acc_bytes + 15u) & ~15u)) / (kSubTileCols * 4u);
     out.ring_buffers = std::max(kMinXBuffers, std::min(kMaxXBuffers, ring_fit));
+
+    // OWNER: every consumer wavefront owns a contiguous share of a range's rows, cut at equal non-zero count
+    std::vector<uint32_t> wave_row;      // [range][kConsumerWaves + 1] local row boundaries
+    if (owner) {
+        wave_row.assign(size_t(NR) * (kConsumerWaves + 1), 0);
+        parallel_for(NR, [&](size_t b) {
+            uint32_t* wr = wave_row.data() + b * (kConsumerWaves + 1);
+            const uint32_t r0 = ranges[b].row0, n = ranges[b].nrows;
+            uint64_t acc = 0;
+            uint32_t w = 1;
+            for (uint32_t r = 0; r < n && w < kConsumerWaves; ++r) {
+                acc += row_nnz[r0 + r];
+                while (w < kConsumerWaves && acc * kConsumerWaves >= range_nnz[b] * w) wr[w++] = r + 1;
+            }
+            for (; w <= kConsumerWaves; ++w) wr[w] = n;
+            wr[kConsumerWaves] = n;
+        });
+    }
 
     timer.lap("plan + row ranges");
     // ---- pass 1: elements per (row range, column partition, sub-tile, source channel) -------------------
@@ -238,6 +264,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 const double gap = range_nnz[b] ? double(ranges[b].nrows) * double(num_cols) / double(range_nnz[b]) : 1e30;
                 const char* force = std::getenv("HISPARSE_ROW_RUNS");
                 blk.flags = (force ? std::atoi(force) != 0 : gap < kDenseMeanGap) ? kBlockDenseRows : 0u;
+            } else if (owner) {
+                blk.flags = 0;
             } else {
                 blk.flags = (ranges[b].nrows <= kDenseBlockRows && range_nnz[b] >= 64ull * ranges[b].nrows) ? kBlockDenseRows : 0u;
             }
@@ -271,6 +299,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     }
     const uint32_t NB = uint32_t(out.blocks.size());
     const uint32_t NU = uint32_t(out.units.size());
+    std::vector<uint32_t> range_of_block(NB);
+    for (uint32_t bi = 0; bi < NB; ++bi) range_of_block[bi] = bi / slices;     // blocks were pushed range by range, slice by slice
 
     timer.lap("enumerate blocks + units");
     // ---- pass 2: collect every unit's elements as (position, value), position = local_row * 8192 + local_col -------
@@ -311,6 +341,23 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         for (uint32_t u = blk.unit_begin; u < blk.unit_end; ++u) {
             UnitPlan& up = plans[u];
             if (up.slots > 0x7fffffffull) { error = "unit too large"; return false; }
+            if (owner) {
+                // the unit's elements are sorted by (row, column): wavefront w's share is the contiguous stretch of its rows;
+                // steps = its 64-slot chunks; lane l takes elements [l * steps, (l + 1) * steps) of the share
+                const uint32_t* wr = wave_row.data() + size_t(range_of_block[bi]) * (kConsumerWaves + 1);
+                const uint64_t* e = scratch.data() + up.scratch;
+                for (uint32_t w = 0; w <= kConsumerWaves; ++w)
+                    up.own_begin[w] = uint32_t(std::lower_bound(e, e + up.n, uint64_t(wr[w]) << (32 + kOwnerColBits)) - e);
+                for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+                    const uint32_t steps = (up.own_begin[w + 1] - up.own_begin[w] + kWaveLanes - 1) / kWaveLanes;
+                    up.run_len[w] = steps;
+                    up.start_step[w] = up.start_record[w] = pos[w];
+                    pos[w] += steps;
+                    out.units[u].end_step[w] = pos[w];
+                    out.elements += uint64_t(steps) * kWaveLanes;
+                }
+                continue;
+            }
             const uint32_t chunks = uint32_t((up.slots + kWaveLanes - 1) / kWaveLanes);
             uint32_t run[kConsumerWaves] = {0};
             for (uint32_t c = 0; c < chunks; ++c) run[(chunk_counter + c) % kConsumerWaves]++;
@@ -332,11 +379,11 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         for (uint32_t w = 0; w < kConsumerWaves; ++w) block_nnz[bi] += pos[w];   // the block's weight: wavefront steps, heads included
         // the kernel addresses a wavefront's stream with a 32-bit byte offset from Block::wave_offset
         for (uint32_t w = 0; w < kConsumerWaves; ++w)
-            if (uint64_t(pos[w]) * (delta ? kRecordBytes : kWaveStrideBytes) >= (1ull << 32)) { error = "row block stream exceeds 4 GiB"; return false; }
-        if (delta) {
+            if (uint64_t(pos[w]) * (delta ? kRecordBytes : owner ? kChunkBytes : kWaveStrideBytes) >= (1ull << 32)) { error = "row block stream exceeds 4 GiB"; return false; }
+        if (delta || owner) {      // every wavefront's steps are contiguous
             for (uint32_t w = 0; w < kConsumerWaves; ++w) {
                 blk.wave_offset[w] = image_bytes;
-                image_bytes += uint64_t(pos[w]) * kRecordBytes;
+                image_bytes += uint64_t(pos[w]) * (delta ? kRecordBytes : kChunkBytes);
             }
         } else {
             // chunks are stored in dealing order (global chunk g of the block at g * 512 bytes; wavefront w consumes
@@ -371,6 +418,31 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     for (uint32_t bi = 0; bi < NB; ++bi)
         for (uint32_t u = out.blocks[bi].unit_begin; u < out.blocks[bi].unit_end; ++u) block_of_unit[u] = bi;
 
+    if (owner) {
+        // ---- OWNER: per (unit, wavefront) share: slot (step s, lane l) holds element l * steps + s of the share; the position word
+        //      IS the element's (local_row << 13 | local_col); padding aims a zero at the wavefront's own spare accumulator -------
+        parallel_for(NU, [&](size_t u) {
+            const UnitPlan& up = plans[u];
+            const Block& blk = out.blocks[block_of_unit[u]];
+            const uint64_t* e = scratch.data() + up.scratch;
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+                const uint32_t steps = up.run_len[w], n = up.own_begin[w + 1] - up.own_begin[w];
+                const uint64_t* mine = e + up.own_begin[w];
+                uint8_t* base = image + blk.wave_offset[w] + uint64_t(up.start_step[w]) * kChunkBytes;
+                for (uint32_t st = 0; st < steps; ++st) {
+                    uint32_t* chunk = reinterpret_cast<uint32_t*>(base + uint64_t(st) * kChunkBytes);
+                    for (uint32_t l = 0; l < kWaveLanes; ++l) {
+                        const uint64_t i = uint64_t(l) * steps + st;
+                        chunk[2 * l] = i < n ? uint32_t(mine[i]) : 0u;
+                        chunk[2 * l + 1] = i < n ? uint32_t(mine[i] >> 32) : (blk.nrows + w) << kOwnerColBits;
+                    }
+                }
+            }
+        });
+        finish_blocks();
+        timer.lap("emit OWNER");
+        return true;
+    }
     if (!delta) {
         // ---- PAIRS: normal units: slot (chunk c, lane l) holds sorted element l * chunks + c (neighbouring lanes far
         //      apart in the unit); dense-row units: element i sits in chunk i / 64, lane i % 64 ------------------------------

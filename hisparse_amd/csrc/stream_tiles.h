@@ -78,6 +78,7 @@ constexpr uint32_t kMinXBuffers = 2;
 constexpr uint32_t kAccumulatorBytes = 8;
 constexpr uint32_t max_block_rows(bool sliced) { return (sliced ? 96u : 32u) * 1024u / kAccumulatorBytes - 1u; }
 constexpr uint32_t kMaxColSlices = 8;
+constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 // PAIRS format
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
 constexpr uint32_t kWaveStrideBytes = kChunkBytes * kConsumerWaves;   // chunks of the 14 wavefronts are interleaved in memory
@@ -89,7 +90,26 @@ constexpr uint32_t kBridgeAdvance = 0xffffu;                  // ... which advan
 constexpr double kDeltaMinMeanGap = 2048.0;                   // denser matrices: PAIRS wins (measured: mouse_gene 43.6 vs 48.0 us, transformer-50 18.6 vs 24.4)
 constexpr double kDeltaMaxMeanGap = 20000.0;                  // sparser matrices: > 4 % of the gaps need bridges, PAIRS wins
 constexpr double kDenseMeanGap = 2048.0;                      // DELTA blocks denser than this sum per lane in registers (kBlockDenseRows)
-enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1, kFormatBitmap = 2 };
+enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1, kFormatBitmap = 2, kFormatOwner = 3 };
+// OWNER format (float modes, hyper-sparse matrices: ogbn-products, 2.4 M columns, 50 non-zeros per row): the cost there is not the
+// element stream but x -- every row block pulls the WHOLE vector through its CU, sub-tile by sub-tile, so the staged x volume is
+// (rows / rows per block) x 4 cols bytes (3.1 GB per SpMV with 8191-row blocks against 1 GB of matrix).  Rows per block are
+// bounded by the LDS accumulators, and LDS float atomics force those to be doubles (ds_add_f32 runs at 0.33 lanes/clk,
+// tools/lds_accum_bench.hip).  OWNER gets 4-byte accumulators WITHOUT atomics: every consumer wavefront owns a contiguous share
+// of the block's rows (equal non-zero count), a unit's elements are split by owner, sorted by (row, column) and dealt to the
+// lanes in consecutive runs, so that
+//   * no other wavefront ever touches the wavefront's accumulators (LDS executes one wavefront's instructions in order:
+//     ds_read / v_add_f32 / ds_write needs no atomic),
+//   * the lanes of one instruction hold non-decreasing rows, a lane sums its run in a register while the row stays the same,
+//     and two lanes can only meet on a row at the end of a unit, where one segmented wavefront reduction sorts it out.
+// Element = { u32 value word, u32 (local_row << 13 | local_col) }, 512 bytes per wavefront step, every wavefront's steps
+// contiguous; padding slots aim value 0 at the wavefront's own spare accumulator ys[nrows + wave].
+// Measured (tools/lds_accum_bench.hip): gather + read-modify-write 3.6 lanes/clk/CU against 2.3 for gather + ds_add_f64, and
+// twice the rows per block.
+constexpr uint32_t kOwnerAccumulatorBytes = 4;
+constexpr uint32_t kOwnerColBits = 13;                        // local_col < kSubTileCols = 2^13; local_row in the 19 bits above
+constexpr uint32_t owner_max_block_rows(uint32_t ring) { return (kMaxLdsBytes - ring * kSubTileCols * 4u) / kOwnerAccumulatorBytes - kConsumerWaves - 1u; }
+constexpr double kOwnerMinMeanGap = 20000.0;                  // == kDeltaMaxMeanGap: sparser than anything DELTA takes
 // BITMAP format (dense-row matrices, e.g. the pruned-NN layers of sw/bm.sh:21-27: 512 rows x 33 K columns, half of them set):
 // a row is cut into GROUPS of 64 consecutive columns; per (row, group) the image holds one 64-bit occupancy mask and the
 // values of the set columns, compacted, in column order.  4 bytes + 1 bit per column position instead of 8 bytes per non-zero
@@ -103,7 +123,6 @@ constexpr uint32_t kBitmapGroupCols = 64;                     // one wavefront s
 constexpr uint32_t kBitmapWaves = 16;                         // all 16 wavefronts of the workgroup stream (no loader wavefronts)
 constexpr uint32_t kBitmapMaxBlockRows = 8191;                // 64 KiB of 8-byte row accumulators
 constexpr uint32_t kBitmapMaskBatch = 32;                     // masks fetched per vector load (one dword per lane)
-constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit
 constexpr uint32_t kBlockLastOfPartition = 2u;                // Block::flags bit: the workgroup's last block of this row partition
@@ -112,7 +131,7 @@ constexpr uint32_t kNoBlock = 0xffffffffu;
 // Mirrored in the kernel source (read through scalar loads).
 struct Block {
     uint32_t row0;          // first row (absolute, padded numbering)
-    uint32_t nrows;         // <= max_block_rows(); local row nrows is the spare accumulator padding elements hit
+    uint32_t nrows;         // <= max_block_rows(); local row nrows is the spare accumulator padding elements hit (OWNER: nrows + wave)
     uint32_t row_part;      // row partition (hs_run_partition filter)
     uint32_t unit_begin;    // units [unit_begin, unit_end), consumed in this order
     uint32_t unit_end;

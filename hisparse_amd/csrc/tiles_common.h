@@ -220,6 +220,24 @@ inline void build_row_ranges(const Layout& L, const std::vector<uint32_t>& row_n
     }
 }
 
+// At most `want` ranges if the row cap allows it: the greedy cut above can leave one small extra range per row partition,
+// and one range too many means one workgroup with two blocks -- twice the kernel time.  The target is raised in small steps
+// until the count fits (or the cap on rows per range makes that impossible).
+inline void build_row_ranges_at_most(const Layout& L, const std::vector<uint32_t>& row_nnz, uint64_t nnz, uint64_t want, uint32_t max_rows,
+                                     std::vector<RowRange>& ranges, std::vector<uint64_t>& range_nnz) {
+    uint64_t target = std::max<uint64_t>(1, (nnz + want - 1) / want);
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        ranges.clear();
+        range_nnz.clear();
+        build_row_ranges(L, row_nnz, target, max_rows, ranges, range_nnz);
+        if (ranges.size() <= want) return;
+        uint64_t by_cap = 0;                      // ranges the row cap alone forces
+        for (uint32_t rp = 0; rp < L.row_parts; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + max_rows - 1) / max_rows;
+        if (by_cap > want) return;
+        target += std::max<uint64_t>(1, target / 128);
+    }
+}
+
 }  // namespace detail
 
 // bitmap_tiles.cpp: the BITMAP builder (called by build_stream_tiles once the format is chosen; `row_nnz` from its pass 0)

@@ -333,3 +333,29 @@ def test_bitmap_choice_unsorted_rows_and_duplicates(monkeypatch):
     assert t["format"] != "bitmap"
     y = tile_emulator.run(t, 0, xw, cp.num_rows)
     assert orc.unpack_result(0, y)[0] == 7.0 and np.array_equal(y, oracle_y(cp, 0, xw))
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("rows,cols,nnz,wgs,slices", [(60000, 90000, 200000, 16, None), (30000, 200000, 150000, 8, 4), (9000, 70000, 20000, 3, 2)])
+def test_owner_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypatch):
+    """Hyper-sparse float matrices pick the OWNER format: float accumulators, wavefront-private rows (checked inside the emulator:
+    sorted lane-major runs, one owner per row, padding at the wavefront's spare accumulator); y matches the oracle."""
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    if slices:
+        monkeypatch.setenv("HISPARSE_COL_SLICES", str(slices))
+    csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=nnz, b=0.5, c=2.0, seed=12)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    assert cp.num_rows * cp.num_cols / cp.nnz > 20000
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 12, impl))
+    t = build(cp, impl, wgs)
+    assert t["format"] == "owner" and t["nnz"] == cp.nnz and t["elements"] >= cp.nnz
+    assert len(t["image"]) == t["elements"] * 8
+    assert t["ring_buffers"] in (2, 3, 4) and (not slices or t["col_slices"] == slices)
+    assert (t["max_block_rows"] + 14) * 4 + t["ring_buffers"] * 32768 <= 160 * 1024
+    got = tile_emulator.run(t, impl, xw, cp.num_rows)
+    assert cases.float_close(got, oracle_y(cp, impl, xw))
+    # fixed point never takes it (saturating 64-bit sums need the atomics), even when asked to
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "owner")
+    csr0 = host.CSRMatrix.generate("powerlaw", 9000, 70000, a=20000, b=0.5, c=1.0, seed=12)
+    cp0 = host.format_matrix(csr0, 0, skip_empty_rows=True)
+    assert build(cp0, 0, 4)["format"] == "pairs"

@@ -83,6 +83,36 @@ def _block_delta(image, blk, units, x_words, ys, is_float):
             step[w] = end
 
 
+def _block_owner(image, blk, units, x_words, ys, is_float):
+    """OWNER (float only): per-wavefront contiguous 512-byte chunks of {value, row << 13 | col}; lane l holds a consecutive run of
+    the wavefront's share, rows never decrease from lane to lane and step to step, no row is shared between wavefronts, padding
+    aims a zero at the wavefront's own spare accumulator nrows + w."""
+    assert is_float
+    nrows = int(blk["nrows"])
+    step = [0] * CONSUMERS
+    owner_of = {}
+    for u in range(int(blk["unit_begin"]), int(blk["unit_end"])):
+        unit = units[u]
+        col0, ncols = int(unit["col0"]), int(unit["ncols"])
+        xt = x_words[col0: col0 + ncols]
+        for w in range(CONSUMERS):
+            end = int(unit["end_step"][w])
+            base = int(blk["wave_offset"][w])
+            if end == step[w]:
+                continue
+            data = image[base + step[w] * CHUNK_BYTES: base + end * CHUNK_BYTES].view(np.uint32).reshape(end - step[w], WAVE, 2)
+            val, where = data[:, :, 0], data[:, :, 1]
+            row, col = (where >> 13).astype(np.int64), (where & 8191).astype(np.int64)
+            order = row.T.reshape(-1)                                   # lane-major: lane 0's run, then lane 1's, ...
+            assert (np.diff(order) >= 0).all()                          # sorted by row across (lane, step)
+            pad = row == nrows + w
+            assert ((row < nrows) | pad).all() and (val[pad] == 0).all() and (col[~pad] < ncols).all()
+            for r in np.unique(row[~pad]):
+                assert owner_of.setdefault(int(r), w) == w              # one owner per row for the whole block
+            _accumulate(ys, True, row[~pad], val[~pad], xt[col[~pad]])
+            step[w] = end
+
+
 WAVESEG_DTYPE = np.dtype([("row_begin", "<u4"), ("row_end", "<u4"), ("g_begin", "<u4"), ("g_end", "<u4"), ("value", "<u8"), ("mask", "<u8"),
                           ("pad", "<u4", (8,))])
 BITMAP_WAVES, GROUP = 16, 64
@@ -125,6 +155,7 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
     image, blocks, units = tiles["image"], tiles["blocks"], tiles["units"]
     delta = tiles["format"] == "delta"
     bitmap = tiles["format"] == "bitmap"
+    owner = tiles["format"] == "owner"
     y = np.zeros(num_rows, dtype=np.uint32) if y_init is None else y_init.copy()
     slices = int(tiles.get("col_slices", 1))
     out = y if slices == 1 else np.zeros(slices * num_rows, dtype=np.uint32)   # per-slice partial results
@@ -142,11 +173,14 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
             if row_part_filter >= 0 and int(blk["row_part"]) != row_part_filter:
                 continue
             nrows, row0, out0 = int(blk["nrows"]), int(blk["row0"]), int(blk["out_offset"])
-            assert nrows <= (8191 if bitmap else (32 if slices == 1 else 96) * 1024 // 8 - 1)   # LDS plan of the kernels: 8-byte accumulators
+            if owner:
+                assert (nrows + CONSUMERS) * 4 + tiles["ring_buffers"] * 32768 <= 160 * 1024     # float accumulators + the x ring
+            else:
+                assert nrows <= (8191 if bitmap else (32 if slices == 1 else 96) * 1024 // 8 - 1)   # LDS plan of the kernels: 8-byte accumulators
             assert out0 % num_rows == row0 and out0 // num_rows < slices
             touched[row0: row0 + nrows] = True
             ys = np.zeros(nrows + 1, dtype=np.float64 if is_float else np.uint64)     # double sums of float products
-            (_block_bitmap if bitmap else _block_delta if delta else _block_pairs)(image, blk, units, x_words, ys, is_float)
+            (_block_owner if owner else _block_bitmap if bitmap else _block_delta if delta else _block_pairs)(image, blk, units, x_words, ys, is_float)
             if is_float:
                 out[out0: out0 + nrows] = ys[:nrows].astype(np.float32).view(np.uint32)
             else:

@@ -6,8 +6,8 @@ import sqlite3
 import sys
 
 out = sys.argv[1]
-KERNEL = "spmv_rowblock_kernel"
-summary = {"kernel": KERNEL}
+KERNELS = ("spmv_rowblock_kernel", "spmv_bitmap_kernel")     # the dominant kernel is whichever of the two the matrix's format runs
+summary = {}
 
 
 def db(sub):
@@ -20,9 +20,11 @@ if d:
     print("== rocprofv3 --kernel-trace --stats (top_kernels; durations in us) ==")
     for name, calls, total, avg, pct in d.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
         print(f"{name[:100]:100s} calls {calls:5d} total_us {total:12.3f} avg_us {avg:10.3f} pct {pct:6.2f}")
-        if KERNEL in name:
+        if any(k in name for k in KERNELS):
+            summary["kernel"] = name.split("<")[0].split("::")[-1]
             summary["kernel_avg_us"] = avg
             summary["kernel_calls"] = calls
+    KERNEL = summary.get("kernel", KERNELS[0])
     row = d.execute(f"select vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels where name like '%{KERNEL}%' limit 1").fetchone()
     if row:
         summary["launch"] = dict(zip(["vgpr", "agpr", "sgpr", "lds_bytes", "scratch", "grid_x", "workgroup_x"], row))
@@ -31,6 +33,7 @@ for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     d = db(sub)
     if not d:
         continue
+    KERNEL = summary.get("kernel", KERNELS[0])
     vals = sorted(v for (v,) in d.execute(f"select value from counters_collection where counter_name = '{counter}' and kernel_name like '%{KERNEL}%'"))
     if vals:
         summary[counter + "_KiB_median"] = vals[len(vals) // 2]
