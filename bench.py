@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py — SpMV throughput of the MI355X hot path on the reference's headline workload.
+"""bench.py — SpMV throughput of the MI355X hot path on the reference's benchmark matrices.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config ogbl_ppa] [--npz FILE]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--npz FILE]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one full SpMV (every row partition) y = A x through the drop-in C-ABI, with the matrix
-(re-tiled at load time), x and y already resident in HBM.  Metric (BASELINE.json): the reference's
-"data throughput" of sw/benchmark.cpp:312-346 — 8 bytes per non-zero per SpMV — in decimal GB/s, plus
-GOPS (2 flops per non-zero) and the GiB-based number the reference prints, and the fraction of the
-8 TB/s HBM roofline.
+A "step" is one full SpMV (every row partition) y = A x through the drop-in C-ABI, with the matrix (re-tiled at load
+time), x and y already resident in HBM.  Metric (BASELINE.json): the reference's "data throughput" of
+sw/benchmark.cpp:312-346 — 8 bytes per non-zero per SpMV — in decimal GB/s, plus GOPS (2 flops per non-zero), the GiB-based
+number the reference prints, and the fraction of the 8 TB/s HBM roofline.
 
-N = 1 workload = BASELINE.json configs[1]: ogbl-ppa (seeded stand-in, see hisparse_amd/datasets.py),
-fixed-point IMPL, default banks.  N > 1: every rank owns one row slab; `--scaling weak` (default) gives
-every rank a slab the size of the whole N = 1 matrix (the global matrix is N slabs tall), `--scaling
-strong` splits the one matrix by non-zero count.  The ranks' y slabs are all-gathered over RCCL each
-step (the only exchange of the path; `--no-gather` leaves y sharded like the reference leaves it in HBM).
+N = 1 (default): the headline line is BASELINE.json configs[1] — ogbl-ppa (seeded stand-in, hisparse_amd/datasets.py),
+fixed-point IMPL, default banks — and it is the LAST line printed.  In front of it the same process measures the other
+single-GPU configurations (transformer-50 / float_pob, ogbn-products / float_stall, mouse_gene / fixed: each with its
+parity check against the oracle) and embeds them as `per_config`, and re-measures the headline matrix ROUND-ROBIN over
+four different ogbl-ppa-sized matrices (1.1 GB of images, more than the 256 MiB Infinity Cache holds) as
+`roofline.frac_mall_cold`.  `--config NAME` measures only that configuration; `--quick` skips the extras.
+
+N > 1 (BASELINE.json configs[4]): mouse_gene, ONE matrix split into N row slabs by non-zero count (`--scaling strong`;
+hisparse_amd/sharding.py), every rank formats and loads its slab and holds all of x.  Timed: K x { slab SpMV, all-gather of
+the y slabs over RCCL } (the gather of step k overlaps the SpMV of step k+1, double-buffered) = `value`; the same K SpMVs
+without any gather are timed too and reported as `compute_only`.  `--scaling weak` gives every rank a slab the size of the
+whole N = 1 matrix instead; `--gather final|off` changes the exchange.
 """
 import argparse
 import json
@@ -26,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+IMPL_NAMES = ["fixed", "float_pob", "float_stall"]
+SPIN_UP_STEPS = 300    # untimed: the clocks have dropped during the CPU legs (oracle, formatting)
 
 
 def log(rank, *a):
@@ -41,15 +49,194 @@ def ensure_built():
         __graft_entry__.build()
 
 
-def read_traffic(kernel_launch_bytes):
-    """HBM bytes per launch from a committed rocprofv3 --pmc summary (profiles/hbm_traffic.json), if present."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def read_traffic(config, stream_bytes):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json:
+    FETCH_SIZE x 2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes).  None when there is no entry for this
+    configuration or when the entry was taken with a different stream image (the kernel or the tiler changed since)."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             t = json.load(f)
-        return t.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
+    e = t.get(config) if isinstance(t.get(config), dict) else (t if config == "ogbl_ppa" and "hbm_bytes_per_launch" in t else None)
+    if not e:
+        return None
+    ref = e.get("stream_bytes")
+    if ref and abs(ref - stream_bytes) > 0.02 * stream_bytes:
+        return None
+    return e.get("hbm_bytes_per_launch")
+
+
+def oracle_check(np, host, impl, packets, xw, y_gpu, seconds):
+    """(parity string, seconds per oracle SpMV, repetitions) — oracle/cpu_ref.c, one thread, the same channel buffers."""
+    from oracle import oracle as orc
+    chans = [packets.channel_ptr(c)[0] for c in range(16)]
+    args = (impl, chans, xw, packets.num_rows, packets.num_cols, packets.num_row_partitions, packets.num_col_partitions, packets.ob_bank, packets.vb_bank)
+    t0 = time.perf_counter()
+    y_cpu = orc.spmv(*args)
+    t_one = time.perf_counter() - t0
+    reps = max(1, min(20, int(seconds / max(t_one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps - 1):
+        orc.spmv(*args)
+    t_cpu = (time.perf_counter() - t0 + t_one) / reps
+    if impl == host.IMPL_FIXED:
+        parity = "bit-exact" if np.array_equal(y_gpu, y_cpu) else "MISMATCH"
+    else:
+        a, b = y_gpu.view(np.float32).astype(np.float64), y_cpu.view(np.float32).astype(np.float64)
+        ok = bool((np.abs(a - b) <= 1e-4 * np.maximum(1.0, np.abs(b))).all())     # SURVEY.md 8d: 1e-4 * max(1, |y_csim|)
+        parity = f"within 1e-4*max(1,|y|) (max abs err {np.abs(a - b).max():.2e}, max |y| {np.abs(b).max():.1f})" if ok else "MISMATCH"
+    return parity, y_cpu, t_cpu, reps
+
+
+def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0, npz=None, impl_override=None, cpu_seconds=0.0, rank=0):
+    """One configuration on one GPU: load, parity against the oracle, K timed steps, HIP-event kernel time."""
+    t0 = time.perf_counter()
+    cfg, csr = datasets.load(name, path=npz)
+    impl = host.impl_id(impl_override or cfg.impl)
+    true_rows = csr.num_rows
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    packets = host.format_matrix(csr, impl, skip_empty_rows=cfg.skip_empty_rows)
+    t_fmt = time.perf_counter() - t0
+    nnz = packets.nnz
+    rng = np.random.default_rng(2024)
+    # x: uniform [0, 2) for fixed point (the reference uses rand() % 2; random values keep the clocks honest), N(0,1) for float
+    x = rng.uniform(0.0, 2.0, packets.num_cols).astype(np.float32) if impl == host.IMPL_FIXED else rng.normal(size=packets.num_cols).astype(np.float32)
+    xw = host.pack_vector(impl, x)
+    eng = device.SpmvEngine(impl, device_id=device_id)
+    eng.load_matrix(packets)
+    eng.load_vector(xw)
+    stats = eng.stats()
+    log(rank, f"{name}: {packets.num_rows}x{packets.num_cols}, nnz {nnz}, partitions {packets.num_row_partitions}x{packets.num_col_partitions}, "
+              f"generate {t_gen:.2f}s format {t_fmt:.2f}s device-load {stats['load_seconds']:.2f}s, CPSR {stats['cpsr_bytes']/1e6:.0f} MB -> "
+              f"{device.STREAM_FORMATS[stats['stream_format']]} stream {stats['stream_bytes']/1e6:.0f} MB")
+    eng.run()
+    y_gpu = eng.read_result()
+    parity, y_cpu, t_cpu, reps = oracle_check(np, host, impl, packets, xw, y_gpu, cpu_seconds)
+    log(rank, f"{name}: oracle {t_cpu*1e3:.1f} ms per SpMV on 1 core; GPU result {parity}")
+    if parity == "MISMATCH":
+        print(json.dumps({"error": "GPU result does not match the oracle", "config": name}))
+        sys.exit(1)
+    for _ in range(SPIN_UP_STEPS):
+        eng.run()
+    eng.sync()
+    for _ in range(warmup):
+        eng.run()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.run()
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    _, ev_kernel_ms = eng.time_runs(0, steps)
+    kernel_ms = ev_kernel_ms / steps
+    ms = elapsed / steps * 1e3
+    value = 8.0 * nnz / (elapsed / steps) / 1e9
+    achieved = 8.0 * nnz / (kernel_ms * 1e-3) / 1e9
+    res = {
+        "workload": f"{name}, {IMPL_NAMES[impl]} IMPL, v={packets.vb_bank} o={packets.ob_bank}",
+        "rows": true_rows, "cols": packets.num_cols, "nnz": int(nnz), "partitions": f"{packets.num_row_partitions}x{packets.num_col_partitions}",
+        "stream_format": device.STREAM_FORMATS[stats["stream_format"]], "col_slices": stats["col_slices"],
+        "ms_per_step": round(ms, 5), "value": round(value, 2), "unit": "GB/s", "gops": round(2.0 * nnz / (elapsed / steps) / 1e9, 2),
+        "gibps_reference_formula": round(8.0 * nnz / 2 ** 30 / (elapsed / steps), 2),
+        "hbm_roofline_fraction_whole_job": round(value / HBM_PEAK_GBS, 4),
+        "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_rowblock_kernel",
+                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_launch": int(8 * nnz),
+                     "streamed_bytes_per_launch": int(stats["stream_bytes"]), "traffic": read_traffic(name, stats["stream_bytes"])},
+        "parity_vs_oracle": parity,
+        "preprocess_s": {"format_csr2cpsr": round(t_fmt, 3), "device_load_retile": round(stats["load_seconds"], 3)},
+    }
+    return res, dict(eng=eng, packets=packets, csr=csr, x=x, xw=xw, impl=impl, nnz=nnz, y_cpu=y_cpu, t_cpu=t_cpu, reps=reps, cfg=cfg)
+
+
+def cpu_baseline_for(np, host, ctx, rank):
+    """The reported CPU baseline: the oracle (csim-equivalent restatement) on one core + two context numbers."""
+    from oracle import oracle as orc
+    packets, impl, nnz, xw, x, csr, y_cpu = ctx["packets"], ctx["impl"], ctx["nnz"], ctx["xw"], ctx["x"], ctx["csr"], ctx["y_cpu"]
+    t_cpu, reps = ctx["t_cpu"], ctx["reps"]
+    chans = [packets.channel_ptr(c)[0] for c in range(16)]
+    base = {"value": round(8.0 * nnz / t_cpu / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} full SpMV(s) of the same matrix through oracle/cpu_ref.c (csim-equivalent restatement, 1 thread), {t_cpu*1e3:.1f} ms each",
+            "gops": round(2.0 * nnz / t_cpu / 1e9, 4), "host_cpus": orc.usable_cores()}
+    try:   # context only: the same restatement with one host thread per cluster (the 16 clusters are independent)
+        threads = min(16, orc.usable_cores())
+        t0 = time.perf_counter()
+        y_par = orc.spmv_per_channel_threads(impl, chans, xw, packets.num_rows, packets.num_cols, packets.num_row_partitions,
+                                             packets.num_col_partitions, packets.ob_bank, packets.vb_bank, threads=threads)
+        t_par = time.perf_counter() - t0
+        if np.array_equal(y_par, y_cpu):
+            base["cpsr_one_thread_per_cluster"] = {"value": round(8.0 * nnz / t_par / 1e9, 3), "unit": "GB/s", "cores": threads,
+                                                   "gops": round(2.0 * nnz / t_par / 1e9, 3), "sample": f"1 SpMV, {t_par*1e3:.1f} ms"}
+    except Exception as e:
+        log(rank, f"per-cluster-thread baseline skipped: {e}")
+    try:   # context only: plain float32 CSR loop (compute_ref, csim.cpp:143-158) with OpenMP over the host cores
+        ip, ix, dv = csr.arrays()
+        xf = np.ascontiguousarray(x, dtype=np.float32)
+        yref = np.zeros(packets.num_rows, dtype=np.float32)
+        best = None
+        for threads in sorted({min(16, orc.usable_cores()), min(64, orc.usable_cores()), orc.usable_cores()}):   # cgroup quotas make "all" a bad guess
+            orc.compute_ref_parallel(packets.num_rows, ip, ix, dv, xf, out=yref, threads=threads)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                orc.compute_ref_parallel(packets.num_rows, ip, ix, dv, xf, out=yref, threads=threads)
+            t_omp = (time.perf_counter() - t0) / 5
+            if best is None or t_omp < best[0]:
+                best = (t_omp, threads)
+        t_omp, threads = best
+        base["csr_openmp_best_thread_count"] = {"value": round(8.0 * nnz / t_omp / 1e9, 3), "unit": "GB/s", "cores": threads,
+                                                "gops": round(2.0 * nnz / t_omp / 1e9, 3),
+                                                "sample": f"5 float32 CSR SpMVs, {t_omp*1e3:.2f} ms each (best of 16 / 64 / all host threads)"}
+    except Exception as e:  # the context number must never break the bench line
+        log(rank, f"csr_openmp baseline skipped: {e}")
+    return base
+
+
+def mall_cold(np, datasets, device, host, first, steps, warmup, rank):
+    """The headline matrix again, ROUND-ROBIN over four different matrices of the same shape (other seeds): 1.1 GB of stream
+    images, more than the 256 MiB Infinity Cache can hold between two uses of the same image.  All contexts launch on one
+    stream; the result is a whole-job number (kernel + combine pass, launch gaps included)."""
+    cfg = first["cfg"]
+    engines, nnzs = [first["eng"]], [first["nnz"]]
+    stream = first["eng"].get_stream()
+    for k in range(1, 4):
+        csr = host.CSRMatrix.generate(cfg.kind, cfg.rows, cfg.cols, a=cfg.a, b=cfg.b, c=cfg.c, seed=cfg.seed + 1000 * k)
+        packets = host.format_matrix(csr, first["impl"], skip_empty_rows=cfg.skip_empty_rows)
+        eng = device.SpmvEngine(first["impl"])
+        eng.load_matrix(packets)
+        eng.load_vector(first["xw"])
+        eng.set_stream(stream)
+        engines.append(eng)
+        nnzs.append(packets.nnz)
+        del csr, packets
+    image_mb = sum(e.stats()["stream_bytes"] for e in engines) / 1e6
+
+    def timed(order):
+        for _ in range(SPIN_UP_STEPS // 3):
+            for e in order:
+                e.run()
+        first["eng"].sync()
+        for i in range(warmup):
+            order[i % len(order)].run()
+        first["eng"].sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            order[i % len(order)].run()
+        first["eng"].sync()
+        return (time.perf_counter() - t0) / steps
+
+    t_rr = timed(engines)                 # four images in turn
+    t_one = timed(engines[:1])            # the same loop over one image (warm Infinity Cache), for comparison on equal terms
+    mean_nnz = sum(nnzs[i % 4] for i in range(steps)) / steps
+    for e in engines[1:]:
+        e.set_stream(None)
+        e.close()
+    log(rank, f"round-robin over 4 images ({image_mb:.0f} MB): {t_rr*1e6:.1f} us per SpMV; one image: {t_one*1e6:.1f} us")
+    return {"images": 4, "image_megabytes_total": round(image_mb, 1), "ms_per_step_round_robin": round(t_rr * 1e3, 5),
+            "ms_per_step_one_image_same_loop": round(t_one * 1e3, 5),
+            "frac_whole_job_round_robin": round(8.0 * mean_nnz / t_rr / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_whole_job_one_image": round(8.0 * first["nnz"] / t_one / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def main():
@@ -57,12 +244,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", default="ogbl_ppa")
+    ap.add_argument("--config", default=None, help="N = 1: measure only this configuration; N > 1: the matrix to shard (default mouse_gene)")
     ap.add_argument("--npz", default=None, help="real dataset file instead of the seeded stand-in")
     ap.add_argument("--impl", default=None, help="override the config's numeric mode")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--gather", choices=["final", "step", "off"], default="final",
-                    help="N > 1: all-gather the y slabs once after the timed SpMVs (default), after every SpMV (overlapped), or never")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong", help="N > 1: split ONE matrix (default) or one matrix-sized slab per rank")
+    ap.add_argument("--gather", choices=["step", "final", "off"], default="step",
+                    help="N > 1: all-gather the y slabs after every SpMV (default, overlapped), once after the timed SpMVs, or never")
+    ap.add_argument("--quick", action="store_true", help="N = 1: headline only (no per-config runs, no round-robin leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for one GPU")
@@ -74,43 +262,88 @@ def main():
     dist_mode = world > 1 or args.force_dist
     if args.gpus != world and world > 1:
         log(rank, f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
-    n_gpus = world
-
     if rank == 0:
         ensure_built()
-    torch = dist = None
     if dist_mode:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-        dist.barrier()
+        return main_distributed(args, rank, local_rank, world)
 
     import numpy as np
+    from hisparse_amd import datasets, device, host
+
+    headline = args.config or "ogbl_ppa"
+    per_config = []
+    if not args.config and not args.quick:
+        sub_steps = max(20, min(args.steps, 200))
+        for name in ("transformer_50", "ogbn_products", "mouse_gene"):
+            res, ctx = measure_single(np, datasets, device, host, name, sub_steps, min(args.warmup, 20), cpu_seconds=0.0, rank=rank)
+            ctx["eng"].close()
+            del ctx
+            per_config.append(res)
+            log(rank, f"{name}: {res['ms_per_step']*1e3:.1f} us per SpMV, kernel {res['roofline']['kernel_ms']*1e3:.1f} us = {res['roofline']['frac']*100:.1f} % of the HBM roofline")
+    res, ctx = measure_single(np, datasets, device, host, headline, args.steps, args.warmup, npz=args.npz, impl_override=args.impl,
+                              cpu_seconds=0.0 if args.no_cpu_baseline else args.cpu_seconds, rank=rank)
+    cpu_baseline = None if args.no_cpu_baseline else cpu_baseline_for(np, host, ctx, rank)
+    if headline == "ogbl_ppa" and not args.quick and not args.npz:
+        cold = mall_cold(np, datasets, device, host, ctx, args.steps, args.warmup, rank)
+        res["roofline"]["frac_mall_cold"] = cold["frac_whole_job_round_robin"]
+        res["roofline"]["mall_cold"] = cold
+    ctx["eng"].close()
+    impl = ctx["impl"]
+    out = {
+        "metric": "SpMV GBPS (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346; GOPS and % of the HBM roofline alongside)",
+        "value": res["value"], "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "spin_up_steps": SPIN_UP_STEPS,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 Q8.24 fixed point (u64 accumulate)" if impl == host.IMPL_FIXED else "f32",
+        "data": "synthetic" if not args.npz else "file",
+        "config": {"workload": res["workload"], "rows": res["rows"], "cols": res["cols"], "nnz_per_gpu": res["nnz"], "nnz_total": res["nnz"],
+                   "partitions": res["partitions"], "stream_format": res["stream_format"], "parallelism": "row-slab x1"},
+        "gops": res["gops"], "gibps_reference_formula": res["gibps_reference_formula"],
+        "hbm_roofline_fraction_whole_job": res["hbm_roofline_fraction_whole_job"],
+        "roofline": res["roofline"], "cpu_baseline": cpu_baseline, "parity_vs_oracle": res["parity_vs_oracle"],
+        "preprocess_s": res["preprocess_s"],
+    }
+    if per_config:
+        out["per_config"] = per_config
+    print(json.dumps(out), flush=True)
+
+
+def main_distributed(args, rank, local_rank, world):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     from hisparse_amd import datasets, device, host, sharding
 
-    # ---- workload ------------------------------------------------------------------------------------
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    dist.barrier()
+    n_gpus = world
+    name = args.config or "mouse_gene"
+    dev = f"cuda:{local_rank}"
+
+    # ---- workload: this rank's row slab ---------------------------------------------------------------------------------
     t0 = time.perf_counter()
-    cfg = datasets.CONFIGS[args.config]
+    cfg = datasets.CONFIGS[name]
     impl = host.impl_id(args.impl or cfg.impl)
     granule = 128 * (8 if impl == host.IMPL_FLOAT_STALL else 1)
-    if n_gpus > 1 and args.scaling == "strong":
-        _, full = datasets.load(args.config, path=args.npz)
+    full_rows = None
+    if args.scaling == "strong":
+        _, full = datasets.load(name, path=args.npz)
         indptr, indices, data = full.arrays()
+        full_rows = full.num_rows
         bounds = sharding.split_rows_by_nnz(indptr, n_gpus, granule)
         lo, hi = bounds[rank], bounds[rank + 1]
+        if hi == lo:
+            print(json.dumps({"error": f"the matrix has fewer than {n_gpus} x {granule} rows: rank {rank} has no slab"}))
+            sys.exit(1)
         ip, ix, dv = sharding.slab_arrays(indptr, indices, data, lo, hi)
         csr = host.CSRMatrix.from_arrays(hi - lo, full.num_cols, ip, ix, dv)
         del full, indptr, indices, data
-    elif n_gpus > 1:
-        # weak: rank r owns slab r of a matrix that is n_gpus slabs tall; same generator, different seed per slab
+    else:   # weak: rank r owns slab r of a matrix that is n_gpus slabs tall; same generator, different seed per slab
         c = cfg
         csr = host.CSRMatrix.generate(c.kind, c.rows, c.cols, a=c.a, b=c.b, c=c.c, seed=c.seed + 1000 * rank) if not args.npz \
             else host.load_csr_matrix_from_float_npz(args.npz)
-    else:
-        _, csr = datasets.load(args.config, path=args.npz)
     true_rows = csr.num_rows
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -118,41 +351,30 @@ def main():
     t_fmt = time.perf_counter() - t0
     nnz = packets.nnz
     rng = np.random.default_rng(2024)
-    # x: uniform [0, 2) for fixed point (the reference uses rand() % 2; random values keep the clocks honest), N(0,1) for float
     x = rng.uniform(0.0, 2.0, packets.num_cols).astype(np.float32) if impl == host.IMPL_FIXED else rng.normal(size=packets.num_cols).astype(np.float32)
     xw = host.pack_vector(impl, x)
-
     eng = device.SpmvEngine(impl, device_id=local_rank)
     eng.load_matrix(packets)
     eng.load_vector(xw)
     stats = eng.stats()
-    log(rank, f"{args.config}: {packets.num_rows}x{packets.num_cols}, nnz {nnz}, partitions {packets.num_row_partitions}x{packets.num_col_partitions}, "
-              f"generate {t_gen:.2f}s format {t_fmt:.2f}s device-load {stats['load_seconds']:.2f}s, CPSR {stats['cpsr_bytes']/1e6:.0f} MB -> stream {stats['stream_bytes']/1e6:.0f} MB")
+    log(rank, f"{name} ({args.scaling}): slab {packets.num_rows}x{packets.num_cols}, nnz {nnz}, generate {t_gen:.2f}s format {t_fmt:.2f}s "
+              f"device-load {stats['load_seconds']:.2f}s, stream {stats['stream_bytes']/1e6:.0f} MB")
 
-    # ---- distributed plumbing: y slab inside an all-gather buffer -------------------------------------
-    # `final`: one all-gather of the y slabs after the K timed SpMVs (inside the timed region) -- the path itself has no
-    # exchange step: rows are independent and the reference leaves y in device memory.  `step`: gather after every SpMV
-    # (iterative-solver pattern, y_k feeds x_k+1), double-buffered so that the gather of step k overlaps the SpMV of k+1.
-    gather = args.gather if dist_mode else "off"
-    y_chunks = gathered = None
+    # ---- y slab inside an all-gather buffer; one explicit stream for the kernels and the point RCCL synchronises against -------
+    rows_all = [None] * world
+    dist.all_gather_object(rows_all, packets.num_rows)
+    chunk = max(rows_all)
+    y_chunks = [torch.zeros(chunk, dtype=torch.int32, device=dev) for _ in range(2)]
+    gathered = [torch.zeros(chunk * world, dtype=torch.int32, device=dev) for _ in range(2)]
+    main_stream = torch.cuda.Stream(device=dev)     # the legacy default stream has handle 0 = "the library's private stream"
+    torch.cuda.set_stream(main_stream)
+    torch.cuda.synchronize()
+    eng.set_stream(main_stream.cuda_stream)
+    eng.bind_device_result(y_chunks[0].data_ptr())
     pending = [None, None]
-    if dist_mode:
-        rows_all = [None] * world
-        dist.all_gather_object(rows_all, packets.num_rows)
-        chunk = max(rows_all)
-        dev = f"cuda:{local_rank}"
-        y_chunks = [torch.zeros(chunk, dtype=torch.int32, device=dev) for _ in range(2)]
-        gathered = [torch.zeros(chunk * world, dtype=torch.int32, device=dev) for _ in range(2)]
-        # one explicit (non-default) stream for both the SpMV kernels and the point RCCL synchronises against: the legacy
-        # default stream has handle 0, which hs_set_stream reads as "use the library's private stream"
-        main_stream = torch.cuda.Stream(device=dev)
-        torch.cuda.set_stream(main_stream)
-        torch.cuda.synchronize()
-        eng.set_stream(main_stream.cuda_stream)
-        eng.bind_device_result(y_chunks[0].data_ptr())
     step_no = [0]
 
-    def step():
+    def step(gather):
         if gather != "step":
             eng.run()
             return
@@ -165,159 +387,99 @@ def main():
         eng.run()
         pending[cur] = dist.all_gather_into_tensor(gathered[cur], y_chunks[cur], async_op=True)
 
-    def final_gather():
-        if gather == "final":
-            dist.all_gather_into_tensor(gathered[0], y_chunks[0])
-
     def sync():
-        if dist_mode:
-            for i in (0, 1):
-                if pending[i] is not None:
-                    pending[i].wait()
-                    pending[i] = None
-            torch.cuda.synchronize()
+        for i in (0, 1):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
+        torch.cuda.synchronize()
         eng.sync()
 
-    # ---- correctness of what is about to be timed (and the CPU baseline) --------------------------------
-    step()
-    final_gather()
-    sync()
-    y_gpu = eng.read_result() if not dist_mode else y_chunks[0][:packets.num_rows].cpu().numpy().view(np.uint32)
-    if gather != "off":   # the gathered buffer must hold this rank's slab at its offset (kernel -> RCCL ordering on the shared stream)
-        mine = gathered[0][rank * y_chunks[0].numel(): rank * y_chunks[0].numel() + packets.num_rows].cpu().numpy().view(np.uint32)
-        if not np.array_equal(mine, y_gpu):
-            print(json.dumps({"error": "all-gathered y differs from the local slab", "rank": rank}))
-            sys.exit(1)
-    cpu_baseline = None
-    parity = "unchecked"
-    if rank == 0 and not args.no_cpu_baseline:
-        from oracle import oracle as orc
-        chans = [packets.channel_ptr(c)[0] for c in range(16)]
-        t0 = time.perf_counter()
-        y_cpu = orc.spmv(impl, chans, xw, packets.num_rows, packets.num_cols, packets.num_row_partitions, packets.num_col_partitions,
-                         packets.ob_bank, packets.vb_bank)
-        t_one = time.perf_counter() - t0
-        reps = max(1, min(20, int(args.cpu_seconds / max(t_one, 1e-6))))
-        t0 = time.perf_counter()
-        for _ in range(reps - 1):
-            orc.spmv(impl, chans, xw, packets.num_rows, packets.num_cols, packets.num_row_partitions, packets.num_col_partitions,
-                     packets.ob_bank, packets.vb_bank)
-        t_cpu = (time.perf_counter() - t0 + t_one) / reps
-        if impl == host.IMPL_FIXED:
-            parity = "bit-exact" if np.array_equal(y_gpu, y_cpu) else "MISMATCH"
-        else:
-            parity = "within 1e-4" if np.allclose(y_gpu.view(np.float32), y_cpu.view(np.float32), rtol=1e-4, atol=1e-4) else "MISMATCH"
-        cpu_baseline = {"value": round(8.0 * nnz / t_cpu / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-                        "sample": f"{reps} full SpMV(s) of the same matrix through oracle/cpu_ref.c (csim-equivalent restatement, 1 thread), {t_cpu*1e3:.1f} ms each",
-                        "gops": round(2.0 * nnz / t_cpu / 1e9, 4), "host_cpus": orc.usable_cores()}
-        # context only: the same restatement with one host thread per cluster (the 16 clusters are independent)
-        try:
-            threads = min(16, orc.usable_cores())
-            t0 = time.perf_counter()
-            y_par = orc.spmv_per_channel_threads(impl, chans, xw, packets.num_rows, packets.num_cols, packets.num_row_partitions,
-                                                 packets.num_col_partitions, packets.ob_bank, packets.vb_bank, threads=threads)
-            t_par = time.perf_counter() - t0
-            if np.array_equal(y_par, y_cpu):
-                cpu_baseline["cpsr_one_thread_per_cluster"] = {"value": round(8.0 * nnz / t_par / 1e9, 3), "unit": "GB/s", "cores": threads,
-                                                               "gops": round(2.0 * nnz / t_par / 1e9, 3), "sample": f"1 SpMV, {t_par*1e3:.1f} ms"}
-        except Exception as e:
-            log(rank, f"per-cluster-thread baseline skipped: {e}")
-        # context only: plain float32 CSR loop (compute_ref, csim.cpp:143-158) with OpenMP over every host core
-        try:
-            ip, ix, dv = csr.arrays()
-            xf = np.ascontiguousarray(x, dtype=np.float32)
-            yref = np.zeros(packets.num_rows, dtype=np.float32)
-            best = None
-            for threads in sorted({min(16, orc.usable_cores()), min(64, orc.usable_cores()), orc.usable_cores()}):   # cgroup quotas make "all" a bad guess
-                orc.compute_ref_parallel(packets.num_rows, ip, ix, dv, xf, out=yref, threads=threads)
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    orc.compute_ref_parallel(packets.num_rows, ip, ix, dv, xf, out=yref, threads=threads)
-                t_omp = (time.perf_counter() - t0) / 5
-                if best is None or t_omp < best[0]:
-                    best = (t_omp, threads)
-            t_omp, threads = best
-            cpu_baseline["csr_openmp_best_thread_count"] = {"value": round(8.0 * nnz / t_omp / 1e9, 3), "unit": "GB/s", "cores": threads,
-                                                            "gops": round(2.0 * nnz / t_omp / 1e9, 3),
-                                                            "sample": f"5 float32 CSR SpMVs, {t_omp*1e3:.2f} ms each (best of 16 / 64 / all host threads)"}
-            del ip, ix, dv
-        except Exception as e:  # the context number must never break the bench line
-            log(rank, f"csr_openmp baseline skipped: {e}")
-        log(rank, f"oracle: {t_cpu*1e3:.1f} ms per SpMV on 1 core; GPU result {parity}")
-        if parity == "MISMATCH":
-            print(json.dumps({"error": "GPU result does not match the oracle", "config": args.config}))
-            sys.exit(1)
-
-    # ---- timing -----------------------------------------------------------------------------------------
-    # The GPU sat idle for seconds during the CPU baseline above and has dropped its clocks; the requested W warm-up steps
-    # (a few ms at most) are not enough to bring them back.  A fixed, untimed spin-up first (reported as spin_up_steps).
-    SPIN_UP_STEPS = 300
-    for _ in range(SPIN_UP_STEPS):
-        step()
-    sync()
-    for _ in range(args.warmup):
-        step()
-    sync()
-    if dist_mode:
+    def timed(gather, steps):
+        for _ in range(SPIN_UP_STEPS):
+            step(gather)
+        sync()
+        for _ in range(args.warmup):
+            step(gather)
+        sync()
         dist.barrier()
         torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    final_gather()
-    sync()
-    if dist_mode:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(gather)
+        if gather == "final":
+            dist.all_gather_into_tensor(gathered[0], y_chunks[0])
+        sync()
         torch.cuda.synchronize()
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist_mode:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(nnz)], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_nnz = float(tot.item())
-    else:
-        total_nnz = float(nnz)
+        return float(t.item())
 
-    # the kernel alone, HIP events on the launch stream, same K launches (rank 0's slab)
-    if dist_mode:
-        eng.set_stream(None)
-    ev_total_ms, ev_kernel_ms = eng.time_runs(0, args.steps)
+    # ---- correctness of what is about to be timed: this rank's slab against the oracle, and the gathered buffer ------------------
+    eng.bind_device_result(y_chunks[0].data_ptr())
+    eng.run()
+    dist.all_gather_into_tensor(gathered[0], y_chunks[0])
+    sync()
+    y_gpu = y_chunks[0][:packets.num_rows].cpu().numpy().view(np.uint32)
+    mine = gathered[0][rank * chunk: rank * chunk + packets.num_rows].cpu().numpy().view(np.uint32)
+    if not np.array_equal(mine, y_gpu):
+        print(json.dumps({"error": "all-gathered y differs from the local slab", "rank": rank}))
+        sys.exit(1)
+    parity, _, t_cpu, _ = oracle_check(np, host, impl, packets, xw, y_gpu, 0.0)
+    flag = torch.tensor([1.0 if parity == "MISMATCH" else 0.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if flag.item() > 0:
+        if rank == 0:
+            print(json.dumps({"error": "a rank's slab does not match the oracle", "config": name}))
+        sys.exit(1)
+
+    # ---- timing: the exchange pattern asked for = `value`; the same SpMVs without any exchange alongside -------------------------
+    elapsed = timed(args.gather, args.steps)
+    compute_elapsed = timed("off", args.steps) if args.gather != "off" else elapsed
+    tot = torch.tensor([float(nnz)], dtype=torch.float64, device=dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    total_nnz = float(tot.item())
+    eng.set_stream(None)
+    _, ev_kernel_ms = eng.time_runs(0, args.steps)
     kernel_ms = ev_kernel_ms / args.steps
-    if dist_mode:
-        dist.barrier()
+    dist.barrier()
 
     out = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = 8.0 * total_nnz / (elapsed / args.steps) / 1e9
+        per_step = elapsed / args.steps
+        value = 8.0 * total_nnz / per_step / 1e9
         achieved = 8.0 * nnz / (kernel_ms * 1e-3) / 1e9
+        gather_text = {"step": " + all_gather(y) over RCCL every step (overlapped with the next SpMV)", "final": " + one final all_gather(y) over RCCL", "off": ""}[args.gather]
         out = {
             "metric": "SpMV GBPS (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346; GOPS and % of the HBM roofline alongside)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "spin_up_steps": SPIN_UP_STEPS,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": args.scaling if n_gpus > 1 else "weak",
-            "vs_baseline": None, "dtype": "u32 Q8.24 fixed point (u64 accumulate)" if impl == host.IMPL_FIXED else "f32",
+            "ms_per_step": round(per_step * 1e3, 5), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "u32 Q8.24 fixed point (u64 accumulate)" if impl == host.IMPL_FIXED else "f32",
             "data": "synthetic" if not args.npz else "file",
-            "config": {"workload": f"{args.config}, {['fixed', 'float_pob', 'float_stall'][impl]} IMPL, v={packets.vb_bank} o={packets.ob_bank}",
-                       "rows": true_rows, "cols": packets.num_cols, "nnz_per_gpu": int(nnz), "nnz_total": int(total_nnz),
-                       "partitions": f"{packets.num_row_partitions}x{packets.num_col_partitions}",
-                       "parallelism": f"row-slab x{n_gpus}" + ({"final": " + one final all_gather(y) over RCCL", "step": " + all_gather(y) over RCCL every step (overlapped)", "off": ""}[gather] if n_gpus > 1 else "")},
-            "gops": round(2.0 * total_nnz / (elapsed / args.steps) / 1e9, 2),
-            "gibps_reference_formula": round(8.0 * total_nnz / 2 ** 30 / (elapsed / args.steps), 2),
+            "config": {"workload": f"{name}, {IMPL_NAMES[impl]} IMPL, v={packets.vb_bank} o={packets.ob_bank}", "rows": full_rows or true_rows * n_gpus,
+                       "cols": packets.num_cols, "nnz_per_gpu": int(nnz), "nnz_total": int(total_nnz), "slab_rows_rank0": true_rows,
+                       "parallelism": f"row-slab x{n_gpus}, balanced by non-zeros" + gather_text},
+            "gops": round(2.0 * total_nnz / per_step / 1e9, 2),
+            "gibps_reference_formula": round(8.0 * total_nnz / 2 ** 30 / per_step, 2),
             "hbm_roofline_fraction_whole_job": round(value / (HBM_PEAK_GBS * n_gpus), 4),
-            "roofline": {"bound": "hbm", "kernel": "spmv_rowblock_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "kernel_ms": round(kernel_ms, 5),
-                         "algorithmic_bytes_per_launch": int(8 * nnz), "streamed_bytes_per_launch": int(stats["stream_bytes"]),
-                         "traffic": read_traffic(8 * nnz)},
-            "cpu_baseline": cpu_baseline,
-            "parity_vs_oracle": parity,
+            "compute_only": {"ms_per_step": round(compute_elapsed / args.steps * 1e3, 5), "value": round(8.0 * total_nnz / (compute_elapsed / args.steps) / 1e9, 2),
+                             "unit": "GB/s", "hbm_roofline_fraction": round(8.0 * total_nnz / (compute_elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4),
+                             "note": "the same K slab SpMVs with y left sharded in HBM, like the reference leaves it (sw/benchmark.cpp:318-338)"},
+            "exchange": {"pattern": args.gather, "bytes_per_rank_per_gather": int(chunk) * 4,
+                         "ms_per_step_added": round((elapsed - compute_elapsed) / args.steps * 1e3, 5)},
+            "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_rowblock_kernel", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "kernel_ms": round(kernel_ms, 5),
+                         "algorithmic_bytes_per_launch": int(8 * nnz), "streamed_bytes_per_launch": int(stats["stream_bytes"]), "traffic": None,
+                         "note": "rank 0's slab"},
+            "cpu_baseline": None if args.no_cpu_baseline else {"value": round(8.0 * nnz / t_cpu / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                                                               "sample": f"rank 0's slab, 1 SpMV through oracle/cpu_ref.c (1 thread), {t_cpu*1e3:.1f} ms"},
+            "parity_vs_oracle": parity + " (every rank's slab)",
             "preprocess_s": {"format_csr2cpsr": round(t_fmt, 3), "device_load_retile": round(stats["load_seconds"], 3)},
         }
     eng.close()
-    if dist_mode:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
     if rank == 0:
         # RCCL writes its version banner to the C stdout buffer; flush it first so that the JSON line is the LAST line
         import ctypes

@@ -403,6 +403,12 @@ int hs_set_stream(hs_context* ctx, void* hip_stream) {
     return HS_OK;
 }
 
+int hs_get_stream(hs_context* ctx, void** hip_stream) {
+    if (!ctx || !hip_stream) return HS_ERR_BAD_ARG;
+    *hip_stream = ctx->stream;
+    return HS_OK;
+}
+
 int hs_device_vector(hs_context* ctx, void** x_dev) {
     if (!ctx || !x_dev) return HS_ERR_BAD_ARG;
     if (!ctx->d_x) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_vector has not been called");

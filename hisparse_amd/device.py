@@ -17,7 +17,7 @@ _lib = None
 
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
-    "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_device_vector", "hs_device_result",
+    "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
     "hs_bind_device_vector", "hs_bind_device_result", "hs_feedback", "hs_iterate", "hs_get_stats", "hs_time_runs", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
@@ -70,6 +70,7 @@ def lib():
         l.hs_sync.argtypes = [vp]
         l.hs_read_result.argtypes = [vp, vp, u32]
         l.hs_set_stream.argtypes = [vp, vp]
+        l.hs_get_stream.argtypes = [vp, C.POINTER(vp)]
         l.hs_device_vector.argtypes = [vp, C.POINTER(vp)]
         l.hs_device_result.argtypes = [vp, C.POINTER(vp)]
         l.hs_bind_device_vector.argtypes = [vp, vp]
@@ -171,6 +172,11 @@ class SpmvEngine:
     # ---- zero-copy hooks ----------------------------------------------------------------------
     def set_stream(self, hip_stream):
         self._check(lib().hs_set_stream(self._h, C.c_void_p(hip_stream or None)))
+
+    def get_stream(self):
+        p = C.c_void_p()
+        self._check(lib().hs_get_stream(self._h, C.byref(p)))
+        return p.value
 
     def device_vector(self):
         p = C.c_void_p()

@@ -109,6 +109,9 @@ int hs_read_result(hs_context* ctx, void* packed_y, uint32_t num_rows);
 /* ---- zero-copy hooks for callers that already live on the GPU (PyTorch tensors, RCCL) ---------- */
 /* Run on a caller-owned hipStream_t instead of the context's private stream (NULL restores it). */
 int hs_set_stream(hs_context* ctx, void* hip_stream);
+/* The hipStream_t the context currently launches on (its private one unless hs_set_stream changed it): lets several contexts of
+ * one device share a stream, i.e. run strictly one after the other (bench.py's round-robin over several matrices). */
+int hs_get_stream(hs_context* ctx, void** hip_stream);
 /* Device addresses of the library's packed x (num_cols words) and packed y (num_rows words). */
 int hs_device_vector(hs_context* ctx, void** x_dev);
 int hs_device_result(hs_context* ctx, void** y_dev);

@@ -1,0 +1,24 @@
+"""Copy the per-config rocprofv3 summaries of tools/profile_cfg.sh (gpurun_out/prof_<config>/) into profiles/ and merge their
+counter results into profiles/hbm_traffic.json (keyed by config; bench.py reads roofline.traffic from there):
+python tools/collect_profiles.py <round tag, e.g. r02> [configs...]"""
+import json, os, shutil, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+configs = sys.argv[2:] or ["ogbl_ppa", "transformer_50", "ogbn_products", "mouse_gene"]
+path = os.path.join(root, "profiles", "hbm_traffic.json")
+try:
+    merged = json.load(open(path))
+    if "hbm_bytes_per_launch" in merged:      # round-1 layout: one flat entry for ogbl-ppa
+        merged = {}
+except (OSError, ValueError):
+    merged = {}
+for c in configs:
+    src = os.path.join(root, "gpurun_out", f"prof_{c}")
+    if not os.path.exists(os.path.join(src, "summary.txt")):
+        print("missing", src)
+        continue
+    shutil.copy(os.path.join(src, "summary.txt"), os.path.join(root, "profiles", f"{tag}_{c}_rocprofv3_summary.txt"))
+    merged[c] = json.load(open(os.path.join(src, "hbm_traffic.json")))
+    merged[c]["round"] = tag
+    print(c, "kernel avg us", merged[c].get("kernel_avg_us"), "HBM bytes", merged[c].get("hbm_bytes_per_launch"), "frac", merged[c].get("roofline_frac_rocprof"))
+json.dump(merged, open(path, "w"), indent=1)

@@ -23,3 +23,9 @@ for k in range(3):
 print("%-16s %-28s kernel us %8.1f (best of 3 x %d) | %s slices %d ring %d blocks %d units %d | ablate %s" % (
     name, os.environ.get("TAG", ""), best * 1e3, runs, device.STREAM_FORMATS[st["stream_format"]], st["col_slices"], st["ring_buffers"],
     st["num_blocks"], st["num_units"], os.environ.get("HISPARSE_ABLATE", "0")))
+if os.environ.get("PROBE_JSON"):      # tools/profile_cfg.sh: what the profiled image looked like
+    import json
+    with open(os.environ["PROBE_JSON"], "w") as f:
+        json.dump({"config": name, "impl": int(impl), "nnz": int(cp.nnz), "stream_bytes": int(st["stream_bytes"]),
+                   "stream_format": device.STREAM_FORMATS[st["stream_format"]], "col_slices": int(st["col_slices"]),
+                   "kernel_us_hip_events_best": best * 1e3}, f)

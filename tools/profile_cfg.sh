@@ -11,6 +11,7 @@ OUT=gpurun_out/prof_$CFG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 CMD="python tools/probe_cfg.py $CFG"
+export PROBE_JSON="$OUT/probe.json"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- $CMD > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o write -- $CMD > "$OUT/write.log" 2>&1

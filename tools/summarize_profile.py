@@ -49,6 +49,13 @@ if "FETCH_SIZE_KiB_median" in summary:
     summary["hbm_write_bytes_per_launch"] = write_b
     summary["hbm_bytes_per_launch"] = read_b + write_b
     summary["correction"] = "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of wide streaming reads), WRITE_SIZE KiB x 1024 as reported"
+try:
+    with open(os.path.join(out, "probe.json")) as f:
+        summary.update(json.load(f))
+    if "kernel_avg_us" in summary:
+        summary["roofline_frac_rocprof"] = 8.0 * summary["nnz"] / (summary["kernel_avg_us"] * 1e-6) / 8e12
+except (OSError, ValueError, KeyError):
+    pass
 print(json.dumps(summary, indent=1))
 with open(os.path.join(out, "hbm_traffic.json"), "w") as f:
     json.dump(summary, f, indent=1)
