@@ -274,7 +274,8 @@ def main():
     per_config = []
     if not args.config and not args.quick:
         sub_steps = max(20, min(args.steps, 200))
-        for name in ("transformer_50", "ogbn_products", "mouse_gene"):
+        # the three other single-GPU configurations of BASELINE.json + the second ogbl-ppa stand-in (symmetric R-MAT)
+        for name in ("transformer_50", "ogbn_products", "mouse_gene", "ogbl_ppa_rmat"):
             res, ctx = measure_single(np, datasets, device, host, name, sub_steps, min(args.warmup, 20), cpu_seconds=0.0, rank=rank)
             ctx["eng"].close()
             del ctx

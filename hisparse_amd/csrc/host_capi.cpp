@@ -3,6 +3,7 @@
 #include "hisparse_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <exception>
@@ -244,6 +245,66 @@ int hsf_csr_generate(const char* kind, uint32_t num_rows, uint32_t num_cols, dou
                 }
                 for (uint32_t col : pick) { cols.push_back(col); vals.push_back(float(rng.uniform() * c)); }
             });
+        } else if (k == "rmat") {
+            // Symmetric R-MAT graph (a = .57, b = .19, c = .19, d = .05: the Graph500 / SURVEY.md section 8d parameters): `b` = 1 scrambles the vertex ids with a bijection (0 keeps the recursive order: hubs at the
+            // low ids), values uniform(0, c); `a` counts the entries DRAWN, repeats are dropped afterwards.  Edges are drawn in 1024 fixed chunks with their own RNG streams, so the matrix is the
+            // same for every thread count; (i, j) and (j, i) are both stored, duplicates and nothing else are dropped.
+            if (!(a > 0) || num_rows != num_cols) return fail(HSF_BAD_ARG, "rmat: need nnz > 0 and a square matrix");
+            const uint32_t n = num_rows;
+            uint32_t scale = 0;
+            while ((uint64_t(1) << scale) < n) ++scale;
+            const uint64_t mul = b != 0.0 ? coprime_multiplier(n, 0x9e3779b1ull + seed * 7919u) : 1;
+            const uint64_t pairs = uint64_t(a / 2.0) + 1;
+            constexpr uint32_t kChunks = 1024;
+            std::vector<std::vector<uint64_t>> drawn(kChunks);
+            {
+                std::atomic<uint32_t> next(0);
+                std::vector<std::thread> pool;
+                const unsigned threads = std::max(1u, std::thread::hardware_concurrency());
+                for (unsigned t = 0; t < threads; ++t)
+                    pool.emplace_back([&]() {
+                        for (uint32_t ch = next.fetch_add(1); ch < kChunks; ch = next.fetch_add(1)) {
+                            Rng rng(mix(seed, 0x726d6174ull + ch));
+                            const uint64_t lo = pairs * ch / kChunks, hi = pairs * (ch + 1) / kChunks;
+                            auto& out = drawn[ch];
+                            out.reserve(size_t(hi - lo) * 2);
+                            for (uint64_t e = lo; e < hi; ++e) {
+                                uint32_t i = 0, j = 0;
+                                for (uint32_t bit = 0; bit < scale; ++bit) {
+                                    const double u = rng.uniform();
+                                    const uint32_t q = u < 0.57 ? 0u : u < 0.76 ? 1u : u < 0.95 ? 2u : 3u;      // a | b | c | d
+                                    i = (i << 1) | (q >> 1);
+                                    j = (j << 1) | (q & 1u);
+                                }
+                                if (i >= n || j >= n || i == j) continue;
+                                const uint64_t si = uint64_t(i) * mul % n, sj = uint64_t(j) * mul % n;
+                                out.push_back((si << 32) | sj);
+                                out.push_back((sj << 32) | si);
+                            }
+                        }
+                    });
+                for (auto& th : pool) th.join();
+            }
+            // bucket by row, sort + unique per row
+            std::vector<uint64_t> count(size_t(n) + 1, 0);
+            for (const auto& v : drawn)
+                for (uint64_t e : v) count[(e >> 32) + 1]++;
+            for (uint32_t r = 0; r < n; ++r) count[r + 1] += count[r];
+            std::vector<uint32_t> cols(count[n]);
+            {
+                std::vector<uint64_t> cursor(count.begin(), count.end() - 1);
+                for (auto& v : drawn) {
+                    for (uint64_t e : v) cols[cursor[e >> 32]++] = uint32_t(e);
+                    std::vector<uint64_t>().swap(v);
+                }
+            }
+            build_rows_parallel(m, [&](uint32_t i, std::vector<uint32_t>& out_cols, std::vector<float>& out_vals) {
+                std::vector<uint32_t> mine(cols.begin() + count[i], cols.begin() + count[i + 1]);
+                std::sort(mine.begin(), mine.end());
+                mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
+                Rng rng(mix(seed, i));
+                for (uint32_t col : mine) { out_cols.push_back(col); out_vals.push_back(float(rng.uniform() * c)); }
+            });
         } else {
             return fail(HSF_BAD_ARG, "unknown generator kind: " + k);
         }
@@ -312,6 +373,18 @@ int hsf_unpack_result(int impl, const uint32_t* words, uint64_t n, float* y) {
     if (!hisparse::impl_valid(impl) || (n && (!y || !words))) return fail(HSF_BAD_ARG, "bad argument");
     hisparse::unpack_result(impl, words, n, y);
     return HSF_OK;
+}
+
+int hsf_csr_to_csc(const hsf_csr* m, int impl, uint32_t* indptr, uint32_t* row_indices, uint32_t* value_words) {
+    if (!m || !indptr || !hisparse::impl_valid(impl)) return fail(HSF_BAD_ARG, "bad argument");
+    return guarded([&]() {
+        // sw/data_loader.h:109-144 (csr2csc) + :147-157 (csc_matrix_convert_from_float): rows stay ascending inside a column
+        const spmv::io::CSCMatrix<float> csc = spmv::io::csr2csc(m->m);
+        std::copy(csc.adj_indptr.begin(), csc.adj_indptr.end(), indptr);
+        if (row_indices) std::copy(csc.adj_indices.begin(), csc.adj_indices.end(), row_indices);
+        if (value_words) hisparse::pack_vector(impl, csc.adj_data.data(), csc.adj_data.size(), value_words);
+        return int(HSF_OK);
+    });
 }
 
 int hsf_split_rows_by_nnz(const uint32_t* indptr, uint32_t num_rows, uint32_t parts, uint32_t granule, uint32_t* bounds) {

@@ -45,6 +45,17 @@ struct hs_context {
     uint32_t format = 0;           // StreamFormat of d_image
     uint32_t* d_partial = nullptr;  // col_slices > 1: per-slice partial results, col_slices x num_rows words
 
+    // SpMSpV extension: the matrix once more, in CSC form (hs_load_matrix_csc), + scratch
+    uint32_t* d_csc_indptr = nullptr;
+    uint32_t* d_csc_rows = nullptr;
+    uint32_t* d_csc_vals = nullptr;
+    void* d_csc_acc = nullptr;
+    uint32_t* d_csc_y = nullptr;
+    uint32_t* d_sx = nullptr;      // sparse x: [capacity] indices then [capacity] value words
+    uint32_t sx_capacity = 0;
+    uint32_t csc_rows = 0, csc_cols = 0;
+    uint64_t csc_nnz = 0;
+
     uint32_t* d_x = nullptr;       // library-owned packed x
     uint32_t* d_y = nullptr;       // library-owned packed y
     const uint32_t* x_bound = nullptr;
@@ -90,6 +101,17 @@ void free_matrix(hs_context* c) {
     c->d_y = nullptr;
     c->y_bound = nullptr;
     c->matrix_loaded = false;
+}
+
+void free_csc(hs_context* c) {
+    for (void* p : {static_cast<void*>(c->d_csc_indptr), static_cast<void*>(c->d_csc_rows), static_cast<void*>(c->d_csc_vals), c->d_csc_acc,
+                    static_cast<void*>(c->d_csc_y), static_cast<void*>(c->d_sx)})
+        if (p) (void)hipFree(p);
+    c->d_csc_indptr = c->d_csc_rows = c->d_csc_vals = c->d_csc_y = c->d_sx = nullptr;
+    c->d_csc_acc = nullptr;
+    c->sx_capacity = 0;
+    c->csc_rows = c->csc_cols = 0;
+    c->csc_nnz = 0;
 }
 
 uint32_t* y_target(hs_context* c) { return c->y_bound ? c->y_bound : c->d_y; }
@@ -210,6 +232,7 @@ int hs_destroy(hs_context* ctx) {
     if (ctx->stream == ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     else (void)hipDeviceSynchronize();
     free_matrix(ctx);
+    free_csc(ctx);
     if (ctx->d_x) (void)hipFree(ctx->d_x);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -372,6 +395,76 @@ int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32
     }
     for (; done < iterations; ++done)
         if ((rc = one_iteration()) != HS_OK) return rc;
+    return HS_OK;
+}
+
+// ---- SpMSpV extension (spmspv.hip) --------------------------------------------------------------------
+int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, uint32_t num_rows,
+                       uint32_t num_cols) {
+    if (!ctx || !indptr || num_rows == 0 || num_cols == 0) return fail(ctx, HS_ERR_BAD_ARG, "null argument or empty matrix");
+    const uint64_t nnz = indptr[num_cols];
+    if (indptr[0] != 0 || (nnz && (!row_indices || !value_words))) return fail(ctx, HS_ERR_BAD_MATRIX, "indptr must start at 0; arrays missing");
+    for (uint32_t c = 0; c < num_cols; ++c)
+        if (indptr[c + 1] < indptr[c]) return fail(ctx, HS_ERR_BAD_MATRIX, "CSC indptr must be non-decreasing");
+    for (uint64_t e = 0; e < nnz; ++e)
+        if (row_indices[e] >= num_rows) return fail(ctx, HS_ERR_BAD_MATRIX, "CSC row index out of range");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_csc(ctx);
+    const bool is_float = ctx->impl != HS_IMPL_FIXED;
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_indptr), (size_t(num_cols) + 1) * 4));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_rows), std::max<size_t>(nnz, 1) * 4));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_vals), std::max<size_t>(nnz, 1) * 4));
+    HS_HIP(ctx, hipMalloc(&ctx->d_csc_acc, size_t(num_rows) * (is_float ? 4 : 8)));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_y), size_t(num_rows) * 4));
+    HS_HIP(ctx, hipMemcpy(ctx->d_csc_indptr, indptr, (size_t(num_cols) + 1) * 4, hipMemcpyHostToDevice));
+    if (nnz) {
+        HS_HIP(ctx, hipMemcpy(ctx->d_csc_rows, row_indices, nnz * 4, hipMemcpyHostToDevice));
+        HS_HIP(ctx, hipMemcpy(ctx->d_csc_vals, value_words, nnz * 4, hipMemcpyHostToDevice));
+    }
+    HS_HIP(ctx, hipMemset(ctx->d_csc_y, 0, size_t(num_rows) * 4));
+    ctx->csc_rows = num_rows;
+    ctx->csc_cols = num_cols;
+    ctx->csc_nnz = nnz;
+    return HS_OK;
+}
+
+int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
+    if (!ctx || (count && !x_entries)) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+    if (!ctx->d_csc_indptr) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix_csc has not been called");
+    for (uint32_t k = 0; k < count; ++k)
+        if (x_entries[k].index >= ctx->csc_cols) return fail(ctx, HS_ERR_BAD_ARG, "sparse vector index out of range");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    if (count > ctx->sx_capacity) {
+        HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_sx) (void)hipFree(ctx->d_sx);
+        ctx->d_sx = nullptr;
+        ctx->sx_capacity = 0;
+        const uint32_t cap = std::max<uint32_t>(count, 1024);
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_sx), size_t(cap) * 8));
+        ctx->sx_capacity = cap;
+    }
+    if (count) {     // IDX_VAL_T pairs -> two arrays (coalesced reads on the device)
+        std::vector<uint32_t> split(size_t(count) * 2);
+        for (uint32_t k = 0; k < count; ++k) {
+            split[k] = x_entries[k].index;
+            split[size_t(count) + k] = x_entries[k].val;
+        }
+        HS_HIP(ctx, hipMemcpyAsync(ctx->d_sx, split.data(), split.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HS_HIP(ctx, hipStreamSynchronize(ctx->stream));     // `split` is a temporary
+    }
+    HS_HIP(ctx, hisparse::dev::launch_spmspv(ctx->impl != HS_IMPL_FIXED, ctx->d_csc_indptr, ctx->d_csc_rows, ctx->d_csc_vals, ctx->d_sx,
+                                             ctx->d_sx + count, count, ctx->csc_rows, ctx->csc_cols, ctx->d_csc_acc, ctx->d_csc_y, ctx->stream));
+    return HS_OK;
+}
+
+int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows) {
+    if (!ctx || !packed_y) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+    if (!ctx->d_csc_indptr) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix_csc has not been called");
+    if (num_rows != ctx->csc_rows) return fail(ctx, HS_ERR_BAD_ARG, "result length must equal the CSC matrix's row count");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_HIP(ctx, hipMemcpyAsync(packed_y, ctx->d_csc_y, size_t(num_rows) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HS_OK;
 }
 

@@ -41,6 +41,12 @@ hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_
                                  uint32_t row_hi, hipStream_t stream, uint32_t* x_fb = nullptr, uint32_t n_fb = 0, uint32_t scale = 0,
                                  uint32_t shift = 0);
 
+// SpMSpV extension (spmspv.hip): y = A x for x given as x_count (index, value word) pairs over a CSC matrix; `accumulators` is
+// scratch of num_rows x 8 bytes (fixed) / 4 bytes (float).  Zeroes the accumulators, scatters, clamps / copies into y.
+hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, const uint32_t* x_index,
+                         const uint32_t* x_words, uint32_t x_count, uint32_t num_rows, uint32_t num_cols, void* accumulators, uint32_t* y,
+                         hipStream_t stream);
+
 // Iterative callers: x[i] = scale (*) y[i] (+) shift, i < n, in Q8.24 (AP_RND, AP_SAT) or fp32 arithmetic.
 hipError_t launch_feedback(bool is_float, const uint32_t* y, uint32_t* x, uint32_t n, uint32_t scale, uint32_t shift, hipStream_t stream);
 

@@ -121,7 +121,9 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner or bitmap"; return false; }
         }
     }
-    const bool delta = out.format == kFormatDelta, owner = out.format == kFormatOwner;
+    bool delta = out.format == kFormatDelta;
+    const bool owner = out.format == kFormatOwner;
+    const bool format_forced = std::getenv("HISPARSE_STREAM_FORMAT") != nullptr;
     const uint32_t acc_bytes = owner ? kOwnerAccumulatorBytes : kAccumulatorBytes;
     const uint32_t spare_rows = owner ? kConsumerWaves : 1u;     // accumulators behind the block's rows that padding elements aim at
 
@@ -330,6 +332,23 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         up.slots = slots;
     });
 
+    // DELTA pays for every position gap beyond 16 bits with a bridge slot.  A graph whose gaps are heavy-tailed (R-MAT: a quarter
+    // of the rows empty, hubs of 10^5 non-zeros) needs one for every 25th element although its MEAN gap looks fine, and its
+    // lanes' runs are unevenly filled: measured 82 us against 60 us in PAIRS on the R-MAT ogbl-ppa stand-in, where the
+    // Chung-Lu stand-in (0.4 % bridges) is faster in DELTA.  So: more than 2 % bridge slots -> PAIRS after all.
+    if (delta && !format_forced) {
+        uint64_t slots = 0;
+        for (const UnitPlan& up : plans) slots += up.slots;
+        if (double(slots) > 1.02 * double(out.nnz)) {
+            delta = false;
+            out.format = kFormatPairs;
+            for (UnitPlan& up : plans) up.slots = up.n;
+            for (uint32_t bi = 0; bi < NB; ++bi) {
+                const uint32_t b = range_of_block[bi];
+                out.blocks[bi].flags = (ranges[b].nrows <= kDenseBlockRows && range_nnz[b] >= 64ull * ranges[b].nrows) ? kBlockDenseRows : 0u;
+            }
+        }
+    }
     timer.lap("sort units");
     // ---- per block: deal every unit's 64-slot chunks to the consumer wavefronts round-robin; lay out the streams -------
     std::vector<uint64_t> block_nnz(NB, 0);   // weight of a block for the workgroup assignment

@@ -47,6 +47,11 @@ CONFIGS = {
     # configs[4]
     "mouse_gene": Config("mouse_gene", "fixed", 45101, 45101, "powerlaw", 28967291, 0.30, 0.1, 44,
                          "mouse_gene_45K_29M_csr_float32.npz"),
+    # SURVEY.md section 8d's own recipe for the two big graphs: symmetric R-MAT (a=.57 b=.19 c=.19), seeds 42 / 43 -- a second
+    # stand-in with a much harder degree distribution (hub rows of 10^5 non-zeros) than the Chung-Lu matrices above
+    # (`a` counts the entries DRAWN; R-MAT repeats itself a lot at this density -- 62.2 M draws leave ~42.4 M distinct entries)
+    "ogbl_ppa_rmat": Config("ogbl_ppa_rmat", "fixed", 576289, 576289, "rmat", 62.2e6, 1.0, 1.0, 42, ""),
+    "ogbn_products_rmat": Config("ogbn_products_rmat", "float_stall", 2449029, 2449029, "rmat", 161e6, 1.0, 1.0, 43, ""),
     # small relatives for tests / smoke
     "ppa_small": Config("ppa_small", "fixed", 40000, 70000, "powerlaw", 1400000, 0.35, 1.0, 7, ""),
     "nn_small": Config("nn_small", "float_pob", 512, 33288, "bernoulli", 0, 0.05, 0.05, 95, ""),

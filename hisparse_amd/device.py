@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
     "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
-    "hs_bind_device_vector", "hs_bind_device_result", "hs_feedback", "hs_iterate", "hs_get_stats", "hs_time_runs", "hs_tiles_build", "hs_tiles_info",
+    "hs_bind_device_vector", "hs_bind_device_result", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_get_stats", "hs_time_runs", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
 
@@ -77,6 +77,9 @@ def lib():
         l.hs_bind_device_result.argtypes = [vp, vp]
         l.hs_feedback.argtypes = [vp, u32, u32]
         l.hs_iterate.argtypes = [vp, u32, u32, u32]
+        l.hs_load_matrix_csc.argtypes = [vp, vp, vp, vp, u32, u32]
+        l.hs_spmspv.argtypes = [vp, vp, u32]
+        l.hs_read_spmspv_result.argtypes = [vp, vp, u32]
         l.hs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.hs_tiles_build.argtypes = [C.POINTER(vp), C.POINTER(u64), C.c_int, u32, u32, u32, u32, u32, u32, u32, C.POINTER(vp)]
@@ -193,6 +196,23 @@ class SpmvEngine:
 
     def bind_device_result(self, ptr):
         self._check(lib().hs_bind_device_result(self._h, C.c_void_p(ptr or None)))
+
+    # ---- SpMSpV extension ---------------------------------------------------------------------------
+    def load_matrix_csc(self, indptr, row_indices, value_words, num_rows):
+        indptr, row_indices, value_words = (np.ascontiguousarray(a, dtype=np.uint32) for a in (indptr, row_indices, value_words))
+        self._check(lib().hs_load_matrix_csc(self._h, indptr.ctypes.data, row_indices.ctypes.data if row_indices.size else None,
+                                            value_words.ctypes.data if value_words.size else None, num_rows, indptr.size - 1))
+        self.csc_rows = num_rows
+
+    def spmspv(self, x_index, x_words):
+        """y = A x for x = {(x_index[k], x_words[k])}; returns the dense packed y."""
+        pairs = np.empty((len(x_index), 2), dtype=np.uint32)       # IDX_VAL_T: {index, val}
+        pairs[:, 0] = x_index
+        pairs[:, 1] = x_words
+        self._check(lib().hs_spmspv(self._h, pairs.ctypes.data if pairs.size else None, len(x_index)))
+        y = np.empty(self.csc_rows, dtype=np.uint32)
+        self._check(lib().hs_read_spmspv_result(self._h, y.ctypes.data, y.size))
+        return y
 
     # ---- measurement ----------------------------------------------------------------------------
     def stats(self):

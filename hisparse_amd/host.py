@@ -62,6 +62,7 @@ def lib():
         l.hsf_pack_vector.argtypes = [C.c_int, f32p, u64, u32p]
         l.hsf_unpack_result.argtypes = [C.c_int, u32p, u64, f32p]
         l.hsf_split_rows_by_nnz.argtypes = [u32p, u32, u32, u32, u32p]
+        l.hsf_csr_to_csc.argtypes = [vp, C.c_int, u32p, u32p, u32p]
         _lib = l
     return _lib
 
@@ -219,3 +220,14 @@ def split_rows_by_nnz_native(indptr, parts, granule):
     bounds = np.zeros(parts + 1, dtype=np.uint32)
     _check(lib().hsf_split_rows_by_nnz(_u32p(indptr), indptr.size - 1, parts, granule, _u32p(bounds)))
     return [int(b) for b in bounds]
+
+
+def csr_to_csc(csr, impl):
+    """(indptr[num_cols + 1], row_indices[nnz], value_words[nnz]) -- csr2csc + conversion to the numeric mode's value words
+    (sw/data_loader.h:109-157), the matrix form of the SpMSpV extension."""
+    rows, cols, nnz = csr.dims
+    indptr = np.zeros(cols + 1, dtype=np.uint32)
+    idx = np.zeros(max(nnz, 1), dtype=np.uint32)
+    words = np.zeros(max(nnz, 1), dtype=np.uint32)
+    _check(lib().hsf_csr_to_csc(csr._h, impl_id(impl), _u32p(indptr), _u32p(idx), _u32p(words)))
+    return indptr, idx[:nnz], words[:nnz]

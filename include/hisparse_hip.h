@@ -132,6 +132,21 @@ int hs_bind_device_result(hs_context* ctx, void* y_dev);
 int hs_feedback(hs_context* ctx, uint32_t scale_word, uint32_t shift_word);
 int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32_t shift_word);
 
+/* ---- SpMSpV (EXTENSION: the reference stubs the types -- SPMSPV_MAT_PKT_T, IDX_VAL_T, spmv/libfpga/common.h:52-54 -- and the CSC
+ * conversion csr2csc, sw/data_loader.h:109-144 -- but has no kernel) --------------------------------------
+ * y = A x for a SPARSE x: only the columns named by x's entries are read.
+ *   hs_load_matrix_csc: CSCMatrix arrays (indptr[num_cols + 1], row index and value word per non-zero, value words in the context's
+ *     numeric mode: hsf_csr_to_csc), independent of the matrix hs_load_matrix holds; validated, copied to the device.
+ *   hs_spmspv: x as `count` IDX_VAL_T pairs (each column at most once for the float modes' tolerance to mean anything; repeated
+ *     entries simply add up).  Asynchronous.  The result is a dense packed y of num_rows words: hs_read_spmspv_result.
+ * Arithmetic as in hs_run: fixed = saturating sum of individually rounded / saturated products (bit-exact, order free);
+ * float = fp32 products added in fp32 in arrival order (tolerance). */
+typedef struct { uint32_t index; uint32_t val; } hs_idx_val;    /* IDX_VAL_T, spmv/libfpga/common.h:54 */
+int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, uint32_t num_rows,
+                       uint32_t num_cols);
+int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count);
+int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows);
+
 /* ---- measurement ------------------------------------------------------------------------------- */
 int hs_get_stats(const hs_context* ctx, hs_stats* stats);
 /* `runs` back-to-back hs_run calls after `warmup` untimed ones, bracketed by HIP events on the

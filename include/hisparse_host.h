@@ -61,6 +61,8 @@ void hsf_csr_free(hsf_csr* m);
  *       "dense"    — csim's create_dense_CSR (:387-409), all ones
  *       "powerlaw" — Chung-Lu style graph: a = target nnz, b = skew exponent beta; values uniform(0, c)
  *       "bernoulli"— pruned-NN layer: every entry present with probability b; values N(0, c)
+ *       "rmat"     — symmetric R-MAT graph, quadrant probabilities .57 / .19 / .19 / .05: a = entries DRAWN (both directions; duplicates are dropped),
+ *                    b != 0 scrambles the vertex ids; values uniform(0, c); square matrices only
  */
 int hsf_csr_generate(const char* kind, uint32_t num_rows, uint32_t num_cols, double a, double b, double c,
                      uint64_t seed, hsf_csr** out);
@@ -78,6 +80,10 @@ void hsf_matrix_free(hsf_matrix* m);
 /* ---- x / y word conversion (sw/benchmark.cpp:207-212, spmv_csim/csim.cpp:172) -------------------- */
 int hsf_pack_vector(int impl, const float* x, uint64_t n, uint32_t* words);
 int hsf_unpack_result(int impl, const uint32_t* words, uint64_t n, float* y);
+
+/* ---- CSC for SpMSpV (sw/data_loader.h:109-157: csr2csc + csc_matrix_convert_from_float) ------------------------------ */
+/* indptr: num_cols + 1; row_indices / value_words: nnz each (value words in the numeric mode's representation, like hsf_pack_vector). */
+int hsf_csr_to_csc(const hsf_csr* m, int impl, uint32_t* indptr, uint32_t* row_indices, uint32_t* value_words);
 
 /* ---- multi-GPU row slabs (hisparse/row_sharding.h; the C++ benchmark's --gpus N uses the same routine) ----------- */
 /* bounds[0..parts]: row boundaries balancing non-zeros, interior ones multiples of `granule` (128 * interleave). */

@@ -276,3 +276,28 @@ void oracle_compute_ref_parallel(uint32_t num_rows, const uint32_t* indptr, cons
         y[r] = acc;
     }
 }
+
+
+/*
+ * SpMSpV (EXTENSION; the reference only stubs it: SPMSPV_MAT_PKT_T / IDX_VAL_T in spmv/libfpga/common.h:52-54, csr2csc in
+ * sw/data_loader.h:109-144, paper section 7): y = A x for a SPARSE x given as (index, value) pairs over a CSC matrix -- for every
+ * stored x entry, its column's non-zeros are multiplied and accumulated with the PE arithmetic of the numeric mode
+ * (pe.h:64,72 / pe-stall.h:52,138).  The row sums equal those of the dense SpMV with x scattered into a zero vector: bit for bit
+ * in fixed point (saturating sums of non-negative terms are order free), up to association in the float modes.
+ */
+int oracle_spmspv(int impl, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, uint32_t num_rows,
+                  uint32_t num_cols, const uint32_t* x_index, const uint32_t* x_words, uint32_t x_count, uint32_t* y) {
+    if (impl < IMPL_FIXED || impl > IMPL_FLOAT_STALL || !indptr || !y || (x_count && (!x_index || !x_words))) return ORACLE_BAD_ARG;
+    memset(y, 0, (size_t)num_rows * 4);
+    for (uint32_t k = 0; k < x_count; ++k) {
+        const uint32_t c = x_index[k];
+        if (c >= num_cols) return ORACLE_COL_OUT_OF_RANGE;
+        for (uint32_t e = indptr[c]; e < indptr[c + 1]; ++e) {
+            const uint32_t r = row_indices[e];
+            if (r >= num_rows) return ORACLE_ROW_OUT_OF_RANGE;
+            if (impl == IMPL_FIXED) y[r] = q_add(y[r], q_mul(value_words[e], x_words[k]));
+            else y[r] = f2bits(bits2f(y[r]) + bits2f(value_words[e]) * bits2f(x_words[k]));
+        }
+    }
+    return ORACLE_OK;
+}

@@ -42,6 +42,7 @@ def lib():
         l.oracle_compute_ref.restype = None
         l.oracle_compute_ref_parallel.argtypes = [u32, u32p, u32p, f32p, f32p, f32p, C.c_int]
         l.oracle_compute_ref_parallel.restype = None
+        l.oracle_spmspv.argtypes = [C.c_int, u32p, u32p, u32p, u32, u32, u32p, u32p, u32, u32p]
         l.oracle_verify.argtypes = [f32p, f32p, C.c_uint64]
         l.oracle_verify.restype = C.c_int64
         _lib = l
@@ -161,6 +162,17 @@ def compute_ref_parallel(num_rows, indptr, indices, data, x, out=None, threads=N
     """OpenMP version of compute_ref over the usable host cores (CPU-baseline context only)."""
     y = np.zeros(num_rows, dtype=np.float32) if out is None else out
     lib().oracle_compute_ref_parallel(num_rows, _u32p(indptr), _u32p(indices), _f32p(data), _f32p(x), _f32p(y), threads or usable_cores())
+    return y
+
+
+def spmspv(impl, indptr, row_indices, value_words, num_rows, num_cols, x_index, x_words):
+    """SpMSpV over a CSC matrix (extension): packed y words (num_rows,)."""
+    indptr, row_indices, value_words, x_index, x_words = (np.ascontiguousarray(a, dtype=np.uint32) for a in (indptr, row_indices, value_words, x_index, x_words))
+    y = np.zeros(num_rows, dtype=np.uint32)
+    rc = lib().oracle_spmspv(impl, _u32p(indptr), _u32p(row_indices), _u32p(value_words), num_rows, num_cols, _u32p(x_index), _u32p(x_words),
+                             x_index.size, _u32p(y))
+    if rc != 0:
+        raise OracleError(f"oracle_spmspv failed: {ERRORS.get(rc, rc)}")
     return y
 
 

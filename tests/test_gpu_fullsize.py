@@ -46,7 +46,7 @@ def _float_report(got_words, want_words, exact):
     }
 
 
-@pytest.mark.parametrize("name", ["ogbl_ppa", "transformer_50", "ogbn_products", "mouse_gene"])
+@pytest.mark.parametrize("name", ["ogbl_ppa", "transformer_50", "ogbn_products", "mouse_gene", "ogbl_ppa_rmat"])
 def test_full_size_random_values_vs_oracle(name, record_property):
     import scipy.sparse as sp
     cfg, csr = datasets.load(name)

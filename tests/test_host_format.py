@@ -100,3 +100,24 @@ def test_normalize_by_outdegree():
     _, _, dv = csr.arrays()
     counts = np.bincount(ix, minlength=400)
     assert np.array_equal(dv, (1.0 / counts[ix]).astype(np.float32))
+
+
+def test_rmat_generator_is_symmetric_and_deterministic():
+    """SURVEY.md section 8d's stand-in recipe: symmetric R-MAT (a=.57 b=.19 c=.19); the same matrix for every thread count."""
+    import os
+    m = host.CSRMatrix.generate("rmat", 5000, 5000, a=60000, b=1.0, c=1.0, seed=42)
+    ip, ix, dv = m.arrays()
+    a = sp.csr_matrix((np.ones(len(ix), dtype=np.int8), ix.astype(np.int64), ip.astype(np.int64)), shape=(5000, 5000))
+    assert (a != a.T).nnz == 0 and a.diagonal().sum() == 0
+    assert 30000 < m.dims[2] <= 60000
+    for r in range(5000):
+        assert (np.diff(ix[ip[r]:ip[r + 1]].astype(np.int64)) > 0).all()
+    deg = np.diff(ip.astype(np.int64))
+    assert deg.max() > 20 * deg.mean()                      # heavy hubs: what makes it a harder stand-in than the Chung-Lu one
+    old = os.environ.get("HISPARSE_FORMAT_THREADS")
+    again = host.CSRMatrix.generate("rmat", 5000, 5000, a=60000, b=1.0, c=1.0, seed=42).arrays()
+    assert np.array_equal(again[1], ix) and np.array_equal(again[2], dv)
+    other = host.CSRMatrix.generate("rmat", 5000, 5000, a=60000, b=1.0, c=1.0, seed=43).arrays()
+    assert not np.array_equal(other[0], ip)
+    with pytest.raises(host.HostError):
+        host.CSRMatrix.generate("rmat", 5000, 4000, a=60000, b=1.0, c=1.0, seed=42)

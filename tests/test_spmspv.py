@@ -1,0 +1,98 @@
+"""SpMSpV extension: y = A x for a sparse x over a CSC matrix.  The reference only stubs the operator
+(IDX_VAL_T / SPMSPV_MAT_PKT_T, spmv/libfpga/common.h:52-54; csr2csc, sw/data_loader.h:109-144), so the contract is derived:
+the result equals the SpMV of the same matrix with x scattered into a zero vector -- bit for bit in fixed point (order free),
+within the float tolerance otherwise.  CPU part: the CSC conversion and the oracle restatement against the SpMV oracle;
+GPU part: hs_load_matrix_csc / hs_spmspv against both."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from hisparse_amd import device, host
+from oracle import oracle as orc
+
+import cases
+
+
+def _case(impl, rows, cols, density, seed, x_nnz):
+    m = cases.random_csr(rows, cols, density, seed, impl)
+    csr = host.CSRMatrix.from_scipy(m)
+    indptr, ridx, words = host.csr_to_csc(csr, impl)
+    rng = np.random.default_rng(seed)
+    xi = np.sort(rng.choice(cols, size=min(x_nnz, cols), replace=False)).astype(np.uint32)
+    xv = cases.random_x(len(xi), seed, impl)
+    xw = host.pack_vector(impl, xv)
+    return m, csr, (indptr, ridx, words), xi, xv, xw
+
+
+def _dense_spmv_oracle(m, impl, xi, xv):
+    """The SpMV oracle (csim restatement) on the same matrix with x densified."""
+    csr = host.CSRMatrix.from_scipy(m)
+    v, o = host.default_banks(impl)
+    cp = host.format_matrix(csr, impl, vb_bank=v, ob_bank=o, skip_empty_rows=True)
+    x = np.zeros(cp.num_cols, dtype=np.float32)
+    x[xi] = xv
+    y = orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], host.pack_vector(impl, x), cp.num_rows, cp.num_cols,
+                 cp.num_row_partitions, cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+    return y[:m.shape[0]]
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_csc_conversion_and_oracle_against_the_spmv_oracle(impl):
+    m, csr, (indptr, ridx, words), xi, xv, xw = _case(impl, 700, 500, 0.03, 5, 60)
+    ref = m.tocsc()
+    ref.sort_indices()
+    assert np.array_equal(indptr, ref.indptr) and np.array_equal(ridx, ref.indices)       # rows ascending inside a column
+    assert np.array_equal(words, host.pack_vector(impl, ref.data))
+    y = orc.spmspv(impl, indptr, ridx, words, 700, 500, xi, xw)
+    want = _dense_spmv_oracle(m, impl, xi, xv)
+    if impl == 0:
+        assert np.array_equal(y, want)
+    else:
+        assert cases.float_close(y, want)
+    assert not orc.spmspv(impl, indptr, ridx, words, 700, 500, xi[:0], xw[:0]).any()      # empty x -> zero y
+    with pytest.raises(orc.OracleError):
+        orc.spmspv(impl, indptr, ridx, words, 700, 500, np.array([500], dtype=np.uint32), xw[:1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("rows,cols,density,x_nnz", [(700, 500, 0.03, 60), (40000, 30000, 0.002, 3000), (3000, 9000, 0.05, 1), (2000, 2000, 0.2, 2000)])
+def test_device_spmspv_matches_oracle_and_dense_spmv(impl, rows, cols, density, x_nnz):
+    m, csr, (indptr, ridx, words), xi, xv, xw = _case(impl, rows, cols, density, 9, x_nnz)
+    want = orc.spmspv(impl, indptr, ridx, words, rows, cols, xi, xw)
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix_csc(indptr, ridx, words, rows)
+        got = eng.spmspv(xi, xw)
+        again = eng.spmspv(xi, xw)                 # accumulators are re-armed every call
+        empty = eng.spmspv(xi[:0], xw[:0])
+        with pytest.raises(device.DeviceError):
+            eng.spmspv(np.array([cols], dtype=np.uint32), xw[:1])
+    assert not empty.any()
+    if impl == 0:
+        assert np.array_equal(got, want) and np.array_equal(again, want)
+        assert np.array_equal(got, _dense_spmv_oracle(m, impl, xi, xv))
+    else:
+        assert cases.float_close(got, want) and cases.float_close(again, want)
+
+
+@pytest.mark.gpu
+def test_saturation_and_errors_on_device():
+    # one row collecting 600 products of 1.0 * 1.0 saturates at 256 - 2^-24 (AP_SAT), exactly like the dense path
+    rows, cols = 128, 640
+    m = sp.csr_matrix((np.ones(600, dtype=np.float32), (np.full(600, 7), np.arange(600))), shape=(rows, cols))
+    csr = host.CSRMatrix.from_scipy(m)
+    indptr, ridx, words = host.csr_to_csc(csr, 0)
+    xi = np.arange(600, dtype=np.uint32)
+    xw = host.pack_vector(0, np.ones(600, dtype=np.float32))
+    with device.SpmvEngine(0) as eng:
+        with pytest.raises(device.DeviceError):
+            eng.csc_rows = rows
+            eng.spmspv(xi, xw)                     # no CSC matrix loaded yet
+        eng.load_matrix_csc(indptr, ridx, words, rows)
+        y = eng.spmspv(xi, xw)
+        bad = indptr.copy()
+        bad[3] = 5000
+        with pytest.raises(device.DeviceError):
+            eng.load_matrix_csc(bad, ridx, words, rows)
+    assert y[7] == 0xFFFFFFFF and not np.delete(y, 7).any()
+    assert np.array_equal(y, orc.spmspv(0, indptr, ridx, words, rows, cols, xi, xw))
