@@ -14,7 +14,12 @@ import cases
 
 
 def _case(impl, rows, cols, density, seed, x_nnz):
-    m = cases.random_csr(rows, cols, density, seed, impl)
+    if rows * cols > 2e8:      # scipy.sparse.random is far too slow at this size: the host library's seeded generator instead
+        g = host.CSRMatrix.generate("powerlaw", rows, cols, a=density * rows * cols, b=0.3, c=1.0 if impl == 0 else 2.0, seed=seed)
+        ip, ix, dv = g.arrays()
+        m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(rows, cols))
+    else:
+        m = cases.random_csr(rows, cols, density, seed, impl)
     csr = host.CSRMatrix.from_scipy(m)
     indptr, ridx, words = host.csr_to_csc(csr, impl)
     rng = np.random.default_rng(seed)
