@@ -1,0 +1,43 @@
+"""tools/perf_model.py (the reference's performance model, performance_model.cpp:431-441, and its v/o sweep,
+design_space_exp.cpp:515-540, re-targeted to this kernel): the model runs without a GPU, its terms are sane, and the sweep covers
+the tile shapes the planner chooses from."""
+import importlib.util
+import io
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("perf_model", os.path.join(ROOT, "tools", "perf_model.py"))
+perf_model = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(perf_model)
+
+
+@pytest.fixture(autouse=True)
+def no_forced_format(monkeypatch):
+    for k in ("HISPARSE_STREAM_FORMAT", "HISPARSE_COL_SLICES", "HISPARSE_MAX_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.parametrize("name,fmt", [("ppa_small", None), ("nn_small", None), ("transformer_50", "bitmap")])
+def test_model_terms(name, fmt):
+    cp, impl, t, parts = perf_model.model(name)
+    assert all(v >= 0 for v in parts.values()) and parts["stream"] > 0
+    total = sum(parts.values())
+    assert total >= 8.0 * cp.nnz / 8e6 * 0.5            # never far below the 8 B/nnz-at-8 TB/s line
+    beta = 8.0 * cp.nnz / len(t["image"])               # format efficiency (performance_model.cpp:431)
+    assert 0.5 < beta < 2.5
+    if fmt:
+        assert t["format"] == fmt
+
+
+def test_sweep_covers_the_planner_shapes_and_restores_the_environment():
+    out = io.StringIO()
+    grid = perf_model.sweep("ppa_small", measure_points=False, out=out)
+    assert len(grid) >= 6 and {cs for cs, _ in grid} >= {1, 2}
+    assert all(m > 0 for m, _ in grid.values())
+    assert "model optimum" in out.getvalue()
+    assert "HISPARSE_COL_SLICES" not in os.environ and "HISPARSE_MAX_ROWS" not in os.environ
+    # more column slices -> every workgroup pulls less of x through its CU: the x refill term must not grow
+    one = [v[0] for (cs, r), v in grid.items() if cs == 1]
+    assert one and min(v[0] for v in grid.values()) <= min(one)

@@ -3,6 +3,9 @@ reference's performance_model.cpp:431-441 (format efficiency beta, vector-tile a
 next to the measured kernel time.
 
   python tools/perf_model.py [config ...]          (needs a GPU for the "measured" column; the model itself does not)
+  python tools/perf_model.py --sweep <config>      tile-size sweep: the model over (column slices x rows per block), the counterpart
+                                                   of the reference's v/o sweep (performance_model/design_space_exp.cpp:515-540);
+                                                   with a GPU every point is also measured
 
 Constants are measurements of this repository (tools/*.hip micro-benchmarks and HISPARSE_ABLATE builds on ogbl-ppa,
 ogbn-products, mouse_gene), not fits per matrix.
@@ -13,7 +16,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hisparse_amd import host, device, datasets
 
 CUS = 256
-STREAM_B_PER_US = {"pairs": 6.60e6, "delta": 6.44e6}   # per-wavefront record streams, ring of 8 (record_stream_bench.hip)
+STREAM_B_PER_US = {"pairs": 6.60e6, "delta": 6.44e6, "owner": 5.86e6, "bitmap": 5.5e6}   # per-wavefront streams (record_stream_bench.hip;
+                                                                                         # owner / bitmap: ablation builds and the bitmap timeline)
+BITMAP_FRONT_US, BITMAP_TAIL_US = 4.0, 3.3   # spmv_bitmap_kernel (tools/bitmap_timeline.py): dispatch ramp + descriptor -> masks -> first values;
+                                             # wavefronts finishing apart + row sums + barrier + store
 STARTUP_US = 3.0            # launch -> block header -> first records landed
 PROLOGUE_US = 0.5           # per block: zero the accumulators, first x sub-tile, barrier (mostly behind the primed stream ring)
 STORE_B_PER_US = 2.4e6      # result store burst when all workgroups finish together (9.2 MB in ~3.8 us) ...
@@ -27,14 +33,20 @@ REFILL_VOLUME_EXPOSED = 0.5 # share of the x refill volume that does not hide be
 LDS_PS_PER_ELEMENT = {0: 11.5, 1: 18.0, 2: 18.0}   # exposed LDS gather + atomic cost per element and CU (u64 / f64)
 
 
-def model(name):
-    cfg, csr = datasets.load(name)
-    impl = host.impl_id(cfg.impl)
-    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+def model(name, cp=None, impl=None):
+    if cp is None:
+        cfg, csr = datasets.load(name)
+        impl = host.impl_id(cfg.impl)
+        cp = host.format_matrix(csr, impl, skip_empty_rows=True)
     t = device.build_tiles(cp, impl, cp.ob_bank, cp.vb_bank, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, CUS)
     blocks, units = t["blocks"], t["units"]
     fmt, slices, ring = t["format"], t["col_slices"], t["ring_buffers"]
     groups = t["num_workgroups"]
+    if fmt == "bitmap":     # no units, no x ring: a front, the stream, a tail (per block of the busiest workgroup)
+        per_wg = max(t["wg_first"][g + 1] - t["wg_first"][g] for g in range(groups))
+        parts = {"stream": len(t["image"]) / STREAM_B_PER_US[fmt], "front (ramp, descriptor -> masks -> values)": BITMAP_FRONT_US,
+                 "tail (finish spread, row sums, store)": BITMAP_TAIL_US * per_wg, "launch": 3.0}
+        return cp, impl, t, parts
     # critical workgroup: steps serialised by the per-unit barrier (sum over units of the slowest wavefront)
     es = units["end_step"].astype(np.int64)
     step_bytes = 384 if fmt == "delta" else 512
@@ -64,7 +76,7 @@ def model(name):
     parts = {
         "stream": stream_us, "startup": STARTUP_US, "prologues": PROLOGUE_US * nblocks[crit], "result store": store_us,
         "unit barriers": BARRIER_US * nunits[crit], "step quantisation": quant_us, "x refill": refill_us,
-        "LDS work": cp.nnz / CUS * LDS_PS_PER_ELEMENT[impl] * 1e-6,
+        "LDS work": cp.nnz / CUS * (12.0 if fmt == "owner" else LDS_PS_PER_ELEMENT[impl]) * 1e-6,   # owner: gather + read-modify-write, 3.6 lanes/clk
     }
     return cp, impl, t, parts
 
@@ -78,7 +90,49 @@ def measure(cp, impl):
     return best
 
 
+def sweep(name, measure_points=True, out=sys.stdout):
+    """Model (and, with a GPU, measurement) over column slices x rows per block; returns {(slices, rows): (model_us, measured_us)}."""
+    cfg, csr = datasets.load(name)
+    impl = host.impl_id(cfg.impl)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    grid = {}
+    saved = {k: os.environ.get(k) for k in ("HISPARSE_COL_SLICES", "HISPARSE_MAX_ROWS")}
+    try:
+        for cs in (1, 2, 4, 8):
+            for rows in (128, 512, 2047, 4095, 8191, 12287, 16369, 24561):
+                os.environ["HISPARSE_COL_SLICES"], os.environ["HISPARSE_MAX_ROWS"] = str(cs), str(rows)
+                try:
+                    _, _, t, parts = model(name, cp, impl)
+                except device.DeviceError:
+                    continue                      # e.g. more slices than sub-tiles
+                if t["col_slices"] != cs or (cs, int(t["max_block_rows"])) in grid:
+                    continue                      # the cap did not bind: same tiling as a point already listed
+                measured = float("nan")
+                if measure_points:
+                    try:
+                        measured = measure(cp, impl)
+                    except device.DeviceError:
+                        measure_points = False
+                grid[(cs, int(t["max_block_rows"]))] = (sum(parts.values()), measured)
+                print(f"  slices {cs}  rows/block {int(t['max_block_rows']):6d}  ring {t['ring_buffers']}  {t['format']:6s} units {len(t['units']):6d}  "
+                      f"model {sum(parts.values()):7.1f} us  measured {measured:7.1f} us", file=out)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if grid:
+        best = min(grid, key=lambda k: grid[k][0])
+        print(f"  model optimum: {best[0]} slice(s), {best[1]} rows per block ({grid[best][0]:.1f} us)", file=out)
+    return grid
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--sweep":
+        print(f"{sys.argv[2]}: tile-size sweep")
+        sweep(sys.argv[2])
+        sys.exit(0)
     names = sys.argv[1:] or ["ogbl_ppa", "mouse_gene", "transformer_50", "ogbn_products"]
     for name in names:
         cp, impl, t, parts = model(name)
