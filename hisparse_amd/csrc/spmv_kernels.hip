@@ -111,10 +111,11 @@ __device__ __forceinline__ void touch_x(const uint32_t* __restrict__ x, uint32_t
                       "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"
 constexpr int kMaxDepth = 16;
 
-template <bool kDelta>
+// kRing: 0 = PAIRS / OWNER with 32-bit position words, 1 = DELTA, 2 = PAIRS / OWNER with 24-bit position words
+template <int kRing>
 struct Ring;
 template <>
-struct Ring<false> {   // PAIRS: one dwordx2 per lane and step
+struct Ring<0> {   // PAIRS: one dwordx2 per lane and step
     static constexpr uint32_t kLaneBytes = 8;
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
@@ -136,7 +137,7 @@ struct Ring<false> {   // PAIRS: one dwordx2 per lane and step
     }
 };
 template <>
-struct Ring<true> {    // DELTA: the value dword and the 16-bit gap of this lane
+struct Ring<1> {    // DELTA: the value dword and the 16-bit gap of this lane
     static constexpr uint32_t kLaneBytes = 4;
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
@@ -148,6 +149,32 @@ struct Ring<true> {    // DELTA: the value dword and the 16-bit gap of this lane
     static __device__ __forceinline__ void take(uint32_t& value, uint32_t& gap) {
         asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]"
                      : "=v"(value), "=v"(gap) : "n"(K), "n"(K + kMaxDepth), "n"(2 * (kDepth - 1)) : "memory");
+    }
+};
+template <>
+struct Ring<2> {    // 24-bit position words: a 448-byte step = 64 value dwords, then 64 x 3 bytes (local_row << 13 | local_col)
+    static constexpr uint32_t kLaneBytes = 4;
+    template <int K>
+    static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
+        // the position word is read as an UNALIGNED dword at byte 256 + 3 * lane (its top byte belongs to the next lane)
+        asm volatile("s_nop 4\n\tglobal_load_dword a[%0], %2, %4 nt\n\tglobal_load_dword a[%1], %3, %4 offset:256 nt" ::"n"(K),
+                     "n"(K + kMaxDepth), "v"(byte_off + lane_off), "v"(byte_off + lane_off - lane_off / 4), "s"(base)
+                     : "memory", HS_RING_AGPRS);
+    }
+    template <int K, int kDepth>
+    static __device__ __forceinline__ void take(uint32_t& value, uint32_t& where) {
+        asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]"
+                     : "=v"(value), "=v"(where) : "n"(K), "n"(K + kMaxDepth), "n"(2 * (kDepth - 1)) : "memory");
+        where &= 0xffffffu;
+    }
+    template <int K, int kDepth>
+    static __device__ __forceinline__ void take2(uint32_t& value0, uint32_t& where0, uint32_t& value1, uint32_t& where1) {
+        asm volatile("s_waitcnt vmcnt(%8)\n\tv_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\t"
+                     "v_accvgpr_read_b32 %3, a[%7]"
+                     : "=v"(value0), "=v"(where0), "=v"(value1), "=v"(where1)
+                     : "n"(K), "n"(K + kMaxDepth), "n"(K + 1), "n"(K + 1 + kMaxDepth), "n"(2 * (kDepth - 2)) : "memory");
+        where0 &= 0xffffffu;
+        where1 &= 0xffffffu;
     }
 };
 // a pointer the compiler must keep in a scalar register pair
@@ -187,6 +214,7 @@ struct Consumer {
     typename Rows<kFloat>::sum_t lane_sum = 0;   // ... and the lane's private sum on it, flushed to LDS when the row changes
     float own_sum = 0;         // OWNER: the lane's fp32 sum on lane_row (accumulators are floats, touched by this wavefront only)
     uint32_t spare = 0;        // OWNER: the wavefront's own spare accumulator (local row nrows + wave)
+    uint32_t row_base = 0;     // OWNER with 24-bit position words: first local row of the wavefront's share (rows are stored relative to it)
     uint64_t t_flush = 0, t_barrier = 0;   // OWNER profiling build (kAblate & 256): clocks spent in end-of-unit flushes / at unit barriers
 };
 
@@ -196,10 +224,12 @@ __device__ uint64_t* g_owner_profile = nullptr;
 // One step (slot K of the ring).  Returns false when the block is finished.
 // kDelta: DELTA format, otherwise PAIRS; kDense: the block's rows are long (Block::flags & kBlockDenseRows): products are
 // summed in registers first (PAIRS: by the whole wavefront on one row; DELTA: by every lane along its own run).
-template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense, int K>
+template <bool kFloat, int kRing, int kAblate, int kDepth, bool kDense, int K>
 __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
     using R = Rows<kFloat>;
-    constexpr uint32_t kStride = kDelta ? kRecordBytes : kWaveStrideBytes;
+    constexpr bool kDelta = kRing == 1, k24 = kRing == 2;
+    constexpr uint32_t kStride = kDelta ? kRecordBytes : k24 ? kWaveStrideBytes24 : kWaveStrideBytes;
+    constexpr uint32_t kColMask = k24 ? kSubTileCols - 1u : 0xffffu, kRowShift = k24 ? kOwnerColBits : 16u;
     const uint32_t s = c.base + K;
     while (s == c.end) {               // this wavefront finished sub-tile u (possibly with no work in it)
         if (!kDelta && kDense && c.u + 1 == c.U && c.run_row != Consumer<kFloat>::kNoRow) {   // last sub-tile: hand the register sum over
@@ -220,7 +250,7 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
         c.head = true;
     }
     uint32_t mat, aux;                 // value word; PAIRS: row << 16 | col, DELTA: gap
-    Ring<kDelta>::template take<K, kDepth>(mat, aux);
+    Ring<kRing>::template take<K, kDepth>(mat, aux);
     if (kDelta) {
         // A lane owns a run of consecutive slots of the position-sorted unit.  The head record of every (unit, wavefront)
         // gives each lane its absolute start position (local_row * 8192 + local_col); every following record carries one
@@ -259,12 +289,12 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
             }
         }
     } else {
-        const uint32_t xv = (kAblate & 2) ? aux : c.xb[aux & 0xffffu];
+        const uint32_t xv = (kAblate & 2) ? aux : c.xb[aux & kColMask];
         if (kAblate & 1) {
             asm volatile("" ::"v"(xv), "v"(mat));
         } else {
             const typename R::prod_t prod = R::product(mat, xv);
-            const uint32_t row = aux >> 16;
+            const uint32_t row = aux >> kRowShift;
             if (kDense) {
                 // Chunks are row-sorted, so the whole wavefront is usually on ONE row, and stays on it for many chunks:
                 // keep a per-lane running sum in registers while the row does not change and touch the LDS accumulator
@@ -287,7 +317,7 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
             }
         }
     }
-    Ring<kDelta>::template issue<K>(c.stream, min(s + kDepth, c.last) * kStride, c.lane_off);
+    Ring<kRing>::template issue<K>(c.stream, min(s + kDepth, c.last) * kStride, c.lane_off);
     return true;
 }
 
@@ -299,6 +329,12 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
 // the same step flush different rows (the lower lane's old row is below its new row, which is at most the higher lane's first
 // row).  Only at the end of a unit, when every lane hands its last row over, can neighbours hold the same row: one segmented
 // wavefront reduction first.
+// 24-bit position words carry the row relative to the wavefront's share in 11 bits; 2047 = the wavefront's spare accumulator
+template <int kRing>
+__device__ __forceinline__ uint32_t owner_row(const Consumer<true>& c, uint32_t field) {
+    if (kRing != 2) return field;
+    return field == kOwnerSpareField ? c.spare : c.row_base + field;
+}
 __device__ __forceinline__ void owner_flush(float* ys32, uint32_t row, float sum) {
     float a = ys32[row];
     a += sum;
@@ -328,8 +364,9 @@ __device__ __forceinline__ void owner_end_of_unit(Consumer<true>& c) {
     c.own_sum = 0;
 }
 
-template <int kAblate, int kDepth, int K>
+template <int kRing, int kAblate, int kDepth, int K>
 __device__ __forceinline__ bool consume_step_owner(Consumer<true>& c) {
+    constexpr uint32_t kStep = kRing == 2 ? kChunkBytes24 : kChunkBytes;
     const uint32_t s = c.base + K;
     while (s == c.end) {               // this wavefront finished sub-tile u (possibly with no work in it)
         if (kAblate & 256) {
@@ -351,8 +388,8 @@ __device__ __forceinline__ bool consume_step_owner(Consumer<true>& c) {
         c.xb = c.xs + c.slot * kSubTileCols;
     }
     uint32_t mat, where;               // value word; local_row << 13 | local_col
-    Ring<false>::template take<K, kDepth>(mat, where);
-    const uint32_t row = where >> kOwnerColBits, col = where & (kSubTileCols - 1u);
+    Ring<kRing>::template take<K, kDepth>(mat, where);
+    const uint32_t row = owner_row<kRing>(c, where >> kOwnerColBits), col = where & (kSubTileCols - 1u);
     if (kAblate & 1) {
         const uint32_t xv = (kAblate & 2) ? where : c.xb[col];
         asm volatile("" ::"v"(xv), "v"(mat), "v"(row));
@@ -372,24 +409,25 @@ __device__ __forceinline__ bool consume_step_owner(Consumer<true>& c) {
         }
         c.own_sum += prod;
     }
-    Ring<false>::template issue<K>(c.stream, min(s + kDepth, c.last) * kChunkBytes, c.lane_off);
+    Ring<kRing>::template issue<K>(c.stream, min(s + kDepth, c.last) * kStep, c.lane_off);
     return true;
 }
 // Two steps of the same unit at once: the two x words and the accumulators of the (up to two) rows the lane leaves are four
 // independent LDS reads -- one round trip for two steps.  (The row entered at step K can be left at step K + 1; its accumulator is
 // not written by step K, whose write goes to the row left THERE, and no other lane's write of this pair can hit it: a higher lane
 // leaves rows >= this lane's last row, which this lane never leaves, a lower lane leaves rows below this lane's first row.)
-template <int kAblate, int kDepth, int K>
+template <int kRing, int kAblate, int kDepth, int K>
 __device__ __forceinline__ bool consume_pair_owner(Consumer<true>& c) {
+    constexpr uint32_t kStep = kRing == 2 ? kChunkBytes24 : kChunkBytes;
     const uint32_t s = c.base + K;
     if ((kAblate & 1) || s == c.end || s + 1 == c.end) {     // a unit ends at or inside the pair: one step at a time
-        if (!consume_step_owner<kAblate, kDepth, K>(c)) return false;
-        return consume_step_owner<kAblate, kDepth, K + 1>(c);
+        if (!consume_step_owner<kRing, kAblate, kDepth, K>(c)) return false;
+        return consume_step_owner<kRing, kAblate, kDepth, K + 1>(c);
     }
     uint32_t mat0, where0, mat1, where1;
-    Ring<false>::template take2<K, kDepth>(mat0, where0, mat1, where1);
-    const uint32_t row0 = where0 >> kOwnerColBits, col0 = where0 & (kSubTileCols - 1u);
-    const uint32_t row1 = where1 >> kOwnerColBits, col1 = where1 & (kSubTileCols - 1u);
+    Ring<kRing>::template take2<K, kDepth>(mat0, where0, mat1, where1);
+    const uint32_t row0 = owner_row<kRing>(c, where0 >> kOwnerColBits), col0 = where0 & (kSubTileCols - 1u);
+    const uint32_t row1 = owner_row<kRing>(c, where1 >> kOwnerColBits), col1 = where1 & (kSubTileCols - 1u);
     float* ys32 = reinterpret_cast<float*>(c.ys);
     const bool leaving0 = row0 != c.lane_row, leaving1 = row1 != row0;
     float old0 = 0.0f, old1 = 0.0f;
@@ -409,45 +447,47 @@ __device__ __forceinline__ bool consume_pair_owner(Consumer<true>& c) {
     }
     c.own_sum += prod1;
     c.lane_row = row1;
-    Ring<false>::template issue<K>(c.stream, min(s + kDepth, c.last) * kChunkBytes, c.lane_off);
-    Ring<false>::template issue<K + 1>(c.stream, min(s + 1 + kDepth, c.last) * kChunkBytes, c.lane_off);
+    Ring<kRing>::template issue<K>(c.stream, min(s + kDepth, c.last) * kStep, c.lane_off);
+    Ring<kRing>::template issue<K + 1>(c.stream, min(s + 1 + kDepth, c.last) * kStep, c.lane_off);
     return true;
 }
-template <int kAblate, int kDepth, int... Ks>
+template <int kRing, int kAblate, int kDepth, int... Ks>
 __device__ __forceinline__ bool consume_round_owner(Consumer<true>& c, std::integer_sequence<int, Ks...>) {
     static_assert(kDepth % 2 == 0, "steps are taken in pairs");
-    return ((Ks % 2 != 0 || consume_pair_owner<kAblate, kDepth, Ks>(c)) && ...);
+    return ((Ks % 2 != 0 || consume_pair_owner<kRing, kAblate, kDepth, Ks>(c)) && ...);
 }
 
-template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense, int... Ks>
+template <bool kFloat, int kRing, int kAblate, int kDepth, bool kDense, int... Ks>
 __device__ __forceinline__ bool consume_round(Consumer<kFloat>& c, std::integer_sequence<int, Ks...>) {
-    return (consume_step<kFloat, kDelta, kAblate, kDepth, kDense, Ks>(c) && ...);
+    return (consume_step<kFloat, kRing, kAblate, kDepth, kDense, Ks>(c) && ...);
 }
-template <bool kDelta, int... Ks>
+template <int kRing, int... Ks>
 __device__ __forceinline__ void prime_ring(const uint8_t* stream, uint32_t last, uint32_t stride, uint32_t lane_off, std::integer_sequence<int, Ks...>) {
-    (Ring<kDelta>::template issue<Ks>(stream, min(static_cast<uint32_t>(Ks), last) * stride, lane_off), ...);
+    (Ring<kRing>::template issue<Ks>(stream, min(static_cast<uint32_t>(Ks), last) * stride, lane_off), ...);
 }
 
 // Before the block's prologue: set the wavefront's consumer up and put the first kDepth loads in flight, so that the HBM
 // latency of the stream overlaps the accumulator zeroing and the first x sub-tile copy.
-template <bool kFloat, bool kDelta, int kDepth, bool kOwner = false>
+template <bool kFloat, int kRing, int kDepth, bool kOwner = false>
 __device__ __forceinline__ void consumer_begin(Consumer<kFloat>& c, const uint8_t* stream, UnitTable unit, uint32_t U, uint32_t wave,
                                                uint32_t lane, const uint32_t* xs, uint32_t ring, typename Rows<kFloat>::acc_t* ys, uint32_t nrows,
-                                               uint32_t total, uint32_t first_end) {
+                                               uint32_t total, uint32_t first_end, uint32_t row_base = 0) {
     static_assert(kDepth <= kMaxDepth, "the ring lives in a0..a31");
-    constexpr uint32_t kStride = kDelta ? kRecordBytes : kOwner ? kChunkBytes : kWaveStrideBytes;
+    constexpr bool kDelta = kRing == 1, k24 = kRing == 2;
+    constexpr uint32_t kStride = kDelta ? kRecordBytes : kOwner ? (k24 ? kChunkBytes24 : kChunkBytes) : k24 ? kWaveStrideBytes24 : kWaveStrideBytes;
     c.stream = scalar_pointer(stream);
     c.unit = unit; c.U = U; c.wave = wave; c.lane = lane; c.ring = ring; c.nrows = nrows;
-    c.lane_off = lane * Ring<kDelta>::kLaneBytes;
+    c.lane_off = lane * Ring<kRing>::kLaneBytes;
     c.last = total ? total - 1 : 0;    // prefetches past the end re-read the last chunk / record (no branch)
     c.xs = xs; c.xb = xs; c.ys = ys;
     c.end = first_end;
     c.lane_row = kOwner ? nrows + wave : nrows;
     c.spare = nrows + wave;
-    prime_ring<kDelta>(c.stream, c.last, kStride, c.lane_off, std::make_integer_sequence<int, kDepth>());
+    c.row_base = row_base;
+    prime_ring<kRing>(c.stream, c.last, kStride, c.lane_off, std::make_integer_sequence<int, kDepth>());
 }
 
-template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kDense, bool kOwner = false>
+template <bool kFloat, int kRing, int kAblate, int kDepth, bool kDense, bool kOwner = false>
 __device__ __forceinline__ void consumer_run(Consumer<kFloat>& c) {
     // The loader branch of the kernel leaves "LDS-DMA may be pending" in hipcc's wait-count bookkeeping, and that state
     // reaches this loop around the block loop and through the shared prologue: every LDS store on a conditional path below
@@ -458,9 +498,9 @@ __device__ __forceinline__ void consumer_run(Consumer<kFloat>& c) {
     const uint64_t t_begin = (kOwner && (kAblate & 256)) ? __builtin_readcyclecounter() : 0;
     for (;; c.base += kDepth) {
         if constexpr (kOwner) {
-            if (!consume_round_owner<kAblate, kDepth>(c, std::make_integer_sequence<int, kDepth>())) break;
+            if (!consume_round_owner<kRing, kAblate, kDepth>(c, std::make_integer_sequence<int, kDepth>())) break;
         } else {
-            if (!consume_round<kFloat, kDelta, kAblate, kDepth, kDense>(c, std::make_integer_sequence<int, kDepth>())) break;
+            if (!consume_round<kFloat, kRing, kAblate, kDepth, kDense>(c, std::make_integer_sequence<int, kDepth>())) break;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory", HS_RING_AGPRS);   // the clamped tail prefetches must land before the ring is reused
@@ -478,9 +518,9 @@ __device__ __forceinline__ void consumer_run(Consumer<kFloat>& c) {
 // kAblate (profiling builds only, HISPARSE_ABLATE): bit 0 = no LDS accumulate, bit 1 = no LDS gather,
 // bit 2 = no x sub-tile refill, bit 3 = no per-sub-tile barrier, bit 4 = no block prologue (zero + first sub-tile),
 // bit 5 = no result store, bit 6 = ignore unit boundaries.  Any non-zero value gives wrong results.
-// kDelta: the image is in the DELTA stream format (stream_tiles.h), otherwise PAIRS.
+// kRing: 1 = the image is in the DELTA stream format (stream_tiles.h), 0 = PAIRS / OWNER chunks with 32-bit position words, 2 = with 24-bit ones.
 // kOwner: the image is in the OWNER format (float only): 4-byte float accumulators, nrows + 14 of them.
-template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kOwner = false>
+template <bool kFloat, int kRing, int kAblate, int kDepth, bool kOwner = false>
 __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const Unit* __restrict__ units, const uint32_t* __restrict__ x,
                                                                   uint32_t* __restrict__ out, int32_t row_part_filter, uint32_t ring,
@@ -519,8 +559,8 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
         first_block = false;
         Consumer<kFloat> c;
         if (!loader && U > 0)
-            consumer_begin<kFloat, kDelta, kDepth, kOwner>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave],
-                                                           blk->first_end[wave]);
+            consumer_begin<kFloat, kRing, kDepth, kOwner>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave],
+                                                           blk->first_end[wave], (kOwner && kRing == 2) ? blk->pad[wave] : 0u);
         if (kOwner) {
             if (!(kAblate & 16)) for (uint32_t i = tid; i < nrows + kConsumerWaves; i += kThreads) reinterpret_cast<float*>(ys)[i] = 0.0f;
         } else
@@ -578,9 +618,9 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 }
             } else {
                 // ---- consumer wavefronts: stream elements, gather x, accumulate rows -----------------------------
-                if constexpr (kOwner) consumer_run<kFloat, kDelta, kAblate, kDepth, false, true>(c);
-                else if (blk->flags & kBlockDenseRows) consumer_run<kFloat, kDelta, kAblate, kDepth, true>(c);
-                else consumer_run<kFloat, kDelta, kAblate, kDepth, false>(c);
+                if constexpr (kOwner) consumer_run<kFloat, kRing, kAblate, kDepth, false, true>(c);
+                else if (blk->flags & kBlockDenseRows) consumer_run<kFloat, kRing, kAblate, kDepth, true>(c);
+                else consumer_run<kFloat, kRing, kAblate, kDepth, false>(c);
             }
         }
         // Every sub-tile barrier has passed -- but LDS atomics WITHOUT return value can still be queued behind it: with heavy
@@ -661,9 +701,9 @@ __global__ __launch_bounds__(256) void feedback_kernel(const uint32_t* __restric
     if (i < n) x[i] = feedback_word<kFloat>(y[i], scale, shift);
 }
 
-template <bool kFloat, bool kDelta, int kAblate, int kDepth, bool kOwner = false>
+template <bool kFloat, int kRing, int kAblate, int kDepth, bool kOwner = false>
 hipError_t configure_one(uint32_t lds_bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_rowblock_kernel<kFloat, kDelta, kAblate, kDepth, kOwner>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_rowblock_kernel<kFloat, kRing, kAblate, kDepth, kOwner>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
 }
 
@@ -677,7 +717,7 @@ int env_int(const char* name, int dflt) {
 // LDS plan: row accumulators first (64-bit integer sums / double sums + 1 spare; OWNER: floats + one spare per consumer
 // wavefront), then the ring of x buffers.
 uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t format) {
-    const uint32_t acc = format == kFormatOwner ? (max_block_rows + kConsumerWaves) * kOwnerAccumulatorBytes : (max_block_rows + 1) * kAccumulatorBytes;
+    const uint32_t acc = (format == kFormatOwner || format == kFormatOwner24) ? (max_block_rows + kConsumerWaves) * kOwnerAccumulatorBytes : (max_block_rows + 1) * kAccumulatorBytes;
     return ((acc + 15u) & ~15u) + ring_buffers * kBufBytes;
 }
 
@@ -686,7 +726,7 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t
 
 // (float, delta, ablate, depth): the product variants first, then the profiling builds (fixed point only)
 #define HS_FOR_EACH_VARIANT(X)                                                                                   \
-    X(true, false, 0, 8) X(true, true, 0, 8) X(false, false, 0, 8) X(false, true, 0, 8)                           \
+    X(true, 0, 0, 8) X(true, 1, 0, 8) X(false, 0, 0, 8) X(false, 1, 0, 8) X(true, 2, 0, 8) X(false, 2, 0, 8)         \
     X(false, false, 0, 16) X(false, true, 0, 16) X(false, false, 3, 8) X(false, true, 3, 8)                       \
     X(false, false, 4, 8) X(false, true, 4, 8) X(false, false, 8, 8) X(false, true, 8, 8) X(false, false, 15, 8) X(false, true, 15, 8) X(false, false, 31, 8) X(false, true, 31, 8)                     \
     X(false, false, 47, 8) X(false, true, 47, 8) X(false, false, 79, 8) X(false, true, 79, 8)                     \
@@ -701,20 +741,25 @@ hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
 #define X(A) if ((e = configure_one<true, false, A, 8, true>(lds_bytes)) != hipSuccess) return e;
     HS_FOR_EACH_OWNER_VARIANT(X)
 #undef X
-    if ((e = configure_one<true, false, 0, 16, true>(lds_bytes)) != hipSuccess) return e;
-    if ((e = configure_one<true, false, 0, 12, true>(lds_bytes)) != hipSuccess) return e;
+    if ((e = configure_one<true, 2, 0, 8, true>(lds_bytes)) != hipSuccess) return e;
     return configure_bitmap_kernels(lds_bytes);
 }
 
 hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.num_workgroups == 0) return hipSuccess;
     if (a.format == kFormatBitmap) return launch_spmv_bitmap(is_float, a, stream);
-    const bool delta = a.format == kFormatDelta;
+    const int ring = a.format == kFormatDelta ? 1 : (a.format == kFormatPairs24 || a.format == kFormatOwner24) ? 2 : 0;
     const dim3 grid(a.num_workgroups), block(kThreads);
     const uint32_t x_base = a.lds_bytes - a.ring_buffers * kBufBytes;
     // profiling aids: HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the prefetch depth
     static const int ablate = env_int("HISPARSE_ABLATE", 0), depth = env_int("HISPARSE_DEPTH", 8);
     bool launched = false;
+    if (a.format == kFormatOwner24) {
+        if (!is_float || ablate != 0 || depth != 8) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((spmv_rowblock_kernel<true, 2, 0, 8, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out,
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);
+        return hipGetLastError();
+    }
     if (a.format == kFormatOwner) {
         if (!is_float) return hipErrorInvalidValue;
         // profiling build: HISPARSE_ABLATE=256 HISPARSE_TIMELINE_OUT=file -> per-wavefront clock totals, accumulated over the
@@ -735,16 +780,6 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
         HS_FOR_EACH_OWNER_VARIANT(X)
         }
 #undef X
-        if (!launched && ablate == 0 && depth == 16) {
-            hipLaunchKernelGGL((spmv_rowblock_kernel<true, false, 0, 16, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out,
-                               a.row_part_filter, a.ring_buffers, x_base, a.part_heads);
-            launched = true;
-        }
-        if (!launched && ablate == 0 && depth == 12) {
-            hipLaunchKernelGGL((spmv_rowblock_kernel<true, false, 0, 12, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out,
-                               a.row_part_filter, a.ring_buffers, x_base, a.part_heads);
-            launched = true;
-        }
         if (ablate == 256 && profile && a.num_workgroups <= 4096) {
             if (const char* path = std::getenv("HISPARSE_TIMELINE_OUT")) {
                 (void)hipStreamSynchronize(stream);
@@ -759,7 +794,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
         return launched ? hipGetLastError() : hipErrorInvalidValue;
     }
 #define X(F, T, A, D)                                                                                                           \
-    if (!launched && is_float == F && delta == T && ablate == A && depth == D) {                                     \
+    if (!launched && is_float == F && ring == int(T) && ablate == A && depth == D) {                                     \
         hipLaunchKernelGGL((spmv_rowblock_kernel<F, T, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \
                            a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                   \
         launched = true;                                                                                                        \

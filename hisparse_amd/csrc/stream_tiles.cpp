@@ -211,6 +211,10 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             }
             for (; w <= kConsumerWaves; ++w) wr[w] = n;
             wr[kConsumerWaves] = n;
+            // no share longer than what an 11-bit relative row can address (24-bit position words): 14 x 2046 >= any block
+            for (uint32_t k = 1; k <= kConsumerWaves; ++k) wr[k] = std::min(wr[k], wr[k - 1] + kAux24MaxRows);
+            wr[kConsumerWaves] = n;
+            for (uint32_t k = kConsumerWaves; k-- > 1;) wr[k] = std::max(wr[k], wr[k + 1] > kAux24MaxRows ? wr[k + 1] - kAux24MaxRows : 0u);
         });
     }
 
@@ -350,6 +354,37 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         }
     }
     timer.lap("sort units");
+    // ---- 24-bit position words (stream_tiles.h: PAIRS24 / OWNER24): 7 bytes per element where 11 bits of row are enough ----------
+    bool aux24 = false;
+    {
+        // Opt-in (HISPARSE_AUX_BITS=24): measured SLOWER than the 8-byte forms although it streams 12 % fewer bytes (mouse_gene 40.8 vs
+        // 39.7 us, ogbn-products 281 vs 266 us): a step becomes two loads (one of them unaligned) instead of one dwordx2, and the
+        // kernels are bound by the number of memory requests a CU keeps in flight, not by the bytes.
+        const char* bits = std::getenv("HISPARSE_AUX_BITS");
+        const bool allowed = bits && std::atoi(bits) == 24;
+        if (owner) {
+            aux24 = allowed;
+            for (uint32_t b = 0; b < NR && aux24; ++b)
+                for (uint32_t w = 0; w < kConsumerWaves; ++w)
+                    if (wave_row[size_t(b) * (kConsumerWaves + 1) + w + 1] - wave_row[size_t(b) * (kConsumerWaves + 1) + w] > kAux24MaxRows) aux24 = false;
+        } else if (!delta) {
+            aux24 = allowed && out.max_block_rows <= kAux24MaxRows;
+        }
+        if (aux24) out.format = owner ? kFormatOwner24 : kFormatPairs24;
+    }
+    const uint32_t chunk_bytes = aux24 ? kChunkBytes24 : kChunkBytes, wave_stride = chunk_bytes * kConsumerWaves;
+    // one element slot of a chunk: value word + position word (32-bit: interleaved pairs; 24-bit: 64 values, then 64 x 3 bytes)
+    auto put = [&](uint8_t* chunk, uint32_t lane, uint32_t value, uint32_t where) {
+        if (aux24) {
+            reinterpret_cast<uint32_t*>(chunk)[lane] = value;
+            uint8_t* a = chunk + kWaveLanes * 4 + lane * 3;
+            a[0] = uint8_t(where); a[1] = uint8_t(where >> 8); a[2] = uint8_t(where >> 16);
+        } else {
+            reinterpret_cast<uint32_t*>(chunk)[2 * lane] = value;
+            reinterpret_cast<uint32_t*>(chunk)[2 * lane + 1] = where;
+        }
+    };
+
     // ---- per block: deal every unit's 64-slot chunks to the consumer wavefronts round-robin; lay out the streams -------
     std::vector<uint64_t> block_nnz(NB, 0);   // weight of a block for the workgroup assignment
     uint64_t image_bytes = 0;
@@ -398,17 +433,19 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         for (uint32_t w = 0; w < kConsumerWaves; ++w) block_nnz[bi] += pos[w];   // the block's weight: wavefront steps, heads included
         // the kernel addresses a wavefront's stream with a 32-bit byte offset from Block::wave_offset
         for (uint32_t w = 0; w < kConsumerWaves; ++w)
-            if (uint64_t(pos[w]) * (delta ? kRecordBytes : owner ? kChunkBytes : kWaveStrideBytes) >= (1ull << 32)) { error = "row block stream exceeds 4 GiB"; return false; }
+            if (uint64_t(pos[w]) * (delta ? kRecordBytes : owner ? chunk_bytes : wave_stride) >= (1ull << 32)) { error = "row block stream exceeds 4 GiB"; return false; }
+        if (owner && aux24)
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) blk.pad[w] = wave_row[size_t(range_of_block[bi]) * (kConsumerWaves + 1) + w];
         if (delta || owner) {      // every wavefront's steps are contiguous
             for (uint32_t w = 0; w < kConsumerWaves; ++w) {
                 blk.wave_offset[w] = image_bytes;
-                image_bytes += uint64_t(pos[w]) * (delta ? kRecordBytes : kChunkBytes);
+                image_bytes += uint64_t(pos[w]) * (delta ? kRecordBytes : chunk_bytes);
             }
         } else {
             // chunks are stored in dealing order (global chunk g of the block at g * 512 bytes; wavefront w consumes
             // g = w, w + 14, w + 28, ...): the 14 wavefronts of a workgroup sweep ONE contiguous region together
-            for (uint32_t w = 0; w < kConsumerWaves; ++w) blk.wave_offset[w] = image_bytes + uint64_t(w) * kChunkBytes;
-            image_bytes += uint64_t(chunk_counter) * kChunkBytes;
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) blk.wave_offset[w] = image_bytes + uint64_t(w) * chunk_bytes;
+            image_bytes += uint64_t(chunk_counter) * chunk_bytes;
         }
     }
 
@@ -447,13 +484,16 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             for (uint32_t w = 0; w < kConsumerWaves; ++w) {
                 const uint32_t steps = up.run_len[w], n = up.own_begin[w + 1] - up.own_begin[w];
                 const uint64_t* mine = e + up.own_begin[w];
-                uint8_t* base = image + blk.wave_offset[w] + uint64_t(up.start_step[w]) * kChunkBytes;
+                uint8_t* base = image + blk.wave_offset[w] + uint64_t(up.start_step[w]) * chunk_bytes;
+                const uint32_t row_base = aux24 ? blk.pad[w] : 0u;            // 24-bit words: rows relative to the wavefront's share
+                const uint32_t spare = aux24 ? kOwnerSpareField : blk.nrows + w;
                 for (uint32_t st = 0; st < steps; ++st) {
-                    uint32_t* chunk = reinterpret_cast<uint32_t*>(base + uint64_t(st) * kChunkBytes);
+                    uint8_t* chunk = base + uint64_t(st) * chunk_bytes;
                     for (uint32_t l = 0; l < kWaveLanes; ++l) {
                         const uint64_t i = uint64_t(l) * steps + st;
-                        chunk[2 * l] = i < n ? uint32_t(mine[i]) : 0u;
-                        chunk[2 * l + 1] = i < n ? uint32_t(mine[i] >> 32) : (blk.nrows + w) << kOwnerColBits;
+                        const uint32_t pos = i < n ? uint32_t(mine[i] >> 32) : 0u;
+                        put(chunk, l, i < n ? uint32_t(mine[i]) : 0u,
+                            i < n ? (pos - (row_base << kOwnerColBits)) : spare << kOwnerColBits);
                     }
                 }
             }
@@ -477,14 +517,13 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 const uint32_t g = up.base + c, w = g % kConsumerWaves;
                 const uint32_t first = up.base + (w + kConsumerWaves - up.base % kConsumerWaves) % kConsumerWaves;  // first chunk of wave w in this unit
                 const uint32_t step = up.start_step[w] + (g - first) / kConsumerWaves;
-                uint32_t* slot = reinterpret_cast<uint32_t*>(image + blk.wave_offset[w] + uint64_t(step) * kWaveStrideBytes + lane * 8);
+                uint8_t* chunk = image + blk.wave_offset[w] + uint64_t(step) * wave_stride;
+                const uint32_t row_shift = aux24 ? kOwnerColBits : 16u;
                 if (i < up.n) {
                     const uint32_t pos = uint32_t(e[i] >> 32);
-                    slot[0] = uint32_t(e[i]);
-                    slot[1] = ((pos / kSubTileCols) << 16) | (pos % kSubTileCols);
+                    put(chunk, lane, uint32_t(e[i]), ((pos / kSubTileCols) << row_shift) | (pos % kSubTileCols));
                 } else {            // padding: zero value aimed at the block's scratch row
-                    slot[0] = 0;
-                    slot[1] = blk.nrows << 16;
+                    put(chunk, lane, 0u, blk.nrows << row_shift);
                 }
             }
         });

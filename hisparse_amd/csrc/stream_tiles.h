@@ -90,7 +90,16 @@ constexpr uint32_t kBridgeAdvance = 0xffffu;                  // ... which advan
 constexpr double kDeltaMinMeanGap = 2048.0;                   // denser matrices: PAIRS wins (measured: mouse_gene 43.6 vs 48.0 us, transformer-50 18.6 vs 24.4)
 constexpr double kDeltaMaxMeanGap = 20000.0;                  // sparser matrices: > 4 % of the gaps need bridges, PAIRS wins
 constexpr double kDenseMeanGap = 2048.0;                      // DELTA blocks denser than this sum per lane in registers (kBlockDenseRows)
-enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1, kFormatBitmap = 2, kFormatOwner = 3 };
+enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1, kFormatBitmap = 2, kFormatOwner = 3, kFormatPairs24 = 4, kFormatOwner24 = 5 };
+// PAIRS24 / OWNER24: the same two formats with a 24-bit position word -- 7 instead of 8 bytes per element.  A wavefront step is
+// 448 bytes: 64 value dwords, then 64 x 3 bytes (local_row << 13 | local_col, little endian), which the kernel reads as unaligned
+// dwords at byte 256 + 3 * lane.  11 bits of row: PAIRS24 whenever no block has more than 2046 rows (local row 2047 would collide
+// with nothing, but nrows itself -- the spare accumulator -- must fit); OWNER24 stores the row RELATIVE to the wavefront's share
+// (Block::pad[wave] = first local row of the share, shares capped at 2046 rows), 2047 = the wavefront's spare accumulator.
+constexpr uint32_t kChunkBytes24 = kWaveLanes * 7;             // 448
+constexpr uint32_t kWaveStrideBytes24 = kChunkBytes24 * kConsumerWaves;
+constexpr uint32_t kAux24MaxRows = 2046;
+constexpr uint32_t kOwnerSpareField = 2047;
 // OWNER format (float modes, hyper-sparse matrices: ogbn-products, 2.4 M columns, 50 non-zeros per row): the cost there is not the
 // element stream but x -- every row block pulls the WHOLE vector through its CU, sub-tile by sub-tile, so the staged x volume is
 // (rows / rows per block) x 4 cols bytes (3.1 GB per SpMV with 8191-row blocks against 1 GB of matrix).  Rows per block are

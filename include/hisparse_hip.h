@@ -57,7 +57,7 @@ enum {
 enum { HS_IMPL_FIXED = 0, HS_IMPL_FLOAT_POB = 1, HS_IMPL_FLOAT_STALL = 2 };
 
 /* device-private stream formats (hisparse_amd/csrc/stream_tiles.h) */
-enum { HS_STREAM_PAIRS = 0, HS_STREAM_DELTA = 1, HS_STREAM_BITMAP = 2, HS_STREAM_OWNER = 3 };
+enum { HS_STREAM_PAIRS = 0, HS_STREAM_DELTA = 1, HS_STREAM_BITMAP = 2, HS_STREAM_OWNER = 3, HS_STREAM_PAIRS24 = 4, HS_STREAM_OWNER24 = 5 };
 
 typedef struct hs_context hs_context;
 
@@ -73,7 +73,7 @@ typedef struct {
     uint32_t num_compute_units; /* of the device */
     uint32_t col_slices;        /* column slices (1 = none; > 1 adds the small combine pass) */
     uint32_t ring_buffers;      /* x sub-tile buffers in the LDS ring */
-    uint32_t stream_format;     /* HS_STREAM_PAIRS (8 B per element), HS_STREAM_DELTA (6 B per slot) or HS_STREAM_BITMAP (4 B + 1 bit per column) or HS_STREAM_OWNER (8 B per element, float accumulators), chosen per matrix */
+    uint32_t stream_format;     /* HS_STREAM_PAIRS (8 B per element), HS_STREAM_DELTA (6 B per slot) or HS_STREAM_BITMAP (4 B + 1 bit per column) HS_STREAM_OWNER (8 B per element, float accumulators) or the 7-byte forms of PAIRS / OWNER, chosen per matrix */
     double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
 } hs_stats;
 

@@ -18,12 +18,15 @@ pytestmark = pytest.mark.gpu
 IMPLS = [0, 1, 2]
 
 
-@pytest.fixture(autouse=True, params=["pairs", "delta", "delta-lane-sums", "delta-no-lane-sums", "bitmap", "owner"])
+@pytest.fixture(autouse=True, params=["pairs", "delta", "delta-lane-sums", "delta-no-lane-sums", "bitmap", "owner", "pairs24", "owner24"])
 def stream_format(request, monkeypatch):
     # every parity test runs once per device stream format (hisparse_amd/csrc/stream_tiles.h); DELTA additionally with the
     # per-lane register sums of long-row blocks forced on and off (by default the block's density decides); BITMAP (normally
     # chosen for dense rows only) forced onto every matrix small enough for a mask per 64 columns of every row
-    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", request.param.split("-")[0])
+    # "pairs24" / "owner24": the opt-in 7-byte forms (HISPARSE_AUX_BITS=24), taken where the row counts allow
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", request.param.split("-")[0].replace("24", ""))
+    if request.param in ("pairs24", "owner24"):
+        monkeypatch.setenv("HISPARSE_AUX_BITS", "24")
     if request.param.endswith("-lane-sums"):
         monkeypatch.setenv("HISPARSE_ROW_RUNS", "0" if "-no-" in request.param else "1")
     return request.param
@@ -50,7 +53,8 @@ def _run_case(impl, m, vb, ob, skip, seed):
     if forced == "owner" and impl == 0:
         forced = "pairs"                 # OWNER is a float format (4-byte float accumulators); fixed point keeps its 64-bit atomics
     if forced != "bitmap" or cp.num_rows * ((cp.num_cols + 63) // 64) * 8 <= (1 << 30):    # a forced bitmap gives way above 1 GiB of masks
-        assert device.STREAM_FORMATS[stats["stream_format"]] == forced
+        got_format = device.STREAM_FORMATS[stats["stream_format"]]
+        assert got_format == forced or (os.environ.get("HISPARSE_AUX_BITS") == "24" and got_format == forced + "24")
     if impl == 0:
         assert np.array_equal(got, want), f"fixed-point mismatch at {np.nonzero(got != want)[0][:8]}"
         assert np.array_equal(again, want)
@@ -400,6 +404,7 @@ def test_full_size_exact_known_answer(name, stream_format, monkeypatch):
     if stream_format != "pairs":
         pytest.skip("one pass over the big matrices, in the format the library picks by itself")
     monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    monkeypatch.delenv("HISPARSE_AUX_BITS", raising=False)
     import scipy.sparse as sp
     from hisparse_amd import datasets
     cfg, csr = datasets.load(name)
@@ -441,6 +446,7 @@ def test_dense_rows_pick_bitmap(impl, rows, cols, density, stream_format, monkey
     if stream_format != "pairs":
         pytest.skip("format chosen by the library here; one pass")
     monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    monkeypatch.delenv("HISPARSE_AUX_BITS", raising=False)
     m = cases.random_csr(rows, cols, density, 17, impl)
     if impl != 0:
         m.data *= np.float32(0.05)       # pruned-NN weights (datasets.py: N(0, 0.05)): the ORACLE's fp32 running sum of 16 K unit-sized

@@ -12,10 +12,13 @@ import cases
 import tile_emulator
 
 
-@pytest.fixture(autouse=True, params=["pairs", "delta", "bitmap"])
+@pytest.fixture(autouse=True, params=["pairs", "delta", "bitmap", "pairs24"])
 def stream_format(request, monkeypatch):
-    # every test of this module runs once per device stream format (stream_tiles.h)
-    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", request.param)
+    # every test of this module runs once per device stream format (stream_tiles.h); "pairs24" = PAIRS with 24-bit position words
+    # (opt-in, HISPARSE_AUX_BITS=24; taken whenever no block has more than 2046 rows)
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", request.param[:5] if request.param.startswith("pairs") else request.param)
+    if request.param == "pairs24":
+        monkeypatch.setenv("HISPARSE_AUX_BITS", "24")
     return request.param
 
 
@@ -82,9 +85,9 @@ def test_structure_invariants(stream_format):
         assert (np.diff(es, axis=0) >= 0).all()
         assert (b["total_steps"] == es[-1]).all() and (b["first_end"] == es[0]).all() and b["first_col0"] == units["col0"][b["unit_begin"]] and b["first_ncols"] == units["ncols"][b["unit_begin"]]
     assert t["format"] == stream_format and t["elements"] >= t["nnz"]
-    if stream_format == "pairs":
-        # bytes: 8 per element slot, padding below 64 slots per unit
-        assert len(t["image"]) == t["elements"] * 8
+    if stream_format in ("pairs", "pairs24"):
+        # bytes: 8 (7 with 24-bit position words) per element slot, padding below 64 slots per unit
+        assert len(t["image"]) == t["elements"] * (8 if stream_format == "pairs" else 7)
         assert t["elements"] - t["nnz"] < 64 * len(units)
     else:
         # bytes: 384 per record = 64 x (u32 value + u16 gap); one head record per (unit, wavefront) that has work
@@ -139,7 +142,7 @@ def test_format_choice(monkeypatch):
         cp = host.format_matrix(csr, 0, skip_empty_rows=True)
         gap = cp.num_rows * cp.num_cols / cp.nnz
         assert (2048 <= gap <= 20000) == (want == "delta"), gap
-        assert build(cp, 0, 16)["format"] == want
+        assert build(cp, 0, 16)["format"][:5] == want          # "pairs" or its 7-byte form "pairs24" (blocks of <= 2046 rows)
     # inside a DELTA matrix, blocks of heavy rows are flagged for per-lane register sums, the sparse bulk is not
     csr = host.CSRMatrix.generate("powerlaw", 30000, 60000, a=600000, b=0.8, c=1.0, seed=3)
     cp = host.format_matrix(csr, 0, skip_empty_rows=True)
@@ -341,6 +344,7 @@ def test_owner_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypa
     """Hyper-sparse float matrices pick the OWNER format: float accumulators, wavefront-private rows (checked inside the emulator:
     sorted lane-major runs, one owner per row, padding at the wavefront's spare accumulator); y matches the oracle."""
     monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    monkeypatch.setenv("HISPARSE_AUX_BITS", "24")
     if slices:
         monkeypatch.setenv("HISPARSE_COL_SLICES", str(slices))
     csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=nnz, b=0.5, c=2.0, seed=12)
@@ -348,8 +352,12 @@ def test_owner_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypa
     assert cp.num_rows * cp.num_cols / cp.nnz > 20000
     xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 12, impl))
     t = build(cp, impl, wgs)
-    assert t["format"] == "owner" and t["nnz"] == cp.nnz and t["elements"] >= cp.nnz
-    assert len(t["image"]) == t["elements"] * 8
+    assert t["format"] == "owner24" and t["nnz"] == cp.nnz and t["elements"] >= cp.nnz       # 24-bit position words: shares <= 2046 rows
+    assert len(t["image"]) == t["elements"] * 7
+    monkeypatch.delenv("HISPARSE_AUX_BITS")
+    t32 = build(cp, impl, wgs)
+    assert t32["format"] == "owner" and len(t32["image"]) == t32["elements"] * 8
+    assert cases.float_close(tile_emulator.run(t32, impl, xw, cp.num_rows), oracle_y(cp, impl, xw))
     assert t["ring_buffers"] in (2, 3, 4) and (not slices or t["col_slices"] == slices)
     assert (t["max_block_rows"] + 14) * 4 + t["ring_buffers"] * 32768 <= 160 * 1024
     got = tile_emulator.run(t, impl, xw, cp.num_rows)
@@ -358,4 +366,4 @@ def test_owner_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypa
     monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "owner")
     csr0 = host.CSRMatrix.generate("powerlaw", 9000, 70000, a=20000, b=0.5, c=1.0, seed=12)
     cp0 = host.format_matrix(csr0, 0, skip_empty_rows=True)
-    assert build(cp0, 0, 4)["format"] == "pairs"
+    assert build(cp0, 0, 4)["format"] in ("pairs", "pairs24")

@@ -24,8 +24,21 @@ def _accumulate(ys, is_float, row, val, xv):
         np.add.at(ys, row, _q_mul(val, xv))
 
 
-def _block_pairs(image, blk, units, x_words, ys, is_float):
+def _chunk(image, at, aux24):
+    """(value words, position words) of one 64-slot chunk: 512 bytes of {value, position} pairs, or -- 24-bit position words --
+    448 bytes = 64 value dwords followed by 64 x 3 bytes."""
+    if not aux24:
+        c = image[at: at + CHUNK_BYTES].view(np.uint32).reshape(WAVE, 2)
+        return c[:, 0], c[:, 1]
+    val = image[at: at + 256].view(np.uint32)
+    a = image[at + 256: at + 448].reshape(WAVE, 3).astype(np.uint32)
+    return val, a[:, 0] | (a[:, 1] << 8) | (a[:, 2] << 16)
+
+
+def _block_pairs(image, blk, units, x_words, ys, is_float, aux24=False):
     nrows = int(blk["nrows"])
+    cb, shift, mask = (448, 13, 8191) if aux24 else (CHUNK_BYTES, 16, 0xFFFF)
+    assert not aux24 or nrows <= 2046
     step = [0] * CONSUMERS
     for u in range(int(blk["unit_begin"]), int(blk["unit_end"])):
         unit = units[u]
@@ -35,10 +48,8 @@ def _block_pairs(image, blk, units, x_words, ys, is_float):
             end = int(unit["end_step"][w])
             base = int(blk["wave_offset"][w])
             for s in range(step[w], end):
-                at = base + s * CHUNK_BYTES * CONSUMERS
-                chunk = image[at: at + CHUNK_BYTES].view(np.uint32).reshape(WAVE, 2)
-                val, cr = chunk[:, 0], chunk[:, 1]
-                col, row = (cr & 0xFFFF).astype(np.int64), (cr >> 16).astype(np.int64)
+                val, cr = _chunk(image, base + s * cb * CONSUMERS, aux24)
+                col, row = (cr & mask).astype(np.int64), (cr >> shift).astype(np.int64)
                 assert (col < ncols).all() and (row <= nrows).all()
                 assert (val[row == nrows] == 0).all()                 # padding aims a zero at the spare accumulator
                 _accumulate(ys, is_float, row, val, xt[col])
@@ -83,7 +94,7 @@ def _block_delta(image, blk, units, x_words, ys, is_float):
             step[w] = end
 
 
-def _block_owner(image, blk, units, x_words, ys, is_float):
+def _block_owner(image, blk, units, x_words, ys, is_float, aux24=False):
     """OWNER (float only): per-wavefront contiguous 512-byte chunks of {value, row << 13 | col}; lane l holds a consecutive run of
     the wavefront's share, rows never decrease from lane to lane and step to step, no row is shared between wavefronts, padding
     aims a zero at the wavefront's own spare accumulator nrows + w."""
@@ -100,9 +111,14 @@ def _block_owner(image, blk, units, x_words, ys, is_float):
             base = int(blk["wave_offset"][w])
             if end == step[w]:
                 continue
-            data = image[base + step[w] * CHUNK_BYTES: base + end * CHUNK_BYTES].view(np.uint32).reshape(end - step[w], WAVE, 2)
-            val, where = data[:, :, 0], data[:, :, 1]
+            cb = 448 if aux24 else CHUNK_BYTES
+            pairs = [_chunk(image, base + st * cb, aux24) for st in range(step[w], end)]
+            val, where = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
             row, col = (where >> 13).astype(np.int64), (where & 8191).astype(np.int64)
+            if aux24:       # rows relative to the wavefront's share (Block.pad[w]); 2047 = the wavefront's spare accumulator
+                share0 = int(blk["pad"][w])
+                assert ((row <= 2046) | (row == 2047)).all()
+                row = np.where(row == 2047, nrows + w, row + share0)
             order = row.T.reshape(-1)                                   # lane-major: lane 0's run, then lane 1's, ...
             assert (np.diff(order) >= 0).all()                          # sorted by row across (lane, step)
             pad = row == nrows + w
@@ -155,7 +171,8 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
     image, blocks, units = tiles["image"], tiles["blocks"], tiles["units"]
     delta = tiles["format"] == "delta"
     bitmap = tiles["format"] == "bitmap"
-    owner = tiles["format"] == "owner"
+    owner = tiles["format"] in ("owner", "owner24")
+    aux24 = tiles["format"] in ("pairs24", "owner24")
     y = np.zeros(num_rows, dtype=np.uint32) if y_init is None else y_init.copy()
     slices = int(tiles.get("col_slices", 1))
     out = y if slices == 1 else np.zeros(slices * num_rows, dtype=np.uint32)   # per-slice partial results
@@ -180,7 +197,10 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
             assert out0 % num_rows == row0 and out0 // num_rows < slices
             touched[row0: row0 + nrows] = True
             ys = np.zeros(nrows + 1, dtype=np.float64 if is_float else np.uint64)     # double sums of float products
-            (_block_owner if owner else _block_bitmap if bitmap else _block_delta if delta else _block_pairs)(image, blk, units, x_words, ys, is_float)
+            if owner or (not bitmap and not delta):
+                (_block_owner if owner else _block_pairs)(image, blk, units, x_words, ys, is_float, aux24)
+            else:
+                (_block_bitmap if bitmap else _block_delta)(image, blk, units, x_words, ys, is_float)
             if is_float:
                 out[out0: out0 + nrows] = ys[:nrows].astype(np.float32).view(np.uint32)
             else:

@@ -41,6 +41,7 @@ def model(name, cp=None, impl=None):
     t = device.build_tiles(cp, impl, cp.ob_bank, cp.vb_bank, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, CUS)
     blocks, units = t["blocks"], t["units"]
     fmt, slices, ring = t["format"], t["col_slices"], t["ring_buffers"]
+    fmt = fmt[:-2] if fmt.endswith("24") else fmt       # 7-byte forms of PAIRS / OWNER: same machinery, fewer stream bytes
     groups = t["num_workgroups"]
     if fmt == "bitmap":     # no units, no x ring: a front, the stream, a tail (per block of the busiest workgroup)
         per_wg = max(t["wg_first"][g + 1] - t["wg_first"][g] for g in range(groups))
@@ -49,7 +50,7 @@ def model(name, cp=None, impl=None):
         return cp, impl, t, parts
     # critical workgroup: steps serialised by the per-unit barrier (sum over units of the slowest wavefront)
     es = units["end_step"].astype(np.int64)
-    step_bytes = 384 if fmt == "delta" else 512
+    step_bytes = 384 if fmt == "delta" else 448 if t["format"].endswith("24") else 512
     sync = np.zeros(groups)
     ideal = np.zeros(groups)
     nunits = np.zeros(groups)
