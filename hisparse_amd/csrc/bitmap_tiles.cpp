@@ -94,7 +94,7 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     out.col_slices = slices;
     out.ring_buffers = 0;
     out.blocks.assign(NB, Block{});
-    out.units.assign(size_t(NB) * kBitmapWaves, Unit{});
+    out.units.assign(size_t(NB) * kBitmapWaves * kBitmapRunSlots, Unit{});
     std::vector<uint64_t> block_nnz(NB, 0), block_base(NB + 1, 0), block_weight(NB, 0);
     // non-zeros of every block (row range x slice of groups)
     parallel_for(NB, [&](size_t bi) {
@@ -146,8 +146,8 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         blk.row_part = rg.row_part;
         blk.flags = 0;
         blk.out_offset = slices > 1 ? k * num_rows + rg.row0 : rg.row0;
-        blk.unit_begin = uint32_t(bi * kBitmapWaves);
-        blk.unit_end = blk.unit_begin + kBitmapWaves;
+        blk.unit_begin = uint32_t(bi * kBitmapWaves * kBitmapRunSlots);
+        blk.unit_end = blk.unit_begin + kBitmapWaves * kBitmapRunSlots;
         blk.first_col0 = uint32_t(c0);
         blk.first_ncols = GS;
         const uint32_t pieces = pieces_of(rg.nrows), stride = row_stride(GS, pieces);
@@ -178,9 +178,8 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         value_at[rg.nrows] = at;
         // wavefront runs.  Few rows: every row is cut into floor(16 / nrows) runs of equal group count.  Many rows: contiguous whole
         // rows per wavefront, balanced by steps-plus-non-zeros.
-        WaveSeg* seg = reinterpret_cast<WaveSeg*>(out.units.data() + blk.unit_begin);
         auto set_seg = [&](uint32_t w, uint32_t r0, uint32_t r1, uint32_t g0, uint32_t g1) {
-            WaveSeg& s = seg[w];
+            WaveSeg& s = *reinterpret_cast<WaveSeg*>(out.units.data() + blk.unit_begin + size_t(w) * kBitmapRunSlots);
             s.row_begin = r0; s.row_end = r1; s.g_begin = g0; s.g_end = g1;
             uint64_t v = value_word0 + value_at[std::min(r0, rg.nrows)];
             if (r1 == r0 + 1 && g0 > 0)        // partial row: values of the groups in front of g0
@@ -188,6 +187,11 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
             const uint64_t mw = mask_word0 + (r0 < rg.nrows ? mask_index(r0, r1 == r0 + 1 && g0 < GS ? g0 : 0) : 0);
             s.value_lo = uint32_t(v); s.value_hi = uint32_t(v >> 32);
             s.mask_lo = uint32_t(mw); s.mask_hi = uint32_t(mw >> 32);
+            // the run's first 32 masks once more, right behind the descriptor (zero beyond the first row-run's end)
+            uint64_t* head = reinterpret_cast<uint64_t*>(&s + 1);
+            const uint32_t steps = r1 > r0 ? g1 - g0 : 0;
+            for (uint32_t j = 0; j < kBitmapMaskBatch; ++j)
+                head[j] = j < steps ? reinterpret_cast<const uint64_t*>(out.image.data())[mw + j] : 0;
         };
         if (pieces > 1) {
             uint32_t w = 0;
@@ -215,11 +219,12 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     assign_workgroups(out, block_weight, G, RP, mine);
     chain_blocks(out, mine, RP);
     // the kernel finds the runs of block i at units[16 i ..] without reading the block first: store them in final block order
+    constexpr uint32_t kPerBlock = kBitmapWaves * kBitmapRunSlots;
     std::vector<Unit> moved(out.units.size());
     for (uint32_t i = 0; i < NB; ++i) {
-        std::copy(out.units.begin() + out.blocks[i].unit_begin, out.units.begin() + out.blocks[i].unit_end, moved.begin() + size_t(i) * kBitmapWaves);
-        out.blocks[i].unit_begin = i * kBitmapWaves;
-        out.blocks[i].unit_end = (i + 1) * kBitmapWaves;
+        std::copy(out.units.begin() + out.blocks[i].unit_begin, out.units.begin() + out.blocks[i].unit_end, moved.begin() + size_t(i) * kPerBlock);
+        out.blocks[i].unit_begin = i * kPerBlock;
+        out.blocks[i].unit_end = (i + 1) * kPerBlock;
     }
     out.units.swap(moved);
     return true;

@@ -50,7 +50,8 @@ struct Batch {
 // 64 = timeline, 256 = nt cache policy on the value loads (correct results)
 template <bool kFloat, int kAblate>
 __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uint64_t* mp, const uint32_t*& vp, const uint32_t* x, uint32_t num_cols,
-                                                                       uint32_t col0, uint32_t steps, uint32_t lane, uint64_t* stamps = nullptr) {
+                                                                       uint32_t col0, uint32_t steps, uint32_t lane, bool have_first,
+                                                                       uint32_t first_masks, uint64_t* stamps = nullptr) {
     using R = Rows<kFloat>;
     typename R::sum_t acc = 0;
     // values: this run's compacted values; offset = running scalar byte offset + 4 * (set bits below the lane)
@@ -70,7 +71,8 @@ __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uin
     // load before the wait; not worth reserving registers for, the loop is bound by the latency chain in front of it, not by issue.)
     const auto mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(mp), 0, steps * 8u, kRsrcFlags);
     uint32_t moff = lane * 4u;
-    uint32_t mcur = __builtin_amdgcn_raw_buffer_load_b32(mr, moff, 0, 0);
+    // the first 32 masks of a wavefront's run arrive with its descriptor (one round trip less in front of the first value load)
+    uint32_t mcur = have_first ? first_masks : __builtin_amdgcn_raw_buffer_load_b32(mr, moff, 0, 0);
     uint32_t m1 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 256u, 0, 0);
     uint32_t m2 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 512u, 0, 0);
     uint32_t m3 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 768u, 0, 0);
@@ -181,10 +183,18 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
         const uint32_t nrows = blk->nrows, out0 = blk->out_offset;
         // the block's 16 wavefront runs sit at units[16 bi ..] (the builder stores them in final block order): descriptor and run
         // are fetched side by side, one dependent round trip before the first mask load instead of two
-        const WaveSegTable seg = (WaveSegTable)(units + static_cast<size_t>(bi) * kBitmapWaves) + wave;
-        const uint32_t row_begin = seg->row_begin, row_end = seg->row_end, g_begin = seg->g_begin, steps = seg->g_end - seg->g_begin;
-        const uint64_t* mp = reinterpret_cast<const uint64_t*>(image) + ((static_cast<uint64_t>(seg->mask_hi) << 32) | seg->mask_lo);
-        const uint32_t* vp = reinterpret_cast<const uint32_t*>(image) + ((static_cast<uint64_t>(seg->value_hi) << 32) | seg->value_lo);
+        // Run header of this wavefront: 64 bytes of WaveSeg + the run's first 32 masks, fetched with two VECTOR loads whose
+        // addresses depend on nothing but the block index -- descriptor and first masks in one round trip (timeline before:
+        // descriptors 0.8 us, then masks 2.0 us, then the first values).
+        const uint32_t* hdr = reinterpret_cast<const uint32_t*>(units) + (static_cast<size_t>(bi) * kBitmapWaves + wave) * (kBitmapRunSlots * 16);
+        const uint32_t seg_word = hdr[min(lane, 15u)];
+        const uint32_t first_masks = hdr[16 + lane];
+        const uint32_t row_begin = __builtin_amdgcn_readlane(seg_word, 0), row_end = __builtin_amdgcn_readlane(seg_word, 1);
+        const uint32_t g_begin = __builtin_amdgcn_readlane(seg_word, 2), steps = __builtin_amdgcn_readlane(seg_word, 3) - g_begin;
+        const uint64_t* mp = reinterpret_cast<const uint64_t*>(image) +
+                             ((static_cast<uint64_t>(__builtin_amdgcn_readlane(seg_word, 7)) << 32) | __builtin_amdgcn_readlane(seg_word, 6));
+        const uint32_t* vp = reinterpret_cast<const uint32_t*>(image) +
+                             ((static_cast<uint64_t>(__builtin_amdgcn_readlane(seg_word, 5)) << 32) | __builtin_amdgcn_readlane(seg_word, 4));
         const uint32_t col0 = blk->first_col0 + g_begin * kBitmapGroupCols;
         stamp(1, col0 + steps + nrows);
 
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
         for (uint32_t i = tid; i <= nrows; i += kBmThreads) ys[i] = 0;           // PE banks start at zero (pe.h:131-135)
         __syncthreads();
         for (uint32_t r = row_begin; r < row_end; ++r) {
-            const typename R::sum_t mine = (kAblate & 8) ? typename R::sum_t(steps) : bitmap_row_run<kFloat, kAblate>(mp, vp, x, num_cols, col0, steps, lane, stamps);
+            const typename R::sum_t mine = (kAblate & 8) ? typename R::sum_t(steps) : bitmap_row_run<kFloat, kAblate>(mp, vp, x, num_cols, col0, steps, lane, r == row_begin, first_masks, stamps);
             if (kAblate & 64) { uint64_t t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(mine)); if (lane == 0) stamps[4] = t; }
             mp += (steps + 7u) / 8u * 8u + 16u;     // the run's masks + its zero padding (bitmap_tiles.cpp)
             if (kAblate & 16) { asm volatile("" ::"v"(mine)); continue; }

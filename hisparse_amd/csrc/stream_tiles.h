@@ -132,6 +132,7 @@ constexpr uint32_t kBitmapGroupCols = 64;                     // one wavefront s
 constexpr uint32_t kBitmapWaves = 16;                         // all 16 wavefronts of the workgroup stream (no loader wavefronts)
 constexpr uint32_t kBitmapMaxBlockRows = 8191;                // 64 KiB of 8-byte row accumulators
 constexpr uint32_t kBitmapMaskBatch = 32;                     // masks fetched per vector load (one dword per lane)
+constexpr uint32_t kBitmapRunSlots = 5;                       // Unit-sized (64-byte) slots per wavefront run: the WaveSeg + a copy of its first 32 masks
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit
 constexpr uint32_t kBlockLastOfPartition = 2u;                // Block::flags bit: the workgroup's last block of this row partition
@@ -163,7 +164,8 @@ struct Unit {
 };
 // BITMAP images re-use the two tables: a Block describes (row range x column slice) -- row0, nrows, row_part, flags, out_offset, next as
 // above, first_col0 = first column of the slice, first_ncols = groups per row in the slice -- and its units [unit_begin, unit_end)
-// are kBitmapWaves WaveSeg entries (same 64 bytes as a Unit), one per wavefront:
+// are kBitmapWaves RUN HEADERS of kBitmapRunSlots x 64 bytes, one per wavefront: a WaveSeg (same 64 bytes as a Unit) followed by a copy
+// of the run's first 32 masks (256 bytes, zero padded) -- the kernel fetches descriptor and first masks in ONE round trip:
 struct WaveSeg {
     uint32_t row_begin, row_end;   // local rows [row_begin, row_end) of the block; row_end - row_begin == 1: the groups [g_begin, g_end)
     uint32_t g_begin, g_end;       //   of that row (relative to the slice), otherwise WHOLE rows (g_begin = 0, g_end = groups per row)

@@ -287,7 +287,7 @@ def test_bitmap_structure_and_parity(impl, rows, cols, density, wgs, monkeypatch
     groups = (cp.num_cols + 63) // 64
     # fewer rows than workgroups: the columns are cut into slices so that every workgroup has a block
     assert slices == max(1, min(8, 1 << int(np.floor(np.log2(max(1, wgs // cp.num_rows))))))
-    assert len(t["units"]) == 16 * len(blocks) and (blocks["unit_end"] - blocks["unit_begin"] == 16).all()
+    assert len(t["units"]) == 80 * len(blocks) and (blocks["unit_end"] - blocks["unit_begin"] == 80).all()   # 16 run headers x 5 slots
     # masks: rows x groups x 8 bytes in total (every row belongs to `slices` blocks that split its groups) + zero padding of
     # at most 23 masks per wavefront run; values: 4 bytes, padded to 8 per block
     mask_bytes = int((blocks["nrows"].astype(np.int64) * blocks["first_ncols"]).sum()) * 8

@@ -138,8 +138,10 @@ def _block_bitmap(image, blk, units, x_words, ys, is_float):
     """spmv_bitmap_kernel: every wavefront walks its run of (row, 64-column group) steps; mask bit l = column 64 g + l is set,
     its value is the next compacted one."""
     nrows, col0, gs = int(blk["nrows"]), int(blk["first_col0"]), int(blk["first_ncols"])
-    assert int(blk["unit_end"]) - int(blk["unit_begin"]) == BITMAP_WAVES
-    segs = units[int(blk["unit_begin"]): int(blk["unit_end"])].view(WAVESEG_DTYPE).reshape(-1)
+    assert int(blk["unit_end"]) - int(blk["unit_begin"]) == BITMAP_WAVES * 5      # run header = WaveSeg + a copy of its first 32 masks
+    headers = units[int(blk["unit_begin"]): int(blk["unit_end"])].view(np.uint8).reshape(BITMAP_WAVES, 5 * 64)
+    segs = np.ascontiguousarray(headers[:, :64]).view(WAVESEG_DTYPE).reshape(-1)
+    head_masks = np.ascontiguousarray(headers[:, 64:]).view(np.uint64)
     masks = image[: image.size // 8 * 8].view(np.uint64)
     values = image[: image.size // 4 * 4].view(np.uint32)
     covered = np.zeros((nrows, gs), dtype=np.int32)
@@ -149,6 +151,8 @@ def _block_bitmap(image, blk, units, x_words, ys, is_float):
         assert r0 <= r1 <= nrows and g0 <= g1 <= gs
         assert r1 - r0 <= 1 or (g0 == 0 and g1 == gs)                 # several rows: whole rows only
         mp, vp = int(sg["mask"]), int(sg["value"])
+        n_first = min(32, g1 - g0) if r1 > r0 else 0                    # the inline copy: the run's first masks, zero beyond
+        assert np.array_equal(head_masks[w, :n_first], masks[mp: mp + n_first]) and not head_masks[w, n_first:].any()
         for r in range(r0, r1):
             covered[r, g0:g1] += 1
             m = masks[mp: mp + (g1 - g0)]
