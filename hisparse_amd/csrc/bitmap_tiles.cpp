@@ -133,6 +133,7 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     }
     if (block_base[NB] / 4 >= (1ull << 40)) { error = "matrix too large for the bitmap image"; return false; }
     out.image.assign(block_base[NB], 0);
+    out.image_bytes = block_base[NB];
     timer.lap("bitmap: plan");
 
     parallel_for(NB, [&](size_t bi) {

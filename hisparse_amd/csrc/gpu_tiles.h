@@ -1,0 +1,84 @@
+// gpu_tiles.h — the data-touching passes of the load-time re-tiling, on the GPU.
+//
+// stream_tiles.cpp keeps ALL the planning (format, tile plan, row ranges, column slices, stream layout, workgroup assignment: small,
+// sequential, a few milliseconds) and asks a "source" for the six things that touch every non-zero:
+//     rows' non-zero counts  ->  (row range, sub-tile) counts  ->  every unit's elements sorted by position
+//     ->  DELTA slot counts / OWNER shares  ->  the emitted image.
+// The host source is the multi-threaded code of round 1 (three walks of the CPSR image, per-unit std::sort, emit loops).  GpuTiler is
+// the same on the device: the 16 channel buffers are uploaded once, one thread per LANE STREAM replays the reference loader's decode
+// (running row index = sum of in-band markers, spmv_cluster.h:73-98 / fp :95-117; sw/data_formatter.h:410,432 for the row <-> lane
+// mapping), (unit, position) keys are radix-sorted with hipCUB, and one emit kernel per format writes the image straight into the
+// buffer the SpMV kernel will read -- the image never exists on the host.  The host builder stays as the byte-for-byte checker
+// (tests/test_gpu_retile.py compares image, Block[] and Unit[] of both).
+#ifndef HISPARSE_GPU_TILES_H_
+#define HISPARSE_GPU_TILES_H_
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "tiles_common.h"
+
+namespace hisparse {
+namespace dev {
+
+class GpuTiler {
+  public:
+    GpuTiler(const detail::Layout& layout, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS], hipStream_t stream);
+    ~GpuTiler();
+    GpuTiler(const GpuTiler&) = delete;
+    GpuTiler& operator=(const GpuTiler&) = delete;
+
+    const std::string& error() const { return error_; }
+    // false + error(): not a valid CPSR image (same conditions the host walk reports) or a HIP failure.
+    // non-zeros per row; total
+    bool count_rows(std::vector<uint32_t>& row_nnz, uint64_t& nnz);
+    // totals per (row range, column partition, sub-tile): cnt[(b * CP + cp) * S + s]
+    bool count_tiles(const std::vector<uint32_t>& block_of_row, uint32_t num_ranges, std::vector<uint32_t>& cnt);
+    // Every unit's elements sorted by position, unit u at [plans[u].scratch, + plans[u].n) of the device arrays.  unit_of as in
+    // stream_tiles.cpp ((range, cp, s) -> unit or 0xffffffff); row0 of every range.  `duplicates` = some (row, column) occurs twice
+    // (the host's order among equal positions is by value word; the caller falls back to the host builder then).
+    bool sort_elements(const std::vector<uint32_t>& block_of_row, const std::vector<uint32_t>& range_row0, const std::vector<uint32_t>& unit_of,
+                       const std::vector<detail::UnitPlan>& plans, bool& duplicates);
+    // DELTA: slots (elements + bridges) of every unit
+    bool delta_slots(std::vector<detail::UnitPlan>& plans);
+    // OWNER: plans[u].own_begin from the wavefront row boundaries of the unit's range
+    bool owner_shares(std::vector<detail::UnitPlan>& plans, const std::vector<uint32_t>& wave_row, const std::vector<uint32_t>& range_of_unit);
+    // The image (image_bytes + slack, zero-filled first).  format: the final StreamFormat; block_of_unit / blocks: pre-reorder indices.
+    bool emit(StreamFormat format, uint64_t image_bytes, uint64_t slack_bytes, const std::vector<detail::UnitPlan>& plans,
+              const std::vector<uint32_t>& block_of_unit, const std::vector<Block>& blocks, bool is_float);
+    // hands the device image over (hipFree by the new owner)
+    uint8_t* release_image() { uint8_t* p = d_image_; d_image_ = nullptr; return p; }
+
+  private:
+    bool fail(const std::string& what);
+    bool check(hipError_t e, const char* what);
+    bool upload_channels();
+    bool decode_error(const char* pass);
+
+    detail::Layout L_;
+    Geometry geom_;
+    const void* const* channel_;
+    const uint64_t* n_packets_;
+    hipStream_t stream_;
+    std::string error_;
+
+    uint8_t* d_channels_ = nullptr;        // the 16 channel buffers back to back
+    void* d_streams_ = nullptr;            // LaneStream[num_streams_]
+    uint32_t num_streams_ = 0;
+    uint64_t* d_stream_base_ = nullptr;    // exclusive prefix of the streams' non-zero counts
+    uint32_t* d_scalar_ = nullptr;         // error / flag words
+    uint32_t* d_block_of_row_ = nullptr;
+    uint64_t total_ = 0;                   // non-zeros
+    uint64_t* d_keys_ = nullptr;           // sorted: unit << 28 | position
+    uint32_t* d_vals_ = nullptr;           // sorted value words
+    uint64_t* d_bridges_ = nullptr;        // DELTA: inclusive scan of the bridge slots in front of every element
+    uint8_t* d_image_ = nullptr;
+};
+
+}  // namespace dev
+}  // namespace hisparse
+
+#endif  // HISPARSE_GPU_TILES_H_

@@ -1,0 +1,576 @@
+// gpu_tiles.hip — GpuTiler: the per-non-zero passes of the load-time re-tiling on gfx950 (see gpu_tiles.h).
+#include "gpu_tiles.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+
+namespace hisparse {
+namespace dev {
+
+using detail::Layout;
+using detail::UnitPlan;
+
+namespace {
+
+constexpr uint32_t kPosBits = 28;                       // position = local_row * 8192 + local_col < 2^28 (rows per block <= 24561)
+constexpr uint64_t kPosMask = (1ull << kPosBits) - 1;
+constexpr uint32_t kErrColumn = 1, kErrRow = 2;
+
+// One lane stream of the CPSR image: lane k of virtual channel pc + 16 f in partition (rp, cp) -- what one PE's loader FIFO sees.
+struct LaneStream {
+    uint64_t byte_off;      // first packet of the stream inside the uploaded channel block
+    uint32_t stride;        // bytes between the stream's packets (INTERLEAVE_FACTOR * 64)
+    uint32_t len;           // elements including markers
+    uint32_t lane;          // k
+    uint32_t row;           // absolute row of round 0 (sw/data_formatter.h:410)
+    uint32_t row_stride;    // rows between two rows of one lane stream: PACK_SIZE * channels * F
+    uint32_t row_limit;     // first row past the row partition
+    uint32_t col_limit;     // columns in the column partition
+    uint32_t cp;            // column partition
+    uint32_t fixed;         // marker count = value word >> 24 (fixed point, spmv_cluster.h:82) or the raw word (float, fp :104)
+    uint32_t pad;
+};
+
+// Walk one lane stream: visit(absolute row, partition-local column, value word) for every non-zero.  Returns 0 or an error code.
+template <typename Visit>
+__device__ __forceinline__ uint32_t walk_stream(const uint8_t* __restrict__ channels, const LaneStream& s, Visit visit) {
+    const uint8_t* p = channels + s.byte_off + s.lane * 4u;
+    uint64_t row = s.row;
+    for (uint32_t i = 0; i < s.len; ++i, p += s.stride) {
+        const uint32_t col = *reinterpret_cast<const uint32_t*>(p);
+        const uint32_t val = *reinterpret_cast<const uint32_t*>(p + 32);
+        if (col == IDX_MARKER) {
+            row += uint64_t(s.fixed ? (val >> 24) : val) * s.row_stride;
+        } else {
+            if (col >= s.col_limit) return kErrColumn;
+            if (row >= s.row_limit) return kErrRow;
+            visit(uint32_t(row), col, val);
+        }
+    }
+    return 0;
+}
+
+__device__ __forceinline__ void report(uint32_t* scalar, uint32_t code, uint32_t stream) {
+    if (code && atomicCAS(scalar, 0u, code) == 0u) scalar[1] = stream;
+}
+
+__global__ __launch_bounds__(256) void count_rows_kernel(const uint8_t* __restrict__ channels, const LaneStream* __restrict__ streams, uint32_t n,
+                                                        uint32_t* __restrict__ row_nnz, uint32_t* __restrict__ stream_count, uint32_t* scalar) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint32_t count = 0;
+    const uint32_t err = walk_stream(channels, streams[t], [&](uint32_t row, uint32_t, uint32_t) {
+        atomicAdd(row_nnz + row, 1u);
+        ++count;
+    });
+    stream_count[t] = count;
+    report(scalar, err, t);
+}
+
+__global__ __launch_bounds__(256) void count_tiles_kernel(const uint8_t* __restrict__ channels, const LaneStream* __restrict__ streams, uint32_t n,
+                                                         const uint32_t* __restrict__ block_of_row, uint32_t tiles, uint32_t S, uint32_t sub_width,
+                                                         uint32_t* __restrict__ cnt) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const LaneStream s = streams[t];
+    // rows only go up inside a stream: count per (current row range, sub-tile) in registers, one atomic per range change
+    uint32_t cur = 0xffffffffu, local[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto flush = [&]() {
+        if (cur == 0xffffffffu) return;
+        for (uint32_t k = 0; k < 8; ++k)
+            if (local[k]) { atomicAdd(cnt + size_t(cur) * tiles + s.cp * S + k, local[k]); local[k] = 0; }
+    };
+    walk_stream(channels, s, [&](uint32_t row, uint32_t col, uint32_t) {
+        const uint32_t b = block_of_row[row], k = col / sub_width;
+        if (S > 8) { atomicAdd(cnt + size_t(b) * tiles + s.cp * S + k, 1u); return; }
+        if (b != cur) { flush(); cur = b; }
+        local[k]++;
+    });
+    flush();
+}
+
+__global__ __launch_bounds__(256) void keys_kernel(const uint8_t* __restrict__ channels, const LaneStream* __restrict__ streams, uint32_t n,
+                                                  const uint32_t* __restrict__ block_of_row, const uint32_t* __restrict__ range_row0,
+                                                  const uint32_t* __restrict__ unit_of, uint32_t tiles, uint32_t S, uint32_t sub_width,
+                                                  const uint64_t* __restrict__ stream_base, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const LaneStream s = streams[t];
+    uint64_t at = stream_base[t];
+    walk_stream(channels, s, [&](uint32_t row, uint32_t col, uint32_t val) {
+        const uint32_t b = block_of_row[row], k = col / sub_width;
+        const uint64_t unit = unit_of[size_t(b) * tiles + s.cp * S + k];
+        const uint64_t pos = uint64_t(row - range_row0[b]) * kSubTileCols + (col - k * sub_width);
+        keys[at] = (unit << kPosBits) | pos;
+        vals[at] = val;
+        ++at;
+    });
+}
+
+__global__ __launch_bounds__(256) void duplicates_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint32_t* flag) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i + 1 < n && keys[i] == keys[i + 1]) *flag = 1;
+}
+
+// DELTA: bridge slots in front of element i (same rule as the host: gaps beyond 65534 advance in steps of 65535)
+__global__ __launch_bounds__(256) void bridges_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint64_t* __restrict__ bridges) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t b = 0;
+    if (i > 0 && (keys[i] >> kPosBits) == (keys[i - 1] >> kPosBits)) {
+        const uint64_t d = (keys[i] & kPosMask) - (keys[i - 1] & kPosMask);
+        if (d > kMaxGap) b = (d - kMaxGap + kBridgeAdvance - 1) / kBridgeAdvance;
+    }
+    bridges[i] = b;
+}
+
+struct DevicePlan {        // what the emit kernels need of a UnitPlan + its block
+    uint64_t start;        // first element in the sorted arrays
+    uint64_t slots;        // DELTA
+    uint64_t first_slot[kConsumerWaves];
+    uint64_t wave_offset[kConsumerWaves];
+    uint32_t n, chunks, base, nrows, flags;
+    uint32_t start_step[kConsumerWaves], run_len[kConsumerWaves];
+    uint32_t own_begin[kConsumerWaves + 1];
+    uint32_t row_base[kConsumerWaves];     // OWNER24
+};
+
+__global__ __launch_bounds__(256) void unit_slots_kernel(const DevicePlan* __restrict__ plans, uint32_t nu, const uint64_t* __restrict__ bridges,
+                                                        uint64_t* __restrict__ slots) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nu) return;
+    const DevicePlan& p = plans[u];
+    uint64_t b = 0;
+    if (p.n) b = bridges[p.start + p.n - 1] - (p.start ? bridges[p.start - 1] : 0);
+    slots[u] = p.n + b;
+}
+
+__global__ __launch_bounds__(256) void owner_shares_kernel(const uint64_t* __restrict__ plan_start, const uint32_t* __restrict__ plan_n,
+                                                          const uint32_t* __restrict__ range_of_unit, const uint32_t* __restrict__ wave_row, uint32_t nu,
+                                                          const uint64_t* __restrict__ keys, uint32_t* __restrict__ own_begin) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nu * (kConsumerWaves + 1)) return;
+    const uint32_t u = t / (kConsumerWaves + 1), w = t % (kConsumerWaves + 1);
+    const uint64_t want = uint64_t(wave_row[size_t(range_of_unit[u]) * (kConsumerWaves + 1) + w]) << kOwnerColBits;
+    const uint64_t* e = keys + plan_start[u];
+    uint32_t lo = 0, hi = plan_n[u];
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if ((e[mid] & kPosMask) < want) lo = mid + 1; else hi = mid;
+    }
+    own_begin[t] = lo;
+}
+
+template <bool k24>
+__device__ __forceinline__ void put(uint8_t* chunk, uint32_t lane, uint32_t value, uint32_t where) {
+    if (k24) {
+        reinterpret_cast<uint32_t*>(chunk)[lane] = value;
+        uint8_t* a = chunk + kWaveLanes * 4 + lane * 3;
+        a[0] = uint8_t(where); a[1] = uint8_t(where >> 8); a[2] = uint8_t(where >> 16);
+    } else {
+        reinterpret_cast<uint2*>(chunk)[lane] = make_uint2(value, where);
+    }
+}
+
+// One workgroup per unit.  PAIRS: slot (chunk c, lane l) holds sorted element l * chunks + c (dense-row blocks: element i in chunk i / 64,
+// lane i % 64), chunks dealt round-robin to the wavefronts.
+template <bool k24>
+__global__ __launch_bounds__(256) void emit_pairs_kernel(const DevicePlan* __restrict__ plans, const uint64_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ vals, uint8_t* __restrict__ image) {
+    const DevicePlan& p = plans[blockIdx.x];
+    constexpr uint32_t kStride = (k24 ? kChunkBytes24 : kChunkBytes) * kConsumerWaves, kShift = k24 ? kOwnerColBits : 16u;
+    const bool dense = p.flags & kBlockDenseRows;
+    const uint64_t total = uint64_t(p.chunks) * kWaveLanes;
+    for (uint64_t i = threadIdx.x; i < total; i += blockDim.x) {
+        const uint32_t lane = dense ? uint32_t(i % kWaveLanes) : uint32_t(i / p.chunks);
+        const uint32_t c = dense ? uint32_t(i / kWaveLanes) : uint32_t(i % p.chunks);
+        const uint32_t g = p.base + c, w = g % kConsumerWaves;
+        const uint32_t first = p.base + (w + kConsumerWaves - p.base % kConsumerWaves) % kConsumerWaves;
+        const uint32_t step = p.start_step[w] + (g - first) / kConsumerWaves;
+        uint8_t* chunk = image + p.wave_offset[w] + uint64_t(step) * kStride;
+        if (i < p.n) {
+            const uint32_t pos = uint32_t(keys[p.start + i] & kPosMask);
+            put<k24>(chunk, lane, vals[p.start + i], ((pos / kSubTileCols) << kShift) | (pos % kSubTileCols));
+        } else {
+            put<k24>(chunk, lane, 0u, p.nrows << kShift);
+        }
+    }
+}
+
+// OWNER: per wavefront share, slot (step s, lane l) holds element l * steps + s of the share; the position word IS the key's low bits
+template <bool k24>
+__global__ __launch_bounds__(256) void emit_owner_kernel(const DevicePlan* __restrict__ plans, const uint64_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ vals, uint8_t* __restrict__ image) {
+    const DevicePlan& p = plans[blockIdx.x];
+    constexpr uint32_t kChunk = k24 ? kChunkBytes24 : kChunkBytes;
+    for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+        const uint32_t steps = p.run_len[w], n = p.own_begin[w + 1] - p.own_begin[w];
+        const uint64_t mine = p.start + p.own_begin[w];
+        uint8_t* base = image + p.wave_offset[w] + uint64_t(p.start_step[w]) * kChunk;
+        const uint32_t spare = k24 ? kOwnerSpareField : p.nrows + w;
+        const uint32_t row_base = k24 ? p.row_base[w] : 0u;
+        for (uint32_t idx = threadIdx.x; idx < steps * kWaveLanes; idx += blockDim.x) {
+            const uint32_t st = idx / kWaveLanes, l = idx % kWaveLanes;
+            const uint64_t i = uint64_t(l) * steps + st;
+            uint8_t* chunk = base + uint64_t(st) * kChunk;
+            if (i < n) put<k24>(chunk, l, vals[mine + i], uint32_t(keys[mine + i] & kPosMask) - (row_base << kOwnerColBits));
+            else put<k24>(chunk, l, 0u, spare << kOwnerColBits);
+        }
+    }
+}
+
+// DELTA: slot -> (gap, value, position after the slot).  S(i) = slot of element i inside its unit = i + bridges up to and including i's.
+struct Slot { uint32_t gap, val, after; };
+__device__ __forceinline__ Slot delta_slot(const DevicePlan& p, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                           const uint64_t* __restrict__ bridges, uint64_t si) {
+    const uint64_t bbase = p.start ? bridges[p.start - 1] : 0;
+    uint32_t lo = 0, hi = p.n;                       // first element i with S(i) >= si
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (mid + (bridges[p.start + mid] - bbase) < si) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t i = lo;
+    const uint64_t s_i = i + (bridges[p.start + i] - bbase);
+    const uint32_t pos = uint32_t(keys[p.start + i] & kPosMask);
+    if (si == s_i) {
+        uint32_t d = 0;
+        if (i > 0) {
+            const uint32_t prev = uint32_t(keys[p.start + i - 1] & kPosMask);
+            const uint64_t b = bridges[p.start + i] - bridges[p.start + i - 1];
+            d = uint32_t(pos - prev - b * kBridgeAdvance);
+        }
+        return Slot{d, vals[p.start + i], pos};
+    }
+    const uint32_t prev = uint32_t(keys[p.start + i - 1] & kPosMask);       // i > 0: element 0 has no bridges
+    const uint64_t s_prev = (i - 1) + (bridges[p.start + i - 1] - bbase);
+    const uint64_t k = si - (s_prev + 1);                                    // 0-based bridge in front of element i
+    return Slot{kBridgeGap, 0u, uint32_t(prev + (k + 1) * kBridgeAdvance)};
+}
+
+__global__ __launch_bounds__(256) void emit_delta_kernel(const DevicePlan* __restrict__ plans, const uint64_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ vals, const uint64_t* __restrict__ bridges,
+                                                        uint8_t* __restrict__ image, uint32_t pad_gap) {
+    const DevicePlan& p = plans[blockIdx.x];
+    if (!p.n) return;
+    const uint32_t scratch_pos = p.nrows * kSubTileCols;      // local row nrows = the spare accumulator
+    const uint32_t first_pos = uint32_t(keys[p.start] & kPosMask);
+    for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+        const uint32_t run = p.run_len[w];
+        if (!run) continue;
+        uint8_t* rec = image + p.wave_offset[w] + uint64_t(p.start_step[w]) * kRecordBytes;      // start_record == start_step
+        for (uint32_t idx = threadIdx.x; idx < (run + 1) * kWaveLanes; idx += blockDim.x) {
+            const uint32_t j = idx / kWaveLanes, l = idx % kWaveLanes;                           // j = 0: the head record
+            const uint64_t s0 = p.first_slot[w] + uint64_t(l) * run;
+            if (j == 0) {
+                uint32_t head = scratch_pos;
+                if (s0 < p.slots) head = s0 == 0 ? first_pos : delta_slot(p, keys, vals, bridges, s0 - 1).after;
+                reinterpret_cast<uint32_t*>(rec)[l] = head;
+                continue;
+            }
+            const uint64_t si = s0 + (j - 1);
+            uint8_t* r = rec + uint64_t(j) * kRecordBytes;
+            uint32_t value = 0, gap = pad_gap;
+            if (si < p.slots) { const Slot s = delta_slot(p, keys, vals, bridges, si); value = s.val; gap = s.gap; }
+            reinterpret_cast<uint32_t*>(r)[l] = value;
+            reinterpret_cast<uint16_t*>(r + kWaveLanes * 4)[l] = uint16_t(gap);
+        }
+    }
+}
+
+template <typename T>
+hipError_t upload(T** dst, const std::vector<T>& src, hipStream_t stream) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(src.size() * sizeof(T), 16));
+    if (e != hipSuccess || src.empty()) return e;
+    return hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, stream);
+}
+
+}  // namespace
+
+GpuTiler::GpuTiler(const Layout& layout, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS], hipStream_t stream)
+    : L_(layout), geom_(*layout.g), channel_(channel), n_packets_(n_packets), stream_(stream) {
+    L_.g = &geom_;
+}
+
+GpuTiler::~GpuTiler() {
+    for (void* p : {static_cast<void*>(d_channels_), d_streams_, static_cast<void*>(d_stream_base_), static_cast<void*>(d_scalar_),
+                    static_cast<void*>(d_block_of_row_), static_cast<void*>(d_keys_), static_cast<void*>(d_vals_), static_cast<void*>(d_bridges_),
+                    static_cast<void*>(d_image_)})
+        if (p) (void)hipFree(p);
+}
+
+bool GpuTiler::fail(const std::string& what) {
+    error_ = what;
+    return false;
+}
+bool GpuTiler::check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    return fail(std::string("gpu re-tile: ") + what + ": " + hipGetErrorString(e));
+}
+
+// The 16 buffers back to back on the device + the lane-stream table (header parsing and bounds checks as in
+// detail::walk_channel_partition, on the host: a few thousand headers).
+bool GpuTiler::upload_channels() {
+    const uint32_t F = L_.F, RP = L_.row_parts, CP = L_.col_parts;
+    const uint64_t parts = uint64_t(RP) * CP, payload_base = parts * (1 + F);
+    uint64_t offset[NUM_HBM_CHANNELS], total = 0;
+    for (uint32_t pc = 0; pc < NUM_HBM_CHANNELS; ++pc) {
+        offset[pc] = total;
+        total += n_packets_[pc] * sizeof(MatPkt);
+    }
+    std::vector<LaneStream> streams;
+    streams.reserve(size_t(parts) * NUM_HBM_CHANNELS * F * PACK_SIZE);
+    const uint64_t stride_rows = uint64_t(PACK_SIZE) * NUM_HBM_CHANNELS * F;
+    for (uint32_t rp = 0; rp < RP; ++rp)
+        for (uint32_t cp = 0; cp < CP; ++cp)
+            for (uint32_t pc = 0; pc < NUM_HBM_CHANNELS; ++pc) {
+                const MatPkt* buf = static_cast<const MatPkt*>(channel_[pc]);
+                const uint64_t pid = uint64_t(rp) * CP + cp, header = pid * (1 + F);
+                auto where = [&]() { return "channel " + std::to_string(pc) + ", row partition " + std::to_string(rp) + ", column partition " + std::to_string(cp) + ": "; };
+                if (header + 1 + F > n_packets_[pc]) return fail(where() + "partition header lies outside the channel buffer");
+                const uint64_t start = buf[header].indices.data[0];
+                const uint64_t row_base = uint64_t(rp) * geom_.logical_ob;
+                for (uint32_t f = 0; f < F; ++f) {
+                    const PackedWord& lens = buf[header + 1 + f].indices;
+                    uint32_t longest = 0;
+                    for (uint32_t k = 0; k < PACK_SIZE; ++k) longest = std::max(longest, lens.data[k]);
+                    if (longest && payload_base + start + uint64_t(longest - 1) * F + f >= n_packets_[pc])
+                        return fail(where() + "payload runs past the end of the channel buffer");
+                    const uint32_t vc = pc + f * NUM_HBM_CHANNELS;
+                    for (uint32_t k = 0; k < PACK_SIZE; ++k) {
+                        LaneStream s{};
+                        s.byte_off = offset[pc] + (payload_base + start + f) * sizeof(MatPkt);
+                        s.stride = F * uint32_t(sizeof(MatPkt));
+                        s.len = lens.data[k];
+                        s.lane = k;
+                        s.row = uint32_t(row_base + uint64_t(vc) * PACK_SIZE + k);
+                        s.row_stride = uint32_t(stride_rows);
+                        s.row_limit = uint32_t(row_base + L_.rows_in_part(rp));
+                        s.col_limit = L_.cols_in_part(cp);
+                        s.cp = cp;
+                        s.fixed = geom_.impl == IMPL_FIXED;
+                        streams.push_back(s);
+                    }
+                }
+            }
+    num_streams_ = uint32_t(streams.size());
+    if (!check(hipMalloc(reinterpret_cast<void**>(&d_channels_), std::max<uint64_t>(total, 64)), "hipMalloc(channels)")) return false;
+    for (uint32_t pc = 0; pc < NUM_HBM_CHANNELS; ++pc)
+        if (n_packets_[pc] &&
+            !check(hipMemcpyAsync(d_channels_ + offset[pc], channel_[pc], n_packets_[pc] * sizeof(MatPkt), hipMemcpyHostToDevice, stream_), "upload channel"))
+            return false;
+    LaneStream* d = nullptr;
+    if (!check(upload(&d, streams, stream_), "upload lane streams")) return false;
+    d_streams_ = d;
+    if (!check(hipMalloc(reinterpret_cast<void**>(&d_scalar_), 64), "hipMalloc")) return false;
+    if (!check(hipMemsetAsync(d_scalar_, 0, 64, stream_), "hipMemset")) return false;
+    return check(hipStreamSynchronize(stream_), "upload");       // the stream table is a temporary
+}
+
+bool GpuTiler::decode_error(const char* pass) {
+    uint32_t words[2] = {0, 0};
+    if (!check(hipMemcpyAsync(words, d_scalar_, 8, hipMemcpyDeviceToHost, stream_), pass)) return false;
+    if (!check(hipStreamSynchronize(stream_), pass)) return false;
+    if (!words[0]) return true;
+    // which stream: for the message only (the host walk names channel / partitions too)
+    return fail(std::string("lane stream ") + std::to_string(words[1]) + ": " +
+                (words[0] == kErrColumn ? "column index outside the column partition" : "decoded row outside the row partition (marker count wrapped?)"));
+}
+
+bool GpuTiler::count_rows(std::vector<uint32_t>& row_nnz, uint64_t& nnz) {
+    if (!upload_channels()) return false;
+    uint32_t *d_rows = nullptr, *d_counts = nullptr;
+    if (!check(hipMalloc(reinterpret_cast<void**>(&d_rows), size_t(L_.num_rows) * 4), "hipMalloc")) return false;
+    bool ok = check(hipMalloc(reinterpret_cast<void**>(&d_counts), std::max<size_t>(size_t(num_streams_) * 4, 16)), "hipMalloc") &&
+              check(hipMemsetAsync(d_rows, 0, size_t(L_.num_rows) * 4, stream_), "hipMemset");
+    if (ok && num_streams_) {
+        hipLaunchKernelGGL(count_rows_kernel, dim3((num_streams_ + 255) / 256), dim3(256), 0, stream_, d_channels_, static_cast<const LaneStream*>(d_streams_),
+                           num_streams_, d_rows, d_counts, d_scalar_);
+        ok = check(hipGetLastError(), "count_rows_kernel") && decode_error("count rows");
+    }
+    std::vector<uint32_t> counts(num_streams_);
+    row_nnz.assign(L_.num_rows, 0);
+    ok = ok && check(hipMemcpyAsync(row_nnz.data(), d_rows, size_t(L_.num_rows) * 4, hipMemcpyDeviceToHost, stream_), "read row counts") &&
+         (num_streams_ == 0 || check(hipMemcpyAsync(counts.data(), d_counts, size_t(num_streams_) * 4, hipMemcpyDeviceToHost, stream_), "read stream counts")) &&
+         check(hipStreamSynchronize(stream_), "count rows");
+    (void)hipFree(d_rows);
+    (void)hipFree(d_counts);
+    if (!ok) return false;
+    std::vector<uint64_t> base(size_t(num_streams_) + 1, 0);
+    for (uint32_t t = 0; t < num_streams_; ++t) base[t + 1] = base[t] + counts[t];
+    total_ = nnz = base[num_streams_];
+    return check(upload(&d_stream_base_, base, stream_), "upload stream bases") && check(hipStreamSynchronize(stream_), "upload stream bases");
+}
+
+bool GpuTiler::count_tiles(const std::vector<uint32_t>& block_of_row, uint32_t num_ranges, std::vector<uint32_t>& cnt) {
+    const uint32_t S = L_.subs_per_cp, tiles = L_.col_parts * S;
+    cnt.assign(size_t(num_ranges) * tiles, 0);
+    uint32_t* d_cnt = nullptr;
+    if (!check(upload(&d_block_of_row_, block_of_row, stream_), "upload block_of_row")) return false;
+    if (!check(hipMalloc(reinterpret_cast<void**>(&d_cnt), std::max<size_t>(cnt.size() * 4, 16)), "hipMalloc")) return false;
+    bool ok = check(hipMemsetAsync(d_cnt, 0, cnt.size() * 4, stream_), "hipMemset");
+    if (ok && num_streams_) {
+        hipLaunchKernelGGL(count_tiles_kernel, dim3((num_streams_ + 255) / 256), dim3(256), 0, stream_, d_channels_, static_cast<const LaneStream*>(d_streams_),
+                           num_streams_, d_block_of_row_, tiles, S, L_.sub_width, d_cnt);
+        ok = check(hipGetLastError(), "count_tiles_kernel");
+    }
+    ok = ok && (cnt.empty() || check(hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost, stream_), "read tile counts")) &&
+         check(hipStreamSynchronize(stream_), "count tiles");
+    (void)hipFree(d_cnt);
+    return ok;
+}
+
+bool GpuTiler::sort_elements(const std::vector<uint32_t>& block_of_row, const std::vector<uint32_t>& range_row0, const std::vector<uint32_t>& unit_of,
+                             const std::vector<UnitPlan>& plans, bool& duplicates) {
+    (void)block_of_row;      // already on the device (count_tiles)
+    duplicates = false;
+    const uint32_t S = L_.subs_per_cp, tiles = L_.col_parts * S;
+    uint32_t *d_row0 = nullptr, *d_unit_of = nullptr, *d_vals_in = nullptr;
+    uint64_t* d_keys_in = nullptr;
+    void* d_temp = nullptr;
+    const size_t n = std::max<uint64_t>(total_, 1);
+    bool ok = check(upload(&d_row0, range_row0, stream_), "upload range rows") && check(upload(&d_unit_of, unit_of, stream_), "upload unit table") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_keys_in), n * 8), "hipMalloc(keys)") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_vals_in), n * 4), "hipMalloc(values)") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_keys_), n * 8), "hipMalloc(keys)") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_vals_), n * 4), "hipMalloc(values)");
+    if (ok && num_streams_) {
+        hipLaunchKernelGGL(keys_kernel, dim3((num_streams_ + 255) / 256), dim3(256), 0, stream_, d_channels_, static_cast<const LaneStream*>(d_streams_),
+                           num_streams_, d_block_of_row_, d_row0, d_unit_of, tiles, S, L_.sub_width, d_stream_base_, d_keys_in, d_vals_in);
+        ok = check(hipGetLastError(), "keys_kernel");
+    }
+    if (ok && total_) {
+        uint32_t unit_bits = 1;
+        while ((uint64_t(1) << unit_bits) < plans.size() + 1) ++unit_bits;
+        const int end_bit = int(kPosBits + unit_bits);
+        size_t temp_bytes = 0;
+        ok = check(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_keys_in, d_keys_, d_vals_in, d_vals_, total_, 0, end_bit, stream_), "radix sort (size)") &&
+             check(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)), "hipMalloc(sort)") &&
+             check(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys_in, d_keys_, d_vals_in, d_vals_, total_, 0, end_bit, stream_), "radix sort");
+        if (ok) {
+            (void)hipMemsetAsync(d_scalar_ + 4, 0, 4, stream_);
+            hipLaunchKernelGGL(duplicates_kernel, dim3(uint32_t((total_ + 255) / 256)), dim3(256), 0, stream_, d_keys_, total_, d_scalar_ + 4);
+            uint32_t flag = 0;
+            ok = check(hipMemcpyAsync(&flag, d_scalar_ + 4, 4, hipMemcpyDeviceToHost, stream_), "duplicates") && check(hipStreamSynchronize(stream_), "sort");
+            duplicates = flag != 0;
+        }
+    }
+    ok = ok && check(hipStreamSynchronize(stream_), "sort");
+    for (void* p : {static_cast<void*>(d_row0), static_cast<void*>(d_unit_of), static_cast<void*>(d_keys_in), static_cast<void*>(d_vals_in), d_temp})
+        if (p) (void)hipFree(p);
+    // the CPSR image is not needed any more
+    if (d_channels_) { (void)hipFree(d_channels_); d_channels_ = nullptr; }
+    return ok;
+}
+
+namespace {
+bool make_device_plans(const std::vector<UnitPlan>& plans, const std::vector<uint32_t>& block_of_unit, const std::vector<Block>& blocks,
+                       std::vector<DevicePlan>& out) {
+    out.resize(plans.size());
+    for (size_t u = 0; u < plans.size(); ++u) {
+        const UnitPlan& up = plans[u];
+        DevicePlan& d = out[u];
+        std::memset(&d, 0, sizeof(d));
+        d.start = up.scratch; d.slots = up.slots; d.n = up.n; d.chunks = up.chunks; d.base = up.base;
+        if (!blocks.empty()) {
+            const Block& blk = blocks[block_of_unit[u]];
+            d.nrows = blk.nrows; d.flags = blk.flags;
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) { d.wave_offset[w] = blk.wave_offset[w]; d.row_base[w] = blk.pad[w]; }
+        }
+        for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+            d.first_slot[w] = up.first_slot[w]; d.start_step[w] = up.start_step[w]; d.run_len[w] = up.run_len[w]; d.own_begin[w] = up.own_begin[w];
+        }
+        d.own_begin[kConsumerWaves] = up.own_begin[kConsumerWaves];
+    }
+    return true;
+}
+}  // namespace
+
+bool GpuTiler::delta_slots(std::vector<UnitPlan>& plans) {
+    const size_t n = std::max<uint64_t>(total_, 1);
+    uint64_t *d_in = nullptr, *d_slots = nullptr;
+    DevicePlan* d_plans = nullptr;
+    void* d_temp = nullptr;
+    std::vector<DevicePlan> dp;
+    make_device_plans(plans, {}, {}, dp);
+    bool ok = check(hipMalloc(reinterpret_cast<void**>(&d_in), n * 8), "hipMalloc") && check(hipMalloc(reinterpret_cast<void**>(&d_bridges_), n * 8), "hipMalloc") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_slots), std::max<size_t>(plans.size() * 8, 16)), "hipMalloc") && check(upload(&d_plans, dp, stream_), "upload plans");
+    if (ok && total_) {
+        hipLaunchKernelGGL(bridges_kernel, dim3(uint32_t((total_ + 255) / 256)), dim3(256), 0, stream_, d_keys_, total_, d_in);
+        size_t temp_bytes = 0;
+        ok = check(hipGetLastError(), "bridges_kernel") &&
+             check(hipcub::DeviceScan::InclusiveSum(nullptr, temp_bytes, d_in, d_bridges_, total_, stream_), "scan (size)") &&
+             check(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)), "hipMalloc(scan)") &&
+             check(hipcub::DeviceScan::InclusiveSum(d_temp, temp_bytes, d_in, d_bridges_, total_, stream_), "scan");
+    }
+    std::vector<uint64_t> slots(plans.size(), 0);
+    if (ok && !plans.empty()) {
+        hipLaunchKernelGGL(unit_slots_kernel, dim3(uint32_t((plans.size() + 255) / 256)), dim3(256), 0, stream_, d_plans, uint32_t(plans.size()), d_bridges_, d_slots);
+        ok = check(hipGetLastError(), "unit_slots_kernel") &&
+             check(hipMemcpyAsync(slots.data(), d_slots, slots.size() * 8, hipMemcpyDeviceToHost, stream_), "read slots");
+    }
+    ok = ok && check(hipStreamSynchronize(stream_), "delta slots");
+    for (void* p : {static_cast<void*>(d_in), static_cast<void*>(d_slots), static_cast<void*>(d_plans), d_temp})
+        if (p) (void)hipFree(p);
+    if (ok)
+        for (size_t u = 0; u < plans.size(); ++u) plans[u].slots = slots[u];
+    return ok;
+}
+
+bool GpuTiler::owner_shares(std::vector<UnitPlan>& plans, const std::vector<uint32_t>& wave_row, const std::vector<uint32_t>& range_of_unit) {
+    const uint32_t nu = uint32_t(plans.size());
+    if (!nu) return true;
+    std::vector<uint64_t> start(nu);
+    std::vector<uint32_t> count(nu);
+    for (uint32_t u = 0; u < nu; ++u) { start[u] = plans[u].scratch; count[u] = plans[u].n; }
+    uint64_t* d_start = nullptr;
+    uint32_t *d_n = nullptr, *d_range = nullptr, *d_wave_row = nullptr, *d_own = nullptr;
+    std::vector<uint32_t> own(size_t(nu) * (kConsumerWaves + 1));
+    bool ok = check(upload(&d_start, start, stream_), "upload") && check(upload(&d_n, count, stream_), "upload") && check(upload(&d_range, range_of_unit, stream_), "upload") &&
+              check(upload(&d_wave_row, wave_row, stream_), "upload") && check(hipMalloc(reinterpret_cast<void**>(&d_own), own.size() * 4), "hipMalloc");
+    if (ok) {
+        hipLaunchKernelGGL(owner_shares_kernel, dim3(uint32_t((own.size() + 255) / 256)), dim3(256), 0, stream_, d_start, d_n, d_range, d_wave_row, nu, d_keys_, d_own);
+        ok = check(hipGetLastError(), "owner_shares_kernel") && check(hipMemcpyAsync(own.data(), d_own, own.size() * 4, hipMemcpyDeviceToHost, stream_), "read shares") &&
+             check(hipStreamSynchronize(stream_), "owner shares");
+    }
+    for (void* p : {static_cast<void*>(d_start), static_cast<void*>(d_n), static_cast<void*>(d_range), static_cast<void*>(d_wave_row), static_cast<void*>(d_own)})
+        if (p) (void)hipFree(p);
+    if (ok)
+        for (uint32_t u = 0; u < nu; ++u)
+            for (uint32_t w = 0; w <= kConsumerWaves; ++w) plans[u].own_begin[w] = own[size_t(u) * (kConsumerWaves + 1) + w];
+    return ok;
+}
+
+bool GpuTiler::emit(StreamFormat format, uint64_t image_bytes, uint64_t slack_bytes, const std::vector<UnitPlan>& plans,
+                    const std::vector<uint32_t>& block_of_unit, const std::vector<Block>& blocks, bool is_float) {
+    std::vector<DevicePlan> dp;
+    make_device_plans(plans, block_of_unit, blocks, dp);
+    DevicePlan* d_plans = nullptr;
+    const size_t bytes = std::max<uint64_t>(image_bytes + slack_bytes, 256);
+    bool ok = check(hipMalloc(reinterpret_cast<void**>(&d_image_), bytes), "hipMalloc(image)") && check(hipMemsetAsync(d_image_, 0, bytes, stream_), "hipMemset(image)") &&
+              check(upload(&d_plans, dp, stream_), "upload plans");
+    const dim3 grid(uint32_t(plans.size())), block(256);
+    if (ok && !plans.empty()) {
+        switch (format) {
+            case kFormatPairs: hipLaunchKernelGGL(emit_pairs_kernel<false>, grid, block, 0, stream_, d_plans, d_keys_, d_vals_, d_image_); break;
+            case kFormatPairs24: hipLaunchKernelGGL(emit_pairs_kernel<true>, grid, block, 0, stream_, d_plans, d_keys_, d_vals_, d_image_); break;
+            case kFormatOwner: hipLaunchKernelGGL(emit_owner_kernel<false>, grid, block, 0, stream_, d_plans, d_keys_, d_vals_, d_image_); break;
+            case kFormatOwner24: hipLaunchKernelGGL(emit_owner_kernel<true>, grid, block, 0, stream_, d_plans, d_keys_, d_vals_, d_image_); break;
+            case kFormatDelta:
+                hipLaunchKernelGGL(emit_delta_kernel, grid, block, 0, stream_, d_plans, d_keys_, d_vals_, d_bridges_, d_image_, is_float ? kBridgeGap : 0u);
+                break;
+            default: ok = fail("gpu re-tile: format not supported");
+        }
+        ok = ok && check(hipGetLastError(), "emit kernel");
+    }
+    ok = ok && check(hipStreamSynchronize(stream_), "emit");
+    if (d_plans) (void)hipFree(d_plans);
+    for (void** p : {reinterpret_cast<void**>(&d_keys_), reinterpret_cast<void**>(&d_vals_), reinterpret_cast<void**>(&d_bridges_)})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    return ok;
+}
+
+}  // namespace dev
+}  // namespace hisparse

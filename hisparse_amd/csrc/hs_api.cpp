@@ -256,16 +256,31 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
 
     hisparse::dev::StreamTiles tiles;
     std::string why;
+    // The per-non-zero passes of the re-tiling run on the GPU (gpu_tiles.h) unless HISPARSE_RETILE=host; BITMAP images and matrices
+    // with duplicate entries are built by the host code, which also remains the byte-for-byte checker of the GPU path.
+    const char* retile = std::getenv("HISPARSE_RETILE");
+    bool on_gpu = !(retile && std::string(retile) == "host");
     try {
         // one 1024-thread workgroup per CU: its row accumulators and x ring fill the 160 KiB LDS
-        if (!hisparse::dev::build_stream_tiles(channel, n_packets, g, num_rows, num_cols, num_row_partitions, num_col_partitions,
-                                               uint32_t(ctx->compute_units), tiles, why))
-            return fail(ctx, HS_ERR_BAD_MATRIX, why);
+        bool ok = hisparse::dev::build_stream_tiles(channel, n_packets, g, num_rows, num_cols, num_row_partitions, num_col_partitions,
+                                                    uint32_t(ctx->compute_units), tiles, why, ctx->stream, on_gpu, kImageSlackBytes);
+        if (!ok && on_gpu && why.rfind("gpu re-tile:", 0) == 0) {       // duplicates, or a HIP failure on the way: the host path decides
+            if (tiles.d_image) (void)hipFree(tiles.d_image);
+            tiles = hisparse::dev::StreamTiles();
+            on_gpu = false;
+            ok = hisparse::dev::build_stream_tiles(channel, n_packets, g, num_rows, num_cols, num_row_partitions, num_col_partitions,
+                                                   uint32_t(ctx->compute_units), tiles, why);
+        }
+        if (!ok) return fail(ctx, HS_ERR_BAD_MATRIX, why);
     } catch (const std::bad_alloc&) {
+        if (tiles.d_image) (void)hipFree(tiles.d_image);
         return fail(ctx, HS_ERR_NO_MEMORY, "out of host memory while re-tiling the matrix");
     }
     const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers, tiles.format);
-    if (lds_bytes > hisparse::dev::kMaxLdsBytes) return fail(ctx, HS_ERR_UNSUPPORTED, "row block does not fit the LDS");
+    if (lds_bytes > hisparse::dev::kMaxLdsBytes) {
+        if (tiles.d_image) (void)hipFree(tiles.d_image);
+        return fail(ctx, HS_ERR_UNSUPPORTED, "row block does not fit the LDS");
+    }
 
     // the dynamic-LDS cap is a property of the FUNCTION, not of this context: always raise it to the full 160 KiB, so that a
     // second context with a smaller matrix on the same device cannot lower it under a first one's launches
@@ -275,7 +290,8 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
         if (e != hipSuccess || bytes == 0) return e;
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
-    HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_image), tiles.image.data(), tiles.image.size(), kImageSlackBytes));
+    if (tiles.d_image) ctx->d_image = tiles.d_image;      // built on the device, slack included
+    else HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_image), tiles.image.data(), tiles.image.size(), kImageSlackBytes));
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_blocks), tiles.blocks.data(), tiles.blocks.size() * sizeof(Block), 0));
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_units), tiles.units.data(), tiles.units.size() * sizeof(Unit), 0));
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_part_heads), tiles.part_heads.data(), tiles.part_heads.size() * sizeof(uint32_t), 0));
@@ -297,7 +313,7 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     s = hs_stats{};
     s.nnz = tiles.nnz;
     for (int c = 0; c < HS_NUM_CHANNELS; ++c) s.cpsr_bytes += n_packets[c] * sizeof(hisparse::MatPkt);
-    s.stream_bytes = tiles.image.size();
+    s.stream_bytes = tiles.image_bytes;
     s.stream_elements = tiles.elements;
     s.num_blocks = uint32_t(tiles.blocks.size());
     s.num_units = uint32_t(tiles.units.size());
@@ -308,6 +324,20 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     s.lds_bytes = lds_bytes;
     s.num_compute_units = uint32_t(ctx->compute_units);
     s.load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    s.retiled_on_gpu = tiles.d_image != nullptr;
+    return HS_OK;
+}
+
+int hs_debug_read_tiles(hs_context* ctx, void* image, uint64_t image_capacity, void* blocks, void* units) {
+    if (!ctx) return HS_ERR_BAD_ARG;
+    if (!ctx->matrix_loaded) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix has not been called");
+    const hs_stats& s = ctx->stats;
+    if (image && image_capacity < s.stream_bytes) return fail(ctx, HS_ERR_BAD_ARG, "image buffer too small");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (image && s.stream_bytes) HS_HIP(ctx, hipMemcpy(image, ctx->d_image, s.stream_bytes, hipMemcpyDeviceToHost));
+    if (blocks && s.num_blocks) HS_HIP(ctx, hipMemcpy(blocks, ctx->d_blocks, size_t(s.num_blocks) * sizeof(Block), hipMemcpyDeviceToHost));
+    if (units && s.num_units) HS_HIP(ctx, hipMemcpy(units, ctx->d_units, size_t(s.num_units) * sizeof(Unit), hipMemcpyDeviceToHost));
     return HS_OK;
 }
 

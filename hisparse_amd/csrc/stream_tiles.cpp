@@ -8,6 +8,7 @@
 // order of spmv/spmv_result_drain.cpp:36,104-113 (net effect: natural row order in y).
 #include "stream_tiles.h"
 #include "tiles_common.h"
+#include "gpu_tiles.h"
 
 #include <algorithm>
 #include <atomic>
@@ -16,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -27,27 +29,12 @@ namespace {
 
 using namespace detail;
 
-struct UnitPlan {           // host-side companion of a device Unit
-    uint32_t n = 0;         // real elements
-    uint64_t scratch = 0;   // index of the unit's first element in the position-sorted scratch list
-    // PAIRS
-    uint32_t chunks = 0;    // ceil(n / 64)
-    uint32_t base = 0;      // chunk counter of the block at the unit's first chunk
-    uint32_t start_step[kConsumerWaves];   // chunk index of the unit's first chunk in wavefront w's stream
-    // DELTA
-    uint64_t slots = 0;     // elements + bridge slots
-    uint32_t run_len[kConsumerWaves];      // slots per lane of wavefront w in this unit
-    uint64_t first_slot[kConsumerWaves];   // first slot of lane 0 of wavefront w
-    uint32_t start_record[kConsumerWaves]; // record index of the unit's head record in wavefront w's stream
-    // OWNER
-    uint32_t own_begin[kConsumerWaves + 1]; // wavefront w owns sorted elements [own_begin[w], own_begin[w + 1]) of the unit
-};
-
 }  // namespace
 
 bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
                         const Geometry& geom, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
-                        uint32_t num_col_partitions, uint32_t max_workgroups, StreamTiles& out, std::string& error) {
+                        uint32_t num_col_partitions, uint32_t max_workgroups, StreamTiles& out, std::string& error,
+                        void* gpu_stream, bool use_gpu, uint64_t image_slack) {
     Layout L;
     L.g = &geom;
     L.num_rows = num_rows;
@@ -70,6 +57,11 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     PhaseTimer timer;
     // ---- pass 0: non-zeros per row (rows of different physical channels are disjoint) ------------
     std::vector<uint32_t> row_nnz(num_rows, 0);
+    std::unique_ptr<GpuTiler> gpu;       // the per-non-zero passes on the device (gpu_tiles.h) instead of the host walks below
+    if (use_gpu) {
+        gpu.reset(new GpuTiler(L, channel, n_packets, static_cast<hipStream_t>(gpu_stream)));
+        if (!gpu->count_rows(row_nnz, out.nnz)) { error = gpu->error(); return false; }
+    } else {
     std::vector<WalkResult> res0(size_t(RP) * NUM_HBM_CHANNELS);
     parallel_for(res0.size(), [&](size_t w) {
         const uint32_t rp = uint32_t(w / NUM_HBM_CHANNELS), pc = uint32_t(w % NUM_HBM_CHANNELS);
@@ -82,6 +74,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     for (const auto& r : res0) {
         if (!r.ok) { error = r.error; return false; }
         out.nnz += r.nnz;
+    }
     }
 
     timer.lap("pass 0 (row counts)");
@@ -102,6 +95,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner or bitmap"; return false; }
         }
         if (bitmap) {
+            gpu.reset();      // BITMAP images are small and built on the host
             if (build_bitmap_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error)) return true;
             if (error.rfind("bitmap:", 0) != 0) return false;     // a real decode error
             error.clear();                                       // not representable as a bitmap (duplicate entries): element streams
@@ -224,6 +218,13 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     std::vector<uint32_t> cnt(size_t(NR) * slots_per_range, 0);
     auto slot = [&](uint32_t b, uint32_t cp, uint32_t s, uint32_t pc) { return size_t(b) * slots_per_range + (size_t(cp) * S + s) * NUM_HBM_CHANNELS + pc; };
     std::vector<WalkResult> res1(size_t(RP) * CP * NUM_HBM_CHANNELS);
+    if (gpu) {      // totals per (range, sub-tile); the per-source-channel split only serves the host's scatter
+        std::vector<uint32_t> totals;
+        if (!gpu->count_tiles(block_of_row, NR, totals)) { error = gpu->error(); return false; }
+        for (uint32_t b = 0; b < NR; ++b)
+            for (uint32_t cp = 0; cp < CP; ++cp)
+                for (uint32_t sub = 0; sub < S; ++sub) cnt[slot(b, cp, sub, 0)] = totals[(size_t(b) * CP + cp) * S + sub];
+    } else {
     parallel_for(res1.size(), [&](size_t w) {
         const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP), rp = uint32_t(w / NUM_HBM_CHANNELS / CP);
         res1[w] = walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t) {
@@ -232,6 +233,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     });
     for (const auto& r : res1)
         if (!r.ok) { error = r.error; return false; }
+    }
 
     timer.lap("pass 1 (unit counts)");
     // ---- enumerate blocks (row range x column slice) and their units; counts -> offsets into a scratch element list ----
@@ -310,7 +312,30 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
 
     timer.lap("enumerate blocks + units");
     // ---- pass 2: collect every unit's elements as (position, value), position = local_row * 8192 + local_col -------
-    std::vector<uint64_t> scratch(scratch_elems);   // high word position, low word value: sorts by position
+    std::vector<uint64_t> scratch;   // high word position, low word value: sorts by position (host path)
+    std::vector<uint32_t> block_of_unit(NU);
+    for (uint32_t bi = 0; bi < NB; ++bi)
+        for (uint32_t u = out.blocks[bi].unit_begin; u < out.blocks[bi].unit_end; ++u) block_of_unit[u] = bi;
+    if (gpu) {
+        std::vector<uint32_t> range_row0(NR);
+        for (uint32_t b = 0; b < NR; ++b) range_row0[b] = ranges[b].row0;
+        bool duplicates = false;
+        if (!gpu->sort_elements(block_of_row, range_row0, unit_of, plans, duplicates)) { error = gpu->error(); return false; }
+        if (duplicates) { error = "gpu re-tile: duplicate entries"; return false; }      // the caller rebuilds on the host
+        std::vector<uint32_t>().swap(cnt);
+        timer.lap("gpu: keys + radix sort");
+        if (delta) {
+            if (!gpu->delta_slots(plans)) { error = gpu->error(); return false; }
+        } else {
+            for (UnitPlan& up : plans) up.slots = up.n;
+        }
+        if (owner) {
+            std::vector<uint32_t> range_of_unit(NU);
+            for (uint32_t u = 0; u < NU; ++u) range_of_unit[u] = range_of_block[block_of_unit[u]];
+            if (!gpu->owner_shares(plans, wave_row, range_of_unit)) { error = gpu->error(); return false; }
+        }
+    } else {
+    scratch.resize(scratch_elems);
     parallel_for(res1.size(), [&](size_t w) {
         const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP), rp = uint32_t(w / NUM_HBM_CHANNELS / CP);
         walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t val) {
@@ -335,6 +360,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         }
         up.slots = slots;
     });
+    }
 
     // DELTA pays for every position gap beyond 16 bits with a bridge slot.  A graph whose gaps are heavy-tailed (R-MAT: a quarter
     // of the rows empty, hubs of 10^5 non-zeros) needs one for every 25th element although its MEAN gap looks fine, and its
@@ -398,10 +424,12 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             if (owner) {
                 // the unit's elements are sorted by (row, column): wavefront w's share is the contiguous stretch of its rows;
                 // steps = its 64-slot chunks; lane l takes elements [l * steps, (l + 1) * steps) of the share
-                const uint32_t* wr = wave_row.data() + size_t(range_of_block[bi]) * (kConsumerWaves + 1);
-                const uint64_t* e = scratch.data() + up.scratch;
-                for (uint32_t w = 0; w <= kConsumerWaves; ++w)
-                    up.own_begin[w] = uint32_t(std::lower_bound(e, e + up.n, uint64_t(wr[w]) << (32 + kOwnerColBits)) - e);
+                if (!gpu) {      // (the device computed the shares already)
+                    const uint32_t* wr = wave_row.data() + size_t(range_of_block[bi]) * (kConsumerWaves + 1);
+                    const uint64_t* e = scratch.data() + up.scratch;
+                    for (uint32_t w = 0; w <= kConsumerWaves; ++w)
+                        up.own_begin[w] = uint32_t(std::lower_bound(e, e + up.n, uint64_t(wr[w]) << (32 + kOwnerColBits)) - e);
+                }
                 for (uint32_t w = 0; w < kConsumerWaves; ++w) {
                     const uint32_t steps = (up.own_begin[w + 1] - up.own_begin[w] + kWaveLanes - 1) / kWaveLanes;
                     up.run_len[w] = steps;
@@ -468,11 +496,17 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     };
 
     timer.lap("stream layout + workgroups");
+    if (gpu) {
+        if (!gpu->emit(out.format, image_bytes, image_slack, plans, block_of_unit, out.blocks, is_float)) { error = gpu->error(); return false; }
+        out.d_image = gpu->release_image();
+        out.image_bytes = image_bytes;
+        finish_blocks();
+        timer.lap("gpu: emit");
+        return true;
+    }
     out.image.assign(image_bytes, 0);
+    out.image_bytes = image_bytes;
     uint8_t* image = out.image.data();
-    std::vector<uint32_t> block_of_unit(NU);
-    for (uint32_t bi = 0; bi < NB; ++bi)
-        for (uint32_t u = out.blocks[bi].unit_begin; u < out.blocks[bi].unit_end; ++u) block_of_unit[u] = bi;
 
     if (owner) {
         // ---- OWNER: per (unit, wavefront) share: slot (step s, lane l) holds element l * steps + s of the share; the position word

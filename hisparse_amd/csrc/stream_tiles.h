@@ -177,8 +177,12 @@ static_assert(sizeof(WaveSeg) == 64, "WaveSeg overlays Unit");
 static_assert(sizeof(Block) == 320, "Block layout is shared with the device code");
 static_assert(sizeof(Unit) == 8 + 4 * kConsumerWaves, "Unit layout is shared with the device code");
 
+class GpuTiler;   // gpu_tiles.h
+
 struct StreamTiles {
-    std::vector<uint8_t> image;          // element streams, uploaded verbatim
+    std::vector<uint8_t> image;          // element streams, uploaded verbatim (host builder)
+    uint8_t* d_image = nullptr;          // GPU builder: the image, already in device memory (image_bytes + slack); the caller owns it
+    uint64_t image_bytes = 0;
     std::vector<Block> blocks;
     std::vector<Unit> units;
     std::vector<uint32_t> wg_first;      // workgroup g owns block_order[wg_first[g] .. wg_first[g+1]), in this order: a host-side
@@ -196,9 +200,13 @@ struct StreamTiles {
 
 // Decode + validate + re-tile.  `max_workgroups` = workgroups the device keeps resident (one per CU).
 // Returns false and sets `error` when the buffers are not a valid CPSR image for the geometry.
+// `gpu_stream` != nullptr: the per-non-zero passes run on the device of the current HIP context (gpu_tiles.h), the image stays there
+// (out.d_image); formats it does not cover (BITMAP) and matrices with duplicate entries are built on the host as before.
+// image_slack: bytes the device allocation of the image must extend past its end (the kernels' clamped prefetches).
 bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
                         const Geometry& geom, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
-                        uint32_t num_col_partitions, uint32_t max_workgroups, StreamTiles& out, std::string& error);
+                        uint32_t num_col_partitions, uint32_t max_workgroups, StreamTiles& out, std::string& error,
+                        void* gpu_stream = nullptr, bool use_gpu = false, uint64_t image_slack = 0);
 
 }  // namespace dev
 }  // namespace hisparse

@@ -127,6 +127,22 @@ WalkResult walk_channel_partition(const Layout& L, const MatPkt* buf, uint64_t n
 }
 
 
+struct UnitPlan {           // host-side companion of a device Unit
+    uint32_t n = 0;         // real elements
+    uint64_t scratch = 0;   // index of the unit's first element in the position-sorted scratch list
+    // PAIRS
+    uint32_t chunks = 0;    // ceil(n / 64)
+    uint32_t base = 0;      // chunk counter of the block at the unit's first chunk
+    uint32_t start_step[kConsumerWaves];   // chunk index of the unit's first chunk in wavefront w's stream
+    // DELTA
+    uint64_t slots = 0;     // elements + bridge slots
+    uint32_t run_len[kConsumerWaves];      // slots per lane of wavefront w in this unit
+    uint64_t first_slot[kConsumerWaves];   // first slot of lane 0 of wavefront w
+    uint32_t start_record[kConsumerWaves]; // record index of the unit's head record in wavefront w's stream
+    // OWNER
+    uint32_t own_begin[kConsumerWaves + 1]; // wavefront w owns sorted elements [own_begin[w], own_begin[w + 1]) of the unit
+};
+
 struct RowRange { uint32_t row0, nrows, row_part; };
 
 // Workgroups: longest-processing-time assignment of blocks, row partition by row partition (a launch of hs_run_partition

@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
     "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
-    "hs_bind_device_vector", "hs_bind_device_result", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_get_stats", "hs_time_runs", "hs_tiles_build", "hs_tiles_info",
+    "hs_bind_device_vector", "hs_bind_device_result", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
 
@@ -33,7 +33,7 @@ class Stats(C.Structure):
     _fields_ = [("nnz", C.c_uint64), ("cpsr_bytes", C.c_uint64), ("stream_bytes", C.c_uint64), ("stream_elements", C.c_uint64),
                 ("num_blocks", C.c_uint32), ("num_units", C.c_uint32), ("num_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("num_compute_units", C.c_uint32), ("col_slices", C.c_uint32), ("ring_buffers", C.c_uint32), ("stream_format", C.c_uint32),
-                ("load_seconds", C.c_double)]
+                ("load_seconds", C.c_double), ("retiled_on_gpu", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -82,6 +82,7 @@ def lib():
         l.hs_read_spmspv_result.argtypes = [vp, vp, u32]
         l.hs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.hs_debug_read_tiles.argtypes = [vp, vp, u64, vp, vp]
         l.hs_tiles_build.argtypes = [C.POINTER(vp), C.POINTER(u64), C.c_int, u32, u32, u32, u32, u32, u32, u32, C.POINTER(vp)]
         l.hs_tiles_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64),
                                     C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
@@ -171,6 +172,16 @@ class SpmvEngine:
         y = np.empty(self.num_rows, dtype=np.uint32)
         self._check(lib().hs_read_result(self._h, y.ctypes.data, y.size))
         return y
+
+    def read_tiles(self):
+        """What hs_load_matrix left on the device: dict(image, blocks, units) (tests compare it with build_tiles)."""
+        st = self.stats()
+        nbytes, nblocks, nunits = st["stream_bytes"], st["num_blocks"], st["num_units"]
+        image = np.zeros(max(nbytes, 1), dtype=np.uint8)
+        blocks = np.zeros(max(nblocks, 1), dtype=BLOCK_DTYPE)
+        units = np.zeros(max(nunits, 1), dtype=UNIT_DTYPE)
+        self._check(lib().hs_debug_read_tiles(self._h, image.ctypes.data, image.size, blocks.ctypes.data, units.ctypes.data))
+        return dict(image=image[:nbytes], blocks=blocks[:nblocks], units=units[:nunits])
 
     # ---- zero-copy hooks ----------------------------------------------------------------------
     def set_stream(self, hip_stream):

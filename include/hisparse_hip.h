@@ -75,6 +75,8 @@ typedef struct {
     uint32_t ring_buffers;      /* x sub-tile buffers in the LDS ring */
     uint32_t stream_format;     /* HS_STREAM_PAIRS (8 B per element), HS_STREAM_DELTA (6 B per slot) or HS_STREAM_BITMAP (4 B + 1 bit per column) HS_STREAM_OWNER (8 B per element, float accumulators) or the 7-byte forms of PAIRS / OWNER, chosen per matrix */
     double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
+    uint32_t retiled_on_gpu;    /* 1: the per-non-zero passes of the re-tiling ran on the device (gpu_tiles.h); 0: on the host */
+    uint32_t reserved;
 } hs_stats;
 
 const char* hs_strerror(int code);
@@ -154,6 +156,10 @@ int hs_get_stats(const hs_context* ctx, hs_stats* stats);
  * whole loop).  kernel_ms: sum over the runs of the duration of the SpMV kernel
  * (spmv_rowblock_kernel) alone, from per-launch event pairs.  Either output may be NULL. */
 int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* kernel_ms);
+
+/* What hs_load_matrix left on the device: the image (stats.stream_bytes), Block[] (num_blocks x 320 B) and Unit[] (num_units x 64 B).
+ * Tests compare this with hs_tiles_build (the host builder) byte for byte.  Any pointer may be NULL. */
+int hs_debug_read_tiles(hs_context* ctx, void* image, uint64_t image_capacity, void* blocks, void* units);
 
 /* ---- introspection of the load-time re-tiling (host only, no GPU needed; used by the tests) -------- */
 typedef struct hs_tiles hs_tiles;

@@ -1,0 +1,133 @@
+"""The load-time re-tiling on the GPU (hisparse_amd/csrc/gpu_tiles.hip) against the host builder (stream_tiles.cpp), byte for byte.
+
+hs_load_matrix runs the per-non-zero passes on the device by default; hs_tiles_build is the host builder with the same planner.
+Both must leave the SAME image, Block[] and Unit[] -- the SpMV parity tests then cover whichever built the image, and this file
+pins that the two are interchangeable.  (the reference formats on the host only, sw/data_formatter.h.)
+"""
+import numpy as np
+import pytest
+
+from hisparse_amd import datasets, device, host
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+FORMATS = ["pairs", "delta", "owner", "pairs24", "owner24"]
+
+
+def _set_format(monkeypatch, fmt):
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", fmt.replace("24", ""))
+    if fmt.endswith("24"):
+        monkeypatch.setenv("HISPARSE_AUX_BITS", "24")
+    monkeypatch.delenv("HISPARSE_RETILE", raising=False)
+
+
+def _compare(cp, impl, expect_gpu=True):
+    with device.SpmvEngine(impl, ob_bank=cp.ob_bank, vb_bank=cp.vb_bank) as eng:
+        eng.load_matrix(cp)
+        st = eng.stats()
+        got = eng.read_tiles()
+    want = device.build_tiles(cp, impl, cp.ob_bank, cp.vb_bank, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions,
+                              st["num_compute_units"])
+    assert bool(st["retiled_on_gpu"]) == expect_gpu
+    assert device.STREAM_FORMATS[st["stream_format"]] == want["format"]
+    assert st["stream_bytes"] == want["image"].size and st["num_blocks"] == want["blocks"].size and st["num_units"] == want["units"].size
+    assert st["stream_elements"] == want["elements"] and st["nnz"] == want["nnz"]
+    assert got["blocks"].tobytes() == want["blocks"].tobytes(), "Block[] differs"
+    assert got["units"].tobytes() == want["units"].tobytes(), "Unit[] differs"
+    if not np.array_equal(got["image"], want["image"]):
+        bad = np.nonzero(got["image"] != want["image"])[0]
+        raise AssertionError(f"image differs at {bad.size} of {want['image'].size} bytes, first at {bad[:8]}")
+    return st
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("skip", [False, True])
+def test_small_banks_many_partitions(monkeypatch, fmt, impl, skip):
+    _set_format(monkeypatch, fmt)
+    m = cases.random_csr(2500, 300, 0.03, 11, impl)
+    _, cp = cases.formatted(m, impl, 4, 8 if impl == 2 else 1, skip)
+    _compare(cp, impl)
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+@pytest.mark.parametrize("impl", [0, 1, 2])
+def test_default_banks(monkeypatch, fmt, impl):
+    _set_format(monkeypatch, fmt)
+    for rows, cols, density, seed in [(1000, 1000, 0.01, 1), (40000, 9000, 0.002, 5), (70, 50000, 0.01, 7), (300000, 64, 0.05, 9)]:
+        m = cases.random_csr(rows, cols, density, seed, impl)
+        csr = host.CSRMatrix.from_scipy(m)
+        cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+        _compare(cp, impl)
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2])
+def test_empty_and_ragged(monkeypatch, impl):
+    import scipy.sparse as sp
+    monkeypatch.delenv("HISPARSE_RETILE", raising=False)
+    for shape in [(64, 64), (1, 1), (129, 7)]:
+        m = sp.csr_matrix(shape, dtype=np.float32)
+        csr = host.CSRMatrix.from_scipy(m)
+        for skip in (False, True):
+            cp = host.format_matrix(csr, impl, skip_empty_rows=skip)
+            _compare(cp, impl)
+    # rows far apart (chained markers with skip_empty_rows), one very long row
+    rng = np.random.default_rng(3)
+    rows = np.concatenate([np.array([0, 5000, 5001, 99999]), np.full(3000, 70000)])
+    cols = np.concatenate([np.array([1, 2, 3, 4]), rng.choice(20000, 3000, replace=False)])
+    vals = rng.uniform(0.1, 1.0, rows.size).astype(np.float32)
+    m = sp.csr_matrix((vals, (rows, cols)), shape=(100000, 20000))
+    m.sort_indices()
+    csr = host.CSRMatrix.from_scipy(m)
+    for skip in (False, True):
+        cp = host.format_matrix(csr, impl, skip_empty_rows=skip)
+        _compare(cp, impl)
+
+
+def test_default_format_choice(monkeypatch):
+    # no forced format: the planner decides (PAIRS / DELTA / OWNER on the GPU; BITMAP images are built by the host code)
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT", raising=False)
+    monkeypatch.delenv("HISPARSE_RETILE", raising=False)
+    for impl in (0, 1, 2):
+        m = cases.random_csr(30000, 30000, 0.001, 21, impl)
+        cp = host.format_matrix(host.CSRMatrix.from_scipy(m), impl, skip_empty_rows=True)
+        _compare(cp, impl)
+    m = cases.random_csr(512, 8192, 0.5, 22, 2)
+    cp = host.format_matrix(host.CSRMatrix.from_scipy(m), 2, skip_empty_rows=True)
+    st = _compare(cp, 2, expect_gpu=False)
+    assert device.STREAM_FORMATS[st["stream_format"]] == "bitmap"
+
+
+def test_host_opt_out(monkeypatch):
+    monkeypatch.setenv("HISPARSE_RETILE", "host")
+    m = cases.random_csr(3000, 3000, 0.01, 4, 0)
+    cp = host.format_matrix(host.CSRMatrix.from_scipy(m), 0, skip_empty_rows=True)
+    _compare(cp, 0, expect_gpu=False)
+
+
+@pytest.mark.parametrize("name", ["ogbl_ppa", "ogbn_products", "mouse_gene", "ogbl_ppa_rmat"])
+def test_full_size_configs(monkeypatch, name):
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT", raising=False)
+    monkeypatch.delenv("HISPARSE_RETILE", raising=False)
+    cfg, csr = datasets.load(name)
+    impl = host.impl_id(cfg.impl)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=cfg.skip_empty_rows)
+    _compare(cp, impl)
+
+
+@pytest.mark.parametrize("impl", [0, 2])
+def test_duplicate_entries_fall_back_to_host(monkeypatch, impl):
+    # the same (row, column) twice: legal input for the reference's formatter; the host builder orders equal positions by value
+    # word, the device sort does not, so hs_load_matrix hands such a matrix to the host builder
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT", raising=False)
+    monkeypatch.delenv("HISPARSE_RETILE", raising=False)
+    m = cases.random_csr(5000, 5000, 0.004, 8, impl)
+    ip, ix, dv = m.indptr.astype(np.uint32), m.indices.astype(np.uint32).copy(), m.data.copy()
+    for r in range(0, 5000, 7):
+        if ip[r + 1] - ip[r] >= 2:
+            ix[ip[r] + 1] = ix[ip[r]]
+    csr = host.CSRMatrix.from_arrays(5000, 5000, ip, ix, dv)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    _compare(cp, impl, expect_gpu=False)
