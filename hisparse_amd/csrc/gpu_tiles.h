@@ -5,7 +5,7 @@
 //     rows' non-zero counts  ->  (row range, sub-tile) counts  ->  every unit's elements sorted by position
 //     ->  DELTA slot counts / OWNER shares  ->  the emitted image.
 // The host source is the multi-threaded code of round 1 (three walks of the CPSR image, per-unit std::sort, emit loops).  GpuTiler is
-// the same on the device: the 16 channel buffers are uploaded once, one thread per LANE STREAM replays the reference loader's decode
+// the same on the device: the 16 channel buffers are uploaded once, one thread per SEGMENT of a lane stream replays the reference loader's decode
 // (running row index = sum of in-band markers, spmv_cluster.h:73-98 / fp :95-117; sw/data_formatter.h:410,432 for the row <-> lane
 // mapping), (unit, position) keys are radix-sorted with hipCUB, and one emit kernel per format writes the image straight into the
 // buffer the SpMV kernel will read -- the image never exists on the host.  The host builder stays as the byte-for-byte checker
@@ -23,6 +23,8 @@
 
 namespace hisparse {
 namespace dev {
+
+hipError_t warm_gpu_tiler();
 
 class GpuTiler {
   public:
@@ -66,9 +68,11 @@ class GpuTiler {
     std::string error_;
 
     uint8_t* d_channels_ = nullptr;        // the 16 channel buffers back to back
-    void* d_streams_ = nullptr;            // LaneStream[num_streams_]
-    uint32_t num_streams_ = 0;
-    uint64_t* d_stream_base_ = nullptr;    // exclusive prefix of the streams' non-zero counts
+    void* d_groups_ = nullptr;             // StreamGroup[num_groups_]: the 8 lane streams of one (partition, virtual channel)
+    uint32_t num_groups_ = 0;
+    uint32_t total_slots_ = 0;             // segments of all lane streams (gpu_tiles.hip: kSegment entries each)
+    uint64_t* d_advance_ = nullptr;        // per segment: marker counts in front of it (exclusive scan)
+    uint64_t* d_base_ = nullptr;           // per segment: non-zeros in front of it (exclusive scan; [total_slots_] = all)
     uint32_t* d_scalar_ = nullptr;         // error / flag words
     uint32_t* d_block_of_row_ = nullptr;
     uint64_t total_ = 0;                   // non-zeros

@@ -19,90 +19,163 @@ constexpr uint32_t kPosBits = 28;                       // position = local_row 
 constexpr uint64_t kPosMask = (1ull << kPosBits) - 1;
 constexpr uint32_t kErrColumn = 1, kErrRow = 2;
 
-// One lane stream of the CPSR image: lane k of virtual channel pc + 16 f in partition (rp, cp) -- what one PE's loader FIFO sees.
-struct LaneStream {
-    uint64_t byte_off;      // first packet of the stream inside the uploaded channel block
-    uint32_t stride;        // bytes between the stream's packets (INTERLEAVE_FACTOR * 64)
-    uint32_t len;           // elements including markers
-    uint32_t lane;          // k
-    uint32_t row;           // absolute row of round 0 (sw/data_formatter.h:410)
+// The 8 lane streams of one virtual channel pc + 16 f in partition (rp, cp) -- what one cluster's 8 PE loader FIFOs see.
+struct StreamGroup {
+    uint64_t byte_off;      // first packet of the group inside the uploaded channel block
+    uint32_t stride;        // bytes between the group's packets (INTERLEAVE_FACTOR * 64)
+    uint32_t len[PACK_SIZE];// elements including markers, per lane
+    uint32_t row;           // absolute row of lane 0 in round 0 (sw/data_formatter.h:410); lane k: + k
     uint32_t row_stride;    // rows between two rows of one lane stream: PACK_SIZE * channels * F
     uint32_t row_limit;     // first row past the row partition
     uint32_t col_limit;     // columns in the column partition
     uint32_t cp;            // column partition
     uint32_t fixed;         // marker count = value word >> 24 (fixed point, spmv_cluster.h:82) or the raw word (float, fp :104)
-    uint32_t pad;
+    uint32_t first;         // first segment slot of the group
+    uint32_t nseg;          // segments per lane: ceil(longest lane / kSegment)
 };
 
-// Walk one lane stream: visit(absolute row, partition-local column, value word) for every non-zero.  Returns 0 or an error code.
+// A lane stream is decoded in SEGMENTS of kSegment consecutive entries: the running row index is a prefix sum of the in-band marker
+// counts, so a first kernel sums the markers of every segment, one device scan turns the sums into every segment's starting row, and
+// all later passes start anywhere.  Thread t of a pass = (group, segment j, lane k), k fastest: the 8 lanes of a packet are 8 adjacent
+// threads (32 contiguous bytes of indices, 32 of values).  Scan slot of that thread = first + k * nseg + j (lane-major, so that the
+// prefix inside one lane stream is a contiguous piece of the scan).
+constexpr uint32_t kSegment = 64;
+
+struct Segment {
+    const uint8_t* p;       // first entry's index word
+    uint32_t n;             // entries
+    uint32_t stride;
+    uint32_t slot;          // scan slot
+    uint32_t lane_slot;     // scan slot of the lane stream's first segment
+    uint32_t group;
+    uint32_t lane;
+};
+
+__device__ __forceinline__ bool find_segment(const uint8_t* __restrict__ channels, const StreamGroup* __restrict__ groups, uint32_t num_groups,
+                                             uint32_t total_slots, uint32_t t, Segment& s) {
+    if (t >= total_slots) return false;
+    uint32_t lo = 0, hi = num_groups;                 // last group with first <= t
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (groups[mid].first <= t) lo = mid; else hi = mid;
+    }
+    const StreamGroup& g = groups[lo];
+    const uint32_t local = t - g.first, j = local / PACK_SIZE, k = local % PACK_SIZE;
+    const uint32_t len = g.len[k], begin = j * kSegment;
+    s.group = lo;
+    s.lane = k;
+    s.lane_slot = g.first + k * g.nseg;
+    s.slot = s.lane_slot + j;
+    s.stride = g.stride;
+    s.n = begin < len ? min(kSegment, len - begin) : 0u;
+    s.p = channels + g.byte_off + uint64_t(begin) * g.stride + k * 4u;
+    return true;
+}
+
+// markers and non-zeros of every segment
+__global__ __launch_bounds__(256) void segment_sums_kernel(const uint8_t* __restrict__ channels, const StreamGroup* __restrict__ groups, uint32_t num_groups,
+                                                          uint32_t total_slots, uint64_t* __restrict__ advance, uint64_t* __restrict__ count) {
+    Segment s;
+    if (!find_segment(channels, groups, num_groups, total_slots, blockIdx.x * blockDim.x + threadIdx.x, s)) return;
+    const bool fixed = groups[s.group].fixed;
+    uint64_t adv = 0;
+    uint32_t cnt = 0;
+    const uint8_t* p = s.p;
+    for (uint32_t i = 0; i < s.n; ++i, p += s.stride) {
+        const uint32_t col = *reinterpret_cast<const uint32_t*>(p);
+        if (col == IDX_MARKER) {
+            const uint32_t val = *reinterpret_cast<const uint32_t*>(p + 32);
+            adv += fixed ? (val >> 24) : val;
+        } else {
+            ++cnt;
+        }
+    }
+    advance[s.slot] = adv;
+    count[s.slot] = cnt;
+}
+
+// Walk one segment: visit(absolute row, partition-local column, value word) for every non-zero.  Returns 0 or an error code.
 template <typename Visit>
-__device__ __forceinline__ uint32_t walk_stream(const uint8_t* __restrict__ channels, const LaneStream& s, Visit visit) {
-    const uint8_t* p = channels + s.byte_off + s.lane * 4u;
-    uint64_t row = s.row;
-    for (uint32_t i = 0; i < s.len; ++i, p += s.stride) {
+__device__ __forceinline__ uint32_t walk_segment(const StreamGroup& g, const Segment& s, const uint64_t* __restrict__ advance, Visit visit) {
+    // rows advanced before this segment (exclusive scan, relative to the lane stream's first segment); anything beyond 2^32 rounds is
+    // outside every partition and must not wrap the product
+    const uint64_t rounds = min(advance[s.slot] - advance[s.lane_slot], uint64_t(1) << 32);
+    uint64_t row = uint64_t(g.row) + s.lane + rounds * g.row_stride;
+    const uint8_t* p = s.p;
+    for (uint32_t i = 0; i < s.n; ++i, p += s.stride) {
         const uint32_t col = *reinterpret_cast<const uint32_t*>(p);
         const uint32_t val = *reinterpret_cast<const uint32_t*>(p + 32);
         if (col == IDX_MARKER) {
-            row += uint64_t(s.fixed ? (val >> 24) : val) * s.row_stride;
+            row += uint64_t(g.fixed ? (val >> 24) : val) * g.row_stride;
         } else {
-            if (col >= s.col_limit) return kErrColumn;
-            if (row >= s.row_limit) return kErrRow;
+            if (col >= g.col_limit) return kErrColumn;
+            if (row >= g.row_limit) return kErrRow;
             visit(uint32_t(row), col, val);
         }
     }
     return 0;
 }
 
-__device__ __forceinline__ void report(uint32_t* scalar, uint32_t code, uint32_t stream) {
-    if (code && atomicCAS(scalar, 0u, code) == 0u) scalar[1] = stream;
+__device__ __forceinline__ void report(uint32_t* scalar, uint32_t code, uint32_t group, uint32_t lane) {
+    if (code && atomicCAS(scalar, 0u, code) == 0u) { scalar[1] = group; scalar[2] = lane; }
 }
 
-__global__ __launch_bounds__(256) void count_rows_kernel(const uint8_t* __restrict__ channels, const LaneStream* __restrict__ streams, uint32_t n,
-                                                        uint32_t* __restrict__ row_nnz, uint32_t* __restrict__ stream_count, uint32_t* scalar) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    uint32_t count = 0;
-    const uint32_t err = walk_stream(channels, streams[t], [&](uint32_t row, uint32_t, uint32_t) {
-        atomicAdd(row_nnz + row, 1u);
-        ++count;
+__global__ __launch_bounds__(256) void count_rows_kernel(const uint8_t* __restrict__ channels, const StreamGroup* __restrict__ groups, uint32_t num_groups,
+                                                        uint32_t total_slots, const uint64_t* __restrict__ advance, uint32_t* __restrict__ row_nnz,
+                                                        uint32_t* scalar) {
+    Segment s;
+    if (!find_segment(channels, groups, num_groups, total_slots, blockIdx.x * blockDim.x + threadIdx.x, s)) return;
+    // rows only go up inside a stream: one atomic per run of equal rows
+    uint32_t cur = 0xffffffffu, run = 0;
+    const uint32_t err = walk_segment(groups[s.group], s, advance, [&](uint32_t row, uint32_t, uint32_t) {
+        if (row != cur) {
+            if (run) atomicAdd(row_nnz + cur, run);
+            cur = row;
+            run = 0;
+        }
+        ++run;
     });
-    stream_count[t] = count;
-    report(scalar, err, t);
+    if (run) atomicAdd(row_nnz + cur, run);
+    report(scalar, err, s.group, s.lane);
 }
 
-__global__ __launch_bounds__(256) void count_tiles_kernel(const uint8_t* __restrict__ channels, const LaneStream* __restrict__ streams, uint32_t n,
+__global__ __launch_bounds__(256) void count_tiles_kernel(const uint8_t* __restrict__ channels, const StreamGroup* __restrict__ groups, uint32_t num_groups,
+                                                         uint32_t total_slots, const uint64_t* __restrict__ advance,
                                                          const uint32_t* __restrict__ block_of_row, uint32_t tiles, uint32_t S, uint32_t sub_width,
                                                          uint32_t* __restrict__ cnt) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const LaneStream s = streams[t];
-    // rows only go up inside a stream: count per (current row range, sub-tile) in registers, one atomic per range change
+    Segment s;
+    if (!find_segment(channels, groups, num_groups, total_slots, blockIdx.x * blockDim.x + threadIdx.x, s)) return;
+    const StreamGroup& g = groups[s.group];
+    const uint32_t cp = g.cp;
+    // count per (current row range, sub-tile) in registers, one atomic per range change
     uint32_t cur = 0xffffffffu, local[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto flush = [&]() {
         if (cur == 0xffffffffu) return;
         for (uint32_t k = 0; k < 8; ++k)
-            if (local[k]) { atomicAdd(cnt + size_t(cur) * tiles + s.cp * S + k, local[k]); local[k] = 0; }
+            if (local[k]) { atomicAdd(cnt + size_t(cur) * tiles + cp * S + k, local[k]); local[k] = 0; }
     };
-    walk_stream(channels, s, [&](uint32_t row, uint32_t col, uint32_t) {
+    walk_segment(g, s, advance, [&](uint32_t row, uint32_t col, uint32_t) {
         const uint32_t b = block_of_row[row], k = col / sub_width;
-        if (S > 8) { atomicAdd(cnt + size_t(b) * tiles + s.cp * S + k, 1u); return; }
+        if (S > 8) { atomicAdd(cnt + size_t(b) * tiles + cp * S + k, 1u); return; }
         if (b != cur) { flush(); cur = b; }
         local[k]++;
     });
     flush();
 }
 
-__global__ __launch_bounds__(256) void keys_kernel(const uint8_t* __restrict__ channels, const LaneStream* __restrict__ streams, uint32_t n,
+__global__ __launch_bounds__(256) void keys_kernel(const uint8_t* __restrict__ channels, const StreamGroup* __restrict__ groups, uint32_t num_groups,
+                                                  uint32_t total_slots, const uint64_t* __restrict__ advance, const uint64_t* __restrict__ base,
                                                   const uint32_t* __restrict__ block_of_row, const uint32_t* __restrict__ range_row0,
                                                   const uint32_t* __restrict__ unit_of, uint32_t tiles, uint32_t S, uint32_t sub_width,
-                                                  const uint64_t* __restrict__ stream_base, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const LaneStream s = streams[t];
-    uint64_t at = stream_base[t];
-    walk_stream(channels, s, [&](uint32_t row, uint32_t col, uint32_t val) {
+                                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    Segment s;
+    if (!find_segment(channels, groups, num_groups, total_slots, blockIdx.x * blockDim.x + threadIdx.x, s)) return;
+    const StreamGroup& g = groups[s.group];
+    const uint32_t cp = g.cp;
+    uint64_t at = base[s.slot];
+    walk_segment(g, s, advance, [&](uint32_t row, uint32_t col, uint32_t val) {
         const uint32_t b = block_of_row[row], k = col / sub_width;
-        const uint64_t unit = unit_of[size_t(b) * tiles + s.cp * S + k];
+        const uint64_t unit = unit_of[size_t(b) * tiles + cp * S + k];
         const uint64_t pos = uint64_t(row - range_row0[b]) * kSubTileCols + (col - k * sub_width);
         keys[at] = (unit << kPosBits) | pos;
         vals[at] = val;
@@ -289,13 +362,19 @@ hipError_t upload(T** dst, const std::vector<T>& src, hipStream_t stream) {
 
 }  // namespace
 
+// hs_create: load this file's code object now instead of inside the first hs_load_matrix
+hipError_t warm_gpu_tiler() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&segment_sums_kernel));
+}
+
 GpuTiler::GpuTiler(const Layout& layout, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS], hipStream_t stream)
     : L_(layout), geom_(*layout.g), channel_(channel), n_packets_(n_packets), stream_(stream) {
     L_.g = &geom_;
 }
 
 GpuTiler::~GpuTiler() {
-    for (void* p : {static_cast<void*>(d_channels_), d_streams_, static_cast<void*>(d_stream_base_), static_cast<void*>(d_scalar_),
+    for (void* p : {static_cast<void*>(d_channels_), d_groups_, static_cast<void*>(d_advance_), static_cast<void*>(d_base_), static_cast<void*>(d_scalar_),
                     static_cast<void*>(d_block_of_row_), static_cast<void*>(d_keys_), static_cast<void*>(d_vals_), static_cast<void*>(d_bridges_),
                     static_cast<void*>(d_image_)})
         if (p) (void)hipFree(p);
@@ -320,9 +399,10 @@ bool GpuTiler::upload_channels() {
         offset[pc] = total;
         total += n_packets_[pc] * sizeof(MatPkt);
     }
-    std::vector<LaneStream> streams;
-    streams.reserve(size_t(parts) * NUM_HBM_CHANNELS * F * PACK_SIZE);
+    std::vector<StreamGroup> groups;
+    groups.reserve(size_t(parts) * NUM_HBM_CHANNELS * F);
     const uint64_t stride_rows = uint64_t(PACK_SIZE) * NUM_HBM_CHANNELS * F;
+    uint64_t slots = 0;
     for (uint32_t rp = 0; rp < RP; ++rp)
         for (uint32_t cp = 0; cp < CP; ++cp)
             for (uint32_t pc = 0; pc < NUM_HBM_CHANNELS; ++pc) {
@@ -338,70 +418,95 @@ bool GpuTiler::upload_channels() {
                     for (uint32_t k = 0; k < PACK_SIZE; ++k) longest = std::max(longest, lens.data[k]);
                     if (longest && payload_base + start + uint64_t(longest - 1) * F + f >= n_packets_[pc])
                         return fail(where() + "payload runs past the end of the channel buffer");
+                    if (!longest) continue;
                     const uint32_t vc = pc + f * NUM_HBM_CHANNELS;
-                    for (uint32_t k = 0; k < PACK_SIZE; ++k) {
-                        LaneStream s{};
-                        s.byte_off = offset[pc] + (payload_base + start + f) * sizeof(MatPkt);
-                        s.stride = F * uint32_t(sizeof(MatPkt));
-                        s.len = lens.data[k];
-                        s.lane = k;
-                        s.row = uint32_t(row_base + uint64_t(vc) * PACK_SIZE + k);
-                        s.row_stride = uint32_t(stride_rows);
-                        s.row_limit = uint32_t(row_base + L_.rows_in_part(rp));
-                        s.col_limit = L_.cols_in_part(cp);
-                        s.cp = cp;
-                        s.fixed = geom_.impl == IMPL_FIXED;
-                        streams.push_back(s);
-                    }
+                    StreamGroup g{};
+                    g.byte_off = offset[pc] + (payload_base + start + f) * sizeof(MatPkt);
+                    g.stride = F * uint32_t(sizeof(MatPkt));
+                    for (uint32_t k = 0; k < PACK_SIZE; ++k) g.len[k] = lens.data[k];
+                    g.row = uint32_t(row_base + uint64_t(vc) * PACK_SIZE);
+                    g.row_stride = uint32_t(stride_rows);
+                    g.row_limit = uint32_t(row_base + L_.rows_in_part(rp));
+                    g.col_limit = L_.cols_in_part(cp);
+                    g.cp = cp;
+                    g.fixed = geom_.impl == IMPL_FIXED;
+                    g.first = uint32_t(slots);
+                    g.nseg = (longest + kSegment - 1) / kSegment;
+                    slots += uint64_t(g.nseg) * PACK_SIZE;
+                    groups.push_back(g);
                 }
             }
-    num_streams_ = uint32_t(streams.size());
+    if (slots >= (uint64_t(1) << 32)) return fail("gpu re-tile: image too large for 32-bit segment indices");
+    num_groups_ = uint32_t(groups.size());
+    total_slots_ = uint32_t(slots);
     if (!check(hipMalloc(reinterpret_cast<void**>(&d_channels_), std::max<uint64_t>(total, 64)), "hipMalloc(channels)")) return false;
     for (uint32_t pc = 0; pc < NUM_HBM_CHANNELS; ++pc)
         if (n_packets_[pc] &&
             !check(hipMemcpyAsync(d_channels_ + offset[pc], channel_[pc], n_packets_[pc] * sizeof(MatPkt), hipMemcpyHostToDevice, stream_), "upload channel"))
             return false;
-    LaneStream* d = nullptr;
-    if (!check(upload(&d, streams, stream_), "upload lane streams")) return false;
-    d_streams_ = d;
+    StreamGroup* d = nullptr;
+    if (!check(upload(&d, groups, stream_), "upload stream groups")) return false;
+    d_groups_ = d;
     if (!check(hipMalloc(reinterpret_cast<void**>(&d_scalar_), 64), "hipMalloc")) return false;
     if (!check(hipMemsetAsync(d_scalar_, 0, 64, stream_), "hipMemset")) return false;
-    return check(hipStreamSynchronize(stream_), "upload");       // the stream table is a temporary
+    return check(hipStreamSynchronize(stream_), "upload");       // the group table is a temporary
 }
 
 bool GpuTiler::decode_error(const char* pass) {
-    uint32_t words[2] = {0, 0};
-    if (!check(hipMemcpyAsync(words, d_scalar_, 8, hipMemcpyDeviceToHost, stream_), pass)) return false;
+    uint32_t words[3] = {0, 0, 0};
+    if (!check(hipMemcpyAsync(words, d_scalar_, 12, hipMemcpyDeviceToHost, stream_), pass)) return false;
     if (!check(hipStreamSynchronize(stream_), pass)) return false;
     if (!words[0]) return true;
     // which stream: for the message only (the host walk names channel / partitions too)
-    return fail(std::string("lane stream ") + std::to_string(words[1]) + ": " +
+    return fail(std::string("lane stream ") + std::to_string(uint64_t(words[1]) * PACK_SIZE + words[2]) + ": " +
                 (words[0] == kErrColumn ? "column index outside the column partition" : "decoded row outside the row partition (marker count wrapped?)"));
 }
 
 bool GpuTiler::count_rows(std::vector<uint32_t>& row_nnz, uint64_t& nnz) {
+    detail::PhaseTimer timer;
     if (!upload_channels()) return false;
-    uint32_t *d_rows = nullptr, *d_counts = nullptr;
-    if (!check(hipMalloc(reinterpret_cast<void**>(&d_rows), size_t(L_.num_rows) * 4), "hipMalloc")) return false;
-    bool ok = check(hipMalloc(reinterpret_cast<void**>(&d_counts), std::max<size_t>(size_t(num_streams_) * 4, 16)), "hipMalloc") &&
-              check(hipMemsetAsync(d_rows, 0, size_t(L_.num_rows) * 4, stream_), "hipMemset");
-    if (ok && num_streams_) {
-        hipLaunchKernelGGL(count_rows_kernel, dim3((num_streams_ + 255) / 256), dim3(256), 0, stream_, d_channels_, static_cast<const LaneStream*>(d_streams_),
-                           num_streams_, d_rows, d_counts, d_scalar_);
+    timer.lap("gpu: upload CPSR image");
+    const StreamGroup* groups = static_cast<const StreamGroup*>(d_groups_);
+    const size_t slots = size_t(total_slots_) + 1;                   // + one zero: the exclusive scans end with the totals
+    const dim3 grid((total_slots_ + 255) / 256), block(256);
+    uint32_t* d_rows = nullptr;
+    uint64_t *d_adv_in = nullptr, *d_cnt_in = nullptr;
+    void* d_temp = nullptr;
+    size_t temp_bytes = 0;
+    bool ok = check(hipMalloc(reinterpret_cast<void**>(&d_rows), std::max<size_t>(size_t(L_.num_rows) * 4, 16)), "hipMalloc") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_adv_in), slots * 8), "hipMalloc") && check(hipMalloc(reinterpret_cast<void**>(&d_cnt_in), slots * 8), "hipMalloc") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_advance_), slots * 8), "hipMalloc") && check(hipMalloc(reinterpret_cast<void**>(&d_base_), slots * 8), "hipMalloc") &&
+              check(hipMemsetAsync(d_rows, 0, size_t(L_.num_rows) * 4, stream_), "hipMemset") &&
+              check(hipMemsetAsync(d_adv_in + total_slots_, 0, 8, stream_), "hipMemset") && check(hipMemsetAsync(d_cnt_in + total_slots_, 0, 8, stream_), "hipMemset") &&
+              check(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_adv_in, d_advance_, slots, stream_), "scan (size)") &&
+              check(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)), "hipMalloc(scan)");
+    auto lap = [&](const char* what) { if (timer.on) { (void)hipStreamSynchronize(stream_); timer.lap(what); } };
+    lap("gpu:   allocations");
+    if (ok && total_slots_) {
+        hipLaunchKernelGGL(segment_sums_kernel, grid, block, 0, stream_, d_channels_, groups, num_groups_, total_slots_, d_adv_in, d_cnt_in);
+        ok = check(hipGetLastError(), "segment_sums_kernel");
+    }
+    lap("gpu:   segment sums");
+    ok = ok && check(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_adv_in, d_advance_, slots, stream_), "scan") &&
+         check(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_cnt_in, d_base_, slots, stream_), "scan");
+    lap("gpu:   scans");
+    if (ok && total_slots_) {
+        hipLaunchKernelGGL(count_rows_kernel, grid, block, 0, stream_, d_channels_, groups, num_groups_, total_slots_, d_advance_, d_rows, d_scalar_);
         ok = check(hipGetLastError(), "count_rows_kernel") && decode_error("count rows");
     }
-    std::vector<uint32_t> counts(num_streams_);
+    lap("gpu:   row counts");
     row_nnz.assign(L_.num_rows, 0);
-    ok = ok && check(hipMemcpyAsync(row_nnz.data(), d_rows, size_t(L_.num_rows) * 4, hipMemcpyDeviceToHost, stream_), "read row counts") &&
-         (num_streams_ == 0 || check(hipMemcpyAsync(counts.data(), d_counts, size_t(num_streams_) * 4, hipMemcpyDeviceToHost, stream_), "read stream counts")) &&
+    uint64_t all = 0;
+    ok = ok && (L_.num_rows == 0 || check(hipMemcpyAsync(row_nnz.data(), d_rows, size_t(L_.num_rows) * 4, hipMemcpyDeviceToHost, stream_), "read row counts")) &&
+         check(hipMemcpyAsync(&all, d_base_ + total_slots_, 8, hipMemcpyDeviceToHost, stream_), "read total") &&
          check(hipStreamSynchronize(stream_), "count rows");
-    (void)hipFree(d_rows);
-    (void)hipFree(d_counts);
-    if (!ok) return false;
-    std::vector<uint64_t> base(size_t(num_streams_) + 1, 0);
-    for (uint32_t t = 0; t < num_streams_; ++t) base[t + 1] = base[t] + counts[t];
-    total_ = nnz = base[num_streams_];
-    return check(upload(&d_stream_base_, base, stream_), "upload stream bases") && check(hipStreamSynchronize(stream_), "upload stream bases");
+    lap("gpu:   read back");
+    for (void* p : {static_cast<void*>(d_rows), static_cast<void*>(d_adv_in), static_cast<void*>(d_cnt_in), d_temp})
+        if (p) (void)hipFree(p);
+    lap("gpu:   frees");
+    total_ = nnz = all;
+    timer.lap("gpu: segment scan + row counts");
+    return ok;
 }
 
 bool GpuTiler::count_tiles(const std::vector<uint32_t>& block_of_row, uint32_t num_ranges, std::vector<uint32_t>& cnt) {
@@ -411,9 +516,9 @@ bool GpuTiler::count_tiles(const std::vector<uint32_t>& block_of_row, uint32_t n
     if (!check(upload(&d_block_of_row_, block_of_row, stream_), "upload block_of_row")) return false;
     if (!check(hipMalloc(reinterpret_cast<void**>(&d_cnt), std::max<size_t>(cnt.size() * 4, 16)), "hipMalloc")) return false;
     bool ok = check(hipMemsetAsync(d_cnt, 0, cnt.size() * 4, stream_), "hipMemset");
-    if (ok && num_streams_) {
-        hipLaunchKernelGGL(count_tiles_kernel, dim3((num_streams_ + 255) / 256), dim3(256), 0, stream_, d_channels_, static_cast<const LaneStream*>(d_streams_),
-                           num_streams_, d_block_of_row_, tiles, S, L_.sub_width, d_cnt);
+    if (ok && total_slots_) {
+        hipLaunchKernelGGL(count_tiles_kernel, dim3((total_slots_ + 255) / 256), dim3(256), 0, stream_, d_channels_, static_cast<const StreamGroup*>(d_groups_),
+                           num_groups_, total_slots_, d_advance_, d_block_of_row_, tiles, S, L_.sub_width, d_cnt);
         ok = check(hipGetLastError(), "count_tiles_kernel");
     }
     ok = ok && (cnt.empty() || check(hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost, stream_), "read tile counts")) &&
@@ -425,6 +530,7 @@ bool GpuTiler::count_tiles(const std::vector<uint32_t>& block_of_row, uint32_t n
 bool GpuTiler::sort_elements(const std::vector<uint32_t>& block_of_row, const std::vector<uint32_t>& range_row0, const std::vector<uint32_t>& unit_of,
                              const std::vector<UnitPlan>& plans, bool& duplicates) {
     (void)block_of_row;      // already on the device (count_tiles)
+    detail::PhaseTimer timer;
     duplicates = false;
     const uint32_t S = L_.subs_per_cp, tiles = L_.col_parts * S;
     uint32_t *d_row0 = nullptr, *d_unit_of = nullptr, *d_vals_in = nullptr;
@@ -436,11 +542,12 @@ bool GpuTiler::sort_elements(const std::vector<uint32_t>& block_of_row, const st
               check(hipMalloc(reinterpret_cast<void**>(&d_vals_in), n * 4), "hipMalloc(values)") &&
               check(hipMalloc(reinterpret_cast<void**>(&d_keys_), n * 8), "hipMalloc(keys)") &&
               check(hipMalloc(reinterpret_cast<void**>(&d_vals_), n * 4), "hipMalloc(values)");
-    if (ok && num_streams_) {
-        hipLaunchKernelGGL(keys_kernel, dim3((num_streams_ + 255) / 256), dim3(256), 0, stream_, d_channels_, static_cast<const LaneStream*>(d_streams_),
-                           num_streams_, d_block_of_row_, d_row0, d_unit_of, tiles, S, L_.sub_width, d_stream_base_, d_keys_in, d_vals_in);
+    if (ok && total_slots_) {
+        hipLaunchKernelGGL(keys_kernel, dim3((total_slots_ + 255) / 256), dim3(256), 0, stream_, d_channels_, static_cast<const StreamGroup*>(d_groups_),
+                           num_groups_, total_slots_, d_advance_, d_base_, d_block_of_row_, d_row0, d_unit_of, tiles, S, L_.sub_width, d_keys_in, d_vals_in);
         ok = check(hipGetLastError(), "keys_kernel");
     }
+    if (timer.on) { (void)hipStreamSynchronize(stream_); timer.lap("gpu: keys"); }
     if (ok && total_) {
         uint32_t unit_bits = 1;
         while ((uint64_t(1) << unit_bits) < plans.size() + 1) ++unit_bits;
@@ -458,6 +565,7 @@ bool GpuTiler::sort_elements(const std::vector<uint32_t>& block_of_row, const st
         }
     }
     ok = ok && check(hipStreamSynchronize(stream_), "sort");
+    timer.lap("gpu: radix sort");
     for (void* p : {static_cast<void*>(d_row0), static_cast<void*>(d_unit_of), static_cast<void*>(d_keys_in), static_cast<void*>(d_vals_in), d_temp})
         if (p) (void)hipFree(p);
     // the CPSR image is not needed any more

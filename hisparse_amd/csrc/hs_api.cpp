@@ -10,6 +10,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -17,6 +19,7 @@
 
 #include "hisparse/common.h"
 #include "spmv_kernels.h"
+#include "gpu_tiles.h"
 #include "stream_tiles.h"
 
 using hisparse::Geometry;
@@ -220,6 +223,13 @@ int hs_create(hs_context** out, int device_id, int impl, uint32_t ob_bank, uint3
         return hip_fail(nullptr, e, "hipSetDevice/hipStreamCreate");
     }
     c->stream = c->own_stream;
+    // "program the device" here, not inside the first hs_load_matrix: the code objects load on first use, and the dynamic-LDS cap
+    // is a property of the FUNCTION (always the full 160 KiB, so that no context can lower it under another one's launches)
+    if ((e = hisparse::dev::configure_spmv_kernels(hisparse::dev::kMaxLdsBytes)) != hipSuccess || (e = hisparse::dev::warm_gpu_tiler()) != hipSuccess) {
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return hip_fail(nullptr, e, "loading the gfx950 kernels");
+    }
     *out = c;
     return HS_OK;
 }
@@ -276,6 +286,9 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
         if (tiles.d_image) (void)hipFree(tiles.d_image);
         return fail(ctx, HS_ERR_NO_MEMORY, "out of host memory while re-tiling the matrix");
     }
+    const bool debug = std::getenv("HISPARSE_PLAN_DEBUG") != nullptr;
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    if (debug) std::fprintf(stderr, "load: image built after %.1f ms\n", since());
     const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers, tiles.format);
     if (lds_bytes > hisparse::dev::kMaxLdsBytes) {
         if (tiles.d_image) (void)hipFree(tiles.d_image);
@@ -298,6 +311,7 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
     if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
+    if (debug) std::fprintf(stderr, "load: descriptors + result buffers on the device after %.1f ms\n", since());
     ctx->num_rows = num_rows;
     ctx->num_cols = num_cols;
     ctx->row_parts = num_row_partitions;

@@ -12,6 +12,7 @@ import cases
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 fails = 0
+on_gpu = 0
 t0 = time.time()
 for case in range(n_cases):
     impl = int(rng.integers(0, 3))
@@ -79,9 +80,18 @@ for case in range(n_cases):
     if not ok:
         bad_runs.append(("partitions", int((got != want).sum()), []))
     st = eng.stats()
+    if st["retiled_on_gpu"]:
+        # the image the device built against the host builder's, byte for byte
+        on_gpu += 1
+        dev = eng.read_tiles()
+        ref = device.build_tiles(cp, impl, cp.ob_bank, cp.vb_bank, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions,
+                                 st["num_compute_units"])
+        for part in ("image", "blocks", "units"):
+            if dev[part].tobytes() != ref[part].tobytes():
+                bad_runs.append(("gpu re-tile: " + part + " differs from the host builder's", 0, []))
     eng.close()
     if bad_runs:
         fails += 1
         print(f"FAIL case {case}: impl {impl} {rows}x{cols} density {density} vb {vb} ob {ob} skip {skip} fmt {fmt} runs '{runs}' slices '{slices}' seed {seed} "
               f"blocks {st['num_blocks']} units {st['num_units']} cs {st['col_slices']} ring {st['ring_buffers']}: {bad_runs}", flush=True)
-print(f"{n_cases} cases, {fails} failing, {time.time() - t0:.0f} s")
+print(f"{n_cases} cases ({on_gpu} re-tiled on the GPU and compared with the host builder), {fails} failing, {time.time() - t0:.0f} s")
