@@ -269,7 +269,10 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             blk.nrows = ranges[b].nrows;
             blk.row_part = ranges[b].row_part;
             if (delta) {   // long rows: position gaps well inside a row (HISPARSE_ROW_RUNS=0|1 forces, for the tests)
-                const double gap = range_nnz[b] ? double(ranges[b].nrows) * double(num_cols) / double(range_nnz[b]) : 1e30;
+                // (over the rows that HAVE non-zeros: the padding rows at the end of a float_stall matrix would make the last block look sparse)
+                uint32_t live_rows = 0;
+                for (uint32_t r = 0; r < ranges[b].nrows; ++r) live_rows += row_nnz[ranges[b].row0 + r] != 0;
+                const double gap = range_nnz[b] ? double(live_rows) * double(num_cols) / double(range_nnz[b]) : 1e30;
                 const char* force = std::getenv("HISPARSE_ROW_RUNS");
                 blk.flags = (force ? std::atoi(force) != 0 : gap < kDenseMeanGap) ? kBlockDenseRows : 0u;
             } else if (owner) {
@@ -362,14 +365,25 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     });
     }
 
-    // DELTA pays for every position gap beyond 16 bits with a bridge slot.  A graph whose gaps are heavy-tailed (R-MAT: a quarter
-    // of the rows empty, hubs of 10^5 non-zeros) needs one for every 25th element although its MEAN gap looks fine, and its
-    // lanes' runs are unevenly filled: measured 82 us against 60 us in PAIRS on the R-MAT ogbl-ppa stand-in, where the
-    // Chung-Lu stand-in (0.4 % bridges) is faster in DELTA.  So: more than 2 % bridge slots -> PAIRS after all.
+    // DELTA or PAIRS, now that every unit's slots are known (automatic choice only):
+    //  * DELTA pays for every position gap beyond 16 bits with a bridge slot.  A graph whose gaps are heavy-tailed (R-MAT: a quarter
+    //    of the rows empty, hubs of 10^5 non-zeros) needs one for every 25th element although its MEAN gap looks fine, and its
+    //    lanes' runs are unevenly filled: measured 82 us against 60 us in PAIRS on the R-MAT ogbl-ppa stand-in, where the
+    //    Chung-Lu stand-in (0.4 % bridges) is faster in DELTA.  So: more than 2 % bridge slots -> PAIRS.
+    //  * DELTA's 6-byte slots only pay when the stream is what bounds the kernel.  Measured over 20 shapes (tools/probe_synth.py,
+    //    40000^2 and 400000 x 100000 power-law matrices at mean gaps 16 ... 4096, ogbl-ppa, mouse_gene):
+    //    t(DELTA) - t(PAIRS) = (bytes saved) / 6.5 TB/s - c with c = 3.5 us fixed point, 6 us float (more instructions per element,
+    //    a head record per unit and wavefront).  So: DELTA only when it saves more than kDeltaMinSavedBytes of stream.
     if (delta && !format_forced) {
-        uint64_t slots = 0;
-        for (const UnitPlan& up : plans) slots += up.slots;
-        if (double(slots) > 1.02 * double(out.nnz)) {
+        uint64_t slots = 0, pairs_bytes = 0, delta_bytes = 0;
+        for (const UnitPlan& up : plans) {
+            slots += up.slots;
+            const uint64_t pairs_chunks = (uint64_t(up.n) + kWaveLanes - 1) / kWaveLanes, records = (up.slots + kWaveLanes - 1) / kWaveLanes;
+            pairs_bytes += pairs_chunks * kChunkBytes;
+            delta_bytes += (records + std::min<uint64_t>(records, kConsumerWaves)) * kRecordBytes;      // + one head per wavefront with records
+        }
+        const uint64_t min_saved = is_float ? kDeltaMinSavedBytesFloat : kDeltaMinSavedBytes;
+        if (double(slots) > 1.02 * double(out.nnz) || pairs_bytes < delta_bytes + min_saved) {
             delta = false;
             out.format = kFormatPairs;
             for (UnitPlan& up : plans) up.slots = up.n;

@@ -43,12 +43,13 @@
 //       (fixed-point tails are padded with gap 0 / value 0).  Each wavefront's records are contiguous.
 //       On ogbl-ppa this is 6.6 bytes per non-zero all in (heads, bridges, padding) instead of 8.03.
 //
-//     DELTA is chosen when the mean position gap rows*cols/nnz lies in [kDeltaMinMeanGap, kDeltaMaxMeanGap]:
-//     denser matrices run faster in PAIRS (fewer instructions per element once the stream is no longer the
-//     bound), hyper-sparse ones would need a bridge for every other gap.  Inside a DELTA matrix, blocks whose
-//     rows are long (heavy rows of a power-law graph; block gap < kDenseMeanGap) are flagged kBlockDenseRows:
-//     there every lane sums its run in a register and touches its LDS accumulator only when its row changes
-//     (otherwise the lanes of one instruction collide on the few rows there are: 56 vs 48 us on mouse_gene).
+//     DELTA is tried when the mean position gap rows*cols/nnz lies in [kDeltaMinMeanGap, kDeltaMaxMeanGap] (hyper-sparse matrices
+//     would need a bridge for every other gap) and kept when, after the sort, it needs at most 2 % bridge slots AND saves more
+//     than kDeltaMinSavedBytes of stream against PAIRS: its slots cost more instructions and a head record per unit and
+//     wavefront, which only pays when the stream bounds the kernel (stream_tiles.cpp has the measurements).  Inside a DELTA matrix,
+//     blocks whose rows are long (block gap < kDenseMeanGap) are flagged kBlockDenseRows: there every lane sums its run in a
+//     register and touches its LDS accumulator only when its row changes (otherwise the lanes of one instruction collide on
+//     the few rows there are: 55.6 vs 38.9 us on mouse_gene).
 //     HISPARSE_STREAM_FORMAT=pairs|delta overrides (the parity tests run both on every case).
 //
 // Markers, lane padding and partition headers of the CPSR image are gone in both formats.
@@ -87,9 +88,12 @@ constexpr uint32_t kRecordBytes = kWaveLanes * (4 + 2);       // one wavefront s
 constexpr uint32_t kMaxGap = 0xfffeu;                         // largest position gap an element slot can carry
 constexpr uint32_t kBridgeGap = 0xffffu;                      // gap code of a slot without element ...
 constexpr uint32_t kBridgeAdvance = 0xffffu;                  // ... which advances the position by this much
-constexpr double kDeltaMinMeanGap = 2048.0;                   // denser matrices: PAIRS wins (measured: mouse_gene 43.6 vs 48.0 us, transformer-50 18.6 vs 24.4)
+constexpr double kDeltaMinMeanGap = 8.0;                      // (denser matrices are BITMAP candidates)
 constexpr double kDeltaMaxMeanGap = 20000.0;                  // sparser matrices: > 4 % of the gaps need bridges, PAIRS wins
-constexpr double kDenseMeanGap = 2048.0;                      // DELTA blocks denser than this sum per lane in registers (kBlockDenseRows)
+constexpr uint64_t kDeltaMinSavedBytes = 23u << 20;           // DELTA must save this much stream against PAIRS (3.5 us at 6.5 TB/s) ...
+constexpr uint64_t kDeltaMinSavedBytesFloat = 40u << 20;      // ... 6 us in the float modes (stream_tiles.cpp: the choice after the sort)
+constexpr double kDenseMeanGap = 320.0;                       // DELTA blocks denser than this (>= 24 elements per row and sub-tile) sum per lane in registers (kBlockDenseRows);
+                                                              // sparser ones lose with it (400000 x 100000, gap 512: 89.8 vs 83.2 us), denser ones win big (40000^2, gap 64: 34.5 vs 53.0)
 enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1, kFormatBitmap = 2, kFormatOwner = 3, kFormatPairs24 = 4, kFormatOwner24 = 5 };
 // PAIRS24 / OWNER24: the same two formats with a 24-bit position word -- 7 instead of 8 bytes per element.  A wavefront step is
 // 448 bytes: 64 value dwords, then 64 x 3 bytes (local_row << 13 | local_col, little endian), which the kernel reads as unaligned

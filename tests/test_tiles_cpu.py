@@ -135,16 +135,21 @@ def test_column_slices(impl, slices, monkeypatch):
 
 
 def test_format_choice(monkeypatch):
-    # unforced: DELTA for sparse-but-not-hyper-sparse matrices (mean position gap rows*cols/nnz in [2048, 20000]), else PAIRS
+    # unforced: DELTA is tried for mean position gaps rows*cols/nnz in [8, 20000] and kept when it needs <= 2 % bridge slots and saves
+    # more than 23 MiB of stream against PAIRS (stream_tiles.cpp); everything else is PAIRS
     monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
-    for rows, cols, nnz, want in [(20000, 60000, 150000, "delta"), (3000, 3000, 90000, "pairs"), (60000, 90000, 100000, "pairs")]:
+    for rows, cols, nnz, want in [(20000, 60000, 150000, "pairs"),       # right gap, but a 1 MB image: nothing to save
+                                  (40000, 40000, 16000000, "delta"),     # 128 MB in PAIRS, 100 MB in DELTA
+                                  (60000, 90000, 100000, "pairs")]:      # hyper-sparse
         csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=nnz, b=0.0, c=1.0, seed=2)
         cp = host.format_matrix(csr, 0, skip_empty_rows=True)
-        gap = cp.num_rows * cp.num_cols / cp.nnz
-        assert (2048 <= gap <= 20000) == (want == "delta"), gap
-        assert build(cp, 0, 16)["format"][:5] == want          # "pairs" or its 7-byte form "pairs24" (blocks of <= 2046 rows)
+        t = build(cp, 0, 16)
+        assert t["format"][:5] == want          # "pairs" or its 7-byte form "pairs24" (blocks of <= 2046 rows)
+        if want == "delta":
+            assert t["image"].size + (23 << 20) < 8 * cp.nnz
     # inside a DELTA matrix, blocks of heavy rows are flagged for per-lane register sums, the sparse bulk is not
-    csr = host.CSRMatrix.generate("powerlaw", 30000, 60000, a=600000, b=0.8, c=1.0, seed=3)
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "delta")
+    csr = host.CSRMatrix.generate("powerlaw", 30000, 60000, a=2400000, b=0.8, c=1.0, seed=3)
     cp = host.format_matrix(csr, 0, skip_empty_rows=True)
     t = build(cp, 0, 64)
     flags = t["blocks"]["flags"] & 1
