@@ -574,6 +574,52 @@ int hs_bind_device_result(hs_context* ctx, void* y_dev) {
     return HS_OK;
 }
 
+// SpMM as k SpMVs over the resident image (hisparse_hip.h): every column of X through the same kernels, so every column of Y is
+// exactly what hs_run gives for it.
+int hs_spmm_device(hs_context* ctx, const void* x_dev, uint64_t ldx, void* y_dev, uint64_t ldy, uint32_t k) {
+    if (!ctx) return HS_ERR_BAD_ARG;
+    if (!ctx->matrix_loaded) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix has not been called");
+    if (k == 0) return HS_OK;
+    if (!x_dev || !y_dev) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+    if ((reinterpret_cast<uintptr_t>(x_dev) & 15u) || (reinterpret_cast<uintptr_t>(y_dev) & 15u) || (ldx & 3u) || (ldy & 3u))
+        return fail(ctx, HS_ERR_BAD_ARG, "device matrices must be 16-byte aligned with leading dimensions that are multiples of 4 words");
+    if (ldx < ctx->num_cols || ldy < ctx->num_rows) return fail(ctx, HS_ERR_BAD_ARG, "leading dimensions must cover the padded column / row counts");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t* x_saved = ctx->x_bound;
+    uint32_t* y_saved = ctx->y_bound;
+    int rc = HS_OK;
+    for (uint32_t j = 0; j < k && rc == HS_OK; ++j) {
+        ctx->x_bound = static_cast<const uint32_t*>(x_dev) + size_t(j) * ldx;
+        ctx->y_bound = static_cast<uint32_t*>(y_dev) + size_t(j) * ldy;
+        rc = enqueue(ctx, -1, nullptr, nullptr);
+    }
+    ctx->x_bound = x_saved;
+    ctx->y_bound = y_saved;
+    return rc;
+}
+
+int hs_spmm(hs_context* ctx, const void* packed_x, uint32_t num_cols, uint32_t k, void* packed_y, uint32_t num_rows) {
+    if (!ctx) return HS_ERR_BAD_ARG;
+    if (!ctx->matrix_loaded) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix has not been called");
+    if (num_cols != ctx->num_cols || num_rows != ctx->num_rows) return fail(ctx, HS_ERR_BAD_ARG, "dimensions must equal the matrix's padded column / row counts");
+    if (k == 0) return HS_OK;
+    if (!packed_x || !packed_y) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t ldx = (uint64_t(num_cols) + 3u) & ~uint64_t(3), ldy = (uint64_t(num_rows) + 3u) & ~uint64_t(3);
+    struct Buffers {   // freed on every return path
+        uint32_t *x = nullptr, *y = nullptr;
+        ~Buffers() { if (x) (void)hipFree(x); if (y) (void)hipFree(y); }
+    } b;
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&b.x), size_t(ldx) * k * 4 + 64));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&b.y), size_t(ldy) * k * 4));
+    HS_HIP(ctx, hipMemcpy2DAsync(b.x, size_t(ldx) * 4, packed_x, size_t(num_cols) * 4, size_t(num_cols) * 4, k, hipMemcpyHostToDevice, ctx->stream));
+    int rc = hs_spmm_device(ctx, b.x, ldx, b.y, ldy, k);
+    if (rc != HS_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    HS_HIP(ctx, hipMemcpy2DAsync(packed_y, size_t(num_rows) * 4, b.y, size_t(ldy) * 4, size_t(num_rows) * 4, k, hipMemcpyDeviceToHost, ctx->stream));
+    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HS_OK;
+}
+
 int hs_get_stats(const hs_context* ctx, hs_stats* stats) {
     if (!ctx || !stats) return HS_ERR_BAD_ARG;
     *stats = ctx->stats;

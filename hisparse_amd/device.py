@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
     "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
-    "hs_bind_device_vector", "hs_bind_device_result", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_tiles_build", "hs_tiles_info",
+    "hs_bind_device_vector", "hs_bind_device_result", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
 
@@ -83,6 +83,8 @@ def lib():
         l.hs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.hs_debug_read_tiles.argtypes = [vp, vp, u64, vp, vp]
+        l.hs_spmm.argtypes = [vp, vp, u32, u32, vp, u32]
+        l.hs_spmm_device.argtypes = [vp, vp, u64, vp, u64, u32]
         l.hs_tiles_build.argtypes = [C.POINTER(vp), C.POINTER(u64), C.c_int, u32, u32, u32, u32, u32, u32, u32, C.POINTER(vp)]
         l.hs_tiles_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64),
                                     C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
@@ -224,6 +226,17 @@ class SpmvEngine:
         y = np.empty(self.csc_rows, dtype=np.uint32)
         self._check(lib().hs_read_spmspv_result(self._h, y.ctypes.data, y.size))
         return y
+
+    def spmm(self, x_words):
+        """Y = A X for X of shape (k, num_cols) value words (one packed vector per row); returns (k, num_rows) words."""
+        x_words = np.ascontiguousarray(x_words, dtype=np.uint32)
+        k = x_words.shape[0]
+        y = np.empty((k, self.num_rows), dtype=np.uint32)
+        self._check(lib().hs_spmm(self._h, x_words.ctypes.data, x_words.shape[1], k, y.ctypes.data, self.num_rows))
+        return y
+
+    def spmm_device(self, x_dev, ldx, y_dev, ldy, k):
+        self._check(lib().hs_spmm_device(self._h, C.c_void_p(x_dev), ldx, C.c_void_p(y_dev), ldy, k))
 
     # ---- measurement ----------------------------------------------------------------------------
     def stats(self):

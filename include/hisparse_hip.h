@@ -149,6 +149,17 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* 
 int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count);
 int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows);
 
+/* ---- SpMM (EXTENSION; the reference has no SpMM) ----------------------------------------------------------
+ * Y = A X for k dense vectors, column j of X / Y being a packed vector of num_cols / num_rows words (the layouts of hs_load_vector
+ * and hs_read_result).  The k columns go through the SpMV kernels one after the other over the image hs_load_matrix left on the
+ * device -- the matrix is streamed k times; a fused k-wide kernel is not built -- so column j of Y is exactly what hs_run gives for
+ * column j of X.  The context's own vector / result and its bindings are left as they were.
+ *   hs_spmm_device: X and Y in device memory, column j at x_dev + j * ldx words / y_dev + j * ldy words; 16-byte aligned, ldx and ldy
+ *     multiples of 4 words with ldx >= num_cols, ldy >= num_rows.  Asynchronous on the context's stream.
+ *   hs_spmm: host pointers, columns back to back (ldx = num_cols, ldy = num_rows); copies in, runs, copies out, synchronous. */
+int hs_spmm_device(hs_context* ctx, const void* x_dev, uint64_t ldx, void* y_dev, uint64_t ldy, uint32_t k);
+int hs_spmm(hs_context* ctx, const void* packed_x, uint32_t num_cols, uint32_t k, void* packed_y, uint32_t num_rows);
+
 /* ---- measurement ------------------------------------------------------------------------------- */
 int hs_get_stats(const hs_context* ctx, hs_stats* stats);
 /* `runs` back-to-back hs_run calls after `warmup` untimed ones, bracketed by HIP events on the

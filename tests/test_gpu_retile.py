@@ -56,9 +56,9 @@ def test_small_banks_many_partitions(monkeypatch, fmt, impl, skip):
 @pytest.mark.parametrize("impl", [0, 1, 2])
 def test_default_banks(monkeypatch, fmt, impl):
     _set_format(monkeypatch, fmt)
+    # (the host generator: scipy.sparse.random takes 10 s and more at these shapes)
     for rows, cols, density, seed in [(1000, 1000, 0.01, 1), (40000, 9000, 0.002, 5), (70, 50000, 0.01, 7), (300000, 64, 0.05, 9)]:
-        m = cases.random_csr(rows, cols, density, seed, impl)
-        csr = host.CSRMatrix.from_scipy(m)
+        csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=rows * cols * density, b=0.3, c=1.5, seed=seed)
         cp = host.format_matrix(csr, impl, skip_empty_rows=True)
         _compare(cp, impl)
 
@@ -91,11 +91,11 @@ def test_default_format_choice(monkeypatch):
     monkeypatch.delenv("HISPARSE_STREAM_FORMAT", raising=False)
     monkeypatch.delenv("HISPARSE_RETILE", raising=False)
     for impl in (0, 1, 2):
-        m = cases.random_csr(30000, 30000, 0.001, 21, impl)
-        cp = host.format_matrix(host.CSRMatrix.from_scipy(m), impl, skip_empty_rows=True)
+        csr = host.CSRMatrix.generate("powerlaw", 30000, 30000, a=900000, b=0.2, c=1.5, seed=21)
+        cp = host.format_matrix(csr, impl, skip_empty_rows=True)
         _compare(cp, impl)
-    m = cases.random_csr(512, 8192, 0.5, 22, 2)
-    cp = host.format_matrix(host.CSRMatrix.from_scipy(m), 2, skip_empty_rows=True)
+    csr = host.CSRMatrix.generate("bernoulli", 512, 8192, b=0.5, c=1.0, seed=22)
+    cp = host.format_matrix(csr, 2, skip_empty_rows=True)
     st = _compare(cp, 2, expect_gpu=False)
     assert device.STREAM_FORMATS[st["stream_format"]] == "bitmap"
 
