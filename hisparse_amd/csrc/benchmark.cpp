@@ -15,6 +15,7 @@
 //   --values literal|intent|keep   literal: every value := `1 / num_cols` in INTEGER arithmetic = 0.0, exactly what
 //                                  sw/benchmark.cpp:411 does (timing parity; y is all zeros); intent (default for .npz):
 //                                  1.0f / num_cols; keep (default for synth:): the data set's own values
+//   --from-csr                     load with hs_load_matrix_csr (pad + convert + re-tile on the device) instead of csr2cpsr + hs_load_matrix
 //   --partition-loop               time the reference's literal launch loop: one hs_run_partition + hs_sync (= finish())
 //                                  per row partition (:318-338) instead of one launch for the whole SpMV
 //   --runs K                       NUM_RUNS (default 50, :29)
@@ -54,6 +55,7 @@ struct Options {
     unsigned runs = 50;  // NUM_RUNS, sw/benchmark.cpp:29
     std::string values;  // literal | intent | keep ("" = default for the dataset kind)
     bool partition_loop = false;
+    bool from_csr = false;     // --from-csr: hs_load_matrix_csr instead of csr2cpsr + hs_load_matrix (single GPU)
     std::string dump_x, dump_y;
     int gpus = 1;
     bool gather = true;
@@ -128,8 +130,14 @@ struct DeviceSlab {   // one device's share of the matrix
     hisparse::ChannelPackets packets;
 };
 
-void load_slab(DeviceSlab& s, const Options& o, int device, const std::vector<uint32_t>& vector) {
+void load_slab(DeviceSlab& s, const Options& o, int device, const std::vector<uint32_t>& vector, const spmv::io::CSRMatrix<float>* csr = nullptr) {
     check(hs_create(&s.ctx, device, o.impl, o.ob_bank_size, o.vb_bank_size), nullptr, "hs_create");
+    if (csr) {     // straight from CSR: the device pads, converts and re-tiles (hisparse_hip.h)
+        check(hs_load_matrix_csr(s.ctx, csr->num_rows, csr->num_cols, csr->adj_indptr.data(), csr->adj_indices.data(), csr->adj_data.data(), nullptr, nullptr),
+              s.ctx, "hs_load_matrix_csr");
+        check(hs_load_vector(s.ctx, vector.data(), s.packets.num_cols), s.ctx, "hs_load_vector");
+        return;
+    }
     const void* ch[HS_NUM_CHANNELS];
     uint64_t n[HS_NUM_CHANNELS];
     for (unsigned c = 0; c < HS_NUM_CHANNELS; ++c) {
@@ -159,7 +167,16 @@ benchmark_result spmv_benchmark(const Options& o, spmv::io::CSRMatrix<float>& ex
     const auto t0 = clock::now();
     hisparse::Geometry g = hisparse::make_geometry(o.impl, o.ob_bank_size, o.vb_bank_size);
     DeviceSlab s;
-    s.packets = hisparse::format_matrix(ext_matrix, g, skip_empty_rows);
+    if (o.from_csr) {      // no CPSR at all: only the padded dimensions and the partition counts the launch loop needs
+        s.packets.geom = g;
+        s.packets.num_rows = uint32_t((uint64_t(ext_matrix.num_rows) + g.row_divisor - 1) / g.row_divisor * g.row_divisor);
+        s.packets.num_cols = (ext_matrix.num_cols + hisparse::PACK_SIZE - 1) / hisparse::PACK_SIZE * hisparse::PACK_SIZE;
+        s.packets.num_row_partitions = uint32_t((s.packets.num_rows + g.logical_ob - 1) / g.logical_ob);
+        s.packets.num_col_partitions = uint32_t((s.packets.num_cols + g.logical_vb - 1) / g.logical_vb);
+        s.packets.nnz = ext_matrix.adj_data.size();
+    } else {
+        s.packets = hisparse::format_matrix(ext_matrix, g, skip_empty_rows);
+    }
     const hisparse::ChannelPackets& packets = s.packets;
     const auto t1 = clock::now();
     res.preprocess_time_s = std::chrono::duration<double>(t1 - t0).count();
@@ -169,7 +186,7 @@ benchmark_result spmv_benchmark(const Options& o, spmv::io::CSRMatrix<float>& ex
 
     std::vector<uint32_t> vector = make_vector(o.impl, packets.num_cols), result(packets.num_rows, 0);
     std::cout << "INFO : Input/result initialization complete!" << std::endl;
-    load_slab(s, o, o.device, vector);
+    load_slab(s, o, o.device, vector, o.from_csr ? &ext_matrix : nullptr);
     hs_context* ctx = s.ctx;
     std::cout << "INFO : Host -> Device data transfer complete!" << std::endl;
     hs_stats st;
@@ -327,6 +344,7 @@ bool parse_args(int argc, char** argv, Options& o) {
         };
         if (a == "--values") o.values = need("--values");
         else if (a == "--partition-loop") o.partition_loop = true;
+        else if (a == "--from-csr") o.from_csr = true;
         else if (a == "--runs") o.runs = unsigned(std::max(1, std::atoi(need("--runs").c_str())));
         else if (a == "--dump-x") o.dump_x = need("--dump-x");
         else if (a == "--dump-y") o.dump_y = need("--dump-y");
@@ -357,7 +375,7 @@ int main(int argc, char** argv) {
     Options o;
     if (!parse_args(argc, argv, o)) {
         std::cout << "Usage: " << argv[0] << " <fixed|float_pob|float_stall> <dataset.npz | synth:kind:rows:cols:a:b:c:seed> <v> <o> [device]"
-                  << " [--values literal|intent|keep] [--partition-loop] [--runs K] [--dump-x FILE] [--dump-y FILE] [--gpus N [--no-gather] [--sharded]]" << std::endl;
+                  << " [--values literal|intent|keep] [--from-csr] [--partition-loop] [--runs K] [--dump-x FILE] [--dump-y FILE] [--gpus N [--no-gather] [--sharded]]" << std::endl;
         return 0;
     }
     std::cout << "------ Running benchmark on " << o.dataset << std::endl;

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <numeric>
 
+#include "hisparse/q8_24.h"
 #include "tiles_common.h"
 
 namespace hisparse {
@@ -16,7 +17,8 @@ namespace dev {
 using namespace detail;
 
 bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
-                        const std::vector<uint32_t>& row_nnz, uint32_t max_workgroups, StreamTiles& out, std::string& error) {
+                        const std::vector<uint32_t>& row_nnz, uint32_t max_workgroups, StreamTiles& out, std::string& error,
+                        const CsrView* csr) {
     const uint32_t num_rows = L.num_rows, num_cols = L.num_cols, RP = L.row_parts, CP = L.col_parts;
     const uint32_t G = std::max<uint32_t>(1, max_workgroups);
     // a mask per 64 columns of every row: only sensible for dense rows; when the format is FORCED onto a big sparse matrix
@@ -33,7 +35,21 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     for (uint32_t r = 0; r < num_rows; ++r) row_ptr[r + 1] = row_ptr[r] + row_nnz[r];
     const uint64_t nnz = row_ptr[num_rows];
     std::vector<uint64_t> elems(nnz);                       // column << 32 | value word: sorts by column
-    {
+    if (csr) {       // the rows are there already; value words as csr_matrix_convert_from_float gives them (sw/data_loader.h:76-84)
+        const bool fixed = L.g->impl == IMPL_FIXED;
+        std::atomic<bool> bad_column(false);
+        parallel_for((csr->num_rows + 1023) / 1024, [&](size_t chunk) {
+            for (uint32_t r = uint32_t(chunk) * 1024; r < std::min<uint64_t>(csr->num_rows, (chunk + 1) * 1024); ++r)
+                for (uint64_t e = csr->indptr[r], o = row_ptr[r]; e < csr->indptr[r + 1]; ++e, ++o) {
+                    if (csr->indices[e] >= csr->num_cols) bad_column = true;
+                    uint32_t word;
+                    if (fixed) word = q8_24_raw_from_double(double(csr->values[e]));
+                    else std::memcpy(&word, &csr->values[e], 4);
+                    elems[o] = (uint64_t(csr->indices[e]) << 32) | word;
+                }
+        });
+        if (bad_column) { error = "CSR column index outside the matrix"; return false; }
+    } else {
         std::vector<uint32_t> cursor(num_rows, 0);
         std::vector<WalkResult> res(size_t(RP) * NUM_HBM_CHANNELS);
         // rows of different physical channels are disjoint, and one task takes the column partitions of its rows in ascending

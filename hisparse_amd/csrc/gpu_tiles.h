@@ -29,6 +29,9 @@ hipError_t warm_gpu_tiler();
 class GpuTiler {
   public:
     GpuTiler(const detail::Layout& layout, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS], hipStream_t stream);
+    // the source is a CSR matrix (hs_load_matrix_csr): rows come from indptr, the element passes run one thread per kCsrSegment
+    // consecutive non-zeros, value words are made on the device (csr_matrix_convert_from_float, sw/data_loader.h:76-84)
+    GpuTiler(const detail::Layout& layout, const CsrView& csr, hipStream_t stream);
     ~GpuTiler();
     GpuTiler(const GpuTiler&) = delete;
     GpuTiler& operator=(const GpuTiler&) = delete;
@@ -58,6 +61,7 @@ class GpuTiler {
     bool fail(const std::string& what);
     bool check(hipError_t e, const char* what);
     bool upload_channels();
+    bool upload_csr(std::vector<uint32_t>& row_nnz);
     bool decode_error(const char* pass);
 
     detail::Layout L_;
@@ -67,6 +71,10 @@ class GpuTiler {
     hipStream_t stream_;
     std::string error_;
 
+    const CsrView* csr_ = nullptr;         // CSR source (then channel_ / n_packets_ are null)
+    uint32_t* d_indptr_ = nullptr;         // CSR source: indptr of the PADDED matrix (num_rows + 1), indices, values
+    uint32_t* d_indices_ = nullptr;
+    float* d_values_ = nullptr;
     uint8_t* d_channels_ = nullptr;        // the 16 channel buffers back to back
     void* d_groups_ = nullptr;             // StreamGroup[num_groups_]: the 8 lane streams of one (partition, virtual channel)
     uint32_t num_groups_ = 0;

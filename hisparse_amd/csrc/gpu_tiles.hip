@@ -183,6 +183,78 @@ __global__ __launch_bounds__(256) void keys_kernel(const uint8_t* __restrict__ c
     });
 }
 
+// ---- CSR source ---------------------------------------------------------------------------------------------------------------
+// One thread per kCsrSegment consecutive non-zeros: the row of the first one by binary search in indptr, then forward.
+constexpr uint32_t kCsrSegment = 16;
+
+struct CsrCursor {
+    uint32_t row;
+    uint64_t e, end;
+};
+__device__ __forceinline__ bool csr_segment(const uint32_t* __restrict__ indptr, uint32_t num_rows, uint64_t nnz, uint64_t t, CsrCursor& c) {
+    c.e = t * kCsrSegment;
+    if (c.e >= nnz) return false;
+    c.end = min(c.e + kCsrSegment, nnz);
+    uint32_t lo = 0, hi = num_rows;              // last row with indptr[row] <= e
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (indptr[mid] <= c.e) lo = mid; else hi = mid;
+    }
+    c.row = lo;
+    return true;
+}
+
+// value word of a CSR float: csr_matrix_convert_from_float (sw/data_loader.h:76-84) = the float's bits, or the Q8.24 conversion of
+// include/hisparse/q8_24.h (negatives, zeros and NaN -> 0; round half up; saturate) -- all exact in double, so bit-identical to the host
+__device__ __forceinline__ uint32_t value_word(float v, bool fixed) {
+    if (!fixed) return __float_as_uint(v);
+    const double d = double(v);
+    if (!(d > 0.0)) return 0u;
+    const double scaled = floor(d * 16777216.0 + 0.5);
+    return scaled >= 4294967296.0 ? 0xffffffffu : uint32_t(scaled);
+}
+
+__global__ __launch_bounds__(256) void csr_count_tiles_kernel(const uint32_t* __restrict__ indptr, const uint32_t* __restrict__ indices, uint32_t num_rows,
+                                                             uint64_t nnz, uint32_t num_cols, uint32_t logical_vb, const uint32_t* __restrict__ block_of_row,
+                                                             uint32_t tiles, uint32_t S, uint32_t sub_width, uint32_t* __restrict__ cnt, uint32_t* scalar) {
+    CsrCursor c;
+    if (!csr_segment(indptr, num_rows, nnz, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, c)) return;
+    size_t cur = ~size_t(0);
+    uint32_t run = 0;
+    for (; c.e < c.end; ++c.e) {
+        while (c.e >= indptr[c.row + 1]) ++c.row;
+        const uint32_t col = indices[c.e];
+        if (col >= num_cols) { report(scalar, kErrColumn, c.row / PACK_SIZE, c.row % PACK_SIZE); return; }
+        const uint32_t cp = col / logical_vb, k = (col - cp * logical_vb) / sub_width;
+        const size_t at = size_t(block_of_row[c.row]) * tiles + cp * S + k;
+        if (at != cur) {
+            if (run) atomicAdd(cnt + cur, run);
+            cur = at;
+            run = 0;
+        }
+        ++run;
+    }
+    if (run) atomicAdd(cnt + cur, run);
+}
+
+__global__ __launch_bounds__(256) void csr_keys_kernel(const uint32_t* __restrict__ indptr, const uint32_t* __restrict__ indices, const float* __restrict__ values,
+                                                      uint32_t num_rows, uint64_t nnz, uint32_t logical_vb, uint32_t fixed,
+                                                      const uint32_t* __restrict__ block_of_row, const uint32_t* __restrict__ range_row0,
+                                                      const uint32_t* __restrict__ unit_of, uint32_t tiles, uint32_t S, uint32_t sub_width,
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    CsrCursor c;
+    if (!csr_segment(indptr, num_rows, nnz, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, c)) return;
+    for (; c.e < c.end; ++c.e) {
+        while (c.e >= indptr[c.row + 1]) ++c.row;
+        const uint32_t col = indices[c.e], cp = col / logical_vb, local = col - cp * logical_vb, k = local / sub_width;
+        const uint32_t b = block_of_row[c.row];
+        const uint64_t unit = unit_of[size_t(b) * tiles + cp * S + k];
+        const uint64_t pos = uint64_t(c.row - range_row0[b]) * kSubTileCols + (local - k * sub_width);
+        keys[c.e] = (unit << kPosBits) | pos;
+        vals[c.e] = value_word(values[c.e], fixed != 0);
+    }
+}
+
 __global__ __launch_bounds__(256) void duplicates_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint32_t* flag) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i + 1 < n && keys[i] == keys[i + 1]) *flag = 1;
@@ -373,7 +445,14 @@ GpuTiler::GpuTiler(const Layout& layout, const void* const channel[NUM_HBM_CHANN
     L_.g = &geom_;
 }
 
+GpuTiler::GpuTiler(const Layout& layout, const CsrView& csr, hipStream_t stream)
+    : L_(layout), geom_(*layout.g), channel_(nullptr), n_packets_(nullptr), stream_(stream), csr_(&csr) {
+    L_.g = &geom_;
+}
+
 GpuTiler::~GpuTiler() {
+    for (void* p : {static_cast<void*>(d_indptr_), static_cast<void*>(d_indices_), static_cast<void*>(d_values_)})
+        if (p) (void)hipFree(p);
     for (void* p : {static_cast<void*>(d_channels_), d_groups_, static_cast<void*>(d_advance_), static_cast<void*>(d_base_), static_cast<void*>(d_scalar_),
                     static_cast<void*>(d_block_of_row_), static_cast<void*>(d_keys_), static_cast<void*>(d_vals_), static_cast<void*>(d_bridges_),
                     static_cast<void*>(d_image_)})
@@ -462,8 +541,37 @@ bool GpuTiler::decode_error(const char* pass) {
                 (words[0] == kErrColumn ? "column index outside the column partition" : "decoded row outside the row partition (marker count wrapped?)"));
 }
 
+// CSR source: validate indptr (host, a pass over num_rows words), upload the three arrays; indptr is extended over the padding rows
+bool GpuTiler::upload_csr(std::vector<uint32_t>& row_nnz) {
+    const CsrView& m = *csr_;
+    if (m.num_rows > L_.num_rows || m.num_cols > L_.num_cols) return fail("CSR matrix larger than the padded dimensions");
+    if (!m.indptr || m.indptr[0] != 0) return fail("CSR indptr must start at 0");
+    for (uint32_t r = 0; r < m.num_rows; ++r)
+        if (m.indptr[r + 1] < m.indptr[r]) return fail("CSR indptr decreases at row " + std::to_string(r));
+    total_ = m.indptr[m.num_rows];
+    if (total_ && (!m.indices || !m.values)) return fail("CSR arrays missing");
+    row_nnz.assign(L_.num_rows, 0);
+    std::vector<uint32_t> indptr(size_t(L_.num_rows) + 1, uint32_t(total_));
+    for (uint32_t r = 0; r < m.num_rows; ++r) { indptr[r] = m.indptr[r]; row_nnz[r] = m.indptr[r + 1] - m.indptr[r]; }
+    const size_t n = std::max<uint64_t>(total_, 1);
+    bool ok = check(upload(&d_indptr_, indptr, stream_), "upload indptr") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_indices_), n * 4), "hipMalloc(indices)") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_values_), n * 4), "hipMalloc(values)") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_scalar_), 64), "hipMalloc") && check(hipMemsetAsync(d_scalar_, 0, 64, stream_), "hipMemset");
+    if (ok && total_)
+        ok = check(hipMemcpyAsync(d_indices_, m.indices, size_t(total_) * 4, hipMemcpyHostToDevice, stream_), "upload indices") &&
+             check(hipMemcpyAsync(d_values_, m.values, size_t(total_) * 4, hipMemcpyHostToDevice, stream_), "upload values");
+    return ok && check(hipStreamSynchronize(stream_), "upload");      // `indptr` is a temporary
+}
+
 bool GpuTiler::count_rows(std::vector<uint32_t>& row_nnz, uint64_t& nnz) {
     detail::PhaseTimer timer;
+    if (csr_) {
+        const bool ok = upload_csr(row_nnz);
+        nnz = total_;
+        timer.lap("gpu: upload CSR");
+        return ok;
+    }
     if (!upload_channels()) return false;
     timer.lap("gpu: upload CPSR image");
     const StreamGroup* groups = static_cast<const StreamGroup*>(d_groups_);
@@ -516,7 +624,17 @@ bool GpuTiler::count_tiles(const std::vector<uint32_t>& block_of_row, uint32_t n
     if (!check(upload(&d_block_of_row_, block_of_row, stream_), "upload block_of_row")) return false;
     if (!check(hipMalloc(reinterpret_cast<void**>(&d_cnt), std::max<size_t>(cnt.size() * 4, 16)), "hipMalloc")) return false;
     bool ok = check(hipMemsetAsync(d_cnt, 0, cnt.size() * 4, stream_), "hipMemset");
-    if (ok && total_slots_) {
+    if (ok && csr_ && total_) {
+        const uint64_t threads = (total_ + kCsrSegment - 1) / kCsrSegment;
+        hipLaunchKernelGGL(csr_count_tiles_kernel, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, stream_, d_indptr_, d_indices_, L_.num_rows, total_,
+                           csr_->num_cols, uint32_t(geom_.logical_vb), d_block_of_row_, tiles, S, L_.sub_width, d_cnt, d_scalar_);
+        ok = check(hipGetLastError(), "csr_count_tiles_kernel");
+        if (ok) {
+            uint32_t words[3] = {0, 0, 0};
+            ok = check(hipMemcpyAsync(words, d_scalar_, 12, hipMemcpyDeviceToHost, stream_), "count tiles") && check(hipStreamSynchronize(stream_), "count tiles");
+            if (ok && words[0]) ok = fail("CSR row " + std::to_string(uint64_t(words[1]) * PACK_SIZE + words[2]) + ": column index outside the matrix");
+        }
+    } else if (ok && total_slots_) {
         hipLaunchKernelGGL(count_tiles_kernel, dim3((total_slots_ + 255) / 256), dim3(256), 0, stream_, d_channels_, static_cast<const StreamGroup*>(d_groups_),
                            num_groups_, total_slots_, d_advance_, d_block_of_row_, tiles, S, L_.sub_width, d_cnt);
         ok = check(hipGetLastError(), "count_tiles_kernel");
@@ -542,7 +660,13 @@ bool GpuTiler::sort_elements(const std::vector<uint32_t>& block_of_row, const st
               check(hipMalloc(reinterpret_cast<void**>(&d_vals_in), n * 4), "hipMalloc(values)") &&
               check(hipMalloc(reinterpret_cast<void**>(&d_keys_), n * 8), "hipMalloc(keys)") &&
               check(hipMalloc(reinterpret_cast<void**>(&d_vals_), n * 4), "hipMalloc(values)");
-    if (ok && total_slots_) {
+    if (ok && csr_ && total_) {
+        const uint64_t threads = (total_ + kCsrSegment - 1) / kCsrSegment;
+        hipLaunchKernelGGL(csr_keys_kernel, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, stream_, d_indptr_, d_indices_, d_values_, L_.num_rows, total_,
+                           uint32_t(geom_.logical_vb), uint32_t(geom_.impl == IMPL_FIXED), d_block_of_row_, d_row0, d_unit_of, tiles, S, L_.sub_width, d_keys_in,
+                           d_vals_in);
+        ok = check(hipGetLastError(), "csr_keys_kernel");
+    } else if (ok && total_slots_) {
         hipLaunchKernelGGL(keys_kernel, dim3((total_slots_ + 255) / 256), dim3(256), 0, stream_, d_channels_, static_cast<const StreamGroup*>(d_groups_),
                            num_groups_, total_slots_, d_advance_, d_base_, d_block_of_row_, d_row0, d_unit_of, tiles, S, L_.sub_width, d_keys_in, d_vals_in);
         ok = check(hipGetLastError(), "keys_kernel");
@@ -568,8 +692,10 @@ bool GpuTiler::sort_elements(const std::vector<uint32_t>& block_of_row, const st
     timer.lap("gpu: radix sort");
     for (void* p : {static_cast<void*>(d_row0), static_cast<void*>(d_unit_of), static_cast<void*>(d_keys_in), static_cast<void*>(d_vals_in), d_temp})
         if (p) (void)hipFree(p);
-    // the CPSR image is not needed any more
+    // the source is not needed any more
     if (d_channels_) { (void)hipFree(d_channels_); d_channels_ = nullptr; }
+    for (void** p : {reinterpret_cast<void**>(&d_indptr_), reinterpret_cast<void**>(&d_indices_), reinterpret_cast<void**>(&d_values_)})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
     return ok;
 }
 

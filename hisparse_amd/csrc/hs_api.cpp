@@ -249,9 +249,10 @@ int hs_destroy(hs_context* ctx) {
     return HS_OK;
 }
 
-int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], const uint64_t n_packets[HS_NUM_CHANNELS],
-                   uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions, uint32_t num_col_partitions) {
-    if (!ctx || !channel || !n_packets) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+namespace {
+// hs_load_matrix (CPSR channel buffers) and hs_load_matrix_csr (`csr` != nullptr, channel / n_packets null) behind one body
+int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t* n_packets, const hisparse::dev::CsrView* csr,
+                     uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions, uint32_t num_col_partitions) {
     const Geometry& g = ctx->geom;
     if (num_rows == 0 || num_cols == 0) return fail(ctx, HS_ERR_BAD_ARG, "empty matrix");
     if (num_rows % g.row_divisor != 0 || num_cols % hisparse::PACK_SIZE != 0)
@@ -269,12 +270,14 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     // The per-non-zero passes of the re-tiling run on the GPU (gpu_tiles.h) unless HISPARSE_RETILE=host; BITMAP images and matrices
     // with duplicate entries are built by the host code, which also remains the byte-for-byte checker of the GPU path.
     const char* retile = std::getenv("HISPARSE_RETILE");
-    bool on_gpu = !(retile && std::string(retile) == "host");
+    bool on_gpu = csr || !(retile && std::string(retile) == "host");
     try {
         // one 1024-thread workgroup per CU: its row accumulators and x ring fill the 160 KiB LDS
         bool ok = hisparse::dev::build_stream_tiles(channel, n_packets, g, num_rows, num_cols, num_row_partitions, num_col_partitions,
-                                                    uint32_t(ctx->compute_units), tiles, why, ctx->stream, on_gpu, kImageSlackBytes);
-        if (!ok && on_gpu && why.rfind("gpu re-tile:", 0) == 0) {       // duplicates, or a HIP failure on the way: the host path decides
+                                                    uint32_t(ctx->compute_units), tiles, why, ctx->stream, on_gpu, kImageSlackBytes, csr);
+        if (!ok && csr && why == "gpu re-tile: duplicate entries")
+            why = "the CSR matrix holds a (row, column) twice: format it with csr2cpsr and use hs_load_matrix";
+        if (!ok && !csr && on_gpu && why.rfind("gpu re-tile:", 0) == 0) {       // duplicates, or a HIP failure on the way: the host path decides
             if (tiles.d_image) (void)hipFree(tiles.d_image);
             tiles = hisparse::dev::StreamTiles();
             on_gpu = false;
@@ -326,7 +329,7 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     hs_stats& s = ctx->stats;
     s = hs_stats{};
     s.nnz = tiles.nnz;
-    for (int c = 0; c < HS_NUM_CHANNELS; ++c) s.cpsr_bytes += n_packets[c] * sizeof(hisparse::MatPkt);
+    for (int c = 0; n_packets && c < HS_NUM_CHANNELS; ++c) s.cpsr_bytes += n_packets[c] * sizeof(hisparse::MatPkt);
     s.stream_bytes = tiles.image_bytes;
     s.stream_elements = tiles.elements;
     s.num_blocks = uint32_t(tiles.blocks.size());
@@ -340,6 +343,37 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
     s.load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     s.retiled_on_gpu = tiles.d_image != nullptr;
     return HS_OK;
+}
+}  // namespace
+
+int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], const uint64_t n_packets[HS_NUM_CHANNELS],
+                   uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions, uint32_t num_col_partitions) {
+    if (!ctx || !channel || !n_packets) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+    return load_matrix_impl(ctx, channel, n_packets, nullptr, num_rows, num_cols, num_row_partitions, num_col_partitions);
+}
+
+int hs_load_matrix_csr(hs_context* ctx, uint32_t num_rows, uint32_t num_cols, const uint32_t* indptr, const uint32_t* indices, const float* values,
+                       uint32_t* padded_rows, uint32_t* padded_cols) {
+    if (!ctx || !indptr) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+    const Geometry& g = ctx->geom;
+    if (num_rows == 0 || num_cols == 0) return fail(ctx, HS_ERR_BAD_ARG, "empty matrix");
+    // util_round_csr_matrix_dim (sw/data_formatter.h:15-29): rows up to a multiple of P*C*F, columns to a multiple of 8
+    const uint64_t rows = (uint64_t(num_rows) + g.row_divisor - 1) / g.row_divisor * g.row_divisor;
+    const uint64_t cols = (uint64_t(num_cols) + hisparse::PACK_SIZE - 1) / hisparse::PACK_SIZE * hisparse::PACK_SIZE;
+    if (rows > 0xffffffffull || cols > 0xffffffffull) return fail(ctx, HS_ERR_BAD_ARG, "padded dimensions exceed 32 bits");
+    hisparse::dev::CsrView view;
+    view.num_rows = num_rows;
+    view.num_cols = num_cols;
+    view.indptr = indptr;
+    view.indices = indices;
+    view.values = values;
+    const int rc = load_matrix_impl(ctx, nullptr, nullptr, &view, uint32_t(rows), uint32_t(cols), uint32_t((rows + g.logical_ob - 1) / g.logical_ob),
+                                    uint32_t((cols + g.logical_vb - 1) / g.logical_vb));
+    if (rc == HS_OK) {
+        if (padded_rows) *padded_rows = uint32_t(rows);
+        if (padded_cols) *padded_cols = uint32_t(cols);
+    }
+    return rc;
 }
 
 int hs_debug_read_tiles(hs_context* ctx, void* image, uint64_t image_capacity, void* blocks, void* units) {

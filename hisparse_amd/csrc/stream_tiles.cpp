@@ -34,7 +34,7 @@ using namespace detail;
 bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
                         const Geometry& geom, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
                         uint32_t num_col_partitions, uint32_t max_workgroups, StreamTiles& out, std::string& error,
-                        void* gpu_stream, bool use_gpu, uint64_t image_slack) {
+                        void* gpu_stream, bool use_gpu, uint64_t image_slack, const CsrView* csr) {
     Layout L;
     L.g = &geom;
     L.num_rows = num_rows;
@@ -47,7 +47,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     const uint32_t F = L.F, CP = num_col_partitions, RP = num_row_partitions, S = L.subs_per_cp;
     const bool is_float = geom.impl != IMPL_FIXED;
     const uint64_t header_pkts = uint64_t(RP) * CP * (1 + F);
-    for (uint32_t c = 0; c < NUM_HBM_CHANNELS; ++c) {
+    if (csr && !use_gpu) { error = "the CSR source needs the GPU re-tile"; return false; }
+    for (uint32_t c = 0; !csr && c < NUM_HBM_CHANNELS; ++c) {
         if (!channel[c] && n_packets[c]) { error = "null channel buffer"; return false; }
         if (n_packets[c] < header_pkts) { error = "channel " + std::to_string(c) + " is shorter than its partition headers"; return false; }
     }
@@ -59,7 +60,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     std::vector<uint32_t> row_nnz(num_rows, 0);
     std::unique_ptr<GpuTiler> gpu;       // the per-non-zero passes on the device (gpu_tiles.h) instead of the host walks below
     if (use_gpu) {
-        gpu.reset(new GpuTiler(L, channel, n_packets, static_cast<hipStream_t>(gpu_stream)));
+        if (csr) gpu.reset(new GpuTiler(L, *csr, static_cast<hipStream_t>(gpu_stream)));
+        else gpu.reset(new GpuTiler(L, channel, n_packets, static_cast<hipStream_t>(gpu_stream)));
         if (!gpu->count_rows(row_nnz, out.nnz)) { error = gpu->error(); return false; }
     } else {
     std::vector<WalkResult> res0(size_t(RP) * NUM_HBM_CHANNELS);
@@ -95,8 +97,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner or bitmap"; return false; }
         }
         if (bitmap) {
-            gpu.reset();      // BITMAP images are small and built on the host
-            if (build_bitmap_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error)) return true;
+            if (!csr) gpu.reset();      // BITMAP images are small and built on the host (a CSR source has no host fallback: keep the tiler)
+            if (build_bitmap_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error, csr)) return true;
             if (error.rfind("bitmap:", 0) != 0) return false;     // a real decode error
             error.clear();                                       // not representable as a bitmap (duplicate entries): element streams
         }

@@ -202,15 +202,27 @@ struct StreamTiles {
     uint64_t elements = 0;               // element slots including bridges and chunk padding (DELTA head records not counted)
 };
 
+// hs_load_matrix_csr: the matrix BEFORE csr2cpsr -- CSRMatrix<float> arrays (sw/data_loader.h:19-31), dimensions not yet rounded up.
+// The builder pads like util_round_csr_matrix_dim (empty rows / counted columns) and converts the values like
+// csr_matrix_convert_from_float, so the image is byte for byte the one the CPSR path gives for the same matrix.
+struct CsrView {
+    uint32_t num_rows = 0, num_cols = 0;     // as loaded (<= the padded dimensions handed to build_stream_tiles)
+    const uint32_t* indptr = nullptr;        // num_rows + 1
+    const uint32_t* indices = nullptr;
+    const float* values = nullptr;
+};
+
 // Decode + validate + re-tile.  `max_workgroups` = workgroups the device keeps resident (one per CU).
 // Returns false and sets `error` when the buffers are not a valid CPSR image for the geometry.
 // `gpu_stream` != nullptr: the per-non-zero passes run on the device of the current HIP context (gpu_tiles.h), the image stays there
 // (out.d_image); formats it does not cover (BITMAP) and matrices with duplicate entries are built on the host as before.
 // image_slack: bytes the device allocation of the image must extend past its end (the kernels' clamped prefetches).
+// `csr` != nullptr: the source is a CSR matrix instead of the CPSR image (channel / n_packets are ignored; needs use_gpu -- BITMAP
+// images are still built by host threads, straight from the CSR rows).
 bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
                         const Geometry& geom, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
                         uint32_t num_col_partitions, uint32_t max_workgroups, StreamTiles& out, std::string& error,
-                        void* gpu_stream = nullptr, bool use_gpu = false, uint64_t image_slack = 0);
+                        void* gpu_stream = nullptr, bool use_gpu = false, uint64_t image_slack = 0, const CsrView* csr = nullptr);
 
 }  // namespace dev
 }  // namespace hisparse

@@ -17,7 +17,7 @@ _lib = None
 
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
-    "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
+    "hs_load_matrix_csr", "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
     "hs_bind_device_vector", "hs_bind_device_result", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
@@ -83,6 +83,7 @@ def lib():
         l.hs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.hs_debug_read_tiles.argtypes = [vp, vp, u64, vp, vp]
+        l.hs_load_matrix_csr.argtypes = [vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(u32)]
         l.hs_spmm.argtypes = [vp, vp, u32, u32, vp, u32]
         l.hs_spmm_device.argtypes = [vp, vp, u64, vp, u64, u32]
         l.hs_tiles_build.argtypes = [C.POINTER(vp), C.POINTER(u64), C.c_int, u32, u32, u32, u32, u32, u32, u32, C.POINTER(vp)]
@@ -120,6 +121,8 @@ class SpmvEngine:
         rc = lib().hs_create(C.byref(self._h), device_id, self.impl, ob_bank, vb_bank)
         if rc != 0:
             raise DeviceError(rc, lib().hs_last_error(None).decode())
+        default_vb, default_ob = host.default_banks(self.impl)
+        self.ob_bank, self.vb_bank = ob_bank or default_ob, vb_bank or default_vb
         self.num_rows = self.num_cols = 0
         self.row_parts = self.col_parts = 0
 
@@ -156,6 +159,22 @@ class SpmvEngine:
         del keep
         self.num_rows, self.num_cols = num_rows, num_cols
         self.row_parts, self.col_parts = num_row_partitions, num_col_partitions
+
+    def load_matrix_csr(self, csr):
+        """Straight from a host.CSRMatrix (or (num_rows, num_cols, indptr, indices, data) arrays) without csr2cpsr: the device pads,
+        converts and re-tiles (hs_load_matrix_csr).  Sets num_rows / num_cols to the padded dimensions x and y then have."""
+        if isinstance(csr, host.CSRMatrix):
+            rows, cols = csr.num_rows, csr.num_cols
+            indptr, indices, data = csr.arrays()
+        else:
+            rows, cols, indptr, indices, data = csr
+        indptr, indices = (np.ascontiguousarray(a, dtype=np.uint32) for a in (indptr, indices))
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        pr, pc = C.c_uint32(), C.c_uint32()
+        self._check(lib().hs_load_matrix_csr(self._h, rows, cols, indptr.ctypes.data, indices.ctypes.data if indices.size else None,
+                                             data.ctypes.data if data.size else None, C.byref(pr), C.byref(pc)))
+        self.num_rows, self.num_cols = pr.value, pc.value
+        self.row_parts, self.col_parts = -(-pr.value // (128 * self.ob_bank)), -(-pc.value // (8 * self.vb_bank))
 
     def load_vector(self, x_words):
         x_words = np.ascontiguousarray(x_words, dtype=np.uint32)

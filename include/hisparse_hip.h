@@ -149,6 +149,19 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* 
 int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count);
 int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows);
 
+/* ---- load straight from CSR (EXTENSION, SURVEY.md section 8(f)-1: the pre-processing on the GPU) ------------------------------------
+ * The reference's driver turns CSRMatrix<float> (sw/data_loader.h:19-31) into CPSR on the host (csr2cpsr + packet assembly,
+ * sw/data_formatter.h:468-544, sw/benchmark.cpp:105-195: 0.2 - 10.6 s single-threaded, paper Table 8) only for the device to decode it
+ * again.  hs_load_matrix_csr skips that round trip: the three CSR arrays are copied to the device, padded like
+ * util_round_csr_matrix_dim (rows to a multiple of 128 * interleave, columns to a multiple of 8), their values converted like
+ * csr_matrix_convert_from_float (sw/data_loader.h:76-84), and the device image is built by the same planner and kernels as in
+ * hs_load_matrix -- it is byte for byte the image hs_load_matrix builds from csr2cpsr's output of the same matrix
+ * (tests/test_gpu_retile.py), so every parity statement carries over.  Column indices inside a row may be in any order; a (row, column)
+ * that occurs twice is refused (HS_ERR_BAD_MATRIX: use the CPSR path).  padded_rows / padded_cols (may be NULL) receive the dimensions
+ * hs_load_vector / hs_read_result then expect. */
+int hs_load_matrix_csr(hs_context* ctx, uint32_t num_rows, uint32_t num_cols, const uint32_t* indptr, const uint32_t* indices, const float* values,
+                       uint32_t* padded_rows, uint32_t* padded_cols);
+
 /* ---- SpMM (EXTENSION; the reference has no SpMM) ----------------------------------------------------------
  * Y = A X for k dense vectors, column j of X / Y being a packed vector of num_cols / num_rows words (the layouts of hs_load_vector
  * and hs_read_result).  The k columns go through the SpMV kernels one after the other over the image hs_load_matrix left on the

@@ -120,3 +120,19 @@ def test_row_sharded_rccl_path_on_one_gpu(tmp_path):
     assert y.size == 20000 and np.array_equal(y, want[:20000])
     r = run("fixed", path, 4, 8, "--gpus", 64)
     assert r.returncode != 0 and "device(s) visible" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl_name,impl,v,o", [("fixed", 0, 4, 1), ("float_stall", 2, 4, 8)])
+def test_from_csr_gives_the_same_y(tmp_path, impl_name, impl, v, o):
+    """--from-csr (hs_load_matrix_csr: no csr2cpsr) against the default path, also through the literal per-partition loop."""
+    m, path = _matrix(tmp_path, impl, rows=300000, cols=512, density=0.002, seed=6)
+    xa, ya, xb, yb = (tmp_path / n for n in ("xa", "ya", "xb", "yb"))
+    ra = run(impl_name, path, v, o, "--values", "keep", "--dump-x", xa, "--dump-y", ya)
+    rb = run(impl_name, path, v, o, "--values", "keep", "--from-csr", "--partition-loop", "--dump-x", xb, "--dump-y", yb)
+    assert ra.returncode == 0 and rb.returncode == 0, ra.stdout + rb.stdout
+    assert RESULT_LINE.search(rb.stdout)
+    assert np.array_equal(np.fromfile(xa, dtype=np.uint32), np.fromfile(xb, dtype=np.uint32))
+    a, b = np.fromfile(ya, dtype=np.uint32), np.fromfile(yb, dtype=np.uint32)
+    assert a.size == b.size and a.any()
+    assert np.array_equal(a, b) if impl == 0 else np.allclose(a.view(np.float32), b.view(np.float32), rtol=1e-5, atol=1e-5)
