@@ -141,8 +141,11 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         const Shape whole[1] = {{max_block_rows(false), kMaxXBuffers}};                                       // 4095 rows, ring 4
         const double sub_tiles = double(CP) * S;
         double best = 1e30;
-        for (uint32_t cs = 1; cs <= kMaxColSlices; cs *= 2) {
-            if (force_slices && uint32_t(std::atoi(force_slices)) != cs) continue;
+        for (uint32_t cs = 1; cs <= kMaxColSlices; ++cs) {
+            // unforced: 1, 2, 4, 8 -- and everything in between for OWNER, where the x volume decides: ogbn-products runs 241 us in 5
+            // slices (102 ranges of 24 K rows, 2 blocks per workgroup) against 280 in 2 (127 ranges) and 275 in 4; ogbl-ppa gains
+            // 1 us of kernel in 5 and loses it in the combine pass, the R-MAT stand-in is 3 us slower
+            if (force_slices ? uint32_t(std::atoi(force_slices)) != cs : (!owner && (cs & (cs - 1)) != 0)) continue;
             if (cs > 1 && uint64_t(CP) * S < cs) continue;                                    // fewer sub-tiles than slices
             for (const Shape& shape : (cs > 1 || owner) ? std::vector<Shape>(sliced, sliced + 2) : std::vector<Shape>(whole, whole + 1)) {
                 uint32_t cap = shape.cap, ring = shape.ring;
@@ -156,7 +159,10 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 const double blocks_per_wg = ranges * cs / G;
                 const double units_per_wg = std::max(1.0, ranges * sub_tiles / G);
                 const double unit_stream_us = double(out.nnz) * 8.0 / (units_per_wg * G) / 25e3;
-                const double volume_us = ranges * double(num_cols) * 4.0 / G / 120e3;
+                // x pulled through a CU: 120 GB/s next to a DELTA / PAIRS stream (ogbl-ppa: 0.1 us per row range); OWNER's units are
+                // short and every one ends in a flush and a barrier, which also scale with the ranges: 1.34 us per range on
+                // ogbn-products = 29 GB/s (tools/slices_probe.sh)
+                const double volume_us = ranges * double(num_cols) * 4.0 / G / (owner ? 29e3 : 120e3);
                 const double latency_us = units_per_wg * std::max(0.0, 0.8 / (ring - 1) - unit_stream_us);
                 const double combine_us = cs > 1 ? 3.5 + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
                 const double cost = volume_us + latency_us + 8.0 * blocks_per_wg + combine_us;

@@ -30,7 +30,7 @@ for case in range(n_cases):
     fmt = str(rng.choice(["pairs", "delta", "bitmap", "owner"]))
     if fmt == "owner" and density > 0.003:
         fmt = "pairs"      # OWNER sums in fp32 like csim; forced onto long rows its rounding (not a defect) would trip the float64 re-check
-    runs = str(rng.choice(["", "0", "1"])); slices = str(rng.choice(["", "", "2", "4"]))
+    runs = str(rng.choice(["", "0", "1"])); slices = str(rng.choice(["", "", "2", "3", "4", "5"]))
     os.environ["HISPARSE_STREAM_FORMAT"] = fmt
     for k, v in (("HISPARSE_ROW_RUNS", runs), ("HISPARSE_COL_SLICES", slices)):
         if v: os.environ[k] = v

@@ -99,7 +99,7 @@ def sweep(name, measure_points=True, out=sys.stdout):
     grid = {}
     saved = {k: os.environ.get(k) for k in ("HISPARSE_COL_SLICES", "HISPARSE_MAX_ROWS")}
     try:
-        for cs in (1, 2, 4, 8):
+        for cs in (1, 2, 3, 4, 5, 6, 8):
             for rows in (128, 512, 2047, 4095, 8191, 12287, 16369, 24561):
                 os.environ["HISPARSE_COL_SLICES"], os.environ["HISPARSE_MAX_ROWS"] = str(cs), str(rows)
                 try:
