@@ -226,27 +226,44 @@ void util_convert_csr_to_dds(uint32_t num_rows, uint32_t num_cols, const DataT* 
                              std::vector<DataT> partitioned_adj_data[], std::vector<uint32_t> partitioned_adj_indices[],
                              std::vector<uint32_t> partitioned_adj_indptr[]) {
     const uint32_t parts = (num_cols + num_cols_per_partition - 1) / num_cols_per_partition;
-    for (uint32_t p = 0; p < parts; ++p) partitioned_adj_indptr[p].assign(size_t(num_rows) + 1, 0);
-    // per-row population of every partition, then an in-place prefix sum down the rows
-    for (uint32_t r = 0; r < num_rows; ++r)
-        for (uint32_t e = adj_indptr[r]; e < adj_indptr[r + 1]; ++e)
-            partitioned_adj_indptr[adj_indices[e] / num_cols_per_partition][r + 1]++;
-    for (uint32_t p = 0; p < parts; ++p) {
+    const unsigned threads = detail::format_threads();
+    detail::parallel_for(parts, threads, [&](size_t p) { partitioned_adj_indptr[p].assign(size_t(num_rows) + 1, 0); });
+    // rows in chunks of about equal non-zero count, one task each (the rows of different chunks are disjoint, so are their
+    // stretches of every partition's arrays): per-row population of every partition, a prefix sum down the rows of every
+    // partition, then the scatter with every chunk starting at its first row's offsets
+    const uint32_t nnz = adj_indptr[num_rows] - adj_indptr[0];
+    const uint32_t chunks = std::max<uint32_t>(1, std::min<uint32_t>(threads * 4, num_rows / 256 + 1));
+    std::vector<uint32_t> first(chunks + 1, num_rows);
+    first[0] = 0;
+    for (uint32_t c = 1, r = 0; c < chunks; ++c) {
+        const uint64_t target = uint64_t(nnz) * c / chunks + adj_indptr[0];
+        while (r < num_rows && adj_indptr[r] < target) ++r;
+        first[c] = r;
+    }
+    detail::parallel_for(chunks, threads, [&](size_t c) {
+        for (uint32_t r = first[c]; r < first[c + 1]; ++r)
+            for (uint32_t e = adj_indptr[r]; e < adj_indptr[r + 1]; ++e)
+                partitioned_adj_indptr[adj_indices[e] / num_cols_per_partition][r + 1]++;
+    });
+    detail::parallel_for(parts, threads, [&](size_t p) {
         auto& ptr = partitioned_adj_indptr[p];
         for (uint32_t r = 0; r < num_rows; ++r) ptr[r + 1] += ptr[r];
         partitioned_adj_data[p].resize(ptr[num_rows]);
         partitioned_adj_indices[p].resize(ptr[num_rows]);
-    }
-    std::vector<uint32_t> cursor(parts, 0);
-    for (uint32_t r = 0; r < num_rows; ++r) {
-        for (uint32_t e = adj_indptr[r]; e < adj_indptr[r + 1]; ++e) {
-            const uint32_t col = adj_indices[e];
-            const uint32_t p = col / num_cols_per_partition;
-            const uint32_t at = cursor[p]++;
-            partitioned_adj_data[p][at] = adj_data[e];
-            partitioned_adj_indices[p][at] = col - p * num_cols_per_partition;
+    });
+    detail::parallel_for(chunks, threads, [&](size_t c) {
+        std::vector<uint32_t> cursor(parts);
+        for (uint32_t p = 0; p < parts; ++p) cursor[p] = partitioned_adj_indptr[p][first[c]];
+        for (uint32_t r = first[c]; r < first[c + 1]; ++r) {
+            for (uint32_t e = adj_indptr[r]; e < adj_indptr[r + 1]; ++e) {
+                const uint32_t col = adj_indices[e];
+                const uint32_t p = col / num_cols_per_partition;
+                const uint32_t at = cursor[p]++;
+                partitioned_adj_data[p][at] = adj_data[e];
+                partitioned_adj_indices[p][at] = col - p * num_cols_per_partition;
+            }
         }
-    }
+    });
 }
 
 // Stable sort of the rows by non-zero count (unused by the SpMV path; kept for surface parity).
@@ -271,40 +288,50 @@ void util_reorder_rows_ascending_nnz(std::vector<DataT> const& adj_data, std::ve
 // Deal rows to streams: row i*(channels*pack) + c*pack + j belongs to channel c, lane j, round i.
 // Lane streams are the concatenation of their rows; arrays are sized to the longest lane of the
 // channel and zero filled.  packed_adj_indptr[c][i] = per-lane element count before round i.
+namespace detail {
+// one channel of util_pack_rows (the channels only read the shared CSR arrays: csr2cpsr runs them as separate tasks)
+template <typename DataT, typename packed_val_t, typename packed_idx_t>
+void pack_rows_of_channel(std::vector<DataT> const& adj_data, std::vector<uint32_t> const& adj_indices, std::vector<uint32_t> const& adj_indptr,
+                          uint32_t num_hbm_channels, uint32_t pack_size, uint32_t c, std::vector<packed_val_t>& packed_adj_data,
+                          std::vector<packed_idx_t>& packed_adj_indices, std::vector<packed_idx_t>& packed_adj_indptr) {
+    const size_t rows = adj_indptr.size() - 1;
+    const size_t rows_per_round = size_t(num_hbm_channels) * pack_size;
+    const size_t rounds = (rows + rows_per_round - 1) / rows_per_round;
+    packed_idx_t running;
+    for (uint32_t j = 0; j < pack_size; ++j) running.data[j] = 0;
+    auto& ptr = packed_adj_indptr;
+    ptr.reserve(ptr.size() + rounds + 1);
+    ptr.push_back(running);
+    for (size_t i = 0; i < rounds; ++i) {
+        for (uint32_t j = 0; j < pack_size; ++j) {
+            const size_t r = i * rows_per_round + size_t(c) * pack_size + j;
+            if (r < rows) running.data[j] += adj_indptr[r + 1] - adj_indptr[r];
+        }
+        ptr.push_back(running);
+    }
+    uint32_t longest = 0;
+    for (uint32_t j = 0; j < pack_size; ++j) longest = std::max(longest, running.data[j]);
+    packed_adj_data.resize(longest);
+    packed_adj_indices.resize(longest);
+    for (uint32_t j = 0; j < pack_size; ++j) {
+        uint32_t at = 0;
+        for (size_t r = size_t(c) * pack_size + j; r < rows; r += rows_per_round)
+            for (uint32_t e = adj_indptr[r]; e < adj_indptr[r + 1]; ++e, ++at) {
+                packed_adj_data[at].data[j] = adj_data[e];
+                packed_adj_indices[at].data[j] = adj_indices[e];
+            }
+    }
+}
+}  // namespace detail
+
 template <typename DataT, typename packed_val_t, typename packed_idx_t>
 void util_pack_rows(std::vector<DataT> const& adj_data, std::vector<uint32_t> const& adj_indices,
                     std::vector<uint32_t> const& adj_indptr, uint32_t num_hbm_channels, uint32_t pack_size,
                     std::vector<packed_val_t> packed_adj_data[], std::vector<packed_idx_t> packed_adj_indices[],
                     std::vector<packed_idx_t> packed_adj_indptr[]) {
-    const size_t rows = adj_indptr.size() - 1;
-    const size_t rows_per_round = size_t(num_hbm_channels) * pack_size;
-    const size_t rounds = (rows + rows_per_round - 1) / rows_per_round;
-    for (uint32_t c = 0; c < num_hbm_channels; ++c) {
-        packed_idx_t running;
-        for (uint32_t j = 0; j < pack_size; ++j) running.data[j] = 0;
-        auto& ptr = packed_adj_indptr[c];
-        ptr.reserve(ptr.size() + rounds + 1);
-        ptr.push_back(running);
-        for (size_t i = 0; i < rounds; ++i) {
-            for (uint32_t j = 0; j < pack_size; ++j) {
-                const size_t r = i * rows_per_round + size_t(c) * pack_size + j;
-                if (r < rows) running.data[j] += adj_indptr[r + 1] - adj_indptr[r];
-            }
-            ptr.push_back(running);
-        }
-        uint32_t longest = 0;
-        for (uint32_t j = 0; j < pack_size; ++j) longest = std::max(longest, running.data[j]);
-        packed_adj_data[c].resize(longest);
-        packed_adj_indices[c].resize(longest);
-        for (uint32_t j = 0; j < pack_size; ++j) {
-            uint32_t at = 0;
-            for (size_t r = size_t(c) * pack_size + j; r < rows; r += rows_per_round)
-                for (uint32_t e = adj_indptr[r]; e < adj_indptr[r + 1]; ++e, ++at) {
-                    packed_adj_data[c][at].data[j] = adj_data[e];
-                    packed_adj_indices[c][at].data[j] = adj_indices[e];
-                }
-        }
-    }
+    for (uint32_t c = 0; c < num_hbm_channels; ++c)
+        detail::pack_rows_of_channel<DataT, packed_val_t, packed_idx_t>(adj_data, adj_indices, adj_indptr, num_hbm_channels, pack_size, c,
+                                                                       packed_adj_data[c], packed_adj_indices[c], packed_adj_indptr[c]);
 }
 
 // CSR -> CPSR.  out_buf_len rows per row partition, vec_buf_len columns per column partition,
@@ -349,13 +376,15 @@ CPSRMatrix<packed_val_t, packed_idx_t, pack_size> csr2cpsr(CSRMatrix<DataT> cons
                                        part_data.data(), part_indices.data(), part_indptr.data());
         detail::parallel_for(out.num_col_partitions, threads, [&](size_t cp) {
             util_pad_marker_end_of_row<DataT>(part_data[cp], part_indices[cp], part_indptr[cp], idx_marker, stride, skip_empty_rows);
-            const size_t s0 = out.slot(rp, uint32_t(cp), 0);
-            util_pack_rows<DataT, packed_val_t, packed_idx_t>(part_data[cp], part_indices[cp], part_indptr[cp], num_hbm_channels,
-                                                              pack_size, &out.formatted_adj_data[s0], &out.formatted_adj_indices[s0],
-                                                              &out.formatted_adj_indptr[s0]);
-            std::vector<DataT>().swap(part_data[cp]);
-            std::vector<IndexT>().swap(part_indices[cp]);
-            std::vector<IndexT>().swap(part_indptr[cp]);
+        });
+        // util_pack_rows, one task per (column partition, channel): a matrix with two column partitions (mouse_gene) still
+        // keeps 32 workers busy
+        detail::parallel_for(size_t(out.num_col_partitions) * num_hbm_channels, threads, [&](size_t task) {
+            const uint32_t cp = uint32_t(task / num_hbm_channels), c = uint32_t(task % num_hbm_channels);
+            const size_t s = out.slot(rp, cp, c);
+            detail::pack_rows_of_channel<DataT, packed_val_t, packed_idx_t>(part_data[cp], part_indices[cp], part_indptr[cp], num_hbm_channels, pack_size, c,
+                                                                           out.formatted_adj_data[s], out.formatted_adj_indices[s],
+                                                                           out.formatted_adj_indptr[s]);
         });
     }
     return out;

@@ -13,8 +13,11 @@
 #ifndef HISPARSE_DATA_LOADER_H_
 #define HISPARSE_DATA_LOADER_H_
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -95,8 +98,20 @@ CSRMatrix<data_type> csr_matrix_convert_from_float(CSRMatrix<float> const& in) {
     CSRMatrix<data_type> out;
     out.num_rows = in.num_rows;
     out.num_cols = in.num_cols;
-    out.adj_data.reserve(in.adj_data.size());
-    for (float v : in.adj_data) out.adj_data.push_back(data_type(v));
+    // (in parallel: 42 M conversions are 0.3 s of one core; HISPARSE_FORMAT_THREADS caps the workers like in csr2cpsr)
+    const size_t n = in.adj_data.size();
+    out.adj_data.resize(n);
+    unsigned workers = std::thread::hardware_concurrency();
+    if (const char* env = std::getenv("HISPARSE_FORMAT_THREADS")) workers = unsigned(std::max(1, std::atoi(env)));
+    workers = unsigned(std::min<size_t>(std::max(1u, workers), n / 65536 + 1));
+    auto convert = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) out.adj_data[i] = data_type(in.adj_data[i]); };
+    if (workers <= 1) {
+        convert(0, n);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < workers; ++t) pool.emplace_back(convert, n * t / workers, n * (t + 1) / workers);
+        for (auto& th : pool) th.join();
+    }
     out.adj_indices = in.adj_indices;
     out.adj_indptr = in.adj_indptr;
     return out;
@@ -139,8 +154,20 @@ CSCMatrix<data_type> csc_matrix_convert_from_float(CSCMatrix<float> const& in) {
     CSCMatrix<data_type> out;
     out.num_rows = in.num_rows;
     out.num_cols = in.num_cols;
-    out.adj_data.reserve(in.adj_data.size());
-    for (float v : in.adj_data) out.adj_data.push_back(data_type(v));
+    // (in parallel: 42 M conversions are 0.3 s of one core; HISPARSE_FORMAT_THREADS caps the workers like in csr2cpsr)
+    const size_t n = in.adj_data.size();
+    out.adj_data.resize(n);
+    unsigned workers = std::thread::hardware_concurrency();
+    if (const char* env = std::getenv("HISPARSE_FORMAT_THREADS")) workers = unsigned(std::max(1, std::atoi(env)));
+    workers = unsigned(std::min<size_t>(std::max(1u, workers), n / 65536 + 1));
+    auto convert = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) out.adj_data[i] = data_type(in.adj_data[i]); };
+    if (workers <= 1) {
+        convert(0, n);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < workers; ++t) pool.emplace_back(convert, n * t / workers, n * (t + 1) / workers);
+        for (auto& th : pool) th.join();
+    }
     out.adj_indices = in.adj_indices;
     out.adj_indptr = in.adj_indptr;
     return out;
