@@ -20,6 +20,8 @@
 #define HISPARSE_DATA_FORMATTER_H_
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
@@ -360,6 +362,14 @@ CPSRMatrix<packed_val_t, packed_idx_t, pack_size> csr2cpsr(CSRMatrix<DataT> cons
     out.formatted_adj_indices.resize(slots);
     out.formatted_adj_indptr.resize(slots);
     const unsigned threads = detail::format_threads();
+    const bool debug = std::getenv("HISPARSE_FORMAT_DEBUG") != nullptr;
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (debug) std::fprintf(stderr, "  csr2cpsr %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+        t_lap = now;
+    };
+    lap("slot vectors");
 
     for (uint32_t rp = 0; rp < out.num_row_partitions; ++rp) {
         const uint32_t first_row = rp * out_buf_len;
@@ -371,12 +381,15 @@ CPSRMatrix<packed_val_t, packed_idx_t, pack_size> csr2cpsr(CSRMatrix<DataT> cons
         std::vector<std::vector<DataT> > part_data(out.num_col_partitions);
         std::vector<std::vector<IndexT> > part_indices(out.num_col_partitions);
         std::vector<std::vector<IndexT> > part_indptr(out.num_col_partitions);
+        lap("local indptr");
         util_convert_csr_to_dds<DataT>(rows_here, csr_matrix.num_cols, csr_matrix.adj_data.data() + base,
                                        csr_matrix.adj_indices.data() + base, local_indptr.data(), vec_buf_len,
                                        part_data.data(), part_indices.data(), part_indptr.data());
+        lap("dds split");
         detail::parallel_for(out.num_col_partitions, threads, [&](size_t cp) {
             util_pad_marker_end_of_row<DataT>(part_data[cp], part_indices[cp], part_indptr[cp], idx_marker, stride, skip_empty_rows);
         });
+        lap("markers");
         // util_pack_rows, one task per (column partition, channel): a matrix with two column partitions (mouse_gene) still
         // keeps 32 workers busy
         detail::parallel_for(size_t(out.num_col_partitions) * num_hbm_channels, threads, [&](size_t task) {
@@ -386,6 +399,7 @@ CPSRMatrix<packed_val_t, packed_idx_t, pack_size> csr2cpsr(CSRMatrix<DataT> cons
                                                                            out.formatted_adj_data[s], out.formatted_adj_indices[s],
                                                                            out.formatted_adj_indptr[s]);
         });
+        lap("pack rows");
     }
     return out;
 }
