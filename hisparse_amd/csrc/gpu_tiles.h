@@ -50,7 +50,8 @@ class GpuTiler {
     // DELTA: slots (elements + bridges) of every unit
     bool delta_slots(std::vector<detail::UnitPlan>& plans);
     // OWNER: plans[u].own_begin from the wavefront row boundaries of the unit's range
-    bool owner_shares(std::vector<detail::UnitPlan>& plans, const std::vector<uint32_t>& wave_row, const std::vector<uint32_t>& range_of_unit);
+    // (balanced: per unit, detail::balanced_owner_shares; otherwise the fixed row ownership of the 24-bit form)
+    bool owner_shares(std::vector<detail::UnitPlan>& plans, const std::vector<uint32_t>& wave_row, const std::vector<uint32_t>& range_of_unit, bool balanced);
     // The image (image_bytes + slack, zero-filled first).  format: the final StreamFormat; block_of_unit / blocks: pre-reorder indices.
     bool emit(StreamFormat format, uint64_t image_bytes, uint64_t slack_bytes, const std::vector<detail::UnitPlan>& plans,
               const std::vector<uint32_t>& block_of_unit, const std::vector<Block>& blocks, bool is_float);

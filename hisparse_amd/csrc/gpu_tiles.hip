@@ -309,6 +309,16 @@ __global__ __launch_bounds__(256) void owner_shares_kernel(const uint64_t* __res
     own_begin[t] = lo;
 }
 
+__global__ __launch_bounds__(256) void owner_balanced_shares_kernel(const uint64_t* __restrict__ plan_start, const uint32_t* __restrict__ plan_n, uint32_t nu,
+                                                                   const uint64_t* __restrict__ keys, uint32_t* __restrict__ own_begin) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nu) return;
+    const uint64_t* e = keys + plan_start[u];
+    uint32_t shares[kConsumerWaves + 1];
+    detail::balanced_owner_shares(plan_n[u], [&](uint32_t i) { return uint32_t((e[i] & kPosMask) >> kOwnerColBits); }, shares);
+    for (uint32_t w = 0; w <= kConsumerWaves; ++w) own_begin[size_t(u) * (kConsumerWaves + 1) + w] = shares[w];
+}
+
 template <bool k24>
 __device__ __forceinline__ void put(uint8_t* chunk, uint32_t lane, uint32_t value, uint32_t where) {
     if (k24) {
@@ -753,7 +763,7 @@ bool GpuTiler::delta_slots(std::vector<UnitPlan>& plans) {
     return ok;
 }
 
-bool GpuTiler::owner_shares(std::vector<UnitPlan>& plans, const std::vector<uint32_t>& wave_row, const std::vector<uint32_t>& range_of_unit) {
+bool GpuTiler::owner_shares(std::vector<UnitPlan>& plans, const std::vector<uint32_t>& wave_row, const std::vector<uint32_t>& range_of_unit, bool balanced) {
     const uint32_t nu = uint32_t(plans.size());
     if (!nu) return true;
     std::vector<uint64_t> start(nu);
@@ -765,7 +775,8 @@ bool GpuTiler::owner_shares(std::vector<UnitPlan>& plans, const std::vector<uint
     bool ok = check(upload(&d_start, start, stream_), "upload") && check(upload(&d_n, count, stream_), "upload") && check(upload(&d_range, range_of_unit, stream_), "upload") &&
               check(upload(&d_wave_row, wave_row, stream_), "upload") && check(hipMalloc(reinterpret_cast<void**>(&d_own), own.size() * 4), "hipMalloc");
     if (ok) {
-        hipLaunchKernelGGL(owner_shares_kernel, dim3(uint32_t((own.size() + 255) / 256)), dim3(256), 0, stream_, d_start, d_n, d_range, d_wave_row, nu, d_keys_, d_own);
+        if (balanced) hipLaunchKernelGGL(owner_balanced_shares_kernel, dim3((nu + 255) / 256), dim3(256), 0, stream_, d_start, d_n, nu, d_keys_, d_own);
+        else hipLaunchKernelGGL(owner_shares_kernel, dim3(uint32_t((own.size() + 255) / 256)), dim3(256), 0, stream_, d_start, d_n, d_range, d_wave_row, nu, d_keys_, d_own);
         ok = check(hipGetLastError(), "owner_shares_kernel") && check(hipMemcpyAsync(own.data(), d_own, own.size() * 4, hipMemcpyDeviceToHost, stream_), "read shares") &&
              check(hipStreamSynchronize(stream_), "owner shares");
     }

@@ -596,11 +596,13 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 };
                 uint32_t issued = 1;                                   // sub-tile 0 was copied synchronously above
                 while (issued < U && issued < ring - 1) refill(issued++);
-                uint64_t t_wait = 0, t_bar = 0;
+                uint64_t t_wait = 0, t_bar = 0, t_issue = 0;
                 const uint64_t t_begin = (kOwner && (kAblate & 256)) ? __builtin_readcyclecounter() : 0;
                 for (uint32_t u = 0; u < U; ++u) {
                     // slot (u + ring - 1) % ring last held sub-tile u-1, which every consumer left at the previous barrier
+                    const uint64_t ti = (kOwner && (kAblate & 256)) ? __builtin_readcyclecounter() : 0;
                     if (issued < U) refill(issued++);
+                    if (kOwner && (kAblate & 256)) t_issue += __builtin_readcyclecounter() - ti;
                     // sub-tile u+1 must be resident before the consumers enter it (they do so after this barrier)
                     const uint32_t younger = issued - min(issued, u + 2);   // refills issued after the one for u+1: 0..ring-2
                     const uint64_t t0 = (kOwner && (kAblate & 256)) ? __builtin_readcyclecounter() : 0;
@@ -615,6 +617,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                     p[1] += t_wait;                                    // waiting for a refill to land
                     p[2] += t_bar;                                     // waiting for the consumers at the unit barrier
                     p[3] += U;
+                    p[4] += t_issue;                                   // descriptor of the refill after next + issuing this one
                 }
             } else {
                 // ---- consumer wavefronts: stream elements, gather x, accumulate rows -----------------------------

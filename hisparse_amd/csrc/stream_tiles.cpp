@@ -198,9 +198,12 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     const uint32_t ring_fit = (kMaxLdsBytes - (((out.max_block_rows + spare_rows) * acc_bytes + 15u) & ~15u)) / (kSubTileCols * 4u);
     out.ring_buffers = std::max(kMinXBuffers, std::min(kMaxXBuffers, ring_fit));
 
-    // OWNER: every consumer wavefront owns a contiguous share of a range's rows, cut at equal non-zero count
+    // OWNER: shares are cut per unit (tiles_common.h: balanced_owner_shares).  The 24-bit form (opt-in) addresses rows relative to a
+    // wavefront's share of the whole block in 11 bits, so it keeps the fixed ownership: every consumer wavefront owns a contiguous
+    // share of a range's rows, cut at equal non-zero count
+    const bool fixed_shares = owner && [] { const char* bits = std::getenv("HISPARSE_AUX_BITS"); return bits && std::atoi(bits) == 24; }();
     std::vector<uint32_t> wave_row;      // [range][kConsumerWaves + 1] local row boundaries
-    if (owner) {
+    if (fixed_shares) {
         wave_row.assign(size_t(NR) * (kConsumerWaves + 1), 0);
         parallel_for(NR, [&](size_t b) {
             uint32_t* wr = wave_row.data() + b * (kConsumerWaves + 1);
@@ -343,7 +346,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         if (owner) {
             std::vector<uint32_t> range_of_unit(NU);
             for (uint32_t u = 0; u < NU; ++u) range_of_unit[u] = range_of_block[block_of_unit[u]];
-            if (!gpu->owner_shares(plans, wave_row, range_of_unit)) { error = gpu->error(); return false; }
+            if (!gpu->owner_shares(plans, wave_row, range_of_unit, !fixed_shares)) { error = gpu->error(); return false; }
         }
     } else {
     scratch.resize(scratch_elems);
@@ -411,7 +414,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         const char* bits = std::getenv("HISPARSE_AUX_BITS");
         const bool allowed = bits && std::atoi(bits) == 24;
         if (owner) {
-            aux24 = allowed;
+            aux24 = allowed && fixed_shares;
             for (uint32_t b = 0; b < NR && aux24; ++b)
                 for (uint32_t w = 0; w < kConsumerWaves; ++w)
                     if (wave_row[size_t(b) * (kConsumerWaves + 1) + w + 1] - wave_row[size_t(b) * (kConsumerWaves + 1) + w] > kAux24MaxRows) aux24 = false;
@@ -447,10 +450,14 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 // the unit's elements are sorted by (row, column): wavefront w's share is the contiguous stretch of its rows;
                 // steps = its 64-slot chunks; lane l takes elements [l * steps, (l + 1) * steps) of the share
                 if (!gpu) {      // (the device computed the shares already)
-                    const uint32_t* wr = wave_row.data() + size_t(range_of_block[bi]) * (kConsumerWaves + 1);
                     const uint64_t* e = scratch.data() + up.scratch;
-                    for (uint32_t w = 0; w <= kConsumerWaves; ++w)
-                        up.own_begin[w] = uint32_t(std::lower_bound(e, e + up.n, uint64_t(wr[w]) << (32 + kOwnerColBits)) - e);
+                    if (fixed_shares) {
+                        const uint32_t* wr = wave_row.data() + size_t(range_of_block[bi]) * (kConsumerWaves + 1);
+                        for (uint32_t w = 0; w <= kConsumerWaves; ++w)
+                            up.own_begin[w] = uint32_t(std::lower_bound(e, e + up.n, uint64_t(wr[w]) << (32 + kOwnerColBits)) - e);
+                    } else {
+                        balanced_owner_shares(up.n, [&](uint32_t i) { return uint32_t(e[i] >> (32 + kOwnerColBits)); }, up.own_begin);
+                    }
                 }
                 for (uint32_t w = 0; w < kConsumerWaves; ++w) {
                     const uint32_t steps = (up.own_begin[w + 1] - up.own_begin[w] + kWaveLanes - 1) / kWaveLanes;

@@ -96,8 +96,9 @@ def _block_delta(image, blk, units, x_words, ys, is_float):
 
 def _block_owner(image, blk, units, x_words, ys, is_float, aux24=False):
     """OWNER (float only): per-wavefront contiguous 512-byte chunks of {value, row << 13 | col}; lane l holds a consecutive run of
-    the wavefront's share, rows never decrease from lane to lane and step to step, no row is shared between wavefronts, padding
-    aims a zero at the wavefront's own spare accumulator nrows + w."""
+    the wavefront's share, rows never decrease from lane to lane and step to step, no row is shared between wavefronts WITHIN A UNIT
+    (the unit barrier orders the accumulator writes, so the shares are cut per unit -- aux24: per block), padding aims a zero at the
+    wavefront's own spare accumulator nrows + w; the shares of a unit differ by at most one step unless a row is longer than a share."""
     assert is_float
     nrows = int(blk["nrows"])
     step = [0] * CONSUMERS
@@ -106,6 +107,8 @@ def _block_owner(image, blk, units, x_words, ys, is_float, aux24=False):
         unit = units[u]
         col0, ncols = int(unit["col0"]), int(unit["ncols"])
         xt = x_words[col0: col0 + ncols]
+        if not aux24:
+            owner_of = {}
         for w in range(CONSUMERS):
             end = int(unit["end_step"][w])
             base = int(blk["wave_offset"][w])

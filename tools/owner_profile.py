@@ -27,6 +27,6 @@ print(f"{name}: {t.shape[0]} workgroups, {st['num_units']} units, ring {st['ring
 cons, load = t[:, :14, :], t[:, 14:, :]
 print(f"  consumers: phase {np.median(cons[:, :, 0]):.0f} (max {cons[:, :, 0].max():.0f})  flush {np.median(cons[:, :, 1]):.0f}  barrier wait {np.median(cons[:, :, 2]):.0f}"
       f"  units {np.median(cons[:, :, 3]):.0f}  steps {np.median(cons[:, :, 4]):.0f} (min {cons[:, :, 4].min():.0f} max {cons[:, :, 4].max():.0f})")
-print(f"  loaders:   phase {np.median(load[:, :, 0]):.0f}  waiting for refills {np.median(load[:, :, 1]):.0f}  barrier wait {np.median(load[:, :, 2]):.0f}")
+print(f"  loaders:   phase {np.median(load[:, :, 0]):.0f}  waiting for refills {np.median(load[:, :, 1]):.0f}  barrier wait {np.median(load[:, :, 2]):.0f}  issuing refills (+ descriptor waits) {np.median(load[:, :, 4]):.0f}")
 print(f"  consumer shares: flush {np.median(cons[:, :, 1] / cons[:, :, 0]) * 100:.1f} %  barrier {np.median(cons[:, :, 2] / cons[:, :, 0]) * 100:.1f} %;"
       f"  loader: refill wait {np.median(load[:, :, 1] / load[:, :, 0]) * 100:.1f} %  barrier {np.median(load[:, :, 2] / load[:, :, 0]) * 100:.1f} %")
