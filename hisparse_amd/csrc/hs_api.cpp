@@ -47,6 +47,8 @@ struct hs_context {
     uint32_t ring_buffers = 4;
     uint32_t format = 0;           // StreamFormat of d_image
     uint32_t* d_partial = nullptr;  // col_slices > 1: per-slice partial results, col_slices x num_rows words
+    uint32_t max_block_rows = 0;
+    uint32_t* d_x_interleaved = nullptr;   // fused SpMM over a BITMAP image: 4 columns of X as [column][vector] words (allocated on first use)
 
     // SpMSpV extension: the matrix once more, in CSC form (hs_load_matrix_csc), + scratch
     uint32_t* d_csc_indptr = nullptr;
@@ -98,6 +100,8 @@ void free_matrix(hs_context* c) {
     if (c->d_y) (void)hipFree(c->d_y);
     if (c->d_partial) (void)hipFree(c->d_partial);
     c->d_partial = nullptr;
+    if (c->d_x_interleaved) (void)hipFree(c->d_x_interleaved);
+    c->d_x_interleaved = nullptr;
     c->d_image = nullptr;
     c->d_blocks = nullptr;
     c->d_units = nullptr;
@@ -322,6 +326,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     ctx->num_workgroups = tiles.num_workgroups;
     ctx->lds_bytes = lds_bytes;
     ctx->col_slices = tiles.col_slices;
+    ctx->max_block_rows = tiles.max_block_rows;
     ctx->ring_buffers = tiles.ring_buffers;
     ctx->format = tiles.format;
     ctx->matrix_loaded = true;
@@ -622,7 +627,36 @@ int hs_spmm_device(hs_context* ctx, const void* x_dev, uint64_t ldx, void* y_dev
     const uint32_t* x_saved = ctx->x_bound;
     uint32_t* y_saved = ctx->y_bound;
     int rc = HS_OK;
-    for (uint32_t j = 0; j < k && rc == HS_OK; ++j) {
+    const bool is_float = ctx->impl != HS_IMPL_FIXED;
+    uint32_t j = 0;
+    // BITMAP images (dense rows: pruned-NN layers, which are multiplied with batches in practice): 4, then 2 columns at a time through
+    // the fused kernel of spmm_bitmap.hip -- masks and values are streamed once for them.  Everything else, and a last odd column:
+    // one SpMV per column.
+    static const bool fused_enabled = [] { const char* e = std::getenv("HISPARSE_SPMM_FUSED"); return !(e && std::string(e) == "0"); }();
+    if (fused_enabled && ctx->format == hisparse::dev::kFormatBitmap && ctx->col_slices == 1) {
+        for (uint32_t group : {4u, 2u}) {
+            if (ctx->max_block_rows > hisparse::dev::spmm_bitmap_max_block_rows(is_float, group)) continue;
+            while (k - j >= group) {
+                if (!ctx->d_x_interleaved) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_x_interleaved), size_t(ctx->num_cols) * 4 * 4 + 64));
+                hisparse::dev::SpmmLaunch a;
+                a.image = ctx->d_image;
+                a.blocks = ctx->d_blocks;
+                a.units = ctx->d_units;
+                a.x = static_cast<const uint32_t*>(x_dev) + size_t(j) * ldx;
+                a.ldx = ldx;
+                a.x_interleaved = ctx->d_x_interleaved;
+                a.y = static_cast<uint32_t*>(y_dev) + size_t(j) * ldy;
+                a.ldy = ldy;
+                a.vectors = group;
+                a.num_cols = ctx->num_cols;
+                a.num_workgroups = ctx->num_workgroups;
+                a.max_block_rows = ctx->max_block_rows;
+                HS_HIP(ctx, hisparse::dev::launch_spmm_bitmap(is_float, a, ctx->stream));
+                j += group;
+            }
+        }
+    }
+    for (; j < k && rc == HS_OK; ++j) {
         ctx->x_bound = static_cast<const uint32_t*>(x_dev) + size_t(j) * ldx;
         ctx->y_bound = static_cast<uint32_t*>(y_dev) + size_t(j) * ldy;
         rc = enqueue(ctx, -1, nullptr, nullptr);

@@ -32,6 +32,23 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t
 hipError_t configure_spmv_kernels(uint32_t lds_bytes);
 // The SpMV kernel: row-owner workgroups, x sub-tiles double-buffered in LDS, no global atomics.
 hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream);
+// Fused SpMM over a BITMAP image (spmm_bitmap.hip): `vectors` (2 or 4) columns of X at once, one column slice only.
+struct SpmmLaunch {
+    const uint8_t* image;
+    const Block* blocks;
+    const Unit* units;
+    const uint32_t* x;            // column j of X at x + j * ldx words
+    uint64_t ldx;
+    uint32_t* x_interleaved;      // scratch, num_cols * vectors words
+    uint32_t* y;                  // column j of Y at y + j * ldy words
+    uint64_t ldy;
+    uint32_t vectors;
+    uint32_t num_cols;
+    uint32_t num_workgroups;
+    uint32_t max_block_rows;
+};
+uint32_t spmm_bitmap_max_block_rows(bool is_float, uint32_t vectors);   // rows per block whose accumulators still fit the LDS
+hipError_t launch_spmm_bitmap(bool is_float, const SpmmLaunch& a, hipStream_t stream);
 // BITMAP images (spmv_bitmap.hip); launch_spmv forwards to it when a.format == kFormatBitmap.
 hipError_t configure_bitmap_kernels(uint32_t lds_bytes);
 hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream);

@@ -164,9 +164,12 @@ int hs_load_matrix_csr(hs_context* ctx, uint32_t num_rows, uint32_t num_cols, co
 
 /* ---- SpMM (EXTENSION; the reference has no SpMM) ----------------------------------------------------------
  * Y = A X for k dense vectors, column j of X / Y being a packed vector of num_cols / num_rows words (the layouts of hs_load_vector
- * and hs_read_result).  The k columns go through the SpMV kernels one after the other over the image hs_load_matrix left on the
- * device -- the matrix is streamed k times; a fused k-wide kernel is not built -- so column j of Y is exactly what hs_run gives for
- * column j of X.  The context's own vector / result and its bindings are left as they were.
+ * and hs_read_result).  Column j of Y is bit for bit what hs_run gives for column j of X.
+ *   BITMAP images (dense rows -- the pruned-NN layers, which meet batches of activations in practice), one column slice: FUSED, 4
+ *     then 2 columns at a time (spmm_bitmap.hip): masks and values are streamed once per group, x interleaved [column][vector];
+ *     transformer-50: 6.3 us per column against 13.5 us for an SpMV (profiles/r02_spmm_bitmap.txt).  HISPARSE_SPMM_FUSED=0 turns it off.
+ *   every other image, and a last odd column: one SpMV launch per column over the resident image (the matrix is streamed k times).
+ * The context's own vector / result and its bindings are left as they were.
  *   hs_spmm_device: X and Y in device memory, column j at x_dev + j * ldx words / y_dev + j * ldy words; 16-byte aligned, ldx and ldy
  *     multiples of 4 words with ldx >= num_cols, ldy >= num_rows.  Asynchronous on the context's stream.
  *   hs_spmm: host pointers, columns back to back (ldx = num_cols, ldy = num_rows); copies in, runs, copies out, synchronous. */

@@ -94,3 +94,60 @@ def test_spmm_device_pointers_and_strides():
         with pytest.raises(device.DeviceError):
             eng.num_rows = 8
             eng.spmm(np.zeros((1, 8), dtype=np.uint32))           # no matrix loaded
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(600, 4096, 0.4), (300, 9000, 0.2), (2, 2500, 0.9)])
+def test_fused_spmm_over_a_bitmap_image(monkeypatch, impl, shape):
+    """Dense rows -> BITMAP image -> hs_spmm takes 4 and 2 columns at a time through spmm_bitmap.hip (k = 7: 4 + 2 + one SpMV).  Every
+    column must equal the SpMV kernel's answer for it BIT FOR BIT (same products, same summation order) and the oracle within the
+    mode's contract."""
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT", raising=False)
+    rows, cols, density = shape
+    csr = host.CSRMatrix.generate("bernoulli", rows, cols, b=density, c=0.05 if impl else 1.0, seed=rows)
+    if impl == 0:
+        ip, ix, dv = csr.arrays()
+        csr = host.CSRMatrix.from_arrays(rows, cols, ip, ix, np.abs(dv) * 0.01)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    k = 7
+    X = np.stack([host.pack_vector(impl, cases.random_x(cp.num_cols, 200 + j, impl)) for j in range(k)])
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix(cp)
+        st = eng.stats()
+        Y = eng.spmm(X)
+        singles = []
+        for j in range(k):
+            eng.load_vector(X[j])
+            eng.run()
+            singles.append(eng.read_result())
+    if rows >= 600:                                   # (fewer rows than CUs -> column slices, float_stall's 1024-row padding on a short
+        # matrix -> PAIRS: the fused kernel steps aside there, the results must still agree)
+        assert device.STREAM_FORMATS[st["stream_format"]] == "bitmap" and st["col_slices"] == 1
+    for j in range(k):
+        assert np.array_equal(Y[j], singles[j]), f"column {j} differs from the SpMV kernel's result"
+        want = _oracle(cp, impl, X[j])
+        assert np.array_equal(Y[j], want) if impl == 0 else cases.float_close(Y[j], want)
+
+
+def test_fused_spmm_transformer_50_full_size():
+    """BASELINE config 3's matrix with a batch of 6 activations: 4 + 2 columns through the fused kernel, bit for bit the SpMV kernel's
+    answers, within 1e-4 * max(1, |y|) of the oracle."""
+    from hisparse_amd import datasets
+    cfg, csr = datasets.load("transformer_50")
+    impl = host.impl_id(cfg.impl)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=cfg.skip_empty_rows)
+    rng = np.random.default_rng(50)
+    X = np.stack([host.pack_vector(impl, rng.normal(size=cp.num_cols).astype(np.float32)) for _ in range(6)])
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix(cp)
+        assert device.STREAM_FORMATS[eng.stats()["stream_format"]] == "bitmap"
+        Y = eng.spmm(X)
+        for j in range(6):
+            eng.load_vector(X[j])
+            eng.run()
+            assert np.array_equal(Y[j], eng.read_result())
+    for j in (0, 5):
+        want = orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], X[j], cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions,
+                        cp.ob_bank, cp.vb_bank).view(np.float32).astype(np.float64)
+        got = Y[j].view(np.float32).astype(np.float64)
+        assert (np.abs(got - want) <= 1e-4 * np.maximum(1.0, np.abs(want))).all()
