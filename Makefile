@@ -15,11 +15,12 @@ HIPFLAGS  := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -ffp
 HOST_HDRS := $(wildcard include/hisparse/*.h) include/hisparse_host.h
 HIP_HDRS  := include/hisparse_hip.h $(wildcard $(CSRC)/*.h) include/hisparse/common.h
 
-.PHONY: all host hip oracle benchmark clean
-all: host hip oracle benchmark
+.PHONY: all host hip cpu oracle benchmark clean
+all: host hip cpu oracle benchmark
 
 host: $(LIBDIR)/libhisparse_host.so
 hip: $(LIBDIR)/libhisparse_hip.so
+cpu: $(LIBDIR)/libhisparse_cpu.so
 oracle: oracle/liboracle.so
 benchmark: $(LIBDIR)/benchmark
 
@@ -32,6 +33,10 @@ $(LIBDIR)/libhisparse_host.so: $(CSRC)/host_capi.cpp $(HOST_HDRS) | $(LIBDIR)
 HIP_SRCS  := $(CSRC)/hs_api.cpp $(CSRC)/tiles_capi.cpp $(CSRC)/stream_tiles.cpp $(CSRC)/bitmap_tiles.cpp $(CSRC)/spmv_kernels.hip $(CSRC)/spmv_bitmap.hip $(CSRC)/spmspv.hip $(CSRC)/spmm_bitmap.hip $(CSRC)/gpu_tiles.hip
 $(LIBDIR)/libhisparse_hip.so: $(HIP_SRCS) $(HIP_HDRS) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS) -pthread
+
+# the same C-ABI on host threads for machines without a GPU: a separate library a driver links INSTEAD (never a fallback of the HIP one)
+$(LIBDIR)/libhisparse_cpu.so: $(CSRC)/cpu_backend.cpp $(HIP_HDRS) include/hisparse/q8_24.h | $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -ffp-contract=off -I$(CSRC) -shared -o $@ $<
 
 # host-only translation unit, built with hipcc for the HIP runtime and RCCL headers (multi-GPU path: one context per device, ncclAllGather of y)
 $(LIBDIR)/benchmark: $(CSRC)/benchmark.cpp $(HOST_HDRS) include/hisparse_hip.h $(LIBDIR)/libhisparse_hip.so $(LIBDIR)/libhisparse_host.so | $(LIBDIR)

@@ -86,13 +86,16 @@ def lib():
         l.hs_load_matrix_csr.argtypes = [vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(u32)]
         l.hs_spmm.argtypes = [vp, vp, u32, u32, vp, u32]
         l.hs_spmm_device.argtypes = [vp, vp, u64, vp, u64, u32]
-        l.hs_tiles_build.argtypes = [C.POINTER(vp), C.POINTER(u64), C.c_int, u32, u32, u32, u32, u32, u32, u32, C.POINTER(vp)]
-        l.hs_tiles_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64),
-                                    C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
-        l.hs_tiles_copy.argtypes = [vp, vp, vp, vp, vp, vp]
-        l.hs_tiles_free.argtypes = [vp]
-        l.hs_tiles_free.restype = None
-        l.hs_tiles_last_error.restype = C.c_char_p
+        # (HISPARSE_HIP_LIB may name libhisparse_cpu.so, the separate host-thread build of the same boundary for machines without a
+        # GPU: it has no re-tiling to introspect.  The default library must export everything: tests/test_capi.py.)
+        if hasattr(l, "hs_tiles_build") or os.path.basename(_LIB_PATH) == "libhisparse_hip.so":
+            l.hs_tiles_build.argtypes = [C.POINTER(vp), C.POINTER(u64), C.c_int, u32, u32, u32, u32, u32, u32, u32, C.POINTER(vp)]
+            l.hs_tiles_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64),
+                                        C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+            l.hs_tiles_copy.argtypes = [vp, vp, vp, vp, vp, vp]
+            l.hs_tiles_free.argtypes = [vp]
+            l.hs_tiles_free.restype = None
+            l.hs_tiles_last_error.restype = C.c_char_p
         _lib = l
     return _lib
 

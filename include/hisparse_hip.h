@@ -29,7 +29,9 @@
  * on the context's HIP stream; hs_sync / hs_read_result wait for them.
  *
  * There is NO CPU fallback: every entry point that needs the GPU fails with HS_ERR_NO_DEVICE or
- * HS_ERR_HIP when none is usable.
+ * HS_ERR_HIP when none is usable.  (libhisparse_cpu.so -- hisparse_amd/csrc/cpu_backend.cpp -- exports the core entry points of this
+ * header on host threads for machines without a GPU; it is a separate library a driver links INSTEAD, as the reference's driver is
+ * built against csim or against the xclbin, and this library never loads it.)
  */
 #ifndef HISPARSE_HIP_H_
 #define HISPARSE_HIP_H_
