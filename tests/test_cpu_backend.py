@@ -73,7 +73,8 @@ print("cpu backend ok", checked)
 
 
 def test_cpu_backend_is_a_separate_library_and_matches_the_oracle():
-    assert os.path.exists(CPU_LIB), "make cpu"
+    if not os.path.exists(CPU_LIB):
+        subprocess.check_call(["make", "-C", ROOT, "cpu"], stdout=subprocess.DEVNULL)
     env = dict(os.environ, HISPARSE_HIP_LIB=CPU_LIB)
     env.pop("HISPARSE_STREAM_FORMAT", None)
     r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}], capture_output=True, text=True, env=env, timeout=600)
