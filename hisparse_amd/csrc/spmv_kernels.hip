@@ -205,6 +205,7 @@ struct Consumer {
     const uint32_t* xs;
     acc_t* ys;
     uint32_t u = 0, slot = 0, end = 0, base = 0;
+    uint32_t next_end = 0;     // end_step of unit u + 1, requested one unit ahead (a scalar load whose latency is off the unit boundary)
     const uint32_t* xb;
     uint32_t pos = 0;          // DELTA: this lane's position in the current sub-tile
     bool head = true;          // DELTA: the next record of this wavefront is a head record
@@ -244,7 +245,8 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
         }
         if (!(kAblate & 8)) lds_barrier();
         if (++c.u == c.U) return false;
-        c.end = c.unit[c.u].end_step[c.wave];
+        c.end = c.next_end;
+        c.next_end = c.unit[min(c.u + 1, c.U - 1)].end_step[c.wave];
         c.slot = c.slot + 1 == c.ring ? 0 : c.slot + 1;
         c.xb = c.xs + c.slot * kSubTileCols;
         c.head = true;
@@ -383,7 +385,8 @@ __device__ __forceinline__ bool consume_step_owner(Consumer<true>& c) {
         if (!(kAblate & 8)) lds_barrier();
         }
         if (++c.u == c.U) return false;
-        c.end = c.unit[c.u].end_step[c.wave];
+        c.end = c.next_end;
+        c.next_end = c.unit[min(c.u + 1, c.U - 1)].end_step[c.wave];
         c.slot = c.slot + 1 == c.ring ? 0 : c.slot + 1;
         c.xb = c.xs + c.slot * kSubTileCols;
     }
@@ -481,6 +484,7 @@ __device__ __forceinline__ void consumer_begin(Consumer<kFloat>& c, const uint8_
     c.last = total ? total - 1 : 0;    // prefetches past the end re-read the last chunk / record (no branch)
     c.xs = xs; c.xb = xs; c.ys = ys;
     c.end = first_end;
+    c.next_end = U > 1 ? unit[1].end_step[wave] : first_end;
     c.lane_row = kOwner ? nrows + wave : nrows;
     c.spare = nrows + wave;
     c.row_base = row_base;
