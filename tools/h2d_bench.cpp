@@ -1,0 +1,73 @@
+// h2d_bench.cpp — how to get a pageable host buffer into HBM fastest (hs_load_matrix hands over 0.4 - 1.8 GB of pageable CPSR / CSR):
+//   (a) one hipMemcpy of the pageable buffer (what the runtime does: pin in pieces + DMA), first time and again;
+//   (b) a ring of pinned staging buffers filled by N host threads (memcpy) and drained by hipMemcpyAsync.
+// build: hipcc -O3 -std=c++17 -pthread -o tools/h2d_bench.bin tools/h2d_bench.cpp ; run: tools/h2d_bench.bin [MB]
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char** argv) {
+    const size_t bytes = size_t(argc > 1 ? std::atoi(argv[1]) : 424) << 20;
+    uint8_t* dev = nullptr;
+    CHECK(hipMalloc(reinterpret_cast<void**>(&dev), bytes));
+    CHECK(hipMemset(dev, 0, bytes));
+    hipStream_t stream;
+    CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (int trial = 0; trial < 2; ++trial) {
+        std::vector<uint8_t> host(bytes);                       // fresh pageable memory per trial
+        for (size_t i = 0; i < bytes; i += 4096) host[i] = uint8_t(i >> 12);
+        double t0 = now_ms();
+        CHECK(hipMemcpy(dev, host.data(), bytes, hipMemcpyHostToDevice));
+        double t1 = now_ms();
+        CHECK(hipMemcpy(dev, host.data(), bytes, hipMemcpyHostToDevice));
+        double t2 = now_ms();
+        std::printf("hipMemcpy pageable %zu MB: first %.1f ms (%.1f GB/s), again %.1f ms (%.1f GB/s)\n", bytes >> 20, t1 - t0, bytes / (t1 - t0) / 1e6,
+                    t2 - t1, bytes / (t2 - t1) / 1e6);
+    }
+    for (int workers : {2, 4, 8, 16}) {
+        for (size_t slot_mb : {4, 16}) {
+            const size_t slot = slot_mb << 20;
+            double t_alloc0 = now_ms();
+            std::vector<uint8_t*> pinned(size_t(workers) * 2);
+            std::vector<hipEvent_t> done(pinned.size());
+            for (size_t i = 0; i < pinned.size(); ++i) {
+                CHECK(hipHostMalloc(reinterpret_cast<void**>(&pinned[i]), slot, hipHostMallocDefault));
+                CHECK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+            }
+            double t_alloc1 = now_ms();
+            std::vector<uint8_t> host(bytes);                   // fresh pageable memory
+            for (size_t i = 0; i < bytes; i += 4096) host[i] = uint8_t(i >> 12);
+            const size_t chunks = (bytes + slot - 1) / slot;
+            double t0 = now_ms();
+            std::vector<std::thread> pool;
+            for (int w = 0; w < workers; ++w)
+                pool.emplace_back([&, w]() {
+                    (void)hipSetDevice(0);
+                    int use = 0;
+                    for (size_t c = size_t(w); c < chunks; c += size_t(workers), use ^= 1) {
+                        const size_t s = size_t(w) * 2 + use, off = c * slot, n = std::min(slot, bytes - off);
+                        if (c >= size_t(workers) * 2) (void)hipEventSynchronize(done[s]);      // the slot's previous DMA has read it
+                        std::memcpy(pinned[s], host.data() + off, n);
+                        (void)hipMemcpyAsync(dev + off, pinned[s], n, hipMemcpyHostToDevice, stream);
+                        (void)hipEventRecord(done[s], stream);
+                    }
+                });
+            for (auto& th : pool) th.join();
+            CHECK(hipStreamSynchronize(stream));
+            double t1 = now_ms();
+            std::printf("staged, %2d workers x 2 x %2zu MB pinned (allocated in %.1f ms): %.1f ms (%.1f GB/s)\n", workers, slot_mb, t_alloc1 - t_alloc0, t1 - t0,
+                        bytes / (t1 - t0) / 1e6);
+            for (size_t i = 0; i < pinned.size(); ++i) { (void)hipHostFree(pinned[i]); (void)hipEventDestroy(done[i]); }
+        }
+    }
+    return 0;
+}
