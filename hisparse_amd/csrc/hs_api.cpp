@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -234,6 +235,20 @@ int hs_create(hs_context** out, int device_id, int impl, uint32_t ob_bank, uint3
         delete c;
         return hip_fail(nullptr, e, "loading the gfx950 kernels");
     }
+    // ... and the runtime's one-time set-up of its pageable-copy paths (7 ms in the first copy of a process, whatever its size:
+    // tools/h2d_bench.cpp), once per process
+    static std::once_flag copy_paths;
+    std::call_once(copy_paths, [c] {
+        std::vector<uint8_t> host(4 << 20, 0);
+        void* dev = nullptr;
+        if (hipMalloc(&dev, host.size()) != hipSuccess) return;
+        (void)hipMemcpy(dev, host.data(), host.size(), hipMemcpyHostToDevice);
+        (void)hipMemcpy(host.data(), dev, host.size(), hipMemcpyDeviceToHost);
+        (void)hipMemcpyAsync(dev, host.data(), host.size(), hipMemcpyHostToDevice, c->own_stream);      // the stream-ordered variants
+        (void)hipMemcpyAsync(host.data(), dev, host.size(), hipMemcpyDeviceToHost, c->own_stream);      // have their own set-up
+        (void)hipStreamSynchronize(c->own_stream);
+        (void)hipFree(dev);
+    });
     *out = c;
     return HS_OK;
 }

@@ -22,6 +22,15 @@ int main(int argc, char** argv) {
     CHECK(hipMemset(dev, 0, bytes));
     hipStream_t stream;
     CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (argc > 2) {      // warm-up size in MB: does a small first copy take the one-time cost off the big one?
+        const size_t warm = size_t(std::atoi(argv[2])) << 20;
+        std::vector<uint8_t> small(warm, 1);
+        double t0 = now_ms();
+        CHECK(hipMemcpy(dev, small.data(), warm, hipMemcpyHostToDevice));
+        double t1 = now_ms();
+        CHECK(hipMemcpy(small.data(), dev, warm, hipMemcpyDeviceToHost));
+        std::printf("warm-up %zu MB: H2D %.1f ms, D2H %.1f ms\n", warm >> 20, t1 - t0, now_ms() - t1);
+    }
     for (int trial = 0; trial < 2; ++trial) {
         std::vector<uint8_t> host(bytes);                       // fresh pageable memory per trial
         for (size_t i = 0; i < bytes; i += 4096) host[i] = uint8_t(i >> 12);
