@@ -67,6 +67,41 @@ def read_traffic(config, stream_bytes):
     return e.get("hbm_bytes_per_launch")
 
 
+def spmm_probe(np, host, eng, impl, packets, rng, xw, k=8, reps=100):
+    """Dense-row (BITMAP) images: hs_spmm_device with k columns of X resident in HBM -- the fused kernel streams the matrix once per 4
+    columns (spmm_bitmap.hip) -- next to k SpMVs; column 0 is checked against the SpMV kernel's own answer (bit for bit)."""
+    import ctypes as C
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    X = rng.normal(size=(k, packets.num_cols)).astype(np.float32) if impl else rng.uniform(0.0, 2.0, (k, packets.num_cols)).astype(np.float32)
+    Xw = np.stack([host.pack_vector(impl, X[j]) for j in range(k)])
+    xd, yd = C.c_void_p(), C.c_void_p()
+    if rt.hipMalloc(C.byref(xd), Xw.nbytes) or rt.hipMalloc(C.byref(yd), k * packets.num_rows * 4) or rt.hipMemcpy(xd, Xw.ctypes.data, Xw.nbytes, 1):
+        return None
+    try:
+        for _ in range(20):
+            eng.spmm_device(xd.value, packets.num_cols, yd.value, packets.num_rows, k)
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.spmm_device(xd.value, packets.num_cols, yd.value, packets.num_rows, k)
+        eng.sync()
+        us = (time.perf_counter() - t0) / reps * 1e6
+        y0 = np.empty(packets.num_rows, dtype=np.uint32)
+        rt.hipMemcpy(y0.ctypes.data, yd, y0.nbytes, 2)
+        eng.load_vector(Xw[0])
+        eng.run()
+        same = bool(np.array_equal(y0, eng.read_result()))
+        eng.load_vector(xw)            # the context's own vector as the caller left it
+    finally:
+        rt.hipFree(xd)
+        rt.hipFree(yd)
+    return {"k": k, "us_per_spmm": round(us, 2), "us_per_column": round(us / k, 2), "column_0_equals_spmv_bit_for_bit": same,
+            "note": "hs_spmm_device, X and Y resident; BITMAP image: 4 columns per pass of the matrix (reference: no SpMM)"}
+
+
 def oracle_check(np, host, impl, packets, xw, y_gpu, seconds):
     """(parity string, seconds per oracle SpMV, repetitions) — oracle/cpu_ref.c, one thread, the same channel buffers."""
     from oracle import oracle as orc
@@ -146,6 +181,7 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
     if not same or st2["stream_bytes"] != stats["stream_bytes"]:
         print(json.dumps({"error": "the CSR load path gives a different image or result than the CPSR path", "config": name}))
         sys.exit(1)
+    spmm = spmm_probe(np, host, eng, impl, packets, rng, xw) if device.STREAM_FORMATS[stats["stream_format"]] == "bitmap" else None
     res = {
         "workload": f"{name}, {IMPL_NAMES[impl]} IMPL, v={packets.vb_bank} o={packets.ob_bank}",
         "rows": true_rows, "cols": packets.num_cols, "nnz": int(nnz), "partitions": f"{packets.num_row_partitions}x{packets.num_col_partitions}",
@@ -161,6 +197,8 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         "preprocess_s": {"format_csr2cpsr": round(t_fmt, 3), "device_load_retile": round(stats["load_seconds"], 3),
                          "device_load_from_csr_instead": round(st2["load_seconds"], 3)},
     }
+    if spmm:
+        res["spmm_extension"] = spmm
     return res, dict(eng=eng, packets=packets, csr=csr, x=x, xw=xw, impl=impl, nnz=nnz, y_cpu=y_cpu, t_cpu=t_cpu, reps=reps, cfg=cfg)
 
 
@@ -316,6 +354,8 @@ def main():
         "roofline": res["roofline"], "cpu_baseline": cpu_baseline, "parity_vs_oracle": res["parity_vs_oracle"],
         "preprocess_s": res["preprocess_s"],
     }
+    if "spmm_extension" in res:
+        out["spmm_extension"] = res["spmm_extension"]
     if per_config:
         out["per_config"] = per_config
     print(json.dumps(out), flush=True)
