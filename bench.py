@@ -393,6 +393,7 @@ def main_distributed(args, rank, local_rank, world):
             sys.exit(1)
         ip, ix, dv = sharding.slab_arrays(indptr, indices, data, lo, hi)
         csr = host.CSRMatrix.from_arrays(hi - lo, full.num_cols, ip, ix, dv)
+        whole = full if rank == 0 else None        # rank 0 also times the unsplit matrix on its one GPU (the curve's N = 1 point)
         del full, indptr, indices, data
     else:   # weak: rank r owns slab r of a matrix that is n_gpus slabs tall; same generator, different seed per slab
         c = cfg
@@ -407,6 +408,8 @@ def main_distributed(args, rank, local_rank, world):
     rng = np.random.default_rng(2024)
     x = rng.uniform(0.0, 2.0, packets.num_cols).astype(np.float32) if impl == host.IMPL_FIXED else rng.normal(size=packets.num_cols).astype(np.float32)
     xw = host.pack_vector(impl, x)
+    if args.scaling != "strong":
+        whole = None
     eng = device.SpmvEngine(impl, device_id=local_rank)
     eng.load_matrix(packets)
     eng.load_vector(xw)
@@ -498,6 +501,25 @@ def main_distributed(args, rank, local_rank, world):
     _, ev_kernel_ms = eng.time_runs(0, args.steps)
     kernel_ms = ev_kernel_ms / args.steps
     dist.barrier()
+    # strong scaling: the SAME matrix, unsplit, on rank 0's GPU alone -- the N = 1 point the N-GPU numbers of this workload belong to
+    # (bench.py --gpus 1 without a launcher measures the ogbl-ppa headline instead)
+    one_gpu = None
+    if whole is not None:
+        with device.SpmvEngine(impl, device_id=local_rank) as eng1:
+            eng1.load_matrix_csr(whole)
+            eng1.load_vector(xw)
+            for _ in range(SPIN_UP_STEPS + args.warmup):
+                eng1.run()
+            eng1.sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                eng1.run()
+            eng1.sync()
+            one = (time.perf_counter() - t1) / args.steps
+            one_gpu = {"n_gpus": 1, "ms_per_step": round(one * 1e3, 5), "value": round(8.0 * whole.nnz / one / 1e9, 2), "unit": "GB/s",
+                       "note": "the same matrix unsplit on rank 0's GPU, y in HBM (no exchange); measured while the other ranks wait"}
+        del whole
+    dist.barrier()
 
     out = None
     if rank == 0:
@@ -520,6 +542,7 @@ def main_distributed(args, rank, local_rank, world):
             "compute_only": {"ms_per_step": round(compute_elapsed / args.steps * 1e3, 5), "value": round(8.0 * total_nnz / (compute_elapsed / args.steps) / 1e9, 2),
                              "unit": "GB/s", "hbm_roofline_fraction": round(8.0 * total_nnz / (compute_elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4),
                              "note": "the same K slab SpMVs with y left sharded in HBM, like the reference leaves it (sw/benchmark.cpp:318-338)"},
+            "same_workload_on_one_gpu": one_gpu,
             "exchange": {"pattern": args.gather, "bytes_per_rank_per_gather": int(chunk) * 4,
                          "ms_per_step_added": round((elapsed - compute_elapsed) / args.steps * 1e3, 5)},
             "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_rowblock_kernel", "achieved": round(achieved, 2),
