@@ -199,8 +199,9 @@ __global__ __launch_bounds__(256) void interleave_vectors_kernel(const uint32_t*
 template <bool kFloat, int kVecs>
 hipError_t launch(const SpmmLaunch& a, hipStream_t stream) {
     const uint32_t lds = (a.max_block_rows + 1) * kVecs * uint32_t(sizeof(typename Rows<kFloat>::acc_t));
-    static const hipError_t configured = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_bitmap_kernel<kFloat, kVecs>),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxLdsBytes));
+    // (per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and a process may drive several)
+    const hipError_t configured = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_bitmap_kernel<kFloat, kVecs>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxLdsBytes));
     if (configured != hipSuccess) return configured;
     hipLaunchKernelGGL((interleave_vectors_kernel<kVecs>), dim3((a.num_cols + 255) / 256), dim3(256), 0, stream, a.x, a.ldx, a.num_cols, a.x_interleaved);
     hipLaunchKernelGGL((spmm_bitmap_kernel<kFloat, kVecs>), dim3(a.num_workgroups), dim3(kBmThreads), lds, stream, a.image, a.blocks, a.units,
