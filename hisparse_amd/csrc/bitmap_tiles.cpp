@@ -88,12 +88,12 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     // ---- plan: column slices only when there are fewer rows than workgroups; row ranges of equal non-zero count --------------
     const uint32_t GR = (num_cols + kBitmapGroupCols - 1) / kBitmapGroupCols;     // groups per row
     uint32_t slices = 1;
-    if (const char* force = std::getenv("HISPARSE_COL_SLICES")) slices = std::max(1, std::atoi(force));
+    if (const char* force = env_switch("HISPARSE_COL_SLICES")) slices = std::max(1, std::atoi(force));
     else while (slices * 2 <= kMaxColSlices && uint64_t(num_rows) * slices * 2 <= G) slices *= 2;
     slices = std::min<uint32_t>(std::min<uint32_t>(slices, kMaxColSlices), GR);
     while (slices > 1 && uint64_t(slices) * num_rows > 0xffffffffull) slices /= 2;
     uint32_t max_rows = kBitmapMaxBlockRows;
-    if (const char* force = std::getenv("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force)));
+    if (const char* force = env_switch("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force)));
     const uint64_t per_round = std::max<uint32_t>(1, G / slices);
     const uint64_t rounds = std::max<uint64_t>(1, ((uint64_t(num_rows) + max_rows - 1) / max_rows + per_round - 1) / per_round);
     const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(per_round * rounds, std::max<uint64_t>(1, nnz / 1024)));

@@ -89,7 +89,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         const double density = live_rows ? double(out.nnz) / (double(live_rows) * double(num_cols)) : 0.0;
         const double mask_bytes = double(num_rows) * double((num_cols + kBitmapGroupCols - 1) / kBitmapGroupCols) * 8.0;
         bool bitmap = density >= kBitmapMinDensity && num_cols >= kBitmapMinCols && mask_bytes <= 2.0 * double(out.nnz);
-        if (const char* force = std::getenv("HISPARSE_STREAM_FORMAT")) {
+        if (const char* force = env_switch("HISPARSE_STREAM_FORMAT")) {
             const std::string f(force);
             if (f == "bitmap") bitmap = true;
             else if (f == "pairs" || f == "delta") bitmap = false;
@@ -108,7 +108,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         const double mean_gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 1e30;
         out.format = (mean_gap >= kDeltaMinMeanGap && mean_gap <= kDeltaMaxMeanGap) ? kFormatDelta : kFormatPairs;
         if (is_float && mean_gap > kOwnerMinMeanGap && out.nnz >= 4096) out.format = kFormatOwner;
-        if (const char* force = std::getenv("HISPARSE_STREAM_FORMAT")) {
+        if (const char* force = env_switch("HISPARSE_STREAM_FORMAT")) {
             const std::string f(force);
             if (f == "pairs") out.format = kFormatPairs;
             else if (f == "delta") out.format = kFormatDelta;
@@ -119,7 +119,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     }
     bool delta = out.format == kFormatDelta;
     const bool owner = out.format == kFormatOwner;
-    const bool format_forced = std::getenv("HISPARSE_STREAM_FORMAT") != nullptr;
+    const bool format_forced = env_switch("HISPARSE_STREAM_FORMAT") != nullptr;
     const uint32_t acc_bytes = owner ? kOwnerAccumulatorBytes : kAccumulatorBytes;
     const uint32_t spare_rows = owner ? kConsumerWaves : 1u;     // accumulators behind the block's rows that padding elements aim at
 
@@ -132,8 +132,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     const uint32_t G = std::max<uint32_t>(1, max_workgroups);
     uint32_t slices = 1, max_rows = max_block_rows(false);
     {
-        const char* force_slices = std::getenv("HISPARSE_COL_SLICES");
-        const char* force_rows = std::getenv("HISPARSE_MAX_ROWS");   // experiments
+        const char* force_slices = env_switch("HISPARSE_COL_SLICES");
+        const char* force_rows = env_switch("HISPARSE_MAX_ROWS");   // experiments
         struct Shape { uint32_t cap, ring; };
         // OWNER: 4-byte accumulators -> 24561 rows with a ring of 2, 16369 with a ring of 3, sliced or not
         const Shape sliced[2] = {{owner ? owner_max_block_rows(2) : max_block_rows(true), 2},
@@ -201,7 +201,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     // OWNER: shares are cut per unit (tiles_common.h: balanced_owner_shares).  The 24-bit form (opt-in) addresses rows relative to a
     // wavefront's share of the whole block in 11 bits, so it keeps the fixed ownership: every consumer wavefront owns a contiguous
     // share of a range's rows, cut at equal non-zero count
-    const bool fixed_shares = owner && [] { const char* bits = std::getenv("HISPARSE_AUX_BITS"); return bits && std::atoi(bits) == 24; }();
+    const bool fixed_shares = owner && [] { const char* bits = env_switch("HISPARSE_AUX_BITS"); return bits && std::atoi(bits) == 24; }();
     std::vector<uint32_t> wave_row;      // [range][kConsumerWaves + 1] local row boundaries
     if (fixed_shares) {
         wave_row.assign(size_t(NR) * (kConsumerWaves + 1), 0);
@@ -284,7 +284,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 uint32_t live_rows = 0;
                 for (uint32_t r = 0; r < ranges[b].nrows; ++r) live_rows += row_nnz[ranges[b].row0 + r] != 0;
                 const double gap = range_nnz[b] ? double(live_rows) * double(num_cols) / double(range_nnz[b]) : 1e30;
-                const char* force = std::getenv("HISPARSE_ROW_RUNS");
+                const char* force = env_switch("HISPARSE_ROW_RUNS");
                 blk.flags = (force ? std::atoi(force) != 0 : gap < kDenseMeanGap) ? kBlockDenseRows : 0u;
             } else if (owner) {
                 blk.flags = 0;
@@ -411,7 +411,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         // Opt-in (HISPARSE_AUX_BITS=24): measured SLOWER than the 8-byte forms although it streams 12 % fewer bytes (mouse_gene 40.8 vs
         // 39.7 us, ogbn-products 281 vs 266 us): a step becomes two loads (one of them unaligned) instead of one dwordx2, and the
         // kernels are bound by the number of memory requests a CU keeps in flight, not by the bytes.
-        const char* bits = std::getenv("HISPARSE_AUX_BITS");
+        const char* bits = env_switch("HISPARSE_AUX_BITS");
         const bool allowed = bits && std::atoi(bits) == 24;
         if (owner) {
             aux24 = allowed && fixed_shares;

@@ -25,6 +25,12 @@ namespace hisparse {
 namespace dev {
 namespace detail {
 
+// an experiment switch of the environment; set-but-empty counts as not set (HISPARSE_MAX_ROWS= used to mean "one row per block")
+inline const char* env_switch(const char* name) {
+    const char* v = std::getenv(name);
+    return v && *v ? v : nullptr;
+}
+
 struct PhaseTimer {   // HISPARSE_PLAN_DEBUG=1: wall time of the load-time passes
     const bool on = std::getenv("HISPARSE_PLAN_DEBUG") != nullptr;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();

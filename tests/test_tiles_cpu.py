@@ -372,3 +372,16 @@ def test_owner_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypa
     csr0 = host.CSRMatrix.generate("powerlaw", 9000, 70000, a=20000, b=0.5, c=1.0, seed=12)
     cp0 = host.format_matrix(csr0, 0, skip_empty_rows=True)
     assert build(cp0, 0, 4)["format"] in ("pairs", "pairs24")
+
+
+def test_empty_environment_switches_count_as_unset(monkeypatch):
+    """`HISPARSE_MAX_ROWS=` (set but empty) once meant "one row per block": 4.9 M blocks for ogbn-products.  Empty = not set."""
+    for name in ("HISPARSE_STREAM_FORMAT", "HISPARSE_MAX_ROWS", "HISPARSE_COL_SLICES", "HISPARSE_ROW_RUNS", "HISPARSE_AUX_BITS"):
+        monkeypatch.delenv(name, raising=False)
+    csr = host.CSRMatrix.generate("powerlaw", 20000, 30000, a=200000, b=0.3, c=1.0, seed=4)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+    want = build(cp, 0, 32)
+    for name in ("HISPARSE_STREAM_FORMAT", "HISPARSE_MAX_ROWS", "HISPARSE_COL_SLICES", "HISPARSE_ROW_RUNS", "HISPARSE_AUX_BITS"):
+        monkeypatch.setenv(name, "")
+    got = build(cp, 0, 32)
+    assert got["format"] == want["format"] and np.array_equal(got["image"], want["image"]) and got["blocks"].tobytes() == want["blocks"].tobytes()
