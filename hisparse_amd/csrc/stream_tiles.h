@@ -108,10 +108,11 @@ constexpr uint32_t kOwnerSpareField = 2047;
 // element stream but x -- every row block pulls the WHOLE vector through its CU, sub-tile by sub-tile, so the staged x volume is
 // (rows / rows per block) x 4 cols bytes (3.1 GB per SpMV with 8191-row blocks against 1 GB of matrix).  Rows per block are
 // bounded by the LDS accumulators, and LDS float atomics force those to be doubles (ds_add_f32 runs at 0.33 lanes/clk,
-// tools/lds_accum_bench.hip).  OWNER gets 4-byte accumulators WITHOUT atomics: every consumer wavefront owns a contiguous share
-// of the block's rows (equal non-zero count), a unit's elements are split by owner, sorted by (row, column) and dealt to the
-// lanes in consecutive runs, so that
-//   * no other wavefront ever touches the wavefront's accumulators (LDS executes one wavefront's instructions in order:
+// tools/lds_accum_bench.hip).  OWNER gets 4-byte accumulators WITHOUT atomics: inside a unit every consumer wavefront owns a
+// contiguous stretch of the rows -- the unit's elements, sorted by (row, column), are cut on row boundaries into 14 shares of
+// equal work (tiles_common.h: balanced_owner_shares; the unit barrier orders the accumulator writes, so rows may change hands
+// from unit to unit; the 24-bit form keeps one ownership per block) -- and a share is dealt to the lanes in consecutive runs, so that
+//   * no other wavefront touches a row's accumulator while the unit lasts (LDS executes one wavefront's instructions in order:
 //     ds_read / v_add_f32 / ds_write needs no atomic),
 //   * the lanes of one instruction hold non-decreasing rows, a lane sums its run in a register while the row stays the same,
 //     and two lanes can only meet on a row at the end of a unit, where one segmented wavefront reduction sorts it out.
