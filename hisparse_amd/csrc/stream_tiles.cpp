@@ -226,6 +226,12 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     timer.lap("plan + row ranges");
     // ---- pass 1: elements per (row range, column partition, sub-tile, source channel) -------------------
     const size_t slots_per_range = size_t(CP) * S * NUM_HBM_CHANNELS;
+    // (row range, sub-tile, source channel) counters: rows x columns / (rows per block x 8192) x 16 words -- a matrix of 10^8 x 10^8
+    // would ask for gigabytes here and for as many Unit descriptors: refuse instead of swapping
+    if (uint64_t(NR) * slots_per_range > (uint64_t(1) << 28)) {
+        error = "matrix too large for this build: " + std::to_string(NR) + " row ranges x " + std::to_string(uint64_t(CP) * S) + " x sub-tiles exceed the unit table";
+        return false;
+    }
     std::vector<uint32_t> cnt(size_t(NR) * slots_per_range, 0);
     auto slot = [&](uint32_t b, uint32_t cp, uint32_t s, uint32_t pc) { return size_t(b) * slots_per_range + (size_t(cp) * S + s) * NUM_HBM_CHANNELS + pc; };
     std::vector<WalkResult> res1(size_t(RP) * CP * NUM_HBM_CHANNELS);
