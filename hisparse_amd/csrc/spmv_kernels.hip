@@ -576,6 +576,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
             if (loader) {
                 // ---- loader wavefronts: keep the ring of x buffers up to three sub-tiles ahead of the consumers ----
                 const uint32_t lw = wave - kConsumerWaves;
+                __builtin_amdgcn_s_setprio(3);                         // the refills are on every unit's critical path: issue them first
                 uint32_t fill_slot = 1 == ring ? 0 : 1;                // ring slot of the next refill (sub-tile v lives in slot v % ring)
                 // Unit descriptors are 64 bytes apart and cold (they stream from HBM once per SpMV): the descriptor of the
                 // refill after next is fetched while this one is in flight, so its miss latency is off the per-unit path
