@@ -47,9 +47,18 @@ void run(const char* name, const uint8_t* d, size_t total, int wgs, uint32_t* si
 
 // the consumer loop of spmv_rowblock_kernel in isolation: kWaves of the 16 wavefronts stream 512-byte chunks that are
 // interleaved across the wavefronts, 8 asm loads in flight per lane, one s_waitcnt vmcnt(7) + one reload per step
-__device__ __forceinline__ void ld(uint64_t& dst, const void* addr) { asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(dst) : "v"(addr) : "memory"); }
+// kPolicy: the cache-policy bits of the stream loads: 0 = nt (what the kernels use), 1 = none, 2 = sc1, 3 = sc0 sc1, 4 = sc0 sc1 nt, 5 = sc1 nt
+template <int kPolicy>
+__device__ __forceinline__ void ld(uint64_t& dst, const void* addr) {
+    if (kPolicy == 0) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(dst) : "v"(addr) : "memory");
+    if (kPolicy == 1) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
+    if (kPolicy == 2) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(dst) : "v"(addr) : "memory");
+    if (kPolicy == 3) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(addr) : "memory");
+    if (kPolicy == 4) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1 nt" : "=v"(dst) : "v"(addr) : "memory");
+    if (kPolicy == 5) asm volatile("global_load_dwordx2 %0, %1, off sc1 nt" : "=v"(dst) : "v"(addr) : "memory");
+}
 template <int N> __device__ __forceinline__ void wt(uint64_t& v) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory"); }
-template <int kWaves>
+template <int kWaves, int kPolicy = 0>
 __global__ __launch_bounds__(1024) void ring_kernel(const uint8_t* __restrict__ src, size_t bytes_per_wg, uint32_t* sink) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64), lane = threadIdx.x & 63;
     if (wave >= kWaves) return;
@@ -58,28 +67,28 @@ __global__ __launch_bounds__(1024) void ring_kernel(const uint8_t* __restrict__ 
     const size_t stride = 512 * kWaves;
     uint64_t buf[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) ld(buf[k], p + (size_t)min((uint32_t)k, last) * stride);
+    for (int k = 0; k < 8; ++k) ld<kPolicy>(buf[k], p + (size_t)min((uint32_t)k, last) * stride);
     uint32_t acc = 0;
     for (uint32_t base = 0; base < total; base += 8) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             wt<7>(buf[k]);
             acc ^= (uint32_t)buf[k] ^ (uint32_t)(buf[k] >> 32);
-            ld(buf[k], p + (size_t)min(base + k + 8, last) * stride);
+            ld<kPolicy>(buf[k], p + (size_t)min(base + k + 8, last) * stride);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (acc == 0x12345678u) sink[0] = acc;
 }
-template <int kWaves>
+template <int kWaves, int kPolicy = 0>
 void run_ring(const char* name, const uint8_t* d, size_t total, int wgs, uint32_t* sink) {
     size_t per = total / wgs / (512 * kWaves * 8) * (512 * kWaves * 8);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((ring_kernel<kWaves>), dim3(wgs), dim3(1024), 0, 0, d, per, sink);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((ring_kernel<kWaves, kPolicy>), dim3(wgs), dim3(1024), 0, 0, d, per, sink);
     hipEventRecord(a);
     const int reps = 20;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ring_kernel<kWaves>), dim3(wgs), dim3(1024), 0, 0, d, per, sink);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ring_kernel<kWaves, kPolicy>), dim3(wgs), dim3(1024), 0, 0, d, per, sink);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     printf("%-28s wgs %5d  %8.1f us per pass  %7.1f GB/s\n", name, wgs, ms / reps * 1e3, (double)per * wgs / (ms / reps * 1e-3) / 1e9);
@@ -103,5 +112,12 @@ int main() {
     run_ring<16>("ring8 asm, 16 waves, 341 MB", d, 341ull << 20, 256, sink);
     run_ring<14>("ring8 asm, 14 waves, 1 GiB", d, total, 256, sink);
     run_ring<8>("ring8 asm, 8 waves, 341 MB", d, 341ull << 20, 256, sink);
+    // cache-policy bits of the stream loads, 1 GiB (nothing survives in the Infinity Cache between passes)
+    run_ring<14, 0>("ring8 14 waves 1 GiB nt", d, total, 256, sink);
+    run_ring<14, 1>("ring8 14 waves 1 GiB (none)", d, total, 256, sink);
+    run_ring<14, 2>("ring8 14 waves 1 GiB sc1", d, total, 256, sink);
+    run_ring<14, 3>("ring8 14 waves 1 GiB sc0 sc1", d, total, 256, sink);
+    run_ring<14, 4>("ring8 14 waves 1 GiB sc0 sc1 nt", d, total, 256, sink);
+    run_ring<14, 5>("ring8 14 waves 1 GiB sc1 nt", d, total, 256, sink);
     return 0;
 }
