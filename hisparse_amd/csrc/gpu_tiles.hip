@@ -416,21 +416,25 @@ __global__ __launch_bounds__(256) void emit_delta_kernel(const DevicePlan* __res
         const uint32_t run = p.run_len[w];
         if (!run) continue;
         uint8_t* rec = image + p.wave_offset[w] + uint64_t(p.start_step[w]) * kRecordBytes;      // start_record == start_step
-        for (uint32_t idx = threadIdx.x; idx < (run + 1) * kWaveLanes; idx += blockDim.x) {
-            const uint32_t j = idx / kWaveLanes, l = idx % kWaveLanes;                           // j = 0: the head record
+        const uint32_t slots_in_records = (run + 2) / 2 * 2;                                     // head + run, in whole two-slot records
+        for (uint32_t idx = threadIdx.x; idx < slots_in_records * kWaveLanes; idx += blockDim.x) {
+            const uint32_t j = idx / kWaveLanes, l = idx % kWaveLanes;                           // j = 0: the head slot
+            uint8_t* r = rec + uint64_t(j / 2) * kRecordBytes;
+            uint32_t* value_word = reinterpret_cast<uint32_t*>(r) + 2 * l + j % 2;
+            uint16_t* gap_word = reinterpret_cast<uint16_t*>(r + kWaveLanes * 8) + 2 * l + j % 2;
             const uint64_t s0 = p.first_slot[w] + uint64_t(l) * run;
             if (j == 0) {
                 uint32_t head = scratch_pos;
                 if (s0 < p.slots) head = s0 == 0 ? first_pos : delta_slot(p, keys, vals, bridges, s0 - 1).after;
-                reinterpret_cast<uint32_t*>(rec)[l] = head;
+                *value_word = head;
                 continue;
             }
+            if (j > run) { *gap_word = uint16_t(pad_gap); continue; }                            // the dead slot of an odd run
             const uint64_t si = s0 + (j - 1);
-            uint8_t* r = rec + uint64_t(j) * kRecordBytes;
             uint32_t value = 0, gap = pad_gap;
             if (si < p.slots) { const Slot s = delta_slot(p, keys, vals, bridges, si); value = s.val; gap = s.gap; }
-            reinterpret_cast<uint32_t*>(r)[l] = value;
-            reinterpret_cast<uint16_t*>(r + kWaveLanes * 4)[l] = uint16_t(gap);
+            *value_word = value;
+            *gap_word = uint16_t(gap);
         }
     }
 }

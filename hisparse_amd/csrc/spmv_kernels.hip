@@ -137,18 +137,20 @@ struct Ring<0> {   // PAIRS: one dwordx2 per lane and step
     }
 };
 template <>
-struct Ring<1> {    // DELTA: the value dword and the 16-bit gap of this lane
-    static constexpr uint32_t kLaneBytes = 4;
+struct Ring<1> {    // DELTA: a record = two slots per lane: {value A, value B} as one dwordx2, {gap A, gap B} as one dword
+    static constexpr uint32_t kLaneBytes = 8;
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
-        asm volatile("s_nop 4\n\tglobal_load_dword a[%0], %2, %4 nt\n\tglobal_load_ushort a[%1], %3, %4 offset:256 nt" ::"n"(K),
+        static_assert(2 * K + 1 < kMaxDepth && K + kMaxDepth < 2 * kMaxDepth, "values in a0..a15, gap words in a16..a23: ring depth <= 8");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %3, %5 nt\n\tglobal_load_dword a[%2], %4, %5 offset:512 nt" ::"n"(2 * K), "n"(2 * K + 1),
                      "n"(K + kMaxDepth), "v"(byte_off + lane_off), "v"(byte_off + lane_off / 2), "s"(base)
                      : "memory", HS_RING_AGPRS);
     }
+    // value A, value B, gaps (A in the low half, B in the high half)
     template <int K, int kDepth>
-    static __device__ __forceinline__ void take(uint32_t& value, uint32_t& gap) {
-        asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a[%2]\n\tv_accvgpr_read_b32 %1, a[%3]"
-                     : "=v"(value), "=v"(gap) : "n"(K), "n"(K + kMaxDepth), "n"(2 * (kDepth - 1)) : "memory");
+    static __device__ __forceinline__ void take_record(uint32_t& value_a, uint32_t& value_b, uint32_t& gaps) {
+        asm volatile("s_waitcnt vmcnt(%6)\n\tv_accvgpr_read_b32 %0, a[%3]\n\tv_accvgpr_read_b32 %1, a[%4]\n\tv_accvgpr_read_b32 %2, a[%5]"
+                     : "=v"(value_a), "=v"(value_b), "=v"(gaps) : "n"(2 * K), "n"(2 * K + 1), "n"(K + kMaxDepth), "n"(2 * (kDepth - 1)) : "memory");
     }
 };
 template <>
@@ -251,46 +253,51 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
         c.xb = c.xs + c.slot * kSubTileCols;
         c.head = true;
     }
-    uint32_t mat, aux;                 // value word; PAIRS: row << 16 | col, DELTA: gap
-    Ring<kRing>::template take<K, kDepth>(mat, aux);
-    if (kDelta) {
-        // A lane owns a run of consecutive slots of the position-sorted unit.  The head record of every (unit, wavefront)
-        // gives each lane its absolute start position (local_row * 8192 + local_col); every following record carries one
-        // value word and one 16-bit gap per lane.  No per-lane branch: a bridge slot (gap 0xffff, value 0) advances 65535
-        // and adds 0 at a valid row of the block; fixed-point padding is (gap 0, value 0); float padding is a bridge whose
-        // row is clamped to the spare accumulator ys[nrows] (0 * x could be NaN for a non-finite x, so float bridge slots
-        // add a literal 0).
-        if (c.head) {                  // wave-uniform
-            c.pos = mat;
-            c.head = false;
-        } else {
-            c.pos += aux;
+    uint32_t mat, aux;                 // value word; PAIRS: row << 16 | col
+    if constexpr (kDelta) {
+        // A lane owns a run of consecutive slots of the position-sorted unit.  The head slot of every (unit, wavefront) -- slot A of
+        // its first record -- gives each lane its absolute start position (local_row * 8192 + local_col); every following slot carries
+        // one value word and one 16-bit gap.  No per-lane branch: a bridge slot (gap 0xffff, value 0) advances 65535 and adds 0 at a
+        // valid row of the block; fixed-point padding is (gap 0, value 0); float padding is a bridge whose row is clamped to the
+        // spare accumulator ys[nrows] (0 * x could be NaN for a non-finite x, so float bridge slots add a literal 0).
+        uint32_t value_a, value_b, gaps;
+        Ring<1>::template take_record<K, kDepth>(value_a, value_b, gaps);
+        auto slot = [&](uint32_t value, uint32_t gap) {
+            c.pos += gap;
             uint32_t row = c.pos / kSubTileCols;
             const uint32_t col = c.pos % kSubTileCols;
             if (kAblate & 1) {
-                asm volatile("" ::"v"(row), "v"(mat));
-            } else {
-                const uint32_t xv = (kAblate & 2) ? col : c.xb[col];
-                typename R::prod_t prod = R::product(mat, xv);
-                if (kFloat) {
-                    if (aux == kBridgeGap) prod = 0;
-                    row = min(row, c.nrows);
-                }
-                if (kDense) {
-                    // Dense rows: a lane's run of consecutive sorted elements stays on one row for many steps (and the lanes
-                    // of one instruction would collide on the few rows there are): sum in a register, touch LDS on row changes.
-                    if (row != c.lane_row) {       // per lane (exec-masked)
-                        R::add_sum(c.ys, c.lane_row, c.lane_sum);
-                        c.lane_row = row;
-                        c.lane_sum = 0;
-                    }
-                    c.lane_sum += R::widen(prod);
-                } else {
-                    R::add(c.ys, row, prod);
-                }
+                asm volatile("" ::"v"(row), "v"(value));
+                return;
             }
+            const uint32_t xv = (kAblate & 2) ? col : c.xb[col];
+            typename R::prod_t prod = R::product(value, xv);
+            if (kFloat) {
+                if (gap == kBridgeGap) prod = 0;
+                row = min(row, c.nrows);
+            }
+            if (kDense) {
+                // Dense rows: a lane's run of consecutive sorted elements stays on one row for many steps (and the lanes
+                // of one instruction would collide on the few rows there are): sum in a register, touch LDS on row changes.
+                if (row != c.lane_row) {       // per lane (exec-masked)
+                    R::add_sum(c.ys, c.lane_row, c.lane_sum);
+                    c.lane_row = row;
+                    c.lane_sum = 0;
+                }
+                c.lane_sum += R::widen(prod);
+            } else {
+                R::add(c.ys, row, prod);
+            }
+        };
+        if (c.head) {                  // wave-uniform: slot A is the head
+            c.pos = value_a;
+            c.head = false;
+        } else {
+            slot(value_a, gaps & 0xffffu);
         }
+        slot(value_b, gaps >> 16);
     } else {
+        Ring<kRing>::template take<K, kDepth>(mat, aux);
         const uint32_t xv = (kAblate & 2) ? aux : c.xb[aux & kColMask];
         if (kAblate & 1) {
             asm volatile("" ::"v"(xv), "v"(mat));
@@ -740,7 +747,7 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t
 // (float, delta, ablate, depth): the product variants first, then the profiling builds (fixed point only)
 #define HS_FOR_EACH_VARIANT(X)                                                                                   \
     X(true, 0, 0, 8) X(true, 1, 0, 8) X(false, 0, 0, 8) X(false, 1, 0, 8) X(true, 2, 0, 8) X(false, 2, 0, 8)         \
-    X(false, false, 0, 16) X(false, true, 0, 16) X(false, false, 3, 8) X(false, true, 3, 8)                       \
+    X(false, false, 0, 16) X(false, false, 3, 8) X(false, true, 3, 8)                       \
     X(false, false, 4, 8) X(false, true, 4, 8) X(false, false, 8, 8) X(false, true, 8, 8) X(false, false, 15, 8) X(false, true, 15, 8) X(false, false, 31, 8) X(false, true, 31, 8)                     \
     X(false, false, 47, 8) X(false, true, 47, 8) X(false, false, 79, 8) X(false, true, 79, 8)                     \
     X(false, false, 127, 8) X(false, true, 127, 8)                                                                 \

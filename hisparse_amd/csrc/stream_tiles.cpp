@@ -397,7 +397,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             slots += up.slots;
             const uint64_t pairs_chunks = (uint64_t(up.n) + kWaveLanes - 1) / kWaveLanes, records = (up.slots + kWaveLanes - 1) / kWaveLanes;
             pairs_bytes += pairs_chunks * kChunkBytes;
-            delta_bytes += (records + std::min<uint64_t>(records, kConsumerWaves)) * kRecordBytes;      // + one head per wavefront with records
+            // slots + one head per wavefront with work, in records of two slots (a run's last record is half empty every other time)
+            delta_bytes += (records + std::min<uint64_t>(records, kConsumerWaves) * 3 / 2) * (kRecordBytes / 2);
         }
         const uint64_t min_saved = is_float ? kDeltaMinSavedBytesFloat : kDeltaMinSavedBytes;
         if (double(slots) > 1.02 * double(out.nnz) || pairs_bytes < delta_bytes + min_saved) {
@@ -488,7 +489,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                 first += uint64_t(run[w]) * kWaveLanes;
                 up.start_step[w] = up.start_record[w] = pos[w];
                 // DELTA: one head record (absolute positions) in front of the wavefront's records of this unit
-                pos[w] += delta ? (run[w] ? run[w] + 1 : 0) : run[w];
+                pos[w] += delta ? (run[w] ? (run[w] + 2) / 2 : 0) : run[w];      // DELTA: records of two slots, the head is the first slot
                 out.units[u].end_step[w] = pos[w];
             }
             out.elements += uint64_t(chunks) * kWaveLanes;
@@ -622,17 +623,20 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         for (uint32_t w = 0; w < kConsumerWaves; ++w) {
             if (!up.run_len[w]) continue;
             uint8_t* rec = image + blk.wave_offset[w] + uint64_t(up.start_record[w]) * kRecordBytes;
-            uint32_t* head = reinterpret_cast<uint32_t*>(rec);
+            // slot q of the run (q = 0: the head) sits in record q / 2, half q % 2: value word at (2 lane + half) * 4, gap at 512 + lane * 4 + half * 2
+            auto value_at = [&](uint32_t q, uint32_t l) -> uint32_t& { return reinterpret_cast<uint32_t*>(rec + uint64_t(q / 2) * kRecordBytes)[2 * l + q % 2]; };
+            auto gap_at = [&](uint32_t q, uint32_t l) -> uint16_t& { return reinterpret_cast<uint16_t*>(rec + uint64_t(q / 2) * kRecordBytes + kWaveLanes * 8)[2 * l + q % 2]; };
+            const uint32_t slots_in_records = (up.run_len[w] + 2) / 2 * 2;      // head + run, rounded up to whole records
             for (uint32_t l = 0; l < kWaveLanes; ++l) {
                 const uint64_t s0 = up.first_slot[w] + uint64_t(l) * up.run_len[w];
                 // position BEFORE the run's first slot; slot 0 carries gap 0 from the first element's own position
-                head[l] = s0 >= up.slots ? scratch_pos : (s0 == 0 ? uint32_t(e[0] >> 32) : after[s0 - 1]);
+                value_at(0, l) = s0 >= up.slots ? scratch_pos : (s0 == 0 ? uint32_t(e[0] >> 32) : after[s0 - 1]);
                 for (uint32_t j = 0; j < up.run_len[w]; ++j) {
-                    uint8_t* r = rec + uint64_t(j + 1) * kRecordBytes;
                     const uint64_t si = s0 + j;
-                    reinterpret_cast<uint32_t*>(r)[l] = si < up.slots ? val[si] : 0u;
-                    reinterpret_cast<uint16_t*>(r + kWaveLanes * 4)[l] = si < up.slots ? gap[si] : pad_gap;   // padding: see consume_block
+                    value_at(j + 1, l) = si < up.slots ? val[si] : 0u;
+                    gap_at(j + 1, l) = si < up.slots ? gap[si] : pad_gap;   // padding: see consume_block
                 }
+                for (uint32_t q = up.run_len[w] + 1; q < slots_in_records; ++q) gap_at(q, l) = pad_gap;      // the dead slot of an odd run
             }
         }
     });

@@ -84,7 +84,12 @@ constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
 constexpr uint32_t kWaveStrideBytes = kChunkBytes * kConsumerWaves;   // chunks of the 14 wavefronts are interleaved in memory
 // DELTA format
-constexpr uint32_t kRecordBytes = kWaveLanes * (4 + 2);       // one wavefront step: 64 x u32 value words, then 64 x u16 gaps
+// One DELTA record = TWO consecutive slots of every lane: 64 x {u32 value A, u32 value B} (one dwordx2 per lane), then 64 x {u16 gap A,
+// u16 gap B} (one dword per lane): two loads per two slots -- the 384-byte single-slot records of round 1 took four (dword + ushort
+// per slot), and the consumer ring is bound by requests, not bytes (profiles/r02_record_stream_bench.txt: 6.76 against 6.39 TB/s in
+// isolation).  A (unit, wavefront) run = its head (slot A of the first record: absolute start positions) + run_len slots, padded to
+// an even slot count with one dead slot (value 0; gap 0 in fixed point, a bridge in the float modes).
+constexpr uint32_t kRecordBytes = kWaveLanes * 2 * (4 + 2);
 constexpr uint32_t kMaxGap = 0xfffeu;                         // largest position gap an element slot can carry
 constexpr uint32_t kBridgeGap = 0xffffu;                      // gap code of a slot without element ...
 constexpr uint32_t kBridgeAdvance = 0xffffu;                  // ... which advances the position by this much

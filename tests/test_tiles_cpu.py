@@ -90,11 +90,12 @@ def test_structure_invariants(stream_format):
         assert len(t["image"]) == t["elements"] * (8 if stream_format == "pairs" else 7)
         assert t["elements"] - t["nnz"] < 64 * len(units)
     else:
-        # bytes: 384 per record = 64 x (u32 value + u16 gap); one head record per (unit, wavefront) that has work
+        # bytes: 768 per record = two slots per lane, 64 x (2 x u32 value + 2 x u16 gap); per (unit, wavefront) that has work one head slot
+        # and, when that makes the slot count odd, one dead slot
         records = sum(int(units["end_step"][b["unit_end"] - 1].sum()) for b in blocks if b["unit_end"] > b["unit_begin"])
-        assert len(t["image"]) == records * 384
-        heads = records - t["elements"] // 64
-        assert 0 < heads <= 14 * len(units)
+        assert len(t["image"]) == records * 768
+        extra = 2 * records - t["elements"] // 64           # head + dead slots
+        assert 0 < extra <= 2 * 14 * len(units)
     # balance: no workgroup carries more than ~1.5x the mean (power-law rows, 64 groups)
     loads = []
     for g in range(t["num_workgroups"]):

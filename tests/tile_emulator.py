@@ -7,7 +7,7 @@ import numpy as np
 
 WAVE, CONSUMERS, SUB_TILE = 64, 14, 8192
 CHUNK_BYTES = 512            # PAIRS: 64 x {u32 value, u32 row << 16 | col}
-RECORD_BYTES = 384           # DELTA: 64 x u32 value, then 64 x u16 gap
+RECORD_BYTES = 768           # DELTA: two slots per lane: 64 x {u32 value A, u32 value B}, then 64 x {u16 gap A, u16 gap B}
 BRIDGE = 0xFFFF
 
 
@@ -67,30 +67,33 @@ def _block_delta(image, blk, units, x_words, ys, is_float):
         for w in range(CONSUMERS):
             end = int(unit["end_step"][w])
             base = int(blk["wave_offset"][w])
-            assert end >= step[w] and end != step[w] + 1              # a (unit, wavefront) has no records, or head + >= 1
+            assert end >= step[w]                                      # a (unit, wavefront) has no records, or head + >= 1 slots
             pos = None
             for s in range(step[w], end):
                 rec = image[base + s * RECORD_BYTES: base + (s + 1) * RECORD_BYTES]
-                val = rec[:WAVE * 4].view(np.uint32)
-                gap = rec[WAVE * 4:].view(np.uint16).astype(np.int64)
-                if pos is None:                                         # head record: absolute start position per lane
-                    pos = val.astype(np.int64)
-                    assert (pos <= nrows * SUB_TILE).all()
-                    continue
-                pos = (pos + gap) & 0xFFFFFFFF                          # u32 arithmetic like the kernel
-                row, col = pos >> 13, pos & (SUB_TILE - 1)
-                live = gap != BRIDGE
-                if is_float:
-                    # bridge slots add a literal zero at min(row, nrows); live slots must be real positions
-                    assert (row[live] < nrows).all() and (col[live] < ncols).all()
-                    _accumulate(ys, True, row[live], val[live], xt[col[live]])
-                else:
-                    # no live test in the fixed-point kernel: every slot multiplies; dead slots carry value 0 and must
-                    # still aim at an accumulator of the block (or the spare one)
-                    assert (row <= nrows).all() and (val[~live] == 0).all()
-                    real = live & (val != 0)
-                    assert (row[real] < nrows).all() and (col[real] < ncols).all()
-                    _accumulate(ys, False, row, val, xt[col])
+                vals = rec[:WAVE * 8].view(np.uint32).reshape(WAVE, 2)
+                gaps = rec[WAVE * 8:].view(np.uint16).reshape(WAVE, 2).astype(np.int64)
+                for half in (0, 1):
+                    val, gap = vals[:, half], gaps[:, half]
+                    if pos is None:                                     # head slot (slot A of the run's first record): absolute start position per lane
+                        assert half == 0
+                        pos = val.astype(np.int64)
+                        assert (pos <= nrows * SUB_TILE).all()
+                        continue
+                    pos = (pos + gap) & 0xFFFFFFFF                      # u32 arithmetic like the kernel
+                    row, col = pos >> 13, pos & (SUB_TILE - 1)
+                    live = gap != BRIDGE
+                    if is_float:
+                        # bridge slots add a literal zero at min(row, nrows); live slots must be real positions
+                        assert (row[live] < nrows).all() and (col[live] < ncols).all()
+                        _accumulate(ys, True, row[live], val[live], xt[col[live]])
+                    else:
+                        # no live test in the fixed-point kernel: every slot multiplies; dead slots carry value 0 and must
+                        # still aim at an accumulator of the block (or the spare one)
+                        assert (row <= nrows).all() and (val[~live] == 0).all()
+                        real = live & (val != 0)
+                        assert (row[real] < nrows).all() and (col[real] < ncols).all()
+                        _accumulate(ys, False, row, val, xt[col])
             step[w] = end
 
 
