@@ -36,12 +36,12 @@
 //       throughput definition (sw/benchmark.cpp:312-314) plus < 2 % chunk padding.
 //
 //     DELTA (6 bytes per slot): lane l of wavefront w owns run_len consecutive slots of the sorted unit.
-//       A 384-byte record = 64 x u32 value words followed by 64 x u16 GAPS: the distance from the lane's
-//       previous position.  Every (unit, wavefront) starts with a HEAD record whose value words are the
-//       lanes' absolute start positions.  Gap 0xffff = BRIDGE: no element, advance 65535 (value word 0);
+//       A slot = a u32 value word + a u16 GAP: the distance from the lane's previous position.  A 768-byte record holds TWO
+//       consecutive slots of every lane (kRecordBytes below).  Every (unit, wavefront) run starts with a HEAD slot whose value
+//       words are the lanes' absolute start positions.  Gap 0xffff = BRIDGE: no element, advance 65535 (value word 0);
 //       it carries a lane across distances that do not fit 16 bits and pads the float formats' tails
 //       (fixed-point tails are padded with gap 0 / value 0).  Each wavefront's records are contiguous.
-//       On ogbl-ppa this is 6.6 bytes per non-zero all in (heads, bridges, padding) instead of 8.03.
+//       On ogbl-ppa this is 6.85 bytes per non-zero all in (heads, bridges, padding, dead slots) instead of 8.03.
 //
 //     DELTA is tried when the mean position gap rows*cols/nnz lies in [kDeltaMinMeanGap, kDeltaMaxMeanGap] (hyper-sparse matrices
 //     would need a bridge for every other gap) and kept when, after the sort, it needs at most 2 % bridge slots AND saves more
