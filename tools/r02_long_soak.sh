@@ -3,8 +3,8 @@
 # device-built image against the host builder's), then the repeated-run soak on the headline matrix.
 mkdir -p gpurun_out
 : > gpurun_out/r02_long_soak.log
-timeout 1200 python tests/gpu_fuzz_soak.py 600 101 2>&1 | tail -6 >> gpurun_out/r02_long_soak.log
-FUZZ_PROFILE=large timeout 1200 python tests/gpu_fuzz_soak.py 200 102 2>&1 | tail -6 >> gpurun_out/r02_long_soak.log
-FUZZ_PROFILE=dense timeout 1200 python tests/gpu_fuzz_soak.py 200 103 2>&1 | tail -6 >> gpurun_out/r02_long_soak.log
+timeout 1200 python tests/gpu_fuzz_soak.py 600 201 2>&1 | tail -6 >> gpurun_out/r02_long_soak.log
+FUZZ_PROFILE=large timeout 1200 python tests/gpu_fuzz_soak.py 200 202 2>&1 | tail -6 >> gpurun_out/r02_long_soak.log
+FUZZ_PROFILE=dense timeout 1200 python tests/gpu_fuzz_soak.py 200 203 2>&1 | tail -6 >> gpurun_out/r02_long_soak.log
 timeout 600 python tests/gpu_soak_ppa.py 2>&1 | tail -6 >> gpurun_out/r02_long_soak.log
 cat gpurun_out/r02_long_soak.log
