@@ -6,6 +6,7 @@
 // group) becomes a 64-bit occupancy mask plus its compacted values.
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <numeric>
 
 #include "hisparse/q8_24.h"
@@ -34,7 +35,8 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     std::vector<uint64_t> row_ptr(size_t(num_rows) + 1, 0);
     for (uint32_t r = 0; r < num_rows; ++r) row_ptr[r + 1] = row_ptr[r] + row_nnz[r];
     const uint64_t nnz = row_ptr[num_rows];
-    std::vector<uint64_t> elems(nnz);                       // column << 32 | value word: sorts by column
+    const std::unique_ptr<uint64_t[]> elems_buf(new uint64_t[std::max<uint64_t>(nnz, 1)]);   // (not zeroed: every entry is written below)
+    uint64_t* const elems = elems_buf.get();               // column << 32 | value word: sorts by column
     if (csr) {       // the rows are there already; value words as csr_matrix_convert_from_float gives them (sw/data_loader.h:76-84)
         const bool fixed = L.g->impl == IMPL_FIXED;
         std::atomic<bool> bad_column(false);
@@ -51,16 +53,20 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         if (bad_column) { error = "CSR column index outside the matrix"; return false; }
     } else {
         std::vector<uint32_t> cursor(num_rows, 0);
-        std::vector<WalkResult> res(size_t(RP) * NUM_HBM_CHANNELS);
-        // rows of different physical channels are disjoint, and one task takes the column partitions of its rows in ascending
-        // order: a row's elements arrive in the order the CSR input had them (sw/data_formatter.h:256-313 keeps it)
+        // (a task per packet lane re-reads the packets eight times: only where there are more hardware threads than channel tasks)
+        // (HISPARSE_WALK_LANES=0|1 forces, for the tests)
+        const char* force_split = env_switch("HISPARSE_WALK_LANES");
+        const uint32_t split = (force_split ? std::atoi(force_split) != 0 : std::thread::hardware_concurrency() > 2 * RP * NUM_HBM_CHANNELS) ? PACK_SIZE : 1;
+        std::vector<WalkResult> res(size_t(RP) * NUM_HBM_CHANNELS * split);
+        // rows of different physical channels and packet lanes are disjoint, and one task takes the column partitions of its rows in
+        // ascending order: a row's elements arrive in the order the CSR input had them (sw/data_formatter.h:256-313 keeps it)
         parallel_for(res.size(), [&](size_t w) {
-            const uint32_t rp = uint32_t(w / NUM_HBM_CHANNELS), pc = uint32_t(w % NUM_HBM_CHANNELS);
+            const uint32_t lane = uint32_t(w % split), pc = uint32_t(w / split % NUM_HBM_CHANNELS), rp = uint32_t(w / split / NUM_HBM_CHANNELS);
             for (uint32_t cp = 0; cp < CP && res[w].ok; ++cp) {
                 const uint64_t col_base = uint64_t(cp) * L.g->logical_vb;
                 WalkResult r = walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t val) {
                     elems[row_ptr[row] + cursor[row]++] = ((col_base + col) << 32) | val;
-                });
+                }, split > 1 ? int(lane) : -1);
                 if (!r.ok) res[w] = r;
             }
         });
@@ -72,7 +78,7 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     std::atomic<bool> duplicates(false);
     parallel_for((num_rows + 1023) / 1024, [&](size_t chunk) {
         for (uint32_t r = uint32_t(chunk) * 1024; r < std::min<uint64_t>(num_rows, (chunk + 1) * 1024); ++r) {
-            uint64_t* e = elems.data() + row_ptr[r];
+            uint64_t* e = elems + row_ptr[r];
             const uint32_t n = row_nnz[r];
             bool sorted = true;
             for (uint32_t i = 1; i < n && sorted; ++i) sorted = (e[i] >> 32) > (e[i - 1] >> 32);
@@ -119,7 +125,7 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         const uint64_t c0 = uint64_t(k) * GR / slices * kBitmapGroupCols, c1 = uint64_t(k + 1) * GR / slices * kBitmapGroupCols;
         uint64_t n = 0;
         for (uint32_t r = rg.row0; r < rg.row0 + rg.nrows; ++r) {
-            const uint64_t* e = elems.data() + row_ptr[r];
+            const uint64_t* e = elems + row_ptr[r];
             const uint64_t* lo = std::lower_bound(e, e + row_nnz[r], c0 << 32);
             const uint64_t* hi = std::lower_bound(e, e + row_nnz[r], c1 << 32);
             n += uint64_t(hi - lo);
@@ -148,7 +154,7 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         out.max_block_rows = std::max(out.max_block_rows, rg.nrows);
     }
     if (block_base[NB] / 4 >= (1ull << 40)) { error = "matrix too large for the bitmap image"; return false; }
-    out.image.assign(block_base[NB], 0);
+    resize_zeroed(out.image, block_base[NB]);
     out.image_bytes = block_base[NB];
     timer.lap("bitmap: plan");
 
@@ -182,7 +188,7 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         uint64_t at = 0;
         for (uint32_t lr = 0; lr < rg.nrows; ++lr) {
             value_at[lr] = at;
-            const uint64_t* e = elems.data() + row_ptr[rg.row0 + lr];
+            const uint64_t* e = elems + row_ptr[rg.row0 + lr];
             const uint32_t n = row_nnz[rg.row0 + lr];
             const uint64_t* p = std::lower_bound(e, e + n, c0 << 32);
             const uint64_t c1 = uint64_t(gs1) * kBitmapGroupCols;

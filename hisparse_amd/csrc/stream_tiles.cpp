@@ -540,7 +540,7 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         timer.lap("gpu: emit");
         return true;
     }
-    out.image.assign(image_bytes, 0);
+    resize_zeroed(out.image, image_bytes);
     out.image_bytes = image_bytes;
     uint8_t* image = out.image.data();
 

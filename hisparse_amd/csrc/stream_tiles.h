@@ -58,6 +58,8 @@
 
 #include <cstdint>
 #include <string>
+#include <memory>
+#include <utility>
 #include <vector>
 
 #include "hisparse/common.h"
@@ -189,8 +191,19 @@ static_assert(sizeof(Unit) == 8 + 4 * kConsumerWaves, "Unit layout is shared wit
 
 class GpuTiler;   // gpu_tiles.h
 
+// resize() leaves new bytes uninitialised: the builders zero-fill a few hundred MB from many threads (detail::resize_zeroed), which
+// also spreads the first-touch page faults a single-threaded assign() would take one after the other
+template <typename T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <typename U> struct rebind { using other = DefaultInitAllocator<U>; };
+    using std::allocator<T>::allocator;
+    template <typename U> void construct(U* p) { ::new (static_cast<void*>(p)) U; }
+    template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+using ImageBytes = std::vector<uint8_t, DefaultInitAllocator<uint8_t>>;
+
 struct StreamTiles {
-    std::vector<uint8_t> image;          // element streams, uploaded verbatim (host builder)
+    ImageBytes image;                    // element streams, uploaded verbatim (host builder)
     uint8_t* d_image = nullptr;          // GPU builder: the image, already in device memory (image_bytes + slack); the caller owns it
     uint64_t image_bytes = 0;
     std::vector<Block> blocks;

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -58,6 +59,15 @@ void parallel_for(size_t n, Fn fn) {
     for (auto& th : pool) th.join();
 }
 
+// v = n zero bytes, filled (and first touched) by many threads
+inline void resize_zeroed(ImageBytes& v, size_t n) {
+    v.clear();
+    v.resize(n);
+    constexpr size_t kPiece = size_t(2) << 20;
+    uint8_t* p = v.data();
+    parallel_for((n + kPiece - 1) / kPiece, [&](size_t i) { std::memset(p + i * kPiece, 0, std::min(kPiece, n - i * kPiece)); });
+}
+
 struct Layout {
     const Geometry* g;
     uint32_t num_rows, num_cols, row_parts, col_parts, F;
@@ -82,7 +92,7 @@ struct WalkResult {
 // Visit every non-zero of physical channel `pc` in partition (rp, cp): visit(absolute_row, partition_local_col, value_word).
 template <typename Visit>
 WalkResult walk_channel_partition(const Layout& L, const MatPkt* buf, uint64_t n_pkts, uint32_t pc, uint32_t rp, uint32_t cp,
-                                  Visit visit) {
+                                  Visit visit, int only_lane = -1) {
     WalkResult res;
     const uint32_t F = L.F;
     const uint32_t parts = L.row_parts * L.col_parts;
@@ -115,6 +125,7 @@ WalkResult walk_channel_partition(const Layout& L, const MatPkt* buf, uint64_t n
         const MatPkt* pkt = buf + payload_base + start + f;
         for (uint32_t p = 0; p < longest; ++p, pkt += F) {
             for (uint32_t k = 0; k < PACK_SIZE; ++k) {
+                if (only_lane >= 0 && k != uint32_t(only_lane)) continue;   // one task per lane stream (rows r % 8 == k are disjoint)
                 if (p >= lens.data[k]) continue;               // lane exhausted: zero padding
                 const uint32_t col = pkt->indices.data[k], val = pkt->vals.data[k];
                 if (col == IDX_MARKER) {

@@ -309,6 +309,22 @@ def test_bitmap_structure_and_parity(impl, rows, cols, density, wgs, monkeypatch
     assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
 
 
+@pytest.mark.parametrize("impl,ob,rows,cols", [(0, 8192, 700, 5000), (1, 1024, 300, 9000), (2, 8192, 1500, 4100)])
+def test_bitmap_walk_by_lane_gives_the_same_image(impl, ob, rows, cols, monkeypatch):
+    """The host BITMAP builder decodes the CPSR image with one task per (channel, packet lane) on hosts with many threads and one per
+    channel otherwise: same image, Block[] and run headers either way (column partitions of a row still arrive in ascending order)."""
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "bitmap")
+    m = cases.random_csr(rows, cols, 0.3, 77, impl)
+    _, cp = cases.formatted(m, impl, 256, ob, True)      # 2048 columns per column partition
+    built = []
+    for lanes in ("0", "1"):
+        monkeypatch.setenv("HISPARSE_WALK_LANES", lanes)
+        built.append(build(cp, impl, 64))
+    a, b = built
+    assert a["format"] == "bitmap" and cp.num_col_partitions > 1
+    assert np.array_equal(a["image"], b["image"]) and a["blocks"].tobytes() == b["blocks"].tobytes() and a["units"].tobytes() == b["units"].tobytes()
+
+
 def test_bitmap_choice_unsorted_rows_and_duplicates(monkeypatch):
     import scipy.sparse as sp
     monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
