@@ -402,3 +402,13 @@ def test_empty_environment_switches_count_as_unset(monkeypatch):
         monkeypatch.setenv(name, "")
     got = build(cp, 0, 32)
     assert got["format"] == want["format"] and np.array_equal(got["image"], want["image"]) and got["blocks"].tobytes() == want["blocks"].tobytes()
+
+
+def test_worker_pool(tmp_path):
+    """parallel_for of the load-time builders runs on parked worker threads (tiles_common.h: WorkerPool): tests/cpp/test_worker_pool.cpp."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "worker_pool"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", f"-I{root}/include", f"-I{root}/hisparse_amd/csrc", f"{root}/tests/cpp/test_worker_pool.cpp", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "WORKER POOL OK" in out.stdout, out.stdout + out.stderr
