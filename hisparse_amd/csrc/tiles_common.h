@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include "hisparse/worker_pool.h"
 #include "stream_tiles.h"
 
 namespace hisparse {
@@ -45,121 +46,10 @@ struct PhaseTimer {   // HISPARSE_PLAN_DEBUG=1: wall time of the load-time passe
     }
 };
 
-// The library's worker threads: started once (first parallel_for of the process), parked on a condition variable between jobs.
-// Starting and joining 255 std::threads per loop cost 5-8 ms on the 256-thread host of the GPU box -- more than most of the loops
-// they ran (the BITMAP builder has six of them).  One job at a time: a second caller (another context loading on another
-// thread) or a task that calls parallel_for itself gets `false` and runs the loop with threads of its own / inline.  The caller
-// works through the indices as well, so a job completes even when the workers are gone (a forked child).
-class WorkerPool {
-  public:
-    static WorkerPool& get() {
-        static WorkerPool pool;
-        return pool;
-    }
-    bool run(size_t n, void (*call)(void*, size_t), void* ctx) {
-        if (in_task()) return false;
-        std::unique_lock<std::mutex> lk(m_);
-        if (busy_) return false;
-        busy_ = true;
-        if (!started_) {
-            started_ = true;
-            const unsigned hw = std::thread::hardware_concurrency();
-            for (unsigned t = 1; t < std::min(hw, 256u); ++t) threads_.emplace_back([this]() { worker(); });
-        }
-        idle_.wait(lk, [&]() { return active_ == 0; });
-        call_ = call; ctx_ = ctx; n_ = n; finished_ = 0; failure_ = nullptr;
-        next_.store(0);
-        ++generation_;
-        lk.unlock();
-        wake_.notify_all();
-        const size_t mine = drain(n, call, ctx);
-        lk.lock();
-        finished_ += mine;
-        idle_.wait(lk, [&]() { return finished_ == n_ && active_ == 0; });
-        call_ = nullptr; n_ = 0; busy_ = false;
-        std::exception_ptr failure = failure_;
-        failure_ = nullptr;
-        lk.unlock();
-        if (failure) std::rethrow_exception(failure);
-        return true;
-    }
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
-        }
-        wake_.notify_all();
-        for (auto& th : threads_) th.join();
-    }
-
-  private:
-    static bool& in_task() {
-        static thread_local bool flag = false;
-        return flag;
-    }
-    // takes indices until they run out; an exception of a task is kept (the first one) and the remaining indices are still counted
-    size_t drain(size_t n, void (*call)(void*, size_t), void* ctx) {
-        size_t done = 0;
-        in_task() = true;
-        for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1), ++done) {
-            try {
-                call(ctx, i);
-            } catch (...) {
-                std::lock_guard<std::mutex> lk(failure_m_);
-                if (!failure_) failure_ = std::current_exception();
-            }
-        }
-        in_task() = false;
-        return done;
-    }
-    void worker() {
-        uint64_t seen = 0;
-        std::unique_lock<std::mutex> lk(m_);
-        for (;;) {
-            wake_.wait(lk, [&]() { return stop_ || generation_ != seen; });
-            if (stop_) return;
-            seen = generation_;
-            if (!call_) continue;            // woke up after the job was over
-            void (*call)(void*, size_t) = call_;
-            void* ctx = ctx_;
-            const size_t n = n_;
-            ++active_;
-            lk.unlock();
-            const size_t mine = drain(n, call, ctx);
-            lk.lock();
-            finished_ += mine;
-            if (--active_ == 0) idle_.notify_all();
-        }
-    }
-    std::mutex m_, failure_m_;
-    std::condition_variable wake_, idle_;
-    std::vector<std::thread> threads_;
-    bool started_ = false, stop_ = false, busy_ = false;
-    uint64_t generation_ = 0;
-    void (*call_)(void*, size_t) = nullptr;
-    void* ctx_ = nullptr;
-    size_t n_ = 0, finished_ = 0;
-    unsigned active_ = 0;
-    std::atomic<size_t> next_{0};
-    std::exception_ptr failure_;
-};
-
 template <typename Fn>
 void parallel_for(size_t n, Fn fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    unsigned threads = unsigned(std::min<size_t>(hw ? hw : 1u, n));
-    if (threads <= 1) {
-        for (size_t i = 0; i < n; ++i) fn(i);
-        return;
-    }
-    if (WorkerPool::get().run(n, [](void* f, size_t i) { (*static_cast<Fn*>(f))(i); }, &fn)) return;
-    std::atomic<size_t> next(0);
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < threads; ++t)
-        pool.emplace_back([&]() {
-            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
-        });
-    for (auto& th : pool) th.join();
+    const unsigned hw = std::thread::hardware_concurrency();
+    hisparse::pooled_for(n, hw ? hw : 1u, fn);
 }
 
 // v = n zero bytes, filled (and first touched) by many threads

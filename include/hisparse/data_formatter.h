@@ -34,6 +34,7 @@
 
 #include "common.h"
 #include "data_loader.h"
+#include "worker_pool.h"
 #include "q8_24.h"
 
 namespace spmv {
@@ -73,21 +74,10 @@ inline unsigned format_threads() {
     return hw ? hw : 1u;
 }
 
-// run fn(i) for i in [0, n) on up to `threads` workers
+// run fn(i) for i in [0, n) on up to `threads` threads (worker_pool.h: parked workers, not a thread start per loop)
 template <typename Fn>
 inline void parallel_for(size_t n, unsigned threads, Fn fn) {
-    if (threads <= 1 || n <= 1) {
-        for (size_t i = 0; i < n; ++i) fn(i);
-        return;
-    }
-    std::atomic<size_t> next(0);
-    std::vector<std::thread> pool;
-    unsigned workers = unsigned(std::min<size_t>(threads, n));
-    for (unsigned t = 0; t < workers; ++t)
-        pool.emplace_back([&]() {
-            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
-        });
-    for (auto& th : pool) th.join();
+    hisparse::pooled_for(n, threads, fn);
 }
 
 }  // namespace detail

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "npz.h"
+#include "worker_pool.h"
 
 namespace spmv {
 namespace io {
@@ -104,14 +105,8 @@ CSRMatrix<data_type> csr_matrix_convert_from_float(CSRMatrix<float> const& in) {
     unsigned workers = std::thread::hardware_concurrency();
     if (const char* env = std::getenv("HISPARSE_FORMAT_THREADS")) workers = unsigned(std::max(1, std::atoi(env)));
     workers = unsigned(std::min<size_t>(std::max(1u, workers), n / 65536 + 1));
-    auto convert = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) out.adj_data[i] = data_type(in.adj_data[i]); };
-    if (workers <= 1) {
-        convert(0, n);
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < workers; ++t) pool.emplace_back(convert, n * t / workers, n * (t + 1) / workers);
-        for (auto& th : pool) th.join();
-    }
+    auto convert = [&](size_t t) { for (size_t i = n * t / workers; i < n * (t + 1) / workers; ++i) out.adj_data[i] = data_type(in.adj_data[i]); };
+    hisparse::pooled_for(workers, workers, convert);
     out.adj_indices = in.adj_indices;
     out.adj_indptr = in.adj_indptr;
     return out;
@@ -160,14 +155,8 @@ CSCMatrix<data_type> csc_matrix_convert_from_float(CSCMatrix<float> const& in) {
     unsigned workers = std::thread::hardware_concurrency();
     if (const char* env = std::getenv("HISPARSE_FORMAT_THREADS")) workers = unsigned(std::max(1, std::atoi(env)));
     workers = unsigned(std::min<size_t>(std::max(1u, workers), n / 65536 + 1));
-    auto convert = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) out.adj_data[i] = data_type(in.adj_data[i]); };
-    if (workers <= 1) {
-        convert(0, n);
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < workers; ++t) pool.emplace_back(convert, n * t / workers, n * (t + 1) / workers);
-        for (auto& th : pool) th.join();
-    }
+    auto convert = [&](size_t t) { for (size_t i = n * t / workers; i < n * (t + 1) / workers; ++i) out.adj_data[i] = data_type(in.adj_data[i]); };
+    hisparse::pooled_for(workers, workers, convert);
     out.adj_indices = in.adj_indices;
     out.adj_indptr = in.adj_indptr;
     return out;

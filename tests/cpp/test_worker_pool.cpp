@@ -27,6 +27,20 @@ int main() {
             }
         });
     for (auto& t : callers) t.join();
+    // a capped job uses at most that many threads (HISPARSE_FORMAT_THREADS)
+    {
+        std::mutex m;
+        std::vector<std::thread::id> seen;
+        auto note = [&](size_t) {
+            std::lock_guard<std::mutex> lk(m);
+            if (std::find(seen.begin(), seen.end(), std::this_thread::get_id()) == seen.end()) seen.push_back(std::this_thread::get_id());
+        };
+        for (int round = 0; round < 50; ++round) {
+            seen.clear();
+            hisparse::pooled_for(1000, 3, note);
+            assert(seen.size() <= 3);
+        }
+    }
     // nested
     std::atomic<int> inner(0);
     parallel_for(8, [&](size_t) { parallel_for(5, [&](size_t) { inner++; }); });
