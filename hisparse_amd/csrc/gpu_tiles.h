@@ -49,9 +49,9 @@ class GpuTiler {
                        const std::vector<detail::UnitPlan>& plans, bool& duplicates);
     // DELTA: slots (elements + bridges) of every unit
     bool delta_slots(std::vector<detail::UnitPlan>& plans);
-    // OWNER: plans[u].own_begin from the wavefront row boundaries of the unit's range
-    // (balanced: per unit, detail::balanced_owner_shares; otherwise the fixed row ownership of the 24-bit form)
-    bool owner_shares(std::vector<detail::UnitPlan>& plans, const std::vector<uint32_t>& wave_row, const std::vector<uint32_t>& range_of_unit, bool balanced);
+    // OWNER: plans[u].own_begin / own_row / own_last: every unit's elements cut into the 14 wavefronts' shares
+    // (detail::balanced_owner_shares; max_span = kOwnerShareRows for OWNER24, 0xffffffff otherwise)
+    bool owner_shares(std::vector<detail::UnitPlan>& plans, uint32_t max_span);
     // The image (image_bytes + slack, zero-filled first).  format: the final StreamFormat; block_of_unit / blocks: pre-reorder indices.
     bool emit(StreamFormat format, uint64_t image_bytes, uint64_t slack_bytes, const std::vector<detail::UnitPlan>& plans,
               const std::vector<uint32_t>& block_of_unit, const std::vector<Block>& blocks, bool is_float);

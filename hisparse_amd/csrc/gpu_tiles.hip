@@ -280,7 +280,7 @@ struct DevicePlan {        // what the emit kernels need of a UnitPlan + its blo
     uint32_t n, chunks, base, nrows, flags;
     uint32_t start_step[kConsumerWaves], run_len[kConsumerWaves];
     uint32_t own_begin[kConsumerWaves + 1];
-    uint32_t row_base[kConsumerWaves];     // OWNER24
+    uint32_t row_base[kConsumerWaves];     // OWNER24: first local row of the wavefront's share of this unit
 };
 
 __global__ __launch_bounds__(256) void unit_slots_kernel(const DevicePlan* __restrict__ plans, uint32_t nu, const uint64_t* __restrict__ bridges,
@@ -293,30 +293,23 @@ __global__ __launch_bounds__(256) void unit_slots_kernel(const DevicePlan* __res
     slots[u] = p.n + b;
 }
 
-__global__ __launch_bounds__(256) void owner_shares_kernel(const uint64_t* __restrict__ plan_start, const uint32_t* __restrict__ plan_n,
-                                                          const uint32_t* __restrict__ range_of_unit, const uint32_t* __restrict__ wave_row, uint32_t nu,
-                                                          const uint64_t* __restrict__ keys, uint32_t* __restrict__ own_begin) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nu * (kConsumerWaves + 1)) return;
-    const uint32_t u = t / (kConsumerWaves + 1), w = t % (kConsumerWaves + 1);
-    const uint64_t want = uint64_t(wave_row[size_t(range_of_unit[u]) * (kConsumerWaves + 1) + w]) << kOwnerColBits;
-    const uint64_t* e = keys + plan_start[u];
-    uint32_t lo = 0, hi = plan_n[u];
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) / 2;
-        if ((e[mid] & kPosMask) < want) lo = mid + 1; else hi = mid;
-    }
-    own_begin[t] = lo;
-}
-
+// per unit: own[u][0..14] = share boundaries, [15..28] = first local row of every share, [29..42] = its last local row
+constexpr uint32_t kShareWords = (kConsumerWaves + 1) + 2 * kConsumerWaves;
 __global__ __launch_bounds__(256) void owner_balanced_shares_kernel(const uint64_t* __restrict__ plan_start, const uint32_t* __restrict__ plan_n, uint32_t nu,
-                                                                   const uint64_t* __restrict__ keys, uint32_t* __restrict__ own_begin) {
+                                                                   const uint64_t* __restrict__ keys, uint32_t max_span, uint32_t* __restrict__ own) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nu) return;
     const uint64_t* e = keys + plan_start[u];
     uint32_t shares[kConsumerWaves + 1];
-    detail::balanced_owner_shares(plan_n[u], [&](uint32_t i) { return uint32_t((e[i] & kPosMask) >> kOwnerColBits); }, shares);
-    for (uint32_t w = 0; w <= kConsumerWaves; ++w) own_begin[size_t(u) * (kConsumerWaves + 1) + w] = shares[w];
+    auto row_of = [&](uint32_t i) { return uint32_t((e[i] & kPosMask) >> kOwnerColBits); };
+    detail::balanced_owner_shares(plan_n[u], row_of, shares, max_span);
+    uint32_t* out = own + size_t(u) * kShareWords;
+    for (uint32_t w = 0; w <= kConsumerWaves; ++w) out[w] = shares[w];
+    for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+        const bool any = shares[w + 1] > shares[w];
+        out[kConsumerWaves + 1 + w] = any ? row_of(shares[w]) : 0u;
+        out[2 * kConsumerWaves + 1 + w] = any ? row_of(shares[w + 1] - 1) : 0u;
+    }
 }
 
 template <bool k24>
@@ -355,24 +348,34 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(const DevicePlan* __res
     }
 }
 
-// OWNER: per wavefront share, slot (step s, lane l) holds element l * steps + s of the share; the position word IS the key's low bits
+// OWNER: per wavefront share, slot (step s, lane l) holds element l * steps + s of the share; the position word IS the key's low bits.
+// k24 (OWNER24, stream_tiles.h): step S of the wavefront's stream is slot S % 4 of its record S / 4 -- value word at lane * 16 + 4 j,
+// 24-bit position word (row relative to the share's first row) at 1024 + lane * 12 + 3 j.
 template <bool k24>
 __global__ __launch_bounds__(256) void emit_owner_kernel(const DevicePlan* __restrict__ plans, const uint64_t* __restrict__ keys,
                                                         const uint32_t* __restrict__ vals, uint8_t* __restrict__ image) {
     const DevicePlan& p = plans[blockIdx.x];
-    constexpr uint32_t kChunk = k24 ? kChunkBytes24 : kChunkBytes;
     for (uint32_t w = 0; w < kConsumerWaves; ++w) {
         const uint32_t steps = p.run_len[w], n = p.own_begin[w + 1] - p.own_begin[w];
         const uint64_t mine = p.start + p.own_begin[w];
-        uint8_t* base = image + p.wave_offset[w] + uint64_t(p.start_step[w]) * kChunk;
-        const uint32_t spare = k24 ? kOwnerSpareField : p.nrows + w;
+        uint8_t* stream = image + p.wave_offset[w];
         const uint32_t row_base = k24 ? p.row_base[w] : 0u;
         for (uint32_t idx = threadIdx.x; idx < steps * kWaveLanes; idx += blockDim.x) {
             const uint32_t st = idx / kWaveLanes, l = idx % kWaveLanes;
             const uint64_t i = uint64_t(l) * steps + st;
-            uint8_t* chunk = base + uint64_t(st) * kChunk;
-            if (i < n) put<k24>(chunk, l, vals[mine + i], uint32_t(keys[mine + i] & kPosMask) - (row_base << kOwnerColBits));
-            else put<k24>(chunk, l, 0u, spare << kOwnerColBits);
+            const uint32_t S = p.start_step[w] + st;
+            const uint32_t value = i < n ? vals[mine + i] : 0u;
+            if (k24) {
+                uint8_t* rec = stream + uint64_t(S / kOwnerRecordSteps) * kOwnerRecordBytes;
+                const uint32_t j = S % kOwnerRecordSteps;
+                const uint32_t where = i < n ? uint32_t(keys[mine + i] & kPosMask) - (row_base << kOwnerColBits) : kOwnerSpareField << kOwnerColBits;
+                reinterpret_cast<uint32_t*>(rec)[l * kOwnerRecordSteps + j] = value;
+                uint8_t* a = rec + kOwnerRecordValueBytes + (l * kOwnerRecordSteps + j) * 3;
+                a[0] = uint8_t(where); a[1] = uint8_t(where >> 8); a[2] = uint8_t(where >> 16);
+            } else {
+                reinterpret_cast<uint2*>(stream + uint64_t(S) * kChunkBytes)[l] =
+                    make_uint2(value, i < n ? uint32_t(keys[mine + i] & kPosMask) : (p.nrows + w) << kOwnerColBits);
+            }
         }
     }
 }
@@ -725,7 +728,7 @@ bool make_device_plans(const std::vector<UnitPlan>& plans, const std::vector<uin
         if (!blocks.empty()) {
             const Block& blk = blocks[block_of_unit[u]];
             d.nrows = blk.nrows; d.flags = blk.flags;
-            for (uint32_t w = 0; w < kConsumerWaves; ++w) { d.wave_offset[w] = blk.wave_offset[w]; d.row_base[w] = blk.pad[w]; }
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) { d.wave_offset[w] = blk.wave_offset[w]; d.row_base[w] = up.own_row[w]; }
         }
         for (uint32_t w = 0; w < kConsumerWaves; ++w) {
             d.first_slot[w] = up.first_slot[w]; d.start_step[w] = up.start_step[w]; d.run_len[w] = up.run_len[w]; d.own_begin[w] = up.own_begin[w];
@@ -767,28 +770,33 @@ bool GpuTiler::delta_slots(std::vector<UnitPlan>& plans) {
     return ok;
 }
 
-bool GpuTiler::owner_shares(std::vector<UnitPlan>& plans, const std::vector<uint32_t>& wave_row, const std::vector<uint32_t>& range_of_unit, bool balanced) {
+bool GpuTiler::owner_shares(std::vector<UnitPlan>& plans, uint32_t max_span) {
     const uint32_t nu = uint32_t(plans.size());
     if (!nu) return true;
     std::vector<uint64_t> start(nu);
     std::vector<uint32_t> count(nu);
     for (uint32_t u = 0; u < nu; ++u) { start[u] = plans[u].scratch; count[u] = plans[u].n; }
     uint64_t* d_start = nullptr;
-    uint32_t *d_n = nullptr, *d_range = nullptr, *d_wave_row = nullptr, *d_own = nullptr;
-    std::vector<uint32_t> own(size_t(nu) * (kConsumerWaves + 1));
-    bool ok = check(upload(&d_start, start, stream_), "upload") && check(upload(&d_n, count, stream_), "upload") && check(upload(&d_range, range_of_unit, stream_), "upload") &&
-              check(upload(&d_wave_row, wave_row, stream_), "upload") && check(hipMalloc(reinterpret_cast<void**>(&d_own), own.size() * 4), "hipMalloc");
+    uint32_t *d_n = nullptr, *d_own = nullptr;
+    std::vector<uint32_t> own(size_t(nu) * kShareWords);
+    bool ok = check(upload(&d_start, start, stream_), "upload") && check(upload(&d_n, count, stream_), "upload") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_own), own.size() * 4), "hipMalloc");
     if (ok) {
-        if (balanced) hipLaunchKernelGGL(owner_balanced_shares_kernel, dim3((nu + 255) / 256), dim3(256), 0, stream_, d_start, d_n, nu, d_keys_, d_own);
-        else hipLaunchKernelGGL(owner_shares_kernel, dim3(uint32_t((own.size() + 255) / 256)), dim3(256), 0, stream_, d_start, d_n, d_range, d_wave_row, nu, d_keys_, d_own);
-        ok = check(hipGetLastError(), "owner_shares_kernel") && check(hipMemcpyAsync(own.data(), d_own, own.size() * 4, hipMemcpyDeviceToHost, stream_), "read shares") &&
+        hipLaunchKernelGGL(owner_balanced_shares_kernel, dim3((nu + 255) / 256), dim3(256), 0, stream_, d_start, d_n, nu, d_keys_, max_span, d_own);
+        ok = check(hipGetLastError(), "owner_balanced_shares_kernel") && check(hipMemcpyAsync(own.data(), d_own, own.size() * 4, hipMemcpyDeviceToHost, stream_), "read shares") &&
              check(hipStreamSynchronize(stream_), "owner shares");
     }
-    for (void* p : {static_cast<void*>(d_start), static_cast<void*>(d_n), static_cast<void*>(d_range), static_cast<void*>(d_wave_row), static_cast<void*>(d_own)})
+    for (void* p : {static_cast<void*>(d_start), static_cast<void*>(d_n), static_cast<void*>(d_own)})
         if (p) (void)hipFree(p);
     if (ok)
-        for (uint32_t u = 0; u < nu; ++u)
-            for (uint32_t w = 0; w <= kConsumerWaves; ++w) plans[u].own_begin[w] = own[size_t(u) * (kConsumerWaves + 1) + w];
+        for (uint32_t u = 0; u < nu; ++u) {
+            const uint32_t* o = own.data() + size_t(u) * kShareWords;
+            for (uint32_t w = 0; w <= kConsumerWaves; ++w) plans[u].own_begin[w] = o[w];
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+                plans[u].own_row[w] = o[kConsumerWaves + 1 + w];
+                plans[u].own_last[w] = o[2 * kConsumerWaves + 1 + w];
+            }
+        }
     return ok;
 }
 

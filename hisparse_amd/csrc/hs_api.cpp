@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "hisparse/channel_packets.h"
 #include "hisparse/common.h"
 #include "spmv_kernels.h"
 #include "gpu_tiles.h"
@@ -294,8 +295,28 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
         // one 1024-thread workgroup per CU: its row accumulators and x ring fill the 160 KiB LDS
         bool ok = hisparse::dev::build_stream_tiles(channel, n_packets, g, num_rows, num_cols, num_row_partitions, num_col_partitions,
                                                     uint32_t(ctx->compute_units), tiles, why, ctx->stream, on_gpu, kImageSlackBytes, csr);
-        if (!ok && csr && why == "gpu re-tile: duplicate entries")
-            why = "the CSR matrix holds a (row, column) twice: format it with csr2cpsr and use hs_load_matrix";
+        if (!ok && csr && why == "gpu re-tile: duplicate entries") {
+            // A (row, column) that occurs twice is legal input for the reference's formatter (csr2cpsr keeps both entries and the PEs add
+            // both products), but the device sort has no defined order among equal positions.  Do what a reference driver does instead:
+            // format on the host (sw/benchmark.cpp:110-195) and hand the CPSR buffers to the host builder, like hs_load_matrix does for
+            // such a matrix.
+            if (tiles.d_image) (void)hipFree(tiles.d_image);
+            tiles = hisparse::dev::StreamTiles();
+            spmv::io::CSRMatrix<float> m;
+            m.num_rows = csr->num_rows;
+            m.num_cols = csr->num_cols;
+            const uint64_t nnz = csr->indptr[csr->num_rows];
+            m.adj_indptr.assign(csr->indptr, csr->indptr + csr->num_rows + 1);
+            m.adj_indices.assign(csr->indices, csr->indices + nnz);
+            m.adj_data.assign(csr->values, csr->values + nnz);
+            const hisparse::ChannelPackets packets = hisparse::format_matrix(m, g, /*skip_empty_rows=*/true);
+            const void* chan[hisparse::NUM_HBM_CHANNELS];
+            uint64_t count[hisparse::NUM_HBM_CHANNELS];
+            for (uint32_t c = 0; c < hisparse::NUM_HBM_CHANNELS; ++c) { chan[c] = packets.channel[c].data(); count[c] = packets.channel[c].size(); }
+            on_gpu = false;
+            ok = packets.num_rows == num_rows && packets.num_cols == num_cols &&
+                 hisparse::dev::build_stream_tiles(chan, count, g, num_rows, num_cols, num_row_partitions, num_col_partitions, uint32_t(ctx->compute_units), tiles, why);
+        }
         if (!ok && !csr && on_gpu && why.rfind("gpu re-tile:", 0) == 0) {       // duplicates, or a HIP failure on the way: the host path decides
             if (tiles.d_image) (void)hipFree(tiles.d_image);
             tiles = hisparse::dev::StreamTiles();
@@ -307,6 +328,12 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     } catch (const std::bad_alloc&) {
         if (tiles.d_image) (void)hipFree(tiles.d_image);
         return fail(ctx, HS_ERR_NO_MEMORY, "out of host memory while re-tiling the matrix");
+    } catch (const std::exception& e) {      // whatever a builder task threw (WorkerPool rethrows it): never through the C ABI
+        if (tiles.d_image) (void)hipFree(tiles.d_image);
+        return fail(ctx, HS_ERR_BAD_MATRIX, std::string("re-tiling the matrix failed: ") + e.what());
+    } catch (...) {
+        if (tiles.d_image) (void)hipFree(tiles.d_image);
+        return fail(ctx, HS_ERR_BAD_MATRIX, "re-tiling the matrix failed");
     }
     const bool debug = std::getenv("HISPARSE_PLAN_DEBUG") != nullptr;
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };

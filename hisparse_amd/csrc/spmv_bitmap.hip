@@ -16,8 +16,11 @@
 // returns 0 without touching memory, the x read of the last (partial) group is range-checked the same way, and so are mask reads
 // past the end of a run -- the whole inner loop is branch-free straight-line code, which is what lets hipcc count its own
 // s_waitcnt vmcnt (16 loads of the next batch stay in flight while a batch is consumed).
-// Numerics identical to spmv_kernels.hip: Q8.24 products rounded/saturated one by one and summed exactly in 64 bits; float
-// products (one fp32 multiply, no FMA) summed in double, rounded once per row and column slice.
+// Numerics: Q8.24 products rounded/saturated one by one and summed exactly in 64 bits -- bit-identical to every other format and to
+// the oracle.  Float: one fp32 multiply per product (no FMA); the (up to 8) products of a batch are added in fp32, the batch sums
+// join the lane's double sum, one double LDS add per (wavefront, row) -- the order of those adds is not fixed when a row is split over
+// several wavefronts, so float results are TOLERANCE parity (1e-4, like every float path here), not bit-identical to the PAIRS / DELTA
+// paths or from launch to launch.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

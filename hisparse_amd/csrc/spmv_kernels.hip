@@ -110,6 +110,7 @@ __device__ __forceinline__ void touch_x(const uint32_t* __restrict__ x, uint32_t
 #define HS_RING_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", \
                       "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"
 constexpr int kMaxDepth = 16;
+constexpr int kOwner24Depth = 3;     // OWNER24: records in flight per wavefront (5.25 KiB)
 
 // kRing: 0 = PAIRS / OWNER with 32-bit position words, 1 = DELTA, 2 = PAIRS / OWNER with 24-bit position words
 template <int kRing>
@@ -179,6 +180,26 @@ struct Ring<2> {    // 24-bit position words: a 448-byte step = 64 value dwords,
         where1 &= 0xffffffu;
     }
 };
+template <>
+struct Ring<3> {    // OWNER24: a record = FOUR steps per lane: the 4 value words as one dwordx4, the 4 x 24-bit position words as one dwordx3
+    // ring slot K (K < 4 records in flight): values in a[4K : 4K+3], position words in a[16+4K : 16+4K+2] (even-aligned tuples)
+    static constexpr uint32_t kLaneBytes = 16;
+    template <int K>
+    static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane16, uint32_t lane12) {
+        static_assert(K < 4 && 16 + 4 * K + 2 < 2 * kMaxDepth, "a0..a15: values of four records, a16..a30: their position words");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 a[%0:%1], %4, %6 nt\n\tglobal_load_dwordx3 a[%2:%3], %5, %6 offset:1024 nt" ::"n"(4 * K), "n"(4 * K + 3),
+                     "n"(16 + 4 * K), "n"(16 + 4 * K + 2), "v"(byte_off + lane16), "v"(byte_off + lane12), "s"(base)
+                     : "memory", HS_RING_AGPRS);
+    }
+    template <int K, int kDepth>
+    static __device__ __forceinline__ void take(uint32_t (&v)[4], uint32_t (&w)[3]) {
+        asm volatile("s_waitcnt vmcnt(%14)\n\tv_accvgpr_read_b32 %0, a[%7]\n\tv_accvgpr_read_b32 %1, a[%8]\n\tv_accvgpr_read_b32 %2, a[%9]\n\t"
+                     "v_accvgpr_read_b32 %3, a[%10]\n\tv_accvgpr_read_b32 %4, a[%11]\n\tv_accvgpr_read_b32 %5, a[%12]\n\tv_accvgpr_read_b32 %6, a[%13]"
+                     : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(w[0]), "=v"(w[1]), "=v"(w[2])
+                     : "n"(4 * K), "n"(4 * K + 1), "n"(4 * K + 2), "n"(4 * K + 3), "n"(16 + 4 * K), "n"(16 + 4 * K + 1), "n"(16 + 4 * K + 2), "n"(2 * (kDepth - 1))
+                     : "memory");
+    }
+};
 // a pointer the compiler must keep in a scalar register pair
 __device__ __forceinline__ const uint8_t* scalar_pointer(const uint8_t* p) {
     const uint64_t a = reinterpret_cast<uint64_t>(p);
@@ -217,12 +238,26 @@ struct Consumer {
     typename Rows<kFloat>::sum_t lane_sum = 0;   // ... and the lane's private sum on it, flushed to LDS when the row changes
     float own_sum = 0;         // OWNER: the lane's fp32 sum on lane_row (accumulators are floats, touched by this wavefront only)
     uint32_t spare = 0;        // OWNER: the wavefront's own spare accumulator (local row nrows + wave)
-    uint32_t row_base = 0;     // OWNER with 24-bit position words: first local row of the wavefront's share (rows are stored relative to it)
+    uint32_t row_base = 0;     // OWNER24: first local row of the wavefront's share of the current unit (rows are stored relative to it)
+    uint32_t lane_off12 = 0;   // OWNER24: lane * 12, the lane's offset among a record's position words
     uint64_t t_flush = 0, t_barrier = 0;   // OWNER profiling build (kAblate & 256): clocks spent in end-of-unit flushes / at unit barriers
 };
 
 // OWNER profiling build: where a wavefront's time goes (HISPARSE_ABLATE=256, tools/owner_profile.py); 8 u64 per wavefront
 __device__ uint64_t* g_owner_profile = nullptr;
+// Timeline build (HISPARSE_ABLATE=512, full work, correct results; tools/rowblock_timeline.py): 100 MHz timestamps of the phases of the
+// first kTimelineBlocks blocks of every workgroup, taken by consumer wavefront 0 and loader wavefront 14:
+//   [0] block entered  [1] prologue done (accumulators zeroed, first sub-tile copied)  [2] own main loop finished
+//   [3] every wavefront's main loop finished (barrier)  [4] result stores issued
+__device__ uint64_t* g_rowblock_timeline = nullptr;
+constexpr uint32_t kTimelineBlocks = 4, kTimelineStamps = 8;
+template <int kAblate>
+__device__ __forceinline__ void timeline_stamp(uint32_t k, uint32_t wave, uint32_t lane, uint32_t i) {
+    if (!(kAblate & 512)) return;
+    if (lane != 0 || (wave != 0 && wave != kConsumerWaves) || k >= kTimelineBlocks || !g_rowblock_timeline) return;
+    const uint64_t t = __builtin_amdgcn_s_memrealtime();
+    g_rowblock_timeline[((static_cast<size_t>(blockIdx.x) * kTimelineBlocks + k) * 2 + (wave ? 1 : 0)) * kTimelineStamps + i] = t;
+}
 
 // One step (slot K of the ring).  Returns false when the block is finished.
 // kDelta: DELTA format, otherwise PAIRS; kDense: the block's rows are long (Block::flags & kBlockDenseRows): products are
@@ -338,12 +373,6 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
 // the same step flush different rows (the lower lane's old row is below its new row, which is at most the higher lane's first
 // row).  Only at the end of a unit, when every lane hands its last row over, can neighbours hold the same row: one segmented
 // wavefront reduction first.
-// 24-bit position words carry the row relative to the wavefront's share in 11 bits; 2047 = the wavefront's spare accumulator
-template <int kRing>
-__device__ __forceinline__ uint32_t owner_row(const Consumer<true>& c, uint32_t field) {
-    if (kRing != 2) return field;
-    return field == kOwnerSpareField ? c.spare : c.row_base + field;
-}
 __device__ __forceinline__ void owner_flush(float* ys32, uint32_t row, float sum) {
     float a = ys32[row];
     a += sum;
@@ -375,7 +404,8 @@ __device__ __forceinline__ void owner_end_of_unit(Consumer<true>& c) {
 
 template <int kRing, int kAblate, int kDepth, int K>
 __device__ __forceinline__ bool consume_step_owner(Consumer<true>& c) {
-    constexpr uint32_t kStep = kRing == 2 ? kChunkBytes24 : kChunkBytes;
+    constexpr uint32_t kStep = kChunkBytes;
+    static_assert(kRing == 0, "8-byte OWNER chunks");
     const uint32_t s = c.base + K;
     while (s == c.end) {               // this wavefront finished sub-tile u (possibly with no work in it)
         if (kAblate & 256) {
@@ -399,7 +429,7 @@ __device__ __forceinline__ bool consume_step_owner(Consumer<true>& c) {
     }
     uint32_t mat, where;               // value word; local_row << 13 | local_col
     Ring<kRing>::template take<K, kDepth>(mat, where);
-    const uint32_t row = owner_row<kRing>(c, where >> kOwnerColBits), col = where & (kSubTileCols - 1u);
+    const uint32_t row = where >> kOwnerColBits, col = where & (kSubTileCols - 1u);
     if (kAblate & 1) {
         const uint32_t xv = (kAblate & 2) ? where : c.xb[col];
         asm volatile("" ::"v"(xv), "v"(mat), "v"(row));
@@ -428,7 +458,8 @@ __device__ __forceinline__ bool consume_step_owner(Consumer<true>& c) {
 // leaves rows >= this lane's last row, which this lane never leaves, a lower lane leaves rows below this lane's first row.)
 template <int kRing, int kAblate, int kDepth, int K>
 __device__ __forceinline__ bool consume_pair_owner(Consumer<true>& c) {
-    constexpr uint32_t kStep = kRing == 2 ? kChunkBytes24 : kChunkBytes;
+    constexpr uint32_t kStep = kChunkBytes;
+    static_assert(kRing == 0, "8-byte OWNER chunks");
     const uint32_t s = c.base + K;
     if ((kAblate & 1) || s == c.end || s + 1 == c.end) {     // a unit ends at or inside the pair: one step at a time
         if (!consume_step_owner<kRing, kAblate, kDepth, K>(c)) return false;
@@ -436,8 +467,8 @@ __device__ __forceinline__ bool consume_pair_owner(Consumer<true>& c) {
     }
     uint32_t mat0, where0, mat1, where1;
     Ring<kRing>::template take2<K, kDepth>(mat0, where0, mat1, where1);
-    const uint32_t row0 = owner_row<kRing>(c, where0 >> kOwnerColBits), col0 = where0 & (kSubTileCols - 1u);
-    const uint32_t row1 = owner_row<kRing>(c, where1 >> kOwnerColBits), col1 = where1 & (kSubTileCols - 1u);
+    const uint32_t row0 = where0 >> kOwnerColBits, col0 = where0 & (kSubTileCols - 1u);
+    const uint32_t row1 = where1 >> kOwnerColBits, col1 = where1 & (kSubTileCols - 1u);
     float* ys32 = reinterpret_cast<float*>(c.ys);
     const bool leaving0 = row0 != c.lane_row, leaving1 = row1 != row0;
     float old0 = 0.0f, old1 = 0.0f;
@@ -467,6 +498,128 @@ __device__ __forceinline__ bool consume_round_owner(Consumer<true>& c, std::inte
     return ((Ks % 2 != 0 || consume_pair_owner<kRing, kAblate, kDepth, Ks>(c)) && ...);
 }
 
+// ---- OWNER24 (stream_tiles.h): the OWNER scheme over records of four steps with 24-bit position words --------------------------------
+// Steps are numbered through the block; record r holds steps 4r .. 4r+3, which may belong to different units (the unit test sits in
+// front of every step, as above).  A position word holds the row relative to the first row of the wavefront's share of the CURRENT
+// unit (Consumer::row_base, from the high half of Unit::end_step), 2047 = the wavefront's spare accumulator.
+template <int kAblate>
+__device__ __forceinline__ bool owner24_next_unit(Consumer<true>& c, uint32_t s) {      // false: the block is finished
+    while (s == c.end) {               // this wavefront finished sub-tile u (possibly with no work in it)
+        if (!(kAblate & 1)) owner_end_of_unit(c);
+        if (!(kAblate & 8)) lds_barrier();
+        if (++c.u == c.U) return false;
+        const uint32_t packed = c.next_end;
+        c.end = packed & kOwnerStepMask;
+        c.row_base = packed >> 16;
+        c.next_end = c.unit[min(c.u + 1, c.U - 1)].end_step[c.wave];
+        c.slot = c.slot + 1 == c.ring ? 0 : c.slot + 1;
+        c.xb = c.xs + c.slot * kSubTileCols;
+    }
+    return true;
+}
+__device__ __forceinline__ uint32_t owner24_row(const Consumer<true>& c, uint32_t where) {
+    const uint32_t field = where >> kOwnerColBits;
+    return field == kOwnerSpareField ? c.spare : c.row_base + field;
+}
+template <int kAblate>
+__device__ __forceinline__ void owner24_one(Consumer<true>& c, uint32_t mat, uint32_t where) {
+    const uint32_t row = owner24_row(c, where), col = where & (kSubTileCols - 1u);
+    if (kAblate & 1) {
+        asm volatile("" ::"v"(mat), "v"(row), "v"(col));
+        return;
+    }
+    float* ys32 = reinterpret_cast<float*>(c.ys);
+    const bool leaving = row != c.lane_row;     // per lane; the very first step of a unit leaves the spare accumulator (adds 0)
+    float old = 0.0f;
+    if (leaving) old = ys32[c.lane_row];
+    const uint32_t xv = c.xb[col];
+    const float prod = __uint_as_float(mat) * __uint_as_float(xv);     // one fp32 multiply, like the float PEs (pe-stall.h:52)
+    if (leaving) {
+        ys32[c.lane_row] = old + c.own_sum;
+        c.lane_row = row;
+        c.own_sum = 0;
+    }
+    c.own_sum += prod;
+}
+// steps s and s + 1 (see consume_pair_owner for why the four LDS reads may go out together)
+template <int kAblate>
+__device__ __forceinline__ bool owner24_pair(Consumer<true>& c, uint32_t s, uint32_t mat0, uint32_t where0, uint32_t mat1, uint32_t where1) {
+    if ((kAblate & 1) || s == c.end || s + 1 == c.end) {      // a unit ends at or inside the pair: one step at a time
+        if (!owner24_next_unit<kAblate>(c, s)) return false;
+        owner24_one<kAblate>(c, mat0, where0);
+        if (!owner24_next_unit<kAblate>(c, s + 1)) return false;
+        owner24_one<kAblate>(c, mat1, where1);
+        return true;
+    }
+    const uint32_t row0 = owner24_row(c, where0), col0 = where0 & (kSubTileCols - 1u);
+    const uint32_t row1 = owner24_row(c, where1), col1 = where1 & (kSubTileCols - 1u);
+    float* ys32 = reinterpret_cast<float*>(c.ys);
+    const bool leaving0 = row0 != c.lane_row, leaving1 = row1 != row0;
+    float old0 = 0.0f, old1 = 0.0f;
+    if (leaving0) old0 = ys32[c.lane_row];
+    if (leaving1) old1 = ys32[row0];
+    const uint32_t xv0 = c.xb[col0], xv1 = c.xb[col1];
+    const float prod0 = __uint_as_float(mat0) * __uint_as_float(xv0), prod1 = __uint_as_float(mat1) * __uint_as_float(xv1);
+    if (leaving0) {
+        ys32[c.lane_row] = old0 + c.own_sum;
+        c.own_sum = 0;
+    }
+    c.own_sum += prod0;
+    if (leaving1) {
+        ys32[row0] = old1 + c.own_sum;
+        c.own_sum = 0;
+    }
+    c.own_sum += prod1;
+    c.lane_row = row1;
+    return true;
+}
+// one record (ring slot K): take it, put the record kDepth further on in flight in its place, then its four steps
+template <int kAblate, int kDepth, int K>
+__device__ __forceinline__ bool consume_record_owner24(Consumer<true>& c) {
+    const uint32_t r = c.base + K;
+    uint32_t v[4], w[3];
+    Ring<3>::template take<K, kDepth>(v, w);
+    Ring<3>::template issue<K>(c.stream, min(r + kDepth, c.last) * kOwnerRecordBytes, c.lane_off, c.lane_off12);
+    const uint32_t where0 = w[0] & 0xffffffu, where1 = __builtin_amdgcn_alignbit(w[1], w[0], 24) & 0xffffffu;
+    const uint32_t where2 = __builtin_amdgcn_alignbit(w[2], w[1], 16) & 0xffffffu, where3 = w[2] >> 8;
+    if (!owner24_pair<kAblate>(c, 4 * r, v[0], where0, v[1], where1)) return false;
+    return owner24_pair<kAblate>(c, 4 * r + 2, v[2], where2, v[3], where3);
+}
+template <int kAblate, int kDepth, int... Ks>
+__device__ __forceinline__ bool consume_round_owner24(Consumer<true>& c, std::integer_sequence<int, Ks...>) {
+    return (consume_record_owner24<kAblate, kDepth, Ks>(c) && ...);
+}
+template <int... Ks>
+__device__ __forceinline__ void prime_ring_owner24(Consumer<true>& c, std::integer_sequence<int, Ks...>) {
+    (Ring<3>::template issue<Ks>(c.stream, min(static_cast<uint32_t>(Ks), c.last) * kOwnerRecordBytes, c.lane_off, c.lane_off12), ...);
+}
+template <int kDepth>
+__device__ __forceinline__ void consumer_begin_owner24(Consumer<true>& c, const uint8_t* stream, UnitTable unit, uint32_t U, uint32_t wave, uint32_t lane,
+                                                       const uint32_t* xs, uint32_t ring, double* ys, uint32_t nrows, uint32_t total_steps,
+                                                       uint32_t first_end) {
+    static_assert(kDepth >= 1 && kDepth <= 4, "records in flight: a0..a30");
+    c.stream = scalar_pointer(stream);
+    c.unit = unit; c.U = U; c.wave = wave; c.lane = lane; c.ring = ring; c.nrows = nrows;
+    c.lane_off = lane * 16u;
+    c.lane_off12 = lane * 12u;
+    const uint32_t records = (total_steps + kOwnerRecordSteps - 1) / kOwnerRecordSteps;
+    c.last = records ? records - 1 : 0;          // prefetches past the end re-read the last record (no branch)
+    c.xs = xs; c.xb = xs; c.ys = ys;
+    c.end = first_end & kOwnerStepMask;
+    c.row_base = first_end >> 16;
+    c.next_end = U > 1 ? unit[1].end_step[wave] : first_end;
+    c.lane_row = nrows + wave;
+    c.spare = nrows + wave;
+    prime_ring_owner24(c, std::make_integer_sequence<int, kDepth>());
+}
+template <int kAblate, int kDepth>
+__device__ __forceinline__ void consumer_run_owner24(Consumer<true>& c) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // see consumer_run: clears hipcc's "LDS-DMA may be pending"
+    for (;; c.base += kDepth)
+        if (!consume_round_owner24<kAblate, kDepth>(c, std::make_integer_sequence<int, kDepth>())) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory", HS_RING_AGPRS);   // the clamped tail prefetches must land before the ring is reused
+}
+
 template <bool kFloat, int kRing, int kAblate, int kDepth, bool kDense, int... Ks>
 __device__ __forceinline__ bool consume_round(Consumer<kFloat>& c, std::integer_sequence<int, Ks...>) {
     return (consume_step<kFloat, kRing, kAblate, kDepth, kDense, Ks>(c) && ...);
@@ -481,10 +634,10 @@ __device__ __forceinline__ void prime_ring(const uint8_t* stream, uint32_t last,
 template <bool kFloat, int kRing, int kDepth, bool kOwner = false>
 __device__ __forceinline__ void consumer_begin(Consumer<kFloat>& c, const uint8_t* stream, UnitTable unit, uint32_t U, uint32_t wave,
                                                uint32_t lane, const uint32_t* xs, uint32_t ring, typename Rows<kFloat>::acc_t* ys, uint32_t nrows,
-                                               uint32_t total, uint32_t first_end, uint32_t row_base = 0) {
+                                               uint32_t total, uint32_t first_end) {
     static_assert(kDepth <= kMaxDepth, "the ring lives in a0..a31");
     constexpr bool kDelta = kRing == 1, k24 = kRing == 2;
-    constexpr uint32_t kStride = kDelta ? kRecordBytes : kOwner ? (k24 ? kChunkBytes24 : kChunkBytes) : k24 ? kWaveStrideBytes24 : kWaveStrideBytes;
+    constexpr uint32_t kStride = kDelta ? kRecordBytes : kOwner ? kChunkBytes : k24 ? kWaveStrideBytes24 : kWaveStrideBytes;
     c.stream = scalar_pointer(stream);
     c.unit = unit; c.U = U; c.wave = wave; c.lane = lane; c.ring = ring; c.nrows = nrows;
     c.lane_off = lane * Ring<kRing>::kLaneBytes;
@@ -494,7 +647,6 @@ __device__ __forceinline__ void consumer_begin(Consumer<kFloat>& c, const uint8_
     c.next_end = U > 1 ? unit[1].end_step[wave] : first_end;
     c.lane_row = kOwner ? nrows + wave : nrows;
     c.spare = nrows + wave;
-    c.row_base = row_base;
     prime_ring<kRing>(c.stream, c.last, kStride, c.lane_off, std::make_integer_sequence<int, kDepth>());
 }
 
@@ -559,7 +711,8 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
         if (bi == kNoBlock) return;
     }
     bool first_block = true;
-    for (uint32_t next = 0;; bi = next) {
+    uint32_t block_no = 0;      // timeline build only
+    for (uint32_t next = 0;; bi = next, ++block_no) {
         const BlockTable blk = (BlockTable)(blocks + bi);
         next = (row_part_filter >= 0 && (blk->flags & kBlockLastOfPartition)) ? 0u : blk->next;
         const uint32_t nrows = blk->nrows, out0 = blk->out_offset;
@@ -568,16 +721,34 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
 
         if (!first_block) __syncthreads();   // the previous block's result store has read the accumulators (and has drained)
         first_block = false;
+        timeline_stamp<kAblate>(block_no, wave, lane, 0);
         Consumer<kFloat> c;
-        if (!loader && U > 0)
-            consumer_begin<kFloat, kRing, kDepth, kOwner>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave],
-                                                           blk->first_end[wave], (kOwner && kRing == 2) ? blk->pad[wave] : 0u);
-        if (kOwner) {
-            if (!(kAblate & 16)) for (uint32_t i = tid; i < nrows + kConsumerWaves; i += kThreads) reinterpret_cast<float*>(ys)[i] = 0.0f;
-        } else
-        if (!(kAblate & 16)) for (uint32_t i = tid; i <= nrows; i += kThreads) ys[i] = 0;           // PE banks start at zero (pe.h:131-135)
-        if (U > 0 && !(kAblate & 16)) fill_x<kSubTileCols / 4 / kThreads, kThreads>(xs, x, blk->first_col0, blk->first_ncols, tid);
+        if (!loader && U > 0) {
+            if constexpr (kRing == 3)
+                consumer_begin_owner24<kDepth>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave], blk->first_end[wave]);
+            else
+                consumer_begin<kFloat, kRing, kDepth, kOwner>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave],
+                                                               blk->first_end[wave]);
+        }
+        // Prologue: the consumer wavefronts zero the accumulators (PE banks start at zero, pe.h:131-135) while the two loader wavefronts
+        // bring sub-tile 0 in by LDS-DMA.  (Until round 3 every thread copied its share of sub-tile 0 through registers: the consumers'
+        // copy then waited behind their own primed stream loads -- vmcnt retires in order -- i.e. for a full HBM round trip although x
+        // sits in L2: 4.3 us of prologue per block in the timeline build, HISPARSE_ABLATE=512.)
+        if (!(kAblate & 16)) {
+            constexpr uint32_t kConsumerThreads = kConsumerWaves * kWaveLanes;
+            if (loader) {
+                if (U > 0) {
+                    dma_fill_x(xs, x, blk->first_col0, blk->first_ncols, wave - kConsumerWaves, lane);
+                    dma_wait<0>();
+                }
+            } else if (kOwner) {
+                for (uint32_t i = tid; i < nrows + kConsumerWaves; i += kConsumerThreads) reinterpret_cast<float*>(ys)[i] = 0.0f;
+            } else {
+                for (uint32_t i = tid; i <= nrows; i += kConsumerThreads) ys[i] = 0;
+            }
+        }
         __syncthreads();
+        timeline_stamp<kAblate>(block_no, wave, lane, 1);
 
         if (U > 0) {
             if (loader) {
@@ -633,11 +804,13 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 }
             } else {
                 // ---- consumer wavefronts: stream elements, gather x, accumulate rows -----------------------------
-                if constexpr (kOwner) consumer_run<kFloat, kRing, kAblate, kDepth, false, true>(c);
+                if constexpr (kRing == 3) consumer_run_owner24<kAblate, kDepth>(c);
+                else if constexpr (kOwner) consumer_run<kFloat, kRing, kAblate, kDepth, false, true>(c);
                 else if (blk->flags & kBlockDenseRows) consumer_run<kFloat, kRing, kAblate, kDepth, true>(c);
                 else consumer_run<kFloat, kRing, kAblate, kDepth, false>(c);
             }
         }
+        timeline_stamp<kAblate>(block_no, wave, lane, 2);
         // Every sub-tile barrier has passed -- but LDS atomics WITHOUT return value can still be queued behind it: with heavy
         // same-address conflicts (dense rows in the plain DELTA path, ds_add_f64) the s_waitcnt lgkmcnt(0) in front of the barrier
         // did not cover them and the accumulators were read too early (40 % of the launches of a 15 %-dense float matrix lost one
@@ -650,7 +823,9 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 asm volatile("" ::"v"(flushed));
             }
             __syncthreads();
+            timeline_stamp<kAblate>(block_no, wave, lane, 3);
             if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = __float_as_uint(reinterpret_cast<float*>(ys)[i]);
+            timeline_stamp<kAblate>(block_no, wave, lane, 4);
             if (!next) break;
             continue;
         }
@@ -659,8 +834,10 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
             asm volatile("" ::"v"(flushed));
         }
         __syncthreads();
+        timeline_stamp<kAblate>(block_no, wave, lane, 3);
         // the accumulators are final (no barrier after the store: the last block's stores drain while the workgroup retires)
         if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = Rows<kFloat>::finish(ys[i]);
+        timeline_stamp<kAblate>(block_no, wave, lane, 4);
         if (!next) break;
     }
 }
@@ -741,6 +918,8 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t
     return ((acc + 15u) & ~15u) + ring_buffers * kBufBytes;
 }
 
+// OWNER24 profiling builds (three records in flight): 1 = no LDS work, 4 = no x refill, 8 = no unit barriers, and combinations
+#define HS_FOR_EACH_OWNER24_ABLATION(X) X(1) X(4) X(5) X(8) X(12) X(13) X(512)
 // OWNER variants (float only): ablate values as for the other formats
 #define HS_FOR_EACH_OWNER_VARIANT(X) X(0) X(1) X(2) X(3) X(4) X(7) X(8) X(11) X(12) X(15) X(127) X(256)
 
@@ -751,7 +930,8 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t
     X(false, false, 4, 8) X(false, true, 4, 8) X(false, false, 8, 8) X(false, true, 8, 8) X(false, false, 15, 8) X(false, true, 15, 8) X(false, false, 31, 8) X(false, true, 31, 8)                     \
     X(false, false, 47, 8) X(false, true, 47, 8) X(false, false, 79, 8) X(false, true, 79, 8)                     \
     X(false, false, 127, 8) X(false, true, 127, 8)                                                                 \
-    X(true, false, 3, 8) X(true, false, 4, 8) X(true, false, 8, 8) X(true, false, 15, 8) X(true, false, 127, 8)
+    X(true, false, 3, 8) X(true, false, 4, 8) X(true, false, 8, 8) X(true, false, 15, 8) X(true, false, 127, 8) \
+    X(false, false, 512, 8) X(false, true, 512, 8) X(true, false, 512, 8) X(true, true, 512, 8)
 
 hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
     hipError_t e;
@@ -761,24 +941,66 @@ hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
 #define X(A) if ((e = configure_one<true, false, A, 8, true>(lds_bytes)) != hipSuccess) return e;
     HS_FOR_EACH_OWNER_VARIANT(X)
 #undef X
-    if ((e = configure_one<true, 2, 0, 8, true>(lds_bytes)) != hipSuccess) return e;
+    if ((e = configure_one<true, 3, 0, 2, true>(lds_bytes)) != hipSuccess || (e = configure_one<true, 3, 0, 3, true>(lds_bytes)) != hipSuccess ||
+        (e = configure_one<true, 3, 0, 4, true>(lds_bytes)) != hipSuccess)
+        return e;
+#define X(A) if ((e = configure_one<true, 3, A, 3, true>(lds_bytes)) != hipSuccess) return e;
+    HS_FOR_EACH_OWNER24_ABLATION(X)
+#undef X
     return configure_bitmap_kernels(lds_bytes);
 }
 
 hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.num_workgroups == 0) return hipSuccess;
     if (a.format == kFormatBitmap) return launch_spmv_bitmap(is_float, a, stream);
-    const int ring = a.format == kFormatDelta ? 1 : (a.format == kFormatPairs24 || a.format == kFormatOwner24) ? 2 : 0;
+    const int ring = a.format == kFormatDelta ? 1 : a.format == kFormatPairs24 ? 2 : 0;
     const dim3 grid(a.num_workgroups), block(kThreads);
     const uint32_t x_base = a.lds_bytes - a.ring_buffers * kBufBytes;
     // profiling aids: HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the prefetch depth
-    static const int ablate = env_int("HISPARSE_ABLATE", 0), depth = env_int("HISPARSE_DEPTH", 8);
+    const int ablate = env_int("HISPARSE_ABLATE", 0), depth = env_int("HISPARSE_DEPTH", 8);     // read per launch: a test may change them
     bool launched = false;
+    // timeline build: HISPARSE_ABLATE=512 HISPARSE_TIMELINE_OUT=file -> the launch is synchronised and its timestamps (workgroups x
+    // kTimelineBlocks x 2 wavefronts x kTimelineStamps u64, 100 MHz) overwrite the file (tools/rowblock_timeline.py)
+    struct TimelineDump {
+        hipStream_t stream; uint32_t workgroups; bool on;
+        ~TimelineDump() {
+            const char* path = std::getenv("HISPARSE_TIMELINE_OUT");
+            if (!on || !path || !buffer()) return;
+            (void)hipStreamSynchronize(stream);
+            std::vector<uint64_t> host(size_t(workgroups) * kTimelineBlocks * 2 * kTimelineStamps);
+            (void)hipMemcpy(host.data(), buffer(), host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+            if (FILE* f = std::fopen(path, "wb")) { std::fwrite(host.data(), sizeof(uint64_t), host.size(), f); std::fclose(f); }
+        }
+        static uint64_t*& buffer() { static uint64_t* b = nullptr; return b; }
+    } timeline_dump{stream, a.num_workgroups, ablate == 512 && a.num_workgroups <= 4096};
+    if (timeline_dump.on) {
+        const size_t bytes = size_t(4096) * kTimelineBlocks * 2 * kTimelineStamps * sizeof(uint64_t);
+        if (!TimelineDump::buffer() && hipMalloc(reinterpret_cast<void**>(&TimelineDump::buffer()), bytes) == hipSuccess)
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rowblock_timeline), &TimelineDump::buffer(), sizeof(uint64_t*));
+        if (TimelineDump::buffer()) (void)hipMemsetAsync(TimelineDump::buffer(), 0, bytes, stream);
+    }
     if (a.format == kFormatOwner24) {
-        if (!is_float || ablate != 0 || depth != 8) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((spmv_rowblock_kernel<true, 2, 0, 8, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out,
-                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);
-        return hipGetLastError();
+        // records in flight per wavefront (1792 bytes each): HISPARSE_DEPTH=2|3|4 for experiments, kOwner24Depth otherwise
+        const int records = std::getenv("HISPARSE_DEPTH") ? depth : kOwner24Depth;
+        if (!is_float) return hipErrorInvalidValue;
+#define X(A)                                                                                                                       \
+    if (ablate == A && records == 3) {                                                                                             \
+        hipLaunchKernelGGL((spmv_rowblock_kernel<true, 3, A, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
+        return hipGetLastError();                                                                                                  \
+    }
+        HS_FOR_EACH_OWNER24_ABLATION(X)
+#undef X
+        if (ablate != 0) return hipErrorInvalidValue;
+#define X(D)                                                                                                                       \
+    if (records == D) {                                                                                                            \
+        hipLaunchKernelGGL((spmv_rowblock_kernel<true, 3, 0, D, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
+        return hipGetLastError();                                                                                                  \
+    }
+        X(2) X(3) X(4)
+#undef X
+        return hipErrorInvalidValue;
     }
     if (a.format == kFormatOwner) {
         if (!is_float) return hipErrorInvalidValue;

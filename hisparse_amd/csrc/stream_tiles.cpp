@@ -93,8 +93,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             const std::string f(force);
             if (f == "bitmap") bitmap = true;
             else if (f == "pairs" || f == "delta") bitmap = false;
-            else if (f == "owner") bitmap = false;
-            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner or bitmap"; return false; }
+            else if (f == "owner" || f == "owner24") bitmap = false;
+            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner, owner24 or bitmap"; return false; }
         }
         if (bitmap) {
             if (!csr) gpu.reset();      // BITMAP images are small and built on the host (a CSR source has no host fallback: keep the tiler)
@@ -107,18 +107,21 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     {
         const double mean_gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 1e30;
         out.format = (mean_gap >= kDeltaMinMeanGap && mean_gap <= kDeltaMaxMeanGap) ? kFormatDelta : kFormatPairs;
-        if (is_float && mean_gap > kOwnerMinMeanGap && out.nnz >= 4096) out.format = kFormatOwner;
+        // hyper-sparse float matrices: OWNER, in its 7-byte record form (OWNER24) unless that turns out larger (decided after the sort)
+        if (is_float && mean_gap > kOwnerMinMeanGap && out.nnz >= 4096) out.format = kFormatOwner24;
         if (const char* force = env_switch("HISPARSE_STREAM_FORMAT")) {
             const std::string f(force);
             if (f == "pairs") out.format = kFormatPairs;
             else if (f == "delta") out.format = kFormatDelta;
             else if (f == "owner") out.format = is_float ? kFormatOwner : kFormatPairs;   // float accumulators only
+            else if (f == "owner24") out.format = is_float ? kFormatOwner24 : kFormatPairs;
             else if (f == "bitmap") {}   // was tried above and is not representable (duplicate entries): automatic choice
-            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner or bitmap"; return false; }
+            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner, owner24 or bitmap"; return false; }
         }
     }
     bool delta = out.format == kFormatDelta;
-    const bool owner = out.format == kFormatOwner;
+    const bool owner = out.format == kFormatOwner || out.format == kFormatOwner24;
+    bool owner24 = out.format == kFormatOwner24;      // may still fall back to the 8-byte form (below)
     const bool format_forced = env_switch("HISPARSE_STREAM_FORMAT") != nullptr;
     const uint32_t acc_bytes = owner ? kOwnerAccumulatorBytes : kAccumulatorBytes;
     const uint32_t spare_rows = owner ? kConsumerWaves : 1u;     // accumulators behind the block's rows that padding elements aim at
@@ -197,31 +200,6 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     }
     const uint32_t ring_fit = (kMaxLdsBytes - (((out.max_block_rows + spare_rows) * acc_bytes + 15u) & ~15u)) / (kSubTileCols * 4u);
     out.ring_buffers = std::max(kMinXBuffers, std::min(kMaxXBuffers, ring_fit));
-
-    // OWNER: shares are cut per unit (tiles_common.h: balanced_owner_shares).  The 24-bit form (opt-in) addresses rows relative to a
-    // wavefront's share of the whole block in 11 bits, so it keeps the fixed ownership: every consumer wavefront owns a contiguous
-    // share of a range's rows, cut at equal non-zero count
-    const bool fixed_shares = owner && [] { const char* bits = env_switch("HISPARSE_AUX_BITS"); return bits && std::atoi(bits) == 24; }();
-    std::vector<uint32_t> wave_row;      // [range][kConsumerWaves + 1] local row boundaries
-    if (fixed_shares) {
-        wave_row.assign(size_t(NR) * (kConsumerWaves + 1), 0);
-        parallel_for(NR, [&](size_t b) {
-            uint32_t* wr = wave_row.data() + b * (kConsumerWaves + 1);
-            const uint32_t r0 = ranges[b].row0, n = ranges[b].nrows;
-            uint64_t acc = 0;
-            uint32_t w = 1;
-            for (uint32_t r = 0; r < n && w < kConsumerWaves; ++r) {
-                acc += row_nnz[r0 + r];
-                while (w < kConsumerWaves && acc * kConsumerWaves >= range_nnz[b] * w) wr[w++] = r + 1;
-            }
-            for (; w <= kConsumerWaves; ++w) wr[w] = n;
-            wr[kConsumerWaves] = n;
-            // no share longer than what an 11-bit relative row can address (24-bit position words): 14 x 2046 >= any block
-            for (uint32_t k = 1; k <= kConsumerWaves; ++k) wr[k] = std::min(wr[k], wr[k - 1] + kAux24MaxRows);
-            wr[kConsumerWaves] = n;
-            for (uint32_t k = kConsumerWaves; k-- > 1;) wr[k] = std::max(wr[k], wr[k + 1] > kAux24MaxRows ? wr[k + 1] - kAux24MaxRows : 0u);
-        });
-    }
 
     timer.lap("plan + row ranges");
     // ---- pass 1: elements per (row range, column partition, sub-tile, source channel) -------------------
@@ -349,11 +327,6 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         } else {
             for (UnitPlan& up : plans) up.slots = up.n;
         }
-        if (owner) {
-            std::vector<uint32_t> range_of_unit(NU);
-            for (uint32_t u = 0; u < NU; ++u) range_of_unit[u] = range_of_block[block_of_unit[u]];
-            if (!gpu->owner_shares(plans, wave_row, range_of_unit, !fixed_shares)) { error = gpu->error(); return false; }
-        }
     } else {
     scratch.resize(scratch_elems);
     parallel_for(res1.size(), [&](size_t w) {
@@ -412,23 +385,65 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         }
     }
     timer.lap("sort units");
-    // ---- 24-bit position words (stream_tiles.h: PAIRS24 / OWNER24): 7 bytes per element where 11 bits of row are enough ----------
+    // ---- OWNER: every unit's elements, sorted by (row, column), are cut into the 14 wavefronts' shares (balanced_owner_shares) -----
+    auto owner_shares = [&](uint32_t max_span) -> bool {
+        if (gpu) {
+            if (!gpu->owner_shares(plans, max_span)) { error = gpu->error(); return false; }
+            return true;
+        }
+        parallel_for(NU, [&](size_t u) {
+            UnitPlan& up = plans[u];
+            const uint64_t* e = scratch.data() + up.scratch;
+            auto row_of = [&](uint32_t i) { return uint32_t(e[i] >> (32 + kOwnerColBits)); };
+            balanced_owner_shares(up.n, row_of, up.own_begin, max_span);
+            for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+                const bool any = up.own_begin[w + 1] > up.own_begin[w];
+                up.own_row[w] = any ? row_of(up.own_begin[w]) : 0u;
+                up.own_last[w] = any ? row_of(up.own_begin[w + 1] - 1) : 0u;
+            }
+        });
+        return true;
+    };
+    if (owner) {
+        if (!owner_shares(owner24 ? kOwnerShareRows : 0xffffffffu)) return false;
+        if (owner24) {
+            // OWNER24 holds a share's rows relative to its first row in 11 bits and a wavefront's step count in 16: otherwise, or when
+            // the row cap has cut so many shares short that the 7-byte records are no smaller than 8-byte chunks, keep the 8-byte form
+            bool fits = true;
+            uint64_t bytes24 = 0, bytes32 = 0;
+            for (uint32_t bi = 0; bi < NB && fits; ++bi) {
+                uint64_t steps[kConsumerWaves] = {0};
+                for (uint32_t u = out.blocks[bi].unit_begin; u < out.blocks[bi].unit_end; ++u) {
+                    const UnitPlan& up = plans[u];
+                    bytes32 += (uint64_t(up.n) + kWaveLanes - 1) / kWaveLanes * kChunkBytes;
+                    for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+                        steps[w] += (up.own_begin[w + 1] - up.own_begin[w] + kWaveLanes - 1) / kWaveLanes;
+                        if (up.own_last[w] - up.own_row[w] >= kOwnerShareRows || up.own_row[w] > 0xffffu) fits = false;
+                    }
+                }
+                for (uint32_t w = 0; w < kConsumerWaves; ++w) {
+                    if (steps[w] > kOwnerStepMask) fits = false;
+                    bytes24 += (steps[w] + kOwnerRecordSteps - 1) / kOwnerRecordSteps * kOwnerRecordBytes;
+                }
+            }
+            if (!fits || (!format_forced && double(bytes24) > 0.97 * double(bytes32))) {
+                owner24 = false;
+                out.format = kFormatOwner;
+                if (!owner_shares(0xffffffffu)) return false;
+            }
+        }
+        timer.lap("owner shares");
+    }
+    // ---- PAIRS with 24-bit position words (stream_tiles.h: PAIRS24): 7 bytes per element where 11 bits of row are enough ----------
     bool aux24 = false;
     {
-        // Opt-in (HISPARSE_AUX_BITS=24): measured SLOWER than the 8-byte forms although it streams 12 % fewer bytes (mouse_gene 40.8 vs
-        // 39.7 us, ogbn-products 281 vs 266 us): a step becomes two loads (one of them unaligned) instead of one dwordx2, and the
-        // kernels are bound by the number of memory requests a CU keeps in flight, not by the bytes.
+        // Opt-in (HISPARSE_AUX_BITS=24): measured SLOWER than the 8-byte form although it streams 12 % fewer bytes (mouse_gene 40.8 vs
+        // 39.7 us): a step becomes two loads (one of them unaligned) instead of one dwordx2, and the kernels are bound by the number of
+        // memory requests a CU keeps in flight, not by the bytes.
         const char* bits = env_switch("HISPARSE_AUX_BITS");
         const bool allowed = bits && std::atoi(bits) == 24;
-        if (owner) {
-            aux24 = allowed && fixed_shares;
-            for (uint32_t b = 0; b < NR && aux24; ++b)
-                for (uint32_t w = 0; w < kConsumerWaves; ++w)
-                    if (wave_row[size_t(b) * (kConsumerWaves + 1) + w + 1] - wave_row[size_t(b) * (kConsumerWaves + 1) + w] > kAux24MaxRows) aux24 = false;
-        } else if (!delta) {
-            aux24 = allowed && out.max_block_rows <= kAux24MaxRows;
-        }
-        if (aux24) out.format = owner ? kFormatOwner24 : kFormatPairs24;
+        if (!owner && !delta) aux24 = allowed && out.max_block_rows <= kAux24MaxRows;
+        if (aux24) out.format = kFormatPairs24;
     }
     const uint32_t chunk_bytes = aux24 ? kChunkBytes24 : kChunkBytes, wave_stride = chunk_bytes * kConsumerWaves;
     // one element slot of a chunk: value word + position word (32-bit: interleaved pairs; 24-bit: 64 values, then 64 x 3 bytes)
@@ -456,22 +471,13 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             if (owner) {
                 // the unit's elements are sorted by (row, column): wavefront w's share is the contiguous stretch of its rows;
                 // steps = its 64-slot chunks; lane l takes elements [l * steps, (l + 1) * steps) of the share
-                if (!gpu) {      // (the device computed the shares already)
-                    const uint64_t* e = scratch.data() + up.scratch;
-                    if (fixed_shares) {
-                        const uint32_t* wr = wave_row.data() + size_t(range_of_block[bi]) * (kConsumerWaves + 1);
-                        for (uint32_t w = 0; w <= kConsumerWaves; ++w)
-                            up.own_begin[w] = uint32_t(std::lower_bound(e, e + up.n, uint64_t(wr[w]) << (32 + kOwnerColBits)) - e);
-                    } else {
-                        balanced_owner_shares(up.n, [&](uint32_t i) { return uint32_t(e[i] >> (32 + kOwnerColBits)); }, up.own_begin);
-                    }
-                }
                 for (uint32_t w = 0; w < kConsumerWaves; ++w) {
                     const uint32_t steps = (up.own_begin[w + 1] - up.own_begin[w] + kWaveLanes - 1) / kWaveLanes;
                     up.run_len[w] = steps;
                     up.start_step[w] = up.start_record[w] = pos[w];
                     pos[w] += steps;
-                    out.units[u].end_step[w] = pos[w];
+                    // OWNER24: the share's first row rides in the high half (stream_tiles.h)
+                    out.units[u].end_step[w] = owner24 ? (pos[w] | up.own_row[w] << 16) : pos[w];
                     out.elements += uint64_t(steps) * kWaveLanes;
                 }
                 continue;
@@ -498,12 +504,12 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
         // the kernel addresses a wavefront's stream with a 32-bit byte offset from Block::wave_offset
         for (uint32_t w = 0; w < kConsumerWaves; ++w)
             if (uint64_t(pos[w]) * (delta ? kRecordBytes : owner ? chunk_bytes : wave_stride) >= (1ull << 32)) { error = "row block stream exceeds 4 GiB"; return false; }
-        if (owner && aux24)
-            for (uint32_t w = 0; w < kConsumerWaves; ++w) blk.pad[w] = wave_row[size_t(range_of_block[bi]) * (kConsumerWaves + 1) + w];
         if (delta || owner) {      // every wavefront's steps are contiguous
             for (uint32_t w = 0; w < kConsumerWaves; ++w) {
                 blk.wave_offset[w] = image_bytes;
-                image_bytes += uint64_t(pos[w]) * (delta ? kRecordBytes : chunk_bytes);
+                // OWNER24: whole records of four steps (the steps behind the last one are never consumed)
+                image_bytes += owner24 ? uint64_t((pos[w] + kOwnerRecordSteps - 1) / kOwnerRecordSteps) * kOwnerRecordBytes
+                                       : uint64_t(pos[w]) * (delta ? kRecordBytes : chunk_bytes);
             }
         } else {
             // chunks are stored in dealing order (global chunk g of the block at g * 512 bytes; wavefront w consumes
@@ -515,14 +521,25 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
 
     // ---- workgroups: longest-processing-time assignment of blocks (tiles_common.h) ------------------------------
     std::vector<std::vector<uint32_t>> mine;
-    assign_workgroups(out, block_nnz, G, RP, mine);
+    {
+        // x larger than an XCD's L2 can keep next to the stream: blocks go to XCDs by column slice (tiles_common.h)
+        bool by_slice = slices > 1 && uint64_t(num_cols) * 4 > kSliceAffinityMinXBytes && G % 8 == 0 && NB >= G;
+        if (const char* force = env_switch("HISPARSE_XCD_AFFINITY")) by_slice = std::atoi(force) != 0 && slices > 1 && G % 8 == 0 && NB >= G;
+        if (by_slice) {
+            std::vector<uint32_t> slice_of_block(NB);
+            for (uint32_t bi = 0; bi < NB; ++bi) slice_of_block[bi] = bi % slices;      // blocks were pushed range by range, slice by slice
+            assign_workgroups_by_slice(out, block_nnz, G, RP, slice_of_block, mine);
+        } else {
+            assign_workgroups(out, block_nnz, G, RP, mine);
+        }
+    }
     // Final block order (chain_blocks) after the copies of unit data the kernel wants inside the Block have been filled in.
     auto finish_blocks = [&]() {
         for (Block& blk : out.blocks) {
             if (blk.unit_end > blk.unit_begin) {
                 for (uint32_t w = 0; w < kConsumerWaves; ++w) {
-                    blk.total_steps[w] = out.units[blk.unit_end - 1].end_step[w];
-                    blk.first_end[w] = out.units[blk.unit_begin].end_step[w];
+                    blk.total_steps[w] = out.units[blk.unit_end - 1].end_step[w] & (owner24 ? kOwnerStepMask : 0xffffffffu);
+                    blk.first_end[w] = out.units[blk.unit_begin].end_step[w];      // OWNER24: with the first share's row_base
                 }
                 blk.first_col0 = out.units[blk.unit_begin].col0;
                 blk.first_ncols = out.units[blk.unit_begin].ncols;
@@ -546,7 +563,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
 
     if (owner) {
         // ---- OWNER: per (unit, wavefront) share: slot (step s, lane l) holds element l * steps + s of the share; the position word
-        //      IS the element's (local_row << 13 | local_col); padding aims a zero at the wavefront's own spare accumulator -------
+        //      IS the element's (local_row << 13 | local_col); padding aims a zero at the wavefront's own spare accumulator.
+        //      OWNER24: step S of the wavefront's stream = slot S % 4 of record S / 4, rows relative to the share's first row -------
         parallel_for(NU, [&](size_t u) {
             const UnitPlan& up = plans[u];
             const Block& blk = out.blocks[block_of_unit[u]];
@@ -554,16 +572,22 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
             for (uint32_t w = 0; w < kConsumerWaves; ++w) {
                 const uint32_t steps = up.run_len[w], n = up.own_begin[w + 1] - up.own_begin[w];
                 const uint64_t* mine = e + up.own_begin[w];
-                uint8_t* base = image + blk.wave_offset[w] + uint64_t(up.start_step[w]) * chunk_bytes;
-                const uint32_t row_base = aux24 ? blk.pad[w] : 0u;            // 24-bit words: rows relative to the wavefront's share
-                const uint32_t spare = aux24 ? kOwnerSpareField : blk.nrows + w;
+                uint8_t* stream = image + blk.wave_offset[w];
                 for (uint32_t st = 0; st < steps; ++st) {
-                    uint8_t* chunk = base + uint64_t(st) * chunk_bytes;
+                    const uint32_t S = up.start_step[w] + st;
                     for (uint32_t l = 0; l < kWaveLanes; ++l) {
                         const uint64_t i = uint64_t(l) * steps + st;
-                        const uint32_t pos = i < n ? uint32_t(mine[i] >> 32) : 0u;
-                        put(chunk, l, i < n ? uint32_t(mine[i]) : 0u,
-                            i < n ? (pos - (row_base << kOwnerColBits)) : spare << kOwnerColBits);
+                        const uint32_t value = i < n ? uint32_t(mine[i]) : 0u, pos = i < n ? uint32_t(mine[i] >> 32) : 0u;
+                        if (owner24) {
+                            uint8_t* rec = stream + uint64_t(S / kOwnerRecordSteps) * kOwnerRecordBytes;
+                            const uint32_t j = S % kOwnerRecordSteps;
+                            const uint32_t where = i < n ? pos - (up.own_row[w] << kOwnerColBits) : kOwnerSpareField << kOwnerColBits;
+                            reinterpret_cast<uint32_t*>(rec)[l * kOwnerRecordSteps + j] = value;
+                            uint8_t* a = rec + kOwnerRecordValueBytes + (l * kOwnerRecordSteps + j) * 3;
+                            a[0] = uint8_t(where); a[1] = uint8_t(where >> 8); a[2] = uint8_t(where >> 16);
+                        } else {
+                            put(stream + uint64_t(S) * chunk_bytes, l, value, i < n ? pos : (blk.nrows + w) << kOwnerColBits);
+                        }
                     }
                 }
             }

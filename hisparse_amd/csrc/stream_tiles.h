@@ -82,6 +82,7 @@ constexpr uint32_t kAccumulatorBytes = 8;
 constexpr uint32_t max_block_rows(bool sliced) { return (sliced ? 96u : 32u) * 1024u / kAccumulatorBytes - 1u; }
 constexpr uint32_t kMaxColSlices = 8;
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
+constexpr uint64_t kSliceAffinityMinXBytes = 3u << 20;      // x beyond this: blocks are assigned to XCDs by column slice (tiles_common.h)
 // PAIRS format
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
 constexpr uint32_t kWaveStrideBytes = kChunkBytes * kConsumerWaves;   // chunks of the 14 wavefronts are interleaved in memory
@@ -102,15 +103,29 @@ constexpr uint64_t kDeltaMinSavedBytesFloat = 40u << 20;      // ... 6 us in the
 constexpr double kDenseMeanGap = 320.0;                       // DELTA blocks denser than this (>= 24 elements per row and sub-tile) sum per lane in registers (kBlockDenseRows);
                                                               // sparser ones lose with it (400000 x 100000, gap 512: 89.8 vs 83.2 us), denser ones win big (40000^2, gap 64: 34.5 vs 53.0)
 enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1, kFormatBitmap = 2, kFormatOwner = 3, kFormatPairs24 = 4, kFormatOwner24 = 5 };
-// PAIRS24 / OWNER24: the same two formats with a 24-bit position word -- 7 instead of 8 bytes per element.  A wavefront step is
-// 448 bytes: 64 value dwords, then 64 x 3 bytes (local_row << 13 | local_col, little endian), which the kernel reads as unaligned
-// dwords at byte 256 + 3 * lane.  11 bits of row: PAIRS24 whenever no block has more than 2046 rows (local row 2047 would collide
-// with nothing, but nrows itself -- the spare accumulator -- must fit); OWNER24 stores the row RELATIVE to the wavefront's share
-// (Block::pad[wave] = first local row of the share, shares capped at 2046 rows), 2047 = the wavefront's spare accumulator.
+// PAIRS24: PAIRS with a 24-bit position word -- 7 instead of 8 bytes per element.  A wavefront step is 448 bytes: 64 value dwords, then
+// 64 x 3 bytes (local_row << 13 | local_col, little endian), which the kernel reads as unaligned dwords at byte 256 + 3 * lane.
+// 11 bits of row: whenever no block has more than 2046 rows (nrows itself -- the spare accumulator -- must fit).  Opt-in
+// (HISPARSE_AUX_BITS=24): two loads per step, one of them unaligned, measured slower than the 8-byte form.
 constexpr uint32_t kChunkBytes24 = kWaveLanes * 7;             // 448
 constexpr uint32_t kWaveStrideBytes24 = kChunkBytes24 * kConsumerWaves;
 constexpr uint32_t kAux24MaxRows = 2046;
+// OWNER24 (round 3): OWNER with 24-bit position words in RECORDS of four steps -- 7 bytes per slot with two ALIGNED loads per four
+// steps (round 2's unaligned 448-byte steps took two loads per step and lost).  Record r of a wavefront's stream holds its steps
+// 4r .. 4r+3 (steps are numbered through the block, across units):
+//     bytes    0 .. 1023   64 lanes x { value word of step 4r, 4r+1, 4r+2, 4r+3 }          one global_load_dwordx4 per lane
+//     bytes 1024 .. 1791   64 lanes x 96 bits = the four 24-bit position words, little end first    one global_load_dwordx3 per lane
+// position word = (row - row_base) << 13 | local_col: the row RELATIVE to the first row of the (unit, wavefront) share in 11 bits,
+// 2047 = the wavefront's spare accumulator (padding).  Shares are still cut per unit (balanced_owner_shares), now also so that no
+// share spans more than kOwnerShareRows rows; the share's row_base travels in the high half of Unit::end_step[w] (the step counts of
+// a wavefront stay below 2^16 or the builder keeps the 8-byte OWNER form).  The tail of a wavefront's stream is padded to a whole
+// record with steps nobody consumes.  ogbn-products: 7.06 instead of 8.07 bytes per non-zero.
+constexpr uint32_t kOwnerRecordSteps = 4;
+constexpr uint32_t kOwnerRecordValueBytes = kWaveLanes * 4 * kOwnerRecordSteps;            // 1024
+constexpr uint32_t kOwnerRecordBytes = kOwnerRecordValueBytes + kWaveLanes * 3 * kOwnerRecordSteps;   // 1792
 constexpr uint32_t kOwnerSpareField = 2047;
+constexpr uint32_t kOwnerShareRows = 2047;                     // relative rows 0 .. 2046
+constexpr uint32_t kOwnerStepMask = 0xffffu;                   // Unit::end_step[w] = steps | row_base << 16 in an OWNER24 image
 // OWNER format (float modes, hyper-sparse matrices: ogbn-products, 2.4 M columns, 50 non-zeros per row): the cost there is not the
 // element stream but x -- every row block pulls the WHOLE vector through its CU, sub-tile by sub-tile, so the staged x volume is
 // (rows / rows per block) x 4 cols bytes (3.1 GB per SpMV with 8191-row blocks against 1 GB of matrix).  Rows per block are

@@ -151,6 +151,8 @@ struct UnitPlan {           // host-side companion of a device Unit
     uint32_t start_record[kConsumerWaves]; // record index of the unit's head record in wavefront w's stream
     // OWNER
     uint32_t own_begin[kConsumerWaves + 1]; // wavefront w owns sorted elements [own_begin[w], own_begin[w + 1]) of the unit
+    uint32_t own_row[kConsumerWaves] = {};  // local row of the share's first element (0 for an empty share): OWNER24's row_base ...
+    uint32_t own_last[kConsumerWaves] = {}; // ... and of its last one
 };
 
 struct RowRange { uint32_t row0, nrows, row_part; };
@@ -161,13 +163,26 @@ struct RowRange { uint32_t row0, nrows, row_part; };
 // 64 x steps elements (a row longer than that stays whole), what it leaves goes to the next wavefront.  Against fixed row ownership
 // (a wavefront's rows for the whole block, cut at equal non-zero count over the block) the slowest wavefront of a hyper-sparse unit
 // does 5 steps instead of 5.4 on average on ogbn-products and the image carries 64 chunks per unit instead of 70.
+// max_span (OWNER24: kOwnerShareRows): no share spans more than max_span rows -- its position words carry the row relative to the
+// share's first row in 11 bits.  A share that would is cut at that row; and a share ends no earlier than the row from which the
+// remaining wavefronts can still cover the rest of the unit, max_span rows each (possible whenever the unit's rows span at most
+// 14 x max_span, which the LDS row cap guarantees; the builder re-checks every share).
 // row_of(i) = local row of sorted element i.  Same code on the host and in gpu_tiles.hip.
 template <typename RowOf>
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline void balanced_owner_shares(uint32_t n, RowOf row_of, uint32_t own_begin[kConsumerWaves + 1]) {
+inline void balanced_owner_shares(uint32_t n, RowOf row_of, uint32_t own_begin[kConsumerWaves + 1], uint32_t max_span = 0xffffffffu) {
     uint32_t begin = 0;
+    const uint32_t last_row = n ? row_of(n - 1) : 0u;
+    auto first_at_or_above = [&](uint32_t lo, uint32_t want) {      // first index in [lo, n) whose row is >= want (rows never decrease)
+        uint32_t hi = n;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (row_of(mid) < want) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
     for (uint32_t w = 0; w < kConsumerWaves; ++w) {
         own_begin[w] = begin;
         const uint32_t left = n - begin, waves_left = kConsumerWaves - w;
@@ -179,6 +194,14 @@ inline void balanced_owner_shares(uint32_t n, RowOf row_of, uint32_t own_begin[k
         if (end == begin && left) {                                                    // one row longer than the share: take it whole
             end = begin + (left < steps * kWaveLanes ? left : steps * kWaveLanes);
             while (end < n && row_of(end) == row_of(end - 1)) ++end;
+        }
+        if (max_span != 0xffffffffu && begin < n) {
+            const uint32_t row0 = row_of(begin);
+            if (end > begin && row_of(end - 1) - row0 >= max_span) end = first_at_or_above(begin, row0 + max_span);
+            if (end < n) {
+                const uint64_t room = uint64_t(waves_left - 1) * max_span;          // rows the remaining wavefronts can cover
+                if (uint64_t(last_row) - row_of(end) + 1 > room) end = first_at_or_above(end, uint32_t(uint64_t(last_row) + 1 - room));
+            }
         }
         begin = end;
     }
@@ -218,6 +241,44 @@ inline void assign_workgroups(StreamTiles& out, const std::vector<uint64_t>& blo
         const uint32_t g = groups % 8 == 0 ? (i % 8) * (groups / 8) + i / 8 : i;
         mine[g].swap(by_rank[i]);
     }
+}
+
+// Column-sliced matrices whose x does not fit an XCD's L2 (4 MiB; ogbn-products: 9.8 MB of x, 5 slices): the same rule INSIDE every
+// XCD, but which XCD gets which blocks is decided by column slice.  The blocks, listed slice by slice, are cut into 8 stretches of
+// equal count: an XCD then works on one slice, at most two, and its 32 workgroups pull the same 1/slices of x through the one L2 at
+// about the same time -- every sub-tile is fetched from HBM once per XCD instead of missing in every workgroup that asks for it
+// (with blocks of all slices on every XCD 16 % of the x refills missed L2, and a refill that waits for HBM holds its whole unit up).
+// `slice_of_block[b]`: column slice of block b.  Needs a multiple of 8 workgroups (the kernels' workgroup -> XCD rule); the caller
+// falls back to assign_workgroups otherwise.
+inline void assign_workgroups_by_slice(StreamTiles& out, const std::vector<uint64_t>& block_weight, uint32_t max_workgroups, uint32_t row_parts,
+                                       const std::vector<uint32_t>& slice_of_block, std::vector<std::vector<uint32_t>>& mine) {
+    const uint32_t NB = uint32_t(out.blocks.size());
+    const uint32_t groups = max_workgroups, per_xcd = groups / 8;
+    out.num_workgroups = groups;
+    mine.assign(groups, {});
+    std::vector<uint32_t> order(NB);
+    for (uint32_t b = 0; b < NB; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return slice_of_block[a] < slice_of_block[b]; });
+    // inside an XCD: heaviest block first, each to the workgroup with the least work so far (ties: the fewest blocks).  A stretch of the
+    // slice-by-slice list holds the row partitions in very unequal numbers, so balancing partition by partition (assign_workgroups)
+    // would leave some workgroups with three blocks and others with one; the whole SpMV is what is balanced here, and every
+    // workgroup's blocks are then put in row-partition order (chain_blocks and hs_run_partition rely on that order only).
+    std::vector<uint64_t> load(groups, 0);
+    for (uint32_t x = 0; x < 8; ++x) {
+        const uint32_t lo = uint32_t(uint64_t(NB) * x / 8), hi = uint32_t(uint64_t(NB) * (x + 1) / 8);
+        std::vector<uint32_t> todo(order.begin() + lo, order.begin() + hi);
+        std::stable_sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { return block_weight[a] > block_weight[b]; });
+        for (uint32_t b : todo) {
+            uint32_t best = x * per_xcd;
+            for (uint32_t g = best + 1; g < (x + 1) * per_xcd; ++g)
+                if (load[g] < load[best] || (load[g] == load[best] && mine[g].size() < mine[best].size())) best = g;
+            mine[best].push_back(b);
+            load[best] += block_weight[b] + 16;
+        }
+        for (uint32_t g = x * per_xcd; g < (x + 1) * per_xcd; ++g)
+            std::stable_sort(mine[g].begin(), mine[g].end(), [&](uint32_t a, uint32_t b) { return out.blocks[a].row_part < out.blocks[b].row_part; });
+    }
+    (void)row_parts;
 }
 
 // Final block order: the first block of workgroup g sits at blocks[g] (ONE dependent load before the kernel's first

@@ -127,13 +127,36 @@ void pooled_for(size_t n, unsigned threads, Fn& fn) {
         return;
     }
     if (WorkerPool::get().run(n, threads, [](void* f, size_t i) { (*static_cast<Fn*>(f))(i); }, &fn)) return;
+    // The pool is busy (another context is loading on another thread) or this is a loop inside a task: threads of this call's own --
+    // at most kFallbackThreads of them (the pool already keeps every core busy), the caller included, with the same exception
+    // contract as the pooled path: the first exception a task throws is kept, the remaining indices still run, it is rethrown here.
+    constexpr unsigned kFallbackThreads = 16;
+    threads = std::min(threads, kFallbackThreads);
     std::atomic<size_t> next(0);
+    std::mutex failure_m;
+    std::exception_ptr failure;
+    auto work = [&]() {
+        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            try {
+                fn(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(failure_m);
+                if (!failure) failure = std::current_exception();
+            }
+        }
+    };
     std::vector<std::thread> own;
-    for (unsigned t = 0; t < threads; ++t)
-        own.emplace_back([&]() {
-            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
-        });
+    own.reserve(threads - 1);
+    for (unsigned t = 1; t < threads; ++t) {
+        try {
+            own.emplace_back(work);
+        } catch (...) {      // no more threads to be had (std::system_error): the ones there are, and the caller, do the work
+            break;
+        }
+    }
+    work();
     for (auto& th : own) th.join();
+    if (failure) std::rethrow_exception(failure);
 }
 
 }  // namespace hisparse

@@ -158,15 +158,17 @@ int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows);
  * util_round_csr_matrix_dim (rows to a multiple of 128 * interleave, columns to a multiple of 8), their values converted like
  * csr_matrix_convert_from_float (sw/data_loader.h:76-84), and the device image is built by the same planner and kernels as in
  * hs_load_matrix -- it is byte for byte the image hs_load_matrix builds from csr2cpsr's output of the same matrix
- * (tests/test_gpu_retile.py), so every parity statement carries over.  Column indices inside a row may be in any order; a (row, column)
- * that occurs twice is refused (HS_ERR_BAD_MATRIX: use the CPSR path).  padded_rows / padded_cols (may be NULL) receive the dimensions
- * hs_load_vector / hs_read_result then expect. */
+ * (tests/test_gpu_retile.py), so every parity statement carries over.  Column indices inside a row may be in any order.  A matrix that
+ * holds a (row, column) twice (legal for the reference's formatter: both products are added) is formatted on the host instead --
+ * csr2cpsr + packet assembly + the host builder, i.e. what hs_load_matrix does with such a matrix.  padded_rows / padded_cols (may be
+ * NULL) receive the dimensions hs_load_vector / hs_read_result then expect. */
 int hs_load_matrix_csr(hs_context* ctx, uint32_t num_rows, uint32_t num_cols, const uint32_t* indptr, const uint32_t* indices, const float* values,
                        uint32_t* padded_rows, uint32_t* padded_cols);
 
 /* ---- SpMM (EXTENSION; the reference has no SpMM) ----------------------------------------------------------
  * Y = A X for k dense vectors, column j of X / Y being a packed vector of num_cols / num_rows words (the layouts of hs_load_vector
- * and hs_read_result).  Column j of Y is bit for bit what hs_run gives for column j of X.
+ * and hs_read_result).  Column j of Y is what hs_run gives for column j of X: bit for bit in fixed point; in the float modes within the
+ * float tolerance of the parity contract (the fused kernels add a row's partial sums in another order than the SpMV kernel).
  *   BITMAP images (dense rows -- the pruned-NN layers, which meet batches of activations in practice), one column slice: FUSED, 4
  *     then 2 columns at a time (spmm_bitmap.hip): masks and values are streamed once per group, x interleaved [column][vector];
  *     transformer-50: 6.3 us per column against 13.5 us for an SpMV (profiles/r02_spmm_bitmap.txt).  HISPARSE_SPMM_FUSED=0 turns it off.

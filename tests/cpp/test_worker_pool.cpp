@@ -4,6 +4,7 @@
 #include "tiles_common.h"
 #include <cassert>
 #include <iostream>
+#include <stdexcept>
 using namespace hisparse::dev::detail;
 int main() {
     // sequential jobs of varying size
@@ -51,6 +52,16 @@ int main() {
         parallel_for(64, [&](size_t i) { if (i == 13) throw std::bad_alloc(); });
     } catch (const std::bad_alloc&) { caught = true; }
     assert(caught);
+    // ... also on the fallback path (a loop inside a task runs on threads of its own): the inner exception comes out of the inner
+    // call, every other inner index still runs, and the outer job carries it to its caller
+    std::atomic<int> ran(0);
+    caught = false;
+    try {
+        parallel_for(4, [&](size_t) {
+            parallel_for(40, [&](size_t i) { ran++; if (i == 7) throw std::length_error("inner"); });
+        });
+    } catch (const std::length_error&) { caught = true; }
+    assert(caught && ran == 160);
     std::vector<int> hit(100, 0);
     parallel_for(100, [&](size_t i) { hit[i]++; });
     for (int v : hit) assert(v == 1);

@@ -33,7 +33,7 @@ def _both(csr, impl, vb=0, ob=0, skip=True):
     return cp, xw, y, sb
 
 
-@pytest.mark.parametrize("fmt", ["pairs", "delta", "owner", "bitmap"])
+@pytest.mark.parametrize("fmt", ["pairs", "delta", "owner", "owner24", "bitmap"])
 @pytest.mark.parametrize("impl", [0, 1, 2])
 def test_same_image_as_the_cpsr_path(monkeypatch, fmt, impl):
     monkeypatch.setenv("HISPARSE_STREAM_FORMAT", fmt)
@@ -73,8 +73,12 @@ def test_unsorted_columns_and_explicit_zeros():
 def test_errors():
     ip = np.array([0, 2, 2, 3], dtype=np.uint32)
     with device.SpmvEngine(0) as eng:
-        with pytest.raises(device.DeviceError, match="twice"):
-            eng.load_matrix_csr((3, 10, ip, np.array([4, 4, 1], dtype=np.uint32), np.ones(3, dtype=np.float32)))
+        # the same (row, column) twice: both products count, like in the reference's formatter (formatted on the host then)
+        eng.load_matrix_csr((3, 10, ip, np.array([4, 4, 1], dtype=np.uint32), np.array([1.0, 2.0, 4.0], dtype=np.float32)))
+        assert not eng.stats()["retiled_on_gpu"]
+        eng.load_vector(host.pack_vector(0, np.ones(eng.num_cols, dtype=np.float32)))
+        eng.run()
+        assert orc.unpack_result(0, eng.read_result())[:3].tolist() == [3.0, 0.0, 4.0]
         with pytest.raises(device.DeviceError, match="column"):
             eng.load_matrix_csr((3, 10, ip, np.array([4, 10, 1], dtype=np.uint32), np.ones(3, dtype=np.float32)))
         with pytest.raises(device.DeviceError, match="indptr"):

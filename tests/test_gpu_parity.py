@@ -23,9 +23,10 @@ def stream_format(request, monkeypatch):
     # every parity test runs once per device stream format (hisparse_amd/csrc/stream_tiles.h); DELTA additionally with the
     # per-lane register sums of long-row blocks forced on and off (by default the block's density decides); BITMAP (normally
     # chosen for dense rows only) forced onto every matrix small enough for a mask per 64 columns of every row
-    # "pairs24" / "owner24": the opt-in 7-byte forms (HISPARSE_AUX_BITS=24), taken where the row counts allow
-    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", request.param.split("-")[0].replace("24", ""))
-    if request.param in ("pairs24", "owner24"):
+    # "pairs24": the opt-in 7-byte form of PAIRS (HISPARSE_AUX_BITS=24), taken where the row counts allow; "owner24": OWNER in records of
+    # four steps with 24-bit position words (the default for hyper-sparse float matrices)
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "pairs" if request.param == "pairs24" else request.param.split("-")[0])
+    if request.param == "pairs24":
         monkeypatch.setenv("HISPARSE_AUX_BITS", "24")
     if request.param.endswith("-lane-sums"):
         monkeypatch.setenv("HISPARSE_ROW_RUNS", "0" if "-no-" in request.param else "1")
@@ -50,7 +51,7 @@ def _run_case(impl, m, vb, ob, skip, seed):
     eng.close()
     assert stats["nnz"] == m.nnz
     forced = os.environ["HISPARSE_STREAM_FORMAT"]
-    if forced == "owner" and impl == 0:
+    if forced in ("owner", "owner24") and impl == 0:
         forced = "pairs"                 # OWNER is a float format (4-byte float accumulators); fixed point keeps its 64-bit atomics
     if forced != "bitmap" or cp.num_rows * ((cp.num_cols + 63) // 64) * 8 <= (1 << 30):    # a forced bitmap gives way above 1 GiB of masks
         got_format = device.STREAM_FORMATS[stats["stream_format"]]

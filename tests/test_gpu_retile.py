@@ -17,8 +17,8 @@ FORMATS = ["pairs", "delta", "owner", "pairs24", "owner24"]
 
 
 def _set_format(monkeypatch, fmt):
-    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", fmt.replace("24", ""))
-    if fmt.endswith("24"):
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "pairs" if fmt == "pairs24" else fmt)
+    if fmt == "pairs24":
         monkeypatch.setenv("HISPARSE_AUX_BITS", "24")
     monkeypatch.delenv("HISPARSE_RETILE", raising=False)
 

@@ -1,0 +1,169 @@
+"""ISA invariants of the shipped gfx950 code (CPU test: unbundles hisparse_amd/lib/libhisparse_hip.so and disassembles it).
+
+The SpMV kernels rely on a few things hipcc does not guarantee and that were each found by a failing measurement or a soak
+(DESIGN.md section 4): the element stream is parked in ACCUMULATOR registers that the compiler must never touch on its own, every
+hand-placed stream load sits behind `s_nop 4` (the hazard recogniser does not look into inline asm: scalar base written -> vector
+memory use), every read of a parked register sits behind a counted `s_waitcnt vmcnt`, nothing spills to scratch, and the hot path has
+no memory-side atomics.  A compiler upgrade that breaks one of these must fail HERE, not in a soak three days later.
+"""
+import os
+import re
+import shutil
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "hisparse_amd", "lib", "libhisparse_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _code_objects(tmp_path):
+    """The gfx950 code objects of every translation unit in the library's .hip_fatbin (clang offload bundles, one per .hip file)."""
+    data = open(LIB, "rb").read()
+    out, pos = [], 0
+    while True:
+        at = data.find(MAGIC, pos)
+        if at < 0:
+            break
+        (entries,) = struct.unpack_from("<Q", data, at + len(MAGIC))
+        off = at + len(MAGIC) + 8
+        for _ in range(entries):
+            o, size, tlen = struct.unpack_from("<QQQ", data, off)
+            triple = data[off + 24: off + 24 + tlen].decode()
+            off += 24 + tlen
+            if triple.startswith("hip") and size:
+                assert triple.endswith("gfx950"), f"unexpected offload target {triple}: this library carries gfx950 code only"
+                path = tmp_path / f"co{len(out)}.co"
+                path.write_bytes(data[at + o: at + o + size])
+                out.append(str(path))
+        pos = at + len(MAGIC)
+    return out
+
+
+def _metadata(co):
+    """kernel name -> {key: int} from the code object's AMDGPU metadata note."""
+    text = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    kernels, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"\s+(?:- )?\.(\w+):\s+(\S+)\s*$", line)
+        if not m:
+            continue
+        key, val = m.groups()
+        if line.lstrip().startswith("- .") and key in ("agpr_count", "args"):     # first key of a kernel entry (keys are sorted)
+            cur = {}
+        if cur is None:
+            continue
+        if key == "name" and not line.lstrip().startswith("- ") and "symbol" not in cur:
+            cur["name"] = val
+        if key == "symbol":
+            cur["symbol"] = val
+            kernels[cur.get("name", val)] = cur
+        if val.isdigit():
+            cur[key] = int(val)
+    return kernels
+
+
+def _disassembly(co):
+    """symbol -> list of instruction strings."""
+    text = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+    funcs, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        if cur is not None and line.startswith("\t"):
+            ins = line.split("//")[0].strip()
+            if ins:
+                cur.append(ins)
+    return funcs
+
+
+@pytest.fixture(scope="module")
+def shipped(tmp_path_factory):
+    if not os.path.exists(LIB):
+        pytest.skip("libhisparse_hip.so has not been built")
+    if not (os.path.exists(f"{LLVM}/llvm-objdump") and os.path.exists(f"{LLVM}/llvm-readelf")):
+        pytest.skip("no llvm-objdump / llvm-readelf")
+    tmp = tmp_path_factory.mktemp("isa")
+    meta, code = {}, {}
+    for co in _code_objects(tmp):
+        meta.update(_metadata(co))
+        code.update(_disassembly(co))
+    shutil.rmtree(tmp, ignore_errors=True)
+    assert meta and code
+    return meta, code
+
+
+ROWBLOCK = re.compile(r"spmv_rowblock_kernelILb([01])ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])E")
+AGPR = re.compile(r"\ba(\d+|\[\d+:\d+\])")
+
+
+def _hot_kernels(names):
+    """the kernels of the SpMV hot path: the product variants of spmv_rowblock_kernel (ablate == 0), spmv_bitmap_kernel, the slice combine"""
+    hot = []
+    for n in names:
+        m = ROWBLOCK.search(n)
+        if m and int(m.group(3)) == 0:
+            hot.append(n)
+        elif "spmv_bitmap_kernel" in n and re.search(r"spmv_bitmap_kernelILb[01]ELi0E", n):
+            hot.append(n)
+        elif "combine_slices_kernel" in n:
+            hot.append(n)
+    return hot
+
+
+def test_hot_kernels_have_no_scratch_no_memory_atomics_no_mfma(shipped):
+    meta, code = shipped
+    hot = _hot_kernels(meta)
+    assert len([n for n in hot if "rowblock" in n]) >= 8 and any("bitmap" in n for n in hot) and any("combine" in n for n in hot), hot
+    for n in hot:
+        assert meta[n].get("private_segment_fixed_size", 0) == 0, f"{n} spills to scratch"
+        body = code[n]
+        bad = [i for i in body if re.match(r"(global|flat|buffer)_atomic", i)]
+        assert not bad, f"{n}: memory-side atomics on the hot path: {bad[:3]}"
+        assert not [i for i in body if i.startswith("v_mfma")], f"{n}: MFMA in a bandwidth-bound gather kernel"
+        assert not [i for i in body if i.startswith("scratch_")], f"{n}: scratch access"
+
+
+def test_element_ring_lives_in_accumulator_registers_behind_counted_waits(shipped):
+    meta, code = shipped
+    rowblock = [n for n in meta if ROWBLOCK.search(n) and int(ROWBLOCK.search(n).group(3)) == 0]     # the product variants (profiling builds aside)
+    assert len(rowblock) >= 8
+    for n in rowblock:
+        assert meta[n]["agpr_count"] == 32, f"{n}: the ring is a0..a31, the compiler allocates none itself"
+        body = code[n]
+        loads = reads = 0
+        for k, ins in enumerate(body):
+            if not AGPR.search(ins.split(" ", 1)[1] if " " in ins else ""):
+                continue
+            prev = body[k - 1] if k else ""
+            if ins.startswith("global_load_dword"):
+                # a hand-placed stream load: behind `s_nop 4` (scalar base -> vector memory hazard), or the second load of the same asm block
+                loads += 1
+                ok = prev == "s_nop 4" or (prev.startswith("global_load_dword") and AGPR.search(prev))
+                assert ok, f"{n}: `{ins}` follows `{prev}` instead of `s_nop 4`"
+            elif ins.startswith("v_accvgpr_read_b32"):
+                # a parked register becomes a compiler-visible value only behind the counted wait of the same asm block
+                reads += 1
+                ok = prev.startswith("s_waitcnt vmcnt(") or prev.startswith("v_accvgpr_read_b32")
+                assert ok, f"{n}: `{ins}` follows `{prev}` instead of a counted s_waitcnt"
+            else:
+                raise AssertionError(f"{n}: `{ins}` touches an accumulator register outside the hand-written ring")
+        assert loads and reads, f"{n}: no ring found ({loads} loads, {reads} reads)"
+
+
+def test_stream_loads_are_non_temporal_and_loaders_use_lds_dma(shipped):
+    meta, code = shipped
+    for n in meta:
+        m = ROWBLOCK.search(n)
+        if not m or int(m.group(3)) != 0:
+            continue
+        body = code[n]
+        stream = [i for i in body if i.startswith("global_load_dword") and AGPR.search(i.split(" ", 1)[1])]
+        assert stream and all(i.endswith(" nt") for i in stream), f"{n}: stream loads without the nt policy"
+        assert any("global_load_lds_dwordx4" in i for i in body), f"{n}: the x ring is not refilled by LDS-DMA"
+        assert any(i.startswith("s_setprio") for i in body), f"{n}: loader wavefronts without raised priority"

@@ -366,17 +366,22 @@ def test_owner_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypa
     """Hyper-sparse float matrices pick the OWNER format: float accumulators, wavefront-private rows (checked inside the emulator:
     sorted lane-major runs, one owner per row, padding at the wavefront's spare accumulator); y matches the oracle."""
     monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
-    monkeypatch.setenv("HISPARSE_AUX_BITS", "24")
     if slices:
         monkeypatch.setenv("HISPARSE_COL_SLICES", str(slices))
     csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=nnz, b=0.5, c=2.0, seed=12)
     cp = host.format_matrix(csr, impl, skip_empty_rows=True)
     assert cp.num_rows * cp.num_cols / cp.nnz > 20000
     xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 12, impl))
+    auto = build(cp, impl, wgs)
+    assert auto["format"] in ("owner", "owner24")      # the 7-byte records unless the 11-bit row cap makes them larger than 8-byte chunks
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "owner24")
     t = build(cp, impl, wgs)
-    assert t["format"] == "owner24" and t["nnz"] == cp.nnz and t["elements"] >= cp.nnz       # 24-bit position words: shares <= 2046 rows
-    assert len(t["image"]) == t["elements"] * 7
-    monkeypatch.delenv("HISPARSE_AUX_BITS")
+    assert t["format"] == "owner24" and t["nnz"] == cp.nnz and t["elements"] >= cp.nnz       # 24-bit position words: shares <= 2047 rows
+    # whole records of four steps per wavefront and block: 7 bytes per slot + at most 3 dead steps per (block, wavefront)
+    assert len(t["image"]) % 1792 == 0 and t["elements"] * 7 <= len(t["image"]) <= t["elements"] * 7 + len(t["blocks"]) * 14 * 3 * 448
+    if auto["format"] == "owner24":
+        assert np.array_equal(auto["image"], t["image"])
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "owner")
     t32 = build(cp, impl, wgs)
     assert t32["format"] == "owner" and len(t32["image"]) == t32["elements"] * 8
     assert cases.float_close(tile_emulator.run(t32, impl, xw, cp.num_rows), oracle_y(cp, impl, xw))
@@ -412,3 +417,41 @@ def test_worker_pool(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", f"-I{root}/include", f"-I{root}/hisparse_amd/csrc", f"{root}/tests/cpp/test_worker_pool.cpp", "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "WORKER POOL OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("impl,ob", [(0, 8), (2, 64)])
+def test_blocks_go_to_xcds_by_column_slice(impl, ob, monkeypatch):
+    """Column-sliced matrices whose x outgrows an XCD's L2 (forced here: HISPARSE_XCD_AFFINITY=1): logical workgroups
+    [x * G/8, (x+1) * G/8) -- XCD x -- hold blocks of at most two column slices, every workgroup has work, every block is run
+    once, the chains stay ordered by row partition (hs_run_partition), and y is what the oracle says."""
+    if impl == 2 and os.environ.get("HISPARSE_STREAM_FORMAT") in ("pairs", "pairs24", "delta", "bitmap"):
+        monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "owner24")
+    if os.environ.get("HISPARSE_STREAM_FORMAT") == "bitmap":
+        pytest.skip("BITMAP images have their own builder")
+    monkeypatch.setenv("HISPARSE_COL_SLICES", "5")
+    monkeypatch.setenv("HISPARSE_MAX_ROWS", "500")
+    monkeypatch.setenv("HISPARSE_XCD_AFFINITY", "1")
+    csr = host.CSRMatrix.generate("powerlaw", 30000, 90000, a=400000, b=0.4, c=1.0 if impl == 0 else 2.0, seed=3)
+    cp = host.format_matrix(csr, impl, ob_bank=ob, skip_empty_rows=True)      # several row partitions
+    assert cp.num_row_partitions > 1
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 3, impl))
+    G = 16
+    t = build(cp, impl, G)
+    assert t["col_slices"] == 5 and t["num_workgroups"] == G and len(t["blocks"]) >= G
+    slice_of = t["blocks"]["out_offset"] // cp.num_rows
+    for xcd in range(8):
+        seen = set()
+        for g in range(xcd * G // 8, (xcd + 1) * G // 8):
+            mine = t["block_order"][t["wg_first"][g]: t["wg_first"][g + 1]]
+            assert len(mine) >= 1
+            parts = t["blocks"]["row_part"][mine]
+            assert (np.diff(parts.astype(np.int64)) >= 0).all()
+            seen |= set(int(s) for s in slice_of[mine])
+        assert len(seen) <= 2, seen
+    want = oracle_y(cp, impl, xw)
+    got = tile_emulator.run(t, impl, xw, cp.num_rows)
+    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+    y = np.zeros(cp.num_rows, dtype=np.uint32)
+    for j in range(cp.num_row_partitions):      # the reference's launch loop: one row partition at a time
+        y = tile_emulator.run(t, impl, xw, cp.num_rows, row_part_filter=j, y_init=y)
+    assert np.array_equal(y, want) if impl == 0 else cases.float_close(y, want)

@@ -97,40 +97,62 @@ def _block_delta(image, blk, units, x_words, ys, is_float):
             step[w] = end
 
 
+OWNER_RECORD_BYTES, OWNER_RECORD_STEPS, OWNER_SPARE = 1792, 4, 2047
+
+
+def _owner24_step(image, base, S):
+    """(value words, 24-bit position words) of step S of a wavefront's OWNER24 stream: slot S % 4 of record S // 4 -- 64 lanes x 4
+    value words, then 64 lanes x 4 x 3 bytes."""
+    rec = image[base + (S // OWNER_RECORD_STEPS) * OWNER_RECORD_BYTES: base + (S // OWNER_RECORD_STEPS + 1) * OWNER_RECORD_BYTES]
+    j = S % OWNER_RECORD_STEPS
+    val = rec[:1024].view(np.uint32).reshape(WAVE, OWNER_RECORD_STEPS)[:, j]
+    a = rec[1024:].reshape(WAVE, OWNER_RECORD_STEPS, 3)[:, j, :].astype(np.uint32)
+    return val, a[:, 0] | (a[:, 1] << 8) | (a[:, 2] << 16)
+
+
 def _block_owner(image, blk, units, x_words, ys, is_float, aux24=False):
     """OWNER (float only): per-wavefront contiguous 512-byte chunks of {value, row << 13 | col}; lane l holds a consecutive run of
     the wavefront's share, rows never decrease from lane to lane and step to step, no row is shared between wavefronts WITHIN A UNIT
-    (the unit barrier orders the accumulator writes, so the shares are cut per unit -- aux24: per block), padding aims a zero at the
-    wavefront's own spare accumulator nrows + w; the shares of a unit differ by at most one step unless a row is longer than a share."""
+    (the unit barrier orders the accumulator writes, so the shares are cut per unit), padding aims a zero at the wavefront's own spare
+    accumulator nrows + w; the shares of a unit differ by at most one step unless a row is longer than a share.
+    aux24 = OWNER24: the same steps in records of four (_owner24_step), 24-bit position words whose row is relative to the first row
+    of the (unit, wavefront) share -- carried in the high half of Unit.end_step[w] -- with 2047 = the spare accumulator."""
     assert is_float
     nrows = int(blk["nrows"])
     step = [0] * CONSUMERS
-    owner_of = {}
     for u in range(int(blk["unit_begin"]), int(blk["unit_end"])):
         unit = units[u]
         col0, ncols = int(unit["col0"]), int(unit["ncols"])
         xt = x_words[col0: col0 + ncols]
-        if not aux24:
-            owner_of = {}
+        owner_of = {}
         for w in range(CONSUMERS):
-            end = int(unit["end_step"][w])
+            end, share0 = int(unit["end_step"][w]), 0
+            if aux24:
+                end, share0 = end & 0xFFFF, end >> 16
+                if u + 1 == int(blk["unit_end"]):
+                    assert int(blk["total_steps"][w]) == end
+                if u == int(blk["unit_begin"]):
+                    assert int(blk["first_end"][w]) == int(unit["end_step"][w])
             base = int(blk["wave_offset"][w])
+            assert end >= step[w]
             if end == step[w]:
                 continue
-            cb = 448 if aux24 else CHUNK_BYTES
-            pairs = [_chunk(image, base + st * cb, aux24) for st in range(step[w], end)]
+            if aux24:
+                pairs = [_owner24_step(image, base, st) for st in range(step[w], end)]
+            else:
+                pairs = [_chunk(image, base + st * CHUNK_BYTES, False) for st in range(step[w], end)]
             val, where = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
             row, col = (where >> 13).astype(np.int64), (where & 8191).astype(np.int64)
-            if aux24:       # rows relative to the wavefront's share (Block.pad[w]); 2047 = the wavefront's spare accumulator
-                share0 = int(blk["pad"][w])
-                assert ((row <= 2046) | (row == 2047)).all()
-                row = np.where(row == 2047, nrows + w, row + share0)
+            if aux24:
+                assert ((row <= 2046) | (row == OWNER_SPARE)).all()
+                assert (row != OWNER_SPARE).any() and row[row != OWNER_SPARE].min() == 0      # row_base IS the share's first row
+                row = np.where(row == OWNER_SPARE, nrows + w, row + share0)
             order = row.T.reshape(-1)                                   # lane-major: lane 0's run, then lane 1's, ...
             assert (np.diff(order) >= 0).all()                          # sorted by row across (lane, step)
             pad = row == nrows + w
             assert ((row < nrows) | pad).all() and (val[pad] == 0).all() and (col[~pad] < ncols).all()
             for r in np.unique(row[~pad]):
-                assert owner_of.setdefault(int(r), w) == w              # one owner per row for the whole block
+                assert owner_of.setdefault(int(r), w) == w              # one owner per row while the unit lasts
             _accumulate(ys, True, row[~pad], val[~pad], xt[col[~pad]])
             step[w] = end
 
