@@ -730,23 +730,15 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 consumer_begin<kFloat, kRing, kDepth, kOwner>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave],
                                                                blk->first_end[wave]);
         }
-        // Prologue: the consumer wavefronts zero the accumulators (PE banks start at zero, pe.h:131-135) while the two loader wavefronts
-        // bring sub-tile 0 in by LDS-DMA.  (Until round 3 every thread copied its share of sub-tile 0 through registers: the consumers'
-        // copy then waited behind their own primed stream loads -- vmcnt retires in order -- i.e. for a full HBM round trip although x
-        // sits in L2: 4.3 us of prologue per block in the timeline build, HISPARSE_ABLATE=512.)
-        if (!(kAblate & 16)) {
-            constexpr uint32_t kConsumerThreads = kConsumerWaves * kWaveLanes;
-            if (loader) {
-                if (U > 0) {
-                    dma_fill_x(xs, x, blk->first_col0, blk->first_ncols, wave - kConsumerWaves, lane);
-                    dma_wait<0>();
-                }
-            } else if (kOwner) {
-                for (uint32_t i = tid; i < nrows + kConsumerWaves; i += kConsumerThreads) reinterpret_cast<float*>(ys)[i] = 0.0f;
-            } else {
-                for (uint32_t i = tid; i <= nrows; i += kConsumerThreads) ys[i] = 0;
-            }
-        }
+        // Prologue.  (Measured in round 3, timeline build HISPARSE_ABLATE=512: 4.3 us pass between a workgroup's first wavefront
+        // entering and this barrier, and most of that is the LAUNCH ramp -- the 16 wavefronts of a 1024-thread workgroup are started
+        // 2 - 4 us apart, the loaders last -- not this code: letting the loaders DMA sub-tile 0 while only the consumers zero changed
+        // nothing, same box: ogbl-ppa 57.5 / 57.4 us, mouse_gene 38.5 / 38.2 us.)
+        if (kOwner) {
+            if (!(kAblate & 16)) for (uint32_t i = tid; i < nrows + kConsumerWaves; i += kThreads) reinterpret_cast<float*>(ys)[i] = 0.0f;
+        } else
+        if (!(kAblate & 16)) for (uint32_t i = tid; i <= nrows; i += kThreads) ys[i] = 0;           // PE banks start at zero (pe.h:131-135)
+        if (U > 0 && !(kAblate & 16)) fill_x<kSubTileCols / 4 / kThreads, kThreads>(xs, x, blk->first_col0, blk->first_ncols, tid);
         __syncthreads();
         timeline_stamp<kAblate>(block_no, wave, lane, 1);
 

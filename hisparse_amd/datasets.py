@@ -52,10 +52,27 @@ CONFIGS = {
     # (`a` counts the entries DRAWN; R-MAT repeats itself a lot at this density -- 62.2 M draws leave ~42.4 M distinct entries)
     "ogbl_ppa_rmat": Config("ogbl_ppa_rmat", "fixed", 576289, 576289, "rmat", 62.2e6, 1.0, 1.0, 42, ""),
     "ogbn_products_rmat": Config("ogbn_products_rmat", "float_stall", 2449029, 2449029, "rmat", 161e6, 1.0, 1.0, 43, ""),
+    # the rest of the reference's benchmark list (sw/bm.sh:3-17; shapes and non-zero counts from the file names and paper Table 2;
+    # skew exponents: guesses by graph family -- social graphs with heavy hubs steeper than the co-star / protein graphs)
+    "gplus": Config("gplus", "fixed", 107614, 107614, "powerlaw", 13673453, 0.45, 1.0, 45, "gplus_108K_13M_csr_float32.npz"),
+    "hollywood": Config("hollywood", "fixed", 1069126, 1069126, "powerlaw", 112751422, 0.35, 1.0, 46, "hollywood_1M_113M_csr_float32.npz"),
+    "pokec": Config("pokec", "fixed", 1632803, 1632803, "powerlaw", 30622564, 0.30, 1.0, 47, "pokec_1633K_31M_csr_float32.npz"),
+    "transformer_60": Config("transformer_60", "float_pob", 512, 33288, "bernoulli", 0, 0.4, 0.05, 60, "transformer_60_512_33288_csr_float32.npz"),
+    "transformer_70": Config("transformer_70", "float_pob", 512, 33288, "bernoulli", 0, 0.3, 0.05, 70, "transformer_70_512_33288_csr_float32.npz"),
+    "transformer_80": Config("transformer_80", "float_pob", 512, 33288, "bernoulli", 0, 0.2, 0.05, 80, "transformer_80_512_33288_csr_float32.npz"),
+    "transformer_90": Config("transformer_90", "float_pob", 512, 33288, "bernoulli", 0, 0.1, 0.05, 90, "transformer_90_512_33288_csr_float32.npz"),
+    "transformer_95": Config("transformer_95", "float_pob", 512, 33288, "bernoulli", 0, 0.05, 0.05, 95, "transformer_95_512_33288_csr_float32.npz"),
     # small relatives for tests / smoke
     "ppa_small": Config("ppa_small", "fixed", 40000, 70000, "powerlaw", 1400000, 0.35, 1.0, 7, ""),
     "nn_small": Config("nn_small", "float_pob", 512, 33288, "bernoulli", 0, 0.05, 0.05, 95, ""),
 }
+
+
+# sw/bm.sh's sweep, in its order, with the fixed-point throughput the paper reports for each on the U280 (GOPS, Table 3) -- the
+# reference's own bar per matrix.  bm.sh runs every matrix in the numeric mode of the bitstream it is given; Table 3 is the fixed one.
+BM_LIST = [("gplus", 21.2), ("ogbl_ppa", 24.4), ("hollywood", 24.9), ("pokec", 11.2), ("ogbn_products", 20.6), ("mouse_gene", 27.2),
+           ("transformer_50", 21.9), ("transformer_60", 18.9), ("transformer_70", 16.5), ("transformer_80", 14.8), ("transformer_90", 9.7),
+           ("transformer_95", 5.7)]
 
 
 def load(name, path=None, scale=1.0):
