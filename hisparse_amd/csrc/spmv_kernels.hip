@@ -216,6 +216,8 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+template <bool kFloat> struct OwnerSum { using type = float; };
+template <> struct OwnerSum<false> { using type = uint32_t; };
 // ---- the consumer side of one row block: stream this wavefront's chunks / records through all sub-tiles of the block ----
 template <bool kFloat>
 struct Consumer {
@@ -236,7 +238,7 @@ struct Consumer {
     prod_t run_sum = 0;        // ... and this lane's share of that sum
     uint32_t lane_row = 0;     // DELTA dense rows: the row this LANE is on (its run of consecutive elements rarely leaves it) ...
     typename Rows<kFloat>::sum_t lane_sum = 0;   // ... and the lane's private sum on it, flushed to LDS when the row changes
-    float own_sum = 0;         // OWNER: the lane's fp32 sum on lane_row (accumulators are floats, touched by this wavefront only)
+    typename OwnerSum<kFloat>::type own_sum = 0;   // OWNER: the lane's sum on lane_row (4-byte accumulators touched by this wavefront only: fp32, or saturating Q8.24)
     uint32_t spare = 0;        // OWNER: the wavefront's own spare accumulator (local row nrows + wave)
     uint32_t row_base = 0;     // OWNER24: first local row of the wavefront's share of the current unit (rows are stored relative to it)
     uint32_t lane_off12 = 0;   // OWNER24: lane * 12, the lane's offset among a record's position words
@@ -373,30 +375,50 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
 // the same step flush different rows (the lower lane's old row is below its new row, which is at most the higher lane's first
 // row).  Only at the end of a unit, when every lane hands its last row over, can neighbours hold the same row: one segmented
 // wavefront reduction first.
-__device__ __forceinline__ void owner_flush(float* ys32, uint32_t row, float sum) {
-    float a = ys32[row];
-    a += sum;
-    ys32[row] = a;
+// The arithmetic of an OWNER accumulator (4 bytes, touched by one wavefront only).  Float: fp32 product and sum, like the float PEs.
+// Fixed point (OWNER24 only): Q8.24 products (rounded / saturated one by one) added with SATURATING unsigned adds -- min(a + b, 2^32-1)
+// is associative and commutative on non-negative terms, so any order of such adds gives min(sum, 2^32-1) = the PE's saturating running
+// sum (pe.h:72), bit for bit, in four bytes instead of the eight the atomic paths need for their exact 64-bit sums.
+template <bool kFloat>
+struct OwnerOps;
+template <>
+struct OwnerOps<true> {
+    using val_t = float;
+    static __device__ __forceinline__ val_t product(uint32_t mat, uint32_t xv) { return __uint_as_float(mat) * __uint_as_float(xv); }   // pe-stall.h:52
+    static __device__ __forceinline__ val_t add(val_t a, val_t b) { return a + b; }
+};
+template <>
+struct OwnerOps<false> {
+    using val_t = uint32_t;
+    static __device__ __forceinline__ val_t product(uint32_t mat, uint32_t xv) { return q8_24_mul(mat, xv); }
+    static __device__ __forceinline__ val_t add(val_t a, val_t b) { return __builtin_elementwise_add_sat(a, b); }      // v_add_u32 ... clamp
+};
+template <bool kFloat>
+__device__ __forceinline__ void owner_flush(typename OwnerOps<kFloat>::val_t* ys32, uint32_t row, typename OwnerOps<kFloat>::val_t sum) {
+    ys32[row] = OwnerOps<kFloat>::add(ys32[row], sum);
 }
-__device__ __forceinline__ void owner_end_of_unit(Consumer<true>& c) {
-    float* ys32 = reinterpret_cast<float*>(c.ys);
+template <bool kFloat>
+__device__ __forceinline__ void owner_end_of_unit(Consumer<kFloat>& c) {
+    using Ops = OwnerOps<kFloat>;
+    using val_t = typename Ops::val_t;
+    val_t* ys32 = reinterpret_cast<val_t*>(c.ys);
     const uint32_t row = c.lane_row;
-    float sum = c.own_sum;
+    val_t sum = c.own_sum;
     const bool live = row != c.spare;                           // lanes that saw only padding have nothing to hand over
     const uint32_t above = __shfl_down(row, 1, kWaveLanes);
     const bool same_above = live && c.lane + 1 < kWaveLanes && above == row;
     if (__ballot(same_above) == 0) {                            // the usual case in a hyper-sparse unit: all rows distinct
-        if (live) owner_flush(ys32, row, sum);
+        if (live) owner_flush<kFloat>(ys32, row, sum);
     } else {
         // equal rows are contiguous lanes: suffix sums inside every run of equal rows, the run's first lane writes
 #pragma unroll
         for (uint32_t d = 1; d < kWaveLanes; d <<= 1) {
-            const float s2 = __shfl_down(sum, d, kWaveLanes);
+            const val_t s2 = __shfl_down(sum, d, kWaveLanes);
             const uint32_t r2 = __shfl_down(row, d, kWaveLanes);
-            if (c.lane + d < kWaveLanes && r2 == row) sum += s2;
+            if (c.lane + d < kWaveLanes && r2 == row) sum = Ops::add(sum, s2);
         }
         const uint32_t below = __shfl_up(row, 1, kWaveLanes);
-        if (live && (c.lane == 0 || below != row)) owner_flush(ys32, row, sum);
+        if (live && (c.lane == 0 || below != row)) owner_flush<kFloat>(ys32, row, sum);
     }
     c.lane_row = c.spare;
     c.own_sum = 0;
@@ -502,10 +524,10 @@ __device__ __forceinline__ bool consume_round_owner(Consumer<true>& c, std::inte
 // Steps are numbered through the block; record r holds steps 4r .. 4r+3, which may belong to different units (the unit test sits in
 // front of every step, as above).  A position word holds the row relative to the first row of the wavefront's share of the CURRENT
 // unit (Consumer::row_base, from the high half of Unit::end_step), 2047 = the wavefront's spare accumulator.
-template <int kAblate>
-__device__ __forceinline__ bool owner24_next_unit(Consumer<true>& c, uint32_t s) {      // false: the block is finished
+template <bool kFloat, int kAblate>
+__device__ __forceinline__ bool owner24_next_unit(Consumer<kFloat>& c, uint32_t s) {      // false: the block is finished
     while (s == c.end) {               // this wavefront finished sub-tile u (possibly with no work in it)
-        if (!(kAblate & 1)) owner_end_of_unit(c);
+        if (!(kAblate & 1)) owner_end_of_unit<kFloat>(c);
         if (!(kAblate & 8)) lds_barrier();
         if (++c.u == c.U) return false;
         const uint32_t packed = c.next_end;
@@ -517,85 +539,90 @@ __device__ __forceinline__ bool owner24_next_unit(Consumer<true>& c, uint32_t s)
     }
     return true;
 }
-__device__ __forceinline__ uint32_t owner24_row(const Consumer<true>& c, uint32_t where) {
+template <bool kFloat>
+__device__ __forceinline__ uint32_t owner24_row(const Consumer<kFloat>& c, uint32_t where) {
     const uint32_t field = where >> kOwnerColBits;
     return field == kOwnerSpareField ? c.spare : c.row_base + field;
 }
-template <int kAblate>
-__device__ __forceinline__ void owner24_one(Consumer<true>& c, uint32_t mat, uint32_t where) {
-    const uint32_t row = owner24_row(c, where), col = where & (kSubTileCols - 1u);
+template <bool kFloat, int kAblate>
+__device__ __forceinline__ void owner24_one(Consumer<kFloat>& c, uint32_t mat, uint32_t where) {
+    using Ops = OwnerOps<kFloat>;
+    using val_t = typename Ops::val_t;
+    const uint32_t row = owner24_row<kFloat>(c, where), col = where & (kSubTileCols - 1u);
     if (kAblate & 1) {
         asm volatile("" ::"v"(mat), "v"(row), "v"(col));
         return;
     }
-    float* ys32 = reinterpret_cast<float*>(c.ys);
+    val_t* ys32 = reinterpret_cast<val_t*>(c.ys);
     const bool leaving = row != c.lane_row;     // per lane; the very first step of a unit leaves the spare accumulator (adds 0)
-    float old = 0.0f;
+    val_t old = 0;
     if (leaving) old = ys32[c.lane_row];
     const uint32_t xv = c.xb[col];
-    const float prod = __uint_as_float(mat) * __uint_as_float(xv);     // one fp32 multiply, like the float PEs (pe-stall.h:52)
+    const val_t prod = Ops::product(mat, xv);
     if (leaving) {
-        ys32[c.lane_row] = old + c.own_sum;
+        ys32[c.lane_row] = Ops::add(old, c.own_sum);
         c.lane_row = row;
         c.own_sum = 0;
     }
-    c.own_sum += prod;
+    c.own_sum = Ops::add(c.own_sum, prod);
 }
 // steps s and s + 1 (see consume_pair_owner for why the four LDS reads may go out together)
-template <int kAblate>
-__device__ __forceinline__ bool owner24_pair(Consumer<true>& c, uint32_t s, uint32_t mat0, uint32_t where0, uint32_t mat1, uint32_t where1) {
+template <bool kFloat, int kAblate>
+__device__ __forceinline__ bool owner24_pair(Consumer<kFloat>& c, uint32_t s, uint32_t mat0, uint32_t where0, uint32_t mat1, uint32_t where1) {
+    using Ops = OwnerOps<kFloat>;
+    using val_t = typename Ops::val_t;
     if ((kAblate & 1) || s == c.end || s + 1 == c.end) {      // a unit ends at or inside the pair: one step at a time
-        if (!owner24_next_unit<kAblate>(c, s)) return false;
-        owner24_one<kAblate>(c, mat0, where0);
-        if (!owner24_next_unit<kAblate>(c, s + 1)) return false;
-        owner24_one<kAblate>(c, mat1, where1);
+        if (!owner24_next_unit<kFloat, kAblate>(c, s)) return false;
+        owner24_one<kFloat, kAblate>(c, mat0, where0);
+        if (!owner24_next_unit<kFloat, kAblate>(c, s + 1)) return false;
+        owner24_one<kFloat, kAblate>(c, mat1, where1);
         return true;
     }
-    const uint32_t row0 = owner24_row(c, where0), col0 = where0 & (kSubTileCols - 1u);
-    const uint32_t row1 = owner24_row(c, where1), col1 = where1 & (kSubTileCols - 1u);
-    float* ys32 = reinterpret_cast<float*>(c.ys);
+    const uint32_t row0 = owner24_row<kFloat>(c, where0), col0 = where0 & (kSubTileCols - 1u);
+    const uint32_t row1 = owner24_row<kFloat>(c, where1), col1 = where1 & (kSubTileCols - 1u);
+    val_t* ys32 = reinterpret_cast<val_t*>(c.ys);
     const bool leaving0 = row0 != c.lane_row, leaving1 = row1 != row0;
-    float old0 = 0.0f, old1 = 0.0f;
+    val_t old0 = 0, old1 = 0;
     if (leaving0) old0 = ys32[c.lane_row];
     if (leaving1) old1 = ys32[row0];
     const uint32_t xv0 = c.xb[col0], xv1 = c.xb[col1];
-    const float prod0 = __uint_as_float(mat0) * __uint_as_float(xv0), prod1 = __uint_as_float(mat1) * __uint_as_float(xv1);
+    const val_t prod0 = Ops::product(mat0, xv0), prod1 = Ops::product(mat1, xv1);
     if (leaving0) {
-        ys32[c.lane_row] = old0 + c.own_sum;
+        ys32[c.lane_row] = Ops::add(old0, c.own_sum);
         c.own_sum = 0;
     }
-    c.own_sum += prod0;
+    c.own_sum = Ops::add(c.own_sum, prod0);
     if (leaving1) {
-        ys32[row0] = old1 + c.own_sum;
+        ys32[row0] = Ops::add(old1, c.own_sum);
         c.own_sum = 0;
     }
-    c.own_sum += prod1;
+    c.own_sum = Ops::add(c.own_sum, prod1);
     c.lane_row = row1;
     return true;
 }
 // one record (ring slot K): take it, put the record kDepth further on in flight in its place, then its four steps
-template <int kAblate, int kDepth, int K>
-__device__ __forceinline__ bool consume_record_owner24(Consumer<true>& c) {
+template <bool kFloat, int kAblate, int kDepth, int K>
+__device__ __forceinline__ bool consume_record_owner24(Consumer<kFloat>& c) {
     const uint32_t r = c.base + K;
     uint32_t v[4], w[3];
     Ring<3>::template take<K, kDepth>(v, w);
     Ring<3>::template issue<K>(c.stream, min(r + kDepth, c.last) * kOwnerRecordBytes, c.lane_off, c.lane_off12);
     const uint32_t where0 = w[0] & 0xffffffu, where1 = __builtin_amdgcn_alignbit(w[1], w[0], 24) & 0xffffffu;
     const uint32_t where2 = __builtin_amdgcn_alignbit(w[2], w[1], 16) & 0xffffffu, where3 = w[2] >> 8;
-    if (!owner24_pair<kAblate>(c, 4 * r, v[0], where0, v[1], where1)) return false;
-    return owner24_pair<kAblate>(c, 4 * r + 2, v[2], where2, v[3], where3);
+    if (!owner24_pair<kFloat, kAblate>(c, 4 * r, v[0], where0, v[1], where1)) return false;
+    return owner24_pair<kFloat, kAblate>(c, 4 * r + 2, v[2], where2, v[3], where3);
 }
-template <int kAblate, int kDepth, int... Ks>
-__device__ __forceinline__ bool consume_round_owner24(Consumer<true>& c, std::integer_sequence<int, Ks...>) {
-    return (consume_record_owner24<kAblate, kDepth, Ks>(c) && ...);
+template <bool kFloat, int kAblate, int kDepth, int... Ks>
+__device__ __forceinline__ bool consume_round_owner24(Consumer<kFloat>& c, std::integer_sequence<int, Ks...>) {
+    return (consume_record_owner24<kFloat, kAblate, kDepth, Ks>(c) && ...);
 }
-template <int... Ks>
-__device__ __forceinline__ void prime_ring_owner24(Consumer<true>& c, std::integer_sequence<int, Ks...>) {
+template <bool kFloat, int... Ks>
+__device__ __forceinline__ void prime_ring_owner24(Consumer<kFloat>& c, std::integer_sequence<int, Ks...>) {
     (Ring<3>::template issue<Ks>(c.stream, min(static_cast<uint32_t>(Ks), c.last) * kOwnerRecordBytes, c.lane_off, c.lane_off12), ...);
 }
-template <int kDepth>
-__device__ __forceinline__ void consumer_begin_owner24(Consumer<true>& c, const uint8_t* stream, UnitTable unit, uint32_t U, uint32_t wave, uint32_t lane,
-                                                       const uint32_t* xs, uint32_t ring, double* ys, uint32_t nrows, uint32_t total_steps,
+template <bool kFloat, int kDepth>
+__device__ __forceinline__ void consumer_begin_owner24(Consumer<kFloat>& c, const uint8_t* stream, UnitTable unit, uint32_t U, uint32_t wave, uint32_t lane,
+                                                       const uint32_t* xs, uint32_t ring, typename Rows<kFloat>::acc_t* ys, uint32_t nrows, uint32_t total_steps,
                                                        uint32_t first_end) {
     static_assert(kDepth >= 1 && kDepth <= 4, "records in flight: a0..a30");
     c.stream = scalar_pointer(stream);
@@ -610,13 +637,13 @@ __device__ __forceinline__ void consumer_begin_owner24(Consumer<true>& c, const 
     c.next_end = U > 1 ? unit[1].end_step[wave] : first_end;
     c.lane_row = nrows + wave;
     c.spare = nrows + wave;
-    prime_ring_owner24(c, std::make_integer_sequence<int, kDepth>());
+    prime_ring_owner24<kFloat>(c, std::make_integer_sequence<int, kDepth>());
 }
-template <int kAblate, int kDepth>
-__device__ __forceinline__ void consumer_run_owner24(Consumer<true>& c) {
+template <bool kFloat, int kAblate, int kDepth>
+__device__ __forceinline__ void consumer_run_owner24(Consumer<kFloat>& c) {
     __builtin_amdgcn_s_waitcnt(0x0f70);   // see consumer_run: clears hipcc's "LDS-DMA may be pending"
     for (;; c.base += kDepth)
-        if (!consume_round_owner24<kAblate, kDepth>(c, std::make_integer_sequence<int, kDepth>())) break;
+        if (!consume_round_owner24<kFloat, kAblate, kDepth>(c, std::make_integer_sequence<int, kDepth>())) break;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory", HS_RING_AGPRS);   // the clamped tail prefetches must land before the ring is reused
 }
 
@@ -725,7 +752,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
         Consumer<kFloat> c;
         if (!loader && U > 0) {
             if constexpr (kRing == 3)
-                consumer_begin_owner24<kDepth>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave], blk->first_end[wave]);
+                consumer_begin_owner24<kFloat, kDepth>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave], blk->first_end[wave]);
             else
                 consumer_begin<kFloat, kRing, kDepth, kOwner>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave],
                                                                blk->first_end[wave]);
@@ -796,7 +823,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 }
             } else {
                 // ---- consumer wavefronts: stream elements, gather x, accumulate rows -----------------------------
-                if constexpr (kRing == 3) consumer_run_owner24<kAblate, kDepth>(c);
+                if constexpr (kRing == 3) consumer_run_owner24<kFloat, kAblate, kDepth>(c);
                 else if constexpr (kOwner) consumer_run<kFloat, kRing, kAblate, kDepth, false, true>(c);
                 else if (blk->flags & kBlockDenseRows) consumer_run<kFloat, kRing, kAblate, kDepth, true>(c);
                 else consumer_run<kFloat, kRing, kAblate, kDepth, false>(c);
@@ -816,7 +843,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
             }
             __syncthreads();
             timeline_stamp<kAblate>(block_no, wave, lane, 3);
-            if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = __float_as_uint(reinterpret_cast<float*>(ys)[i]);
+            if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = reinterpret_cast<uint32_t*>(ys)[i];     // fp32 bits, or the saturated Q8.24 sum
             timeline_stamp<kAblate>(block_no, wave, lane, 4);
             if (!next) break;
             continue;
@@ -939,6 +966,7 @@ hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
 #define X(A) if ((e = configure_one<true, 3, A, 3, true>(lds_bytes)) != hipSuccess) return e;
     HS_FOR_EACH_OWNER24_ABLATION(X)
 #undef X
+    if ((e = configure_one<false, 3, 0, 3, true>(lds_bytes)) != hipSuccess || (e = configure_one<false, 3, 512, 3, true>(lds_bytes)) != hipSuccess) return e;
     return configure_bitmap_kernels(lds_bytes);
 }
 
@@ -974,7 +1002,16 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.format == kFormatOwner24) {
         // records in flight per wavefront (1792 bytes each): HISPARSE_DEPTH=2|3|4 for experiments, kOwner24Depth otherwise
         const int records = std::getenv("HISPARSE_DEPTH") ? depth : kOwner24Depth;
-        if (!is_float) return hipErrorInvalidValue;
+        if (!is_float) {      // fixed point: saturating 32-bit accumulators (OwnerOps<false>); the product build and the timeline build
+            if (records != 3 || (ablate != 0 && ablate != 512)) return hipErrorInvalidValue;
+            if (ablate == 512)
+                hipLaunchKernelGGL((spmv_rowblock_kernel<false, 3, 512, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out,
+                                   a.row_part_filter, a.ring_buffers, x_base, a.part_heads);
+            else
+                hipLaunchKernelGGL((spmv_rowblock_kernel<false, 3, 0, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out,
+                                   a.row_part_filter, a.ring_buffers, x_base, a.part_heads);
+            return hipGetLastError();
+        }
 #define X(A)                                                                                                                       \
     if (ablate == A && records == 3) {                                                                                             \
         hipLaunchKernelGGL((spmv_rowblock_kernel<true, 3, A, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \

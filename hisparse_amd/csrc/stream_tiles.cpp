@@ -29,12 +29,39 @@ namespace {
 
 using namespace detail;
 
+thread_local bool g_no_owner = false;      // second attempt of build_stream_tiles after a fixed-point OWNER24 image turned out not to fit
+const char* const kOwnerDoesNotFit = "owner24: a share or a step count exceeds the record format";
+
+bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
+                             const Geometry& geom, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
+                             uint32_t num_col_partitions, uint32_t max_workgroups, StreamTiles& out, std::string& error,
+                             void* gpu_stream, bool use_gpu, uint64_t image_slack, const CsrView* csr);
+
 }  // namespace
 
 bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
                         const Geometry& geom, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
                         uint32_t num_col_partitions, uint32_t max_workgroups, StreamTiles& out, std::string& error,
                         void* gpu_stream, bool use_gpu, uint64_t image_slack, const CsrView* csr) {
+    g_no_owner = false;
+    bool ok = build_stream_tiles_once(channel, n_packets, geom, num_rows, num_cols, num_row_partitions, num_col_partitions, max_workgroups, out, error, gpu_stream,
+                                      use_gpu, image_slack, csr);
+    if (!ok && error == kOwnerDoesNotFit) {
+        g_no_owner = true;
+        error.clear();
+        ok = build_stream_tiles_once(channel, n_packets, geom, num_rows, num_cols, num_row_partitions, num_col_partitions, max_workgroups, out, error, gpu_stream,
+                                     use_gpu, image_slack, csr);
+        g_no_owner = false;
+    }
+    return ok;
+}
+
+namespace {
+
+bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
+                        const Geometry& geom, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
+                        uint32_t num_col_partitions, uint32_t max_workgroups, StreamTiles& out, std::string& error,
+                             void* gpu_stream, bool use_gpu, uint64_t image_slack, const CsrView* csr) {
     Layout L;
     L.g = &geom;
     L.num_rows = num_rows;
@@ -107,14 +134,16 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     {
         const double mean_gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 1e30;
         out.format = (mean_gap >= kDeltaMinMeanGap && mean_gap <= kDeltaMaxMeanGap) ? kFormatDelta : kFormatPairs;
-        // hyper-sparse float matrices: OWNER, in its 7-byte record form (OWNER24) unless that turns out larger (decided after the sort)
-        if (is_float && mean_gap > kOwnerMinMeanGap && out.nnz >= 4096) out.format = kFormatOwner24;
+        // hyper-sparse matrices: OWNER, in its 7-byte record form (OWNER24) unless that turns out larger (decided after the sort).  Fixed
+        // point too since round 3: saturating 32-bit accumulators (spmv_kernels.hip: OwnerOps) -- pokec in PAIRS, with 8-byte atomic
+        // accumulators, 12287-row blocks and 26 600 units of 1 150 elements, ran at 24 % of the roofline
+        if (mean_gap > kOwnerMinMeanGap && out.nnz >= 4096 && !g_no_owner) out.format = kFormatOwner24;
         if (const char* force = env_switch("HISPARSE_STREAM_FORMAT")) {
             const std::string f(force);
             if (f == "pairs") out.format = kFormatPairs;
             else if (f == "delta") out.format = kFormatDelta;
             else if (f == "owner") out.format = is_float ? kFormatOwner : kFormatPairs;   // float accumulators only
-            else if (f == "owner24") out.format = is_float ? kFormatOwner24 : kFormatPairs;
+            else if (f == "owner24") out.format = g_no_owner ? kFormatPairs : kFormatOwner24;
             else if (f == "bitmap") {}   // was tried above and is not representable (duplicate entries): automatic choice
             else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner, owner24 or bitmap"; return false; }
         }
@@ -426,7 +455,11 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
                     bytes24 += (steps[w] + kOwnerRecordSteps - 1) / kOwnerRecordSteps * kOwnerRecordBytes;
                 }
             }
-            if (!fits || (!format_forced && double(bytes24) > 0.97 * double(bytes32))) {
+            if (!is_float && !fits) {      // fixed point has no 8-byte OWNER form to fall back to: plan again without OWNER
+                error = kOwnerDoesNotFit;
+                return false;
+            }
+            if (is_float && (!fits || (!format_forced && double(bytes24) > 0.97 * double(bytes32)))) {
                 owner24 = false;
                 out.format = kFormatOwner;
                 if (!owner_shares(0xffffffffu)) return false;
@@ -668,6 +701,8 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
     timer.lap("emit DELTA");
     return true;
 }
+
+}  // namespace
 
 }  // namespace dev
 }  // namespace hisparse

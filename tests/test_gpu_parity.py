@@ -51,8 +51,8 @@ def _run_case(impl, m, vb, ob, skip, seed):
     eng.close()
     assert stats["nnz"] == m.nnz
     forced = os.environ["HISPARSE_STREAM_FORMAT"]
-    if forced in ("owner", "owner24") and impl == 0:
-        forced = "pairs"                 # OWNER is a float format (4-byte float accumulators); fixed point keeps its 64-bit atomics
+    if forced == "owner" and impl == 0:
+        forced = "pairs"                 # the 8-byte OWNER form is float only (fixed point: OWNER24 with saturating 32-bit accumulators)
     if forced != "bitmap" or cp.num_rows * ((cp.num_cols + 63) // 64) * 8 <= (1 << 30):    # a forced bitmap gives way above 1 GiB of masks
         got_format = device.STREAM_FORMATS[stats["stream_format"]]
         assert got_format == forced or (os.environ.get("HISPARSE_AUX_BITS") == "24" and got_format == forced + "24")

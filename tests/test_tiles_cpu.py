@@ -137,11 +137,11 @@ def test_column_slices(impl, slices, monkeypatch):
 
 def test_format_choice(monkeypatch):
     # unforced: DELTA is tried for mean position gaps rows*cols/nnz in [8, 20000] and kept when it needs <= 2 % bridge slots and saves
-    # more than 23 MiB of stream against PAIRS (stream_tiles.cpp); everything else is PAIRS
+    # more than 23 MiB of stream against PAIRS (stream_tiles.cpp); gaps beyond 20000: OWNER24; everything else is PAIRS
     monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
     for rows, cols, nnz, want in [(20000, 60000, 150000, "pairs"),       # right gap, but a 1 MB image: nothing to save
                                   (40000, 40000, 16000000, "delta"),     # 128 MB in PAIRS, 100 MB in DELTA
-                                  (60000, 90000, 100000, "pairs")]:      # hyper-sparse
+                                  (60000, 90000, 100000, "owner")]:      # hyper-sparse: OWNER24 (fixed point: saturating 32-bit accumulators)
         csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=nnz, b=0.0, c=1.0, seed=2)
         cp = host.format_matrix(csr, 0, skip_empty_rows=True)
         t = build(cp, 0, 16)
@@ -389,11 +389,21 @@ def test_owner_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypa
     assert (t["max_block_rows"] + 14) * 4 + t["ring_buffers"] * 32768 <= 160 * 1024
     got = tile_emulator.run(t, impl, xw, cp.num_rows)
     assert cases.float_close(got, oracle_y(cp, impl, xw))
-    # fixed point never takes it (saturating 64-bit sums need the atomics), even when asked to
+    # fixed point: the 8-byte OWNER form is float only, OWNER24 takes hyper-sparse fixed-point matrices too (saturating 32-bit sums)
     monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "owner")
     csr0 = host.CSRMatrix.generate("powerlaw", 9000, 70000, a=20000, b=0.5, c=1.0, seed=12)
     cp0 = host.format_matrix(csr0, 0, skip_empty_rows=True)
     assert build(cp0, 0, 4)["format"] in ("pairs", "pairs24")
+    for forced in ("owner24", None):
+        if forced:
+            monkeypatch.setenv("HISPARSE_STREAM_FORMAT", forced)
+        else:
+            monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+        t0 = build(cp0, 0, 4)
+        assert t0["format"] == "owner24"
+        x0 = host.pack_vector(0, cases.random_x(cp0.num_cols, 12, 0) * 40.0)      # large x: some rows saturate
+        want0 = oracle_y(cp0, 0, x0)
+        assert np.array_equal(tile_emulator.run(t0, 0, x0, cp0.num_rows), want0)
 
 
 def test_empty_environment_switches_count_as_unset(monkeypatch):

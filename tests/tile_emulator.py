@@ -117,7 +117,7 @@ def _block_owner(image, blk, units, x_words, ys, is_float, aux24=False):
     accumulator nrows + w; the shares of a unit differ by at most one step unless a row is longer than a share.
     aux24 = OWNER24: the same steps in records of four (_owner24_step), 24-bit position words whose row is relative to the first row
     of the (unit, wavefront) share -- carried in the high half of Unit.end_step[w] -- with 2047 = the spare accumulator."""
-    assert is_float
+    assert is_float or aux24       # fixed point: OWNER24 only (saturating 32-bit adds in any order == the exact sum, clamped once, below)
     nrows = int(blk["nrows"])
     step = [0] * CONSUMERS
     for u in range(int(blk["unit_begin"]), int(blk["unit_end"])):
@@ -153,7 +153,7 @@ def _block_owner(image, blk, units, x_words, ys, is_float, aux24=False):
             assert ((row < nrows) | pad).all() and (val[pad] == 0).all() and (col[~pad] < ncols).all()
             for r in np.unique(row[~pad]):
                 assert owner_of.setdefault(int(r), w) == w              # one owner per row while the unit lasts
-            _accumulate(ys, True, row[~pad], val[~pad], xt[col[~pad]])
+            _accumulate(ys, is_float, row[~pad], val[~pad], xt[col[~pad]])
             step[w] = end
 
 
