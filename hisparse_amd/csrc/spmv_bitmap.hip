@@ -113,6 +113,12 @@ __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uin
         }
         if (kFloat) acc += R::widen(part);
     };
+    // (Round 3: 128-column steps -- lane l takes columns 2 l and 2 l + 1 of a pair of groups with one 8-byte value load and one 8-byte x
+    // load, half the round trips -- were built and measured at 23.9 us against 13.8: picking a lane's two bits and its prefix count out of
+    // two standard masks costs ~20 vector instructions and 4 scalar registers per step, the unrolled batch spilled 59 SGPRs, and the
+    // larger code pays twice at the cold instruction cache of every launch.  The timeline says the run is bound by round trips
+    // (transformer-80, with 2.5 x fewer non-zeros, takes the same 7.0 us for its runs), so wide steps remain the lever -- but they need
+    // masks stored as (even columns, odd columns) pairs so that v_mbcnt and SGPR-pair selects do the work; an image-format change.)
     // Two batches: 16 loads of the next one are in flight while a batch is consumed.  Three in flight measured SLOWER (16.6 ->
     // 17.7 us on transformer-50), and so did the nt policy on the value loads (-> 17.6 us: the 36 MB image lives in the 256 MiB
     // Infinity Cache between launches); the timeline (tools/bitmap_timeline.py) shows the run itself streaming at ~5.5 TB/s and

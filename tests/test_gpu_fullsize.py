@@ -83,6 +83,33 @@ def test_full_size_random_values_vs_oracle(name, record_property):
     assert rep2["rows_over_bound"] == 0, rep2
     if rep["max_abs_y"] <= 1.0:                      # csim's absolute check, where its premise (values of order 1) holds
         assert rep["rows_over_csim_abs_1e-4"] == 0, rep
+    # the GPU's rounding error against the EXACT product must be of csim's own order: at most twice csim's fp32 running sum's
+    # (the double-sum paths are ~10 x closer than csim; OWNER / OWNER24 sum in fp32 like csim does, in another order)
+    record_property("contract_relative_1e-4", True)
+    record_property("contract_csim_absolute_1e-4", rep["rows_over_csim_abs_1e-4"] == 0)
+    assert rep["max_abs_err_gpu_vs_float64"] <= 2.0 * rep["max_abs_err_csim_vs_float64"] + 1e-6, rep
+
+
+@pytest.mark.parametrize("name,paper_gops", datasets.BM_LIST)
+def test_reference_sweep_full_size_fixed_point(name, paper_gops, record_property):
+    """Every matrix of the reference's sweep (sw/bm.sh:3-17) at full size in the numeric mode of the paper's Table 3 (fixed point),
+    random values, through the default planner: bit-exact against the oracle.  The out-of-sample test of the format / tile planner's
+    thresholds: pokec and ogbn-products (hyper-sparse -> OWNER24 with saturating accumulators), transformer-90 / -95 (below BITMAP's
+    density threshold -> dense-row element streams), hollywood (113 M non-zeros, two row partitions)."""
+    cfg, csr = datasets.load(name)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=cfg.skip_empty_rows)
+    xw = host.pack_vector(0, _random_x(0, cp.num_cols, 7))
+    with device.SpmvEngine(0) as eng:
+        eng.load_matrix(cp)
+        eng.load_vector(xw)
+        eng.run()
+        got = eng.read_result()
+        st = eng.stats()
+    want = _oracle(cp, 0, xw)
+    record_property("stream_format", device.STREAM_FORMATS[st["stream_format"]])
+    record_property("col_slices", st["col_slices"])
+    assert st["nnz"] == csr.nnz
+    assert np.array_equal(got, want), f"{name}: {int((got != want).sum())} of {got.size} rows differ from the oracle"
 
 
 def test_config5_mouse_gene_8way_row_split_on_hip(record_property):

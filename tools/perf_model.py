@@ -7,8 +7,9 @@ next to the measured kernel time.
                                                    of the reference's v/o sweep (performance_model/design_space_exp.cpp:515-540);
                                                    with a GPU every point is also measured
 
-Constants are measurements of this repository (tools/*.hip micro-benchmarks and HISPARSE_ABLATE builds on ogbl-ppa,
-ogbn-products, mouse_gene), not fits per matrix.
+Constants are measurements of this repository (round 3: the timeline builds HISPARSE_ABLATE=512 / 64, the OWNER profile, ablation
+builds and tools/*.hip micro-benchmarks), not fits per matrix.  tests/test_perf_model.py keeps the model within
+15 % of the measured kernel on the five configurations (-m gpu).
 """
 import math, os, sys
 import numpy as np
@@ -16,68 +17,71 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hisparse_amd import host, device, datasets
 
 CUS = 256
-STREAM_B_PER_US = {"pairs": 6.60e6, "delta": 6.44e6, "owner": 5.86e6, "bitmap": 5.5e6}   # per-wavefront streams (record_stream_bench.hip;
-                                                                                         # owner / bitmap: ablation builds and the bitmap timeline)
-BITMAP_FRONT_US, BITMAP_TAIL_US = 4.0, 3.3   # spmv_bitmap_kernel (tools/bitmap_timeline.py): dispatch ramp + descriptor -> masks -> first values;
-                                             # wavefronts finishing apart + row sums + barrier + store
-STARTUP_US = 3.0            # launch -> block header -> first records landed
-PROLOGUE_US = 0.5           # per block: zero the accumulators, first x sub-tile, barrier (mostly behind the primed stream ring)
-STORE_B_PER_US = 2.4e6      # result store burst when all workgroups finish together (9.2 MB in ~3.8 us) ...
-STORE_LATENCY_US = 1.2      # ... plus the write latency at the end of a block
-REFILL_LAND_US = 0.8        # one x sub-tile refill (LDS-DMA) lands
-REFILL_B_PER_US_CU = 120e3  # L2 -> LDS through one CU
-CU_STREAM_B_PER_US = 25e3   # one CU's share of the stream
-BARRIER_US = 0.05           # per (block, sub-tile) unit
-QUANTISATION_EXPOSED = 0.3  # share of the barrier-synchronisation slack that is not absorbed by the other wavefronts' bandwidth
-REFILL_VOLUME_EXPOSED = 0.5 # share of the x refill volume that does not hide behind the stream
-LDS_PS_PER_ELEMENT = {0: 11.5, 1: 18.0, 2: 18.0}   # exposed LDS gather + atomic cost per element and CU (u64 / f64)
+# ---- constants: measurements of round 3 (timeline builds HISPARSE_ABLATE=512 / 64, ablation builds, tools/*.hip) ---------------------
+LAUNCH_US = 3.0             # HIP-event start -> first wavefront's first instruction, + last store -> event end (events vs timeline stamps)
+RAMP_US = 4.3               # a 1024-thread workgroup's wavefronts are started 2-4 us apart; zero + first x sub-tile + barrier ride on it
+NEXT_BLOCK_US = 3.5         # the same for a workgroup's further blocks (descriptor, zeroing, first sub-tile; no launch ramp)
+STORE_US = 1.0              # result store of a block (+ the write latency at its end)
+SPREAD = 0.05               # workgroups finish up to 5 % of the main loop apart (dynamic: memory-system fairness, not step counts)
+CU_STREAM_B_PER_US = {"pairs": 25.8e3, "delta": 25.8e3, "owner": 26.5e3}   # one CU's 14 consumer rings while nothing else binds: 6.6-6.8 TB/s / 256
+# a (row block, x sub-tile) UNIT costs at least this much, however little it holds: end-of-unit flush + barrier + the loaders' refill issue
+# (8 LDS-DMA instructions, ~1000 clocks, tools/owner_profile.py) + its landing.  OWNER / OWNER24: pokec (<= 3 steps per wavefront and unit)
+# 1.38 us, ogbn-products (<= 5) 1.5 us; the atomic formats' units have no flush and a ring of 3-4: 0.45 us
+UNIT_FLOOR_US = {"owner": lambda steps: 1.2 + 0.06 * steps, "pairs": lambda steps: 0.45, "delta": lambda steps: 0.45}
+LDS_EXPOSED_PS = {"pairs": {0: 6.0, 1: 9.0, 2: 9.0}, "delta": {0: 9.0, 1: 14.0, 2: 14.0}, "owner": {0: 0.0, 1: 0.0, 2: 0.0}}   # per element and CU, beside a saturated stream
+BITMAP_FRONT_US, BITMAP_TAIL_US = 4.0, 2.8   # spmv_bitmap_kernel (tools/bitmap_timeline.py): ramp + descriptor -> masks -> first values; finish spread + row sums + barrier + store
+BITMAP_BATCH_US = 0.44      # one batch of 8 steps (16 loads) per wavefront: the run is bound by load round trips, not bytes (transformer-50 and -80: 7.0 us both)
+BITMAP_LAUNCH_US = 1.5
 
 
 def model(name, cp=None, impl=None):
+    """(ChannelPackets, impl, tiles, {term: microseconds}) -- the terms add up to the modelled duration of the SpMV kernel as a HIP-event
+    pair around the launch sees it."""
     if cp is None:
         cfg, csr = datasets.load(name)
         impl = host.impl_id(cfg.impl)
         cp = host.format_matrix(csr, impl, skip_empty_rows=True)
     t = device.build_tiles(cp, impl, cp.ob_bank, cp.vb_bank, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, CUS)
     blocks, units = t["blocks"], t["units"]
-    fmt, slices, ring = t["format"], t["col_slices"], t["ring_buffers"]
-    fmt = fmt[:-2] if fmt.endswith("24") else fmt       # 7-byte forms of PAIRS / OWNER: same machinery, fewer stream bytes
+    family = {"pairs24": "pairs", "owner24": "owner"}.get(t["format"], t["format"])
     groups = t["num_workgroups"]
-    if fmt == "bitmap":     # no units, no x ring: a front, the stream, a tail (per block of the busiest workgroup)
+    if family == "bitmap":     # no units, no x ring: a front, the runs, a tail (per block of the busiest workgroup)
         per_wg = max(t["wg_first"][g + 1] - t["wg_first"][g] for g in range(groups))
-        parts = {"stream": len(t["image"]) / STREAM_B_PER_US[fmt], "front (ramp, descriptor -> masks -> values)": BITMAP_FRONT_US,
-                 "tail (finish spread, row sums, store)": BITMAP_TAIL_US * per_wg, "launch": 3.0}
+        segs = units.view(np.uint8).reshape(len(blocks), 16, 5 * 64)[:, :, :16].copy().view(np.uint32).reshape(len(blocks), 16, 4)
+        steps = (segs[:, :, 1] - segs[:, :, 0]).astype(np.int64) * (segs[:, :, 3] - segs[:, :, 2]).astype(np.int64)     # rows x groups of a wavefront's run
+        batches = -(-steps.max(axis=1) // 8)                                  # the slowest wavefront of every block
+        run_us = float(batches.max()) * BITMAP_BATCH_US * per_wg
+        stream_us = len(t["image"]) / 6.6e6                                   # what the bytes alone would need
+        parts = {"launch": BITMAP_LAUNCH_US, "front (ramp, descriptor -> masks -> values)": BITMAP_FRONT_US,
+                 "stream": max(run_us, stream_us), "tail (finish spread, row sums, store)": BITMAP_TAIL_US * per_wg}
         return cp, impl, t, parts
-    # critical workgroup: steps serialised by the per-unit barrier (sum over units of the slowest wavefront)
-    es = units["end_step"].astype(np.int64)
-    step_bytes = 384 if fmt == "delta" else 448 if t["format"].endswith("24") else 512
-    sync = np.zeros(groups)
-    ideal = np.zeros(groups)
-    nunits = np.zeros(groups)
-    nblocks = np.zeros(groups)
-    rows = np.zeros(groups)
+    # per workgroup: its blocks one after the other; a block's main loop is the slower of (its stream at one CU's rate) and (its units at
+    # the per-unit floor, each unit as long as its slowest wavefront's steps)
+    packed = t["format"] == "owner24"
+    es = (units["end_step"] & 0xFFFF if packed else units["end_step"]).astype(np.int64)
+    step_bytes = {"pairs": 512, "pairs24": 448, "delta": 768, "owner": 512, "owner24": 448}[t["format"]]      # per wavefront step (DELTA: a record of two slots per lane)
+    rate, floor = CU_STREAM_B_PER_US[family], UNIT_FLOOR_US[family]
+    main = np.zeros(groups); stream = np.zeros(groups); floors = np.zeros(groups); nblocks = np.zeros(groups); elems = np.zeros(groups)
     for g in range(groups):
         for b in t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]:
             blk = blocks[b]
             nblocks[g] += 1
-            rows[g] += int(blk["nrows"])
             if blk["unit_end"] == blk["unit_begin"]:
                 continue
             e = es[blk["unit_begin"]:blk["unit_end"]]
             d = np.diff(np.vstack([np.zeros((1, 14), dtype=np.int64), e]), axis=0)
-            sync[g] += d.max(axis=1).sum()
-            ideal[g] += d.sum() / 14.0
-            nunits[g] += len(e)
-    stream_us = len(t["image"]) / STREAM_B_PER_US[fmt]
-    crit = int(np.argmax(sync))
-    quant_us = QUANTISATION_EXPOSED * stream_us * (sync.max() / max(ideal.mean(), 1e-9) - 1.0)   # barrier-synchronised wavefronts + imbalance
-    unit_stream_us = len(t["image"]) / max(len(units), 1) / CU_STREAM_B_PER_US
-    refill_us = nunits[crit] * max(0.0, REFILL_LAND_US / max(ring - 1, 1) - unit_stream_us) + REFILL_VOLUME_EXPOSED * nunits[crit] * 32768 / REFILL_B_PER_US_CU
-    store_us = nblocks[crit] * STORE_LATENCY_US + rows.sum() * 4 / STORE_B_PER_US / max(1.0, nblocks.mean())
+            s_us = d.sum() * step_bytes / rate
+            f_us = sum(floor(int(m)) for m in d.max(axis=1))
+            stream[g] += s_us
+            floors[g] += f_us
+            main[g] += max(s_us, f_us)
+            elems[g] += d.sum() * 64
+    crit = int(np.argmax(main + nblocks * (NEXT_BLOCK_US + STORE_US)))
+    lds_us = elems[crit] * LDS_EXPOSED_PS[family][impl] * 1e-6
     parts = {
-        "stream": stream_us, "startup": STARTUP_US, "prologues": PROLOGUE_US * nblocks[crit], "result store": store_us,
-        "unit barriers": BARRIER_US * nunits[crit], "step quantisation": quant_us, "x refill": refill_us,
-        "LDS work": cp.nnz / CUS * (12.0 if fmt == "owner" else LDS_PS_PER_ELEMENT[impl]) * 1e-6,   # owner: gather + read-modify-write, 3.6 lanes/clk
+        "launch": LAUNCH_US, "ramp + prologue": RAMP_US, "further blocks' prologues": NEXT_BLOCK_US * max(0.0, nblocks[crit] - 1),
+        "stream": min(stream[crit], main[crit]), "unit floor beyond the stream (flush, barrier, refill)": max(0.0, main[crit] - stream[crit]),
+        "LDS work beside the stream": lds_us, "result stores": STORE_US * nblocks[crit], "finish spread": SPREAD * main[crit],
     }
     return cp, impl, t, parts
 
@@ -86,6 +90,8 @@ def measure(cp, impl):
     eng = device.SpmvEngine(impl)
     eng.load_matrix(cp)
     eng.load_vector(host.pack_vector(impl, np.random.default_rng(0).uniform(0, 2, cp.num_cols).astype(np.float32)))
+    for _ in range(100):      # clocks up
+        eng.run()
     best = min(eng.time_runs(5, 30)[1] / 30 for _ in range(3)) * 1e3
     eng.close()
     return best
