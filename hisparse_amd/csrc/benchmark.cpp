@@ -20,6 +20,7 @@
 //                                  per row partition (:318-338) instead of one launch for the whole SpMV
 //   --runs K                       NUM_RUNS (default 50, :29)
 //   --dump-x FILE / --dump-y FILE  raw little-endian u32 value words of the packed x / y (for the parity test)
+//   --gpus N [--no-gather] [--peer-gather]   (--peer-gather: also time the gather as peer stores over xGMI, hs_push_result, no collective)
 //   --gpus N [--no-gather]         shard the matrix by row slabs (hisparse/row_sharding.h) over devices 0..N-1 of this node:
 //                                  one hs_context per device, this one host thread issuing to the N streams, and one
 //                                  ncclAllGather (RCCL over xGMI) of the y slabs per SpMV; both the compute-only and the
@@ -59,6 +60,7 @@ struct Options {
     std::string dump_x, dump_y;
     int gpus = 1;
     bool gather = true;
+    bool peer_gather = false;   // --peer-gather: ALSO time the gather as peer stores over xGMI (hs_push_result) instead of ncclAllGather
     bool sharded = false;   // take the multi-GPU path even with one GPU (exercises RCCL on a single-GPU box)
 };
 
@@ -281,30 +283,92 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
             nccl_check(ncclAllGather(gathered[d] + size_t(d) * chunk, gathered[d], chunk, ncclUint32, comm[d], stream[d]), "ncclAllGather");
         nccl_check(ncclGroupEnd(), "ncclGroupEnd");
     };
+    // The same gather WITHOUT a collective (--peer-gather): every device stores its slab straight into every other device's gather buffer
+    // over xGMI (hs_push_result: one small kernel on the producer's stream, plain stores into peer memory); an event per device tells
+    // the others' streams when its slab has been pushed.  With one device (--sharded) the "peer" is a second buffer on the same device.
+    std::vector<hipEvent_t> pushed(N, nullptr);
+    std::vector<uint32_t*> loopback(N, nullptr);
+    if (o.peer_gather) {
+        for (int d = 0; d < N; ++d) {
+            hip_check(hipSetDevice(d), "hipSetDevice");
+            for (int p = 0; p < N; ++p)
+                if (p != d) {
+                    const hipError_t e = hipDeviceEnablePeerAccess(p, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hip_check(e, "hipDeviceEnablePeerAccess");
+                    (void)hipGetLastError();
+                }
+            hip_check(hipEventCreateWithFlags(&pushed[d], hipEventDisableTiming), "hipEventCreate");
+            if (N == 1) {
+                hip_check(hipMalloc(reinterpret_cast<void**>(&loopback[d]), size_t(chunk) * 4), "hipMalloc");
+                hip_check(hipMemset(loopback[d], 0, size_t(chunk) * 4), "hipMemset");
+            }
+        }
+    }
+    auto push_all = [&]() {
+        for (int d = 0; d < N; ++d) {
+            void* dst[8];
+            uint32_t n = 0;
+            for (int p = 0; p < N; ++p)
+                if (p != d) dst[n++] = gathered[p] + size_t(d) * chunk;
+            if (N == 1) dst[n++] = loopback[d];
+            check(hs_push_result(slab[d].ctx, dst, n, chunk), slab[d].ctx, "hs_push_result");
+            hip_check(hipSetDevice(d), "hipSetDevice");
+            hip_check(hipEventRecord(pushed[d], stream[d]), "hipEventRecord");
+        }
+        for (int d = 0; d < N; ++d) {      // nobody goes on (e.g. to an SpMV that reads the gathered y as its x) before every slab has arrived
+            hip_check(hipSetDevice(d), "hipSetDevice");
+            for (int p = 0; p < N; ++p)
+                if (p != d) hip_check(hipStreamWaitEvent(stream[d], pushed[p], 0), "hipStreamWaitEvent");
+        }
+    };
     auto sync_all = [&]() {
         for (int d = 0; d < N; ++d) {
             hip_check(hipSetDevice(d), "hipSetDevice");
             hip_check(hipStreamSynchronize(stream[d]), "hipStreamSynchronize");
         }
     };
-    auto timed = [&](bool with_gather) {
-        for (int i = 0; i < 5; ++i) { spmv_all(); if (with_gather) gather_all(); }
+    auto timed = [&](int how) {      // 0: no gather, 1: ncclAllGather, 2: peer stores
+        auto step = [&]() { spmv_all(); if (how == 1) gather_all(); else if (how == 2) push_all(); };
+        for (int i = 0; i < 5; ++i) step();
         sync_all();
         const auto a = clock::now();
-        for (unsigned i = 0; i < o.runs; ++i) { spmv_all(); if (with_gather) gather_all(); }
+        for (unsigned i = 0; i < o.runs; ++i) step();
         sync_all();
         return std::chrono::duration<double, std::milli>(clock::now() - a).count() / o.runs;
     };
     std::cout << "INFO : Invoking kernel:" << std::endl;
-    const double compute_ms = timed(false);
+    const double compute_ms = timed(0);
     benchmark_result compute_only = res;
     fill_result(compute_only, double(nnz_total), compute_ms);
     std::cout << "  compute only (y left sharded, like the reference leaves it in HBM): " << compute_only << std::endl;
     if (o.gather) {
-        const double both_ms = timed(true);
+        const double both_ms = timed(1);
         fill_result(res, double(nnz_total), both_ms);
         std::cout << "  compute + one all-gather of y per SpMV (RCCL, " << chunk * 4.0 / 1e3 << " kB per rank): " << res << std::endl;
         std::cout << "  all-gather cost per SpMV: " << (both_ms - compute_ms) * 1e3 << " us" << std::endl;
+        if (o.peer_gather) {
+            const double peer_ms = timed(2);
+            benchmark_result peer = res;
+            fill_result(peer, double(nnz_total), peer_ms);
+            std::cout << "  compute + gather by peer stores over xGMI (hs_push_result, no collective): " << peer << std::endl;
+            std::cout << "  peer-store gather cost per SpMV: " << (peer_ms - compute_ms) * 1e3 << " us" << std::endl;
+            // the pushed slabs must equal what the collective delivered
+            spmv_all();
+            push_all();
+            sync_all();
+            std::vector<uint32_t> a(chunk), b(chunk);
+            bool same = true;
+            for (int d = 0; d < N && same; ++d) {
+                const int reader = N == 1 ? 0 : (d + 1) % N;
+                hip_check(hipSetDevice(reader), "hipSetDevice");
+                hip_check(hipMemcpy(a.data(), N == 1 ? loopback[d] : gathered[reader] + size_t(d) * chunk, size_t(chunk) * 4, hipMemcpyDeviceToHost), "hipMemcpy");
+                hip_check(hipSetDevice(d), "hipSetDevice");
+                hip_check(hipMemcpy(b.data(), gathered[d] + size_t(d) * chunk, size_t(chunk) * 4, hipMemcpyDeviceToHost), "hipMemcpy");
+                same = a == b;
+            }
+            std::cout << "  peer-store gather: pushed slabs " << (same ? "identical to" : "DIFFER from") << " their sources" << std::endl;
+            if (!same) std::exit(EXIT_FAILURE);
+        }
     } else {
         res = compute_only;
     }
@@ -328,6 +392,8 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
         check(hs_set_stream(slab[d].ctx, nullptr), slab[d].ctx, "hs_set_stream");
         hs_destroy(slab[d].ctx);
         ncclCommDestroy(comm[d]);
+        if (pushed[d]) hip_check(hipEventDestroy(pushed[d]), "hipEventDestroy");
+        if (loopback[d]) hip_check(hipFree(loopback[d]), "hipFree");
         hip_check(hipFree(gathered[d]), "hipFree");
         hip_check(hipStreamDestroy(stream[d]), "hipStreamDestroy");
     }
@@ -350,6 +416,7 @@ bool parse_args(int argc, char** argv, Options& o) {
         else if (a == "--dump-y") o.dump_y = need("--dump-y");
         else if (a == "--gpus") o.gpus = std::max(1, std::atoi(need("--gpus").c_str()));
         else if (a == "--no-gather") o.gather = false;
+        else if (a == "--peer-gather") o.peer_gather = true;
         else if (a == "--sharded") o.sharded = true;
         else if (a == "--device") o.device = std::atoi(need("--device").c_str());
         else if (a.rfind("--", 0) == 0) { std::cout << "ERROR : unknown option " << a << std::endl; return false; }
@@ -375,7 +442,7 @@ int main(int argc, char** argv) {
     Options o;
     if (!parse_args(argc, argv, o)) {
         std::cout << "Usage: " << argv[0] << " <fixed|float_pob|float_stall> <dataset.npz | synth:kind:rows:cols:a:b:c:seed> <v> <o> [device]"
-                  << " [--values literal|intent|keep] [--from-csr] [--partition-loop] [--runs K] [--dump-x FILE] [--dump-y FILE] [--gpus N [--no-gather] [--sharded]]" << std::endl;
+                  << " [--values literal|intent|keep] [--from-csr] [--partition-loop] [--runs K] [--dump-x FILE] [--dump-y FILE] [--gpus N [--no-gather] [--peer-gather] [--sharded]]" << std::endl;
         return 0;
     }
     std::cout << "------ Running benchmark on " << o.dataset << std::endl;

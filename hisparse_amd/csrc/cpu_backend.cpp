@@ -291,6 +291,7 @@ int hs_device_vector(hs_context* ctx, void**) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_device_result(hs_context* ctx, void**) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_bind_device_vector(hs_context* ctx, const void*) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_bind_device_result(hs_context* ctx, void*) { HS_CPU_UNSUPPORTED(ctx); }
+int hs_push_result(hs_context* ctx, void* const*, uint32_t, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_feedback(hs_context* ctx, uint32_t, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_iterate(hs_context* ctx, uint32_t, uint32_t, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_load_matrix_csc(hs_context* ctx, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }

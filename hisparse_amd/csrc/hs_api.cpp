@@ -655,6 +655,19 @@ int hs_bind_device_result(hs_context* ctx, void* y_dev) {
     return HS_OK;
 }
 
+int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t num_words) {
+    if (!ctx) return HS_ERR_BAD_ARG;
+    if (!ctx->matrix_loaded) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix has not been called");
+    if (n_dst == 0) return HS_OK;
+    if (!dst || n_dst > hisparse::dev::kMaxPushTargets) return fail(ctx, HS_ERR_BAD_ARG, "1 .. 8 destinations");
+    if (num_words > ctx->num_rows || (num_words & 3u)) return fail(ctx, HS_ERR_BAD_ARG, "num_words must be a multiple of 4 and at most the padded row count");
+    for (uint32_t k = 0; k < n_dst; ++k)
+        if (!dst[k] || (reinterpret_cast<uintptr_t>(dst[k]) & 15u)) return fail(ctx, HS_ERR_BAD_ARG, "destinations must be 16-byte aligned device pointers");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_HIP(ctx, hisparse::dev::launch_push_result(y_target(ctx), dst, n_dst, num_words, ctx->stream));
+    return HS_OK;
+}
+
 // SpMM as k SpMVs over the resident image (hisparse_hip.h): every column of X through the same kernels, so every column of Y is
 // exactly what hs_run gives for it.
 int hs_spmm_device(hs_context* ctx, const void* x_dev, uint64_t ldx, void* y_dev, uint64_t ldy, uint32_t k) {

@@ -64,6 +64,10 @@ hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* 
                          const uint32_t* x_words, uint32_t x_count, uint32_t num_rows, uint32_t num_cols, void* accumulators, uint32_t* y,
                          hipStream_t stream);
 
+// Multi-GPU gather without a collective: y[0, words) into n_dst <= kMaxPushTargets other buffers (peers' memory over xGMI) with plain stores.
+constexpr uint32_t kMaxPushTargets = 8;
+hipError_t launch_push_result(const uint32_t* y, void* const* dst, uint32_t n_dst, uint32_t words, hipStream_t stream);
+
 // Iterative callers: x[i] = scale (*) y[i] (+) shift, i < n, in Q8.24 (AP_RND, AP_SAT) or fp32 arithmetic.
 hipError_t launch_feedback(bool is_float, const uint32_t* y, uint32_t* x, uint32_t n, uint32_t scale, uint32_t shift, hipStream_t stream);
 

@@ -775,6 +775,10 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 const uint32_t lw = wave - kConsumerWaves;
                 __builtin_amdgcn_s_setprio(3);                         // the refills are on every unit's critical path: issue them first
                 uint32_t fill_slot = 1 == ring ? 0 : 1;                // ring slot of the next refill (sub-tile v lives in slot v % ring)
+                // (Round 3: a ring of unit descriptors in LDS, filled by the loaders with vector loads riding on the refills and read by
+                // the consumers with ds_read -- no scalar load anywhere in the unit loop -- was built, parity- and soak-green, and
+                // changed nothing: mouse_gene slab 22.0 vs 21.7 us, pokec 89.9 vs 89.4, ogbl-ppa 58.5 vs 57.7, ogbn-products 206 vs 204,
+                // same box.  The scalar descriptor loads below are not what a short unit waits for.)
                 // Unit descriptors are 64 bytes apart and cold (they stream from HBM once per SpMV): the descriptor of the
                 // refill after next is fetched while this one is in flight, so its miss latency is off the per-unit path
                 // (hyper-sparse matrices have hundreds of short units per block: 1 us each used to add up to 300 us).
@@ -915,6 +919,16 @@ __global__ __launch_bounds__(256) void feedback_kernel(const uint32_t* __restric
                                                        uint32_t shift) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = feedback_word<kFloat>(y[i], scale, shift);
+}
+
+// hs_push_result: the y slab into up to kMaxPushTargets other buffers -- on a multi-GPU node those are the peers' gather buffers, written
+// over xGMI with plain stores (hipDeviceEnablePeerAccess): a gather of the row slabs without a collective on the critical path.
+struct PushTargets { uint32_t* dst[kMaxPushTargets]; };
+__global__ __launch_bounds__(256) void push_result_kernel(const uint32_t* __restrict__ y, PushTargets t, uint32_t n_dst, uint32_t words) {
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;      // words is a multiple of 4 (padded row counts)
+    if (i >= words) return;
+    const uint4 v = *reinterpret_cast<const uint4*>(y + i);
+    for (uint32_t k = 0; k < n_dst; ++k) *reinterpret_cast<uint4*>(t.dst[k] + i) = v;
 }
 
 template <bool kFloat, int kRing, int kAblate, int kDepth, bool kOwner = false>
@@ -1091,6 +1105,15 @@ hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_
         default: return hipErrorInvalidValue;
     }
     static_assert(kMaxColSlices == 8, "combine_slices_kernel is instantiated for 2 .. 8 slices");
+    return hipGetLastError();
+}
+
+hipError_t launch_push_result(const uint32_t* y, void* const* dst, uint32_t n_dst, uint32_t words, hipStream_t stream) {
+    if (n_dst == 0 || words == 0) return hipSuccess;
+    if (n_dst > kMaxPushTargets || (words & 3u)) return hipErrorInvalidValue;
+    PushTargets t{};
+    for (uint32_t k = 0; k < n_dst; ++k) t.dst[k] = static_cast<uint32_t*>(dst[k]);
+    hipLaunchKernelGGL(push_result_kernel, dim3((words / 4 + 255) / 256), dim3(256), 0, stream, y, t, n_dst, words);
     return hipGetLastError();
 }
 

@@ -195,7 +195,14 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                 // short and every one ends in a flush and a barrier, which also scale with the ranges: 1.34 us per range on
                 // ogbn-products = 29 GB/s (tools/slices_probe.sh)
                 const double volume_us = ranges * double(num_cols) * 4.0 / G / (owner ? 29e3 : 120e3);
-                const double latency_us = units_per_wg * std::max(0.0, 0.8 / (ring - 1) - unit_stream_us);
+                double latency_us = units_per_wg * std::max(0.0, 0.8 / (ring - 1) - unit_stream_us);
+                // Blocks of a few long rows (<= kDenseBlockRows) take the dense-row path: a wavefront sums a row in registers and pays a
+                // wavefront-wide reduction at every row change.  That is right for rows that fill many chunks of a sub-tile (pruned-NN
+                // layers: 16 K non-zeros per row) and slow when a (row, sub-tile) holds only a chunk or two -- one rank's slab of mouse_gene
+                // split 8 ways (5632 rows x 45 K columns, 22-row blocks, 117 non-zeros per row and sub-tile) ran 2.5 us per unit, 22.7 us
+                // for 29 MB; in 3 column slices (blocks of 66 rows, ordinary path) 11.5 us + the combine pass.  Price it.
+                const double rows_per_block = double(num_rows) / ranges, per_row_and_tile = double(out.nnz) / std::max(1.0, double(num_rows) * sub_tiles);
+                if (!owner && rows_per_block <= kDenseBlockRows && per_row_and_tile < 4.0 * kWaveLanes) latency_us += units_per_wg * 1.75;
                 const double combine_us = cs > 1 ? 3.5 + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
                 const double cost = volume_us + latency_us + 8.0 * blocks_per_wg + combine_us;
                 if (std::getenv("HISPARSE_PLAN_DEBUG"))

@@ -62,6 +62,9 @@ CONFIGS = {
     "transformer_80": Config("transformer_80", "float_pob", 512, 33288, "bernoulli", 0, 0.2, 0.05, 80, "transformer_80_512_33288_csr_float32.npz"),
     "transformer_90": Config("transformer_90", "float_pob", 512, 33288, "bernoulli", 0, 0.1, 0.05, 90, "transformer_90_512_33288_csr_float32.npz"),
     "transformer_95": Config("transformer_95", "float_pob", 512, 33288, "bernoulli", 0, 0.05, 0.05, 95, "transformer_95_512_33288_csr_float32.npz"),
+    # one rank's share of mouse_gene split 8 / 4 ways by non-zeros (bench.py --gpus 8 / 4): the small-slab regime (tools/, tests)
+    "mouse_gene_slab8": Config("mouse_gene_slab8", "fixed", 5638, 45101, "powerlaw", 3620911, 0.30, 0.1, 44, ""),
+    "mouse_gene_slab4": Config("mouse_gene_slab4", "fixed", 11275, 45101, "powerlaw", 7241822, 0.30, 0.1, 44, ""),
     # small relatives for tests / smoke
     "ppa_small": Config("ppa_small", "fixed", 40000, 70000, "powerlaw", 1400000, 0.35, 1.0, 7, ""),
     "nn_small": Config("nn_small", "float_pob", 512, 33288, "bernoulli", 0, 0.05, 0.05, 95, ""),

@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
     "hs_load_matrix_csr", "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
-    "hs_bind_device_vector", "hs_bind_device_result", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_tiles_build", "hs_tiles_info",
+    "hs_bind_device_vector", "hs_bind_device_result", "hs_push_result", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
 
@@ -75,6 +75,7 @@ def lib():
         l.hs_device_result.argtypes = [vp, C.POINTER(vp)]
         l.hs_bind_device_vector.argtypes = [vp, vp]
         l.hs_bind_device_result.argtypes = [vp, vp]
+        l.hs_push_result.argtypes = [vp, C.POINTER(vp), u32, u32]
         l.hs_feedback.argtypes = [vp, u32, u32]
         l.hs_iterate.argtypes = [vp, u32, u32, u32]
         l.hs_load_matrix_csc.argtypes = [vp, vp, vp, vp, u32, u32]
@@ -273,6 +274,11 @@ class SpmvEngine:
     def iterate(self, iterations, scale_word, shift_word):
         """`iterations` x { run; feedback }, replayed from one captured hipGraph."""
         self._check(lib().hs_iterate(self._h, int(iterations), int(scale_word), int(shift_word)))
+
+    def push_result(self, dst_ptrs, num_words):
+        """hs_push_result: the first num_words result words into the given device buffers (stream-ordered, plain stores)."""
+        arr = (C.c_void_p * len(dst_ptrs))(*dst_ptrs)
+        self._check(lib().hs_push_result(self._h, arr, len(dst_ptrs), num_words))
 
     def time_runs(self, warmup, runs, kernel=True):
         """(total_ms for `runs` SpMVs, summed duration of the dominant kernel over those runs or None)."""

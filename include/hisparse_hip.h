@@ -122,6 +122,11 @@ int hs_device_result(hs_context* ctx, void** y_dev);
 /* Make the kernels read x from / write y to caller-owned device memory, 16-byte aligned (NULL restores the library's). */
 int hs_bind_device_vector(hs_context* ctx, const void* x_dev);
 int hs_bind_device_result(hs_context* ctx, void* y_dev);
+/* EXTENSION (multi-GPU): stream-ordered copy of the first num_words words of the result (the context's own y or
+ * the bound one) into n_dst <= 8 other device buffers with plain stores -- on a node with peer access enabled
+ * (hipDeviceEnablePeerAccess) those are the other GPUs' gather buffers, written over xGMI: a gather of the row slabs with no collective
+ * on the critical path (hisparse_amd/csrc/benchmark.cpp --gpus N --peer-gather).  num_words: multiple of 4; dst: 16-byte aligned. */
+int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t num_words);
 
 /* ---- iterative callers (EXTENSION: no reference counterpart) --------------
  * The reference's drivers run one SpMV and read y back; an iterative caller (PageRank: sw/data_formatter.h:33-47

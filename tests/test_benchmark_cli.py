@@ -118,6 +118,12 @@ def test_row_sharded_rccl_path_on_one_gpu(tmp_path):
     cp, want = _oracle_y(m, 0, 4096, 8192, x)
     y = np.fromfile(yf, dtype=np.uint32)
     assert y.size == 20000 and np.array_equal(y, want[:20000])
+    # the same gather without a collective: every device stores its slab into the others' buffers (hs_push_result; with one device the
+    # "peer" is a second buffer on it) -- timed beside ncclAllGather, and the pushed slab must equal its source
+    r = run("fixed", path, 4, 8, "--values", "keep", "--gpus", 1, "--sharded", "--peer-gather", "--dump-y", yf)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "peer-store gather cost per SpMV" in r.stdout and "pushed slabs identical to their sources" in r.stdout
+    assert np.array_equal(np.fromfile(yf, dtype=np.uint32), want[:20000])
     r = run("fixed", path, 4, 8, "--gpus", 64)
     assert r.returncode != 0 and "device(s) visible" in r.stdout
 
