@@ -56,7 +56,8 @@ struct hs_context {
     uint32_t* d_csc_indptr = nullptr;
     uint32_t* d_csc_rows = nullptr;
     uint32_t* d_csc_vals = nullptr;
-    void* d_csc_acc = nullptr;
+    hisparse::dev::SpmspvScratch csc_scratch;      // expanded / binned product lists, scan + sort storage, direct-path accumulators
+    uint64_t spmspv_products = 0;                  // products formed by the last hs_spmspv
     uint32_t* d_csc_y = nullptr;
     uint32_t* d_sx = nullptr;      // sparse x: [capacity] indices then [capacity] value words
     uint32_t sx_capacity = 0;
@@ -113,11 +114,13 @@ void free_matrix(hs_context* c) {
 }
 
 void free_csc(hs_context* c) {
-    for (void* p : {static_cast<void*>(c->d_csc_indptr), static_cast<void*>(c->d_csc_rows), static_cast<void*>(c->d_csc_vals), c->d_csc_acc,
-                    static_cast<void*>(c->d_csc_y), static_cast<void*>(c->d_sx)})
+    hisparse::dev::SpmspvScratch& w = c->csc_scratch;
+    for (void* p : {static_cast<void*>(c->d_csc_indptr), static_cast<void*>(c->d_csc_rows), static_cast<void*>(c->d_csc_vals), w.accumulators,
+                    static_cast<void*>(c->d_csc_y), static_cast<void*>(c->d_sx), static_cast<void*>(w.keys[0]), static_cast<void*>(w.keys[1]),
+                    static_cast<void*>(w.vals[0]), static_cast<void*>(w.vals[1]), static_cast<void*>(w.lengths), static_cast<void*>(w.place), w.temp})
         if (p) (void)hipFree(p);
     c->d_csc_indptr = c->d_csc_rows = c->d_csc_vals = c->d_csc_y = c->d_sx = nullptr;
-    c->d_csc_acc = nullptr;
+    w = hisparse::dev::SpmspvScratch();
     c->sx_capacity = 0;
     c->csc_rows = c->csc_cols = 0;
     c->csc_nnz = 0;
@@ -540,7 +543,15 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* 
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_indptr), (size_t(num_cols) + 1) * 4));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_rows), std::max<size_t>(nnz, 1) * 4));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_vals), std::max<size_t>(nnz, 1) * 4));
-    HS_HIP(ctx, hipMalloc(&ctx->d_csc_acc, size_t(num_rows) * (is_float ? 4 : 8)));
+    hisparse::dev::SpmspvScratch& w = ctx->csc_scratch;
+    HS_HIP(ctx, hipMalloc(&w.accumulators, size_t(num_rows) * (is_float ? 4 : 8)));
+    w.capacity = std::max<uint64_t>(nnz, 1);
+    for (int k = 0; k < 2; ++k) {
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.keys[k]), size_t(w.capacity) * 4));
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.vals[k]), size_t(w.capacity) * 4));
+    }
+    w.temp_bytes = hisparse::dev::spmspv_sort_temp_bytes(w.capacity, num_rows);
+    HS_HIP(ctx, hipMalloc(&w.temp, w.temp_bytes));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemcpy(ctx->d_csc_indptr, indptr, (size_t(num_cols) + 1) * 4, hipMemcpyHostToDevice));
     if (nnz) {
@@ -567,6 +578,12 @@ int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
         ctx->sx_capacity = 0;
         const uint32_t cap = std::max<uint32_t>(count, 1024);
         HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_sx), size_t(cap) * 8));
+        hisparse::dev::SpmspvScratch& w = ctx->csc_scratch;
+        if (w.lengths) (void)hipFree(w.lengths);
+        if (w.place) (void)hipFree(w.place);
+        w.lengths = w.place = nullptr;
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.lengths), (size_t(cap) + 1) * 4));
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.place), (size_t(cap) + 1) * 4));
         ctx->sx_capacity = cap;
     }
     if (count) {     // IDX_VAL_T pairs -> two arrays (coalesced reads on the device)
@@ -579,7 +596,8 @@ int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
         HS_HIP(ctx, hipStreamSynchronize(ctx->stream));     // `split` is a temporary
     }
     HS_HIP(ctx, hisparse::dev::launch_spmspv(ctx->impl != HS_IMPL_FIXED, ctx->d_csc_indptr, ctx->d_csc_rows, ctx->d_csc_vals, ctx->d_sx,
-                                             ctx->d_sx + count, count, ctx->csc_rows, ctx->csc_cols, ctx->d_csc_acc, ctx->d_csc_y, ctx->stream));
+                                             ctx->d_sx + count, count, ctx->csc_rows, ctx->csc_cols, ctx->csc_scratch, ctx->d_csc_y, ctx->stream,
+                                             &ctx->spmspv_products));
     return HS_OK;
 }
 

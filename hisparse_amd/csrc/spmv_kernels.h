@@ -58,11 +58,24 @@ hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_
                                  uint32_t row_hi, hipStream_t stream, uint32_t* x_fb = nullptr, uint32_t n_fb = 0, uint32_t scale = 0,
                                  uint32_t shift = 0);
 
-// SpMSpV extension (spmspv.hip): y = A x for x given as x_count (index, value word) pairs over a CSC matrix; `accumulators` is
-// scratch of num_rows x 8 bytes (fixed) / 4 bytes (float).  Zeroes the accumulators, scatters, clamps / copies into y.
+// SpMSpV extension (spmspv.hip): y = A x for x given as x_count (index, value word) pairs over a CSC matrix.  The selected columns'
+// products are expanded into a (row, product) list, binned by row block and accumulated in LDS (no global atomics); a handful of
+// products goes through a direct scatter instead.  Scratch, owned by the caller (hs_api.cpp):
+struct SpmspvScratch {
+    uint32_t* keys[2] = {nullptr, nullptr};     // [capacity] rows of the expanded products, and the binned copy
+    uint32_t* vals[2] = {nullptr, nullptr};     // [capacity] product words
+    uint64_t capacity = 0;                      // = the matrix's non-zeros
+    uint32_t* lengths = nullptr;                // [x capacity + 1] selected column lengths ...
+    uint32_t* place = nullptr;                  // ... and their exclusive scan
+    void* temp = nullptr;                       // hipCUB temporary storage (spmspv_sort_temp_bytes)
+    size_t temp_bytes = 0;
+    void* accumulators = nullptr;               // num_rows x 8 bytes (fixed) / 4 bytes (float): the direct path's global accumulators
+};
+size_t spmspv_sort_temp_bytes(uint64_t max_elements, uint32_t num_rows);
+// products_out (may be null): how many products the call formed.  Synchronises the stream once (the product count sizes the passes).
 hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, const uint32_t* x_index,
-                         const uint32_t* x_words, uint32_t x_count, uint32_t num_rows, uint32_t num_cols, void* accumulators, uint32_t* y,
-                         hipStream_t stream);
+                         const uint32_t* x_words, uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& scratch, uint32_t* y,
+                         hipStream_t stream, uint64_t* products_out = nullptr);
 
 // Multi-GPU gather without a collective: y[0, words) into n_dst <= kMaxPushTargets other buffers (peers' memory over xGMI) with plain stores.
 constexpr uint32_t kMaxPushTargets = 8;

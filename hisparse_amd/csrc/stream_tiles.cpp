@@ -562,8 +562,12 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     // ---- workgroups: longest-processing-time assignment of blocks (tiles_common.h) ------------------------------
     std::vector<std::vector<uint32_t>> mine;
     {
-        // x larger than an XCD's L2 can keep next to the stream: blocks go to XCDs by column slice (tiles_common.h)
-        bool by_slice = slices > 1 && uint64_t(num_cols) * 4 > kSliceAffinityMinXBytes && G % 8 == 0 && NB >= G;
+        // Blocks to XCDs by column slice (tiles_common.h: assign_workgroups_by_slice) -- OPT-IN (HISPARSE_XCD_AFFINITY=1).  Built in round 3
+        // for matrices whose x outgrows an XCD's L2 (ogbn-products: 9.8 MB of x, 5 slices; ~20 % of the x refills miss L2) and measured:
+        // same kernel time (203.6 vs 205.5 us, same box) and, by the counters, the SAME traffic (1084.7 vs 1087.5 MB of reads per launch:
+        // 208 MB of it x either way) -- the refills are evicted by the matrix stream passing through the same L2, not by the other
+        // slices' x.  Kept for experiments; the default stays the spread assignment.
+        bool by_slice = false;
         if (const char* force = env_switch("HISPARSE_XCD_AFFINITY")) by_slice = std::atoi(force) != 0 && slices > 1 && G % 8 == 0 && NB >= G;
         if (by_slice) {
             std::vector<uint32_t> slice_of_block(NB);

@@ -82,7 +82,6 @@ constexpr uint32_t kAccumulatorBytes = 8;
 constexpr uint32_t max_block_rows(bool sliced) { return (sliced ? 96u : 32u) * 1024u / kAccumulatorBytes - 1u; }
 constexpr uint32_t kMaxColSlices = 8;
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
-constexpr uint64_t kSliceAffinityMinXBytes = 3u << 20;      // x beyond this: blocks are assigned to XCDs by column slice (tiles_common.h)
 // PAIRS format
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
 constexpr uint32_t kWaveStrideBytes = kChunkBytes * kConsumerWaves;   // chunks of the 14 wavefronts are interleaved in memory

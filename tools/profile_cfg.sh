@@ -17,4 +17,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- $CMD > "$O
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o write -- $CMD > "$OUT/write.log" 2>&1
 python tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
 tail -3 "$OUT/stats.log" >> "$OUT/summary.txt"
+# the rocpd databases are tens of MB each and gpurun merges at most 64 MiB back: keep the summaries only
+rm -rf "$OUT/stats" "$OUT/fetch" "$OUT/write"
 cat "$OUT/summary.txt"
