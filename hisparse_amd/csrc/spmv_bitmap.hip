@@ -118,7 +118,13 @@ __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uin
     // two standard masks costs ~20 vector instructions and 4 scalar registers per step, the unrolled batch spilled 59 SGPRs, and the
     // larger code pays twice at the cold instruction cache of every launch.  The timeline says the run is bound by round trips
     // (transformer-80, with 2.5 x fewer non-zeros, takes the same 7.0 us for its runs), so wide steps remain the lever -- but they need
-    // masks stored as (even columns, odd columns) pairs so that v_mbcnt and SGPR-pair selects do the work; an image-format change.)
+    // masks stored as (even columns, odd columns) pairs so that v_mbcnt and SGPR-pair selects do the work; an image-format change.
+    // A second experiment says that would not pay either: batches of 16 steps (twice the loads in flight, per-lane set bits instead of
+    // masks in SGPRs) ran 20.3 us against 16.2, same box, with the run phase at 7.6 us instead of 7.0.  So the run is bound neither by
+    // bytes nor by round trips but by vector-memory INSTRUCTIONS: 266 K steps x 2 loads / 256 CUs = 2080 wave-loads per CU in 7 us =
+    // one per 7 clocks, and a 64-lane dword load occupies the CU's address path for 4 of them whether the lanes carry 32 useful
+    // values (50 % density) or 13 (20 %).  The levers left are structural: several ROWS of the same group range per wavefront (one x
+    // load for all of them) and compacted value loads handed to the lanes through ds_bpermute.)
     // Two batches: 16 loads of the next one are in flight while a batch is consumed.  Three in flight measured SLOWER (16.6 ->
     // 17.7 us on transformer-50), and so did the nt policy on the value loads (-> 17.6 us: the 36 MB image lives in the 256 MiB
     // Infinity Cache between launches); the timeline (tools/bitmap_timeline.py) shows the run itself streaming at ~5.5 TB/s and
