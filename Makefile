@@ -30,7 +30,7 @@ $(LIBDIR):
 $(LIBDIR)/libhisparse_host.so: $(CSRC)/host_capi.cpp $(HOST_HDRS) | $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $< -lz
 
-HIP_SRCS  := $(CSRC)/hs_api.cpp $(CSRC)/tiles_capi.cpp $(CSRC)/stream_tiles.cpp $(CSRC)/bitmap_tiles.cpp $(CSRC)/spmv_kernels.hip $(CSRC)/spmv_bitmap.hip $(CSRC)/spmspv.hip $(CSRC)/spmm_bitmap.hip $(CSRC)/gpu_tiles.hip
+HIP_SRCS  := $(CSRC)/hs_api.cpp $(CSRC)/tiles_capi.cpp $(CSRC)/stream_tiles.cpp $(CSRC)/bitmap_tiles.cpp $(CSRC)/spmv_kernels.hip $(CSRC)/spmv_bitmap.hip $(CSRC)/spmspv.hip $(CSRC)/spmm_bitmap.hip $(CSRC)/spmm_mfma.hip $(CSRC)/gpu_tiles.hip
 $(LIBDIR)/libhisparse_hip.so: $(HIP_SRCS) $(HIP_HDRS) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS) -pthread
 

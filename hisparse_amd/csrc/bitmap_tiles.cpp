@@ -238,6 +238,68 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     });
     timer.lap("bitmap: emit");
 
+    // ---- float modes: the second image, for the SpMM on the matrix engine (stream_tiles.h: MfmaImage; kernel: spmm_mfma.hip) -------------
+    if (L.g->impl != IMPL_FIXED && !env_switch("HISPARSE_NO_MFMA_IMAGE")) {
+        MfmaImage& mi = out.mfma;
+        mi.tiles = (num_rows + kMfmaTileRows - 1) / kMfmaTileRows;
+        mi.groups = GR;
+        // wavefront units of `chunk` groups: enough of them for every SIMD of the chip (1024) to get two or three; four units (one
+        // workgroup) never straddle two row tiles
+        mi.chunk = std::max<uint32_t>(4, std::min<uint32_t>(32, uint32_t(uint64_t(mi.tiles) * GR / 2560 + 1)));
+        mi.chunks = ((GR + mi.chunk - 1) / mi.chunk + 3) / 4 * 4;
+        const uint64_t mask_words = uint64_t(mi.tiles) * GR * kMfmaTileRows * 2;
+        mi.offsets_word = mask_words;
+        mi.values_word = mi.offsets_word + uint64_t(mi.tiles) * mi.chunks;
+        if ((mi.values_word + nnz + 64) >= (uint64_t(1) << 32)) {
+            mi = MfmaImage();          // value offsets are 32-bit words: beyond that the SpMM keeps its other path
+        } else {
+            resize_zeroed(mi.words, (mi.values_word + nnz + 64) * 4);
+            uint32_t* words = reinterpret_cast<uint32_t*>(mi.words.data());
+            uint64_t* masks = reinterpret_cast<uint64_t*>(words);
+            uint32_t* unit_base = words + mi.offsets_word;
+            uint32_t* values = words + mi.values_word;
+            // masks: the 16 rows of a tile side by side per group
+            parallel_for(num_rows, [&](size_t r) {
+                const uint32_t t = uint32_t(r / kMfmaTileRows), i = uint32_t(r % kMfmaTileRows);
+                const uint64_t* e = elems + row_ptr[r];
+                for (uint32_t k = 0; k < row_nnz[r]; ++k) {
+                    const uint64_t col = e[k] >> 32;
+                    masks[(uint64_t(t) * GR + col / kBitmapGroupCols) * kMfmaTileRows + i] |= 1ull << (col % kBitmapGroupCols);
+                }
+            });
+            // values in the order the kernel's lanes take them: tile, group, MFMA step s (columns 4 s .. 4 s + 3 of the group), lane
+            // l = 16 k + i (row i of the tile, column 4 s + k): the values of one step are one contiguous, coalesced load
+            std::vector<uint64_t> tile_base(size_t(mi.tiles) + 1, 0);
+            for (uint32_t t = 0; t < mi.tiles; ++t) {
+                uint64_t n = 0;
+                for (uint32_t r = t * kMfmaTileRows; r < std::min(num_rows, (t + 1) * kMfmaTileRows); ++r) n += row_nnz[r];
+                tile_base[t + 1] = tile_base[t] + n;
+            }
+            parallel_for(mi.tiles, [&](size_t t) {
+                uint32_t cursor[kMfmaTileRows] = {0};            // next element of every row of the tile (rows are in column order)
+                uint64_t at = tile_base[t];
+                for (uint32_t g = 0; g < GR; ++g) {
+                    if (g % mi.chunk == 0) unit_base[t * mi.chunks + g / mi.chunk] = uint32_t(at);
+                    const uint64_t* m = masks + (uint64_t(t) * GR + g) * kMfmaTileRows;
+                    uint32_t first[kMfmaTileRows];               // the row's first element of this group
+                    for (uint32_t i = 0; i < kMfmaTileRows; ++i) first[i] = cursor[i];
+                    for (uint32_t s4 = 0; s4 < 16; ++s4)
+                        for (uint32_t k = 0; k < 4; ++k)
+                            for (uint32_t i = 0; i < kMfmaTileRows; ++i) {
+                                const uint32_t p = 4 * s4 + k;
+                                if (!((m[i] >> p) & 1ull)) continue;
+                                const uint32_t r = uint32_t(t) * kMfmaTileRows + i;
+                                const uint32_t rank = uint32_t(__builtin_popcountll(m[i] & ((1ull << p) - 1ull)));
+                                values[at++] = uint32_t(elems[row_ptr[r] + first[i] + rank]);
+                            }
+                    for (uint32_t i = 0; i < kMfmaTileRows; ++i) cursor[i] += uint32_t(__builtin_popcountll(m[i]));
+                }
+                for (uint32_t c = (GR + mi.chunk - 1) / mi.chunk; c < mi.chunks; ++c) unit_base[t * mi.chunks + c] = uint32_t(at);   // units past the last group: empty
+            });
+        }
+        timer.lap("bitmap: second image (matrix engine SpMM)");
+    }
+
     std::vector<std::vector<uint32_t>> mine;
     assign_workgroups(out, block_weight, G, RP, mine);
     chain_blocks(out, mine, RP);

@@ -51,6 +51,13 @@ struct hs_context {
     uint32_t* d_partial = nullptr;  // col_slices > 1: per-slice partial results, col_slices x num_rows words
     uint32_t max_block_rows = 0;
     uint32_t* d_x_interleaved = nullptr;   // fused SpMM over a BITMAP image: 4 columns of X as [column][vector] words (allocated on first use)
+    // SpMM on the matrix engine (float BITMAP matrices): the second image + scratch (spmm_mfma.hip)
+    uint32_t* d_mfma = nullptr;
+    hisparse::dev::MfmaImage mfma_info;    // geometry only (words empty)
+    uint32_t* d_mfma_x = nullptr;
+    float* d_mfma_partial = nullptr;
+    uint32_t* d_mfma_flag = nullptr;
+    uint32_t mfma_call = 0;
 
     // SpMSpV extension: the matrix once more, in CSC form (hs_load_matrix_csc), + scratch
     uint32_t* d_csc_indptr = nullptr;
@@ -105,6 +112,11 @@ void free_matrix(hs_context* c) {
     c->d_partial = nullptr;
     if (c->d_x_interleaved) (void)hipFree(c->d_x_interleaved);
     c->d_x_interleaved = nullptr;
+    for (void* p : {static_cast<void*>(c->d_mfma), static_cast<void*>(c->d_mfma_x), static_cast<void*>(c->d_mfma_partial), static_cast<void*>(c->d_mfma_flag)})
+        if (p) (void)hipFree(p);
+    c->d_mfma = c->d_mfma_x = c->d_mfma_flag = nullptr;
+    c->d_mfma_partial = nullptr;
+    c->mfma_info = hisparse::dev::MfmaImage();
     c->d_image = nullptr;
     c->d_blocks = nullptr;
     c->d_units = nullptr;
@@ -363,6 +375,16 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
     if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
+    if (!tiles.mfma.words.empty()) {      // float BITMAP matrix: the second image for the SpMM on the matrix engine + its scratch
+        const hisparse::dev::MfmaImage& mi = tiles.mfma;
+        HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_mfma), mi.words.data(), mi.words.size(), 0));
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_x), hisparse::dev::spmm_mfma_x_words(mi.groups) * 4));
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_partial), hisparse::dev::spmm_mfma_partial_words(mi.tiles, mi.chunks) * 4));
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_flag), 64));
+        HS_HIP(ctx, hipMemset(ctx->d_mfma_flag, 0, 64));
+        ctx->mfma_info.tiles = mi.tiles; ctx->mfma_info.groups = mi.groups; ctx->mfma_info.chunk = mi.chunk; ctx->mfma_info.chunks = mi.chunks;
+        ctx->mfma_info.offsets_word = mi.offsets_word; ctx->mfma_info.values_word = mi.values_word;
+    }
     if (debug) std::fprintf(stderr, "load: descriptors + result buffers on the device after %.1f ms\n", since());
     ctx->num_rows = num_rows;
     ctx->num_cols = num_cols;
@@ -705,7 +727,31 @@ int hs_spmm_device(hs_context* ctx, const void* x_dev, uint64_t ldx, void* y_dev
     // BITMAP images (dense rows: pruned-NN layers, which are multiplied with batches in practice): 4, then 2 columns at a time through
     // the fused kernel of spmm_bitmap.hip -- masks and values are streamed once for them.  Everything else, and a last odd column:
     // one SpMV per column.
-    static const bool fused_enabled = [] { const char* e = std::getenv("HISPARSE_SPMM_FUSED"); return !(e && std::string(e) == "0"); }();
+    const char* fused_env = std::getenv("HISPARSE_SPMM_FUSED");      // read per call (a test may change it)
+    const bool fused_enabled = !(fused_env && std::string(fused_env) == "0");
+    const char* mfma_env = std::getenv("HISPARSE_SPMM_MFMA");
+    // float BITMAP matrices, 16 columns at a time on the matrix engine: the matrix is streamed once per 16 columns and every x word is
+    // shared by 16 rows in registers (spmm_mfma.hip)
+    if (fused_enabled && !(mfma_env && std::string(mfma_env) == "0") && ctx->d_mfma && is_float) {
+        while (k - j >= 16) {
+            hisparse::dev::SpmmMfmaLaunch a;
+            a.words = ctx->d_mfma;
+            a.offsets_word = ctx->mfma_info.offsets_word; a.values_word = ctx->mfma_info.values_word;
+            a.tiles = ctx->mfma_info.tiles; a.groups = ctx->mfma_info.groups; a.chunk = ctx->mfma_info.chunk; a.chunks = ctx->mfma_info.chunks;
+            a.x = static_cast<const uint32_t*>(x_dev) + size_t(j) * ldx;
+            a.ldx = ldx;
+            a.x_interleaved = ctx->d_mfma_x;
+            a.partial = ctx->d_mfma_partial;
+            a.flag = ctx->d_mfma_flag;
+            a.call = ++ctx->mfma_call ? ctx->mfma_call : ++ctx->mfma_call;
+            a.y = static_cast<uint32_t*>(y_dev) + size_t(j) * ldy;
+            a.ldy = ldy;
+            a.num_rows = ctx->num_rows;
+            a.num_cols = ctx->num_cols;
+            HS_HIP(ctx, hisparse::dev::launch_spmm_mfma(a, ctx->stream));
+            j += 16;
+        }
+    }
     if (fused_enabled && ctx->format == hisparse::dev::kFormatBitmap && ctx->col_slices == 1) {
         for (uint32_t group : {4u, 2u}) {
             if (ctx->max_block_rows > hisparse::dev::spmm_bitmap_max_block_rows(is_float, group)) continue;

@@ -49,6 +49,26 @@ struct SpmmLaunch {
 };
 uint32_t spmm_bitmap_max_block_rows(bool is_float, uint32_t vectors);   // rows per block whose accumulators still fit the LDS
 hipError_t launch_spmm_bitmap(bool is_float, const SpmmLaunch& a, hipStream_t stream);
+// SpMM on the matrix engine over the second image of a float BITMAP matrix (spmm_mfma.hip; stream_tiles.h: MfmaImage): 16 columns of X per
+// call.  Leaves y untouched (and sets *flag) when X holds a non-finite word: 0.0 x inf inside an MFMA would poison rows that do not touch
+// that column -- launch_spmm_exact then computes the 16 columns the way the PEs would.
+struct SpmmMfmaLaunch {
+    const uint32_t* words;        // the MfmaImage on the device
+    uint64_t offsets_word, values_word;
+    uint32_t tiles, groups, chunk, chunks;
+    const uint32_t* x;            // column j of X at x + j * ldx words
+    uint64_t ldx;
+    uint32_t* x_interleaved;      // scratch: spmm_mfma_x_words(groups) words
+    float* partial;               // scratch: spmm_mfma_partial_words(tiles, chunks) floats
+    uint32_t* flag;               // scratch: one word (zero at allocation): becomes `call` when X holds a non-finite word
+    uint32_t call;                // a number no earlier call on this context has used (never 0)
+    uint32_t* y;                  // column j of Y at y + j * ldy words
+    uint64_t ldy;
+    uint32_t num_rows, num_cols;
+};
+size_t spmm_mfma_x_words(uint32_t groups);
+size_t spmm_mfma_partial_words(uint32_t tiles, uint32_t chunks);
+hipError_t launch_spmm_mfma(const SpmmMfmaLaunch& a, hipStream_t stream);
 // BITMAP images (spmv_bitmap.hip); launch_spmv forwards to it when a.format == kFormatBitmap.
 hipError_t configure_bitmap_kernels(uint32_t lds_bytes);
 hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream);

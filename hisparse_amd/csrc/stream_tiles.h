@@ -216,8 +216,25 @@ struct DefaultInitAllocator : std::allocator<T> {
 };
 using ImageBytes = std::vector<uint8_t, DefaultInitAllocator<uint8_t>>;
 
+// The second image of a float BITMAP matrix, for the SpMM on the matrix engine (spmm_mfma.hip): rows in TILES of 16, every
+// (tile, 64-column group) holds the 16 rows' occupancy masks side by side; the values are compacted in the order the kernel's lanes take
+// them -- tile, group, MFMA step s (columns 4 s .. 4 s + 3), lane 16 k + i (row i, column 4 s + k) -- so that the values of one step are
+// one coalesced load at (running base + set bits below the lane in the step's ballot); the value index at the start of every wavefront's
+// chunk of groups sits in a table.  One allocation of 32-bit words:
+//   [masks: tiles x groups x 16 x u64][unit bases: tiles x chunks x u32][values]
+struct MfmaImage {
+    ImageBytes words;                    // as laid out above (empty: no such image)
+    uint32_t tiles = 0;                  // ceil(num_rows / 16)
+    uint32_t groups = 0;                 // 64-column groups per row
+    uint32_t chunk = 0;                  // groups per wavefront unit
+    uint32_t chunks = 0;                 // ceil(groups / chunk), rounded up to a multiple of 4 (a workgroup of four units stays inside one row tile)
+    uint64_t offsets_word = 0, values_word = 0;   // word offsets of the two tables behind the masks
+};
+constexpr uint32_t kMfmaTileRows = 16;
+
 struct StreamTiles {
     ImageBytes image;                    // element streams, uploaded verbatim (host builder)
+    MfmaImage mfma;                      // float BITMAP images only (bitmap_tiles.cpp)
     uint8_t* d_image = nullptr;          // GPU builder: the image, already in device memory (image_bytes + slack); the caller owns it
     uint64_t image_bytes = 0;
     std::vector<Block> blocks;
