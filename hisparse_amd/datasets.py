@@ -64,6 +64,7 @@ CONFIGS = {
     "transformer_95": Config("transformer_95", "float_pob", 512, 33288, "bernoulli", 0, 0.05, 0.05, 95, "transformer_95_512_33288_csr_float32.npz"),
     # one rank's share of mouse_gene split 8 / 4 ways by non-zeros (bench.py --gpus 8 / 4): the small-slab regime (tools/, tests)
     "mouse_gene_slab8": Config("mouse_gene_slab8", "fixed", 5638, 45101, "powerlaw", 3620911, 0.30, 0.1, 44, ""),
+    "mouse_gene_slab2": Config("mouse_gene_slab2", "fixed", 22550, 45101, "powerlaw", 14483645, 0.30, 0.1, 44, ""),
     "mouse_gene_slab4": Config("mouse_gene_slab4", "fixed", 11275, 45101, "powerlaw", 7241822, 0.30, 0.1, 44, ""),
     # small relatives for tests / smoke
     "ppa_small": Config("ppa_small", "fixed", 40000, 70000, "powerlaw", 1400000, 0.35, 1.0, 7, ""),

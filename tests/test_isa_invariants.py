@@ -167,3 +167,14 @@ def test_stream_loads_are_non_temporal_and_loaders_use_lds_dma(shipped):
         assert stream and all(i.endswith(" nt") for i in stream), f"{n}: stream loads without the nt policy"
         assert any("global_load_lds_dwordx4" in i for i in body), f"{n}: the x ring is not refilled by LDS-DMA"
         assert any(i.startswith("s_setprio") for i in body), f"{n}: loader wavefronts without raised priority"
+
+
+def test_spmm_kernel_uses_the_matrix_engine(shipped):
+    """The one place in this library where a dense contraction exists: the SpMM over a float BITMAP matrix runs on v_mfma_f32_16x16x4_f32
+    (spmm_mfma.hip), without scratch."""
+    meta, code = shipped
+    names = [n for n in meta if "spmm_mfma_kernel" in n]
+    assert len(names) == 1
+    body = code[names[0]]
+    assert len([i for i in body if i.startswith("v_mfma_f32_16x16x4_f32")]) == 16
+    assert meta[names[0]].get("private_segment_fixed_size", 0) == 0

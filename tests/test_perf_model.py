@@ -60,9 +60,10 @@ def test_model_within_15_percent_of_the_measured_kernel(name, record_property):
 @pytest.mark.gpu
 def test_planner_choice_is_the_measured_optimum_of_the_sweep(record_property):
     """The tile-size sweep (the counterpart of design_space_exp.cpp:515-540) on ogbn-products, every point measured: the plan the planner
-    picks unforced must be within 4 % of the best measured point (boxes repeat to ~2 %)."""
+    picks unforced must be within 4 % of the best measured point (boxes repeat to ~2 %).  (Row caps from 8191 up: the full sweep down to
+    128 rows per block -- milliseconds per SpMV, profiles/r03_perf_model_gpu_tests.txt -- takes five minutes and adds nothing near the optimum.)"""
     out = io.StringIO()
-    grid = perf_model.sweep("ogbn_products", measure_points=True, out=out)
+    grid = perf_model.sweep("ogbn_products", measure_points=True, out=out, rows_options=(8191, 12287, 16369, 24561))
     print(out.getvalue())
     cp, impl, t, parts = perf_model.model("ogbn_products")
     chosen = (t["col_slices"], int(t["max_block_rows"]))

@@ -97,7 +97,7 @@ def measure(cp, impl):
     return best
 
 
-def sweep(name, measure_points=True, out=sys.stdout):
+def sweep(name, measure_points=True, out=sys.stdout, rows_options=(128, 512, 2047, 4095, 8191, 12287, 16369, 24561)):
     """Model (and, with a GPU, measurement) over column slices x rows per block; returns {(slices, rows): (model_us, measured_us)}."""
     cfg, csr = datasets.load(name)
     impl = host.impl_id(cfg.impl)
@@ -106,7 +106,7 @@ def sweep(name, measure_points=True, out=sys.stdout):
     saved = {k: os.environ.get(k) for k in ("HISPARSE_COL_SLICES", "HISPARSE_MAX_ROWS")}
     try:
         for cs in (1, 2, 3, 4, 5, 6, 8):
-            for rows in (128, 512, 2047, 4095, 8191, 12287, 16369, 24561):
+            for rows in rows_options:
                 os.environ["HISPARSE_COL_SLICES"], os.environ["HISPARSE_MAX_ROWS"] = str(cs), str(rows)
                 try:
                     _, _, t, parts = model(name, cp, impl)
