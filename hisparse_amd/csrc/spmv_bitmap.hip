@@ -125,6 +125,11 @@ __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uin
     // one per 7 clocks, and a 64-lane dword load occupies the CU's address path for 4 of them whether the lanes carry 32 useful
     // values (50 % density) or 13 (20 %).  The levers left are structural: several ROWS of the same group range per wavefront (one x
     // load for all of them) and compacted value loads handed to the lanes through ds_bpermute.)
+    // A third experiment: ablation builds say that with every load and all arithmetic removed the run still takes 5.8 of its 9.6 us (8
+    // vector-ALU instructions per step), so the eight multiply-adds of a batch were put under exec = mask in one asm block (hipcc emits
+    // multiply + v_cndmask + add: one vector instruction more per step).  Slower, 16.5 against 15.8 us on the same box: the asm block has to
+    // wait for the LAST of the batch's 16 loads before its first multiply, while hipcc's code consumes the loads as they land
+    // (vmcnt(14), (12), ...) -- the loop lives on that overlap, not on instruction count.
     // Two batches: 16 loads of the next one are in flight while a batch is consumed.  Three in flight measured SLOWER (16.6 ->
     // 17.7 us on transformer-50), and so did the nt policy on the value loads (-> 17.6 us: the 36 MB image lives in the 256 MiB
     // Infinity Cache between launches); the timeline (tools/bitmap_timeline.py) shows the run itself streaming at ~5.5 TB/s and
@@ -258,7 +263,7 @@ hipError_t configure_bitmap_kernels(uint32_t lds_bytes) {
 hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.num_workgroups == 0) return hipSuccess;
     const dim3 grid(a.num_workgroups), block(kBmThreads);
-    static const int ablate = bitmap_env_int("HISPARSE_ABLATE", 0);
+    const int ablate = bitmap_env_int("HISPARSE_ABLATE", 0);       // read per launch: a process may switch profiling builds between runs
     // timeline build: HISPARSE_ABLATE=64 HISPARSE_TIMELINE_OUT=file -> every launch is synchronised and its per-wavefront
     // timestamps (workgroups x 16 x 8 u64, 100 MHz) overwrite the file (tools/bitmap_timeline.py reads it)
     static uint64_t* timeline = nullptr;

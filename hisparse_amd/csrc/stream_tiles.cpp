@@ -177,8 +177,12 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             // unforced: 1, 2, 4, 8 -- and everything in between for OWNER, where the x volume decides: ogbn-products runs 241 us in 5
             // slices (102 ranges of 24 K rows, 2 blocks per workgroup) against 280 in 2 (127 ranges) and 275 in 4; ogbl-ppa gains
             // 1 us of kernel in 5 and loses it in the combine pass, the R-MAT stand-in is 3 us slower
-            if (force_slices ? uint32_t(std::atoi(force_slices)) != cs : (!owner && (cs & (cs - 1)) != 0)) continue;
+            // (a matrix of at most eight sub-tiles: every count up to that -- a slice per sub-tile is the plan without x refills and
+            // unit barriers, and a power of two above the sub-tile count would leave whole slices, i.e. workgroups, empty)
+            const uint32_t live_tiles = (num_cols + kSubTileCols - 1) / kSubTileCols;
+            if (force_slices ? uint32_t(std::atoi(force_slices)) != cs : (!owner && (cs & (cs - 1)) != 0 && live_tiles > kMaxColSlices)) continue;
             if (cs > 1 && uint64_t(CP) * S < cs) continue;                                    // fewer sub-tiles than slices
+            if (!force_slices && !owner && live_tiles <= kMaxColSlices && cs > live_tiles) continue;
             for (const Shape& shape : (cs > 1 || owner) ? std::vector<Shape>(sliced, sliced + 2) : std::vector<Shape>(whole, whole + 1)) {
                 uint32_t cap = shape.cap, ring = shape.ring;
                 if (force_rows) {
@@ -203,11 +207,22 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                 // for 29 MB; in 3 column slices (blocks of 66 rows, ordinary path) 11.5 us + the combine pass.  Price it.
                 const double rows_per_block = double(num_rows) / ranges, per_row_and_tile = double(out.nnz) / std::max(1.0, double(num_rows) * sub_tiles);
                 if (!owner && rows_per_block <= kDenseBlockRows && per_row_and_tile < 4.0 * kWaveLanes) latency_us += units_per_wg * 1.75;
+                // PAIRS deals a unit's elements, sorted by (row, column), to the lanes in consecutive runs: the 64 lanes of a step sit
+                // 1/896 of the unit apart, and when the block has fewer than 896 rows several of them are in the SAME row -- their
+                // ds_add_u64 on one accumulator are serialised.  One rank's slab of mouse_gene split 4 ways (44-row blocks, ~20 lanes
+                // per row): 15-26 us in one slice against 12.7-13.7 us in six (268-row blocks, one sub-tile each, combine pass included).
+                // ~2 clocks per extra lane and wavefront step, all wavefronts of a workgroup through the one LDS.  (DELTA blocks of
+                // long rows keep per-lane sums instead -- no atomics to collide.)
+                const double lanes_per_row = std::min(64.0, 896.0 / std::max(1.0, rows_per_block));
+                // (DELTA is still tentative here: below ~1.6 bytes saved per non-zero x nnz < the threshold it falls back to PAIRS, see "DELTA or PAIRS")
+                const bool pairs_likely = !delta || (!format_forced && double(out.nnz) * 1.6 < double(is_float ? kDeltaMinSavedBytesFloat : kDeltaMinSavedBytes));
+                const double conflict_us = (!owner && pairs_likely && lanes_per_row > 1.0 && per_row_and_tile >= 16.0)
+                                               ? double(out.nnz) / G / kWaveLanes * (lanes_per_row - 1.0) * 2.0 / 2400.0 : 0.0;
                 const double combine_us = cs > 1 ? 3.5 + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
-                const double cost = volume_us + latency_us + 8.0 * blocks_per_wg + combine_us;
+                const double cost = volume_us + latency_us + conflict_us + 8.0 * blocks_per_wg + combine_us;
                 if (std::getenv("HISPARSE_PLAN_DEBUG"))
-                    std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f blocks/wg %.1f combine %.1f => %.1f us\n", cs, cap, ring, ranges,
-                                 volume_us, latency_us, blocks_per_wg, combine_us, cost);
+                    std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f conflicts %.1f blocks/wg %.1f combine %.1f => %.1f us\n", cs, cap, ring, ranges,
+                                 volume_us, latency_us, conflict_us, blocks_per_wg, combine_us, cost);
                 if (cost < best) { best = cost; slices = cs; max_rows = cap; }
             }
         }
