@@ -9,6 +9,7 @@
 #include <memory>
 #include <numeric>
 
+#include "gpu_tiles.h"
 #include "hisparse/q8_24.h"
 #include "tiles_common.h"
 
@@ -19,7 +20,7 @@ using namespace detail;
 
 bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
                         const std::vector<uint32_t>& row_nnz, uint32_t max_workgroups, StreamTiles& out, std::string& error,
-                        const CsrView* csr) {
+                        const CsrView* csr, GpuTiler* gpu, uint64_t image_slack) {
     const uint32_t num_rows = L.num_rows, num_cols = L.num_cols, RP = L.row_parts, CP = L.col_parts;
     const uint32_t G = std::max<uint32_t>(1, max_workgroups);
     // a mask per 64 columns of every row: only sensible for dense rows; when the format is FORCED onto a big sparse matrix
@@ -32,12 +33,15 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     PhaseTimer timer;
 
     // ---- rows back in CSR form: (absolute column, value word) per row ------------------------------------------------------
+    // (host builder only: with a GpuTiler the elements stay on the device and every pass over them is a kernel of gpu_tiles.hip;
+    // the plan, the block layout and the wavefront runs below are the same code for both, so the two leave the same bytes)
     std::vector<uint64_t> row_ptr(size_t(num_rows) + 1, 0);
     for (uint32_t r = 0; r < num_rows; ++r) row_ptr[r + 1] = row_ptr[r] + row_nnz[r];
     const uint64_t nnz = row_ptr[num_rows];
-    const std::unique_ptr<uint64_t[]> elems_buf(new uint64_t[std::max<uint64_t>(nnz, 1)]);   // (not zeroed: every entry is written below)
+    const std::unique_ptr<uint64_t[]> elems_buf(new uint64_t[gpu ? 1 : std::max<uint64_t>(nnz, 1)]);   // (not zeroed: every entry is written below)
     uint64_t* const elems = elems_buf.get();               // column << 32 | value word: sorts by column
-    if (csr) {       // the rows are there already; value words as csr_matrix_convert_from_float gives them (sw/data_loader.h:76-84)
+    if (gpu) {
+    } else if (csr) {       // the rows are there already; value words as csr_matrix_convert_from_float gives them (sw/data_loader.h:76-84)
         const bool fixed = L.g->impl == IMPL_FIXED;
         std::atomic<bool> bad_column(false);
         parallel_for((csr->num_rows + 1023) / 1024, [&](size_t chunk) {
@@ -76,7 +80,7 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     // column order inside a row (the reference does not require sorted CSR input); a column that occurs twice in a row cannot be
     // a bit in a mask -> the caller falls back to the element-stream formats
     std::atomic<bool> duplicates(false);
-    parallel_for((num_rows + 1023) / 1024, [&](size_t chunk) {
+    if (!gpu) parallel_for((num_rows + 1023) / 1024, [&](size_t chunk) {
         for (uint32_t r = uint32_t(chunk) * 1024; r < std::min<uint64_t>(num_rows, (chunk + 1) * 1024); ++r) {
             uint64_t* e = elems + row_ptr[r];
             const uint32_t n = row_nnz[r];
@@ -118,18 +122,28 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     out.blocks.assign(NB, Block{});
     out.units.assign(size_t(NB) * kBitmapWaves * kBitmapRunSlots, Unit{});
     std::vector<uint64_t> block_nnz(NB, 0), block_base(NB + 1, 0), block_weight(NB, 0);
-    // non-zeros of every block (row range x slice of groups)
+    // non-zeros of every (row, slice of groups) and of every block (row range x slice)
+    std::vector<uint32_t> slice_nnz;          // [row * slices + k]
+    if (slices == 1) {
+        slice_nnz = row_nnz;
+    } else if (gpu) {
+        if (!gpu->bitmap_slice_counts(slices, GR, slice_nnz)) { error = gpu->error(); return false; }
+    } else {
+        slice_nnz.assign(size_t(num_rows) * slices, 0);
+        parallel_for((num_rows + 1023) / 1024, [&](size_t chunk) {
+            for (uint32_t r = uint32_t(chunk) * 1024; r < std::min<uint64_t>(num_rows, (chunk + 1) * 1024); ++r) {
+                const uint64_t* e = elems + row_ptr[r];
+                for (uint32_t k = 0; k < slices; ++k) {
+                    const uint64_t c0 = uint64_t(k) * GR / slices * kBitmapGroupCols, c1 = uint64_t(k + 1) * GR / slices * kBitmapGroupCols;
+                    slice_nnz[size_t(r) * slices + k] = uint32_t(std::lower_bound(e, e + row_nnz[r], c1 << 32) - std::lower_bound(e, e + row_nnz[r], c0 << 32));
+                }
+            }
+        });
+    }
     parallel_for(NB, [&](size_t bi) {
         const RowRange& rg = ranges[bi / slices];
-        const uint32_t k = uint32_t(bi % slices);
-        const uint64_t c0 = uint64_t(k) * GR / slices * kBitmapGroupCols, c1 = uint64_t(k + 1) * GR / slices * kBitmapGroupCols;
         uint64_t n = 0;
-        for (uint32_t r = rg.row0; r < rg.row0 + rg.nrows; ++r) {
-            const uint64_t* e = elems + row_ptr[r];
-            const uint64_t* lo = std::lower_bound(e, e + row_nnz[r], c0 << 32);
-            const uint64_t* hi = std::lower_bound(e, e + row_nnz[r], c1 << 32);
-            n += uint64_t(hi - lo);
-        }
+        for (uint32_t r = rg.row0; r < rg.row0 + rg.nrows; ++r) n += slice_nnz[size_t(r) * slices + bi % slices];
         block_nnz[bi] = n;
     });
     // A row is cut into `pieces` runs of (almost) equal group count -- one per wavefront when the block has few rows, one run per
@@ -154,9 +168,23 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         out.max_block_rows = std::max(out.max_block_rows, rg.nrows);
     }
     if (block_base[NB] / 4 >= (1ull << 40)) { error = "matrix too large for the bitmap image"; return false; }
-    resize_zeroed(out.image, block_base[NB]);
+    if (!gpu) resize_zeroed(out.image, block_base[NB]);
     out.image_bytes = block_base[NB];
     timer.lap("bitmap: plan");
+    // device builder: what its kernels need of the layout (filled per block below), and every wavefront run's start
+    std::vector<GpuTiler::BitmapBlock> dev_blocks(gpu ? NB : 0);
+    std::vector<GpuTiler::BitmapRun> dev_runs(gpu ? size_t(NB) * kBitmapWaves : 0);
+    std::vector<uint64_t> row_value_base(gpu ? size_t(num_rows) * slices : 0), run_value(gpu ? size_t(NB) * kBitmapWaves : 0);
+    if (gpu) {
+        uint64_t prefix0 = 0;
+        for (uint32_t bi = 0; bi < NB; ++bi) {
+            const RowRange& rg = ranges[bi / slices];
+            const uint32_t k = bi % slices, gs0 = uint32_t(uint64_t(k) * GR / slices), gs1 = uint32_t(uint64_t(k + 1) * GR / slices);
+            const uint32_t pieces = pieces_of(rg.nrows), stride = row_stride(gs1 - gs0, pieces);
+            dev_blocks[bi] = GpuTiler::BitmapBlock{rg.row0, rg.nrows, gs0, gs1 - gs0, pieces, stride, block_base[bi] / 8, prefix0};
+            prefix0 += uint64_t(rg.nrows) * stride;
+        }
+    }
 
     parallel_for(NB, [&](size_t bi) {
         const RowRange& rg = ranges[bi / slices];
@@ -180,14 +208,17 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
             piece_at[j + 1] = piece_at[j] + padded(cut(GS, pieces, j + 1) - cut(GS, pieces, j));
         }
         auto mask_index = [&](uint32_t lr, uint32_t g) { return uint64_t(lr) * stride + piece_at[piece_of[g]] + (g - cut(GS, pieces, piece_of[g])); };
-        uint64_t* mask = reinterpret_cast<uint64_t*>(out.image.data() + block_base[bi]);
-        uint32_t* value = reinterpret_cast<uint32_t*>(out.image.data() + block_base[bi] + uint64_t(rg.nrows) * stride * 8);
+        uint64_t* mask = gpu ? nullptr : reinterpret_cast<uint64_t*>(out.image.data() + block_base[bi]);
+        uint32_t* value = gpu ? nullptr : reinterpret_cast<uint32_t*>(out.image.data() + block_base[bi] + uint64_t(rg.nrows) * stride * 8);
         const uint64_t mask_word0 = block_base[bi] / 8, value_word0 = (block_base[bi] + uint64_t(rg.nrows) * stride * 8) / 4;
         // masks + compacted values in (row, group) order; value_at[r] = values of the block before local row r
         std::vector<uint64_t> value_at(size_t(rg.nrows) + 1, 0);
-        uint64_t at = 0;
         for (uint32_t lr = 0; lr < rg.nrows; ++lr) {
-            value_at[lr] = at;
+            value_at[lr + 1] = value_at[lr] + slice_nnz[size_t(rg.row0 + lr) * slices + k];
+            if (gpu) row_value_base[size_t(rg.row0 + lr) * slices + k] = value_word0 + value_at[lr];
+        }
+        uint64_t at = 0;
+        for (uint32_t lr = 0; !gpu && lr < rg.nrows; ++lr) {
             const uint64_t* e = elems + row_ptr[rg.row0 + lr];
             const uint32_t n = row_nnz[rg.row0 + lr];
             const uint64_t* p = std::lower_bound(e, e + n, c0 << 32);
@@ -198,21 +229,26 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
                 value[at++] = uint32_t(*p);
             }
         }
-        value_at[rg.nrows] = at;
         // wavefront runs.  Few rows: every row is cut into floor(16 / nrows) runs of equal group count.  Many rows: contiguous whole
         // rows per wavefront, balanced by steps-plus-non-zeros.
         auto set_seg = [&](uint32_t w, uint32_t r0, uint32_t r1, uint32_t g0, uint32_t g1) {
             WaveSeg& s = *reinterpret_cast<WaveSeg*>(out.units.data() + blk.unit_begin + size_t(w) * kBitmapRunSlots);
             s.row_begin = r0; s.row_end = r1; s.g_begin = g0; s.g_end = g1;
             uint64_t v = value_word0 + value_at[std::min(r0, rg.nrows)];
-            if (r1 == r0 + 1 && g0 > 0)        // partial row: values of the groups in front of g0
-                for (uint32_t g = 0; g < g0; ++g) v += uint64_t(__builtin_popcountll(mask[mask_index(r0, g)]));
+            const bool partial = r1 == r0 + 1 && g0 > 0;     // partial row: + the values of the groups in front of g0
             const uint64_t mw = mask_word0 + (r0 < rg.nrows ? mask_index(r0, r1 == r0 + 1 && g0 < GS ? g0 : 0) : 0);
-            s.value_lo = uint32_t(v); s.value_hi = uint32_t(v >> 32);
             s.mask_lo = uint32_t(mw); s.mask_hi = uint32_t(mw >> 32);
+            const uint32_t steps = r1 > r0 ? g1 - g0 : 0;
+            if (gpu) {    // the device looks both up in what it built (run_value + prefix, heads: patched in below)
+                dev_runs[bi * kBitmapWaves + w] = GpuTiler::BitmapRun{mw, partial ? dev_blocks[bi].prefix0 + mask_index(r0, g0) : 0, steps, partial ? 1u : 0u};
+                run_value[bi * kBitmapWaves + w] = v;
+                return;
+            }
+            if (partial)
+                for (uint32_t g = 0; g < g0; ++g) v += uint64_t(__builtin_popcountll(mask[mask_index(r0, g)]));
+            s.value_lo = uint32_t(v); s.value_hi = uint32_t(v >> 32);
             // the run's first 32 masks once more, right behind the descriptor (zero beyond the first row-run's end)
             uint64_t* head = reinterpret_cast<uint64_t*>(&s + 1);
-            const uint32_t steps = r1 > r0 ? g1 - g0 : 0;
             for (uint32_t j = 0; j < kBitmapMaskBatch; ++j)
                 head[j] = j < steps ? reinterpret_cast<const uint64_t*>(out.image.data())[mw + j] : 0;
         };
@@ -250,10 +286,11 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         const uint64_t mask_words = uint64_t(mi.tiles) * GR * kMfmaTileRows * 2;
         mi.offsets_word = mask_words;
         mi.values_word = mi.offsets_word + uint64_t(mi.tiles) * mi.chunks;
+        mi.words_bytes = (mi.values_word + nnz + 64) * 4;
         if ((mi.values_word + nnz + 64) >= (uint64_t(1) << 32)) {
             mi = MfmaImage();          // value offsets are 32-bit words: beyond that the SpMM keeps its other path
-        } else {
-            resize_zeroed(mi.words, (mi.values_word + nnz + 64) * 4);
+        } else if (!gpu) {
+            resize_zeroed(mi.words, mi.words_bytes);
             uint32_t* words = reinterpret_cast<uint32_t*>(mi.words.data());
             uint64_t* masks = reinterpret_cast<uint64_t*>(words);
             uint32_t* unit_base = words + mi.offsets_word;
@@ -298,6 +335,27 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
             });
         }
         timer.lap("bitmap: second image (matrix engine SpMM)");
+    }
+    if (gpu) {      // masks, values, run heads and the second image: kernels (gpu_tiles.hip); the descriptors above are completed from what they return
+        std::vector<uint32_t> range_of_row(num_rows), run_prefix;
+        for (uint32_t b = 0; b < NR; ++b) std::fill(range_of_row.begin() + ranges[b].row0, range_of_row.begin() + ranges[b].row0 + ranges[b].nrows, b);
+        std::vector<uint64_t> run_heads;
+        bool dup = false;
+        if (!gpu->bitmap_emit(slices, GR, range_of_row, dev_blocks, row_value_base, out.image_bytes, image_slack, dev_runs, run_prefix, run_heads,
+                              out.mfma.words_bytes ? &out.mfma : nullptr, dup)) {
+            error = gpu->error();
+            return false;
+        }
+        if (dup) { error = "bitmap: duplicate column in a row"; out.format = kFormatPairs; out.mfma = MfmaImage(); return false; }
+        for (size_t r = 0; r < dev_runs.size(); ++r) {
+            WaveSeg& s = *reinterpret_cast<WaveSeg*>(out.units.data() + r * kBitmapRunSlots);
+            const uint64_t v = run_value[r] + run_prefix[r];
+            s.value_lo = uint32_t(v); s.value_hi = uint32_t(v >> 32);
+            std::copy(run_heads.begin() + r * kBitmapMaskBatch, run_heads.begin() + (r + 1) * kBitmapMaskBatch, reinterpret_cast<uint64_t*>(&s + 1));
+        }
+        out.d_image = gpu->release_image();
+        out.mfma.d_words = gpu->release_mfma();
+        timer.lap("bitmap: device emit");
     }
 
     std::vector<std::vector<uint32_t>> mine;

@@ -300,5 +300,6 @@ int hs_read_spmspv_result(hs_context* ctx, void*, uint32_t) { HS_CPU_UNSUPPORTED
 int hs_spmm_device(hs_context* ctx, const void*, uint64_t, void*, uint64_t, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_spmm(hs_context* ctx, const void*, uint32_t, uint32_t, void*, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_debug_read_tiles(hs_context* ctx, void*, uint64_t, void*, void*) { HS_CPU_UNSUPPORTED(ctx); }
+int hs_debug_read_mfma_image(hs_context* ctx, void*, uint64_t, uint64_t*) { HS_CPU_UNSUPPORTED(ctx); }
 
 }  // extern "C"

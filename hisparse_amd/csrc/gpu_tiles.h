@@ -55,6 +55,26 @@ class GpuTiler {
     // The image (image_bytes + slack, zero-filled first).  format: the final StreamFormat; block_of_unit / blocks: pre-reorder indices.
     bool emit(StreamFormat format, uint64_t image_bytes, uint64_t slack_bytes, const std::vector<detail::UnitPlan>& plans,
               const std::vector<uint32_t>& block_of_unit, const std::vector<Block>& blocks, bool is_float);
+    // ---- BITMAP (bitmap_tiles.cpp plans; masks, values, run heads and the matrix-engine image are made here) -------------------------
+    // non-zeros per (row, column slice of groups): cnt[row * slices + k]; slice k = groups [k GR / slices, (k + 1) GR / slices)
+    bool bitmap_slice_counts(uint32_t slices, uint32_t groups_per_row, std::vector<uint32_t>& cnt);
+    struct BitmapBlock {            // one (row range, column slice); layout as bitmap_tiles.cpp lays it out
+        uint32_t row0, nrows, gs0, GS, pieces, stride;
+        uint64_t mask_word0;        // 8-byte word index of the block's first mask
+        uint64_t prefix0;           // first entry of the block in the per-mask prefix array (nrows x stride entries per block)
+    };
+    struct BitmapRun {              // a wavefront's run: where its masks start (8-byte word index) and in the prefix array; groups in its first row
+        uint64_t mask_word, prefix_at;
+        uint32_t steps, pad;
+    };
+    // Builds the image (image_bytes + slack, zero-filled first): every element sets its bit (a bit found set = the (row, column) occurs
+    // twice -> duplicates, nothing else is valid then), a per-row prefix count of the masks gives every element its place among the
+    // compacted values.  run_prefix[r] = values of the run's row in front of its first group; run_heads[r * 32 ..] = its first 32 masks.
+    // mfma (may be null; its layout fields filled by the caller): the second image, left on the device (release_mfma).
+    bool bitmap_emit(uint32_t slices, uint32_t groups_per_row, const std::vector<uint32_t>& range_of_row, const std::vector<BitmapBlock>& blocks,
+                     const std::vector<uint64_t>& row_value_base, uint64_t image_bytes, uint64_t slack_bytes, const std::vector<BitmapRun>& runs,
+                     std::vector<uint32_t>& run_prefix, std::vector<uint64_t>& run_heads, const MfmaImage* mfma, bool& duplicates);
+    uint8_t* release_mfma() { uint8_t* p = d_mfma_; d_mfma_ = nullptr; return p; }
     // hands the device image over (hipFree by the new owner)
     uint8_t* release_image() { uint8_t* p = d_image_; d_image_ = nullptr; return p; }
 
@@ -89,6 +109,7 @@ class GpuTiler {
     uint32_t* d_vals_ = nullptr;           // sorted value words
     uint64_t* d_bridges_ = nullptr;        // DELTA: inclusive scan of the bridge slots in front of every element
     uint8_t* d_image_ = nullptr;
+    uint8_t* d_mfma_ = nullptr;            // BITMAP, float modes: the matrix-engine image (stream_tiles.h: MfmaImage)
 };
 
 }  // namespace dev

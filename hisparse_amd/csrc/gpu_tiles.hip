@@ -442,6 +442,162 @@ __global__ __launch_bounds__(256) void emit_delta_kernel(const DevicePlan* __res
     }
 }
 
+// ---- BITMAP (bitmap_tiles.cpp; kernel: spmv_bitmap.hip) -------------------------------------------------------------------------
+// The planning (row ranges, slices, block layout, wavefront runs) stays on the host; these kernels do what touches every non-zero:
+// count per (row, slice), set the bit, prefix-count the masks per row, place the value, and the same for the matrix-engine image.
+struct ElementSource {          // either the uploaded CPSR image or the CSR arrays
+    const uint8_t* channels;
+    const StreamGroup* groups;
+    const uint64_t* advance;
+    const uint32_t* indptr;
+    const uint32_t* indices;
+    const float* values;
+    uint64_t nnz;
+    uint32_t num_groups, total_slots, num_rows, num_cols, logical_vb, fixed, csr;
+};
+
+// visit(row, absolute column, value word) for the elements thread t is responsible for; false + *err on a column outside the matrix
+template <typename Visit>
+__device__ __forceinline__ void visit_elements(const ElementSource& src, uint64_t t, uint32_t* err, Visit visit) {
+    if (src.csr) {
+        CsrCursor c;
+        if (!csr_segment(src.indptr, src.num_rows, src.nnz, t, c)) return;
+        for (; c.e < c.end; ++c.e) {
+            while (c.e >= src.indptr[c.row + 1]) ++c.row;
+            const uint32_t col = src.indices[c.e];
+            if (col >= src.num_cols) { report(err, kErrColumn, c.row / PACK_SIZE, c.row % PACK_SIZE); return; }
+            visit(c.row, col, value_word(src.values[c.e], src.fixed != 0));
+        }
+        return;
+    }
+    Segment s;
+    if (t >= src.total_slots || !find_segment(src.channels, src.groups, src.num_groups, src.total_slots, uint32_t(t), s)) return;
+    const StreamGroup& g = src.groups[s.group];
+    const uint32_t col_base = g.cp * src.logical_vb;
+    walk_segment(g, s, src.advance, [&](uint32_t row, uint32_t col, uint32_t val) { visit(row, col_base + col, val); });
+}
+
+// part k of n items cut into `parts`: [k n / parts, (k + 1) n / parts) -- the cut bitmap_tiles.cpp uses for column slices and row pieces
+__device__ __forceinline__ uint32_t cut_at(uint32_t n, uint32_t parts, uint32_t k) { return uint32_t(uint64_t(k) * n / parts); }
+__device__ __forceinline__ uint32_t part_of(uint32_t n, uint32_t parts, uint32_t x) {
+    uint32_t k = min(parts - 1, uint32_t((uint64_t(x) + 1) * parts / n));
+    while (cut_at(n, parts, k) > x) --k;
+    while (k + 1 < parts && cut_at(n, parts, k + 1) <= x) ++k;
+    return k;
+}
+__device__ __forceinline__ uint32_t padded_masks(uint32_t steps) { return (steps + 7u) / 8u * 8u + 16u; }
+// offset of group g (block-local) inside a row's masks: the pieces one after the other, each padded (bitmap_tiles.cpp: mask_index)
+__device__ __forceinline__ uint32_t mask_offset(const GpuTiler::BitmapBlock& b, uint32_t g) {
+    if (b.pieces <= 1) return g;
+    const uint32_t j = part_of(b.GS, b.pieces, g);
+    uint32_t at = 0;
+    for (uint32_t i = 0; i < j; ++i) at += padded_masks(cut_at(b.GS, b.pieces, i + 1) - cut_at(b.GS, b.pieces, i));
+    return at + (g - cut_at(b.GS, b.pieces, j));
+}
+
+__global__ __launch_bounds__(256) void bitmap_slice_counts_kernel(ElementSource src, uint32_t slices, uint32_t GR, uint32_t* __restrict__ cnt, uint32_t* err) {
+    visit_elements(src, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, err, [&](uint32_t row, uint32_t col, uint32_t) {
+        atomicAdd(cnt + size_t(row) * slices + part_of(GR, slices, col / kBitmapGroupCols), 1u);
+    });
+}
+
+// every element sets its bit; flags[0] = a bit was set already.  masks2: the matrix-engine image's masks (or null)
+__global__ __launch_bounds__(256) void bitmap_masks_kernel(ElementSource src, uint32_t slices, uint32_t GR, const uint32_t* __restrict__ range_of_row,
+                                                          const GpuTiler::BitmapBlock* __restrict__ blocks, unsigned long long* __restrict__ image64,
+                                                          unsigned long long* __restrict__ masks2, uint32_t* flags, uint32_t* err) {
+    visit_elements(src, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, err, [&](uint32_t row, uint32_t col, uint32_t) {
+        const uint32_t G = col / kBitmapGroupCols, k = slices > 1 ? part_of(GR, slices, G) : 0u;
+        const GpuTiler::BitmapBlock& b = blocks[size_t(range_of_row[row]) * slices + k];
+        const unsigned long long bit = 1ull << (col % kBitmapGroupCols);
+        const uint64_t mw = b.mask_word0 + uint64_t(row - b.row0) * b.stride + mask_offset(b, G - b.gs0);
+        if (atomicOr(image64 + mw, bit) & bit) flags[0] = 1u;
+        if (masks2) atomicOr(masks2 + (uint64_t(row / kMfmaTileRows) * GR + G) * kMfmaTileRows + row % kMfmaTileRows, bit);
+    });
+}
+
+// one wavefront per (row, slice): prefix[i] = set bits in the row's masks in front of mask i (exclusive), over the row's `stride` masks
+__global__ __launch_bounds__(256) void bitmap_prefix_kernel(uint32_t num_rows, uint32_t slices, const uint32_t* __restrict__ range_of_row,
+                                                           const GpuTiler::BitmapBlock* __restrict__ blocks, const unsigned long long* __restrict__ image64,
+                                                           uint32_t* __restrict__ prefix) {
+    const uint64_t w = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kWaveLanes;
+    const uint32_t lane = threadIdx.x % kWaveLanes;
+    if (w >= uint64_t(num_rows) * slices) return;
+    const uint32_t row = uint32_t(w / slices), k = uint32_t(w % slices);
+    const GpuTiler::BitmapBlock& b = blocks[size_t(range_of_row[row]) * slices + k];
+    const unsigned long long* m = image64 + b.mask_word0 + uint64_t(row - b.row0) * b.stride;
+    uint32_t* out = prefix + b.prefix0 + uint64_t(row - b.row0) * b.stride;
+    uint32_t carry = 0;
+    for (uint32_t i0 = 0; i0 < b.stride; i0 += kWaveLanes) {
+        const uint32_t i = i0 + lane;
+        const uint32_t c = i < b.stride ? uint32_t(__popcll(m[i])) : 0u;
+        uint32_t incl = c;
+        for (uint32_t d = 1; d < kWaveLanes; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, kWaveLanes);
+            if (lane >= d) incl += up;
+        }
+        if (i < b.stride) out[i] = carry + incl - c;
+        carry += __shfl(incl, kWaveLanes - 1, kWaveLanes);
+    }
+}
+
+// every element's value word goes to (values before its row) + (values of its row in front of its group) + (set bits below its own)
+__global__ __launch_bounds__(256) void bitmap_values_kernel(ElementSource src, uint32_t slices, uint32_t GR, const uint32_t* __restrict__ range_of_row,
+                                                           const GpuTiler::BitmapBlock* __restrict__ blocks, const uint64_t* __restrict__ row_value_base,
+                                                           const uint32_t* __restrict__ prefix, uint8_t* __restrict__ image, uint32_t* err) {
+    const unsigned long long* image64 = reinterpret_cast<const unsigned long long*>(image);
+    uint32_t* image32 = reinterpret_cast<uint32_t*>(image);
+    visit_elements(src, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, err, [&](uint32_t row, uint32_t col, uint32_t val) {
+        const uint32_t G = col / kBitmapGroupCols, k = slices > 1 ? part_of(GR, slices, G) : 0u;
+        const GpuTiler::BitmapBlock& b = blocks[size_t(range_of_row[row]) * slices + k];
+        const uint64_t in_block = uint64_t(row - b.row0) * b.stride + mask_offset(b, G - b.gs0);
+        const unsigned long long m = image64[b.mask_word0 + in_block];
+        const uint32_t below = uint32_t(__popcll(m & ((1ull << (col % kBitmapGroupCols)) - 1ull)));
+        image32[row_value_base[size_t(row) * slices + k] + prefix[b.prefix0 + in_block] + below] = val;
+    });
+}
+
+// a run's first 32 masks (zero beyond its steps) and the values of its row in front of its first group
+__global__ __launch_bounds__(256) void bitmap_run_heads_kernel(const GpuTiler::BitmapRun* __restrict__ runs, uint32_t num_runs, const unsigned long long* __restrict__ image64,
+                                                              const uint32_t* __restrict__ prefix, uint32_t* __restrict__ run_prefix, unsigned long long* __restrict__ heads) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, r = t / kBitmapMaskBatch, j = t % kBitmapMaskBatch;
+    if (r >= num_runs) return;
+    const GpuTiler::BitmapRun run = runs[r];
+    heads[t] = j < run.steps ? image64[run.mask_word + j] : 0ull;
+    if (j == 0) run_prefix[r] = run.steps ? prefix[run.prefix_at] : 0u;
+}
+
+// matrix-engine image: non-zeros of every (row tile, group)
+__global__ __launch_bounds__(256) void mfma_group_counts_kernel(const unsigned long long* __restrict__ masks2, uint64_t tile_groups, uint32_t* __restrict__ cnt) {
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t > tile_groups) return;
+    uint32_t c = 0;
+    if (t < tile_groups)
+        for (uint32_t i = 0; i < kMfmaTileRows; ++i) c += uint32_t(__popcll(masks2[t * kMfmaTileRows + i]));
+    cnt[t] = c;            // [tile_groups] = 0: the exclusive scan ends with the total
+}
+__global__ __launch_bounds__(256) void mfma_unit_base_kernel(const uint32_t* __restrict__ group_pos, uint32_t tiles, uint32_t GR, uint32_t chunk, uint32_t chunks,
+                                                            uint32_t* __restrict__ unit_base) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles * chunks) return;
+    const uint32_t tile = t / chunks, c = t % chunks;
+    unit_base[t] = uint64_t(c) * chunk < GR ? group_pos[size_t(tile) * GR + c * chunk] : group_pos[size_t(tile + 1) * GR];
+}
+// values in the order the kernel's lanes take them: tile, group, column of the group, row of the tile (bitmap_tiles.cpp)
+__global__ __launch_bounds__(256) void mfma_values_kernel(ElementSource src, uint32_t GR, const unsigned long long* __restrict__ masks2,
+                                                         const uint32_t* __restrict__ group_pos, uint32_t* __restrict__ values, uint32_t* err) {
+    visit_elements(src, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, err, [&](uint32_t row, uint32_t col, uint32_t val) {
+        const uint32_t G = col / kBitmapGroupCols, p = col % kBitmapGroupCols, i = row % kMfmaTileRows;
+        const uint64_t tg = uint64_t(row / kMfmaTileRows) * GR + G;
+        const unsigned long long* m = masks2 + tg * kMfmaTileRows;
+        uint32_t rank = 0;
+        for (uint32_t r = 0; r < kMfmaTileRows; ++r) {
+            rank += uint32_t(__popcll(m[r] & ((1ull << p) - 1ull)));
+            if (r < i) rank += uint32_t((m[r] >> p) & 1ull);
+        }
+        values[group_pos[tg] + rank] = val;
+    });
+}
+
 template <typename T>
 hipError_t upload(T** dst, const std::vector<T>& src, hipStream_t stream) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(src.size() * sizeof(T), 16));
@@ -472,7 +628,7 @@ GpuTiler::~GpuTiler() {
         if (p) (void)hipFree(p);
     for (void* p : {static_cast<void*>(d_channels_), d_groups_, static_cast<void*>(d_advance_), static_cast<void*>(d_base_), static_cast<void*>(d_scalar_),
                     static_cast<void*>(d_block_of_row_), static_cast<void*>(d_keys_), static_cast<void*>(d_vals_), static_cast<void*>(d_bridges_),
-                    static_cast<void*>(d_image_)})
+                    static_cast<void*>(d_image_), static_cast<void*>(d_mfma_)})
         if (p) (void)hipFree(p);
 }
 
@@ -826,6 +982,125 @@ bool GpuTiler::emit(StreamFormat format, uint64_t image_bytes, uint64_t slack_by
     if (d_plans) (void)hipFree(d_plans);
     for (void** p : {reinterpret_cast<void**>(&d_keys_), reinterpret_cast<void**>(&d_vals_), reinterpret_cast<void**>(&d_bridges_)})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
+    return ok;
+}
+
+// ---- BITMAP ------------------------------------------------------------------------------------------------------------------------
+bool GpuTiler::bitmap_slice_counts(uint32_t slices, uint32_t GR, std::vector<uint32_t>& cnt) {
+    cnt.assign(size_t(L_.num_rows) * slices, 0);
+    ElementSource src{d_channels_, static_cast<const StreamGroup*>(d_groups_), d_advance_, d_indptr_, d_indices_, d_values_, total_, num_groups_, total_slots_,
+                      L_.num_rows, csr_ ? csr_->num_cols : L_.num_cols, uint32_t(geom_.logical_vb), uint32_t(geom_.impl == IMPL_FIXED), csr_ ? 1u : 0u};
+    const uint64_t threads = csr_ ? (total_ + kCsrSegment - 1) / kCsrSegment : total_slots_;
+    uint32_t* d_cnt = nullptr;
+    bool ok = check(hipMalloc(reinterpret_cast<void**>(&d_cnt), std::max<size_t>(cnt.size() * 4, 16)), "hipMalloc") &&
+              check(hipMemsetAsync(d_cnt, 0, cnt.size() * 4, stream_), "hipMemset");
+    if (ok && threads) {
+        hipLaunchKernelGGL(bitmap_slice_counts_kernel, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, stream_, src, slices, GR, d_cnt, d_scalar_);
+        ok = check(hipGetLastError(), "bitmap_slice_counts_kernel");
+    }
+    ok = ok && (cnt.empty() || check(hipMemcpyAsync(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost, stream_), "read slice counts"));
+    if (ok) {
+        uint32_t words[3] = {0, 0, 0};
+        ok = check(hipMemcpyAsync(words, d_scalar_, 12, hipMemcpyDeviceToHost, stream_), "slice counts") && check(hipStreamSynchronize(stream_), "slice counts");
+        if (ok && words[0]) ok = fail("CSR row " + std::to_string(uint64_t(words[1]) * PACK_SIZE + words[2]) + ": column index outside the matrix");
+    }
+    if (d_cnt) (void)hipFree(d_cnt);
+    return ok;
+}
+
+bool GpuTiler::bitmap_emit(uint32_t slices, uint32_t GR, const std::vector<uint32_t>& range_of_row, const std::vector<BitmapBlock>& blocks,
+                           const std::vector<uint64_t>& row_value_base, uint64_t image_bytes, uint64_t slack_bytes, const std::vector<BitmapRun>& runs,
+                           std::vector<uint32_t>& run_prefix, std::vector<uint64_t>& run_heads, const MfmaImage* mfma, bool& duplicates) {
+    detail::PhaseTimer timer;
+    duplicates = false;
+    ElementSource src{d_channels_, static_cast<const StreamGroup*>(d_groups_), d_advance_, d_indptr_, d_indices_, d_values_, total_, num_groups_, total_slots_,
+                      L_.num_rows, csr_ ? csr_->num_cols : L_.num_cols, uint32_t(geom_.logical_vb), uint32_t(geom_.impl == IMPL_FIXED), csr_ ? 1u : 0u};
+    const uint64_t threads = csr_ ? (total_ + kCsrSegment - 1) / kCsrSegment : total_slots_;
+    const dim3 egrid(uint32_t((threads + 255) / 256)), block(256);
+    uint64_t prefix_words = 0;
+    for (const BitmapBlock& b : blocks) prefix_words = std::max<uint64_t>(prefix_words, b.prefix0 + uint64_t(b.nrows) * b.stride);
+    const size_t bytes = std::max<uint64_t>(image_bytes + slack_bytes, 256);
+    const uint32_t num_runs = uint32_t(runs.size());
+    run_prefix.assign(num_runs, 0);
+    run_heads.assign(size_t(num_runs) * kBitmapMaskBatch, 0);
+    uint32_t *d_range = nullptr, *d_prefix = nullptr, *d_flags = nullptr, *d_run_prefix = nullptr, *d_cnt = nullptr, *d_pos = nullptr;
+    BitmapBlock* d_blocks = nullptr;
+    BitmapRun* d_runs = nullptr;
+    uint64_t* d_row_base = nullptr;
+    unsigned long long* d_heads = nullptr;
+    void* d_temp = nullptr;
+    bool ok = check(hipMalloc(reinterpret_cast<void**>(&d_image_), bytes), "hipMalloc(image)") && check(hipMemsetAsync(d_image_, 0, bytes, stream_), "hipMemset(image)") &&
+              check(upload(&d_range, range_of_row, stream_), "upload row ranges") && check(upload(&d_blocks, blocks, stream_), "upload blocks") &&
+              check(upload(&d_row_base, row_value_base, stream_), "upload row bases") && check(upload(&d_runs, runs, stream_), "upload runs") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_prefix), std::max<size_t>(prefix_words * 4, 16)), "hipMalloc(prefix)") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_flags), 16), "hipMalloc") && check(hipMemsetAsync(d_flags, 0, 16, stream_), "hipMemset") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_run_prefix), std::max<size_t>(size_t(num_runs) * 4, 16)), "hipMalloc") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_heads), std::max<size_t>(run_heads.size() * 8, 16)), "hipMalloc");
+    unsigned long long* image64 = reinterpret_cast<unsigned long long*>(d_image_);
+    unsigned long long* masks2 = nullptr;
+    if (ok && mfma) {
+        ok = check(hipMalloc(reinterpret_cast<void**>(&d_mfma_), std::max<size_t>(mfma->words_bytes, 16)), "hipMalloc(second image)") &&
+             check(hipMemsetAsync(d_mfma_, 0, mfma->words_bytes, stream_), "hipMemset(second image)");
+        masks2 = reinterpret_cast<unsigned long long*>(d_mfma_);
+    }
+    if (ok && threads) {
+        hipLaunchKernelGGL(bitmap_masks_kernel, egrid, block, 0, stream_, src, slices, GR, d_range, d_blocks, image64, masks2, d_flags, d_scalar_);
+        ok = check(hipGetLastError(), "bitmap_masks_kernel");
+    }
+    uint32_t flags[4] = {0, 0, 0, 0}, errw[3] = {0, 0, 0};
+    ok = ok && check(hipMemcpyAsync(flags, d_flags, 16, hipMemcpyDeviceToHost, stream_), "read flags") &&
+         check(hipMemcpyAsync(errw, d_scalar_, 12, hipMemcpyDeviceToHost, stream_), "read flags") && check(hipStreamSynchronize(stream_), "bitmap masks");
+    if (ok && errw[0]) ok = fail("CSR row " + std::to_string(uint64_t(errw[1]) * PACK_SIZE + errw[2]) + ": column index outside the matrix");
+    timer.lap("gpu: bitmap masks");
+    duplicates = ok && flags[0] != 0;
+    if (ok && !duplicates) {
+        const uint64_t waves = uint64_t(L_.num_rows) * slices;
+        if (waves) {
+            hipLaunchKernelGGL(bitmap_prefix_kernel, dim3(uint32_t((waves * kWaveLanes + 255) / 256)), block, 0, stream_, L_.num_rows, slices, d_range, d_blocks, image64, d_prefix);
+            ok = check(hipGetLastError(), "bitmap_prefix_kernel");
+        }
+        if (ok && threads) {
+            hipLaunchKernelGGL(bitmap_values_kernel, egrid, block, 0, stream_, src, slices, GR, d_range, d_blocks, d_row_base, d_prefix, d_image_, d_scalar_);
+            ok = check(hipGetLastError(), "bitmap_values_kernel");
+        }
+        if (ok && num_runs) {
+            hipLaunchKernelGGL(bitmap_run_heads_kernel, dim3((num_runs * kBitmapMaskBatch + 255) / 256), block, 0, stream_, d_runs, num_runs, image64, d_prefix, d_run_prefix, d_heads);
+            ok = check(hipGetLastError(), "bitmap_run_heads_kernel") &&
+                 check(hipMemcpyAsync(run_prefix.data(), d_run_prefix, size_t(num_runs) * 4, hipMemcpyDeviceToHost, stream_), "read run offsets") &&
+                 check(hipMemcpyAsync(run_heads.data(), d_heads, run_heads.size() * 8, hipMemcpyDeviceToHost, stream_), "read run heads");
+        }
+        if (ok && mfma) {       // [masks: tiles x groups x 16 x 8 bytes][first value of every unit][values]
+            const uint64_t tile_groups = uint64_t(mfma->tiles) * mfma->groups;
+            uint32_t* words = reinterpret_cast<uint32_t*>(d_mfma_);
+            size_t temp_bytes = 0;
+            ok = check(hipMalloc(reinterpret_cast<void**>(&d_cnt), (tile_groups + 1) * 4), "hipMalloc") && check(hipMalloc(reinterpret_cast<void**>(&d_pos), (tile_groups + 1) * 4), "hipMalloc") &&
+                 check(hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_cnt, d_pos, tile_groups + 1, stream_), "scan (size)") &&
+                 check(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)), "hipMalloc(scan)");
+            if (ok) {
+                hipLaunchKernelGGL(mfma_group_counts_kernel, dim3(uint32_t((tile_groups + 1 + 255) / 256)), block, 0, stream_, masks2, tile_groups, d_cnt);
+                ok = check(hipGetLastError(), "mfma_group_counts_kernel") &&
+                     check(hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_cnt, d_pos, tile_groups + 1, stream_), "scan");
+            }
+            if (ok) {
+                hipLaunchKernelGGL(mfma_unit_base_kernel, dim3((mfma->tiles * mfma->chunks + 255) / 256), block, 0, stream_, d_pos, mfma->tiles, mfma->groups, mfma->chunk,
+                                   mfma->chunks, words + mfma->offsets_word);
+                ok = check(hipGetLastError(), "mfma_unit_base_kernel");
+            }
+            if (ok && threads) {
+                hipLaunchKernelGGL(mfma_values_kernel, egrid, block, 0, stream_, src, mfma->groups, masks2, d_pos, words + mfma->values_word, d_scalar_);
+                ok = check(hipGetLastError(), "mfma_values_kernel");
+            }
+        }
+    }
+    ok = ok && check(hipStreamSynchronize(stream_), "bitmap emit");
+    timer.lap("gpu: bitmap prefix + values + run heads + second image");
+    for (void* p : {static_cast<void*>(d_range), static_cast<void*>(d_prefix), static_cast<void*>(d_flags), static_cast<void*>(d_run_prefix), static_cast<void*>(d_cnt),
+                    static_cast<void*>(d_pos), static_cast<void*>(d_blocks), static_cast<void*>(d_runs), static_cast<void*>(d_row_base), static_cast<void*>(d_heads), d_temp})
+        if (p) (void)hipFree(p);
+    if (!ok || duplicates) {
+        if (d_image_) { (void)hipFree(d_image_); d_image_ = nullptr; }
+        if (d_mfma_) { (void)hipFree(d_mfma_); d_mfma_ = nullptr; }
+    }
     return ok;
 }
 

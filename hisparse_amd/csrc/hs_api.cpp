@@ -53,6 +53,7 @@ struct hs_context {
     uint32_t* d_x_interleaved = nullptr;   // fused SpMM over a BITMAP image: 4 columns of X as [column][vector] words (allocated on first use)
     // SpMM on the matrix engine (float BITMAP matrices): the second image + scratch (spmm_mfma.hip)
     uint32_t* d_mfma = nullptr;
+    uint64_t mfma_bytes = 0;
     hisparse::dev::MfmaImage mfma_info;    // geometry only (words empty)
     uint32_t* d_mfma_x = nullptr;
     float* d_mfma_partial = nullptr;
@@ -302,6 +303,12 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
 
     hisparse::dev::StreamTiles tiles;
     std::string why;
+    auto drop_device_images = [](hisparse::dev::StreamTiles& t) {      // what a builder left on the device for a load that fails after it
+        if (t.d_image) (void)hipFree(t.d_image);
+        if (t.mfma.d_words) (void)hipFree(t.mfma.d_words);
+        t.d_image = nullptr;
+        t.mfma.d_words = nullptr;
+    };
     // The per-non-zero passes of the re-tiling run on the GPU (gpu_tiles.h) unless HISPARSE_RETILE=host; BITMAP images and matrices
     // with duplicate entries are built by the host code, which also remains the byte-for-byte checker of the GPU path.
     const char* retile = std::getenv("HISPARSE_RETILE");
@@ -315,7 +322,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
             // both products), but the device sort has no defined order among equal positions.  Do what a reference driver does instead:
             // format on the host (sw/benchmark.cpp:110-195) and hand the CPSR buffers to the host builder, like hs_load_matrix does for
             // such a matrix.
-            if (tiles.d_image) (void)hipFree(tiles.d_image);
+            drop_device_images(tiles);
             tiles = hisparse::dev::StreamTiles();
             spmv::io::CSRMatrix<float> m;
             m.num_rows = csr->num_rows;
@@ -333,7 +340,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
                  hisparse::dev::build_stream_tiles(chan, count, g, num_rows, num_cols, num_row_partitions, num_col_partitions, uint32_t(ctx->compute_units), tiles, why);
         }
         if (!ok && !csr && on_gpu && why.rfind("gpu re-tile:", 0) == 0) {       // duplicates, or a HIP failure on the way: the host path decides
-            if (tiles.d_image) (void)hipFree(tiles.d_image);
+            drop_device_images(tiles);
             tiles = hisparse::dev::StreamTiles();
             on_gpu = false;
             ok = hisparse::dev::build_stream_tiles(channel, n_packets, g, num_rows, num_cols, num_row_partitions, num_col_partitions,
@@ -341,13 +348,13 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
         }
         if (!ok) return fail(ctx, HS_ERR_BAD_MATRIX, why);
     } catch (const std::bad_alloc&) {
-        if (tiles.d_image) (void)hipFree(tiles.d_image);
+        drop_device_images(tiles);
         return fail(ctx, HS_ERR_NO_MEMORY, "out of host memory while re-tiling the matrix");
     } catch (const std::exception& e) {      // whatever a builder task threw (WorkerPool rethrows it): never through the C ABI
-        if (tiles.d_image) (void)hipFree(tiles.d_image);
+        drop_device_images(tiles);
         return fail(ctx, HS_ERR_BAD_MATRIX, std::string("re-tiling the matrix failed: ") + e.what());
     } catch (...) {
-        if (tiles.d_image) (void)hipFree(tiles.d_image);
+        drop_device_images(tiles);
         return fail(ctx, HS_ERR_BAD_MATRIX, "re-tiling the matrix failed");
     }
     const bool debug = std::getenv("HISPARSE_PLAN_DEBUG") != nullptr;
@@ -355,7 +362,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     if (debug) std::fprintf(stderr, "load: image built after %.1f ms\n", since());
     const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers, tiles.format);
     if (lds_bytes > hisparse::dev::kMaxLdsBytes) {
-        if (tiles.d_image) (void)hipFree(tiles.d_image);
+        drop_device_images(tiles);
         return fail(ctx, HS_ERR_UNSUPPORTED, "row block does not fit the LDS");
     }
 
@@ -375,9 +382,11 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
     if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
-    if (!tiles.mfma.words.empty()) {      // float BITMAP matrix: the second image for the SpMM on the matrix engine + its scratch
+    if (tiles.mfma.present()) {      // float BITMAP matrix: the second image for the SpMM on the matrix engine + its scratch
         const hisparse::dev::MfmaImage& mi = tiles.mfma;
-        HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_mfma), mi.words.data(), mi.words.size(), 0));
+        if (mi.d_words) ctx->d_mfma = reinterpret_cast<uint32_t*>(mi.d_words);      // built on the device
+        else HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_mfma), mi.words.data(), mi.words.size(), 0));
+        ctx->mfma_bytes = mi.words_bytes;
         HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_x), hisparse::dev::spmm_mfma_x_words(mi.groups) * 4));
         HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_partial), hisparse::dev::spmm_mfma_partial_words(mi.tiles, mi.chunks) * 4));
         HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_flag), 64));
@@ -458,6 +467,19 @@ int hs_debug_read_tiles(hs_context* ctx, void* image, uint64_t image_capacity, v
     if (image && s.stream_bytes) HS_HIP(ctx, hipMemcpy(image, ctx->d_image, s.stream_bytes, hipMemcpyDeviceToHost));
     if (blocks && s.num_blocks) HS_HIP(ctx, hipMemcpy(blocks, ctx->d_blocks, size_t(s.num_blocks) * sizeof(Block), hipMemcpyDeviceToHost));
     if (units && s.num_units) HS_HIP(ctx, hipMemcpy(units, ctx->d_units, size_t(s.num_units) * sizeof(Unit), hipMemcpyDeviceToHost));
+    return HS_OK;
+}
+
+int hs_debug_read_mfma_image(hs_context* ctx, void* words, uint64_t capacity, uint64_t* bytes) {
+    if (!ctx) return HS_ERR_BAD_ARG;
+    if (!ctx->matrix_loaded) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix has not been called");
+    const uint64_t n = ctx->d_mfma ? ctx->mfma_bytes : 0;
+    if (bytes) *bytes = n;
+    if (!words || !n) return HS_OK;
+    if (capacity < n) return fail(ctx, HS_ERR_BAD_ARG, "buffer too small");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    HS_HIP(ctx, hipMemcpy(words, ctx->d_mfma, n, hipMemcpyDeviceToHost));
     return HS_OK;
 }
 

@@ -124,8 +124,12 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner, owner24 or bitmap"; return false; }
         }
         if (bitmap) {
-            if (!csr) gpu.reset();      // BITMAP images are small and built on the host (a CSR source has no host fallback: keep the tiler)
-            if (build_bitmap_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error, csr)) return true;
+            // the per-non-zero passes of the BITMAP builder are kernels too (HISPARSE_BITMAP_BUILD=host: the host loops of round 2,
+            // from the row counts the device returned -- the checker of tests/test_gpu_retile.py)
+            const char* where = env_switch("HISPARSE_BITMAP_BUILD");
+            const bool on_host = !gpu || (where && std::string(where) == "host");
+            if (on_host && !csr) gpu.reset();      // (a CSR source has no host fallback for the element formats: keep the tiler)
+            if (build_bitmap_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error, csr, on_host ? nullptr : gpu.get(), image_slack)) return true;
             if (error.rfind("bitmap:", 0) != 0) return false;     // a real decode error
             error.clear();                                       // not representable as a bitmap (duplicate entries): element streams
         }

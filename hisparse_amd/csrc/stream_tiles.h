@@ -229,6 +229,9 @@ struct MfmaImage {
     uint32_t chunk = 0;                  // groups per wavefront unit
     uint32_t chunks = 0;                 // ceil(groups / chunk), rounded up to a multiple of 4 (a workgroup of four units stays inside one row tile)
     uint64_t offsets_word = 0, values_word = 0;   // word offsets of the two tables behind the masks
+    uint64_t words_bytes = 0;            // size of the image (= words.size() when it was built on the host)
+    uint8_t* d_words = nullptr;          // built on the device (gpu_tiles.hip): the new owner frees it; `words` is empty then
+    bool present() const { return words_bytes != 0 && (d_words != nullptr || !words.empty()); }
 };
 constexpr uint32_t kMfmaTileRows = 16;
 

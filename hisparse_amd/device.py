@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
     "hs_load_matrix_csr", "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
-    "hs_bind_device_vector", "hs_bind_device_result", "hs_push_result", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_tiles_build", "hs_tiles_info",
+    "hs_bind_device_vector", "hs_bind_device_result", "hs_push_result", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_debug_read_mfma_image", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
 
@@ -84,6 +84,7 @@ def lib():
         l.hs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.hs_debug_read_tiles.argtypes = [vp, vp, u64, vp, vp]
+        l.hs_debug_read_mfma_image.argtypes = [vp, vp, u64, C.POINTER(u64)]
         l.hs_load_matrix_csr.argtypes = [vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(u32)]
         l.hs_spmm.argtypes = [vp, vp, u32, u32, vp, u32]
         l.hs_spmm_device.argtypes = [vp, vp, u64, vp, u64, u32]
@@ -207,6 +208,15 @@ class SpmvEngine:
         units = np.zeros(max(nunits, 1), dtype=UNIT_DTYPE)
         self._check(lib().hs_debug_read_tiles(self._h, image.ctypes.data, image.size, blocks.ctypes.data, units.ctypes.data))
         return dict(image=image[:nbytes], blocks=blocks[:nblocks], units=units[:nunits])
+
+    def read_mfma_image(self):
+        """The second image of a float BITMAP matrix (SpMM on the matrix engine), as bytes; empty when there is none."""
+        n = C.c_uint64()
+        self._check(lib().hs_debug_read_mfma_image(self._h, None, 0, C.byref(n)))
+        words = np.zeros(max(n.value, 1), dtype=np.uint8)
+        if n.value:
+            self._check(lib().hs_debug_read_mfma_image(self._h, words.ctypes.data, words.size, C.byref(n)))
+        return words[:n.value]
 
     # ---- zero-copy hooks ----------------------------------------------------------------------
     def set_stream(self, hip_stream):

@@ -196,6 +196,9 @@ int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* 
 /* What hs_load_matrix left on the device: the image (stats.stream_bytes), Block[] (num_blocks x 320 B) and Unit[] (num_units x 64 B).
  * Tests compare this with hs_tiles_build (the host builder) byte for byte.  Any pointer may be NULL. */
 int hs_debug_read_tiles(hs_context* ctx, void* image, uint64_t image_capacity, void* blocks, void* units);
+/* The second image of a float BITMAP matrix (the SpMM on the matrix engine reads it): *bytes = its size (0: none); copied out when
+ * `words` is not NULL.  Tests compare the image built by the device kernels with the host builder's (HISPARSE_BITMAP_BUILD=host). */
+int hs_debug_read_mfma_image(hs_context* ctx, void* words, uint64_t capacity, uint64_t* bytes);
 
 /* ---- introspection of the load-time re-tiling (host only, no GPU needed; used by the tests) -------- */
 typedef struct hs_tiles hs_tiles;

@@ -96,8 +96,67 @@ def test_default_format_choice(monkeypatch):
         _compare(cp, impl)
     csr = host.CSRMatrix.generate("bernoulli", 512, 8192, b=0.5, c=1.0, seed=22)
     cp = host.format_matrix(csr, 2, skip_empty_rows=True)
-    st = _compare(cp, 2, expect_gpu=False)
+    st = _compare(cp, 2)
     assert device.STREAM_FORMATS[st["stream_format"]] == "bitmap"
+
+
+def _mfma_image(cp, impl, where):
+    import os
+    old = os.environ.pop("HISPARSE_BITMAP_BUILD", None)
+    if where:
+        os.environ["HISPARSE_BITMAP_BUILD"] = where
+    try:
+        with device.SpmvEngine(impl, ob_bank=cp.ob_bank, vb_bank=cp.vb_bank) as eng:
+            eng.load_matrix(cp)
+            return eng.read_mfma_image(), eng.stats()
+    finally:
+        os.environ.pop("HISPARSE_BITMAP_BUILD", None)
+        if old is not None:
+            os.environ["HISPARSE_BITMAP_BUILD"] = old
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(512, 8192, 0.5), (3, 40000, 0.3), (16, 2048, 0.6), (9, 2500, 0.2), (130, 4096, 0.15), (2500, 2100, 0.25),
+                                   (20000, 2048, 0.13), (1, 70000, 0.9), (700, 3000, 0.02)])
+def test_bitmap_images_built_on_the_device(monkeypatch, impl, shape):
+    """BITMAP: masks, compacted values, run heads (and, float modes, the matrix-engine image) come from the kernels of gpu_tiles.hip and
+    must be byte for byte what the host builder writes: whole-row and partial-row runs, column slices (fewer rows than compute units),
+    rows too sparse for the format (forced), one row, float_stall's row padding."""
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "bitmap")
+    monkeypatch.delenv("HISPARSE_RETILE", raising=False)
+    rows, cols, density = shape
+    csr = host.CSRMatrix.generate("bernoulli", rows, cols, b=density, c=1.0, seed=rows + cols)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    st = _compare(cp, impl)
+    assert device.STREAM_FORMATS[st["stream_format"]] == "bitmap"
+    got, _ = _mfma_image(cp, impl, None)
+    want, st_host = _mfma_image(cp, impl, "host")
+    assert not st_host["retiled_on_gpu"]
+    assert (got.size > 0) == (impl != 0) and got.size == want.size
+    assert got.tobytes() == want.tobytes(), "matrix-engine image differs"
+
+
+@pytest.mark.parametrize("slices", [2, 3, 8])
+def test_bitmap_column_slices_on_the_device(monkeypatch, slices):
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "bitmap")
+    monkeypatch.setenv("HISPARSE_COL_SLICES", str(slices))
+    csr = host.CSRMatrix.generate("bernoulli", 40, 9000, b=0.4, c=1.0, seed=5)
+    for impl in (0, 1):
+        cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+        st = _compare(cp, impl)
+        assert st["col_slices"] == slices
+
+
+def test_bitmap_duplicate_column_falls_back(monkeypatch):
+    # a column twice in a row cannot be a bit in a mask: the device builder notices (the bit is set already) and the element formats take over
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "bitmap")
+    m = cases.random_csr(64, 4096, 0.3, 3, 0)
+    ip, ix, dv = m.indptr.astype(np.uint32), m.indices.astype(np.uint32).copy(), m.data.copy()
+    ix[ip[5] + 1] = ix[ip[5]]
+    csr = host.CSRMatrix.from_arrays(64, 4096, ip, ix, dv)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+    st = _compare(cp, 0, expect_gpu=False)
+    assert device.STREAM_FORMATS[st["stream_format"]] != "bitmap"
 
 
 def test_host_opt_out(monkeypatch):
