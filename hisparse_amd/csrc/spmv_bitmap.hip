@@ -54,7 +54,7 @@ struct Batch {
 template <bool kFloat, int kAblate>
 __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uint64_t* mp, const uint32_t*& vp, const uint32_t* x, uint32_t num_cols,
                                                                        uint32_t col0, uint32_t steps, uint32_t lane, bool have_first,
-                                                                       uint32_t first_masks, uint64_t* stamps = nullptr) {
+                                                                       const uint32_t (&first_masks)[4], uint64_t* stamps = nullptr) {
     using R = Rows<kFloat>;
     typename R::sum_t acc = 0;
     // values: this run's compacted values; offset = running scalar byte offset + 4 * (set bits below the lane)
@@ -66,24 +66,27 @@ __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uin
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) xk[k] = (lane + k * kBitmapGroupCols) * 4u;
     uint32_t voff = 0;                                   // bytes into the run's values (scalar)
-    // masks: one dword per lane = 32 masks per vector load, four vectors (128 steps) ahead -- a vector requested only one
-    // superbatch before it is needed would expose the memory latency once per superbatch.  Reads past the run's own masks find the
-    // zero masks the image pads every run with (bitmap_tiles.cpp), or 0 from the range check: no tail code anywhere.
+    // masks: the 8 masks of a batch = 16 dwords, fetched by lanes 0-15 of ONE vector load (the other lanes aim beyond the descriptor), four
+    // batches ahead.  (Until round 3 a vector held 32 masks -- four batches -- and v_readlane picked dword (bb % 4) * 16 + j with a
+    // computed lane select: two scalar adds per step in a loop that turned out to be bound by instruction issue.  Now the selects are the
+    // constants 0..15 and a batch costs one more load instruction.)  Reads past the run's own masks find the zero masks the image pads
+    // every run with (bitmap_tiles.cpp), or 0 from the range check (the advancing part of the offset is in the VECTOR offset: the scalar
+    // offset is not range-checked): no tail code anywhere.
     // (Fetching the masks through the scalar cache instead -- s_load_dwordx16 = one batch, no v_readlane -- was tried: the
     // scalar loads must be requested a batch ahead with hand-placed waits, and hipcc copies the destination registers of an asm
-    // load before the wait; not worth reserving registers for, the loop is bound by the latency chain in front of it, not by issue.)
+    // load before the wait; not worth reserving registers for.)
     const auto mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(mp), 0, steps * 8u, kRsrcFlags);
-    uint32_t moff = lane * 4u;
-    // the first 32 masks of a wavefront's run arrive with its descriptor (one round trip less in front of the first value load)
-    uint32_t mcur = have_first ? first_masks : __builtin_amdgcn_raw_buffer_load_b32(mr, moff, 0, 0);
-    uint32_t m1 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 256u, 0, 0);
-    uint32_t m2 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 512u, 0, 0);
-    uint32_t m3 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 768u, 0, 0);
-    // batch bb (8 steps, 16 loads); its masks are dwords (bb % 4) * 16 .. + 15 of the current mask vector.  The lane select of
-    // v_readlane is a scalar register, so ONE copy of this code serves every batch and the kernel stays a few KiB (every launch
-    // starts with a cold instruction cache).
+    uint32_t moff = lane < 2 * kBatch ? lane * 4u : kInvalidOffset;
+    constexpr uint32_t kBatchMaskBytes = kBatch * 8u;
+    // the first four batches' masks of a wavefront's run arrive with its descriptor (one round trip less in front of the first value load)
+    uint32_t mcur = have_first ? first_masks[0] : __builtin_amdgcn_raw_buffer_load_b32(mr, moff, 0, 0);
+    uint32_t m1 = have_first ? first_masks[1] : __builtin_amdgcn_raw_buffer_load_b32(mr, moff + kBatchMaskBytes, 0, 0);
+    uint32_t m2 = have_first ? first_masks[2] : __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 2 * kBatchMaskBytes, 0, 0);
+    uint32_t m3 = have_first ? first_masks[3] : __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 3 * kBatchMaskBytes, 0, 0);
+    // batch bb (8 steps, 16 loads); its masks are dwords 0 .. 15 of the current mask vector.  ONE copy of this code serves every batch
+    // and the kernel stays a few KiB (every launch starts with a cold instruction cache).
     auto issue = [&](Batch<kFloat>& b, uint32_t bb) {
-        const uint32_t sel = (bb & 3u) * (2 * kBatch);
+        constexpr uint32_t sel = 0;
         const uint32_t xc = min(col0 + bb * (kBatch * kBitmapGroupCols), num_cols);      // first column of the batch (scalar)
         const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(x + xc), 0, (num_cols - xc) * 4u, kRsrcFlags);
 #pragma unroll
@@ -96,13 +99,31 @@ __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uin
             const uint32_t off = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0)) * 4u;
             b.v[k] = (kAblate & 1) ? off : __builtin_amdgcn_raw_buffer_load_b32(vr, off, voff, (kAblate & 256) ? 2 : 0);
             b.xv[k] = (kAblate & 2) ? lo : __builtin_amdgcn_raw_buffer_load_b32(xr, xk[k], 0, 0);
-            voff += static_cast<uint32_t>(__builtin_popcountll(b.m[k])) * 4u;
+            // voff += 4 * popcount: one s_bcnt1 + one s_lshl2_add (hipcc keeps a running count, shifts it and adds the base: four)
+            const uint32_t set = static_cast<uint32_t>(__builtin_popcountll(b.m[k]));
+            asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(voff) : "s"(set), "s"(voff) : "scc");
         }
     };
     // Only the lanes whose bit is set take part; in float mode the eight products of a batch are added up in fp32 first and join
     // the double sum once per batch (one conversion + one double add instead of eight).
     auto consume = [&](const Batch<kFloat>& b) {
         typename R::prod_t part = 0;
+        if constexpr (kFloat && !(kAblate & 4) && (kBatch % 2) == 0) {
+            // two steps per multiply and per add (v_pk_mul_f32 / v_pk_add_f32 on register pairs): the loop is bound by vector-ALU issue.
+            // The products are the same fp32 products; their fp32 sum inside a batch now runs in two interleaved chains.
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 part2 = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < kBatch; k += 2) {
+                const f2 v = {__uint_as_float(b.v[k]), __uint_as_float(b.v[k + 1])}, xx = {__uint_as_float(b.xv[k]), __uint_as_float(b.xv[k + 1])};
+                f2 prod = v * xx;
+                if (!__builtin_amdgcn_inverse_ballot_w64(b.m[k])) prod.x = 0.f;
+                if (!__builtin_amdgcn_inverse_ballot_w64(b.m[k + 1])) prod.y = 0.f;
+                part2 += prod;
+            }
+            acc += R::widen(part2.x + part2.y);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
             if (kAblate & 4) { acc += static_cast<typename R::sum_t>(b.v[k] ^ b.xv[k]); continue; }
@@ -136,14 +157,13 @@ __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uin
     // ~7 us of the kernel's life spent in front of it (dispatch ramp, descriptor -> masks -> first values: three dependent round
     // trips) and behind it (wavefronts finish 6 us apart, the last one holds the barrier).
     Batch<kFloat> A, B;
-    auto rotate_masks = [&](uint32_t bb) {
-        if ((bb & 3u) == 0) {            // batch bb opens a new mask vector (wave-uniform branch)
-            mcur = m1; m1 = m2; m2 = m3;
-            moff += 256u;
-            m3 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 768u, 0, 0);
-        }
+    auto rotate_masks = [&](uint32_t) {    // the next batch's masks become current; the vector four batches ahead is requested
+        mcur = m1; m1 = m2; m2 = m3;
+        moff += kBatchMaskBytes;
+        m3 = __builtin_amdgcn_raw_buffer_load_b32(mr, moff + 3 * kBatchMaskBytes, 0, 0);
     };
     issue(A, 0);
+    rotate_masks(1);
     if (kAblate & 64) {   // timeline build: [2] = the first masks have arrived (issue() has used them)
         uint64_t t;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(voff));
@@ -208,7 +228,10 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
         // descriptors 0.8 us, then masks 2.0 us, then the first values).
         const uint32_t* hdr = reinterpret_cast<const uint32_t*>(units) + (static_cast<size_t>(bi) * kBitmapWaves + wave) * (kBitmapRunSlots * 16);
         const uint32_t seg_word = hdr[min(lane, 15u)];
-        const uint32_t first_masks = hdr[16 + lane];
+        // (the copy of the run's first 32 masks: batch b's 16 dwords in lanes 0-15 of vector b)
+        uint32_t first_masks[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) first_masks[b] = hdr[16 + 16 * b + (lane & 15u)];
         const uint32_t row_begin = __builtin_amdgcn_readlane(seg_word, 0), row_end = __builtin_amdgcn_readlane(seg_word, 1);
         const uint32_t g_begin = __builtin_amdgcn_readlane(seg_word, 2), steps = __builtin_amdgcn_readlane(seg_word, 3) - g_begin;
         const uint64_t* mp = reinterpret_cast<const uint64_t*>(image) +
