@@ -289,8 +289,15 @@ hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t st
     const int ablate = bitmap_env_int("HISPARSE_ABLATE", 0);       // read per launch: a process may switch profiling builds between runs
     // timeline build: HISPARSE_ABLATE=64 HISPARSE_TIMELINE_OUT=file -> every launch is synchronised and its per-wavefront
     // timestamps (workgroups x 16 x 8 u64, 100 MHz) overwrite the file (tools/bitmap_timeline.py reads it)
-    static uint64_t* timeline = nullptr;
-    if ((ablate & 64) && !timeline) (void)hipMalloc(reinterpret_cast<void**>(&timeline), size_t(4096) * kBitmapWaves * 8 * sizeof(uint64_t));
+    // (one buffer per device: a process may drive several, benchmark.cpp --gpus N)
+    static uint64_t* timelines[16] = {};
+    uint64_t* timeline = nullptr;
+    if (ablate & 64) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+        if (!timelines[dev]) (void)hipMalloc(reinterpret_cast<void**>(&timelines[dev]), size_t(4096) * kBitmapWaves * 8 * sizeof(uint64_t));
+        timeline = timelines[dev];
+    }
     bool launched = false;
 #define X(F, A)                                                                                                                                  \
     if (!launched && is_float == F && ablate == A) {                                                                                             \

@@ -1005,7 +1005,12 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
             (void)hipMemcpy(host.data(), buffer(), host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
             if (FILE* f = std::fopen(path, "wb")) { std::fwrite(host.data(), sizeof(uint64_t), host.size(), f); std::fclose(f); }
         }
-        static uint64_t*& buffer() { static uint64_t* b = nullptr; return b; }
+        static uint64_t*& buffer() {      // one per device (the device symbol is per device too)
+            static uint64_t* b[16] = {};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            return b[dev >= 0 && dev < 16 ? dev : 0];
+        }
     } timeline_dump{stream, a.num_workgroups, ablate == 512 && a.num_workgroups <= 4096};
     if (timeline_dump.on) {
         const size_t bytes = size_t(4096) * kTimelineBlocks * 2 * kTimelineStamps * sizeof(uint64_t);
