@@ -5,6 +5,7 @@
 // (tiles_common.h: the same walk as the other formats), the rows are put back into column order, and every (row, 64-column
 // group) becomes a 64-bit occupancy mask plus its compacted values.
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -151,17 +152,38 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     // fetches masks eight at a time and issues up to two batches past the end of a run, which then find "no column set".
     auto pieces_of = [](uint32_t nrows) { return nrows * 2 <= kBitmapWaves ? kBitmapWaves / nrows : 1u; };
     auto padded = [](uint32_t steps) { return (steps + 7u) / 8u * 8u + 16u; };
-    auto cut = [](uint32_t GS, uint32_t pieces, uint32_t j) { return uint32_t(uint64_t(j) * GS / pieces); };
-    auto row_stride = [&](uint32_t GS, uint32_t pieces) {
+    // The 16 wavefronts of a workgroup do NOT run at the same speed: a SIMD's instruction arbiter serves its oldest wavefront first, so
+    // wavefronts 0-3 (the first on each SIMD) finished an equal share after 6.9 us, 4-7 after 8.7, 8-11 after 10.5 and 12-15 after
+    // 12.1 us (transformer-50, tools/bitmap_timeline.py, round 3) -- and the first twelve then sat at the barrier.  So the shares are
+    // weighted by the wavefront's place on its SIMD (kBitmapSkew; HISPARSE_BITMAP_SKEW=a/b/c/d overrides, 100/100/100/100 = equal
+    // shares: 14.3 us against 13.0 on transformer-50, same box, profiles/r03_bitmap_weighted_shares.txt), and the pieces of a row go to
+    // wavefronts piece * nrows + row, so that every row gets old and young wavefronts alike.
+    uint32_t skew[4] = {kBitmapSkew[0], kBitmapSkew[1], kBitmapSkew[2], kBitmapSkew[3]};
+    if (const char* e = env_switch("HISPARSE_BITMAP_SKEW")) {
+        unsigned a, b, c, d;
+        if (std::sscanf(e, "%u%*[,/ ]%u%*[,/ ]%u%*[,/ ]%u", &a, &b, &c, &d) == 4 && a && b && c && d && a < 10000 && b < 10000 && c < 10000 && d < 10000) { skew[0] = a; skew[1] = b; skew[2] = c; skew[3] = d; }
+    }
+    auto wave_weight = [&](uint32_t w) { return skew[std::min<uint32_t>(w / 4, 3)]; };
+    // first group of piece j of a row (of any row of the block: the weight of a piece is that of the wavefront row 0's piece goes to)
+    auto cut = [&](uint32_t GS, uint32_t pieces, uint32_t nrows, uint32_t j) {
+        uint64_t before = 0, all = 0;
+        for (uint32_t i = 0; i < pieces; ++i) {
+            if (i < j) before += wave_weight(i * nrows);
+            all += wave_weight(i * nrows);
+        }
+        // (cutting at whole batches of 8 steps instead was measured too: no difference)
+        return j >= pieces ? GS : uint32_t(before * GS / all);
+    };
+    auto row_stride = [&](uint32_t GS, uint32_t pieces, uint32_t nrows) {
         uint32_t n = 0;
-        for (uint32_t j = 0; j < pieces; ++j) n += padded(cut(GS, pieces, j + 1) - cut(GS, pieces, j));
+        for (uint32_t j = 0; j < pieces; ++j) n += padded(cut(GS, pieces, nrows, j + 1) - cut(GS, pieces, nrows, j));
         return n;
     };
     for (uint32_t bi = 0; bi < NB; ++bi) {
         const RowRange& rg = ranges[bi / slices];
         const uint32_t k = bi % slices;
         const uint32_t gs0 = uint32_t(uint64_t(k) * GR / slices), gs1 = uint32_t(uint64_t(k + 1) * GR / slices);
-        const uint64_t masks = uint64_t(rg.nrows) * row_stride(gs1 - gs0, pieces_of(rg.nrows));
+        const uint64_t masks = uint64_t(rg.nrows) * row_stride(gs1 - gs0, pieces_of(rg.nrows), rg.nrows);
         // [masks: 8 bytes each][values: 4 bytes each, padded to 8]
         block_base[bi + 1] = block_base[bi] + masks * 8 + ((block_nnz[bi] + 1) & ~uint64_t(1)) * 4;
         block_weight[bi] = uint64_t(rg.nrows) * (gs1 - gs0) / kBitmapWaves + 1;          // wavefront steps
@@ -180,8 +202,9 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         for (uint32_t bi = 0; bi < NB; ++bi) {
             const RowRange& rg = ranges[bi / slices];
             const uint32_t k = bi % slices, gs0 = uint32_t(uint64_t(k) * GR / slices), gs1 = uint32_t(uint64_t(k + 1) * GR / slices);
-            const uint32_t pieces = pieces_of(rg.nrows), stride = row_stride(gs1 - gs0, pieces);
-            dev_blocks[bi] = GpuTiler::BitmapBlock{rg.row0, rg.nrows, gs0, gs1 - gs0, pieces, stride, block_base[bi] / 8, prefix0};
+            const uint32_t pieces = pieces_of(rg.nrows), stride = row_stride(gs1 - gs0, pieces, rg.nrows);
+            dev_blocks[bi] = GpuTiler::BitmapBlock{rg.row0, rg.nrows, gs0, gs1 - gs0, pieces, stride, block_base[bi] / 8, prefix0, {}};
+            for (uint32_t j = 0; j <= pieces; ++j) dev_blocks[bi].piece_cut[j] = cut(gs1 - gs0, pieces, rg.nrows, j);
             prefix0 += uint64_t(rg.nrows) * stride;
         }
     }
@@ -201,13 +224,14 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         blk.unit_end = blk.unit_begin + kBitmapWaves * kBitmapRunSlots;
         blk.first_col0 = uint32_t(c0);
         blk.first_ncols = GS;
-        const uint32_t pieces = pieces_of(rg.nrows), stride = row_stride(GS, pieces);
-        std::vector<uint32_t> piece_of(GS), piece_at(pieces + 1, 0);          // group -> piece; piece -> offset inside the row's masks
+        const uint32_t pieces = pieces_of(rg.nrows), stride = row_stride(GS, pieces, rg.nrows);
+        std::vector<uint32_t> piece_of(GS), piece_at(pieces + 1, 0), piece_cut(pieces + 1);   // group -> piece; piece -> offset inside the row's masks
+        for (uint32_t j = 0; j <= pieces; ++j) piece_cut[j] = cut(GS, pieces, rg.nrows, j);
         for (uint32_t j = 0; j < pieces; ++j) {
-            for (uint32_t g = cut(GS, pieces, j); g < cut(GS, pieces, j + 1); ++g) piece_of[g] = j;
-            piece_at[j + 1] = piece_at[j] + padded(cut(GS, pieces, j + 1) - cut(GS, pieces, j));
+            for (uint32_t g = piece_cut[j]; g < piece_cut[j + 1]; ++g) piece_of[g] = j;
+            piece_at[j + 1] = piece_at[j] + padded(piece_cut[j + 1] - piece_cut[j]);
         }
-        auto mask_index = [&](uint32_t lr, uint32_t g) { return uint64_t(lr) * stride + piece_at[piece_of[g]] + (g - cut(GS, pieces, piece_of[g])); };
+        auto mask_index = [&](uint32_t lr, uint32_t g) { return uint64_t(lr) * stride + piece_at[piece_of[g]] + (g - piece_cut[piece_of[g]]); };
         uint64_t* mask = gpu ? nullptr : reinterpret_cast<uint64_t*>(out.image.data() + block_base[bi]);
         uint32_t* value = gpu ? nullptr : reinterpret_cast<uint32_t*>(out.image.data() + block_base[bi] + uint64_t(rg.nrows) * stride * 8);
         const uint64_t mask_word0 = block_base[bi] / 8, value_word0 = (block_base[bi] + uint64_t(rg.nrows) * stride * 8) / 4;
@@ -253,17 +277,19 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
                 head[j] = j < steps ? reinterpret_cast<const uint64_t*>(out.image.data())[mw + j] : 0;
         };
         if (pieces > 1) {
-            uint32_t w = 0;
             for (uint32_t lr = 0; lr < rg.nrows; ++lr)
-                for (uint32_t j = 0; j < pieces; ++j, ++w) set_seg(w, lr, lr + 1, cut(GS, pieces, j), cut(GS, pieces, j + 1));
-            for (; w < kBitmapWaves; ++w) set_seg(w, rg.nrows, rg.nrows, 0, 0);      // idle wavefronts
+                for (uint32_t j = 0; j < pieces; ++j) set_seg(j * rg.nrows + lr, lr, lr + 1, piece_cut[j], piece_cut[j + 1]);
+            for (uint32_t w = rg.nrows * pieces; w < kBitmapWaves; ++w) set_seg(w, rg.nrows, rg.nrows, 0, 0);      // idle wavefronts
         } else {
-            // cost of a row = its steps + its non-zeros / 16 (issue slots vs. bytes); cut the prefix sum into 16 equal parts
+            // cost of a row = its steps + its non-zeros / 16 (issue slots vs. bytes); cut the prefix sum into 16 parts by the wavefronts' weights
             std::vector<uint64_t> cost(size_t(rg.nrows) + 1, 0);
             for (uint32_t lr = 0; lr < rg.nrows; ++lr) cost[lr + 1] = cost[lr] + GS + (value_at[lr + 1] - value_at[lr]) / 16;
+            uint64_t weight_all = 0, weight_so_far = 0;
+            for (uint32_t w = 0; w < kBitmapWaves; ++w) weight_all += wave_weight(w);
             uint32_t r0 = 0;
             for (uint32_t w = 0; w < kBitmapWaves; ++w) {
-                const uint64_t goal = cost[rg.nrows] * (w + 1) / kBitmapWaves;
+                weight_so_far += wave_weight(w);
+                const uint64_t goal = cost[rg.nrows] * weight_so_far / weight_all;
                 uint32_t r1 = uint32_t(std::lower_bound(cost.begin() + r0, cost.end(), goal) - cost.begin());
                 r1 = w + 1 == kBitmapWaves ? rg.nrows : std::min(std::max(r1, r0), rg.nrows);
                 // a whole-row run must not be mistaken for a partial one: one row = [0, GS) of that row, which is the same thing

@@ -62,10 +62,11 @@ class GpuTiler {
         uint32_t row0, nrows, gs0, GS, pieces, stride;
         uint64_t mask_word0;        // 8-byte word index of the block's first mask
         uint64_t prefix0;           // first entry of the block in the per-mask prefix array (nrows x stride entries per block)
+        uint32_t piece_cut[kBitmapWaves + 1];   // first group of every piece of a row (pieces + 1 entries; the shares are weighted, bitmap_tiles.cpp)
     };
     struct BitmapRun {              // a wavefront's run: where its masks start (8-byte word index) and in the prefix array; groups in its first row
         uint64_t mask_word, prefix_at;
-        uint32_t steps, pad;
+        uint32_t steps, pad;        // pad = 1: the run starts inside a row (its value offset needs the row's prefix)
     };
     // Builds the image (image_bytes + slack, zero-filled first): every element sets its bit (a bit found set = the (row, column) occurs
     // twice -> duplicates, nothing else is valid then), a per-row prefix count of the masks gives every element its place among the

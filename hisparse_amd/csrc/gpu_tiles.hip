@@ -489,10 +489,12 @@ __device__ __forceinline__ uint32_t padded_masks(uint32_t steps) { return (steps
 // offset of group g (block-local) inside a row's masks: the pieces one after the other, each padded (bitmap_tiles.cpp: mask_index)
 __device__ __forceinline__ uint32_t mask_offset(const GpuTiler::BitmapBlock& b, uint32_t g) {
     if (b.pieces <= 1) return g;
-    const uint32_t j = part_of(b.GS, b.pieces, g);
-    uint32_t at = 0;
-    for (uint32_t i = 0; i < j; ++i) at += padded_masks(cut_at(b.GS, b.pieces, i + 1) - cut_at(b.GS, b.pieces, i));
-    return at + (g - cut_at(b.GS, b.pieces, j));
+    uint32_t j = 0, at = 0;
+    while (j + 1 < b.pieces && b.piece_cut[j + 1] <= g) {
+        at += padded_masks(b.piece_cut[j + 1] - b.piece_cut[j]);
+        ++j;
+    }
+    return at + (g - b.piece_cut[j]);
 }
 
 __global__ __launch_bounds__(256) void bitmap_slice_counts_kernel(ElementSource src, uint32_t slices, uint32_t GR, uint32_t* __restrict__ cnt, uint32_t* err) {
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(256) void bitmap_run_heads_kernel(const GpuTiler::B
     if (r >= num_runs) return;
     const GpuTiler::BitmapRun run = runs[r];
     heads[t] = j < run.steps ? image64[run.mask_word + j] : 0ull;
-    if (j == 0) run_prefix[r] = run.steps ? prefix[run.prefix_at] : 0u;
+    if (j == 0) run_prefix[r] = run.pad ? prefix[run.prefix_at] : 0u;      // pad = the run starts inside a row (also when it is empty)
 }
 
 // matrix-engine image: non-zeros of every (row tile, group)

@@ -157,6 +157,7 @@ constexpr uint32_t kBitmapMinCols = 2048;                     // shorter rows: a
 constexpr uint32_t kBitmapGroupCols = 64;                     // one wavefront step
 constexpr uint32_t kBitmapWaves = 16;                         // all 16 wavefronts of the workgroup stream (no loader wavefronts)
 constexpr uint32_t kBitmapMaxBlockRows = 8191;                // 64 KiB of 8-byte row accumulators
+constexpr uint32_t kBitmapSkew[4] = {165, 125, 75, 35};       // share of a wavefront by its place on its SIMD (wavefronts 0-3, 4-7, 8-11, 12-15): bitmap_tiles.cpp
 constexpr uint32_t kBitmapMaskBatch = 32;                     // masks fetched per vector load (one dword per lane)
 constexpr uint32_t kBitmapRunSlots = 5;                       // Unit-sized (64-byte) slots per wavefront run: the WaveSeg + a copy of its first 32 masks
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout

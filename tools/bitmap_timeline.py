@@ -28,3 +28,11 @@ for i, n in enumerate(names):
     print(f"  {n:22s} median {np.median(v):6.2f}   min {v.min():6.2f}   max {v.max():6.2f}")
 d = (t[:, :, 1:] - t[:, :, :-1]) / 100.0
 print("  per-wavefront phase durations (median): " + ", ".join(f"{names[i]}->{names[i+1]} {np.median(d[:, :, i]):.2f}" for i in range(7)))
+# systematic order inside a workgroup?  median over the workgroups, per wavefront index
+for i in (0, 2, 3, 4):
+    v = np.median((t[:, :, i] - t0) / 100.0, axis=0)
+    print(f"  {names[i]:22s} by wavefront index: " + " ".join(f"{x:5.2f}" for x in v))
+# and per XCD (workgroup id % 8)
+fin = (t[:, :, 4] - t0) / 100.0
+print("  run finished, median per XCD (blockIdx % 8): " + " ".join(f"{np.median(fin[k::8]):5.2f}" for k in range(8)))
+print("  run finished, max per workgroup: median %.2f, min %.2f, max %.2f" % (np.median(fin.max(axis=1)), fin.max(axis=1).min(), fin.max(axis=1).max()))

@@ -29,9 +29,9 @@ CU_STREAM_B_PER_US = {"pairs": 25.8e3, "delta": 25.8e3, "owner": 26.5e3}   # one
 # 1.38 us, ogbn-products (<= 5) 1.5 us; the atomic formats' units have no flush and a ring of 3-4: 0.45 us
 UNIT_FLOOR_US = {"owner": lambda steps: 1.2 + 0.06 * steps, "pairs": lambda steps: 0.45, "delta": lambda steps: 0.45}
 LDS_EXPOSED_PS = {"pairs": {0: 6.0, 1: 9.0, 2: 9.0}, "delta": {0: 9.0, 1: 14.0, 2: 14.0}, "owner": {0: 0.0, 1: 0.0, 2: 0.0}}   # per element and CU, beside a saturated stream
-BITMAP_FRONT_US, BITMAP_TAIL_US = 4.0, 2.8   # spmv_bitmap_kernel (tools/bitmap_timeline.py): ramp + descriptor -> masks -> first values; finish spread + row sums + barrier + store
-BITMAP_BATCH_US = 0.44      # one batch of 8 steps (16 loads) per wavefront: the run is bound by load round trips, not bytes (transformer-50 and -80: 7.0 us both)
-BITMAP_LAUNCH_US = 1.5
+BITMAP_FRONT_US, BITMAP_TAIL_US = 4.0, 2.0   # spmv_bitmap_kernel (tools/bitmap_timeline.py): ramp + descriptor -> masks -> first values; row sums + barrier + store
+BITMAP_BATCH_US = 0.62      # per batch of 8 steps and wavefront, averaged over the workgroup's 16 (their shares are weighted by issue priority so that they finish together: the MEAN counts; transformer-50 and -80 take the same time)
+BITMAP_LAUNCH_US = 2.5        # event pair around one launch (the measured column); back-to-back steps overlap most of it
 
 
 def model(name, cp=None, impl=None):
@@ -49,7 +49,7 @@ def model(name, cp=None, impl=None):
         per_wg = max(t["wg_first"][g + 1] - t["wg_first"][g] for g in range(groups))
         segs = units.view(np.uint8).reshape(len(blocks), 16, 5 * 64)[:, :, :16].copy().view(np.uint32).reshape(len(blocks), 16, 4)
         steps = (segs[:, :, 1] - segs[:, :, 0]).astype(np.int64) * (segs[:, :, 3] - segs[:, :, 2]).astype(np.int64)     # rows x groups of a wavefront's run
-        batches = -(-steps.max(axis=1) // 8)                                  # the slowest wavefront of every block
+        batches = steps.sum(axis=1) / 16.0 / 8.0                              # mean over the 16 wavefronts of every block
         run_us = float(batches.max()) * BITMAP_BATCH_US * per_wg
         stream_us = len(t["image"]) / 6.6e6                                   # what the bytes alone would need
         parts = {"launch": BITMAP_LAUNCH_US, "front (ramp, descriptor -> masks -> values)": BITMAP_FRONT_US,
