@@ -181,10 +181,11 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             // unforced: 1, 2, 4, 8 -- and everything in between for OWNER, where the x volume decides: ogbn-products runs 241 us in 5
             // slices (102 ranges of 24 K rows, 2 blocks per workgroup) against 280 in 2 (127 ranges) and 275 in 4; ogbl-ppa gains
             // 1 us of kernel in 5 and loses it in the combine pass, the R-MAT stand-in is 3 us slower
-            // (a matrix of at most eight sub-tiles: every count up to that -- a slice per sub-tile is the plan without x refills and
-            // unit barriers, and a power of two above the sub-tile count would leave whole slices, i.e. workgroups, empty)
+            // (a matrix of at most sixteen sub-tiles: every count -- a slice per sub-tile (or two) is the plan without x refills and
+            // unit barriers (gplus, 14 sub-tiles: 23.7 us in 7 slices, 26.1 in 8), and a power of two above the sub-tile count would leave
+            // whole slices, i.e. workgroups, empty)
             const uint32_t live_tiles = (num_cols + kSubTileCols - 1) / kSubTileCols;
-            if (force_slices ? uint32_t(std::atoi(force_slices)) != cs : (!owner && (cs & (cs - 1)) != 0 && live_tiles > kMaxColSlices)) continue;
+            if (force_slices ? uint32_t(std::atoi(force_slices)) != cs : (!owner && (cs & (cs - 1)) != 0 && live_tiles > 2 * kMaxColSlices)) continue;
             if (cs > 1 && uint64_t(CP) * S < cs) continue;                                    // fewer sub-tiles than slices
             if (!force_slices && !owner && live_tiles <= kMaxColSlices && cs > live_tiles) continue;
             for (const Shape& shape : (cs > 1 || owner) ? std::vector<Shape>(sliced, sliced + 2) : std::vector<Shape>(whole, whole + 1)) {
@@ -209,6 +210,14 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                 // layers: 16 K non-zeros per row) and slow when a (row, sub-tile) holds only a chunk or two -- one rank's slab of mouse_gene
                 // split 8 ways (5632 rows x 45 K columns, 22-row blocks, 117 non-zeros per row and sub-tile) ran 2.5 us per unit, 22.7 us
                 // for 29 MB; in 3 column slices (blocks of 66 rows, ordinary path) 11.5 us + the combine pass.  Price it.
+                // an unsliced block walks ALL sub-tiles: every unit boundary costs it a head record per wavefront, a barrier and a refill
+                // issue, ~0.3 us that the stream does not hide (gplus, 14 units per block: 28.6 us in one slice, 24.0 in seven, same
+                // format; mouse_gene's 2-way slabs 21.9 -> 20.8) -- sliced plans have a fraction of the units and pay the combine pass instead
+                if (!owner && cs == 1) latency_us += units_per_wg * 0.3;
+                // few sub-tiles dealt to slices that do not divide them: the blocks of the slices with one sub-tile more set the time (gplus,
+                // 14 sub-tiles: 23.9 / 27.4 / 24.7 / 26.1 us in 5 / 6 / 7 / 8 slices)
+                if (!owner && cs > 1 && live_tiles <= 2 * kMaxColSlices)
+                    latency_us += 0.75 * (double(out.nnz) * 8.0 / G / 25e3) * (double((live_tiles + cs - 1) / cs) * cs / live_tiles - 1.0);
                 const double rows_per_block = double(num_rows) / ranges, per_row_and_tile = double(out.nnz) / std::max(1.0, double(num_rows) * sub_tiles);
                 if (!owner && rows_per_block <= kDenseBlockRows && per_row_and_tile < 4.0 * kWaveLanes) latency_us += units_per_wg * 1.75;
                 // PAIRS deals a unit's elements, sorted by (row, column), to the lanes in consecutive runs: the 64 lanes of a step sit

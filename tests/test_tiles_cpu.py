@@ -51,9 +51,10 @@ def test_emulated_kernel_matches_oracle(impl, skip, rows, cols, density, vb, ob,
         assert cases.float_close(got, want)
 
 
-def test_structure_invariants(stream_format):
+def test_structure_invariants(stream_format, monkeypatch):
     if stream_format == "bitmap":
         pytest.skip("element-stream structure; BITMAP has its own test below")
+    monkeypatch.setenv("HISPARSE_COL_SLICES", "1")      # the unsliced structure (the planner would slice this 7-sub-tile matrix; sliced plans: test_column_slices*)
     csr = host.CSRMatrix.generate("powerlaw", 30000, 50000, a=600000, b=0.4, c=1.0, seed=3)
     cp = host.format_matrix(csr, 0, skip_empty_rows=True)
     t = build(cp, 0, 64)
@@ -150,6 +151,7 @@ def test_format_choice(monkeypatch):
             assert t["image"].size + (23 << 20) < 8 * cp.nnz
     # inside a DELTA matrix, blocks of heavy rows are flagged for per-lane register sums, the sparse bulk is not
     monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "delta")
+    monkeypatch.setenv("HISPARSE_COL_SLICES", "1")       # short row ranges (the planner would slice this matrix: long ranges, no dense block)
     csr = host.CSRMatrix.generate("powerlaw", 30000, 60000, a=2400000, b=0.8, c=1.0, seed=3)
     cp = host.format_matrix(csr, 0, skip_empty_rows=True)
     t = build(cp, 0, 64)
