@@ -437,7 +437,11 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             // slots + one head per wavefront with work, in records of two slots (a run's last record is half empty every other time)
             delta_bytes += (records + std::min<uint64_t>(records, kConsumerWaves) * 3 / 2) * (kRecordBytes / 2);
         }
-        const uint64_t min_saved = is_float ? kDeltaMinSavedBytesFloat : kDeltaMinSavedBytes;
+        // (the fixed cost c is mostly the head record per unit and wavefront: 14 units per block -> 3.5 us, but a sliced plan with one or two
+        // units per block pays ~1.2 us -- gplus in 7 slices: 24 MB saved, 24.7 us in PAIRS, 21.9 in DELTA.  Fixed point only: measured there.)
+        const double units_per_block = double(plans.size()) / std::max<uint32_t>(1, NB);
+        const uint64_t min_saved = is_float ? kDeltaMinSavedBytesFloat
+                                            : std::min<uint64_t>(kDeltaMinSavedBytes, uint64_t((1.0 + 0.18 * units_per_block) * 6.5e6));
         if (double(slots) > 1.02 * double(out.nnz) || pairs_bytes < delta_bytes + min_saved) {
             delta = false;
             out.format = kFormatPairs;
