@@ -21,7 +21,7 @@ try:
 except OSError:
     git_head, dirty = None, None
 tag = sys.argv[1]
-configs = sys.argv[2:] or ["ogbl_ppa", "transformer_50", "ogbn_products", "mouse_gene", "ogbl_ppa_rmat", "pokec", "hollywood", "gplus"]
+configs = sys.argv[2:] or ["ogbl_ppa", "transformer_50", "ogbn_products", "mouse_gene", "ogbl_ppa_rmat", "pokec", "hollywood", "gplus", "transformer_80", "transformer_95"]
 path = os.path.join(root, "profiles", "hbm_traffic.json")
 try:
     merged = json.load(open(path))

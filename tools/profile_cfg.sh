@@ -10,7 +10,7 @@ export RUNS=${2:-20}
 OUT=gpurun_out/prof_$CFG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python tools/probe_cfg.py $CFG"
+CMD="python tools/probe_cfg.py $CFG ${PROFILE_IMPL:-}"      # PROFILE_IMPL=fixed|float_pob|float_stall: another numeric mode than the config's own
 export PROBE_JSON="$OUT/probe.json"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- $CMD > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1

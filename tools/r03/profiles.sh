@@ -5,4 +5,9 @@ for cfg in ogbl_ppa transformer_50 ogbn_products mouse_gene ogbl_ppa_rmat pokec 
   timeout 600 bash tools/profile_cfg.sh $cfg 30 > gpurun_out/prof_$cfg.log 2>&1
   tail -12 gpurun_out/prof_$cfg/summary.txt | head -3
 done
+# the reference sweep's matrices under 50 % of the roofline that are not in the list above, in the sweep's numeric mode (fixed point)
+for cfg in transformer_80 transformer_95; do
+  PROFILE_IMPL=fixed timeout 600 bash tools/profile_cfg.sh $cfg 30 > gpurun_out/prof_$cfg.log 2>&1
+  tail -12 gpurun_out/prof_$cfg/summary.txt | head -3
+done
 timeout 600 python -m pytest tests/test_benchmark_cli.py -q -m gpu 2>&1 | tail -3
