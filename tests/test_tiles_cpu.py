@@ -467,3 +467,32 @@ def test_blocks_go_to_xcds_by_column_slice(impl, ob, monkeypatch):
     for j in range(cp.num_row_partitions):      # the reference's launch loop: one row partition at a time
         y = tile_emulator.run(t, impl, xw, cp.num_rows, row_part_filter=j, y_init=y)
     assert np.array_equal(y, want) if impl == 0 else cases.float_close(y, want)
+
+
+def test_plans_of_small_and_narrow_matrices(monkeypatch):
+    """Round-3 planner rules (stream_tiles.cpp, "tile plan"), each on the shape it was measured on, emulated against the oracle:
+    a few-row PAIRS block puts many lanes of a step into one row (LDS atomics collide) -> one slice per sub-tile; a matrix of at most 16
+    sub-tiles may take any slice count, preferably one that divides the sub-tiles; unsliced plans pay per unit boundary; DELTA's fixed
+    cost shrinks with the units per block."""
+    for k in ("HISPARSE_STREAM_FORMAT", "HISPARSE_COL_SLICES", "HISPARSE_MAX_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    # one rank's slab of mouse_gene split 4 ways: 6 live sub-tiles -> 6 slices (15-27 us in one slice, 13.3-13.9 in six)
+    csr = host.CSRMatrix.generate("powerlaw", 11264, 45101, a=7.2e6, b=0.30, c=0.1, seed=44)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+    t = build(cp, 0, 256)
+    assert t["col_slices"] == 6 and len(t["blocks"]) == 252 and len(t["units"]) == 252
+    xw = host.pack_vector(0, cases.random_x(cp.num_cols, 3, 0))
+    assert np.array_equal(tile_emulator.run(t, 0, xw, cp.num_rows), oracle_y(cp, 0, xw))
+    # 14 sub-tiles (gplus's shape, a tenth of its non-zeros): 7 slices = two sub-tiles each, not 6 or 8
+    csr = host.CSRMatrix.generate("powerlaw", 107614, 107614, a=1.4e6, b=0.35, c=1.0, seed=7)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+    t = build(cp, 0, 256)
+    assert t["col_slices"] == 7
+    per_block = t["blocks"]["unit_end"] - t["blocks"]["unit_begin"]
+    assert per_block.max() <= 2
+    xw = host.pack_vector(0, cases.random_x(cp.num_cols, 4, 0))
+    assert np.array_equal(tile_emulator.run(t, 0, xw, cp.num_rows), oracle_y(cp, 0, xw))
+    # a wide matrix keeps the power-of-two slice counts
+    csr = host.CSRMatrix.generate("powerlaw", 60000, 300000, a=3.0e6, b=0.3, c=1.0, seed=9)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+    assert build(cp, 0, 256)["col_slices"] in (1, 2, 4, 8)
