@@ -75,24 +75,13 @@ __device__ __forceinline__ void dma_fill_x(uint32_t* dst, const uint32_t* __rest
                                          (__attribute__((address_space(3))) uint32_t*)(dst + c), 16, 0, 0);
     }
 }
-// "at most kFills refills are still in flight" (vmcnt retires in order; the loader wavefronts issue nothing else -- except, with
-// kTouch, the kTouchPerFill prefetch loads that follow every refill)
-constexpr uint32_t kTouchPerFill = kSubTileCols * 4u / 128u / (kLoaderWaves * kWaveLanes);   // one dword per 128-byte line: 2 per lane
-template <int kFills, bool kTouch = false>
+// "at most kFills refills are still in flight" (vmcnt retires in order; the loader wavefronts issue nothing else).
+// (Round 2 tried touching the NEXT sub-tile into this XCD's L2 ahead of its refill -- one dword per 128-byte line, parked in an accumulator
+// register -- because the row blocks of an XCD walk the sub-tiles in the same order at about the same time and every refill misses L2 at the
+// same moment: it shifted the loaders' wait into the barrier and left the total; removed.)
+template <int kFills>
 __device__ __forceinline__ void dma_wait() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFills * (kDmaPerFill + (kTouch ? kTouchPerFill : 0u)) + (kTouch ? kTouchPerFill : 0u)) : "memory");
-}
-// Pull a sub-tile of x into this XCD's L2 ahead of its refill: the row blocks of an XCD walk the sub-tiles in the same order at
-// about the same time, so without this every refill of every workgroup is an L2 MISS at the same moment (x, 9.8 MB on
-// ogbn-products, does not stay in a 4 MiB L2), and with a ring of two buffers the refill latency is on the critical path.
-__device__ __forceinline__ void touch_x(const uint32_t* __restrict__ x, uint32_t col0, uint32_t ncols, uint32_t w, uint32_t lane) {
-#pragma unroll
-    for (uint32_t j = 0; j < kTouchPerFill; ++j) {
-        const uint32_t c = ((w * kTouchPerFill + j) * kWaveLanes + lane) * 32u;            // one word per 128 bytes
-        // the data goes to an accumulator register (loader wavefronts use none, and hipcc allocates none in this kernel): a VGPR
-        // output would be handed to something else by the compiler while the load is still in flight
-        asm volatile("global_load_dword a0, %0, off" ::"v"(x + col0 + min(c, ncols - 1)) : "memory", "a0");
-    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFills * kDmaPerFill) : "memory");
 }
 
 // The element stream is loaded with hand-placed instructions: hipcc's s_waitcnt placement degrades to vmcnt(0)
@@ -183,7 +172,6 @@ struct Ring<2> {    // 24-bit position words: a 448-byte step = 64 value dwords,
 template <>
 struct Ring<3> {    // OWNER24: a record = FOUR steps per lane: the 4 value words as one dwordx4, the 4 x 24-bit position words as one dwordx3
     // ring slot K (K < 4 records in flight): values in a[4K : 4K+3], position words in a[16+4K : 16+4K+2] (even-aligned tuples)
-    static constexpr uint32_t kLaneBytes = 16;
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane16, uint32_t lane12) {
         static_assert(K < 4 && 16 + 4 * K + 2 < 2 * kMaxDepth, "a0..a15: values of four records, a16..a30: their position words");
