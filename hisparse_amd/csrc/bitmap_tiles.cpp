@@ -307,7 +307,18 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         mi.groups = GR;
         // wavefront units of `chunk` groups: enough of them for every SIMD of the chip (1024) to get two or three; four units (one
         // workgroup) never straddle two row tiles
-        mi.chunk = std::max<uint32_t>(4, std::min<uint32_t>(32, uint32_t(uint64_t(mi.tiles) * GR / 2560 + 1)));
+        // groups per wavefront unit: the workgroups (4 units each) run in ceil(workgroups / CUs) rounds of `chunk` groups; a unit costs ~1.5
+        // groups' worth of set-up and its share of the finish pass; and a CU with only one or two workgroups is short of wavefronts to hide
+        // its loads behind.  transformer-50 (32 tiles x 521 groups, k = 16, same box): chunk 4 / 5 / 6 / 7 / 8 / 9 / 10 / 11 / 13 / 17 ->
+        // 28.6 / 27.0 / 25.0 / 27.3 / 29.0 / 25.6 / 26.7 / 27.2 / 31.0 / 29.9 us (profiles/r03_spmm_mfma_chunk.txt)
+        double best_cost = 1e30;
+        for (uint32_t chunk = 4; chunk <= 32; ++chunk) {
+            const uint64_t wgs = uint64_t(mi.tiles) * (((GR + chunk - 1) / chunk + 3) / 4);
+            const double rounds = double((wgs + G - 1) / G);
+            const double cost = rounds * (chunk + 1.5) * (1.0 + 0.7 / rounds);
+            if (cost < best_cost) { best_cost = cost; mi.chunk = chunk; }
+        }
+        if (const char* force = env_switch("HISPARSE_MFMA_CHUNK")) mi.chunk = std::max(1, std::atoi(force));      // experiments
         mi.chunks = ((GR + mi.chunk - 1) / mi.chunk + 3) / 4 * 4;
         const uint64_t mask_words = uint64_t(mi.tiles) * GR * kMfmaTileRows * 2;
         mi.offsets_word = mask_words;
