@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 IMPL_NAMES = ["fixed", "float_pob", "float_stall"]
-SPIN_UP_STEPS = 300    # untimed: the clocks have dropped during the CPU legs (oracle, formatting)
+SPIN_UP_STEPS = 1000    # untimed: the clocks have dropped during the CPU legs (oracle, formatting)
 
 
 def log(rank, *a):
