@@ -395,6 +395,17 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         timer.lap("bitmap: device emit");
     }
 
+    // x in LDS (spmv_bitmap.hip, kXLds): when a block's stretch of x and its accumulators fit the LDS together and the stretch is used by
+    // more than one row (HISPARSE_BITMAP_X_LDS=0|1 forces)
+    {
+        uint32_t widest = 0;
+        for (uint32_t k = 0; k < slices; ++k) widest = std::max(widest, uint32_t(uint64_t(k + 1) * GR / slices) - uint32_t(uint64_t(k) * GR / slices));
+        const uint64_t acc_bytes = ((uint64_t(out.max_block_rows) + 1) * kAccumulatorBytes + 15u) & ~uint64_t(15);
+        const bool fits = widest <= kBitmapMaxXLdsGroups && acc_bytes + uint64_t(widest) * kBitmapGroupCols * 4 <= kMaxLdsBytes;
+        bool want = fits && uint64_t(num_rows) >= 2ull * NR;
+        if (const char* force = env_switch("HISPARSE_BITMAP_X_LDS")) want = fits && std::atoi(force) != 0;
+        out.bitmap_x_groups = want ? widest : 0u;
+    }
     std::vector<std::vector<uint32_t>> mine;
     assign_workgroups(out, block_weight, G, RP, mine);
     chain_blocks(out, mine, RP);

@@ -45,6 +45,7 @@ struct hs_context {
     uint32_t* d_part_heads = nullptr;
     uint32_t num_workgroups = 0;
     uint32_t lds_bytes = 0;
+    uint32_t bitmap_x_groups = 0;
     uint32_t col_slices = 1;
     uint32_t ring_buffers = 4;
     uint32_t format = 0;           // StreamFormat of d_image
@@ -165,6 +166,7 @@ hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     a.num_cols = c->num_cols;
     a.num_workgroups = c->num_workgroups;
     a.lds_bytes = c->lds_bytes;
+    a.bitmap_x_groups = c->bitmap_x_groups;
     return a;
 }
 
@@ -360,7 +362,9 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     const bool debug = std::getenv("HISPARSE_PLAN_DEBUG") != nullptr;
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     if (debug) std::fprintf(stderr, "load: image built after %.1f ms\n", since());
-    const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers, tiles.format);
+    // (BITMAP: + the block's stretch of x behind the accumulators when the builder asks for it, spmv_bitmap.hip kXLds)
+    const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers, tiles.format) +
+                               tiles.bitmap_x_groups * hisparse::dev::kBitmapGroupCols * 4u;
     if (lds_bytes > hisparse::dev::kMaxLdsBytes) {
         drop_device_images(tiles);
         return fail(ctx, HS_ERR_UNSUPPORTED, "row block does not fit the LDS");
@@ -401,6 +405,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     ctx->col_parts = num_col_partitions;
     ctx->num_workgroups = tiles.num_workgroups;
     ctx->lds_bytes = lds_bytes;
+    ctx->bitmap_x_groups = tiles.bitmap_x_groups;
     ctx->col_slices = tiles.col_slices;
     ctx->max_block_rows = tiles.max_block_rows;
     ctx->ring_buffers = tiles.ring_buffers;

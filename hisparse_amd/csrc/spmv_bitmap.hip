@@ -39,6 +39,7 @@ constexpr int kBmThreads = kWaveLanes * kBitmapWaves;   // 1024
 constexpr int kBatch = 8;                               // steps per batch: 16 loads issued back to back
 constexpr uint32_t kInvalidOffset = 0x80000000u;        // beyond any num_records below: the load returns 0 (no memory access)
 constexpr uint32_t kRsrcFlags = 0x00020000u;            // raw 32-bit buffer, gfx9 family
+constexpr int kXCopyPasses = (kBitmapMaxXLdsGroups * (kBitmapGroupCols / 4) + kBmThreads - 1) / kBmThreads;   // 16-byte loads per thread that cover the largest x stretch kept in LDS
 
 typedef const __attribute__((address_space(4))) WaveSeg* WaveSegTable;
 
@@ -51,14 +52,29 @@ struct Batch {
 // One wavefront, one row: groups [0, steps) of the run that starts at mask `mp`, value `vp`, column `col0`.  Returns the lane's sum.
 // kAblate (profiling builds, HISPARSE_ABLATE): bit 0 = no value loads, bit 1 = no x loads, bit 2 = no arithmetic (wrong results);
 // 64 = timeline, 256 = nt cache policy on the value loads (correct results)
-template <bool kFloat, int kAblate>
+typedef const __attribute__((address_space(3))) uint32_t* LdsWords;
+
+// A wave-uniform pointer, said so: a buffer descriptor built from a pointer hipcc cannot PROVE uniform is loaded under a "waterfall" loop
+// (v_readfirstlane + compare + branch around every load) -- seen in one instantiation of this kernel, where nothing is divergent.
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32)));     // (the builtin returns int: no sign extension)
+    const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)));
+    return reinterpret_cast<T*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// kXLds: the block's stretch of x has been copied into LDS (xs_run = the word of the run's first column); the x operand of a step is then
+// a conflict-free ds_read_b32 (lane l reads word 64 g + l) instead of a second buffer load per step -- the loads are what the run waits for
+// (ablation builds, round 3: no x loads 11.6 us against 14.1), and a block's x stretch is read once per row AND piece otherwise.
+template <bool kFloat, int kAblate, bool kXLds>
 __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uint64_t* mp, const uint32_t*& vp, const uint32_t* x, uint32_t num_cols,
                                                                        uint32_t col0, uint32_t steps, uint32_t lane, bool have_first,
-                                                                       const uint32_t (&first_masks)[4], uint64_t* stamps = nullptr) {
+                                                                       const uint32_t (&first_masks)[4], LdsWords xs_run, uint64_t* stamps = nullptr) {
     using R = Rows<kFloat>;
     typename R::sum_t acc = 0;
     // values: this run's compacted values; offset = running scalar byte offset + 4 * (set bits below the lane)
-    const auto vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(vp), 0, 0x7fffffffu, kRsrcFlags);
+    const auto vr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<uint32_t*>(vp)), 0, 0x7fffffffu, kRsrcFlags);
     // x: a fresh descriptor per batch whose base is the batch's first column and whose length is what is left of the vector
     // (scalar arithmetic only): the per-step lane offsets are then eight loop-invariant registers, and the last group of a row,
     // which may hang over the end of x, is still range-checked
@@ -75,7 +91,7 @@ __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uin
     // (Fetching the masks through the scalar cache instead -- s_load_dwordx16 = one batch, no v_readlane -- was tried: the
     // scalar loads must be requested a batch ahead with hand-placed waits, and hipcc copies the destination registers of an asm
     // load before the wait; not worth reserving registers for.)
-    const auto mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(mp), 0, steps * 8u, kRsrcFlags);
+    const auto mr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<uint64_t*>(mp)), 0, steps * 8u, kRsrcFlags);
     uint32_t moff = lane < 2 * kBatch ? lane * 4u : kInvalidOffset;
     constexpr uint32_t kBatchMaskBytes = kBatch * 8u;
     // the first four batches' masks of a wavefront's run arrive with its descriptor (one round trip less in front of the first value load)
@@ -98,10 +114,11 @@ __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uin
             // looks at it.  Cheaper than steering those lanes to an out-of-range offset (two more vector instructions per step).
             const uint32_t off = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0)) * 4u;
             b.v[k] = (kAblate & 1) ? off : __builtin_amdgcn_raw_buffer_load_b32(vr, off, voff, (kAblate & 256) ? 2 : 0);
-            b.xv[k] = (kAblate & 2) ? lo : __builtin_amdgcn_raw_buffer_load_b32(xr, xk[k], 0, 0);
+            if constexpr (kXLds) b.xv[k] = (kAblate & 2) ? lo : xs_run[(bb * kBatch + k) * kBitmapGroupCols + lane];
+            else b.xv[k] = (kAblate & 2) ? lo : __builtin_amdgcn_raw_buffer_load_b32(xr, xk[k], 0, 0);
             // voff += 4 * popcount: one s_bcnt1 + one s_lshl2_add (hipcc keeps a running count, shifts it and adds the base: four)
             const uint32_t set = static_cast<uint32_t>(__builtin_popcountll(b.m[k]));
-            asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(voff) : "s"(set), "s"(voff) : "scc");
+            asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(voff) : "s"(set), "s"(__builtin_amdgcn_readfirstlane(voff)) : "scc");      // (readfirstlane: a no-op that tells hipcc the value is uniform)
         }
     };
     // Only the lanes whose bit is set take part; in float mode the eight products of a batch are added up in fp32 first and join
@@ -187,11 +204,12 @@ __device__ __forceinline__ typename Rows<kFloat>::sum_t bitmap_row_run(const uin
     return acc;
 }
 
-template <bool kFloat, int kAblate>
+template <bool kFloat, int kAblate, bool kXLds = false>
 __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                 const Unit* __restrict__ units, const uint32_t* __restrict__ x, uint32_t num_cols,
                                                                 uint32_t* __restrict__ out, int32_t row_part_filter,
-                                                                const uint32_t* __restrict__ part_heads, uint64_t* __restrict__ timeline) {
+                                                                const uint32_t* __restrict__ part_heads, uint64_t* __restrict__ timeline,
+                                                                uint32_t x_lds_offset) {
     using R = Rows<kFloat>;
     using acc_t = typename R::acc_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -217,6 +235,7 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
         if (bi == kNoBlock) return;
     }
     bool first_block = true;
+    uint32_t staged_col0 = 0, staged_groups = 0;      // kXLds: the stretch of x the LDS holds
     for (uint32_t next = 0;; bi = next) {
         const BlockTable blk = (BlockTable)(blocks + bi);
         next = (row_part_filter >= 0 && (blk->flags & kBlockLastOfPartition)) ? 0u : blk->next;
@@ -242,11 +261,33 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
         stamp(1, col0 + steps + nrows);
 
         if (!first_block) __syncthreads();   // the previous block's result store has read the accumulators
-        first_block = false;
         for (uint32_t i = tid; i <= nrows; i += kBmThreads) ys[i] = 0;           // PE banks start at zero (pe.h:131-135)
+        LdsWords xs_run = nullptr;
+        if constexpr (kXLds) {
+            // the block's stretch of x -> LDS, 16 bytes per thread and pass, every load in flight before the first LDS write (the copy
+            // rides on the run headers' round trip); words past the end of x are range-checked to 0.  A workgroup's next block of the
+            // same column slice finds it there.
+            const uint32_t c0 = blk->first_col0, groups = blk->first_ncols;
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            auto* xs = (__attribute__((address_space(3))) u4*)(lds + x_lds_offset);
+            if (first_block || c0 != staged_col0 || groups != staged_groups) {
+                const auto xr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<uint32_t*>(x + min(c0, num_cols))), 0, (num_cols - min(c0, num_cols)) * 4u, kRsrcFlags);
+                const uint32_t quads = groups * (kBitmapGroupCols / 4);
+                u4 r[kXCopyPasses];
+#pragma unroll
+                for (int j = 0; j < kXCopyPasses; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (tid + j * kBmThreads) * 16u, 0, 0);
+#pragma unroll
+                for (int j = 0; j < kXCopyPasses; ++j)
+                    if (tid + j * kBmThreads < quads) xs[tid + j * kBmThreads] = r[j];
+                staged_col0 = c0;
+                staged_groups = groups;
+            }
+            xs_run = (LdsWords)xs + g_begin * kBitmapGroupCols;
+        }
+        first_block = false;
         __syncthreads();
         for (uint32_t r = row_begin; r < row_end; ++r) {
-            const typename R::sum_t mine = (kAblate & 8) ? typename R::sum_t(steps) : bitmap_row_run<kFloat, kAblate>(mp, vp, x, num_cols, col0, steps, lane, r == row_begin, first_masks, stamps);
+            const typename R::sum_t mine = (kAblate & 8) ? typename R::sum_t(steps) : bitmap_row_run<kFloat, kAblate, kXLds>(mp, vp, x, num_cols, col0, steps, lane, r == row_begin, first_masks, xs_run, stamps);
             if (kAblate & 64) { uint64_t t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(mine)); if (lane == 0) stamps[4] = t; }
             mp += (steps + 7u) / 8u * 8u + 16u;     // the run's masks + its zero padding (bitmap_tiles.cpp)
             if (kAblate & 16) { asm volatile("" ::"v"(mine)); continue; }
@@ -265,6 +306,7 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
     }
 }
 
+#define HS_FOR_EACH_BITMAP_XLDS_VARIANT(X) X(false, 0) X(true, 0) X(true, 1) X(true, 2) X(true, 3) X(true, 7) X(true, 15) X(true, 64)
 #define HS_FOR_EACH_BITMAP_VARIANT(X) X(false, 0) X(true, 0) X(true, 1) X(true, 2) X(true, 3) X(true, 4) X(true, 7) X(true, 15) X(true, 31) X(true, 23) X(true, 64) X(true, 256)
 
 int bitmap_env_int(const char* name, int dflt) {
@@ -279,6 +321,10 @@ hipError_t configure_bitmap_kernels(uint32_t lds_bytes) {
 #define X(F, A) \
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_bitmap_kernel<F, A>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != hipSuccess) return e;
     HS_FOR_EACH_BITMAP_VARIANT(X)
+#undef X
+#define X(F, A) \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_bitmap_kernel<F, A, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes))) != hipSuccess) return e;
+    HS_FOR_EACH_BITMAP_XLDS_VARIANT(X)
 #undef X
     return hipSuccess;
 }
@@ -299,10 +345,20 @@ hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t st
         timeline = timelines[dev];
     }
     bool launched = false;
+    // a.bitmap_x_groups != 0: the launch's LDS has room for that many groups of x behind the accumulators (hs_api.cpp sizes it)
+    const uint32_t x_lds_offset = a.bitmap_x_groups ? a.lds_bytes - a.bitmap_x_groups * kBitmapGroupCols * 4u : 0u;
+#define X(F, A)                                                                                                                                  \
+    if (!launched && a.bitmap_x_groups && is_float == F && ablate == A) {                                                                        \
+        hipLaunchKernelGGL((spmv_bitmap_kernel<F, A, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.num_cols, a.out, \
+                           a.row_part_filter, a.part_heads, timeline, x_lds_offset);                                                             \
+        launched = true;                                                                                                                         \
+    }
+    HS_FOR_EACH_BITMAP_XLDS_VARIANT(X)
+#undef X
 #define X(F, A)                                                                                                                                  \
     if (!launched && is_float == F && ablate == A) {                                                                                             \
-        hipLaunchKernelGGL((spmv_bitmap_kernel<F, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.num_cols, a.out,     \
-                           a.row_part_filter, a.part_heads, timeline);                                                                           \
+        hipLaunchKernelGGL((spmv_bitmap_kernel<F, A>), grid, block, a.bitmap_x_groups ? x_lds_offset : a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.num_cols, a.out, \
+                           a.row_part_filter, a.part_heads, timeline, 0u);                                                                       \
         launched = true;                                                                                                                         \
     }
     HS_FOR_EACH_BITMAP_VARIANT(X)

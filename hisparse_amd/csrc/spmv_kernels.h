@@ -24,6 +24,7 @@ struct SpmvLaunch {
     uint32_t num_cols;            // length of x in words (BITMAP: the x reads of a row's last group are range-checked against it)
     uint32_t num_workgroups;
     uint32_t lds_bytes;
+    uint32_t bitmap_x_groups = 0; // BITMAP: lds_bytes ends with room for this many 64-column groups of x (0: x is read through L2)
 };
 
 // Dynamic LDS a launch needs for blocks of at most `max_block_rows` rows and a ring of `ring_buffers` x buffers.

@@ -157,7 +157,8 @@ constexpr uint32_t kBitmapMinCols = 2048;                     // shorter rows: a
 constexpr uint32_t kBitmapGroupCols = 64;                     // one wavefront step
 constexpr uint32_t kBitmapWaves = 16;                         // all 16 wavefronts of the workgroup stream (no loader wavefronts)
 constexpr uint32_t kBitmapMaxBlockRows = 8191;                // 64 KiB of 8-byte row accumulators
-constexpr uint32_t kBitmapSkew[4] = {165, 125, 75, 35};       // share of a wavefront by its place on its SIMD (wavefronts 0-3, 4-7, 8-11, 12-15): bitmap_tiles.cpp
+constexpr uint32_t kBitmapMaxXLdsGroups = 576;                // a block's stretch of x is kept in LDS when it has at most this many groups (144 KiB) and its accumulators fit beside it
+constexpr uint32_t kBitmapSkew[4] = {170, 140, 65, 25};       // share of a wavefront by its place on its SIMD (wavefronts 0-3, 4-7, 8-11, 12-15): bitmap_tiles.cpp
 constexpr uint32_t kBitmapMaskBatch = 32;                     // masks fetched per vector load (one dword per lane)
 constexpr uint32_t kBitmapRunSlots = 5;                       // Unit-sized (64-byte) slots per wavefront run: the WaveSeg + a copy of its first 32 masks
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
@@ -239,6 +240,7 @@ constexpr uint32_t kMfmaTileRows = 16;
 struct StreamTiles {
     ImageBytes image;                    // element streams, uploaded verbatim (host builder)
     MfmaImage mfma;                      // float BITMAP images only (bitmap_tiles.cpp)
+    uint32_t bitmap_x_groups = 0;        // BITMAP: groups of x a block reads (its column slice), when the kernel is to keep that stretch in LDS; else 0
     uint8_t* d_image = nullptr;          // GPU builder: the image, already in device memory (image_bytes + slack); the caller owns it
     uint64_t image_bytes = 0;
     std::vector<Block> blocks;
