@@ -760,8 +760,11 @@ int hs_spmm_device(hs_context* ctx, const void* x_dev, uint64_t ldx, void* y_dev
     // float BITMAP matrices, 16 columns at a time on the matrix engine: the matrix is streamed once per 16 columns and every x word is
     // shared by 16 rows in registers (spmm_mfma.hip)
     if (fused_enabled && !(mfma_env && std::string(mfma_env) == "0") && ctx->d_mfma && is_float) {
-        while (k - j >= 16) {
+        // (5 .. 15 columns left over: still one pass -- 25 us on transformer-50 whatever it carries, against 25 us per FOUR columns of the fused kernel)
+        while (k - j >= 5) {
+            const uint32_t vectors = std::min<uint32_t>(16, k - j);
             hisparse::dev::SpmmMfmaLaunch a;
+            a.vectors = vectors;
             a.words = ctx->d_mfma;
             a.offsets_word = ctx->mfma_info.offsets_word; a.values_word = ctx->mfma_info.values_word;
             a.tiles = ctx->mfma_info.tiles; a.groups = ctx->mfma_info.groups; a.chunk = ctx->mfma_info.chunk; a.chunks = ctx->mfma_info.chunks;
@@ -776,7 +779,7 @@ int hs_spmm_device(hs_context* ctx, const void* x_dev, uint64_t ldx, void* y_dev
             a.num_rows = ctx->num_rows;
             a.num_cols = ctx->num_cols;
             HS_HIP(ctx, hisparse::dev::launch_spmm_mfma(a, ctx->stream));
-            j += 16;
+            j += vectors;
         }
     }
     if (fused_enabled && ctx->format == hisparse::dev::kFormatBitmap && ctx->col_slices == 1) {

@@ -45,14 +45,14 @@ struct Operands {
 // X columns (vector j at x + j * ldx) -> interleaved words [column][16 vectors], zero-filled up to `padded_cols` (whole groups); *flag
 // becomes `call` when any word is not finite (a call number instead of a flag that would need zeroing first)
 __global__ __launch_bounds__(256) void interleave_x16_kernel(const uint32_t* __restrict__ x, uint64_t ldx, uint32_t num_cols, uint32_t padded_cols,
-                                                            uint32_t* __restrict__ xi, uint32_t* __restrict__ flag, uint32_t call) {
+                                                            uint32_t vectors, uint32_t* __restrict__ xi, uint32_t* __restrict__ flag, uint32_t call) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= padded_cols) return;
     uint32_t w[kVec];
     bool bad = false;
 #pragma unroll
     for (uint32_t j = 0; j < kVec; ++j) {
-        w[j] = c < num_cols ? x[size_t(j) * ldx + c] : 0u;
+        w[j] = (c < num_cols && j < vectors) ? x[size_t(j) * ldx + c] : 0u;       // (a pass of fewer than 16 vectors: zero vectors fill the tile)
         bad |= (w[j] & 0x7f800000u) == 0x7f800000u;
     }
     uint4* dst = reinterpret_cast<uint4*>(xi + size_t(c) * kVec);
@@ -130,10 +130,10 @@ __global__ __launch_bounds__(kUnitThreads) void spmm_mfma_kernel(const uint32_t*
 __global__ __launch_bounds__(256) void spmm_finish_kernel(const uint32_t* __restrict__ words, uint64_t offsets_word, uint64_t values_word, uint32_t groups,
                                                          uint32_t chunks, uint32_t num_rows, uint32_t num_cols, const float* __restrict__ partial,
                                                          const uint32_t* __restrict__ x, uint64_t ldx, const uint32_t* __restrict__ flag, uint32_t call,
-                                                         uint32_t* __restrict__ y, uint64_t ldy) {
+                                                         uint32_t* __restrict__ y, uint64_t ldy, uint32_t vectors) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t row = t / kVec, j = t % kVec;
-    if (row >= num_rows) return;
+    if (row >= num_rows || j >= vectors) return;
     const uint32_t tile = row / kMfmaTileRows, i = row % kMfmaTileRows;
     double sum = 0.0;
     if (*flag != call) {
@@ -179,12 +179,12 @@ size_t spmm_mfma_partial_words(uint32_t tiles, uint32_t chunks) { return size_t(
 
 hipError_t launch_spmm_mfma(const SpmmMfmaLaunch& a, hipStream_t stream) {
     const uint32_t padded_cols = a.groups * 64u, workgroups = a.tiles * a.chunks / 4u;
-    hipLaunchKernelGGL(interleave_x16_kernel, dim3((padded_cols + 255) / 256), dim3(256), 0, stream, a.x, a.ldx, a.num_cols, padded_cols, a.x_interleaved, a.flag,
-                       a.call);
+    hipLaunchKernelGGL(interleave_x16_kernel, dim3((padded_cols + 255) / 256), dim3(256), 0, stream, a.x, a.ldx, a.num_cols, padded_cols, a.vectors, a.x_interleaved,
+                       a.flag, a.call);
     hipLaunchKernelGGL(spmm_mfma_kernel, dim3(workgroups), dim3(kUnitThreads), 0, stream, a.words, a.offsets_word, a.values_word, a.groups, a.chunk, a.chunks,
                        reinterpret_cast<const float*>(a.x_interleaved), a.flag, a.call, a.partial);
     hipLaunchKernelGGL(spmm_finish_kernel, dim3((a.num_rows * kVec + 255) / 256), dim3(256), 0, stream, a.words, a.offsets_word, a.values_word, a.groups,
-                       a.chunks, a.num_rows, a.num_cols, a.partial, a.x, a.ldx, a.flag, a.call, a.y, a.ldy);
+                       a.chunks, a.num_rows, a.num_cols, a.partial, a.x, a.ldx, a.flag, a.call, a.y, a.ldy, a.vectors);
     return hipGetLastError();
 }
 

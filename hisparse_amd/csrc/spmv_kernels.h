@@ -66,6 +66,7 @@ struct SpmmMfmaLaunch {
     uint32_t* y;                  // column j of Y at y + j * ldy words
     uint64_t ldy;
     uint32_t num_rows, num_cols;
+    uint32_t vectors = 16;        // columns of X / Y this pass really has (1 .. 16): the others are zero vectors, their results are not written
 };
 size_t spmm_mfma_x_words(uint32_t groups);
 size_t spmm_mfma_partial_words(uint32_t tiles, uint32_t chunks);

@@ -159,9 +159,10 @@ def test_fused_spmm_transformer_50_full_size():
 
 
 @pytest.mark.parametrize("impl", [1, 2])
-@pytest.mark.parametrize("rows,cols,density,k", [(600, 4096, 0.4, 16), (300, 9000, 0.2, 35), (1030, 2500, 0.6, 16), (17, 3000, 0.5, 32)])
+@pytest.mark.parametrize("rows,cols,density,k", [(600, 4096, 0.4, 16), (300, 9000, 0.2, 35), (1030, 2500, 0.6, 16), (17, 3000, 0.5, 32), (600, 4096, 0.4, 8),
+                                                 (300, 9000, 0.2, 21), (100, 5000, 0.3, 5)])
 def test_spmm_on_the_matrix_engine(monkeypatch, impl, rows, cols, density, k):
-    """Float BITMAP matrices, k >= 16: 16 columns at a time through spmm_mfma.hip (v_mfma_f32_16x16x4_f32 over the second image: rows in
+    """Float BITMAP matrices, k >= 5: up to 16 columns at a time through spmm_mfma.hip (a pass of fewer vectors is filled up with zero vectors) (v_mfma_f32_16x16x4_f32 over the second image: rows in
     tiles of 16, x shared by the 16 rows of a tile, the matrix streamed once per 16 columns), the rest through the fused 4-column kernel
     and the SpMV kernel.  Every column against the oracle's SpMV of it (1e-4) and against the same call with the matrix engine switched
     off."""
