@@ -147,7 +147,7 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         for (uint32_t r = rg.row0; r < rg.row0 + rg.nrows; ++r) n += slice_nnz[size_t(r) * slices + bi % slices];
         block_nnz[bi] = n;
     });
-    // A row is cut into `pieces` runs of (almost) equal group count -- one per wavefront when the block has few rows, one run per
+    // A row is cut into `pieces` runs (weighted group counts, below) -- one per wavefront when the block has few rows, one run per
     // row otherwise -- and every run's masks are followed by zero masks up to a multiple of 8 plus two whole batches: the kernel
     // fetches masks eight at a time and issues up to two batches past the end of a run, which then find "no column set".
     auto pieces_of = [](uint32_t nrows) { return nrows * 2 <= kBitmapWaves ? kBitmapWaves / nrows : 1u; };
@@ -253,7 +253,7 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
                 value[at++] = uint32_t(*p);
             }
         }
-        // wavefront runs.  Few rows: every row is cut into floor(16 / nrows) runs of equal group count.  Many rows: contiguous whole
+        // wavefront runs.  Few rows: every row is cut into floor(16 / nrows) runs of weighted group count.  Many rows: contiguous whole
         // rows per wavefront, balanced by steps-plus-non-zeros.
         auto set_seg = [&](uint32_t w, uint32_t r0, uint32_t r1, uint32_t g0, uint32_t g1) {
             WaveSeg& s = *reinterpret_cast<WaveSeg*>(out.units.data() + blk.unit_begin + size_t(w) * kBitmapRunSlots);

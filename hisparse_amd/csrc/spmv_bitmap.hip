@@ -5,17 +5,19 @@
 // stages have nothing left to do:
 //   CPSR_matrix_loader (spmv_cluster.h:73-98)       a wavefront step = one 64-column GROUP of one row: a 64-bit occupancy mask
 //     streams {value, column} pairs                  + the values of the set columns, compacted (4 B + 1 bit per position, not 8 B)
-//   vecbuf_access_unit + shuffle 1 (x[col] gather)   x[64 g + lane]: a coalesced 256-byte read straight from L2 -- no x sub-tiles
-//                                                    in LDS, no gather, no per-sub-tile barrier
+//   vecbuf_access_unit + shuffle 1 (x[col] gather)   x[64 g + lane]: no gather and no per-sub-tile barrier -- a conflict-free ds_read_b32 from the
+//                                                    block's whole stretch of x, copied into LDS once per workgroup (kXLds; up to
+//                                                    36 864 columns), or a coalesced 256-byte read straight from L2 where that does not fit
 //   shuffle 2 + PE accumulate (pe.h:62-81)           per-lane register sums along the wavefront's run of groups, ONE wavefront-wide
 //                                                    sum and ONE LDS add per (wavefront, row)
 //   result packer + drain                            coalesced store, AP_SAT clamp / fp32 rounding once (column-sliced blocks write
 //                                                    partials, combine_slices_kernel adds them)
 // Lane l of a step takes column 64 g + l: its value sits at (values before this group) + (set bits below l) = a scalar running
-// offset + v_mbcnt(mask).  All loads are BUFFER loads: a lane whose bit is clear gets an out-of-range offset and the hardware
-// returns 0 without touching memory, the x read of the last (partial) group is range-checked the same way, and so are mask reads
-// past the end of a run -- the whole inner loop is branch-free straight-line code, which is what lets hipcc count its own
-// s_waitcnt vmcnt (16 loads of the next batch stay in flight while a batch is consumed).
+// offset + v_mbcnt(mask).  All global loads are BUFFER loads: the x read of a row's last (partial) group is range-checked by the
+// hardware, and so are mask reads past the end of a run -- the whole inner loop is branch-free straight-line code, which is what lets
+// hipcc count its own s_waitcnt (the loads of the next batch stay in flight while a batch is consumed).
+// The 16 wavefronts' runs are NOT equal: a SIMD serves its oldest wavefront first and this loop is hungry for issue slots, so the builder
+// weights the shares by the wavefront's place on its SIMD (bitmap_tiles.cpp, kBitmapSkew) and all sixteen finish together.
 // Numerics: Q8.24 products rounded/saturated one by one and summed exactly in 64 bits -- bit-identical to every other format and to
 // the oracle.  Float: one fp32 multiply per product (no FMA); the (up to 8) products of a batch are added in fp32, the batch sums
 // join the lane's double sum, one double LDS add per (wavefront, row) -- the order of those adds is not fixed when a row is split over
