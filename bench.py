@@ -3,6 +3,9 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--npz FILE]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+          or simply `python bench.py --gpus N`: without a launcher's WORLD_SIZE in the environment the script starts its N ranks itself
+          (the same torch.distributed.run command line, master on 127.0.0.1) and fails loudly -- a JSON error line, exit code 2 --
+          when the machine shows fewer than N GPUs.  It never prints an `n_gpus: 1` line for a `--gpus N > 1` request.
 
 A "step" is one full SpMV (every row partition) y = A x through the drop-in C-ABI, with the matrix (re-tiled at load
 time), x and y already resident in HBM.  Metric (BASELINE.json): the reference's "data throughput" of
@@ -136,7 +139,8 @@ def spmm_probe(np, host, eng, impl, packets, rng, xw, k=8, reps=100):
         rt.hipFree(xd)
         rt.hipFree(yd)
     return {"k": k, "us_per_spmm": round(us, 2), "us_per_column": round(us / k, 2), "column_0_equals_spmv_bit_for_bit": same,
-            "note": "hs_spmm_device, X and Y resident; BITMAP image: 4 columns per pass of the matrix (reference: no SpMM)"}
+            "note": "hs_spmm_device, X and Y resident; float BITMAP images: 5-16 columns per pass through the matrix engine (spmm_mfma.hip, sums in another "
+                    "order than the SpMV kernel: tolerance parity per column), fixed point: 4 columns per pass (spmm_bitmap.hip, bit for bit); reference: no SpMM"}
 
 
 def oracle_check(np, host, impl, packets, xw, y_gpu, seconds, exact=None):
@@ -221,6 +225,13 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         eng.run()
     eng.sync()
     elapsed = time.perf_counter() - t0
+    # the reference's own step: queue.finish() after every launch (sw/benchmark.cpp:331-337), so its spmv_time_ms is a LATENCY -- the same
+    # K SpMVs with a host synchronisation after each one, beside the pipelined figure above (which is `value`)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.run()
+        eng.sync()
+    elapsed_sync = time.perf_counter() - t0
     # Two HIP-event measurements, both reported; WHICH one prices the roofline is fixed by the plan, not by which came out smaller:
     #   * one kernel per step (no slice-combine pass): two events around the K back-to-back launches / K -- an event pair around every
     #     launch adds ~2 us to each, a fifth of a 14 us kernel (rocprofv3 agrees with the region figure);
@@ -254,6 +265,8 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         "rows": true_rows, "cols": packets.num_cols, "nnz": int(nnz), "partitions": f"{packets.num_row_partitions}x{packets.num_col_partitions}",
         "stream_format": device.STREAM_FORMATS[stats["stream_format"]], "col_slices": stats["col_slices"],
         "ms_per_step": round(ms, 5), "value": round(value, 2), "unit": "GB/s", "gops": round(2.0 * nnz / (elapsed / steps) / 1e9, 2),
+        "ms_per_step_synchronous": round(elapsed_sync / steps * 1e3, 5),
+        "value_synchronous": round(8.0 * nnz / (elapsed_sync / steps) / 1e9, 2),
         "spin_up_steps": spun,
         "gibps_reference_formula": round(8.0 * nnz / 2 ** 30 / (elapsed / steps), 2),
         "hbm_roofline_fraction_whole_job": round(value / HBM_PEAK_GBS, 4),
@@ -417,6 +430,43 @@ def predict_scaling(np, datasets, device, host, sharding, name, steps, rank):
     return out
 
 
+def fail(message, **extra):
+    """A request this run cannot honour: ONE JSON line with `error` (so a driver that parses the last line sees it) and exit code 2."""
+    print(json.dumps({"error": message, **extra}), flush=True)
+    sys.exit(2)
+
+
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` -- exactly what the driver would type -- and pass its
+    output and exit code through.  With the RCCL backend every rank needs its own GPU: fewer visible GPUs than N is an error, not a
+    reason to measure something smaller."""
+    import socket
+    import subprocess
+    if args.backend == "nccl":
+        have = visible_gpus()
+        if have < args.gpus:
+            fail(f"--gpus {args.gpus} asked for, {have} GPU(s) visible on this machine: nothing measured", n_gpus_requested=args.gpus, gpus_visible=have)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(0, "no launcher in the environment: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        fail(f"the {args.gpus}-rank run exited with code {rc}", n_gpus_requested=args.gpus)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -428,6 +478,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong", help="N > 1: split ONE matrix (default) or one matrix-sized slab per rank")
     ap.add_argument("--gather", choices=["step", "final", "off"], default="step",
                     help="N > 1: all-gather the y slabs after every SpMV (default, overlapped), once after the timed SpMVs, or never")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N > 1: nccl = RCCL over xGMI, one GPU per rank (the measurement).  gloo = the launcher / sharding self-test on host "
+                         "memory: needs HISPARSE_HIP_LIB=<libhisparse_cpu.so> (the separate host-thread build of the C-ABI); never a measurement")
     ap.add_argument("--quick", action="store_true", help="N = 1: headline only (no per-config runs, no round-robin leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -438,10 +491,16 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus < 1:
+        fail(f"--gpus {args.gpus}: need at least one")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)             # no launcher: start the N ranks ourselves (never falls through to the 1-GPU line)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:                   # a line labelled n_gpus = N must have been measured by N ranks
+        if rank == 0:
+            fail(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to measure one and label it the other")
+        sys.exit(2)
     dist_mode = world > 1 or args.force_dist
-    if args.gpus != world and world > 1:
-        log(rank, f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
     if rank == 0:
         ensure_built()
     if dist_mode:
@@ -547,12 +606,26 @@ def main_distributed(args, rank, local_rank, world):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    on_gpu = args.backend == "nccl"
+    if on_gpu:
+        have = visible_gpus()
+        if local_rank >= have:
+            if rank == 0:
+                fail(f"{world} ranks over RCCL need {world} GPUs, {have} visible", n_gpus_requested=world, gpus_visible=have)
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
+    elif os.path.basename(device._LIB_PATH) == "libhisparse_hip.so":
+        if rank == 0:
+            fail("--backend gloo is the launcher / sharding self-test on host memory: point HISPARSE_HIP_LIB at libhisparse_cpu.so "
+                 "(the HIP library has no host path and writes y to device memory)")
+        sys.exit(2)
+    dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     dist.barrier()
     n_gpus = world
     name = args.config or "mouse_gene"
-    dev = f"cuda:{local_rank}"
+    dev = f"cuda:{local_rank}" if on_gpu else "cpu"
+    spin_up_steps = SPIN_UP_STEPS if on_gpu else 0
+    cuda_sync = torch.cuda.synchronize if on_gpu else (lambda: None)
 
     # ---- workload: this rank's row slab ---------------------------------------------------------------------------------
     t0 = time.perf_counter()
@@ -588,7 +661,7 @@ def main_distributed(args, rank, local_rank, world):
     xw = host.pack_vector(impl, x)
     if args.scaling != "strong":
         whole = None
-    eng = device.SpmvEngine(impl, device_id=local_rank)
+    eng = device.SpmvEngine(impl, device_id=local_rank if on_gpu else 0)
     eng.load_matrix(packets)
     eng.load_vector(xw)
     stats = eng.stats()
@@ -601,25 +674,34 @@ def main_distributed(args, rank, local_rank, world):
     chunk = max(rows_all)
     y_chunks = [torch.zeros(chunk, dtype=torch.int32, device=dev) for _ in range(2)]
     gathered = [torch.zeros(chunk * world, dtype=torch.int32, device=dev) for _ in range(2)]
-    main_stream = torch.cuda.Stream(device=dev)     # the legacy default stream has handle 0 = "the library's private stream"
-    torch.cuda.set_stream(main_stream)
-    torch.cuda.synchronize()
-    eng.set_stream(main_stream.cuda_stream)
-    eng.bind_device_result(y_chunks[0].data_ptr())
+    if on_gpu:
+        main_stream = torch.cuda.Stream(device=dev)     # the legacy default stream has handle 0 = "the library's private stream"
+        torch.cuda.set_stream(main_stream)
+        torch.cuda.synchronize()
+        eng.set_stream(main_stream.cuda_stream)
     pending = [None, None]
     step_no = [0]
 
+    def run_into(y_tensor):
+        """one slab SpMV whose result lands in y_tensor: the kernels write straight into it (hs_bind_device_result); the host-memory
+        self-test (--backend gloo, libhisparse_cpu.so has no binding hooks) copies the library's own y instead"""
+        if on_gpu:
+            eng.bind_device_result(y_tensor.data_ptr())
+            eng.run()
+        else:
+            eng.run()
+            y_tensor[:packets.num_rows] = torch.from_numpy(eng.read_result().view(np.int32))
+
     def step(gather):
         if gather != "step":
-            eng.run()
+            run_into(y_chunks[0])
             return
         cur = step_no[0] & 1
         step_no[0] += 1
         if pending[cur] is not None:
             pending[cur].wait()              # the gather that read this slab two steps ago (stream-level wait, no host sync)
             pending[cur] = None
-        eng.bind_device_result(y_chunks[cur].data_ptr())
-        eng.run()
+        run_into(y_chunks[cur])
         pending[cur] = dist.all_gather_into_tensor(gathered[cur], y_chunks[cur], async_op=True)
 
     def sync():
@@ -627,33 +709,32 @@ def main_distributed(args, rank, local_rank, world):
             if pending[i] is not None:
                 pending[i].wait()
                 pending[i] = None
-        torch.cuda.synchronize()
+        cuda_sync()
         eng.sync()
 
     def timed(gather, steps):
-        for _ in range(SPIN_UP_STEPS):
+        for _ in range(spin_up_steps):
             step(gather)
         sync()
         for _ in range(args.warmup):
             step(gather)
         sync()
         dist.barrier()
-        torch.cuda.synchronize()
+        cuda_sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             step(gather)
         if gather == "final":
             dist.all_gather_into_tensor(gathered[0], y_chunks[0])
         sync()
-        torch.cuda.synchronize()
+        cuda_sync()
         dist.barrier()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     # ---- correctness of what is about to be timed: this rank's slab against the oracle, and the gathered buffer ------------------
-    eng.bind_device_result(y_chunks[0].data_ptr())
-    eng.run()
+    run_into(y_chunks[0])
     dist.all_gather_into_tensor(gathered[0], y_chunks[0])
     sync()
     y_gpu = y_chunks[0][:packets.num_rows].cpu().numpy().view(np.uint32)
@@ -675,7 +756,8 @@ def main_distributed(args, rank, local_rank, world):
     tot = torch.tensor([float(nnz)], dtype=torch.float64, device=dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     total_nnz = float(tot.item())
-    eng.set_stream(None)
+    if on_gpu:
+        eng.set_stream(None)
     _, ev_kernel_ms = eng.time_runs(0, args.steps)
     kernel_ms = ev_kernel_ms / args.steps
     dist.barrier()
@@ -683,10 +765,10 @@ def main_distributed(args, rank, local_rank, world):
     # (bench.py --gpus 1 without a launcher measures the ogbl-ppa headline instead)
     one_gpu = None
     if whole is not None:
-        with device.SpmvEngine(impl, device_id=local_rank) as eng1:
+        with device.SpmvEngine(impl, device_id=local_rank if on_gpu else 0) as eng1:
             eng1.load_matrix_csr(whole)
             eng1.load_vector(xw)
-            for _ in range(SPIN_UP_STEPS + args.warmup):
+            for _ in range(spin_up_steps + args.warmup):
                 eng1.run()
             eng1.sync()
             t1 = time.perf_counter()
@@ -707,8 +789,9 @@ def main_distributed(args, rank, local_rank, world):
         gather_text = {"step": " + all_gather(y) over RCCL every step (overlapped with the next SpMV)", "final": " + one final all_gather(y) over RCCL", "off": ""}[args.gather]
         out = {
             "metric": "SpMV GBPS (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346; GOPS and % of the HBM roofline alongside)",
-            "value": round(value, 2), "unit": "GB/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "spin_up_steps": SPIN_UP_STEPS,
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "spin_up_steps": spin_up_steps,
             "ms_per_step": round(per_step * 1e3, 5), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "backend": "nccl (RCCL)" if on_gpu else f"gloo on host memory with {os.path.basename(device._LIB_PATH)}: launcher self-test, NOT a measurement",
             "dtype": "u32 Q8.24 fixed point (u64 accumulate)" if impl == host.IMPL_FIXED else "f32",
             "data": "synthetic" if not args.npz else "file",
             "config": {"workload": f"{name}, {IMPL_NAMES[impl]} IMPL, v={packets.vb_bank} o={packets.ob_bank}", "rows": full_rows or true_rows * n_gpus,
