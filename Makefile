@@ -15,7 +15,7 @@ HIPFLAGS  := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -ffp
 HOST_HDRS := $(wildcard include/hisparse/*.h) include/hisparse_host.h
 HIP_HDRS  := include/hisparse_hip.h $(wildcard $(CSRC)/*.h) include/hisparse/common.h
 
-.PHONY: all host hip cpu oracle benchmark clean
+.PHONY: all host hip cpu oracle benchmark clean prof
 all: host hip cpu oracle benchmark
 
 host: $(LIBDIR)/libhisparse_host.so
@@ -30,9 +30,30 @@ $(LIBDIR):
 $(LIBDIR)/libhisparse_host.so: $(CSRC)/host_capi.cpp $(HOST_HDRS) | $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $< -lz
 
-HIP_SRCS  := $(CSRC)/hs_api.cpp $(CSRC)/tiles_capi.cpp $(CSRC)/stream_tiles.cpp $(CSRC)/bitmap_tiles.cpp $(CSRC)/spmv_kernels.hip $(CSRC)/spmv_bitmap.hip $(CSRC)/spmspv.hip $(CSRC)/spmm_bitmap.hip $(CSRC)/spmm_mfma.hip $(CSRC)/gpu_tiles.hip
-$(LIBDIR)/libhisparse_hip.so: $(HIP_SRCS) $(HIP_HDRS) | $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS) -pthread
+# One object per translation unit (an edit of one kernel file recompiles that file only); objects live in build/ (git-ignored, and listed in
+# .gpurunignore: the GPU box needs the libraries, not the objects).
+HIP_UNITS := hs_api.cpp tiles_capi.cpp stream_tiles.cpp bitmap_tiles.cpp spmv_kernels.hip spmv_bitmap.hip spmspv.hip spmm_bitmap.hip spmm_mfma.hip gpu_tiles.hip
+OBJDIR    := $(ROOT)/build
+HIP_OBJS  := $(addprefix $(OBJDIR)/prod/,$(addsuffix .o,$(HIP_UNITS)))
+PROF_OBJS := $(addprefix $(OBJDIR)/prof/,$(addsuffix .o,$(HIP_UNITS)))
+$(OBJDIR)/prod/%.o: $(CSRC)/% $(HIP_HDRS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(HIPFLAGS) -x hip -c -o $@ $<
+$(OBJDIR)/prof/%.o: $(CSRC)/% $(HIP_HDRS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(HIPFLAGS) -DHISPARSE_PROFILING -x hip -c -o $@ $<
+$(LIBDIR)/libhisparse_hip.so: $(HIP_OBJS) | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_OBJS) -pthread
+
+# The profiling library: the same sources with -DHISPARSE_PROFILING -- the HISPARSE_ABLATE / HISPARSE_DEPTH instantiations (most give WRONG
+# results by design) and the timeline builds.  Never loaded by default; tools/ select it with HISPARSE_HIP_LIB.  `make HISPARSE_PROFILING=1`
+# (or `make prof`) builds it next to the product library.
+prof: $(LIBDIR)/libhisparse_hip_prof.so
+$(LIBDIR)/libhisparse_hip_prof.so: $(PROF_OBJS) | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(PROF_OBJS) -pthread
+ifeq ($(HISPARSE_PROFILING),1)
+all: prof
+endif
 
 # the same C-ABI on host threads for machines without a GPU: a separate library a driver links INSTEAD (never a fallback of the HIP one)
 $(LIBDIR)/libhisparse_cpu.so: $(CSRC)/cpu_backend.cpp $(HIP_HDRS) include/hisparse/q8_24.h | $(LIBDIR)
@@ -46,4 +67,4 @@ oracle/liboracle.so: oracle/cpu_ref.c
 	$(MAKE) -C oracle
 
 clean:
-	rm -rf $(LIBDIR) oracle/liboracle.so oracle/_ref
+	rm -rf $(LIBDIR) $(OBJDIR) oracle/liboracle.so oracle/_ref

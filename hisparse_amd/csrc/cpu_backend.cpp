@@ -285,6 +285,7 @@ int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* 
 
 // ---- not part of this backend: device-memory hooks and the extensions ---------------------------------------------------------
 #define HS_CPU_UNSUPPORTED(ctx) return fail(ctx, HS_ERR_UNSUPPORTED, std::string(__func__) + " is not part of the CPU backend (libhisparse_cpu.so)")
+int hs_set_option(hs_context* ctx, const char*, const char*) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_set_stream(hs_context* ctx, void*) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_get_stream(hs_context* ctx, void**) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_device_vector(hs_context* ctx, void**) { HS_CPU_UNSUPPORTED(ctx); }

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,12 +24,14 @@
 #include "spmv_kernels.h"
 #include "gpu_tiles.h"
 #include "stream_tiles.h"
+#include "tiles_common.h"
 
 using hisparse::Geometry;
 using hisparse::dev::Block;
 using hisparse::dev::Unit;
 
 struct hs_context {
+    hisparse::dev::detail::OptionMap options;    // hs_set_option: "HISPARSE_<KEY>" -> value
     int device = -1;
     int impl = 0;
     Geometry geom;
@@ -102,6 +105,16 @@ int hip_fail(hs_context* ctx, hipError_t e, const char* what) {
         hipError_t e_ = (call);                                 \
         if (e_ != hipSuccess) return hip_fail(ctx, e_, #call);  \
     } while (0)
+
+// a call-time switch of this context: hs_set_option first, the environment as the fallback for tools
+const char* ctx_option(const hs_context* c, const char* name) { return hisparse::dev::detail::option_lookup(&c->options, name); }
+
+// hs_set_option's keys (the HISPARSE_<KEY> environment switches the library understands); plan-time ones take effect at the next load
+const char* const kOptionKeys[] = {
+    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG", "FORMAT_THREADS",
+    "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT_THREADS", "DIRECT_Y",
+    "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "ITERATE_COOPERATIVE",
+};
 
 void free_matrix(hs_context* c) {
     if (c->d_image) (void)hipFree(c->d_image);
@@ -182,6 +195,7 @@ void partition_rows(const hs_context* c, uint32_t j, uint32_t& lo, uint32_t& hi)
 // x = scale (*) y (+) shift afterwards -- folded into the combine launch of a column-sliced matrix, its own launch otherwise.
 struct Feedback { uint32_t scale, shift; };
 int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1, const Feedback* feedback = nullptr) {
+    if (const char* why = hisparse::dev::profiling_switch_error()) return fail(c, HS_ERR_BAD_ARG, why);
     if (k0) HS_HIP(c, hipEventRecord(k0, c->stream));
     HS_HIP(c, hisparse::dev::launch_spmv(c->impl != HS_IMPL_FIXED, launch_args(c, filter), c->stream));
     if (k1) HS_HIP(c, hipEventRecord(k1, c->stream));
@@ -313,7 +327,8 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     };
     // The per-non-zero passes of the re-tiling run on the GPU (gpu_tiles.h) unless HISPARSE_RETILE=host; BITMAP images and matrices
     // with duplicate entries are built by the host code, which also remains the byte-for-byte checker of the GPU path.
-    const char* retile = std::getenv("HISPARSE_RETILE");
+    const hisparse::dev::detail::OptionScope option_scope(&ctx->options);      // this context's hs_set_option values rule the planning below
+    const char* retile = hisparse::dev::detail::env_switch("HISPARSE_RETILE");
     bool on_gpu = csr || !(retile && std::string(retile) == "host");
     try {
         // one 1024-thread workgroup per CU: its row accumulators and x ring fill the 160 KiB LDS
@@ -359,7 +374,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
         drop_device_images(tiles);
         return fail(ctx, HS_ERR_BAD_MATRIX, "re-tiling the matrix failed");
     }
-    const bool debug = std::getenv("HISPARSE_PLAN_DEBUG") != nullptr;
+    const bool debug = ctx_option(ctx, "HISPARSE_PLAN_DEBUG") != nullptr;
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     if (debug) std::fprintf(stderr, "load: image built after %.1f ms\n", since());
     // (BITMAP: + the block's stretch of x behind the accumulators when the builder asks for it, spmv_bitmap.hip kXLds)
@@ -547,7 +562,7 @@ int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32
     // stream-ordered launches are the default.  HISPARSE_ITERATE_GRAPH=1 captures chunks of 32 iterations into one
     // hipGraph and replays them instead; measured on ROCm 7.2 that is no faster (1k x 1k: 8.4 vs 8.6 us per iteration)
     // and slower for large matrices (ogbl-ppa 64.7 vs 60.9 us: gaps between graph nodes), so it stays opt-in.
-    const char* graph_env = std::getenv("HISPARSE_ITERATE_GRAPH");
+    const char* graph_env = ctx_option(ctx, "HISPARSE_ITERATE_GRAPH");
     const bool use_graph = graph_env && std::atoi(graph_env) != 0;
     const uint32_t chunk = use_graph ? std::min<uint32_t>(iterations, 32) : 1;
     uint32_t done = 0;
@@ -646,7 +661,7 @@ int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
     }
     HS_HIP(ctx, hisparse::dev::launch_spmspv(ctx->impl != HS_IMPL_FIXED, ctx->d_csc_indptr, ctx->d_csc_rows, ctx->d_csc_vals, ctx->d_sx,
                                              ctx->d_sx + count, count, ctx->csc_rows, ctx->csc_cols, ctx->csc_scratch, ctx->d_csc_y, ctx->stream,
-                                             &ctx->spmspv_products));
+                                             &ctx->spmspv_products, ctx_option(ctx, "HISPARSE_SPMSPV")));
     return HS_OK;
 }
 
@@ -674,6 +689,21 @@ int hs_read_result(hs_context* ctx, void* packed_y, uint32_t num_rows) {
     HS_HIP(ctx, hipSetDevice(ctx->device));
     HS_HIP(ctx, hipMemcpyAsync(packed_y, y_target(ctx), size_t(num_rows) * 4, hipMemcpyDeviceToHost, ctx->stream));
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HS_OK;
+}
+
+int hs_set_option(hs_context* ctx, const char* key, const char* value) {
+    if (!ctx || !key) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+    std::string k(key);
+    for (char& ch : k) ch = char(std::toupper(static_cast<unsigned char>(ch)));
+    if (k.rfind("HISPARSE_", 0) == 0) k = k.substr(9);
+    bool known = false;
+    for (const char* name : kOptionKeys) known = known || k == name;
+    if (k == "ABLATE" || k == "DEPTH" || k == "TIMELINE_OUT")
+        return fail(ctx, HS_ERR_BAD_ARG, "'" + k + "' is a profiling switch of libhisparse_hip_prof.so (wrong results by design), not an option of this library");
+    if (!known) return fail(ctx, HS_ERR_BAD_ARG, "unknown option '" + std::string(key) + "'");
+    if (value && *value) ctx->options["HISPARSE_" + k] = value;
+    else ctx->options.erase("HISPARSE_" + k);
     return HS_OK;
 }
 
@@ -754,9 +784,9 @@ int hs_spmm_device(hs_context* ctx, const void* x_dev, uint64_t ldx, void* y_dev
     // BITMAP images (dense rows: pruned-NN layers, which are multiplied with batches in practice): 4, then 2 columns at a time through
     // the fused kernel of spmm_bitmap.hip -- masks and values are streamed once for them.  Everything else, and a last odd column:
     // one SpMV per column.
-    const char* fused_env = std::getenv("HISPARSE_SPMM_FUSED");      // read per call (a test may change it)
+    const char* fused_env = ctx_option(ctx, "HISPARSE_SPMM_FUSED");      // read per call (a test may change it)
     const bool fused_enabled = !(fused_env && std::string(fused_env) == "0");
-    const char* mfma_env = std::getenv("HISPARSE_SPMM_MFMA");
+    const char* mfma_env = ctx_option(ctx, "HISPARSE_SPMM_MFMA");
     // float BITMAP matrices, 16 columns at a time on the matrix engine: the matrix is streamed once per 16 columns and every x word is
     // shared by 16 rows in registers (spmm_mfma.hip)
     if (fused_enabled && !(mfma_env && std::string(mfma_env) == "0") && ctx->d_mfma && is_float) {

@@ -165,7 +165,7 @@ size_t spmspv_sort_temp_bytes(uint64_t max_elements, uint32_t num_rows) {
 
 hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, const uint32_t* x_index,
                          const uint32_t* x_words, uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& s, uint32_t* y,
-                         hipStream_t stream, uint64_t* products_out) {
+                         hipStream_t stream, uint64_t* products_out, const char* force_path) {
     hipError_t e;
     uint32_t total = 0;
     if (x_count) {
@@ -179,7 +179,7 @@ hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* 
     }
     if (products_out) *products_out = total;
     const dim3 expand_grid(std::min<uint32_t>((x_count + 3) / 4, 4096)), block(256);       // 4 wavefronts per workgroup, one x entry each
-    const char* force = std::getenv("HISPARSE_SPMSPV");      // atomic | binned: force a path (tests, A/B runs); read per call
+    const char* force = force_path;      // atomic | binned: force a path (hs_set_option "spmspv" / HISPARSE_SPMSPV; tests, A/B runs)
     const bool force_direct = force && std::string(force) == "atomic", force_binned = force && std::string(force) == "binned" && total > 0;
     if (!force_binned && (total < kSpmspvDirectLimit || (num_rows + kBlockRows - 1) / kBlockRows < kSpmspvMinBlocks || force_direct)) {
         // ---- a handful of products: zero, scatter with memory-side atomics, clamp / copy -----------------------------------------

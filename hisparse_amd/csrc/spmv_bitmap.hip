@@ -308,13 +308,14 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
     }
 }
 
+// product library: the two numeric modes; the ablation / timeline instantiations only in libhisparse_hip_prof.so (spmv_kernels.hip)
+#ifdef HISPARSE_PROFILING
 #define HS_FOR_EACH_BITMAP_XLDS_VARIANT(X) X(false, 0) X(true, 0) X(true, 1) X(true, 2) X(true, 3) X(true, 7) X(true, 15) X(true, 64)
 #define HS_FOR_EACH_BITMAP_VARIANT(X) X(false, 0) X(true, 0) X(true, 1) X(true, 2) X(true, 3) X(true, 4) X(true, 7) X(true, 15) X(true, 31) X(true, 23) X(true, 64) X(true, 256)
-
-int bitmap_env_int(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    return e ? std::atoi(e) : dflt;
-}
+#else
+#define HS_FOR_EACH_BITMAP_XLDS_VARIANT(X) X(false, 0) X(true, 0)
+#define HS_FOR_EACH_BITMAP_VARIANT(X) X(false, 0) X(true, 0)
+#endif
 
 }  // namespace
 
@@ -334,7 +335,8 @@ hipError_t configure_bitmap_kernels(uint32_t lds_bytes) {
 hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.num_workgroups == 0) return hipSuccess;
     const dim3 grid(a.num_workgroups), block(kBmThreads);
-    const int ablate = bitmap_env_int("HISPARSE_ABLATE", 0);       // read per launch: a process may switch profiling builds between runs
+    int ablate = 0, depth_unused = 8;       // read per launch (profiling library only): a process may switch profiling builds between runs
+    if (!profiling_switches(ablate, depth_unused)) return hipErrorInvalidValue;
     // timeline build: HISPARSE_ABLATE=64 HISPARSE_TIMELINE_OUT=file -> every launch is synchronised and its per-wavefront
     // timestamps (workgroups x 16 x 8 u64, 100 MHz) overwrite the file (tools/bitmap_timeline.py reads it)
     // (one buffer per device: a process may drive several, benchmark.cpp --gpus N)

@@ -27,6 +27,14 @@ struct SpmvLaunch {
     uint32_t bitmap_x_groups = 0; // BITMAP: lds_bytes ends with room for this many 64-column groups of x (0: x is read through L2)
 };
 
+// HISPARSE_ABLATE / HISPARSE_DEPTH (environment): profiling switches of libhisparse_hip_prof.so (-DHISPARSE_PROFILING), read per launch.
+// In the product library they select nothing: profiling_switches returns false when either is set to a non-default value, and the
+// launch functions then fail (hs_api.cpp reports HS_ERR_BAD_ARG through profiling_switch_error) -- an inherited environment variable
+// must never change what a production SpMV computes.
+bool profiling_switches(int& ablate, int& depth);
+bool profiling_depth_given();
+const char* profiling_switch_error();      // nullptr, or why the product library will not launch in this environment
+
 // Dynamic LDS a launch needs for blocks of at most `max_block_rows` rows and a ring of `ring_buffers` x buffers.
 uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t format = kFormatPairs);
 // One-time per device: allow the kernels to use up to `lds_bytes` of dynamic LDS.
@@ -97,7 +105,7 @@ size_t spmspv_sort_temp_bytes(uint64_t max_elements, uint32_t num_rows);
 // products_out (may be null): how many products the call formed.  Synchronises the stream once (the product count sizes the passes).
 hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, const uint32_t* x_index,
                          const uint32_t* x_words, uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& scratch, uint32_t* y,
-                         hipStream_t stream, uint64_t* products_out = nullptr);
+                         hipStream_t stream, uint64_t* products_out = nullptr, const char* force_path = nullptr);
 
 // Multi-GPU gather without a collective: y[0, words) into n_dst <= kMaxPushTargets other buffers (peers' memory over xGMI) with plain stores.
 constexpr uint32_t kMaxPushTargets = 8;

@@ -932,6 +932,38 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
+bool profiling_depth_given() {
+#ifdef HISPARSE_PROFILING
+    return std::getenv("HISPARSE_DEPTH") != nullptr;
+#else
+    return false;
+#endif
+}
+bool profiling_switches(int& ablate, int& depth) {
+#ifdef HISPARSE_PROFILING
+    ablate = env_int("HISPARSE_ABLATE", 0);
+    depth = env_int("HISPARSE_DEPTH", 8);
+    return true;
+#else
+    ablate = 0;
+    depth = 8;
+    return profiling_switch_error() == nullptr;
+#endif
+}
+const char* profiling_switch_error() {
+#ifdef HISPARSE_PROFILING
+    return nullptr;
+#else
+    if (env_int("HISPARSE_ABLATE", 0) != 0)
+        return "HISPARSE_ABLATE is set: the ablation builds (wrong results by design) live in libhisparse_hip_prof.so (make HISPARSE_PROFILING=1, "
+               "HISPARSE_HIP_LIB=...); this library will not launch with it in the environment";
+    if (std::getenv("HISPARSE_DEPTH") != nullptr)
+        return "HISPARSE_DEPTH is set: prefetch-depth experiments live in libhisparse_hip_prof.so (make HISPARSE_PROFILING=1); this library will "
+               "not launch with it in the environment";
+    return nullptr;
+#endif
+}
+
 // LDS plan: row accumulators first (64-bit integer sums / double sums + 1 spare; OWNER: floats + one spare per consumer
 // wavefront), then the ring of x buffers.
 uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t format) {
@@ -939,20 +971,39 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t
     return ((acc + 15u) & ~15u) + ring_buffers * kBufBytes;
 }
 
+// The PRODUCT library (libhisparse_hip.so) carries one instantiation per (numeric mode, stream format) and nothing else.  The ablation
+// and timeline instantiations -- most of which give WRONG results by design -- exist only in libhisparse_hip_prof.so
+// (`make HISPARSE_PROFILING=1`, -DHISPARSE_PROFILING), which tools/ load through HISPARSE_HIP_LIB; in the product library a set
+// HISPARSE_ABLATE / HISPARSE_DEPTH makes every launch fail (hs_run: HS_ERR_BAD_ARG) instead of being obeyed or silently ignored.
+#ifdef HISPARSE_PROFILING
 // OWNER24 profiling builds (three records in flight): 1 = no LDS work, 4 = no x refill, 8 = no unit barriers, and combinations
-#define HS_FOR_EACH_OWNER24_ABLATION(X) X(1) X(4) X(5) X(8) X(12) X(13) X(512)
+#define HS_FOR_EACH_OWNER24_ABLATION(X) X(0) X(1) X(4) X(5) X(8) X(12) X(13) X(512)
+#define HS_FOR_EACH_OWNER24_DEPTH(X) X(2) X(3) X(4)
+#define HS_FOR_EACH_OWNER24_FIXED(X) X(0) X(512)
 // OWNER variants (float only): ablate values as for the other formats
 #define HS_FOR_EACH_OWNER_VARIANT(X) X(0) X(1) X(2) X(3) X(4) X(7) X(8) X(11) X(12) X(15) X(127) X(256)
+#else
+#define HS_FOR_EACH_OWNER24_ABLATION(X) X(0)
+#define HS_FOR_EACH_OWNER24_DEPTH(X) X(3)
+#define HS_FOR_EACH_OWNER24_FIXED(X) X(0)
+#define HS_FOR_EACH_OWNER_VARIANT(X) X(0)
+#endif
 
-// (float, delta, ablate, depth): the product variants first, then the profiling builds (fixed point only)
+// (float, ring format, ablate, depth): the product variants first, then the profiling builds (fixed point only)
+#define HS_FOR_EACH_PRODUCT_VARIANT(X)                                                                           \
+    X(true, 0, 0, 8) X(true, 1, 0, 8) X(false, 0, 0, 8) X(false, 1, 0, 8) X(true, 2, 0, 8) X(false, 2, 0, 8)
+#ifndef HISPARSE_PROFILING
+#define HS_FOR_EACH_VARIANT(X) HS_FOR_EACH_PRODUCT_VARIANT(X)
+#else
 #define HS_FOR_EACH_VARIANT(X)                                                                                   \
-    X(true, 0, 0, 8) X(true, 1, 0, 8) X(false, 0, 0, 8) X(false, 1, 0, 8) X(true, 2, 0, 8) X(false, 2, 0, 8)         \
+    HS_FOR_EACH_PRODUCT_VARIANT(X)                                                                               \
     X(false, false, 0, 16) X(false, false, 3, 8) X(false, true, 3, 8)                       \
     X(false, false, 4, 8) X(false, true, 4, 8) X(false, false, 8, 8) X(false, true, 8, 8) X(false, false, 15, 8) X(false, true, 15, 8) X(false, false, 31, 8) X(false, true, 31, 8)                     \
     X(false, false, 47, 8) X(false, true, 47, 8) X(false, false, 79, 8) X(false, true, 79, 8)                     \
     X(false, false, 127, 8) X(false, true, 127, 8)                                                                 \
     X(true, false, 3, 8) X(true, false, 4, 8) X(true, false, 8, 8) X(true, false, 15, 8) X(true, false, 127, 8) \
     X(false, false, 512, 8) X(false, true, 512, 8) X(true, false, 512, 8) X(true, true, 512, 8)
+#endif
 
 hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
     hipError_t e;
@@ -962,13 +1013,15 @@ hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
 #define X(A) if ((e = configure_one<true, false, A, 8, true>(lds_bytes)) != hipSuccess) return e;
     HS_FOR_EACH_OWNER_VARIANT(X)
 #undef X
-    if ((e = configure_one<true, 3, 0, 2, true>(lds_bytes)) != hipSuccess || (e = configure_one<true, 3, 0, 3, true>(lds_bytes)) != hipSuccess ||
-        (e = configure_one<true, 3, 0, 4, true>(lds_bytes)) != hipSuccess)
-        return e;
+#define X(D) if (D != 3 && (e = configure_one<true, 3, 0, D, true>(lds_bytes)) != hipSuccess) return e;
+    HS_FOR_EACH_OWNER24_DEPTH(X)
+#undef X
 #define X(A) if ((e = configure_one<true, 3, A, 3, true>(lds_bytes)) != hipSuccess) return e;
     HS_FOR_EACH_OWNER24_ABLATION(X)
 #undef X
-    if ((e = configure_one<false, 3, 0, 3, true>(lds_bytes)) != hipSuccess || (e = configure_one<false, 3, 512, 3, true>(lds_bytes)) != hipSuccess) return e;
+#define X(A) if ((e = configure_one<false, 3, A, 3, true>(lds_bytes)) != hipSuccess) return e;
+    HS_FOR_EACH_OWNER24_FIXED(X)
+#undef X
     return configure_bitmap_kernels(lds_bytes);
 }
 
@@ -978,8 +1031,10 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     const int ring = a.format == kFormatDelta ? 1 : a.format == kFormatPairs24 ? 2 : 0;
     const dim3 grid(a.num_workgroups), block(kThreads);
     const uint32_t x_base = a.lds_bytes - a.ring_buffers * kBufBytes;
-    // profiling aids: HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the prefetch depth
-    const int ablate = env_int("HISPARSE_ABLATE", 0), depth = env_int("HISPARSE_DEPTH", 8);     // read per launch: a test may change them
+    // profiling aids (libhisparse_hip_prof.so only): HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the
+    // prefetch depth; read per launch, a tool may change them between launches.  The product library refuses to run with either set.
+    int ablate = 0, depth = 8;
+    if (!profiling_switches(ablate, depth)) return hipErrorInvalidValue;
     bool launched = false;
     // timeline build: HISPARSE_ABLATE=512 HISPARSE_TIMELINE_OUT=file -> the launch is synchronised and its timestamps (workgroups x
     // kTimelineBlocks x 2 wavefronts x kTimelineStamps u64, 100 MHz) overwrite the file (tools/rowblock_timeline.py)
@@ -1008,16 +1063,18 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     }
     if (a.format == kFormatOwner24) {
         // records in flight per wavefront (1792 bytes each): HISPARSE_DEPTH=2|3|4 for experiments, kOwner24Depth otherwise
-        const int records = std::getenv("HISPARSE_DEPTH") ? depth : kOwner24Depth;
+        const int records = profiling_depth_given() ? depth : kOwner24Depth;
         if (!is_float) {      // fixed point: saturating 32-bit accumulators (OwnerOps<false>); the product build and the timeline build
-            if (records != 3 || (ablate != 0 && ablate != 512)) return hipErrorInvalidValue;
-            if (ablate == 512)
-                hipLaunchKernelGGL((spmv_rowblock_kernel<false, 3, 512, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out,
-                                   a.row_part_filter, a.ring_buffers, x_base, a.part_heads);
-            else
-                hipLaunchKernelGGL((spmv_rowblock_kernel<false, 3, 0, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out,
-                                   a.row_part_filter, a.ring_buffers, x_base, a.part_heads);
-            return hipGetLastError();
+            if (records != 3) return hipErrorInvalidValue;
+#define X(A)                                                                                                                       \
+    if (ablate == A) {                                                                                                             \
+        hipLaunchKernelGGL((spmv_rowblock_kernel<false, 3, A, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
+        return hipGetLastError();                                                                                                  \
+    }
+            HS_FOR_EACH_OWNER24_FIXED(X)
+#undef X
+            return hipErrorInvalidValue;
         }
 #define X(A)                                                                                                                       \
     if (ablate == A && records == 3) {                                                                                             \
@@ -1034,7 +1091,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
                            a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
         return hipGetLastError();                                                                                                  \
     }
-        X(2) X(3) X(4)
+        HS_FOR_EACH_OWNER24_DEPTH(X)
 #undef X
         return hipErrorInvalidValue;
     }

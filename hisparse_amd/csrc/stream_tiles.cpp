@@ -233,7 +233,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                                                ? double(out.nnz) / G / kWaveLanes * (lanes_per_row - 1.0) * 2.0 / 2400.0 : 0.0;
                 const double combine_us = cs > 1 ? 3.5 + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
                 const double cost = volume_us + latency_us + conflict_us + 8.0 * blocks_per_wg + combine_us;
-                if (std::getenv("HISPARSE_PLAN_DEBUG"))
+                if (detail::env_switch("HISPARSE_PLAN_DEBUG"))
                     std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f conflicts %.1f blocks/wg %.1f combine %.1f => %.1f us\n", cs, cap, ring, ranges,
                                  volume_us, latency_us, conflict_us, blocks_per_wg, combine_us, cost);
                 if (cost < best) { best = cost; slices = cs; max_rows = cap; }

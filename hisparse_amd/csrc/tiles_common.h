@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -30,14 +31,39 @@ namespace hisparse {
 namespace dev {
 namespace detail {
 
-// an experiment switch of the environment; set-but-empty counts as not set (HISPARSE_MAX_ROWS= used to mean "one row per block")
-inline const char* env_switch(const char* name) {
+// Tuning switches.  The configuration surface of the library is hs_set_option(ctx, key, value) (hisparse_hip.h): a context's options are
+// in force while ITS matrix is planned and built (OptionScope, taken by hs_load_matrix* under a process-wide lock: the builders run on
+// worker threads, so the scope cannot be thread-local).  The environment variable HISPARSE_<KEY> remains as the fallback for tools and
+// tests; set-but-empty counts as not set (HISPARSE_MAX_ROWS= used to mean "one row per block").
+using OptionMap = std::map<std::string, std::string>;
+inline const OptionMap*& active_options() {
+    static const OptionMap* active = nullptr;
+    return active;
+}
+inline std::mutex& options_mutex() {
+    static std::mutex m;
+    return m;
+}
+struct OptionScope {
+    std::unique_lock<std::mutex> lock;
+    explicit OptionScope(const OptionMap* options) : lock(options_mutex()) { active_options() = options; }
+    ~OptionScope() { active_options() = nullptr; }
+    OptionScope(const OptionScope&) = delete;
+    OptionScope& operator=(const OptionScope&) = delete;
+};
+// name: the environment spelling, "HISPARSE_<KEY>"
+inline const char* option_lookup(const OptionMap* options, const char* name) {
+    if (options) {
+        const auto it = options->find(name);
+        if (it != options->end()) return it->second.empty() ? nullptr : it->second.c_str();
+    }
     const char* v = std::getenv(name);
     return v && *v ? v : nullptr;
 }
+inline const char* env_switch(const char* name) { return option_lookup(active_options(), name); }
 
 struct PhaseTimer {   // HISPARSE_PLAN_DEBUG=1: wall time of the load-time passes
-    const bool on = std::getenv("HISPARSE_PLAN_DEBUG") != nullptr;
+    const bool on = env_switch("HISPARSE_PLAN_DEBUG") != nullptr;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void lap(const char* what) {
         const auto now = std::chrono::steady_clock::now();

@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
     "hs_load_matrix_csr", "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
-    "hs_bind_device_vector", "hs_bind_device_result", "hs_push_result", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_debug_read_mfma_image", "hs_tiles_build", "hs_tiles_info",
+    "hs_bind_device_vector", "hs_bind_device_result", "hs_push_result", "hs_set_option", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_debug_read_mfma_image", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
 
@@ -76,6 +76,7 @@ def lib():
         l.hs_bind_device_vector.argtypes = [vp, vp]
         l.hs_bind_device_result.argtypes = [vp, vp]
         l.hs_push_result.argtypes = [vp, C.POINTER(vp), u32, u32]
+        l.hs_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
         l.hs_feedback.argtypes = [vp, u32, u32]
         l.hs_iterate.argtypes = [vp, u32, u32, u32]
         l.hs_load_matrix_csc.argtypes = [vp, vp, vp, vp, u32, u32]
@@ -217,6 +218,10 @@ class SpmvEngine:
         if n.value:
             self._check(lib().hs_debug_read_mfma_image(self._h, words.ctypes.data, words.size, C.byref(n)))
         return words[:n.value]
+
+    def set_option(self, key, value=None):
+        """hs_set_option: a tuning switch of this context (plan-time keys apply to the next load_matrix*); None clears it."""
+        self._check(lib().hs_set_option(self._h, str(key).encode(), None if value is None else str(value).encode()))
 
     # ---- zero-copy hooks ----------------------------------------------------------------------
     def set_stream(self, hip_stream):

@@ -128,6 +128,18 @@ int hs_bind_device_result(hs_context* ctx, void* y_dev);
  * on the critical path (hisparse_amd/csrc/benchmark.cpp --gpus N --peer-gather).  num_words: multiple of 4; dst: 16-byte aligned. */
 int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t num_words);
 
+/* ---- tuning options (EXTENSION) ----------------------------------------------------------------------
+ * The library's configuration surface.  key: the name of a tuning switch, case-insensitive, with or without the "HISPARSE_" prefix of its
+ * environment spelling -- plan-time keys (take effect at the NEXT hs_load_matrix / hs_load_matrix_csr of this context): stream_format
+ * (pairs|delta|owner|owner24|bitmap), col_slices, max_rows, row_runs, aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
+ * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light_threads, direct_y, plan_debug; call-time keys: spmm_fused, spmm_mfma,
+ * spmspv (atomic|binned), spmspv_crossover, iterate_graph, iterate_cooperative.  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
+ * Options set here win over the environment variable of the same name, which stays as the fallback for tools and tests.  None of them
+ * changes WHAT is computed.  The switches that do (HISPARSE_ABLATE, HISPARSE_DEPTH: profiling builds with parts of the work removed) are
+ * not options: they exist only in libhisparse_hip_prof.so, and this library refuses to run (HS_ERR_BAD_ARG from hs_run, hs_run_partition,
+ * hs_iterate, hs_time_runs) while one of them is set in the environment. */
+int hs_set_option(hs_context* ctx, const char* key, const char* value);
+
 /* ---- iterative callers (EXTENSION: no reference counterpart) --------------
  * The reference's drivers run one SpMV and read y back; an iterative caller (PageRank: sw/data_formatter.h:33-47
  * normalises the matrix for it) would feed y back into x over PCIe.  On the GPU the feedback stays in HBM:

@@ -1,0 +1,68 @@
+"""hs_set_option (hisparse_hip.h): the library's configuration surface -- per context, winning over the environment -- and the refusal of
+the profiling switches in the product library."""
+import numpy as np
+import pytest
+
+from hisparse_amd import device, host
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(impl=0):
+    m = cases.random_csr(6000, 30000, 0.004, 11, impl)
+    csr = host.CSRMatrix.from_scipy(m)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 5, impl))
+    return cp, xw
+
+
+def test_options_select_the_plan_per_context_and_beat_the_environment(monkeypatch):
+    cp, xw = _case()
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "delta")
+    results = {}
+    for fmt in ("pairs", "delta", "owner24", None):
+        with device.SpmvEngine(0) as eng:
+            if fmt:
+                eng.set_option("stream_format", fmt)           # without the prefix, lower case
+            eng.set_option("HISPARSE_COL_SLICES", "2")           # the environment spelling works too
+            eng.load_matrix(cp)
+            st = eng.stats()
+            assert device.STREAM_FORMATS[st["stream_format"]] == (fmt or "delta")       # None: the environment is the fallback
+            assert st["col_slices"] == 2
+            eng.load_vector(xw)
+            eng.run()
+            results[fmt] = eng.read_result()
+            eng.set_option("col_slices", None)                   # cleared: the next load plans by itself
+            eng.set_option("stream_format", "pairs")
+            eng.load_matrix(cp)
+            assert device.STREAM_FORMATS[eng.stats()["stream_format"]] == "pairs"
+    ys = list(results.values())
+    assert all(np.array_equal(ys[0], y) for y in ys[1:])         # no option changes WHAT is computed
+
+
+def test_unknown_and_profiling_keys_are_refused():
+    with device.SpmvEngine(0) as eng:
+        for key in ("no_such_switch", "ablate", "HISPARSE_DEPTH"):
+            with pytest.raises(device.DeviceError) as e:
+                eng.set_option(key, "1")
+            assert e.value.code == -1
+
+
+def test_product_library_does_not_run_with_a_profiling_switch_in_the_environment(monkeypatch):
+    cp, xw = _case()
+    with device.SpmvEngine(0) as eng:
+        eng.load_matrix(cp)
+        eng.load_vector(xw)
+        eng.run()
+        want = eng.read_result()
+        monkeypatch.setenv("HISPARSE_ABLATE", "3")
+        with pytest.raises(device.DeviceError) as e:
+            eng.run()
+        assert e.value.code == -1 and "libhisparse_hip_prof.so" in str(e.value)
+        with pytest.raises(device.DeviceError):
+            eng.time_runs(0, 2)
+        monkeypatch.delenv("HISPARSE_ABLATE")
+        eng.run()
+        assert np.array_equal(eng.read_result(), want)

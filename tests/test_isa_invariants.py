@@ -178,3 +178,45 @@ def test_spmm_kernel_uses_the_matrix_engine(shipped):
     body = code[names[0]]
     assert len([i for i in body if i.startswith("v_mfma_f32_16x16x4_f32")]) == 16
     assert meta[names[0]].get("private_segment_fixed_size", 0) == 0
+
+
+def test_product_library_carries_no_profiling_instantiation(shipped):
+    """the ablation / timeline / prefetch-depth instantiations -- most give wrong results by design -- are
+    compiled only into libhisparse_hip_prof.so (-DHISPARSE_PROFILING).  Every spmv_rowblock_kernel / spmv_bitmap_kernel in the product
+    library has ablate == 0 and the one depth its format ships with."""
+    meta, _ = shipped
+    rowblock = [ROWBLOCK.search(n) for n in meta if ROWBLOCK.search(n)]
+    assert rowblock
+    for m in rowblock:
+        is_float, ring, ablate, depth, owner = (int(g) for g in m.groups())
+        assert ablate == 0, f"profiling instantiation in the product library: {m.group(0)}"
+        assert depth == (3 if ring == 3 else 8), f"experimental prefetch depth in the product library: {m.group(0)}"
+    bitmap = [re.search(r"spmv_bitmap_kernelILb([01])ELi(\d+)E", n) for n in meta if "spmv_bitmap_kernel" in n]
+    assert bitmap and all(int(m.group(2)) == 0 for m in bitmap)
+    light = [re.search(r"spmv_light_kernelILb([01])ELi(\d+)E", n) for n in meta if "spmv_light_kernel" in n]
+    assert all(m is None or int(m.group(2)) == 0 for m in light)
+
+
+def test_product_library_refuses_profiling_switches():
+    """...and an inherited HISPARSE_ABLATE cannot change what a production SpMV computes: the launch entry reports it (no GPU needed:
+    the check sits in front of any HIP call)."""
+    import ctypes as C
+    lib = C.CDLL(LIB)
+    probe = "_ZN8hisparse3dev22profiling_switch_errorEv"
+    assert hasattr(lib, probe)
+    fn = getattr(lib, probe)
+    fn.restype = C.c_char_p
+    old = {k: os.environ.pop(k, None) for k in ("HISPARSE_ABLATE", "HISPARSE_DEPTH")}
+    try:
+        assert fn() is None
+        os.environ["HISPARSE_ABLATE"] = "3"
+        assert b"libhisparse_hip_prof.so" in fn()
+        os.environ["HISPARSE_ABLATE"] = "0"
+        assert fn() is None
+        os.environ["HISPARSE_DEPTH"] = "16"
+        assert b"HISPARSE_DEPTH" in fn()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v

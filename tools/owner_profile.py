@@ -7,6 +7,9 @@ path = os.path.join(tempfile.gettempdir(), "owner_profile.bin")
 os.environ["HISPARSE_ABLATE"] = "256"
 os.environ["HISPARSE_TIMELINE_OUT"] = path
 os.environ.setdefault("HISPARSE_STREAM_FORMAT", "owner")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _prof
+_prof.use_profiling_library()      # the timeline / ablation instantiations are not in the product library
 from hisparse_amd import host, device, datasets
 
 name = sys.argv[1] if len(sys.argv) > 1 else "ogbn_products"

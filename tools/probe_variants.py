@@ -5,13 +5,17 @@ whole-step time of every variant and checks every variant's y against the first 
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from hisparse_amd import host, device, datasets
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _prof
 
 name = sys.argv[1]
 variants = []
 for spec in sys.argv[2:]:
     tag, _, envs = spec.partition(":")
     variants.append((tag, dict(kv.split("=", 1) for kv in envs.split(",") if kv)))
+if any(_prof.needs_profiling_library(env) for _, env in variants) or _prof.needs_profiling_library(os.environ):
+    _prof.use_profiling_library()      # HISPARSE_ABLATE / HISPARSE_DEPTH variants live in libhisparse_hip_prof.so only
+from hisparse_amd import host, device, datasets
 cfg, csr = datasets.load(name)
 impl = host.impl_id(os.environ.get("IMPL", cfg.impl))
 cp = host.format_matrix(csr, impl, skip_empty_rows=True)

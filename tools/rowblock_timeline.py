@@ -6,6 +6,9 @@ import os, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 path = os.path.join(tempfile.gettempdir(), "rowblock_timeline.bin")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _prof
+_prof.use_profiling_library()      # the timeline / ablation instantiations are not in the product library
 from hisparse_amd import host, device, datasets
 
 name = sys.argv[1]
