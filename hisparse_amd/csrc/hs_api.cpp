@@ -52,6 +52,7 @@ struct hs_context {
     uint32_t col_slices = 1;
     uint32_t ring_buffers = 4;
     uint32_t format = 0;           // StreamFormat of d_image
+    bool light = false;            // the LIGHT plan: d_image is a PAIRS image run by spmv_light_kernel (stream_tiles.h)
     uint32_t* d_partial = nullptr;  // col_slices > 1: per-slice partial results, col_slices x num_rows words
     uint32_t max_block_rows = 0;
     uint32_t* d_x_interleaved = nullptr;   // fused SpMM over a BITMAP image: 4 columns of X as [column][vector] words (allocated on first use)
@@ -112,7 +113,7 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 // hs_set_option's keys (the HISPARSE_<KEY> environment switches the library understands); plan-time ones take effect at the next load
 const char* const kOptionKeys[] = {
     "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG", "FORMAT_THREADS",
-    "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT_THREADS", "DIRECT_Y",
+    "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT",
     "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "ITERATE_COOPERATIVE",
 };
 
@@ -180,6 +181,7 @@ hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     a.num_workgroups = c->num_workgroups;
     a.lds_bytes = c->lds_bytes;
     a.bitmap_x_groups = c->bitmap_x_groups;
+    a.light = c->light;
     return a;
 }
 
@@ -378,8 +380,9 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     if (debug) std::fprintf(stderr, "load: image built after %.1f ms\n", since());
     // (BITMAP: + the block's stretch of x behind the accumulators when the builder asks for it, spmv_bitmap.hip kXLds)
-    const uint32_t lds_bytes = hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers, tiles.format) +
-                               tiles.bitmap_x_groups * hisparse::dev::kBitmapGroupCols * 4u;
+    const uint32_t lds_bytes = tiles.light ? hisparse::dev::spmv_light_lds_bytes(tiles.max_block_rows)
+                                           : hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers, tiles.format) +
+                                                 tiles.bitmap_x_groups * hisparse::dev::kBitmapGroupCols * 4u;
     if (lds_bytes > hisparse::dev::kMaxLdsBytes) {
         drop_device_images(tiles);
         return fail(ctx, HS_ERR_UNSUPPORTED, "row block does not fit the LDS");
@@ -425,6 +428,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     ctx->max_block_rows = tiles.max_block_rows;
     ctx->ring_buffers = tiles.ring_buffers;
     ctx->format = tiles.format;
+    ctx->light = tiles.light;
     ctx->matrix_loaded = true;
 
     hs_stats& s = ctx->stats;
@@ -443,6 +447,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     s.num_compute_units = uint32_t(ctx->compute_units);
     s.load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     s.retiled_on_gpu = tiles.d_image != nullptr;
+    s.light_kernel = tiles.light ? 1u : 0u;
     return HS_OK;
 }
 }  // namespace

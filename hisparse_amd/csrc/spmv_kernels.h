@@ -25,6 +25,7 @@ struct SpmvLaunch {
     uint32_t num_workgroups;
     uint32_t lds_bytes;
     uint32_t bitmap_x_groups = 0; // BITMAP: lds_bytes ends with room for this many 64-column groups of x (0: x is read through L2)
+    bool light = false;           // the LIGHT plan (StreamTiles::light): a PAIRS image consumed by spmv_light_kernel, 256-thread workgroups, lds_bytes = spmv_light_lds_bytes
 };
 
 // HISPARSE_ABLATE / HISPARSE_DEPTH (environment): profiling switches of libhisparse_hip_prof.so (-DHISPARSE_PROFILING), read per launch.
@@ -37,6 +38,7 @@ const char* profiling_switch_error();      // nullptr, or why the product librar
 
 // Dynamic LDS a launch needs for blocks of at most `max_block_rows` rows and a ring of `ring_buffers` x buffers.
 uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t format = kFormatPairs);
+uint32_t spmv_light_lds_bytes(uint32_t max_block_rows);       // the LIGHT kernel: accumulators only
 // One-time per device: allow the kernels to use up to `lds_bytes` of dynamic LDS.
 hipError_t configure_spmv_kernels(uint32_t lds_bytes);
 // The SpMV kernel: row-owner workgroups, x sub-tiles double-buffered in LDS, no global atomics.

@@ -43,6 +43,8 @@ namespace dev {
 namespace {
 
 constexpr int kThreads = kWaveLanes * kWavesPerWorkgroup;       // 1024
+constexpr int kLightThreads = 256;                               // the LIGHT kernel's workgroup (up to four per CU)
+constexpr int kLightBatch = 4;                                   // chunks in flight per wavefront
 constexpr uint32_t kBufBytes = kSubTileCols * 4u;               // one x buffer of the LDS ring (32 KiB)
 
 // Copy one x sub-tile into an LDS buffer with kStride cooperating threads (t = 0 .. kStride-1).
@@ -919,6 +921,113 @@ __global__ __launch_bounds__(256) void push_result_kernel(const uint32_t* __rest
     for (uint32_t k = 0; k < n_dst; ++k) *reinterpret_cast<uint4*>(t.dst[k] + i) = v;
 }
 
+
+// ---- the LIGHT kernel (round 4): small matrices, one launch ------------------------------------------------------------------------------
+// A matrix of a few million non-zeros (a pruned-NN layer below BITMAP's density, one rank's slab of a graph split 8 ways, the 1k x 1k
+// plumbing case) is launch-bound in the row-block kernel: its 1024-thread workgroups ramp up over 2-4 us, x is staged through LDS although
+// the whole vector sits in L2, and a column-sliced plan pays a second launch for the combine pass -- 10-16 us for 1-4 us of bytes.  This
+// kernel runs the SAME PAIRS image (stream_tiles.h: chunks of 64 x { value word, local_row << 16 | local_col }, stored block by block in
+// dealing order, i.e. the chunks of a block are contiguous and unit by unit) with
+//   * 256-thread workgroups, up to four per CU, every wavefront a consumer: wavefront w takes chunks w, w + 4, ... of the block, four in flight;
+//   * no x ring, no loader wavefronts, no unit barriers: x[col0(unit) + local_col] is a plain gather (the vector is L2-resident at this
+//     size); a unit is only the place where col0 changes, found per chunk from the block's (<= kLightMaxUnits) unit ends held in registers;
+//   * one column slice always, so y is written by the kernel itself: ONE launch per SpMV;
+//   * 8-byte LDS accumulators as in the row-block kernel (exact 64-bit sums / double sums): the same arithmetic, bit for bit in fixed point.
+// Blocks flagged kBlockDenseRows hold their elements in sorted order (chunk i / 64, lane i % 64): a chunk touches one or two rows, so the
+// wavefront adds it up with a segmented reduction and only the first lane of every row run touches LDS.
+// The plan (stream_tiles.cpp: "light") cuts up to 4 x CUs row ranges of equal non-zero count.  Reference: the cluster / PE arithmetic as
+// for spmv_rowblock_kernel (pe.h:62-81, pe-pob.h:63-65); drain order spmv_result_drain.cpp:104-113.
+template <bool kFloat, int kAblate>
+__global__ __launch_bounds__(kLightThreads) void spmv_light_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
+                                                                    const Unit* __restrict__ units, const uint32_t* __restrict__ x,
+                                                                    uint32_t* __restrict__ out, int32_t row_part_filter,
+                                                                    const uint32_t* __restrict__ part_heads) {
+    using R = Rows<kFloat>;
+    using acc_t = typename R::acc_t;
+    using sum_t = typename R::sum_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    acc_t* ys = reinterpret_cast<acc_t*>(lds);                    // [nrows + 1]
+    constexpr uint32_t kWaves = kLightThreads / kWaveLanes;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWaveLanes - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWaveLanes);
+    uint32_t wg = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    uint32_t bi = wg;
+    if (row_part_filter >= 0) {
+        bi = ((const __attribute__((address_space(4))) uint32_t*)part_heads)[static_cast<uint32_t>(row_part_filter) * gridDim.x + wg];
+        if (bi == kNoBlock) return;
+    }
+    bool first_block = true;
+    for (uint32_t next = 0;; bi = next) {
+        const BlockTable blk = (BlockTable)(blocks + bi);
+        next = (row_part_filter >= 0 && (blk->flags & kBlockLastOfPartition)) ? 0u : blk->next;
+        const uint32_t nrows = blk->nrows, out0 = blk->out_offset, ub = blk->unit_begin;
+        const uint32_t U = blk->unit_end - ub;
+        const bool dense = (blk->flags & kBlockDenseRows) != 0;
+        const uint8_t* chunks = image + blk->wave_offset[0];      // chunk g of the block at g * 512
+        if (!first_block) __syncthreads();                        // the previous block's store has read the accumulators
+        first_block = false;
+        // lane u < U of every wavefront: where unit u ends among the block's chunks (its 14 per-wavefront stream positions add up to that:
+        // the image was dealt for the row-block kernel's consumer wavefronts) and its first column
+        uint32_t my_end = 0, my_col0 = 0;
+        if (lane < U) {
+            const uint4* u4 = reinterpret_cast<const uint4*>(units + ub + lane);     // 64 bytes: col0, ncols, end_step[14]
+            const uint4 a = u4[0], b = u4[1], c = u4[2], d = u4[3];
+            my_col0 = a.x;
+            my_end = a.z + a.w + b.x + b.y + b.z + b.w + c.x + c.y + c.z + c.w + d.x + d.y + d.z + d.w;
+        }
+        for (uint32_t i = tid; i <= nrows; i += kLightThreads) ys[i] = 0;
+        const uint32_t total = U ? __builtin_amdgcn_readfirstlane(__shfl(my_end, U - 1, kWaveLanes)) : 0u;      // chunks of the block
+        __syncthreads();
+        const uint32_t lane_off = lane * 8u;
+        for (uint32_t g0 = wave; g0 < total; g0 += kWaves * kLightBatch) {
+            uint2 e[kLightBatch];
+            uint32_t xv[kLightBatch];
+#pragma unroll
+            for (int j = 0; j < kLightBatch; ++j) {
+                const uint32_t g = min(g0 + j * kWaves, total - 1);                 // past the end: the last chunk again (its products are dropped)
+                e[j] = *reinterpret_cast<const uint2*>(chunks + size_t(g) * kChunkBytes + lane_off);
+            }
+#pragma unroll
+            for (int j = 0; j < kLightBatch; ++j) {
+                const uint32_t g = min(g0 + j * kWaves, total - 1);
+                const uint64_t inside = __ballot(lane < U && g < my_end);           // units this chunk lies in front of the end of: the first one holds it
+                const uint32_t u = static_cast<uint32_t>(__builtin_ctzll(inside));
+                const uint32_t col0 = __shfl(my_col0, u, kWaveLanes);
+                xv[j] = (kAblate & 2) ? e[j].y : x[col0 + (e[j].y & 0xffffu)];
+            }
+#pragma unroll
+            for (int j = 0; j < kLightBatch; ++j) {
+                if (g0 + j * kWaves >= total) break;                                 // wave-uniform
+                const uint32_t row = e[j].y >> 16;
+                const typename R::prod_t prod = R::product(e[j].x, xv[j]);
+                if (kAblate & 1) { asm volatile("" ::"v"(prod), "v"(row)); continue; }
+                if (dense) {
+                    // sorted elements: rows never decrease from lane to lane.  Suffix sums inside every run of equal rows; the run's first
+                    // lane adds the run's sum (one LDS atomic per row and chunk instead of up to 64 colliding ones)
+                    sum_t sum = R::widen(prod);
+#pragma unroll
+                    for (uint32_t dlt = 1; dlt < kWaveLanes; dlt <<= 1) {
+                        const sum_t s2 = __shfl_down(sum, dlt, kWaveLanes);
+                        const uint32_t r2 = __shfl_down(row, dlt, kWaveLanes);
+                        if (lane + dlt < kWaveLanes && r2 == row) sum += s2;
+                    }
+                    const uint32_t below = __shfl_up(row, 1, kWaveLanes);
+                    if (lane == 0 || below != row) R::add_sum(ys, row, sum);
+                } else {
+                    R::add(ys, row, prod);
+                }
+            }
+        }
+        // no-return LDS atomics can outlive lgkmcnt(0) (spmv_rowblock_kernel): a returning one on the spare accumulator, awaited, cannot
+        const acc_t flushed = atomicAdd(ys + nrows, static_cast<acc_t>(0));
+        asm volatile("" ::"v"(flushed));
+        __syncthreads();
+        if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kLightThreads) out[out0 + i] = R::finish(ys[i]);
+        if (!next) break;
+    }
+}
+
 template <bool kFloat, int kRing, int kAblate, int kDepth, bool kOwner = false>
 hipError_t configure_one(uint32_t lds_bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_rowblock_kernel<kFloat, kRing, kAblate, kDepth, kOwner>),
@@ -966,6 +1075,7 @@ const char* profiling_switch_error() {
 
 // LDS plan: row accumulators first (64-bit integer sums / double sums + 1 spare; OWNER: floats + one spare per consumer
 // wavefront), then the ring of x buffers.
+uint32_t spmv_light_lds_bytes(uint32_t max_block_rows) { return ((max_block_rows + 1) * kAccumulatorBytes + 15u) & ~15u; }
 uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t format) {
     const uint32_t acc = (format == kFormatOwner || format == kFormatOwner24) ? (max_block_rows + kConsumerWaves) * kOwnerAccumulatorBytes : (max_block_rows + 1) * kAccumulatorBytes;
     return ((acc + 15u) & ~15u) + ring_buffers * kBufBytes;
@@ -978,12 +1088,14 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t
 #ifdef HISPARSE_PROFILING
 // OWNER24 profiling builds (three records in flight): 1 = no LDS work, 4 = no x refill, 8 = no unit barriers, and combinations
 #define HS_FOR_EACH_OWNER24_ABLATION(X) X(0) X(1) X(4) X(5) X(8) X(12) X(13) X(512)
+#define HS_FOR_EACH_LIGHT_VARIANT(X) X(0) X(1) X(2) X(3) X(32) X(35)
 #define HS_FOR_EACH_OWNER24_DEPTH(X) X(2) X(3) X(4)
 #define HS_FOR_EACH_OWNER24_FIXED(X) X(0) X(512)
 // OWNER variants (float only): ablate values as for the other formats
 #define HS_FOR_EACH_OWNER_VARIANT(X) X(0) X(1) X(2) X(3) X(4) X(7) X(8) X(11) X(12) X(15) X(127) X(256)
 #else
 #define HS_FOR_EACH_OWNER24_ABLATION(X) X(0)
+#define HS_FOR_EACH_LIGHT_VARIANT(X) X(0)
 #define HS_FOR_EACH_OWNER24_DEPTH(X) X(3)
 #define HS_FOR_EACH_OWNER24_FIXED(X) X(0)
 #define HS_FOR_EACH_OWNER_VARIANT(X) X(0)
@@ -1028,6 +1140,21 @@ hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
 hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.num_workgroups == 0) return hipSuccess;
     if (a.format == kFormatBitmap) return launch_spmv_bitmap(is_float, a, stream);
+    if (a.light) {
+        if (a.format != kFormatPairs) return hipErrorInvalidValue;
+        int ablate = 0, depth_unused = 8;
+        if (!profiling_switches(ablate, depth_unused)) return hipErrorInvalidValue;
+        const dim3 grid(a.num_workgroups), block(kLightThreads);
+#define X(A)                                                                                                                                  \
+    if (ablate == A) {                                                                                                                        \
+        if (is_float) hipLaunchKernelGGL((spmv_light_kernel<true, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, a.row_part_filter, a.part_heads); \
+        else hipLaunchKernelGGL((spmv_light_kernel<false, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, a.row_part_filter, a.part_heads);       \
+        return hipGetLastError();                                                                                                             \
+    }
+        HS_FOR_EACH_LIGHT_VARIANT(X)
+#undef X
+        return hipErrorInvalidValue;
+    }
     const int ring = a.format == kFormatDelta ? 1 : a.format == kFormatPairs24 ? 2 : 0;
     const dim3 grid(a.num_workgroups), block(kThreads);
     const uint32_t x_base = a.lds_bytes - a.ring_buffers * kBufBytes;

@@ -132,6 +132,14 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             if (build_bitmap_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error, csr, on_host ? nullptr : gpu.get(), image_slack)) return true;
             if (error.rfind("bitmap:", 0) != 0) return false;     // a real decode error
             error.clear();                                       // not representable as a bitmap (duplicate entries): element streams
+            // The bitmap builder may have filled `out` before it found the duplicate (the device builder sees it only in its mask
+            // pass, after blocks / units / max_block_rows / col_slices were laid out): the element-format path below push_backs onto
+            // these tables and derives its sort-key widths from their sizes, so give it `out` as pass 0 left it.
+            {
+                const uint64_t nnz_keep = out.nnz;      // (no device image to give back: the tiler keeps its buffers until a build succeeds)
+                out = StreamTiles();
+                out.nnz = nnz_keep;
+            }
         }
     }
     // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse; hyper-sparse float matrices: OWNER --
@@ -152,6 +160,18 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner, owner24 or bitmap"; return false; }
         }
     }
+    // ---- LIGHT plan (stream_tiles.h): a small matrix is launch-bound in the row-block kernel -- one slice, up to 4 x CUs small blocks of a
+    //      PAIRS image, linear dealing, spmv_light_kernel.  Automatic when no format is forced; HISPARSE_LIGHT=0|1 forces (1: with any
+    //      matrix of at most kLightMaxUnits sub-tiles whose format is not forced to something other than pairs).
+    bool light = false;
+    {
+        const char* forced = env_switch("HISPARSE_STREAM_FORMAT");
+        const bool fits = out.nnz > 0 && uint64_t(CP) * S <= kLightMaxUnits && num_rows < (1u << 31);
+        light = fits && !forced && out.nnz <= kLightMaxNnz;
+        if (const char* force = env_switch("HISPARSE_LIGHT")) light = std::atoi(force) != 0 && fits && (!forced || std::string(forced) == "pairs");
+        if (light) out.format = kFormatPairs;
+        out.light = light;
+    }
     bool delta = out.format == kFormatDelta;
     const bool owner = out.format == kFormatOwner || out.format == kFormatOwner24;
     bool owner24 = out.format == kFormatOwner24;      // may still fall back to the 8-byte form (below)
@@ -165,9 +185,11 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     // thousand non-zeros (hyper-sparse matrices).  Cost model in microseconds, constants measured on MI355X:
     //   x volume through one CU at ~120 GB/s; a refill takes ~0.8 us to land, ring-1 of them overlap, a unit's stream
     //   time (~25 GB/s per CU) hides the rest; ~8 us of prologue + epilogue per block; the combine kernel.
-    const uint32_t G = std::max<uint32_t>(1, max_workgroups);
-    uint32_t slices = 1, max_rows = max_block_rows(false);
-    {
+    const uint32_t G = std::max<uint32_t>(1, max_workgroups) * (light ? kLightWorkgroupsPerCu : 1u);
+    uint32_t slices = 1, max_rows = light ? kLightMaxBlockRows : max_block_rows(false);
+    if (light) {
+        if (const char* force_rows = env_switch("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force_rows)));   // tests: chains of blocks
+    } else {
         const char* force_slices = env_switch("HISPARSE_COL_SLICES");
         const char* force_rows = env_switch("HISPARSE_MAX_ROWS");   // experiments
         struct Shape { uint32_t cap, ring; };
@@ -254,7 +276,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     // every workgroup ends up with the same number of blocks
     const uint64_t per_round = std::max<uint32_t>(1, G / slices);
     const uint64_t rounds = std::max<uint64_t>(1, ((uint64_t(num_rows) + max_rows - 1) / max_rows + per_round - 1) / per_round);
-    const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(per_round * rounds, out.nnz / 4096));
+    const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(per_round * rounds, out.nnz / (light ? kLightMinBlockNnz : 4096u)));
     build_row_ranges_at_most(L, row_nnz, out.nnz, want_ranges, max_rows, ranges, range_nnz);
     const uint32_t NR = uint32_t(ranges.size());
     std::vector<uint32_t> block_of_row(num_rows);   // row -> row range
@@ -336,6 +358,8 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                 blk.flags = (force ? std::atoi(force) != 0 : gap < kDenseMeanGap) ? kBlockDenseRows : 0u;
             } else if (owner) {
                 blk.flags = 0;
+            } else if (light) {
+                blk.flags = kBlockDenseRows;      // linear dealing for every block: the kernel's segmented wavefront sum takes any row pattern
             } else {
                 blk.flags = (ranges[b].nrows <= kDenseBlockRows && range_nnz[b] >= 64ull * ranges[b].nrows) ? kBlockDenseRows : 0u;
             }
@@ -514,7 +538,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         // memory requests a CU keeps in flight, not by the bytes.
         const char* bits = env_switch("HISPARSE_AUX_BITS");
         const bool allowed = bits && std::atoi(bits) == 24;
-        if (!owner && !delta) aux24 = allowed && out.max_block_rows <= kAux24MaxRows;
+        if (!owner && !delta && !light) aux24 = allowed && out.max_block_rows <= kAux24MaxRows;
         if (aux24) out.format = kFormatPairs24;
     }
     const uint32_t chunk_bytes = aux24 ? kChunkBytes24 : kChunkBytes, wave_stride = chunk_bytes * kConsumerWaves;

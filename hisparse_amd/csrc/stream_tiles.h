@@ -161,6 +161,15 @@ constexpr uint32_t kBitmapMaxXLdsGroups = 576;                // a block's stret
 constexpr uint32_t kBitmapSkew[4] = {170, 140, 65, 25};       // share of a wavefront by its place on its SIMD (wavefronts 0-3, 4-7, 8-11, 12-15): bitmap_tiles.cpp
 constexpr uint32_t kBitmapMaskBatch = 32;                     // masks fetched per vector load (one dword per lane)
 constexpr uint32_t kBitmapRunSlots = 5;                       // Unit-sized (64-byte) slots per wavefront run: the WaveSeg + a copy of its first 32 masks
+// LIGHT plan (round 4): matrices of at most kLightMaxNnz non-zeros over at most kLightMaxUnits x sub-tiles are launch-bound in the row-block
+// kernel (1024-thread workgroups, x staged through LDS, a combine launch for sliced plans).  They get a PAIRS image cut into up to
+// kLightWorkgroupsPerCu x CUs row ranges of one column slice, every block dealt linearly (kBlockDenseRows: chunk i / 64, lane i % 64), and
+// the kernel spmv_light_kernel (spmv_kernels.hip): 256-thread workgroups, x gathered straight from L2, y written by the one launch.
+constexpr uint64_t kLightMaxNnz = 5u << 20;                   // ~ 42 MB of PAIRS stream
+constexpr uint32_t kLightMaxUnits = 16;                       // sub-tiles of a block (one slice): lanes 0 .. 15 hold the unit ends
+constexpr uint32_t kLightWorkgroupsPerCu = 4;
+constexpr uint32_t kLightMaxBlockRows = 4095;                 // 32 KiB of accumulators per workgroup
+constexpr uint32_t kLightMinBlockNnz = 1024;                  // no block smaller than 16 chunks (unless the matrix is)
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit
 constexpr uint32_t kBlockLastOfPartition = 2u;                // Block::flags bit: the workgroup's last block of this row partition
@@ -251,6 +260,7 @@ struct StreamTiles {
                                          // (hs_run_partition starts there and stops at kBlockLastOfPartition)
     uint32_t num_workgroups = 0;
     uint32_t max_block_rows = 0;
+    bool light = false;                  // the LIGHT plan (below): PAIRS image, one slice, up to kLightWorkgroupsPerCu x CUs small blocks, spmv_light_kernel
     uint32_t col_slices = 1;             // > 1: blocks write per-slice partial results, a combine pass adds them
     uint32_t ring_buffers = kMaxXBuffers;
     StreamFormat format = kFormatPairs;

@@ -78,7 +78,7 @@ typedef struct {
     uint32_t stream_format;     /* HS_STREAM_PAIRS (8 B per element), HS_STREAM_DELTA (6 B per slot) or HS_STREAM_BITMAP (4 B + 1 bit per column) HS_STREAM_OWNER (8 B per element, float accumulators) or the 7-byte forms of PAIRS / OWNER, chosen per matrix */
     double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
     uint32_t retiled_on_gpu;    /* 1: the per-non-zero passes of the re-tiling ran on the device (gpu_tiles.h); 0: on the host */
-    uint32_t reserved;
+    uint32_t light_kernel;      /* 1: the LIGHT plan -- a small matrix run by the 256-thread single-launch kernel (spmv_light_kernel) over a PAIRS image */
 } hs_stats;
 
 const char* hs_strerror(int code);
@@ -132,7 +132,7 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
  * The library's configuration surface.  key: the name of a tuning switch, case-insensitive, with or without the "HISPARSE_" prefix of its
  * environment spelling -- plan-time keys (take effect at the NEXT hs_load_matrix / hs_load_matrix_csr of this context): stream_format
  * (pairs|delta|owner|owner24|bitmap), col_slices, max_rows, row_runs, aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
- * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light_threads, direct_y, plan_debug; call-time keys: spmm_fused, spmm_mfma,
+ * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), plan_debug; call-time keys: spmm_fused, spmm_mfma,
  * spmspv (atomic|binned), spmspv_crossover, iterate_graph, iterate_cooperative.  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
  * Options set here win over the environment variable of the same name, which stays as the fallback for tools and tests.  None of them
  * changes WHAT is computed.  The switches that do (HISPARSE_ABLATE, HISPARSE_DEPTH: profiling builds with parts of the work removed) are

@@ -18,14 +18,17 @@ pytestmark = pytest.mark.gpu
 IMPLS = [0, 1, 2]
 
 
-@pytest.fixture(autouse=True, params=["pairs", "delta", "delta-lane-sums", "delta-no-lane-sums", "bitmap", "owner", "pairs24", "owner24"])
+@pytest.fixture(autouse=True, params=["pairs", "delta", "delta-lane-sums", "delta-no-lane-sums", "bitmap", "owner", "pairs24", "owner24", "light"])
 def stream_format(request, monkeypatch):
     # every parity test runs once per device stream format (hisparse_amd/csrc/stream_tiles.h); DELTA additionally with the
     # per-lane register sums of long-row blocks forced on and off (by default the block's density decides); BITMAP (normally
     # chosen for dense rows only) forced onto every matrix small enough for a mask per 64 columns of every row
     # "pairs24": the opt-in 7-byte form of PAIRS (HISPARSE_AUX_BITS=24), taken where the row counts allow; "owner24": OWNER in records of
     # four steps with 24-bit position words (the default for hyper-sparse float matrices)
-    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "pairs" if request.param == "pairs24" else request.param.split("-")[0])
+    # "light" (round 4): the small-matrix plan -- the PAIRS image cut into up to 4 x CUs blocks and run by spmv_light_kernel (one launch,
+    # 256-thread workgroups, x gathered from L2); taken by every case of at most 16 x sub-tiles, plain PAIRS otherwise
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "pairs" if request.param in ("pairs24", "light") else request.param.split("-")[0])
+    monkeypatch.setenv("HISPARSE_LIGHT", "1" if request.param == "light" else "0")
     if request.param == "pairs24":
         monkeypatch.setenv("HISPARSE_AUX_BITS", "24")
     if request.param.endswith("-lane-sums"):
@@ -50,6 +53,8 @@ def _run_case(impl, m, vb, ob, skip, seed):
     stats = eng.stats()
     eng.close()
     assert stats["nnz"] == m.nnz
+    sub_tiles = cp.num_col_partitions * max(1, -(-(8 * cp.vb_bank) // 8192))      # column partitions x sub-tiles of 8192 columns per partition
+    assert stats["light_kernel"] == (1 if os.environ.get("HISPARSE_LIGHT") == "1" and sub_tiles <= 16 and m.nnz > 0 else 0)
     forced = os.environ["HISPARSE_STREAM_FORMAT"]
     if forced == "owner" and impl == 0:
         forced = "pairs"                 # the 8-byte OWNER form is float only (fixed point: OWNER24 with saturating 32-bit accumulators)

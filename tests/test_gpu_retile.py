@@ -159,6 +159,35 @@ def test_bitmap_duplicate_column_falls_back(monkeypatch):
     assert device.STREAM_FORMATS[st["stream_format"]] != "bitmap"
 
 
+@pytest.mark.parametrize("impl", [0, 1])
+def test_bitmap_duplicate_in_a_many_block_matrix_leaves_no_stale_tables(monkeypatch, impl):
+    # the device BITMAP builder sees a duplicate only in its mask pass, after blocks / units / max_block_rows / col_slices
+    # were laid out; the element-format path that takes over must start from an empty StreamTiles (it push_backs onto the tables and sizes
+    # its sort keys by them).  A dense matrix of several thousand rows = hundreds of BITMAP blocks and runs, duplicates in many rows;
+    # image and tables must equal the host builder's, and y the oracle's.
+    from oracle import oracle as orc
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT", raising=False)
+    monkeypatch.delenv("HISPARSE_RETILE", raising=False)
+    m = cases.random_csr(3000, 4096, 0.2, 21, impl)
+    ip, ix, dv = m.indptr.astype(np.uint32), m.indices.astype(np.uint32).copy(), m.data.copy()
+    for r in range(3, 3000, 97):
+        if ip[r + 1] - ip[r] >= 2:
+            ix[ip[r] + 1] = ix[ip[r]]
+    csr = host.CSRMatrix.from_arrays(3000, 4096, ip, ix, dv)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    st = _compare(cp, impl, expect_gpu=False)
+    assert device.STREAM_FORMATS[st["stream_format"]] != "bitmap"
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 9, impl))
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix(cp)
+        eng.load_vector(xw)
+        eng.run()
+        got = eng.read_result()
+    want = orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions,
+                    cp.ob_bank, cp.vb_bank)
+    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+
+
 def test_host_opt_out(monkeypatch):
     monkeypatch.setenv("HISPARSE_RETILE", "host")
     m = cases.random_csr(3000, 3000, 0.01, 4, 0)
