@@ -44,7 +44,7 @@ namespace {
 
 constexpr int kThreads = kWaveLanes * kWavesPerWorkgroup;       // 1024
 constexpr int kLightThreads = 256;                               // the LIGHT kernel's workgroup (up to four per CU)
-constexpr int kLightBatch = 4;                                   // chunks in flight per wavefront
+constexpr int kLightBatch = 8;                                   // chunks in flight per wavefront
 constexpr uint32_t kBufBytes = kSubTileCols * 4u;               // one x buffer of the LDS ring (32 KiB)
 
 // Copy one x sub-tile into an LDS buffer with kStride cooperating threads (t = 0 .. kStride-1).
@@ -928,17 +928,19 @@ __global__ __launch_bounds__(256) void push_result_kernel(const uint32_t* __rest
 // the whole vector sits in L2, and a column-sliced plan pays a second launch for the combine pass -- 10-16 us for 1-4 us of bytes.  This
 // kernel runs the SAME PAIRS image (stream_tiles.h: chunks of 64 x { value word, local_row << 16 | local_col }, stored block by block in
 // dealing order, i.e. the chunks of a block are contiguous and unit by unit) with
-//   * 256-thread workgroups, up to four per CU, every wavefront a consumer: wavefront w takes chunks w, w + 4, ... of the block, four in flight;
+//   * 256-thread workgroups, up to six per CU, every wavefront a consumer of a CONSECUTIVE quarter of the block's chunks, eight in flight;
+//     a lane therefore walks consecutive sorted elements and sums in a register while its row stays the same;
 //   * no x ring, no loader wavefronts, no unit barriers: x[col0(unit) + local_col] is a plain gather (the vector is L2-resident at this
 //     size); a unit is only the place where col0 changes, found per chunk from the block's (<= kLightMaxUnits) unit ends held in registers;
 //   * one column slice always, so y is written by the kernel itself: ONE launch per SpMV;
 //   * 8-byte LDS accumulators as in the row-block kernel (exact 64-bit sums / double sums): the same arithmetic, bit for bit in fixed point.
-// Blocks flagged kBlockDenseRows hold their elements in sorted order (chunk i / 64, lane i % 64): a chunk touches one or two rows, so the
-// wavefront adds it up with a segmented reduction and only the first lane of every row run touches LDS.
+// (Two other accumulation schemes were measured on one rank's slab of mouse_gene split 8 ways and lost: linear dealing with one LDS atomic
+// per element -- up to 64 lanes on one accumulator -- and linear dealing with a DPP segmented scan per chunk, ~80 vector instructions for
+// 64 elements: 17.3 / 17.5 us per SpMV against 10.8 for the row-block plan, profiles/r04_light_*.txt.)
 // The plan (stream_tiles.cpp: "light") cuts up to 4 x CUs row ranges of equal non-zero count.  Reference: the cluster / PE arithmetic as
 // for spmv_rowblock_kernel (pe.h:62-81, pe-pob.h:63-65); drain order spmv_result_drain.cpp:104-113.
 template <bool kFloat, int kAblate>
-__global__ __launch_bounds__(kLightThreads) void spmv_light_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
+__global__ __launch_bounds__(kLightThreads, 6) void spmv_light_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                     const Unit* __restrict__ units, const uint32_t* __restrict__ x,
                                                                     uint32_t* __restrict__ out, int32_t row_part_filter,
                                                                     const uint32_t* __restrict__ part_heads) {
@@ -963,8 +965,27 @@ __global__ __launch_bounds__(kLightThreads) void spmv_light_kernel(const uint8_t
         next = (row_part_filter >= 0 && (blk->flags & kBlockLastOfPartition)) ? 0u : blk->next;
         const uint32_t nrows = blk->nrows, out0 = blk->out_offset, ub = blk->unit_begin;
         const uint32_t U = blk->unit_end - ub;
-        const bool dense = (blk->flags & kBlockDenseRows) != 0;
-        const uint8_t* chunks = image + blk->wave_offset[0];      // chunk g of the block at g * 512
+        const uint8_t* chunks = scalar_pointer(image + blk->wave_offset[0]);      // chunk g of the block at g * 512 (scalar base + 32-bit offset: a block's stream stays below 4 GiB)
+        // chunks of the block = the 14 per-wavefront step counts the image was dealt for, added up: known from the Block itself, so the
+        // first batch of element loads goes out BEFORE the unit table is fetched (one dependent round trip less in a kernel that is
+        // nothing but a chain of them)
+        uint32_t total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kConsumerWaves; ++w) total += blk->total_steps[w];
+        // wavefront w takes the CONSECUTIVE chunks [g_begin, g_end): in the strided layout of a PAIRS unit (slot (chunk c, lane l) = sorted
+        // element l x chunks + c) a lane then walks consecutive sorted elements -- a run that stays on one row for many chunks
+        const uint32_t per_wave = (total + kWaves - 1) / kWaves;
+        const uint32_t g_begin = min(wave * per_wave, total), g_end = min(g_begin + per_wave, total);
+        const uint32_t lane_off = lane * 8u;
+        uint2 e[kLightBatch];
+        auto load_batch = [&](uint2 (&dst)[kLightBatch], uint32_t g0) {
+#pragma unroll
+            for (int j = 0; j < kLightBatch; ++j) {
+                const uint32_t g = min(g0 + j, g_end - 1);                          // past the end: the last chunk again (its products are dropped)
+                dst[j] = *reinterpret_cast<const uint2*>(chunks + (g * kChunkBytes + lane_off));
+            }
+        };
+        if (g_begin < g_end) load_batch(e, g_begin);
         if (!first_block) __syncthreads();                        // the previous block's store has read the accumulators
         first_block = false;
         // lane u < U of every wavefront: where unit u ends among the block's chunks (its 14 per-wavefront stream positions add up to that:
@@ -977,46 +998,59 @@ __global__ __launch_bounds__(kLightThreads) void spmv_light_kernel(const uint8_t
             my_end = a.z + a.w + b.x + b.y + b.z + b.w + c.x + c.y + c.z + c.w + d.x + d.y + d.z + d.w;
         }
         for (uint32_t i = tid; i <= nrows; i += kLightThreads) ys[i] = 0;
-        const uint32_t total = U ? __builtin_amdgcn_readfirstlane(__shfl(my_end, U - 1, kWaveLanes)) : 0u;      // chunks of the block
         __syncthreads();
-        const uint32_t lane_off = lane * 8u;
-        for (uint32_t g0 = wave; g0 < total; g0 += kWaves * kLightBatch) {
-            uint2 e[kLightBatch];
+        // the unit the wavefront's first chunk lies in; from there on units are entered in order (scalar bookkeeping only)
+        uint32_t u = 0, unit_end = 0, col0 = 0;
+        if (g_begin < g_end) {
+            u = static_cast<uint32_t>(__builtin_ctzll(__ballot(lane < U && g_begin < my_end)));
+            unit_end = __builtin_amdgcn_readlane(my_end, u);
+            col0 = __builtin_amdgcn_readlane(my_col0, u);
+        }
+        uint32_t lane_row = nrows;                                // the row this lane is summing (starts on the spare accumulator: adds 0 there)
+        sum_t lane_sum = 0;
+        for (uint32_t g0 = g_begin; g0 < g_end; g0 += kLightBatch) {
             uint32_t xv[kLightBatch];
 #pragma unroll
             for (int j = 0; j < kLightBatch; ++j) {
-                const uint32_t g = min(g0 + j * kWaves, total - 1);                 // past the end: the last chunk again (its products are dropped)
-                e[j] = *reinterpret_cast<const uint2*>(chunks + size_t(g) * kChunkBytes + lane_off);
-            }
-#pragma unroll
-            for (int j = 0; j < kLightBatch; ++j) {
-                const uint32_t g = min(g0 + j * kWaves, total - 1);
-                const uint64_t inside = __ballot(lane < U && g < my_end);           // units this chunk lies in front of the end of: the first one holds it
-                const uint32_t u = static_cast<uint32_t>(__builtin_ctzll(inside));
-                const uint32_t col0 = __shfl(my_col0, u, kWaveLanes);
+                const uint32_t g = min(g0 + j, g_end - 1);
+                while (g >= unit_end) {                                              // wave-uniform: the next unit with chunks
+                    ++u;
+                    unit_end = __builtin_amdgcn_readlane(my_end, u);
+                    col0 = __builtin_amdgcn_readlane(my_col0, u);
+                }
                 xv[j] = (kAblate & 2) ? e[j].y : x[col0 + (e[j].y & 0xffffu)];
             }
+            // products first (one 32-bit register each: the Q8.24 product, or the fp32 one), so that the element registers are free for
+            // the next batch, whose loads travel while this one is added up
+            typename OwnerOps<kFloat>::val_t prod[kLightBatch];
+            uint32_t rows[kLightBatch];
 #pragma unroll
             for (int j = 0; j < kLightBatch; ++j) {
-                if (g0 + j * kWaves >= total) break;                                 // wave-uniform
-                const uint32_t row = e[j].y >> 16;
-                const typename R::prod_t prod = R::product(e[j].x, xv[j]);
-                if (kAblate & 1) { asm volatile("" ::"v"(prod), "v"(row)); continue; }
-                if (dense) {
-                    // sorted elements: rows never decrease from lane to lane.  Suffix sums inside every run of equal rows; the run's first
-                    // lane adds the run's sum (one LDS atomic per row and chunk instead of up to 64 colliding ones)
-                    sum_t sum = R::widen(prod);
+                prod[j] = OwnerOps<kFloat>::product(e[j].x, xv[j]);
+                rows[j] = e[j].y >> 16;
+            }
+            if (g0 + kLightBatch < g_end) load_batch(e, g0 + kLightBatch);
 #pragma unroll
-                    for (uint32_t dlt = 1; dlt < kWaveLanes; dlt <<= 1) {
-                        const sum_t s2 = __shfl_down(sum, dlt, kWaveLanes);
-                        const uint32_t r2 = __shfl_down(row, dlt, kWaveLanes);
-                        if (lane + dlt < kWaveLanes && r2 == row) sum += s2;
-                    }
-                    const uint32_t below = __shfl_up(row, 1, kWaveLanes);
-                    if (lane == 0 || below != row) R::add_sum(ys, row, sum);
-                } else {
-                    R::add(ys, row, prod);
+            for (int j = 0; j < kLightBatch; ++j) {
+                if (g0 + j >= g_end) break;                                          // wave-uniform
+                if (kAblate & 1) { asm volatile("" ::"v"(prod[j]), "v"(rows[j])); continue; }
+                // a lane sums in a register while its row stays the same and touches the LDS accumulator only when it changes
+                if (rows[j] != lane_row) {                                           // per lane
+                    R::add_sum(ys, lane_row, lane_sum);
+                    lane_row = rows[j];
+                    lane_sum = 0;
                 }
+                lane_sum += R::widen(static_cast<typename R::prod_t>(prod[j]));
+            }
+        }
+        // hand the last sums over: a block of ONE long row (a pruned-NN layer) leaves all 64 lanes on the same row -- DPP total, one add
+        if (!(kAblate & 1)) {
+            const uint32_t row0 = __builtin_amdgcn_readfirstlane(lane_row);
+            if (__ballot(lane_row != row0) == 0) {
+                const sum_t sum = wave_total_in_lane63(lane_sum);
+                if (lane == kWaveLanes - 1) R::add_sum(ys, row0, sum);
+            } else {
+                R::add_sum(ys, lane_row, lane_sum);
             }
         }
         // no-return LDS atomics can outlive lgkmcnt(0) (spmv_rowblock_kernel): a returning one on the spare accumulator, awaited, cannot

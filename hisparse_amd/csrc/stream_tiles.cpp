@@ -169,6 +169,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         const bool fits = out.nnz > 0 && uint64_t(CP) * S <= kLightMaxUnits && num_rows < (1u << 31);
         light = fits && !forced && out.nnz <= kLightMaxNnz;
         if (const char* force = env_switch("HISPARSE_LIGHT")) light = std::atoi(force) != 0 && fits && (!forced || std::string(forced) == "pairs");
+        if (const char* force_slices = env_switch("HISPARSE_COL_SLICES")) light = light && std::atoi(force_slices) <= 1;      // a forced sliced plan is the row-block kernel's
         if (light) out.format = kFormatPairs;
         out.light = light;
     }
@@ -185,7 +186,9 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     // thousand non-zeros (hyper-sparse matrices).  Cost model in microseconds, constants measured on MI355X:
     //   x volume through one CU at ~120 GB/s; a refill takes ~0.8 us to land, ring-1 of them overlap, a unit's stream
     //   time (~25 GB/s per CU) hides the rest; ~8 us of prologue + epilogue per block; the combine kernel.
-    const uint32_t G = std::max<uint32_t>(1, max_workgroups) * (light ? kLightWorkgroupsPerCu : 1u);
+    uint32_t light_wgs = kLightWorkgroupsPerCu;
+    if (const char* force = env_switch("HISPARSE_LIGHT_WGS")) light_wgs = std::min<uint32_t>(6u, std::max(1, std::atoi(force)));
+    const uint32_t G = std::max<uint32_t>(1, max_workgroups) * (light ? light_wgs : 1u);
     uint32_t slices = 1, max_rows = light ? kLightMaxBlockRows : max_block_rows(false);
     if (light) {
         if (const char* force_rows = env_switch("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force_rows)));   // tests: chains of blocks
@@ -359,7 +362,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             } else if (owner) {
                 blk.flags = 0;
             } else if (light) {
-                blk.flags = kBlockDenseRows;      // linear dealing for every block: the kernel's segmented wavefront sum takes any row pattern
+                blk.flags = 0;                    // strided dealing for every block: a lane of the light kernel walks consecutive sorted elements
             } else {
                 blk.flags = (ranges[b].nrows <= kDenseBlockRows && range_nnz[b] >= 64ull * ranges[b].nrows) ? kBlockDenseRows : 0u;
             }

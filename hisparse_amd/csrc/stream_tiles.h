@@ -163,12 +163,14 @@ constexpr uint32_t kBitmapMaskBatch = 32;                     // masks fetched p
 constexpr uint32_t kBitmapRunSlots = 5;                       // Unit-sized (64-byte) slots per wavefront run: the WaveSeg + a copy of its first 32 masks
 // LIGHT plan (round 4): matrices of at most kLightMaxNnz non-zeros over at most kLightMaxUnits x sub-tiles are launch-bound in the row-block
 // kernel (1024-thread workgroups, x staged through LDS, a combine launch for sliced plans).  They get a PAIRS image cut into up to
-// kLightWorkgroupsPerCu x CUs row ranges of one column slice, every block dealt linearly (kBlockDenseRows: chunk i / 64, lane i % 64), and
+// kLightWorkgroupsPerCu x CUs row ranges of one column slice, every block in the strided layout (lane l of chunk c = sorted element l x chunks + c), and
 // the kernel spmv_light_kernel (spmv_kernels.hip): 256-thread workgroups, x gathered straight from L2, y written by the one launch.
-constexpr uint64_t kLightMaxNnz = 5u << 20;                   // ~ 42 MB of PAIRS stream
+constexpr uint64_t kLightMaxNnz = 2u << 20;                   // 17 MB of PAIRS stream.  Above that the gathers decide: one rank's slab of mouse_gene split 8 ways
+                                                              // (3.6 M non-zeros, random columns: a 64-lane gather is 64 L1 look-ups, ~6 us per CU) runs 17-18 us in this
+                                                              // kernel whatever the accumulation scheme against 10 us for the sliced row-block plan + combine pass (x in LDS)
 constexpr uint32_t kLightMaxUnits = 16;                       // sub-tiles of a block (one slice): lanes 0 .. 15 hold the unit ends
-constexpr uint32_t kLightWorkgroupsPerCu = 4;
-constexpr uint32_t kLightMaxBlockRows = 4095;                 // 32 KiB of accumulators per workgroup
+constexpr uint32_t kLightWorkgroupsPerCu = 4;                 // measured flat between 2 and 6 per CU (the kernel is compiled for 6: 85 registers); HISPARSE_LIGHT_WGS=1..6 for experiments
+constexpr uint32_t kLightMaxBlockRows = 3071;                 // 24 KiB of accumulators per workgroup: up to six of them per CU
 constexpr uint32_t kLightMinBlockNnz = 1024;                  // no block smaller than 16 chunks (unless the matrix is)
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit

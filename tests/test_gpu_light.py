@@ -29,7 +29,7 @@ def _clean(monkeypatch):
 
 
 @pytest.mark.parametrize("impl", [0, 1, 2])
-@pytest.mark.parametrize("shape", [(1000, 1000, 0.01), (5638, 45101, 0.0142), (512, 33288, 0.05), (300000, 64, 0.05), (70, 50000, 0.01), (8, 8, 1.0), (20000, 20000, 0.00002)])
+@pytest.mark.parametrize("shape", [(1000, 1000, 0.01), (5638, 45101, 0.007), (512, 33288, 0.05), (300000, 64, 0.05), (70, 50000, 0.01), (8, 8, 1.0), (20000, 20000, 0.00002)])
 def test_small_matrices_take_the_light_plan_and_match_the_oracle(impl, shape):
     rows, cols, density = shape
     csr = host.CSRMatrix.generate("bernoulli", rows, cols, b=density, c=1.0 if impl == 0 else 0.5, seed=rows + impl)
@@ -45,7 +45,7 @@ def test_small_matrices_take_the_light_plan_and_match_the_oracle(impl, shape):
         assert st["light_kernel"] == (0 if dense_rows else 1), st
         if st["light_kernel"]:
             assert st["col_slices"] == 1 and device.STREAM_FORMATS[st["stream_format"]] == "pairs"
-            assert st["num_blocks"] <= 4 * st["num_compute_units"] and st["lds_bytes"] <= 32768 + 16
+            assert st["num_blocks"] <= 6 * st["num_compute_units"] and st["lds_bytes"] <= 24576 + 16
         eng.load_vector(xw)
         eng.run()
         want = _oracle(cp, impl, xw)
@@ -103,9 +103,11 @@ def test_non_finite_x_reaches_only_the_rows_that_hold_the_column():
     assert np.isfinite(got[~touched]).all() and not np.isfinite(got[touched]).any()
 
 
-def test_slab_of_the_8_gpu_run_is_one_launch():
-    cfg, csr = datasets.load("mouse_gene_slab8")
-    with device.SpmvEngine(0) as eng:
-        eng.load_matrix_csr(csr)
-        st = eng.stats()
-        assert st["light_kernel"] == 1 and st["col_slices"] == 1
+def test_pruned_nn_layers_below_bitmap_density_are_one_launch():
+    # transformer-90 / -95 (sw/bm.sh:26-27): 1.7 M / 0.85 M non-zeros -- 5 column slices + a combine launch in round 3 (16.4 us)
+    for name in ("transformer_90", "transformer_95"):
+        cfg, csr = datasets.load(name)
+        with device.SpmvEngine(0) as eng:
+            eng.load_matrix_csr(csr)
+            st = eng.stats()
+            assert st["light_kernel"] == 1 and st["col_slices"] == 1, (name, st)
