@@ -104,6 +104,11 @@ def read_traffic(config, stream_bytes):
     if ref and abs(ref - stream_bytes) > 0.02 * stream_bytes:
         prov["source"] += "; STALE: profiled on another stream image"
         return None, prov
+    # the committed rocprofv3 --kernel-trace --stats pass of the same command (tools/profile_cfg.sh): the dominant kernel's average
+    # duration and the fraction it prices, next to this run's HIP-event figure
+    prov["kernel_us_rocprof"] = e.get("kernel_avg_us")
+    prov["frac_rocprof"] = round(e["roofline_frac_rocprof"], 4) if e.get("roofline_frac_rocprof") else None
+    prov["step_us_in_the_profiled_process"] = e.get("step_us_wall_best")
     return e.get("hbm_bytes_per_launch"), prov
 
 
@@ -263,19 +268,20 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
     res = {
         "workload": f"{name}, {IMPL_NAMES[impl]} IMPL, v={packets.vb_bank} o={packets.ob_bank}",
         "rows": true_rows, "cols": packets.num_cols, "nnz": int(nnz), "partitions": f"{packets.num_row_partitions}x{packets.num_col_partitions}",
-        "stream_format": device.STREAM_FORMATS[stats["stream_format"]], "col_slices": stats["col_slices"],
+        "stream_format": device.STREAM_FORMATS[stats["stream_format"]] + (" (light kernel)" if stats.get("light_kernel") else ""), "col_slices": stats["col_slices"],
         "ms_per_step": round(ms, 5), "value": round(value, 2), "unit": "GB/s", "gops": round(2.0 * nnz / (elapsed / steps) / 1e9, 2),
         "ms_per_step_synchronous": round(elapsed_sync / steps * 1e3, 5),
         "value_synchronous": round(8.0 * nnz / (elapsed_sync / steps) / 1e9, 2),
         "spin_up_steps": spun,
         "gibps_reference_formula": round(8.0 * nnz / 2 ** 30 / (elapsed / steps), 2),
         "hbm_roofline_fraction_whole_job": round(value / HBM_PEAK_GBS, 4),
-        "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_rowblock_kernel",
+        "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_light_kernel" if stats.get("light_kernel") else "spmv_rowblock_kernel",
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "kernel_ms": round(kernel_ms, 5), "kernel_ms_from": kernel_ms_how, "kernel_ms_event_pairs": round(kernel_ms_pairs, 5),
                      "step_ms_two_events_around_K_launches": round(step_ms_region, 5),
                      "frac_event_pairs": round(8.0 * nnz / (kernel_ms_pairs * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(8 * nnz),
-                     "streamed_bytes_per_launch": int(stats["stream_bytes"]), "traffic": traffic, "traffic_provenance": traffic_from},
+                     "streamed_bytes_per_launch": int(stats["stream_bytes"]), "traffic": traffic, "traffic_provenance": traffic_from,
+                     "frac_rocprof": traffic_from.get("frac_rocprof"), "kernel_us_rocprof": traffic_from.get("kernel_us_rocprof")},
         "parity_vs_oracle": parity,
         "preprocess_s": {"format_csr2cpsr": round(t_fmt, 3), "device_load_retile": round(stats["load_seconds"], 3),
                          "device_load_from_csr_instead": round(st2["load_seconds"], 3)},
@@ -381,7 +387,22 @@ def mall_cold(np, datasets, device, host, first, steps, warmup, rank):
             "frac_whole_job_one_image": round(8.0 * first["nnz"] / t_one / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def predict_scaling(np, datasets, device, host, sharding, name, steps, rank):
+def quote_hbm_fraction(res):
+    """Which whole-job number may be called "fraction of the HBM roofline": an image below 256 MiB lives in the Infinity Cache between the
+    launches of a loop over ONE matrix, so for those the MALL-cold (round-robin over > 256 MiB of images) figure is the HBM number and the
+    warm one is a cache number; larger images: the warm loop (they lose 0-2 points cold)."""
+    r = res["roofline"]
+    small = r["streamed_bytes_per_launch"] < 256 * 2 ** 20
+    cold = r.get("frac_mall_cold")
+    if small and cold is not None:
+        res["hbm_roofline_fraction_quoted"] = cold
+        res["hbm_roofline_fraction_quoted_from"] = "whole job, MALL-cold round-robin (the image fits the 256 MiB Infinity Cache: the warm loop is a cache number)"
+    else:
+        res["hbm_roofline_fraction_quoted"] = res["hbm_roofline_fraction_whole_job"]
+        res["hbm_roofline_fraction_quoted_from"] = "whole job, one image" + (" (image below 256 MiB and no cold leg measured: an Infinity-Cache number)" if small else "")
+
+
+def predict_scaling(np, datasets, device, host, sharding, name, steps, rank, ways=(2, 4, 8)):
     """Strong-scaling evidence that ONE GPU can give: for N in 2, 4, 8 every row slab of the N-way split
     (sharding.split_rows_by_nnz, exactly what rank r of `bench.py --gpus N` loads) is timed on this GPU; the slowest slab bounds the
     N-GPU compute-only step, so  efficiency(N) = t(unsplit) / (N x max slab time).  No collective is involved or predicted."""
@@ -411,7 +432,7 @@ def predict_scaling(np, datasets, device, host, sharding, name, steps, rank):
     t_whole, st_whole = step_us(full)
     out = {"workload": f"{name}, {IMPL_NAMES[impl]} IMPL", "nnz": int(full.nnz), "unsplit_us": round(t_whole, 2),
            "unsplit_plan": f"{device.STREAM_FORMATS[st_whole['stream_format']]}, {st_whole['col_slices']} slices, {st_whole['num_blocks']} blocks", "splits": []}
-    for n in (2, 4, 8):
+    for n in ways:
         bounds = sharding.split_rows_by_nnz(indptr, n, granule)
         slabs = []
         for r in range(n):
@@ -511,46 +532,81 @@ def main():
 
     from hisparse_amd import sharding
 
-    def bm_entry(name, paper_gops, res):
-        """one line of the reference's sweep (sw/bm.sh) next to the paper's U280 figure for the same matrix (Table 3, fixed point)"""
-        return {"matrix": name, "impl": "fixed", "nnz": res["nnz"], "stream_format": res["stream_format"], "col_slices": res["col_slices"],
-                "ms_per_step": res["ms_per_step"], "value": res["value"], "unit": "GB/s", "gops": res["gops"],
-                "hbm_roofline_fraction_whole_job": res["hbm_roofline_fraction_whole_job"], "frac_kernel": res["roofline"]["frac"],
-                "kernel_ms": res["roofline"]["kernel_ms"], "streamed_bytes_per_launch": res["roofline"]["streamed_bytes_per_launch"],
-                "image_fits_infinity_cache": res["roofline"]["streamed_bytes_per_launch"] < 256 * 2 ** 20,
-                "parity_vs_oracle": res["parity_vs_oracle"], "paper_table3_gops_u280_fixed": paper_gops, "gops_vs_paper": round(res["gops"] / paper_gops, 1)}
+    def bm_entry(name, paper_gops, res, impl="fixed"):
+        """one line of the reference's sweep (sw/bm.sh) next to the paper's U280 figure for the same matrix and numeric mode (Table 3: fixed
+        point; Table 7: float_pob = "PB", float_stall = "RI")"""
+        row = {"matrix": name, "impl": impl, "nnz": res["nnz"], "partitions": res["partitions"], "stream_format": res["stream_format"], "col_slices": res["col_slices"],
+               "ms_per_step": res["ms_per_step"], "ms_per_step_synchronous": res["ms_per_step_synchronous"], "value": res["value"], "unit": "GB/s", "gops": res["gops"],
+               "hbm_roofline_fraction_whole_job": res["hbm_roofline_fraction_whole_job"], "frac": res["roofline"]["frac"], "frac_kernel": res["roofline"]["frac"],
+               "frac_rocprof": res["roofline"].get("frac_rocprof"), "frac_mall_cold": res["roofline"].get("frac_mall_cold"),
+               "kernel_ms": res["roofline"]["kernel_ms"], "streamed_bytes_per_launch": res["roofline"]["streamed_bytes_per_launch"],
+               "image_fits_infinity_cache": res["roofline"]["streamed_bytes_per_launch"] < 256 * 2 ** 20,
+               "parity_vs_oracle": res["parity_vs_oracle"],
+               "paper_gops_u280": paper_gops, "paper_table": "Table 3" if impl == "fixed" else "Table 7", "gops_vs_paper": round(res["gops"] / paper_gops, 1) if paper_gops else None}
+        if impl == "fixed":
+            row["paper_table3_gops_u280_fixed"] = paper_gops
+        if "float_error" in res:
+            row["float_error"] = res["float_error"]
+        return row
+
+    def float_sweep(already):
+        """The matrices the paper quotes in all three numeric modes (Table 7) in float_pob (o = 1024: 8 x the row partitions) and float_stall
+        (F = 8), each checked against the oracle at full size inside measure_single; `already`: (name, impl) -> res measured above."""
+        rows = []
+        for name, fx, pb, ri in datasets.BM_FLOAT:
+            for impl_name, paper in (("float_pob", pb), ("float_stall", ri)):
+                res = already.get((name, impl_name))
+                if res is None:
+                    res, ctx = measure_single(np, datasets, device, host, name, sub_steps, sub_warm, impl_override=impl_name, rank=rank, with_spmm=False)
+                    ctx["eng"].close()
+                    del ctx
+                fixed = already.get((name, "fixed"))
+                row = bm_entry(name, paper, res, impl_name)
+                if fixed is not None:      # VERDICT round 3, item 5: each within 5 points of the fixed-point figure, or a named cause
+                    row["fixed_point_fraction_whole_job"] = fixed["hbm_roofline_fraction_whole_job"]
+                    row["points_vs_fixed_point"] = round((res["hbm_roofline_fraction_whole_job"] - fixed["hbm_roofline_fraction_whole_job"]) * 100, 1)
+                rows.append(row)
+                log(rank, f"bm {name}/{impl_name}: {res['ms_per_step']*1e3:.1f} us per SpMV = {res['gops']:.0f} GOPS, {res['hbm_roofline_fraction_whole_job']*100:.1f} % of the HBM roofline "
+                          f"(paper {paper} GOPS); {res['parity_vs_oracle']}")
+        return rows
 
     sub_steps = max(20, min(args.steps, 200))
     sub_warm = min(args.warmup, 20)
     if args.predict_scaling:      # only the strong-scaling prediction (bench.py --predict-scaling [--config mouse_gene])
         print(json.dumps({"predict_scaling": predict_scaling(np, datasets, device, host, sharding, args.config or "mouse_gene", sub_steps, rank)}), flush=True)
         return
-    if args.config == "bm":       # only the reference's sweep, one line per matrix, the whole list as the last line
+    if args.config == "bm":       # only the reference's sweep (sw/bm.sh runs it in the mode of its bitstream: --impl), the whole list as the last line
+        sweep_impl = args.impl or "fixed"
+        paper7 = {n: {"fixed": fx, "float_pob": pb, "float_stall": ri} for n, fx, pb, ri in datasets.BM_FLOAT}
         rows = []
         for name, paper in datasets.BM_LIST:
-            res, ctx = measure_single(np, datasets, device, host, name, sub_steps, sub_warm, impl_override="fixed", rank=rank, with_spmm=False)
+            res, ctx = measure_single(np, datasets, device, host, name, sub_steps, sub_warm, impl_override=sweep_impl, rank=rank, with_spmm=False)
             ctx["eng"].close()
             del ctx
-            rows.append(bm_entry(name, paper, res))
-            log(rank, f"bm {name}: {res['ms_per_step']*1e3:.1f} us per SpMV = {res['gops']:.0f} GOPS ({res['hbm_roofline_fraction_whole_job']*100:.1f} % of the HBM roofline), paper {paper}")
-        print(json.dumps({"metric": "SpMV GBPS / GOPS per matrix of sw/bm.sh, fixed IMPL, 1 x MI355X", "bm_list": rows}), flush=True)
+            quoted = paper if sweep_impl == "fixed" else paper7.get(name, {}).get(sweep_impl)
+            rows.append(bm_entry(name, quoted, res, sweep_impl))
+            log(rank, f"bm {name}/{sweep_impl}: {res['ms_per_step']*1e3:.1f} us per SpMV = {res['gops']:.0f} GOPS ({res['hbm_roofline_fraction_whole_job']*100:.1f} % of the HBM roofline), paper {quoted}")
+        print(json.dumps({"metric": f"SpMV GBPS / GOPS per matrix of sw/bm.sh, {sweep_impl} IMPL, 1 x MI355X", "bm_list": rows}), flush=True)
         return
 
     headline = args.config or "ogbl_ppa"
-    per_config, bm_rows, scaling = [], {}, None
+    per_config, bm_rows, scaling, scaling_more, float_rows = [], {}, None, [], []
     if not args.config and not args.quick:
         # the three other single-GPU configurations of BASELINE.json + the second ogbl-ppa stand-in (symmetric R-MAT, SURVEY.md 8d),
         # each also round-robin over enough images to be Infinity-Cache-cold
+        measured = {}      # (matrix, numeric mode) -> result, for the float sweep below
         for name in ("transformer_50", "ogbn_products", "mouse_gene", "ogbl_ppa_rmat"):
             res, ctx = measure_single(np, datasets, device, host, name, sub_steps, sub_warm, cpu_seconds=0.0, rank=rank)
             cold = mall_cold(np, datasets, device, host, ctx, sub_steps, sub_warm, rank)
             res["roofline"]["frac_mall_cold"] = cold["frac_whole_job_round_robin"]
             res["roofline"]["mall_cold"] = cold
+            quote_hbm_fraction(res)
             ctx["eng"].close()
             del ctx
             per_config.append(res)
             if name == "mouse_gene":
                 bm_rows[name] = res
+            measured[(name, res["workload"].split(", ")[1].split(" ")[0])] = res
             log(rank, f"{name}: {res['ms_per_step']*1e3:.1f} us per SpMV, kernel {res['roofline']['kernel_ms']*1e3:.1f} us = {res['roofline']['frac']*100:.1f} % of the HBM roofline")
         # the rest of the reference's sweep (sw/bm.sh:3-17), in the numeric mode of the paper's Table 3
         for name, _ in datasets.BM_LIST:
@@ -560,8 +616,13 @@ def main():
             ctx["eng"].close()
             del ctx
             bm_rows[name] = res
+            measured[(name, "fixed")] = res
             log(rank, f"bm {name}/fixed: {res['ms_per_step']*1e3:.1f} us per SpMV = {res['gops']:.0f} GOPS, {res['hbm_roofline_fraction_whole_job']*100:.1f} % of the HBM roofline")
+        # ... and the float modes of the sweep on the matrices the paper quotes in all three (Table 7; sw/bm.sh:19-35)
+        float_rows = float_sweep(measured)
         scaling = predict_scaling(np, datasets, device, host, sharding, "mouse_gene", sub_steps, rank)
+        # the larger graphs, where row slabs are still 15-25 us of streaming (8-way split only: 1 + 8 loads each)
+        scaling_more = [predict_scaling(np, datasets, device, host, sharding, name, sub_steps, rank, ways=(8,)) for name in ("hollywood", "ogbn_products")]
     res, ctx = measure_single(np, datasets, device, host, headline, args.steps, args.warmup, npz=args.npz, impl_override=args.impl,
                               cpu_seconds=0.0 if args.no_cpu_baseline else args.cpu_seconds, rank=rank)
     cpu_baseline = None if args.no_cpu_baseline else cpu_baseline_for(np, host, ctx, rank)
@@ -569,6 +630,7 @@ def main():
         cold = mall_cold(np, datasets, device, host, ctx, args.steps, args.warmup, rank)
         res["roofline"]["frac_mall_cold"] = cold["frac_whole_job_round_robin"]
         res["roofline"]["mall_cold"] = cold
+        quote_hbm_fraction(res)
     ctx["eng"].close()
     impl = ctx["impl"]
     bm_rows[headline] = res
@@ -582,6 +644,9 @@ def main():
                    "partitions": res["partitions"], "stream_format": res["stream_format"], "parallelism": "row-slab x1"},
         "gops": res["gops"], "gibps_reference_formula": res["gibps_reference_formula"],
         "hbm_roofline_fraction_whole_job": res["hbm_roofline_fraction_whole_job"],
+        "hbm_roofline_fraction_quoted": res.get("hbm_roofline_fraction_quoted", res["hbm_roofline_fraction_whole_job"]),
+        "hbm_roofline_fraction_quoted_from": res.get("hbm_roofline_fraction_quoted_from", "whole job, one image"),
+        "ms_per_step_synchronous": res["ms_per_step_synchronous"], "value_synchronous": res["value_synchronous"],
         "roofline": res["roofline"], "cpu_baseline": cpu_baseline, "parity_vs_oracle": res["parity_vs_oracle"], "parity_pins": PARITY_PINS,
         "preprocess_s": res["preprocess_s"],
     }
@@ -593,8 +658,12 @@ def main():
         out["per_config"] = per_config
     if len(bm_rows) == len(datasets.BM_LIST):
         out["bm_list"] = [bm_entry(name, paper, bm_rows[name]) for name, paper in datasets.BM_LIST]
+    if float_rows:
+        out["bm_list_float"] = float_rows
     if scaling:
         out["strong_scaling_prediction"] = scaling
+    if scaling_more:
+        out["strong_scaling_prediction_more"] = scaling_more
     print(json.dumps(out), flush=True)
 
 

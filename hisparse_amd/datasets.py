@@ -84,6 +84,11 @@ BM_LIST = [("gplus", 21.2), ("ogbl_ppa", 24.4), ("hollywood", 24.9), ("pokec", 1
            ("transformer_95", 5.7)]
 
 
+# The paper's Table 7: the matrices it quotes in all three numeric modes -- GOPS on the U280 as (fixed, float_pob "PB", float_stall "RI").
+# sw/bm.sh:19-35 runs the whole list in the mode of the bitstream it is given (ob = 1 for float_pob, else 8).
+BM_FLOAT = [("transformer_80", 14.8, 13.4, 6.3), ("mouse_gene", 27.2, 25.0, 13.1), ("pokec", 11.2, 3.4, 9.1), ("ogbn_products", 20.6, 6.7, 16.3)]
+
+
 def load(name, path=None, scale=1.0):
     """(Config, CSRMatrix).  `scale` < 1 shrinks rows, cols and nnz of a generated stand-in proportionally."""
     cfg = CONFIGS[name]

@@ -112,6 +112,42 @@ def test_reference_sweep_full_size_fixed_point(name, paper_gops, record_property
     assert np.array_equal(got, want), f"{name}: {int((got != want).sum())} of {got.size} rows differ from the oracle"
 
 
+FLOAT_SWEEP = [(name, impl) for name, _, _, _ in datasets.BM_FLOAT for impl in ("float_pob", "float_stall") if (name, impl) != ("ogbn_products", "float_stall")]
+
+
+@pytest.mark.parametrize("name,impl_name", FLOAT_SWEEP)
+def test_reference_sweep_full_size_float_modes(name, impl_name, record_property):
+    """The float variants of the reference's sweep (sw/bm.sh:19-35 runs the list in the mode of its bitstream: ob = 1 for float_pob,
+    else 8) on the matrices the paper quotes in all three modes (Table 7): transformer-80, mouse_gene, pokec, ogbn-products -- at full
+    size, random values, default planner.  float_pob's 1024-row banks mean 8 x the row partitions (ogbn-products: 19 x 75); float_stall
+    interleaves 8 virtual channels.  Tolerance contract as in test_full_size_random_values_vs_oracle (ogbn-products / float_stall is
+    covered there)."""
+    import scipy.sparse as sp
+    cfg, csr = datasets.load(name)
+    impl = host.impl_id(impl_name)
+    rows, cols = csr.num_rows, csr.num_cols
+    ip, ix, dv = csr.arrays()
+    cp = host.format_matrix(csr, impl, skip_empty_rows=cfg.skip_empty_rows)
+    x = _random_x(impl, cp.num_cols, 20260929)
+    xw = host.pack_vector(impl, x)
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix(cp)
+        eng.load_vector(xw)
+        eng.run()
+        got = eng.read_result()
+        st = eng.stats()
+    want = _oracle(cp, impl, xw)
+    exact = sp.csr_matrix((dv.astype(np.float64), ix.astype(np.int64), ip.astype(np.int64)), shape=(rows, cols)) @ x[:cols].astype(np.float64)
+    rep = _float_report(got, want, exact)
+    print(f"\n{name}/{impl_name}: {device.STREAM_FORMATS[st['stream_format']]}, {st['col_slices']} slices, partitions {cp.num_row_partitions}x{cp.num_col_partitions}: {rep}")
+    for k, v in rep.items():
+        record_property(k, v)
+    record_property("stream_format", device.STREAM_FORMATS[st["stream_format"]])
+    assert st["nnz"] == csr.nnz
+    assert rep["rows_over_bound"] == 0, rep
+    assert rep["max_abs_err_gpu_vs_float64"] <= 2.0 * rep["max_abs_err_csim_vs_float64"] + 1e-6, rep
+
+
 def test_config5_mouse_gene_8way_row_split_on_hip(record_property):
     """BASELINE.json configs[4]: mouse_gene row-partitioned 8 ways (sw/benchmark.cpp:318-338 and sw/data_formatter.h:494,
     500-511 are the reference's grounds for treating row partitions as independent).  The 8 slabs of sharding.

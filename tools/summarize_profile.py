@@ -6,7 +6,7 @@ import sqlite3
 import sys
 
 out = sys.argv[1]
-KERNELS = ("spmv_rowblock_kernel", "spmv_bitmap_kernel")     # the dominant kernel is whichever of the two the matrix's format runs
+KERNELS = ("spmv_rowblock_kernel", "spmv_bitmap_kernel", "spmv_light_kernel")     # the dominant kernel is whichever of these the matrix's plan runs
 summary = {}
 
 
@@ -24,6 +24,8 @@ if d:
             summary["kernel"] = name.split("<")[0].split("::")[-1]
             summary["kernel_avg_us"] = avg
             summary["kernel_calls"] = calls
+        if "combine_slices_kernel" in name:
+            summary["combine_avg_us"] = avg
     KERNEL = summary.get("kernel", KERNELS[0])
     row = d.execute(f"select vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels where name like '%{KERNEL}%' limit 1").fetchone()
     if row:
@@ -54,6 +56,12 @@ try:
         summary.update(json.load(f))
     if "kernel_avg_us" in summary:
         summary["roofline_frac_rocprof"] = 8.0 * summary["nnz"] / (summary["kernel_avg_us"] * 1e-6) / 8e12
+        # the kernels of one step must fit inside the step the same process timed (plain back-to-back launches, tools/probe_cfg.py)
+        summary["step_kernels_avg_us"] = summary["kernel_avg_us"] + summary.get("combine_avg_us", 0.0)
+        if "step_us_wall_best" in summary:
+            summary["kernels_fit_inside_the_timed_step"] = summary["step_kernels_avg_us"] <= summary["step_us_wall_best"] * 1.03
+            print(f"consistency: kernel {summary['kernel_avg_us']:.2f} us + combine {summary.get('combine_avg_us', 0.0):.2f} us = {summary['step_kernels_avg_us']:.2f} us "
+                  f"vs the step this process timed without the profiler's per-launch overhead: {summary['step_us_wall_best']:.2f} us (under rocprofv3 the wall-clock step carries its tracing)")
 except (OSError, ValueError, KeyError):
     pass
 print(json.dumps(summary, indent=1))
