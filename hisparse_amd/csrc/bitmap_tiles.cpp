@@ -111,6 +111,25 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
     std::vector<RowRange> ranges;
     std::vector<uint64_t> range_nnz;
     build_row_ranges_at_most(L, row_nnz, nnz, want_ranges, max_rows, ranges, range_nnz);
+    // Rows without a non-zero at the END of a range (the padding of util_round_csr_matrix_dim: float_stall rounds 512 rows up to 1024) get
+    // a range of their own whose wavefront runs are all idle -- the kernel just writes their zeros.  Left in the last real range they made it
+    // a 514-row block of whole-row runs, 521 mask steps per EMPTY row: transformer-80 / float_stall ran 1164 us instead of 11 (round 4).
+    {
+        std::vector<RowRange> cut;
+        std::vector<uint64_t> cut_nnz;
+        for (size_t i = 0; i < ranges.size(); ++i) {
+            const RowRange rg = ranges[i];
+            uint32_t live = rg.nrows;
+            while (live > 0 && row_nnz[rg.row0 + live - 1] == 0) --live;
+            if (live == 0 || live == rg.nrows) { cut.push_back(rg); cut_nnz.push_back(range_nnz[i]); continue; }
+            cut.push_back(RowRange{rg.row0, live, rg.row_part});
+            cut_nnz.push_back(range_nnz[i]);
+            cut.push_back(RowRange{rg.row0 + live, rg.nrows - live, rg.row_part});
+            cut_nnz.push_back(0);
+        }
+        ranges.swap(cut);
+        range_nnz.swap(cut_nnz);
+    }
     const uint32_t NR = uint32_t(ranges.size());
     const uint32_t NB = NR * slices;
 
@@ -186,7 +205,7 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         const uint64_t masks = uint64_t(rg.nrows) * row_stride(gs1 - gs0, pieces_of(rg.nrows), rg.nrows);
         // [masks: 8 bytes each][values: 4 bytes each, padded to 8]
         block_base[bi + 1] = block_base[bi] + masks * 8 + ((block_nnz[bi] + 1) & ~uint64_t(1)) * 4;
-        block_weight[bi] = uint64_t(rg.nrows) * (gs1 - gs0) / kBitmapWaves + 1;          // wavefront steps
+        block_weight[bi] = block_nnz[bi] ? uint64_t(rg.nrows) * (gs1 - gs0) / kBitmapWaves + 1 : 1;          // wavefront steps (a block of empty rows: none)
         out.max_block_rows = std::max(out.max_block_rows, rg.nrows);
     }
     if (block_base[NB] / 4 >= (1ull << 40)) { error = "matrix too large for the bitmap image"; return false; }
@@ -255,12 +274,15 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         }
         // wavefront runs.  Few rows: every row is cut into floor(16 / nrows) runs of weighted group count.  Many rows: contiguous whole
         // rows per wavefront, balanced by steps-plus-non-zeros.
-        auto set_seg = [&](uint32_t w, uint32_t r0, uint32_t r1, uint32_t g0, uint32_t g1) {
+        // piece: the piece of the row the run is (partial-row runs), or -1.  A piece may hold NO group (a slice of 1 group cut into 2 pieces):
+        // its run has no steps, and its masks are the 16 zero ones of its own place in the row, not the next piece's (round 4)
+        auto set_seg = [&](uint32_t w, uint32_t r0, uint32_t r1, uint32_t g0, uint32_t g1, int piece = -1) {
             WaveSeg& s = *reinterpret_cast<WaveSeg*>(out.units.data() + blk.unit_begin + size_t(w) * kBitmapRunSlots);
             s.row_begin = r0; s.row_end = r1; s.g_begin = g0; s.g_end = g1;
             uint64_t v = value_word0 + value_at[std::min(r0, rg.nrows)];
             const bool partial = r1 == r0 + 1 && g0 > 0;     // partial row: + the values of the groups in front of g0
-            const uint64_t mw = mask_word0 + (r0 < rg.nrows ? mask_index(r0, r1 == r0 + 1 && g0 < GS ? g0 : 0) : 0);
+            const uint64_t mw = mask_word0 + (r0 >= rg.nrows ? 0 : (piece >= 0 && g1 == g0) ? uint64_t(r0) * stride + piece_at[piece]
+                                                                                            : mask_index(r0, r1 == r0 + 1 && g0 < GS ? g0 : 0));
             s.mask_lo = uint32_t(mw); s.mask_hi = uint32_t(mw >> 32);
             const uint32_t steps = r1 > r0 ? g1 - g0 : 0;
             if (gpu) {    // the device looks both up in what it built (run_value + prefix, heads: patched in below)
@@ -276,9 +298,11 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
             for (uint32_t j = 0; j < kBitmapMaskBatch; ++j)
                 head[j] = j < steps ? reinterpret_cast<const uint64_t*>(out.image.data())[mw + j] : 0;
         };
-        if (pieces > 1) {
+        if (block_nnz[bi] == 0) {
+            for (uint32_t w = 0; w < kBitmapWaves; ++w) set_seg(w, rg.nrows, rg.nrows, 0, 0);      // nothing to stream: the block only writes its rows' zeros
+        } else if (pieces > 1) {
             for (uint32_t lr = 0; lr < rg.nrows; ++lr)
-                for (uint32_t j = 0; j < pieces; ++j) set_seg(j * rg.nrows + lr, lr, lr + 1, piece_cut[j], piece_cut[j + 1]);
+                for (uint32_t j = 0; j < pieces; ++j) set_seg(j * rg.nrows + lr, lr, lr + 1, piece_cut[j], piece_cut[j + 1], int(j));
             for (uint32_t w = rg.nrows * pieces; w < kBitmapWaves; ++w) set_seg(w, rg.nrows, rg.nrows, 0, 0);      // idle wavefronts
         } else {
             // cost of a row = its steps + its non-zeros / 16 (issue slots vs. bytes); cut the prefix sum into 16 parts by the wavefronts' weights

@@ -297,6 +297,7 @@ int hs_feedback(hs_context* ctx, uint32_t, uint32_t) { HS_CPU_UNSUPPORTED(ctx); 
 int hs_iterate(hs_context* ctx, uint32_t, uint32_t, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_load_matrix_csc(hs_context* ctx, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_spmspv(hs_context* ctx, const hs_idx_val*, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
+int hs_spmspv_device(hs_context* ctx, const hs_idx_val*, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_read_spmspv_result(hs_context* ctx, void*, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_spmm_device(hs_context* ctx, const void*, uint64_t, void*, uint64_t, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_spmm(hs_context* ctx, const void*, uint32_t, uint32_t, void*, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }

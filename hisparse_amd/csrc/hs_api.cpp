@@ -69,13 +69,19 @@ struct hs_context {
     uint32_t* d_csc_indptr = nullptr;
     uint32_t* d_csc_rows = nullptr;
     uint32_t* d_csc_vals = nullptr;
-    hisparse::dev::SpmspvScratch csc_scratch;      // expanded / binned product lists, scan + sort storage, direct-path accumulators
-    uint64_t spmspv_products = 0;                  // products formed by the last hs_spmspv
-    uint32_t* d_csc_y = nullptr;
-    uint32_t* d_sx = nullptr;      // sparse x: [capacity] indices then [capacity] value words
+    hisparse::dev::SpmspvScratch csc_scratch;      // the product list (rows, product words, row blocks) and its counters
+    std::vector<uint32_t> csc_col_len;             // host copy of the column lengths: splits a host-side x whose products exceed the list
+    uint32_t spmspv_call = 0;                      // picks the product counter (spmspv.hip)
+    uint32_t* d_csc_y = nullptr;                   // max(csc rows, the dense matrix's padded rows) words
+    uint32_t csc_y_words = 0;
+    hisparse::dev::hs_idx_val_dev* d_sx = nullptr; // hs_spmspv: the caller's IDX_VAL_T pairs on the device ...
+    hisparse::dev::hs_idx_val_dev* h_sx = nullptr; // ... and the pinned staging buffer they are copied from (asynchronously)
+    hipEvent_t sx_copied = nullptr;                // the staging buffer is free again
     uint32_t sx_capacity = 0;
+    uint32_t* d_x_dense = nullptr;                 // dense dispatch: x scattered into a zero vector (num_cols words)
     uint32_t csc_rows = 0, csc_cols = 0;
     uint64_t csc_nnz = 0;
+    uint64_t spmspv_dense_dispatches = 0;          // calls of hs_spmspv answered by the dense SpMV (hs_get_stats does not carry it: tests read it through hs_last_error)
 
     uint32_t* d_x = nullptr;       // library-owned packed x
     uint32_t* d_y = nullptr;       // library-owned packed y
@@ -143,13 +149,20 @@ void free_matrix(hs_context* c) {
 
 void free_csc(hs_context* c) {
     hisparse::dev::SpmspvScratch& w = c->csc_scratch;
-    for (void* p : {static_cast<void*>(c->d_csc_indptr), static_cast<void*>(c->d_csc_rows), static_cast<void*>(c->d_csc_vals), w.accumulators,
-                    static_cast<void*>(c->d_csc_y), static_cast<void*>(c->d_sx), static_cast<void*>(w.keys[0]), static_cast<void*>(w.keys[1]),
-                    static_cast<void*>(w.vals[0]), static_cast<void*>(w.vals[1]), static_cast<void*>(w.lengths), static_cast<void*>(w.place), w.temp})
+    for (void* p : {static_cast<void*>(c->d_csc_indptr), static_cast<void*>(c->d_csc_rows), static_cast<void*>(c->d_csc_vals), static_cast<void*>(c->d_csc_y),
+                    static_cast<void*>(c->d_sx), static_cast<void*>(w.keys), static_cast<void*>(w.vals), static_cast<void*>(w.blks), static_cast<void*>(w.counters),
+                    static_cast<void*>(c->d_x_dense)})
         if (p) (void)hipFree(p);
-    c->d_csc_indptr = c->d_csc_rows = c->d_csc_vals = c->d_csc_y = c->d_sx = nullptr;
+    if (c->h_sx) (void)hipHostFree(c->h_sx);
+    if (c->sx_copied) (void)hipEventDestroy(c->sx_copied);
+    c->h_sx = nullptr;
+    c->sx_copied = nullptr;
+    c->d_csc_indptr = c->d_csc_rows = c->d_csc_vals = c->d_csc_y = c->d_x_dense = nullptr;
+    c->d_sx = nullptr;
     w = hisparse::dev::SpmspvScratch();
+    c->csc_col_len.clear();
     c->sx_capacity = 0;
+    c->csc_y_words = 0;
     c->csc_rows = c->csc_cols = 0;
     c->csc_nnz = 0;
 }
@@ -605,33 +618,80 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* 
         if (indptr[c + 1] < indptr[c]) return fail(ctx, HS_ERR_BAD_MATRIX, "CSC indptr must be non-decreasing");
     for (uint64_t e = 0; e < nnz; ++e)
         if (row_indices[e] >= num_rows) return fail(ctx, HS_ERR_BAD_MATRIX, "CSC row index out of range");
+    if ((uint64_t(num_rows) + 8191) / 8192 > 65536) return fail(ctx, HS_ERR_UNSUPPORTED, "more than 65536 row blocks of 8192 rows");
     HS_HIP(ctx, hipSetDevice(ctx->device));
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_csc(ctx);
-    const bool is_float = ctx->impl != HS_IMPL_FIXED;
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_indptr), (size_t(num_cols) + 1) * 4));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_rows), std::max<size_t>(nnz, 1) * 4));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_vals), std::max<size_t>(nnz, 1) * 4));
     hisparse::dev::SpmspvScratch& w = ctx->csc_scratch;
-    HS_HIP(ctx, hipMalloc(&w.accumulators, size_t(num_rows) * (is_float ? 4 : 8)));
-    w.capacity = std::max<uint64_t>(nnz, 1);
-    for (int k = 0; k < 2; ++k) {
-        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.keys[k]), size_t(w.capacity) * 4));
-        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.vals[k]), size_t(w.capacity) * 4));
-    }
-    w.temp_bytes = hisparse::dev::spmspv_sort_temp_bytes(w.capacity, num_rows);
-    HS_HIP(ctx, hipMalloc(&w.temp, w.temp_bytes));
-    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_y), size_t(num_rows) * 4));
+    w.capacity = std::min<uint64_t>(std::max<uint64_t>(nnz, 1), 0xfffffff0ull);
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.keys), size_t(w.capacity) * 4));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.vals), size_t(w.capacity) * 4));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.blks), hisparse::dev::spmspv_list_bytes(w.capacity)));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.counters), 3 * sizeof(unsigned long long)));
+    HS_HIP(ctx, hipMemset(w.counters, 0, 3 * sizeof(unsigned long long)));
+    // y: also large enough for the dense SpMV's padded rows (dense dispatch of hs_spmspv writes it directly)
+    ctx->csc_y_words = std::max(num_rows, ctx->matrix_loaded ? ctx->num_rows : 0u);
+    ctx->csc_y_words = std::max<uint32_t>(ctx->csc_y_words, uint32_t((uint64_t(num_rows) + ctx->geom.row_divisor - 1) / ctx->geom.row_divisor * ctx->geom.row_divisor));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_y), size_t(ctx->csc_y_words) * 4));
     HS_HIP(ctx, hipMemcpy(ctx->d_csc_indptr, indptr, (size_t(num_cols) + 1) * 4, hipMemcpyHostToDevice));
     if (nnz) {
         HS_HIP(ctx, hipMemcpy(ctx->d_csc_rows, row_indices, nnz * 4, hipMemcpyHostToDevice));
         HS_HIP(ctx, hipMemcpy(ctx->d_csc_vals, value_words, nnz * 4, hipMemcpyHostToDevice));
     }
-    HS_HIP(ctx, hipMemset(ctx->d_csc_y, 0, size_t(num_rows) * 4));
+    HS_HIP(ctx, hipMemset(ctx->d_csc_y, 0, size_t(ctx->csc_y_words) * 4));
+    ctx->csc_col_len.resize(num_cols);
+    for (uint32_t c = 0; c < num_cols; ++c) ctx->csc_col_len[c] = indptr[c + 1] - indptr[c];
     ctx->csc_rows = num_rows;
     ctx->csc_cols = num_cols;
     ctx->csc_nnz = nnz;
+    ctx->spmspv_call = 0;
     return HS_OK;
+}
+
+namespace {
+
+// one pass: expand + accumulate over `count` device-resident entries
+int spmspv_pass(hs_context* ctx, const hisparse::dev::hs_idx_val_dev* x_dev, uint32_t count, bool add_to_y) {
+    HS_HIP(ctx, hisparse::dev::launch_spmspv(ctx->impl != HS_IMPL_FIXED, ctx->d_csc_indptr, ctx->d_csc_rows, ctx->d_csc_vals, x_dev, count, ctx->csc_rows,
+                                             ctx->csc_cols, ctx->csc_scratch, ctx->spmspv_call, add_to_y, ctx->d_csc_y, ctx->stream));
+    ++ctx->spmspv_call;
+    return HS_OK;
+}
+
+// The dense SpMV instead (hs_spmspv above the crossover): x scattered into a zero vector, the context's loaded matrix, y into the SpMSpV
+// result buffer.  Only when hs_load_matrix holds a matrix of the CSC matrix's shape (padded) -- the caller's contract is that it is the
+// SAME matrix (hisparse_hip.h) -- and x names no column twice.
+bool dense_dispatch_possible(const hs_context* ctx) {
+    if (!ctx->matrix_loaded) return false;
+    const Geometry& g = ctx->geom;
+    const uint64_t rows = (uint64_t(ctx->csc_rows) + g.row_divisor - 1) / g.row_divisor * g.row_divisor, cols = (uint64_t(ctx->csc_cols) + 7) / 8 * 8;
+    return rows == ctx->num_rows && cols == ctx->num_cols && ctx->csc_y_words >= ctx->num_rows;
+}
+int spmspv_dense(hs_context* ctx, const hisparse::dev::hs_idx_val_dev* x_dev, uint32_t count) {
+    if (!ctx->d_x_dense) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_x_dense), size_t(ctx->num_cols) * 4));
+    HS_HIP(ctx, hisparse::dev::launch_spmspv_scatter_x(x_dev, count, ctx->num_cols, ctx->d_x_dense, ctx->stream));
+    const uint32_t* saved_x = ctx->x_bound;
+    uint32_t* saved_y = ctx->y_bound;
+    ctx->x_bound = ctx->d_x_dense;
+    ctx->y_bound = ctx->d_csc_y;
+    const int rc = enqueue(ctx, -1, nullptr, nullptr);
+    ctx->x_bound = saved_x;
+    ctx->y_bound = saved_y;
+    if (rc == HS_OK) ++ctx->spmspv_dense_dispatches;
+    return rc;
+}
+
+}  // namespace
+
+int hs_spmspv_device(hs_context* ctx, const hs_idx_val* x_entries_dev, uint32_t count) {
+    if (!ctx || (count && !x_entries_dev)) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
+    if (!ctx->d_csc_indptr) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix_csc has not been called");
+    if (reinterpret_cast<uintptr_t>(x_entries_dev) & 7u) return fail(ctx, HS_ERR_BAD_ARG, "device entries must be 8-byte aligned");
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    return spmspv_pass(ctx, reinterpret_cast<const hisparse::dev::hs_idx_val_dev*>(x_entries_dev), count, false);
 }
 
 int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
@@ -643,30 +703,52 @@ int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
     if (count > ctx->sx_capacity) {
         HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_sx) (void)hipFree(ctx->d_sx);
-        ctx->d_sx = nullptr;
+        if (ctx->h_sx) (void)hipHostFree(ctx->h_sx);
+        ctx->d_sx = ctx->h_sx = nullptr;
         ctx->sx_capacity = 0;
         const uint32_t cap = std::max<uint32_t>(count, 1024);
         HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_sx), size_t(cap) * 8));
-        hisparse::dev::SpmspvScratch& w = ctx->csc_scratch;
-        if (w.lengths) (void)hipFree(w.lengths);
-        if (w.place) (void)hipFree(w.place);
-        w.lengths = w.place = nullptr;
-        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.lengths), (size_t(cap) + 1) * 4));
-        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.place), (size_t(cap) + 1) * 4));
+        HS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_sx), size_t(cap) * 8, hipHostMallocDefault));
+        if (!ctx->sx_copied) HS_HIP(ctx, hipEventCreateWithFlags(&ctx->sx_copied, hipEventDisableTiming));
         ctx->sx_capacity = cap;
+    } else if (ctx->sx_copied && count) {
+        HS_HIP(ctx, hipEventSynchronize(ctx->sx_copied));      // the previous call's copy out of the staging buffer (long done, normally)
     }
-    if (count) {     // IDX_VAL_T pairs -> two arrays (coalesced reads on the device)
-        std::vector<uint32_t> split(size_t(count) * 2);
+    // The product list holds as many products as the matrix has non-zeros: an x that names columns more than once can ask for more.  The
+    // host knows every column's length, so such a call is cut into passes that fit (y = first pass, y += the others).  Repeats also
+    // rule the dense dispatch out (two entries of one column are two separately rounded products, not one product of their sum).
+    std::vector<uint32_t> pass_end;      // entries [pass_end[i-1], pass_end[i]) form pass i
+    uint64_t in_pass = 0;
+    bool repeats = false;
+    {
+        std::vector<uint8_t> seen((size_t(ctx->csc_cols) + 7) / 8, 0);
         for (uint32_t k = 0; k < count; ++k) {
-            split[k] = x_entries[k].index;
-            split[size_t(count) + k] = x_entries[k].val;
+            const uint32_t col = x_entries[k].index, len = ctx->csc_col_len[col];
+            if (seen[col >> 3] & (1u << (col & 7))) repeats = true;
+            seen[col >> 3] |= uint8_t(1u << (col & 7));
+            if (in_pass + len > ctx->csc_scratch.capacity && in_pass) { pass_end.push_back(k); in_pass = 0; }
+            in_pass += len;
         }
-        HS_HIP(ctx, hipMemcpyAsync(ctx->d_sx, split.data(), split.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        HS_HIP(ctx, hipStreamSynchronize(ctx->stream));     // `split` is a temporary
+        pass_end.push_back(count);
     }
-    HS_HIP(ctx, hisparse::dev::launch_spmspv(ctx->impl != HS_IMPL_FIXED, ctx->d_csc_indptr, ctx->d_csc_rows, ctx->d_csc_vals, ctx->d_sx,
-                                             ctx->d_sx + count, count, ctx->csc_rows, ctx->csc_cols, ctx->csc_scratch, ctx->d_csc_y, ctx->stream,
-                                             &ctx->spmspv_products, ctx_option(ctx, "HISPARSE_SPMSPV")));
+    if (count) {
+        std::memcpy(ctx->h_sx, x_entries, size_t(count) * sizeof(hs_idx_val));
+        HS_HIP(ctx, hipMemcpyAsync(ctx->d_sx, ctx->h_sx, size_t(count) * sizeof(hs_idx_val), hipMemcpyHostToDevice, ctx->stream));
+        HS_HIP(ctx, hipEventRecord(ctx->sx_copied, ctx->stream));
+    }
+    // above the crossover the dense SpMV is faster (it reads every non-zero once, coalesced; the sparse path makes every row block's
+    // workgroup sweep the whole product list): hisparse_hip.h
+    double crossover = 0.02;
+    if (const char* v = ctx_option(ctx, "HISPARSE_SPMSPV_CROSSOVER")) crossover = std::atof(v);
+    const char* force = ctx_option(ctx, "HISPARSE_SPMSPV");
+    const bool want_dense = force ? std::string(force) == "dense" : (crossover > 0.0 && double(count) > crossover * double(ctx->csc_cols));
+    if (want_dense && !repeats && dense_dispatch_possible(ctx)) return spmspv_dense(ctx, ctx->d_sx, count);
+    uint32_t begin = 0;
+    for (size_t i = 0; i < pass_end.size(); ++i) {
+        const int rc = spmspv_pass(ctx, ctx->d_sx + begin, pass_end[i] - begin, i != 0);
+        if (rc != HS_OK) return rc;
+        begin = pass_end[i];
+    }
     return HS_OK;
 }
 
@@ -675,8 +757,15 @@ int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows) {
     if (!ctx->d_csc_indptr) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix_csc has not been called");
     if (num_rows != ctx->csc_rows) return fail(ctx, HS_ERR_BAD_ARG, "result length must equal the CSC matrix's row count");
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long overflow = 0;
     HS_HIP(ctx, hipMemcpyAsync(packed_y, ctx->d_csc_y, size_t(num_rows) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HS_HIP(ctx, hipMemcpyAsync(&overflow, ctx->csc_scratch.counters + 2, sizeof(overflow), hipMemcpyDeviceToHost, ctx->stream));
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (overflow) {      // only hs_spmspv_device can get here: hs_spmspv cuts such a call into passes
+        HS_HIP(ctx, hipMemset(ctx->csc_scratch.counters + 2, 0, sizeof(overflow)));
+        return fail(ctx, HS_ERR_BAD_ARG, "hs_spmspv_device: the entries asked for more products than the matrix has non-zeros (columns named more than "
+                                         "once): the result is incomplete; hs_spmspv with host entries splits such a call");
+    }
     return HS_OK;
 }
 

@@ -5,26 +5,25 @@
 // natural next kernel on the same datapath.  The work is proportional to the non-zeros of the SELECTED columns only, which is the
 // point of the operator.
 //
-// Round 3: the SpMV kernels' row-owner scheme instead of a device-scope atomic per product (memory-side atomics run at ~24 G/s on
-// this chip):
-//   1. lengths of the selected columns -> exclusive scan (hipCUB) -> every column's place in an element list, and the total;
-//   2. EXPAND: one wavefront per stored x entry streams that entry's matrix column (row index + value word, both contiguous in
-//      CSC: two coalesced loads per 64 non-zeros), multiplies with the PE arithmetic of the numeric mode and writes
-//      (row, product word) to its place in the list;
-//   3. BIN: one radix-sort pass structure over the row's HIGH bits only (hipcub::DeviceRadixSort on bits [13, log2 rows)): the list
-//      ordered by row block of 8192 rows, unordered inside a block;
-//   4. ACCUMULATE: one workgroup per row block finds its stretch of the list by binary search, adds the products into 64-bit LDS
-//      accumulators (ds_add_u64 / ds_add_f64: exact integer sums, double sums of the fp32 products) and writes ITS rows of y --
-//      every row exactly once, so y needs no zeroing pass and no finish pass.
-// No global atomics anywhere on this path.  It pays from a few million products on matrices with at least 32 row blocks (measured
-// crossovers below); smaller jobs go through the round-2 scatter kernel (a device-scope atomic per product into a zeroed accumulator
-// vector), which is launch-bound at that size either way.  HISPARSE_SPMSPV=atomic forces the scatter (A/B runs).
+// Round 4: two launches, nothing else -- no scan, no sort, no host synchronisation, no H2D inside the call (round 3's path took a
+// hipCUB scan, a stream sync to learn the product count, a radix sort and an H2D before its first product: 53-205 us where the dense
+// SpMV takes 56):
+//   1. EXPAND: one wavefront per stored x entry claims room in the product list with ONE atomic on a device counter (its column's
+//      length), streams the column (row index + value word: two coalesced loads per 64 non-zeros), multiplies with the PE arithmetic of
+//      the numeric mode and writes, per product: the row (u32), the product word (u32) and the row BLOCK it falls in (u16, 8192 rows);
+//   2. ACCUMULATE: one workgroup per row block sweeps the 2-byte block ids of the whole list (16 bytes = 8 products per lane and load:
+//      the list is L2-resident and the ids are all a workgroup reads of the products that are not its own), fetches row and product
+//      of the matches, adds them into 64-bit LDS accumulators (ds_add_u64 / ds_add_f64: exact integer sums, double sums of the fp32
+//      products) and writes ITS rows of y -- every row exactly once, so y needs no zeroing pass and no finish pass.
+// The order of the list is whatever the atomics make it; the sums do not care (fixed point: exact; float: tolerance, as everywhere).
+// No memory-side atomic per product (they run at ~24 G/s on this chip): one per selected COLUMN.
+// Every workgroup of the second launch reads 2 bytes per product, so the cost grows with (row blocks x products): the operator pays
+// below a few per cent of the columns; above the measured crossover the caller's dense SpMV is faster and hs_spmspv dispatches to it
+// when it can (hs_api.cpp; hisparse_hip.h says so).
 //   fixed: products rounded / saturated one by one (q8_24_mul), summed exactly in 64 bits, clamped once -- bit-identical to the
 //          saturating PE sum, in any order;
-//   float: one fp32 multiply per product; the sum order is not fixed (LDS atomics, or memory-side ones on the direct path): tolerance
-//          parity like every float path.
+//   float: one fp32 multiply per product, double sums per row block, rounded once: tolerance parity like every float path.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdlib>
@@ -40,23 +39,7 @@ namespace {
 
 constexpr uint32_t kBlockBits = 13;                       // a row block = 8192 rows: 64 KiB of 8-byte LDS accumulators
 constexpr uint32_t kBlockRows = 1u << kBlockBits;
-// The binned path costs ~200 us before the first product (scan, one stream sync, expand, sort, accumulate) and runs one workgroup per
-// 8192-row block; the direct scatter costs ~50 us + 1 us per 20 K products.  Measured (tools/spmspv_probe.py, profiles/r03_spmspv.txt):
-// ogbl-ppa, 4.3 M products: 205 vs 273 us, 21 M: 610 vs 1023 us; 0.4 M: 205 vs 86 us; mouse_gene (6 row blocks): binned slower at any size.
-constexpr uint32_t kSpmspvDirectLimit = 1u << 21;         // fewer products than this: the direct scatter
-constexpr uint32_t kSpmspvMinBlocks = 32;                 // fewer row blocks than this: too little parallelism in the accumulate pass
-
-__global__ __launch_bounds__(256) void spmspv_lengths_kernel(const uint32_t* __restrict__ indptr, const uint32_t* __restrict__ x_index, uint32_t x_count,
-                                                            uint32_t num_cols, uint32_t* __restrict__ len) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > x_count) return;
-    uint32_t n = 0;
-    if (k < x_count) {
-        const uint32_t col = x_index[k];
-        if (col < num_cols) n = indptr[col + 1] - indptr[col];      // (checked on the host as well; never read out of range)
-    }
-    len[k] = n;                                                     // len[x_count] = 0: the exclusive scan leaves the total there
-}
+constexpr uint32_t kIdsPerLoad = 8;                       // block ids a lane reads at once (16 bytes)
 
 template <bool kFloat>
 __device__ __forceinline__ uint32_t product_word(uint32_t value_word, uint32_t x_word) {
@@ -64,163 +47,175 @@ __device__ __forceinline__ uint32_t product_word(uint32_t value_word, uint32_t x
     return q8_24_mul(value_word, x_word);
 }
 
+// counters: [0], [1] = product counts of the calls with even / odd call number (the other one is reset by this call's accumulate
+// kernel, so no memset sits between two calls), [2] = overflow flag (sticky until hs_load_matrix_csc)
 template <bool kFloat>
 __global__ __launch_bounds__(256) void spmspv_expand_kernel(const uint32_t* __restrict__ indptr, const uint32_t* __restrict__ row_indices,
-                                                           const uint32_t* __restrict__ value_words, const uint32_t* __restrict__ x_index,
-                                                           const uint32_t* __restrict__ x_words, uint32_t x_count, uint32_t num_cols,
-                                                           const uint32_t* __restrict__ place, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                           const uint32_t* __restrict__ value_words, const uint2* __restrict__ x_entries, uint32_t x_count,
+                                                           uint32_t num_cols, unsigned long long* __restrict__ counter, unsigned long long* __restrict__ overflow, uint32_t capacity,
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint16_t* __restrict__ blks) {
     const uint32_t lane = threadIdx.x & (kWaveLanes - 1);
     const uint32_t wave = blockIdx.x * (blockDim.x / kWaveLanes) + threadIdx.x / kWaveLanes;
     const uint32_t waves = gridDim.x * (blockDim.x / kWaveLanes);
     for (uint32_t k = wave; k < x_count; k += waves) {
-        const uint32_t col = x_index[k];
-        if (col >= num_cols) continue;
-        const uint32_t xw = x_words[k];
-        const uint32_t lo = indptr[col], hi = indptr[col + 1], at = place[k];
-        for (uint32_t e = lo + lane; e < hi; e += kWaveLanes) {
-            keys[at + (e - lo)] = row_indices[e];
-            vals[at + (e - lo)] = product_word<kFloat>(value_words[e], xw);
-        }
-    }
-}
-
-// One workgroup per row block: its products sit in [first key with key >> 13 >= b, first key with key >> 13 > b) of the binned list.
-template <bool kFloat>
-__global__ __launch_bounds__(1024) void spmspv_accumulate_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t total,
-                                                                uint32_t* __restrict__ y, uint32_t num_rows) {
-    using R = Rows<kFloat>;
-    __shared__ typename R::acc_t acc[kBlockRows];
-    const uint32_t b = blockIdx.x, row0 = b << kBlockBits;
-    for (uint32_t i = threadIdx.x; i < kBlockRows; i += blockDim.x) acc[i] = 0;
-    auto first_at_or_above = [&](uint32_t block) {          // rows are binned by block only: monotone in key >> kBlockBits
-        uint32_t lo = 0, hi = total;
-        while (lo < hi) {
-            const uint32_t mid = lo + (hi - lo) / 2;
-            if ((keys[mid] >> kBlockBits) < block) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-    };
-    const uint32_t begin = first_at_or_above(b), end = first_at_or_above(b + 1);
-    __syncthreads();
-    for (uint32_t i = begin + threadIdx.x; i < end; i += blockDim.x) {
-        const uint32_t local = keys[i] & (kBlockRows - 1u);
-        if (kFloat) R::add(acc, local, __uint_as_float(vals[i]));                          // ds_add_f64 of the fp32 product
-        else atomicAdd(acc + local, static_cast<unsigned long long>(vals[i]));             // ds_add_u64
-    }
-    // no-return LDS atomics can outlive s_waitcnt lgkmcnt(0) (spmv_kernels.hip): a RETURNING atomic per wavefront, awaited
-    const typename R::acc_t flushed = atomicAdd(acc + (threadIdx.x / kWaveLanes), static_cast<typename R::acc_t>(0));
-    asm volatile("" ::"v"(flushed));
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kBlockRows && row0 + i < num_rows; i += blockDim.x) y[row0 + i] = R::finish(acc[i]);
-}
-
-// ---- the direct path for a handful of products ------------------------------------------------------------------------------------
-template <bool kFloat>
-__global__ __launch_bounds__(256) void spmspv_scatter_kernel(const uint32_t* __restrict__ indptr, const uint32_t* __restrict__ row_indices,
-                                                            const uint32_t* __restrict__ value_words, const uint32_t* __restrict__ x_index,
-                                                            const uint32_t* __restrict__ x_words, uint32_t x_count, uint32_t num_cols,
-                                                            unsigned long long* __restrict__ acc64, float* __restrict__ acc32) {
-    const uint32_t lane = threadIdx.x & (kWaveLanes - 1);
-    const uint32_t wave = blockIdx.x * (blockDim.x / kWaveLanes) + threadIdx.x / kWaveLanes;
-    const uint32_t waves = gridDim.x * (blockDim.x / kWaveLanes);
-    for (uint32_t k = wave; k < x_count; k += waves) {
-        const uint32_t col = x_index[k];
-        if (col >= num_cols) continue;
-        const uint32_t xw = x_words[k];
+        const uint2 entry = x_entries[k];                  // IDX_VAL_T { index, val }
+        const uint32_t col = entry.x, xw = entry.y;
+        if (col >= num_cols) continue;                     // (checked on the host where the host holds the entries)
         const uint32_t lo = indptr[col], hi = indptr[col + 1];
+        if (hi == lo) continue;
+        unsigned long long claimed = 0;
+        if (lane == 0) claimed = atomicAdd(counter, static_cast<unsigned long long>(hi - lo));
+        const uint32_t at_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(claimed >> 32));
+        const uint32_t at = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(claimed));
+        if (at_hi != 0 || at > capacity || hi - lo > capacity - at) {    // the list is full (an x with repeated entries can ask for more than nnz products)
+            if (lane == 0) atomicOr(overflow, 1ull);
+            continue;
+        }
         for (uint32_t e = lo + lane; e < hi; e += kWaveLanes) {
             const uint32_t row = row_indices[e];
-            if (kFloat) atomicAdd(acc32 + row, __uint_as_float(value_words[e]) * __uint_as_float(xw));
-            else atomicAdd(acc64 + row, static_cast<unsigned long long>(q8_24_mul(value_words[e], xw)));
+            keys[at + (e - lo)] = row;
+            vals[at + (e - lo)] = product_word<kFloat>(value_words[e], xw);
+            blks[at + (e - lo)] = static_cast<uint16_t>(row >> kBlockBits);
         }
     }
 }
 
-template <bool kFloat>
-__global__ __launch_bounds__(256) void spmspv_finish_kernel(const unsigned long long* __restrict__ acc64, const float* __restrict__ acc32,
-                                                           uint32_t* __restrict__ y, uint32_t num_rows) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= num_rows) return;
-    if (kFloat) y[i] = __float_as_uint(acc32[i]);
-    else y[i] = acc64[i] > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(acc64[i]);      // AP_SAT (pe.h:72)
+// One workgroup per row block.  kAdd: y += (a second pass of a call whose products did not fit the list at once; saturating / fp32 add).
+// The sweep over the block ids and the fetch of the matching products are DECOUPLED through a queue in LDS: a trip of the loop looks at
+// 8192 products (one 16-byte load of ids per lane, the next trip's already in flight) and pushes the indices of its own into the queue;
+// the queue is drained -- row and product word of every entry loaded four at a time, one LDS add each -- only when the next trip might
+// overflow it, and at the end.  (The first version fetched a match where it found it: with 1 product in 71 matching, nearly every one of
+// a lane's 8 ids had SOME lane of the wavefront taking the branch, i.e. 8 dependent load round trips per trip: 179 us for 420 K
+// products, profiles/r04_spmspv.txt.)
+constexpr uint32_t kTripProducts = 1024 * kIdsPerLoad;     // 8192
+constexpr uint32_t kQueueEntries = 2 * kTripProducts;      // 64 KiB: drained when fewer than one trip's worth of room is left
+template <bool kFloat, bool kAdd>
+__global__ __launch_bounds__(1024) void spmspv_accumulate_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                                const uint16_t* __restrict__ blks, const unsigned long long* __restrict__ counter,
+                                                                unsigned long long* __restrict__ counter_next, uint32_t capacity, uint32_t* __restrict__ y,
+                                                                uint32_t num_rows) {
+    using R = Rows<kFloat>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    typename R::acc_t* acc = reinterpret_cast<typename R::acc_t*>(lds);                      // [kBlockRows]
+    uint32_t* queue = reinterpret_cast<uint32_t*>(lds + kBlockRows * sizeof(typename R::acc_t));   // [kQueueEntries]
+    __shared__ uint32_t queued;
+    const uint32_t tid = threadIdx.x, b = blockIdx.x, row0 = b << kBlockBits;
+    const unsigned long long claimed = ((const __attribute__((address_space(4))) unsigned long long*)counter)[0];
+    const uint32_t total = claimed > capacity ? capacity : static_cast<uint32_t>(claimed);      // (beyond the capacity: the overflow flag is up and the call reports it)
+    const uint4* ids4 = reinterpret_cast<const uint4*>(blks);
+    const uint4 none = make_uint4(0, 0, 0, 0);
+    uint4 w = tid * kIdsPerLoad < total ? ids4[tid] : none;      // (the allocation is padded to whole 16-byte words)
+    for (uint32_t i = tid; i < kBlockRows; i += 1024) acc[i] = 0;
+    if (tid == 0) queued = 0;
+    if (b == 0 && tid == 0) *counter_next = 0;             // the next call's counter (nobody reads it before that call's expand kernel)
+    __syncthreads();
+    auto drain = [&](uint32_t n) {
+        for (uint32_t q = tid; q < n; q += 4 * 1024) {
+            uint32_t idx[4], key[4], val[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) idx[k] = queue[min(q + k * 1024u, n - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { key[k] = keys[idx[k]]; val[k] = vals[idx[k]]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (q + k * 1024u >= n) break;
+                const uint32_t local = key[k] & (kBlockRows - 1u);
+                if (kFloat) R::add(acc, local, __uint_as_float(val[k]));                                // ds_add_f64 of the fp32 product
+                else atomicAdd(acc + local, static_cast<unsigned long long>(val[k]));                   // ds_add_u64
+            }
+        }
+    };
+    for (uint32_t base = 0; base < total; base += kTripProducts) {
+        const uint32_t i = base + tid * kIdsPerLoad;
+        const uint4 ahead = i + kTripProducts < total ? ids4[(i + kTripProducts) / kIdsPerLoad] : none;
+        const uint32_t word[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (uint32_t j = 0; j < kIdsPerLoad; ++j) {
+            const uint32_t id = (word[j / 2] >> (16 * (j % 2))) & 0xffffu;
+            if (id == b && i + j < total) queue[atomicAdd(&queued, 1u)] = i + j;      // (ids past `total` are leftovers of earlier calls)
+        }
+        __syncthreads();
+        const uint32_t n = queued;
+        __syncthreads();                                   // everybody has read the count before the next trip's pushes move it
+        if (n > kQueueEntries - kTripProducts || base + kTripProducts >= total) {
+            drain(n);
+            __syncthreads();
+            if (tid == 0) queued = 0;
+            __syncthreads();
+        }
+        w = ahead;
+    }
+    // no-return LDS atomics can outlive s_waitcnt lgkmcnt(0) (spmv_kernels.hip): a RETURNING atomic per wavefront, awaited
+    const typename R::acc_t flushed = atomicAdd(acc + (tid / kWaveLanes), static_cast<typename R::acc_t>(0));
+    asm volatile("" ::"v"(flushed));
+    __syncthreads();
+    for (uint32_t i = tid; i < kBlockRows && row0 + i < num_rows; i += 1024) {
+        uint32_t word = R::finish(acc[i]);
+        if (kAdd) {
+            const uint32_t old = y[row0 + i];
+            if (kFloat) word = __float_as_uint(__uint_as_float(old) + __uint_as_float(word));
+            else word = __builtin_elementwise_add_sat(old, word);      // min(a + b, 2^32-1): saturating sums compose (spmv_kernels.hip: combine)
+        }
+        y[row0 + i] = word;
+    }
 }
 
-uint32_t bits_for(uint32_t n) {       // smallest b with 2^b >= n
-    uint32_t b = 0;
-    while ((uint64_t(1) << b) < n) ++b;
-    return b;
+// x scattered into a dense zero vector (the dense dispatch of hs_spmspv: unique indices only, checked by the caller)
+__global__ __launch_bounds__(256) void spmspv_scatter_x_kernel(const uint2* __restrict__ x_entries, uint32_t x_count, uint32_t num_cols, uint32_t* __restrict__ x_dense) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= x_count) return;
+    const uint2 e = x_entries[k];
+    if (e.x < num_cols) x_dense[e.x] = e.y;
 }
 
 }  // namespace
 
-size_t spmspv_sort_temp_bytes(uint64_t max_elements, uint32_t num_rows) {
-    size_t bytes = 0;
-    uint32_t* k = nullptr;
-    const int end_bit = int(std::max(kBlockBits + 1, bits_for(num_rows)));
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, k, k, size_t(std::max<uint64_t>(max_elements, 1)), int(kBlockBits), end_bit, nullptr);
-    size_t scan = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, k, k, size_t(1) << 24, nullptr);      // (x entries: far fewer than this)
-    return std::max(bytes, scan) + 256;
+size_t spmspv_list_bytes(uint64_t capacity) { return ((size_t(capacity) * 2 + 15) & ~size_t(15)) + 16; }      // the block-id array, padded to whole loads
+
+hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, const hs_idx_val_dev* x_entries,
+                         uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& s, uint32_t call, bool add_to_y, uint32_t* y,
+                         hipStream_t stream) {
+    unsigned long long* counter = s.counters + (call & 1u);
+    unsigned long long* counter_next = s.counters + ((call + 1u) & 1u);
+    const uint32_t capacity = static_cast<uint32_t>(std::min<uint64_t>(s.capacity, 0xffffffffull));
+    const dim3 block(256);
+    if (x_count) {
+        const dim3 grid(std::min<uint32_t>((x_count + 3) / 4, 8192));       // 4 wavefronts per workgroup, one x entry each
+        const uint2* xe = reinterpret_cast<const uint2*>(x_entries);
+        if (is_float)
+            hipLaunchKernelGGL(spmspv_expand_kernel<true>, grid, block, 0, stream, indptr, row_indices, value_words, xe, x_count, num_cols, counter, s.counters + 2,
+                               capacity, s.keys, s.vals, s.blks);
+        else
+            hipLaunchKernelGGL(spmspv_expand_kernel<false>, grid, block, 0, stream, indptr, row_indices, value_words, xe, x_count, num_cols, counter, s.counters + 2,
+                               capacity, s.keys, s.vals, s.blks);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const dim3 grid((num_rows + kBlockRows - 1) / kBlockRows);
+    const uint32_t lds = kBlockRows * 8u + kQueueEntries * 4u;      // accumulators + queue: 128 KiB
+#define X(F, A)                                                                                                                                                  \
+    do {                                                                                                                                                         \
+        static bool configured_on[64] = {};      /* the dynamic-LDS cap is a property of the function, per device */                                            \
+        int dev_ = 0;                                                                                                                                            \
+        (void)hipGetDevice(&dev_);                                                                                                                               \
+        bool& configured = configured_on[dev_ >= 0 && dev_ < 64 ? dev_ : 0];                                                                                     \
+        if (!configured) {                                                                                                                                       \
+            const hipError_t ce = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmspv_accumulate_kernel<F, A>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)); \
+            if (ce != hipSuccess) return ce;                                                                                                                     \
+            configured = true;                                                                                                                                   \
+        }                                                                                                                                                        \
+        hipLaunchKernelGGL((spmspv_accumulate_kernel<F, A>), grid, dim3(1024), lds, stream, s.keys, s.vals, s.blks, counter, counter_next, capacity, y, num_rows); \
+    } while (0)
+    if (is_float) { if (add_to_y) X(true, true); else X(true, false); }
+    else { if (add_to_y) X(false, true); else X(false, false); }
+#undef X
+    return hipGetLastError();
 }
 
-hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, const uint32_t* x_index,
-                         const uint32_t* x_words, uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& s, uint32_t* y,
-                         hipStream_t stream, uint64_t* products_out, const char* force_path) {
-    hipError_t e;
-    uint32_t total = 0;
-    if (x_count) {
-        // 1. where every selected column's products go, and how many there are
-        hipLaunchKernelGGL(spmspv_lengths_kernel, dim3((x_count + 256) / 256), dim3(256), 0, stream, indptr, x_index, x_count, num_cols, s.lengths);
-        size_t temp = s.temp_bytes;
-        if ((e = hipcub::DeviceScan::ExclusiveSum(s.temp, temp, s.lengths, s.place, size_t(x_count) + 1, stream)) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(&total, s.place + x_count, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-        if (total > s.capacity) return hipErrorInvalidValue;      // cannot happen: capacity = the matrix's non-zeros
-    }
-    if (products_out) *products_out = total;
-    const dim3 expand_grid(std::min<uint32_t>((x_count + 3) / 4, 4096)), block(256);       // 4 wavefronts per workgroup, one x entry each
-    const char* force = force_path;      // atomic | binned: force a path (hs_set_option "spmspv" / HISPARSE_SPMSPV; tests, A/B runs)
-    const bool force_direct = force && std::string(force) == "atomic", force_binned = force && std::string(force) == "binned" && total > 0;
-    if (!force_binned && (total < kSpmspvDirectLimit || (num_rows + kBlockRows - 1) / kBlockRows < kSpmspvMinBlocks || force_direct)) {
-        // ---- a handful of products: zero, scatter with memory-side atomics, clamp / copy -----------------------------------------
-        if ((e = hipMemsetAsync(s.accumulators, 0, size_t(num_rows) * (is_float ? 4 : 8), stream)) != hipSuccess) return e;
-        if (total) {
-            if (is_float)
-                hipLaunchKernelGGL(spmspv_scatter_kernel<true>, expand_grid, block, 0, stream, indptr, row_indices, value_words, x_index, x_words, x_count,
-                                   num_cols, nullptr, static_cast<float*>(s.accumulators));
-            else
-                hipLaunchKernelGGL(spmspv_scatter_kernel<false>, expand_grid, block, 0, stream, indptr, row_indices, value_words, x_index, x_words, x_count,
-                                   num_cols, static_cast<unsigned long long*>(s.accumulators), nullptr);
-        }
-        const dim3 grid((num_rows + 255) / 256);
-        if (is_float) hipLaunchKernelGGL(spmspv_finish_kernel<true>, grid, block, 0, stream, nullptr, static_cast<const float*>(s.accumulators), y, num_rows);
-        else hipLaunchKernelGGL(spmspv_finish_kernel<false>, grid, block, 0, stream, static_cast<const unsigned long long*>(s.accumulators), nullptr, y, num_rows);
-        return hipGetLastError();
-    }
-    // 2. expand
-    if (is_float)
-        hipLaunchKernelGGL(spmspv_expand_kernel<true>, expand_grid, block, 0, stream, indptr, row_indices, value_words, x_index, x_words, x_count, num_cols,
-                           s.place, s.keys[0], s.vals[0]);
-    else
-        hipLaunchKernelGGL(spmspv_expand_kernel<false>, expand_grid, block, 0, stream, indptr, row_indices, value_words, x_index, x_words, x_count, num_cols,
-                           s.place, s.keys[0], s.vals[0]);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    // 3. bin by row block (the high bits of the row only; a matrix of at most one block needs no binning)
-    const uint32_t* keys = s.keys[0];
-    const uint32_t* vals = s.vals[0];
-    const uint32_t row_bits = bits_for(num_rows);
-    if (row_bits > kBlockBits) {
-        size_t temp = s.temp_bytes;
-        if ((e = hipcub::DeviceRadixSort::SortPairs(s.temp, temp, s.keys[0], s.keys[1], s.vals[0], s.vals[1], size_t(total), int(kBlockBits), int(row_bits),
-                                                    stream)) != hipSuccess)
-            return e;
-        keys = s.keys[1];
-        vals = s.vals[1];
-    }
-    // 4. accumulate per row block and write y
-    const dim3 grid((num_rows + kBlockRows - 1) / kBlockRows);
-    if (is_float) hipLaunchKernelGGL(spmspv_accumulate_kernel<true>, grid, dim3(1024), 0, stream, keys, vals, total, y, num_rows);
-    else hipLaunchKernelGGL(spmspv_accumulate_kernel<false>, grid, dim3(1024), 0, stream, keys, vals, total, y, num_rows);
+hipError_t launch_spmspv_scatter_x(const hs_idx_val_dev* x_entries, uint32_t x_count, uint32_t num_cols, uint32_t* x_dense, hipStream_t stream) {
+    const hipError_t e = hipMemsetAsync(x_dense, 0, size_t(num_cols) * 4, stream);
+    if (e != hipSuccess || x_count == 0) return e;
+    hipLaunchKernelGGL(spmspv_scatter_x_kernel, dim3((x_count + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const uint2*>(x_entries), x_count, num_cols, x_dense);
     return hipGetLastError();
 }
 

@@ -90,24 +90,25 @@ hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_
                                  uint32_t row_hi, hipStream_t stream, uint32_t* x_fb = nullptr, uint32_t n_fb = 0, uint32_t scale = 0,
                                  uint32_t shift = 0);
 
-// SpMSpV extension (spmspv.hip): y = A x for x given as x_count (index, value word) pairs over a CSC matrix.  The selected columns'
-// products are expanded into a (row, product) list, binned by row block and accumulated in LDS (no global atomics); a handful of
-// products goes through a direct scatter instead.  Scratch, owned by the caller (hs_api.cpp):
+// SpMSpV extension (spmspv.hip): y = A x for x given as x_count IDX_VAL_T pairs ON THE DEVICE over a CSC matrix.  Two launches: the
+// selected columns' products are expanded into a (row, product, row block) list -- one atomic per column on a device counter gives it its
+// place -- and one workgroup per block of 8192 rows accumulates its own in LDS and writes its rows of y.  No scan, no sort, no host
+// synchronisation.  Scratch, owned by the caller (hs_api.cpp):
+struct hs_idx_val_dev { uint32_t index, val; };      // == hs_idx_val (hisparse_hip.h), IDX_VAL_T of spmv/libfpga/common.h:54
 struct SpmspvScratch {
-    uint32_t* keys[2] = {nullptr, nullptr};     // [capacity] rows of the expanded products, and the binned copy
-    uint32_t* vals[2] = {nullptr, nullptr};     // [capacity] product words
-    uint64_t capacity = 0;                      // = the matrix's non-zeros
-    uint32_t* lengths = nullptr;                // [x capacity + 1] selected column lengths ...
-    uint32_t* place = nullptr;                  // ... and their exclusive scan
-    void* temp = nullptr;                       // hipCUB temporary storage (spmspv_sort_temp_bytes)
-    size_t temp_bytes = 0;
-    void* accumulators = nullptr;               // num_rows x 8 bytes (fixed) / 4 bytes (float): the direct path's global accumulators
+    uint32_t* keys = nullptr;                   // [capacity] rows of the expanded products
+    uint32_t* vals = nullptr;                   // [capacity] product words
+    uint16_t* blks = nullptr;                   // [capacity, padded: spmspv_list_bytes] row block of every product
+    uint64_t capacity = 0;                      // = the matrix's non-zeros (x without repeated entries never needs more)
+    unsigned long long* counters = nullptr;     // [0], [1]: product count of even / odd calls (zeroed at allocation, then by the kernels); [2]: overflow flag
 };
-size_t spmspv_sort_temp_bytes(uint64_t max_elements, uint32_t num_rows);
-// products_out (may be null): how many products the call formed.  Synchronises the stream once (the product count sizes the passes).
-hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, const uint32_t* x_index,
-                         const uint32_t* x_words, uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& scratch, uint32_t* y,
-                         hipStream_t stream, uint64_t* products_out = nullptr, const char* force_path = nullptr);
+size_t spmspv_list_bytes(uint64_t capacity);
+// call: the context's SpMSpV call number (picks the counter).  add_to_y: y += instead of y = (further passes of one call).
+hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, const hs_idx_val_dev* x_entries,
+                         uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& scratch, uint32_t call, bool add_to_y, uint32_t* y,
+                         hipStream_t stream);
+// x_dense[0, num_cols) = 0, then x_dense[index] = val for every entry (hs_spmspv's dense dispatch)
+hipError_t launch_spmspv_scatter_x(const hs_idx_val_dev* x_entries, uint32_t x_count, uint32_t num_cols, uint32_t* x_dense, hipStream_t stream);
 
 // Multi-GPU gather without a collective: y[0, words) into n_dst <= kMaxPushTargets other buffers (peers' memory over xGMI) with plain stores.
 constexpr uint32_t kMaxPushTargets = 8;

@@ -280,7 +280,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     const uint64_t per_round = std::max<uint32_t>(1, G / slices);
     const uint64_t rounds = std::max<uint64_t>(1, ((uint64_t(num_rows) + max_rows - 1) / max_rows + per_round - 1) / per_round);
     const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(per_round * rounds, out.nnz / (light ? kLightMinBlockNnz : 4096u)));
-    build_row_ranges_at_most(L, row_nnz, out.nnz, want_ranges, max_rows, ranges, range_nnz);
+    build_row_ranges_at_most(L, row_nnz, out.nnz, want_ranges, max_rows, ranges, range_nnz, out.nnz / 4096 >= per_round * rounds ? per_round : 0);
     const uint32_t NR = uint32_t(ranges.size());
     std::vector<uint32_t> block_of_row(num_rows);   // row -> row range
     for (uint32_t b = 0; b < NR; ++b) {

@@ -366,8 +366,17 @@ inline void build_row_ranges(const Layout& L, const std::vector<uint32_t>& row_n
 // At most `want` ranges if the row cap allows it: the greedy cut above can leave one small extra range per row partition,
 // and one range too many means one workgroup with two blocks -- twice the kernel time.  The target is raised in small steps
 // until the count fits (or the cap on rows per range makes that impossible).
+// round_to (0: off): when the row cap forces MORE ranges than wanted -- float_pob's 131 072-row partitions under a 24 561-row block cap:
+// 19 x 6 = 114 ranges on ogbn-products where 2 x 51 were wanted -- the count is raised to the next multiple of round_to (the ranges one
+// round of workgroups takes), so that every workgroup gets the same number of (smaller) blocks instead of a third of them one block more:
+// 570 blocks over 256 workgroups ran 335.7 us, the round-3 figure of the same matrix in float_stall's 3 partitions 206.8 (round 4).
 inline void build_row_ranges_at_most(const Layout& L, const std::vector<uint32_t>& row_nnz, uint64_t nnz, uint64_t want, uint32_t max_rows,
-                                     std::vector<RowRange>& ranges, std::vector<uint64_t>& range_nnz) {
+                                     std::vector<RowRange>& ranges, std::vector<uint64_t>& range_nnz, uint64_t round_to = 0) {
+    if (round_to) {
+        uint64_t by_cap = 0;
+        for (uint32_t rp = 0; rp < L.row_parts; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + max_rows - 1) / max_rows;
+        if (by_cap > want) want = (by_cap + round_to - 1) / round_to * round_to;
+    }
     uint64_t target = std::max<uint64_t>(1, (nnz + want - 1) / want);
     for (int attempt = 0; attempt < 64; ++attempt) {
         ranges.clear();

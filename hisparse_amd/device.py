@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
     "hs_load_matrix_csr", "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
-    "hs_bind_device_vector", "hs_bind_device_result", "hs_push_result", "hs_set_option", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_read_spmspv_result", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_debug_read_mfma_image", "hs_tiles_build", "hs_tiles_info",
+    "hs_bind_device_vector", "hs_bind_device_result", "hs_push_result", "hs_set_option", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_spmspv_device", "hs_read_spmspv_result", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_debug_read_mfma_image", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
 
@@ -81,6 +81,7 @@ def lib():
         l.hs_iterate.argtypes = [vp, u32, u32, u32]
         l.hs_load_matrix_csc.argtypes = [vp, vp, vp, vp, u32, u32]
         l.hs_spmspv.argtypes = [vp, vp, u32]
+        l.hs_spmspv_device.argtypes = [vp, vp, u32]
         l.hs_read_spmspv_result.argtypes = [vp, vp, u32]
         l.hs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -261,6 +262,22 @@ class SpmvEngine:
         pairs[:, 0] = x_index
         pairs[:, 1] = x_words
         self._check(lib().hs_spmspv(self._h, pairs.ctypes.data if pairs.size else None, len(x_index)))
+        y = np.empty(self.csc_rows, dtype=np.uint32)
+        self._check(lib().hs_read_spmspv_result(self._h, y.ctypes.data, y.size))
+        return y
+
+    def spmspv_async(self, x_index, x_words):
+        """hs_spmspv without reading y back (asynchronous): for timing loops; read_spmspv_result() fetches the last result."""
+        pairs = np.empty((len(x_index), 2), dtype=np.uint32)
+        pairs[:, 0] = x_index
+        pairs[:, 1] = x_words
+        self._check(lib().hs_spmspv(self._h, pairs.ctypes.data if pairs.size else None, len(x_index)))
+
+    def spmspv_device(self, pairs_dev, count):
+        """hs_spmspv_device: `count` IDX_VAL_T pairs already in device memory (pointer as int)."""
+        self._check(lib().hs_spmspv_device(self._h, C.c_void_p(pairs_dev), count))
+
+    def read_spmspv_result(self):
         y = np.empty(self.csc_rows, dtype=np.uint32)
         self._check(lib().hs_read_spmspv_result(self._h, y.ctypes.data, y.size))
         return y

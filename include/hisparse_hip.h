@@ -158,14 +158,27 @@ int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32
  * y = A x for a SPARSE x: only the columns named by x's entries are read.
  *   hs_load_matrix_csc: CSCMatrix arrays (indptr[num_cols + 1], row index and value word per non-zero, value words in the context's
  *     numeric mode: hsf_csr_to_csc), independent of the matrix hs_load_matrix holds; validated, copied to the device.
- *   hs_spmspv: x as `count` IDX_VAL_T pairs (each column at most once for the float modes' tolerance to mean anything; repeated
- *     entries simply add up).  Asynchronous.  The result is a dense packed y of num_rows words: hs_read_spmspv_result.
+ *   hs_spmspv: x as `count` IDX_VAL_T pairs in HOST memory.  Asynchronous: the pairs are copied through a pinned staging buffer of the
+ *     context (the call returns once they are in it), two kernels follow on the context's stream -- EXPAND (one wavefront per entry writes
+ *     its column's products into a list: one atomic per COLUMN claims the room) and ACCUMULATE (one workgroup per 8192 rows adds its own
+ *     products in LDS and writes its rows) -- no scan, no sort, no host synchronisation.  The result is a dense packed y of num_rows words:
+ *     hs_read_spmspv_result.  An entry may name a column more than once (the products simply add up); a call whose products exceed the
+ *     matrix's non-zero count is cut into passes.
+ *     CROSSOVER: every row block's workgroup sweeps the whole product list, so the operator pays for a few per cent of the columns at most.
+ *     Above `spmspv_crossover` (hs_set_option; default 0.02 = 2 % of the columns, measured on ogbl-ppa: profiles/r04_spmspv.txt; 0 = never)
+ *     hs_spmspv runs the DENSE SpMV instead -- x scattered into a zero vector, one hs_run -- which is faster there, PROVIDED hs_load_matrix /
+ *     hs_load_matrix_csr of this context holds the same matrix (same shape after padding; that it IS the same matrix is the caller's
+ *     contract) and x names no column twice.  Otherwise the sparse path runs whatever the size.
+ *   hs_spmspv_device: the same with the pairs already in DEVICE memory (8-byte aligned): nothing but the two launches.  No index check
+ *     (out-of-range columns are ignored), no dense dispatch, and the products must fit the list (true whenever no column is named twice);
+ *     otherwise hs_read_spmspv_result reports HS_ERR_BAD_ARG.
  * Arithmetic as in hs_run: fixed = saturating sum of individually rounded / saturated products (bit-exact, order free);
- * float = fp32 products added in fp32 in arrival order (tolerance). */
+ * float = fp32 products summed in double per row block, rounded once (tolerance). */
 typedef struct { uint32_t index; uint32_t val; } hs_idx_val;    /* IDX_VAL_T, spmv/libfpga/common.h:54 */
 int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, uint32_t num_rows,
                        uint32_t num_cols);
 int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count);
+int hs_spmspv_device(hs_context* ctx, const hs_idx_val* x_entries_dev, uint32_t count);
 int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows);
 
 /* ---- load straight from CSR (EXTENSION, SURVEY.md section 8(f)-1: the pre-processing on the GPU) ------------------------------------

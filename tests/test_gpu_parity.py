@@ -54,7 +54,8 @@ def _run_case(impl, m, vb, ob, skip, seed):
     eng.close()
     assert stats["nnz"] == m.nnz
     sub_tiles = cp.num_col_partitions * max(1, -(-(8 * cp.vb_bank) // 8192))      # column partitions x sub-tiles of 8192 columns per partition
-    assert stats["light_kernel"] == (1 if os.environ.get("HISPARSE_LIGHT") == "1" and sub_tiles <= 16 and m.nnz > 0 else 0)
+    sliced = os.environ.get("HISPARSE_COL_SLICES", "1") not in ("", "1")      # a forced sliced plan is the row-block kernel's
+    assert stats["light_kernel"] == (1 if os.environ.get("HISPARSE_LIGHT") == "1" and sub_tiles <= 16 and m.nnz > 0 and not sliced else 0)
     forced = os.environ["HISPARSE_STREAM_FORMAT"]
     if forced == "owner" and impl == 0:
         forced = "pairs"                 # the 8-byte OWNER form is float only (fixed point: OWNER24 with saturating 32-bit accumulators)

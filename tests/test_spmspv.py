@@ -60,14 +60,13 @@ def test_csc_conversion_and_oracle_against_the_spmv_oracle(impl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", ["atomic", "binned", "auto"])
+@pytest.mark.parametrize("path", ["sparse", "dense", "auto"])
 @pytest.mark.parametrize("impl", [0, 1, 2])
 @pytest.mark.parametrize("rows,cols,density,x_nnz", [(700, 500, 0.03, 60), (40000, 30000, 0.002, 3000), (3000, 9000, 0.05, 1), (2000, 2000, 0.2, 2000),
                                                      (400000, 60000, 3.3e-4, 30000)])
 def test_device_spmspv_matches_oracle_and_dense_spmv(impl, rows, cols, density, x_nnz, path, monkeypatch):
-    # both device paths on every case: the direct scatter (memory-side atomics) and the binned row-owner path (expand -> bin by row
-    # block -> LDS accumulate, no global atomics); "auto" = the library's own choice (the last case, 4 M products over 49 row blocks,
-    # is the one it sends down the binned path)
+    # "sparse": the two-launch path (expand into the product list, one workgroup per row block accumulates its own) whatever the size;
+    # "dense": the dispatch to the dense SpMV of the same matrix loaded on the same context; "auto": the library's choice by the crossover
     if path == "auto":
         monkeypatch.delenv("HISPARSE_SPMSPV", raising=False)
     else:
@@ -75,6 +74,8 @@ def test_device_spmspv_matches_oracle_and_dense_spmv(impl, rows, cols, density, 
     m, csr, (indptr, ridx, words), xi, xv, xw = _case(impl, rows, cols, density, 9, x_nnz)
     want = orc.spmspv(impl, indptr, ridx, words, rows, cols, xi, xw)
     with device.SpmvEngine(impl) as eng:
+        if path != "sparse":
+            eng.load_matrix_csr(csr)                   # the same matrix for the dense dispatch
         eng.load_matrix_csc(indptr, ridx, words, rows)
         got = eng.spmspv(xi, xw)
         again = eng.spmspv(xi, xw)                 # accumulators are re-armed every call
@@ -88,6 +89,63 @@ def test_device_spmspv_matches_oracle_and_dense_spmv(impl, rows, cols, density, 
             assert np.array_equal(got, _dense_spmv_oracle(m, impl, xi, xv))
     else:
         assert cases.float_close(got, want) and cases.float_close(again, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl", [0, 1])
+def test_repeated_entries_add_up_and_oversized_calls_are_split(impl):
+    # a column named several times is legal (its products simply add up) and makes the product count exceed the matrix's
+    # non-zeros -- the list's capacity.  hs_spmspv cuts such a call into passes (y =, then y +=); every column four times here.
+    rows, cols = 30000, 2000
+    m, csr, (indptr, ridx, words), xi, xv, xw = _case(impl, rows, cols, 0.01, 4, cols)
+    xi4 = np.concatenate([xi, xi[::-1], xi, xi]).astype(np.uint32)
+    rng = np.random.default_rng(1)
+    xw4 = host.pack_vector(impl, cases.random_x(len(xi4), 6, impl) * (0.25 if impl == 0 else 1.0))
+    want = orc.spmspv(impl, indptr, ridx, words, rows, cols, xi4, xw4)
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix_csr(csr)                       # a dense matrix is there, but repeats rule the dense dispatch out
+        eng.load_matrix_csc(indptr, ridx, words, rows)
+        got = eng.spmspv(xi4, xw4)
+        few = eng.spmspv(xi4[:3], xw4[:3])             # and a small call afterwards starts from a clean list
+    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+    want_few = orc.spmspv(impl, indptr, ridx, words, rows, cols, xi4[:3], xw4[:3])
+    assert np.array_equal(few, want_few) if impl == 0 else cases.float_close(few, want_few)
+
+
+@pytest.mark.gpu
+def test_device_resident_entries_and_the_overflow_report():
+    import ctypes as C
+    impl, rows, cols = 0, 50000, 40000
+    m, csr, (indptr, ridx, words), xi, xv, xw = _case(impl, rows, cols, 0.001, 12, 500)
+    pairs = np.empty((len(xi), 2), dtype=np.uint32)
+    pairs[:, 0], pairs[:, 1] = xi, xw
+    want = orc.spmspv(impl, indptr, ridx, words, rows, cols, xi, xw)
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix_csc(indptr, ridx, words, rows)
+        every = np.empty((cols * 3, 2), dtype=np.uint32)          # every column three times: 3 x nnz products, more than the list holds
+        every[:, 0] = np.tile(np.arange(cols, dtype=np.uint32), 3)
+        every[:, 1] = host.pack_vector(impl, np.full(cols * 3, 0.001, dtype=np.float32))
+        d = C.c_void_p()
+        assert rt.hipMalloc(C.byref(d), every.nbytes) == 0
+        try:
+            assert rt.hipMemcpy(d, pairs.ctypes.data, pairs.nbytes, 1) == 0
+            for _ in range(3):                                     # nothing but the two launches per call; the counters re-arm themselves
+                eng.spmspv_device(d.value, len(xi))
+            assert np.array_equal(eng.read_spmspv_result(), want)
+            assert rt.hipMemcpy(d, every.ctypes.data, every.nbytes, 1) == 0
+            eng.spmspv_device(d.value, cols * 3)
+            with pytest.raises(device.DeviceError) as e:
+                eng.read_spmspv_result()
+            assert "more products" in str(e.value)
+            assert rt.hipMemcpy(d, pairs.ctypes.data, pairs.nbytes, 1) == 0
+            eng.spmspv_device(d.value, len(xi))                    # the flag is cleared, the next call is fine
+            assert np.array_equal(eng.read_spmspv_result(), want)
+        finally:
+            rt.hipFree(d)
 
 
 @pytest.mark.gpu

@@ -142,7 +142,7 @@ def test_format_choice(monkeypatch):
     monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
     for rows, cols, nnz, want in [(20000, 60000, 150000, "pairs"),       # right gap, but a 1 MB image: nothing to save
                                   (40000, 40000, 16000000, "delta"),     # 128 MB in PAIRS, 100 MB in DELTA
-                                  (60000, 90000, 100000, "owner")]:      # hyper-sparse: OWNER24 (fixed point: saturating 32-bit accumulators)
+                                  (300000, 400000, 200000, "owner")]:    # hyper-sparse, too wide for the LIGHT plan (52 sub-tiles): OWNER24 (fixed point: saturating 32-bit accumulators)
         csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=nnz, b=0.0, c=1.0, seed=2)
         cp = host.format_matrix(csr, 0, skip_empty_rows=True)
         t = build(cp, 0, 16)
@@ -368,6 +368,7 @@ def test_owner_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypa
     """Hyper-sparse float matrices pick the OWNER format: float accumulators, wavefront-private rows (checked inside the emulator:
     sorted lane-major runs, one owner per row, padding at the wavefront's spare accumulator); y matches the oracle."""
     monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    monkeypatch.setenv("HISPARSE_LIGHT", "0")      # (matrices this small would take the LIGHT plan: the choice among the row-block kernel's formats is what is tested)
     if slices:
         monkeypatch.setenv("HISPARSE_COL_SLICES", str(slices))
     csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=nnz, b=0.5, c=2.0, seed=12)
@@ -476,6 +477,7 @@ def test_plans_of_small_and_narrow_matrices(monkeypatch):
     cost shrinks with the units per block."""
     for k in ("HISPARSE_STREAM_FORMAT", "HISPARSE_COL_SLICES", "HISPARSE_MAX_ROWS"):
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("HISPARSE_LIGHT", "0")      # the second case (1.4 M non-zeros) would take the LIGHT plan: these are the row-block kernel's plans
     # one rank's slab of mouse_gene split 4 ways: 6 live sub-tiles -> 6 slices (15-27 us in one slice, 13.3-13.9 in six)
     csr = host.CSRMatrix.generate("powerlaw", 11264, 45101, a=7.2e6, b=0.30, c=0.1, seed=44)
     cp = host.format_matrix(csr, 0, skip_empty_rows=True)
@@ -496,3 +498,13 @@ def test_plans_of_small_and_narrow_matrices(monkeypatch):
     csr = host.CSRMatrix.generate("powerlaw", 60000, 300000, a=3.0e6, b=0.3, c=1.0, seed=9)
     cp = host.format_matrix(csr, 0, skip_empty_rows=True)
     assert build(cp, 0, 256)["col_slices"] in (1, 2, 4, 8)
+    # round 4: without the switch the 1.4 M non-zero matrix takes the LIGHT plan -- one slice, up to 4 blocks per CU, strided dealing,
+    # the image an ordinary PAIRS image (the emulator runs it with the row-block kernel's dealing: same sums)
+    monkeypatch.delenv("HISPARSE_LIGHT")
+    csr = host.CSRMatrix.generate("powerlaw", 107614, 107614, a=1.4e6, b=0.35, c=1.0, seed=7)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+    t = build(cp, 0, 256)
+    assert t["format"] == "pairs" and t["col_slices"] == 1 and 256 < len(t["blocks"]) <= 1024 and t["max_block_rows"] <= 3071
+    assert not (t["blocks"]["flags"] & 1).any()
+    xw = host.pack_vector(0, cases.random_x(cp.num_cols, 4, 0))
+    assert np.array_equal(tile_emulator.run(t, 0, xw, cp.num_rows), oracle_y(cp, 0, xw))

@@ -194,7 +194,9 @@ def _block_bitmap(image, blk, units, x_words, ys, is_float):
             assert (col < x_words.size).all()
             _accumulate(ys, is_float, np.full(n, r, dtype=np.int64), values[vp: vp + n], x_words[col])
             vp += n
-    assert (covered == 1).all()                                       # every (row, group) of the block belongs to exactly one wavefront
+    # every (row, group) of the block belongs to exactly one wavefront -- or to none at all: a block made of the matrix's empty padding rows
+    # (float_stall rounds the rows up to a multiple of 1024) has sixteen idle runs and only writes its rows' zeros (bitmap_tiles.cpp, round 4)
+    assert (covered == 1).all() or (covered == 0).all()
 
 
 def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
