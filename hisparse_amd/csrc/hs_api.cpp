@@ -81,6 +81,7 @@ struct hs_context {
     uint32_t* d_x_dense = nullptr;                 // dense dispatch: x scattered into a zero vector (num_cols words)
     uint32_t csc_rows = 0, csc_cols = 0;
     uint64_t csc_nnz = 0;
+    double dense_spmv_us = 0.0;                    // the dense SpMV of the loaded matrix, timed once (hs_spmspv's dispatch rule); 0: not yet
     uint64_t spmspv_dense_dispatches = 0;          // calls of hs_spmspv answered by the dense SpMV (hs_get_stats does not carry it: tests read it through hs_last_error)
 
     uint32_t* d_x = nullptr;       // library-owned packed x
@@ -442,6 +443,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     ctx->ring_buffers = tiles.ring_buffers;
     ctx->format = tiles.format;
     ctx->light = tiles.light;
+    ctx->dense_spmv_us = 0.0;
     ctx->matrix_loaded = true;
 
     hs_stats& s = ctx->stats;
@@ -647,6 +649,7 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* 
     ctx->csc_rows = num_rows;
     ctx->csc_cols = num_cols;
     ctx->csc_nnz = nnz;
+    ctx->dense_spmv_us = 0.0;
     ctx->spmspv_call = 0;
     return HS_OK;
 }
@@ -736,13 +739,51 @@ int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
         HS_HIP(ctx, hipMemcpyAsync(ctx->d_sx, ctx->h_sx, size_t(count) * sizeof(hs_idx_val), hipMemcpyHostToDevice, ctx->stream));
         HS_HIP(ctx, hipEventRecord(ctx->sx_copied, ctx->stream));
     }
-    // above the crossover the dense SpMV is faster (it reads every non-zero once, coalesced; the sparse path makes every row block's
-    // workgroup sweep the whole product list): hisparse_hip.h
-    double crossover = 0.02;
-    if (const char* v = ctx_option(ctx, "HISPARSE_SPMSPV_CROSSOVER")) crossover = std::atof(v);
+    // Above the crossover the dense SpMV is faster (it reads every non-zero once, coalesced; on the sparse path every row block's
+    // workgroup sweeps the whole product list): hisparse_hip.h.  The host knows this call's product count exactly (the columns' lengths),
+    // the sparse path costs ~12 us + products / 5 G/s (profiles/r04_spmspv.txt: ogbl-ppa, mouse_gene, pokec), and the dense SpMV of the
+    // loaded matrix is TIMED once, on the first call that could use it (three launches on a zero vector and one synchronisation; hyper-
+    // sparse matrices run at a third of the roofline, so no formula over the non-zero count would do).  `spmspv_crossover` (a fraction of
+    // the columns) overrides the rule; `spmspv` = sparse | dense forces a path.
+    uint64_t products = 0;
+    for (uint32_t k = 0; k < count; ++k) products += ctx->csc_col_len[x_entries[k].index];
     const char* force = ctx_option(ctx, "HISPARSE_SPMSPV");
-    const bool want_dense = force ? std::string(force) == "dense" : (crossover > 0.0 && double(count) > crossover * double(ctx->csc_cols));
-    if (want_dense && !repeats && dense_dispatch_possible(ctx)) return spmspv_dense(ctx, ctx->d_sx, count);
+    const bool possible = !repeats && dense_dispatch_possible(ctx);
+    bool want_dense = false;
+    if (force) {
+        want_dense = std::string(force) == "dense";
+    } else if (const char* v = ctx_option(ctx, "HISPARSE_SPMSPV_CROSSOVER")) {
+        const double crossover = std::atof(v);
+        want_dense = crossover > 0.0 && double(count) > crossover * double(ctx->csc_cols);
+    } else if (possible && 12.0 + double(products) / 5000.0 > 30.0) {      // (below 30 us no dense SpMV of a matrix worth a CSC copy competes)
+        if (ctx->dense_spmv_us <= 0.0) {
+            if (!ctx->d_x_dense) {
+                HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_x_dense), size_t(ctx->num_cols) * 4));
+                HS_HIP(ctx, hipMemsetAsync(ctx->d_x_dense, 0, size_t(ctx->num_cols) * 4, ctx->stream));
+            }
+            const uint32_t* saved_x = ctx->x_bound;
+            uint32_t* saved_y = ctx->y_bound;
+            ctx->x_bound = ctx->d_x_dense;
+            ctx->y_bound = ctx->d_csc_y;
+            int rc = enqueue(ctx, -1, nullptr, nullptr);      // warm, then three timed
+            hipEvent_t t0 = nullptr, t1 = nullptr;
+            if (rc == HS_OK && hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) {
+                (void)hipEventRecord(t0, ctx->stream);
+                for (int i = 0; i < 3 && rc == HS_OK; ++i) rc = enqueue(ctx, -1, nullptr, nullptr);
+                (void)hipEventRecord(t1, ctx->stream);
+                float ms = 0.0f;
+                if (rc == HS_OK && hipEventSynchronize(t1) == hipSuccess && hipEventElapsedTime(&ms, t0, t1) == hipSuccess) ctx->dense_spmv_us = std::max(1.0, double(ms) * 1000.0 / 3.0);
+            }
+            if (t0) (void)hipEventDestroy(t0);
+            if (t1) (void)hipEventDestroy(t1);
+            ctx->x_bound = saved_x;
+            ctx->y_bound = saved_y;
+            if (rc != HS_OK) return rc;
+        }
+        // + the scatter of x into the zero vector (a memset and a small kernel: ~8 us)
+        want_dense = ctx->dense_spmv_us > 0.0 && 12.0 + double(products) / 5000.0 > ctx->dense_spmv_us + 8.0;
+    }
+    if (want_dense && possible) return spmspv_dense(ctx, ctx->d_sx, count);
     uint32_t begin = 0;
     for (size_t i = 0; i < pass_end.size(); ++i) {
         const int rc = spmspv_pass(ctx, ctx->d_sx + begin, pass_end[i] - begin, i != 0);

@@ -37,9 +37,11 @@ namespace dev {
 
 namespace {
 
-constexpr uint32_t kBlockBits = 13;                       // a row block = 8192 rows: 64 KiB of 8-byte LDS accumulators
-constexpr uint32_t kBlockRows = 1u << kBlockBits;
+constexpr uint32_t kMaxBlockBits = 13;                    // a row block = at most 8192 rows: 64 KiB of 8-byte LDS accumulators
+constexpr uint32_t kMinBlockBits = 9;
 constexpr uint32_t kIdsPerLoad = 8;                       // block ids a lane reads at once (16 bytes)
+constexpr uint32_t kExpandColumns = 64;                   // x entries per workgroup of the expand kernel
+constexpr uint32_t kExpandThreads = 256;
 
 template <bool kFloat>
 __device__ __forceinline__ uint32_t product_word(uint32_t value_word, uint32_t x_word) {
@@ -48,67 +50,115 @@ __device__ __forceinline__ uint32_t product_word(uint32_t value_word, uint32_t x
 }
 
 // counters: [0], [1] = product counts of the calls with even / odd call number (the other one is reset by this call's accumulate
-// kernel, so no memset sits between two calls), [2] = overflow flag (sticky until hs_load_matrix_csc)
+// kernel, so no memset sits between two calls), [2] = overflow flag (sticky until hs_read_spmspv_result reports it)
+//
+// EXPAND.  A workgroup takes 64 entries of x: lane c of its first wavefront reads entry c's column length, a DPP prefix sum places the 64
+// columns' products behind each other, ONE atomic on the device counter claims the room for all of them (an atomic per column was the
+// first version: 5762 atomics on one address took 115 of the 142 us of a 1 % selection of ogbl-ppa), and then all 256 threads walk the
+// workgroup's products FLAT -- product p belongs to the column whose prefix range holds p (binary search over the 65 prefix sums in LDS) --
+// so that a hub column of 60 K entries is spread over the workgroup like everything else and every store is coalesced.
 template <bool kFloat>
-__global__ __launch_bounds__(256) void spmspv_expand_kernel(const uint32_t* __restrict__ indptr, const uint32_t* __restrict__ row_indices,
-                                                           const uint32_t* __restrict__ value_words, const uint2* __restrict__ x_entries, uint32_t x_count,
-                                                           uint32_t num_cols, unsigned long long* __restrict__ counter, unsigned long long* __restrict__ overflow, uint32_t capacity,
-                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint16_t* __restrict__ blks) {
-    const uint32_t lane = threadIdx.x & (kWaveLanes - 1);
-    const uint32_t wave = blockIdx.x * (blockDim.x / kWaveLanes) + threadIdx.x / kWaveLanes;
-    const uint32_t waves = gridDim.x * (blockDim.x / kWaveLanes);
-    for (uint32_t k = wave; k < x_count; k += waves) {
-        const uint2 entry = x_entries[k];                  // IDX_VAL_T { index, val }
-        const uint32_t col = entry.x, xw = entry.y;
-        if (col >= num_cols) continue;                     // (checked on the host where the host holds the entries)
-        const uint32_t lo = indptr[col], hi = indptr[col + 1];
-        if (hi == lo) continue;
-        unsigned long long claimed = 0;
-        if (lane == 0) claimed = atomicAdd(counter, static_cast<unsigned long long>(hi - lo));
-        const uint32_t at_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(claimed >> 32));
-        const uint32_t at = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(claimed));
-        if (at_hi != 0 || at > capacity || hi - lo > capacity - at) {    // the list is full (an x with repeated entries can ask for more than nnz products)
-            if (lane == 0) atomicOr(overflow, 1ull);
-            continue;
+__global__ __launch_bounds__(kExpandThreads) void spmspv_expand_kernel(const uint32_t* __restrict__ indptr, const uint32_t* __restrict__ row_indices,
+                                                                      const uint32_t* __restrict__ value_words, const uint2* __restrict__ x_entries,
+                                                                      uint32_t x_count, uint32_t num_cols, unsigned long long* __restrict__ counter,
+                                                                      unsigned long long* __restrict__ overflow, uint32_t capacity, uint32_t block_bits,
+                                                                      uint32_t columns, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                                      uint16_t* __restrict__ blks) {
+    // columns (<= 64): entries of x per workgroup -- 64 when x has thousands of entries, fewer when it has few, so that a handful of LONG
+    // columns (mouse_gene: 22 columns of 640 non-zeros) is still spread over many workgroups
+    __shared__ uint32_t s_lo[kExpandColumns], s_xw[kExpandColumns], s_pre[kExpandColumns + 1], s_base, s_ok;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWaveLanes - 1);
+    if (tid < kExpandColumns) {
+        const uint32_t k = blockIdx.x * columns + tid;
+        uint32_t lo = 0, len = 0, xw = 0;
+        if (tid < columns && k < x_count) {
+            const uint2 entry = x_entries[k];              // IDX_VAL_T { index, val }
+            if (entry.x < num_cols) {                      // (checked on the host where the host holds the entries)
+                lo = indptr[entry.x];
+                len = indptr[entry.x + 1] - lo;
+                xw = entry.y;
+            }
         }
-        for (uint32_t e = lo + lane; e < hi; e += kWaveLanes) {
-            const uint32_t row = row_indices[e];
-            keys[at + (e - lo)] = row;
-            vals[at + (e - lo)] = product_word<kFloat>(value_words[e], xw);
-            blks[at + (e - lo)] = static_cast<uint16_t>(row >> kBlockBits);
+        const uint32_t incl = wave_inclusive_scan(len);    // (a workgroup's 64 columns stay below 2^32 products: capacity < 2^32)
+        s_lo[tid] = lo;
+        s_xw[tid] = xw;
+        s_pre[tid + 1] = incl;
+        if (tid == 0) s_pre[0] = 0;
+        if (lane == kWaveLanes - 1) {
+            uint32_t ok = 1, base = 0;
+            if (incl) {
+                const unsigned long long claimed = atomicAdd(counter, static_cast<unsigned long long>(incl));
+                if (claimed > capacity || incl > capacity - claimed) {      // the list is full (an x with repeated entries can ask for more than nnz products)
+                    atomicOr(overflow, 1ull);
+                    ok = 0;
+                }
+                base = static_cast<uint32_t>(claimed);
+            }
+            s_base = base;
+            s_ok = ok;
         }
+    }
+    __syncthreads();
+    const uint32_t total = s_pre[kExpandColumns], base = s_base;
+    if (!s_ok) return;
+    for (uint32_t p = tid; p < total; p += kExpandThreads) {
+        uint32_t c = 0;                                    // the last column whose prefix is <= p
+#pragma unroll
+        for (uint32_t step = kExpandColumns / 2; step; step >>= 1)
+            if (s_pre[c + step] <= p) c += step;
+        const uint32_t e = s_lo[c] + (p - s_pre[c]);
+        const uint32_t row = row_indices[e];
+        keys[base + p] = row;
+        vals[base + p] = product_word<kFloat>(value_words[e], s_xw[c]);
+        blks[base + p] = static_cast<uint16_t>(row >> block_bits);
     }
 }
 
-// One workgroup per row block.  kAdd: y += (a second pass of a call whose products did not fit the list at once; saturating / fp32 add).
-// The sweep over the block ids and the fetch of the matching products are DECOUPLED through a queue in LDS: a trip of the loop looks at
-// 8192 products (one 16-byte load of ids per lane, the next trip's already in flight) and pushes the indices of its own into the queue;
-// the queue is drained -- row and product word of every entry loaded four at a time, one LDS add each -- only when the next trip might
-// overflow it, and at the end.  (The first version fetched a match where it found it: with 1 product in 71 matching, nearly every one of
-// a lane's 8 ids had SOME lane of the wavefront taking the branch, i.e. 8 dependent load round trips per trip: 179 us for 420 K
-// products, profiles/r04_spmspv.txt.)
-constexpr uint32_t kTripProducts = 1024 * kIdsPerLoad;     // 8192
-constexpr uint32_t kQueueEntries = 2 * kTripProducts;      // 64 KiB: drained when fewer than one trip's worth of room is left
+// ACCUMULATE.  One workgroup per row block of 2^block_bits rows (8192 at most; fewer for matrices of few rows, so that there are
+// workgroups enough).  kAdd: y += (a later pass of a call whose products did not fit the list at once; saturating / fp32 add).
+// The sweep over the block ids and the fetch of the matching products are DECOUPLED through a queue in LDS: a trip looks at 32 K products
+// (four 16-byte loads of ids per lane, the next trip's already in flight), the lanes that found one of their own push its index -- one LDS
+// atomic per wavefront and id position, the lanes' places from the ballot -- and the queue is drained after the trip: row and product word
+// of every entry loaded four at a time, one LDS add each.  (Fetching a match where it was found cost 8 dependent load round trips per
+// 8 ids; a trip per 8 K products with a barrier pair each left the id loads' latency exposed: 179 / 142 us for 420 K products,
+// profiles/r04_spmspv.txt.)  An entry that does not fit the queue any more is added on the spot.
+constexpr uint32_t kTripLoads = 4;
+constexpr uint32_t kTripProducts = 1024 * kIdsPerLoad * kTripLoads;      // 32768
+constexpr uint32_t kQueueEntries = 8192;                                 // 32 KiB
 template <bool kFloat, bool kAdd>
 __global__ __launch_bounds__(1024) void spmspv_accumulate_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                                 const uint16_t* __restrict__ blks, const unsigned long long* __restrict__ counter,
-                                                                unsigned long long* __restrict__ counter_next, uint32_t capacity, uint32_t* __restrict__ y,
-                                                                uint32_t num_rows) {
+                                                                unsigned long long* __restrict__ counter_next, uint32_t capacity, uint32_t block_bits,
+                                                                uint32_t* __restrict__ y, uint32_t num_rows) {
     using R = Rows<kFloat>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    typename R::acc_t* acc = reinterpret_cast<typename R::acc_t*>(lds);                      // [kBlockRows]
-    uint32_t* queue = reinterpret_cast<uint32_t*>(lds + kBlockRows * sizeof(typename R::acc_t));   // [kQueueEntries]
+    typename R::acc_t* acc = reinterpret_cast<typename R::acc_t*>(lds);                              // [block rows]
+    const uint32_t block_rows = 1u << block_bits;
+    uint32_t* queue = reinterpret_cast<uint32_t*>(lds + block_rows * sizeof(typename R::acc_t));     // [kQueueEntries]
     __shared__ uint32_t queued;
-    const uint32_t tid = threadIdx.x, b = blockIdx.x, row0 = b << kBlockBits;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWaveLanes - 1), b = blockIdx.x, row0 = b << block_bits;
     const unsigned long long claimed = ((const __attribute__((address_space(4))) unsigned long long*)counter)[0];
     const uint32_t total = claimed > capacity ? capacity : static_cast<uint32_t>(claimed);      // (beyond the capacity: the overflow flag is up and the call reports it)
     const uint4* ids4 = reinterpret_cast<const uint4*>(blks);
     const uint4 none = make_uint4(0, 0, 0, 0);
-    uint4 w = tid * kIdsPerLoad < total ? ids4[tid] : none;      // (the allocation is padded to whole 16-byte words)
-    for (uint32_t i = tid; i < kBlockRows; i += 1024) acc[i] = 0;
+    auto load_trip = [&](uint4 (&w)[kTripLoads], uint32_t base) {
+#pragma unroll
+        for (uint32_t q = 0; q < kTripLoads; ++q) {
+            const uint32_t i = base + (q * 1024 + tid) * kIdsPerLoad;
+            w[q] = i < total ? ids4[i / kIdsPerLoad] : none;      // (the allocation is padded to whole 16-byte words)
+        }
+    };
+    uint4 w[kTripLoads];
+    load_trip(w, 0);
+    for (uint32_t i = tid; i < block_rows; i += 1024) acc[i] = 0;
     if (tid == 0) queued = 0;
     if (b == 0 && tid == 0) *counter_next = 0;             // the next call's counter (nobody reads it before that call's expand kernel)
     __syncthreads();
+    auto add_one = [&](uint32_t idx) {
+        const uint32_t local = keys[idx] & (block_rows - 1u), v = vals[idx];
+        if (kFloat) R::add(acc, local, __uint_as_float(v));
+        else atomicAdd(acc + local, static_cast<unsigned long long>(v));
+    };
     auto drain = [&](uint32_t n) {
         for (uint32_t q = tid; q < n; q += 4 * 1024) {
             uint32_t idx[4], key[4], val[4];
@@ -119,37 +169,59 @@ __global__ __launch_bounds__(1024) void spmspv_accumulate_kernel(const uint32_t*
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (q + k * 1024u >= n) break;
-                const uint32_t local = key[k] & (kBlockRows - 1u);
+                const uint32_t local = key[k] & (block_rows - 1u);
                 if (kFloat) R::add(acc, local, __uint_as_float(val[k]));                                // ds_add_f64 of the fp32 product
                 else atomicAdd(acc + local, static_cast<unsigned long long>(val[k]));                   // ds_add_u64
             }
         }
     };
     for (uint32_t base = 0; base < total; base += kTripProducts) {
-        const uint32_t i = base + tid * kIdsPerLoad;
-        const uint4 ahead = i + kTripProducts < total ? ids4[(i + kTripProducts) / kIdsPerLoad] : none;
-        const uint32_t word[4] = {w.x, w.y, w.z, w.w};
+        uint4 ahead[kTripLoads];
+        load_trip(ahead, base + kTripProducts);
+        // which of this lane's 32 ids are the block's own (bit q * 8 + j), how many, and where they go: ONE LDS atomic per wavefront and
+        // trip claims the wavefront's stretch of the queue (a DPP prefix sum of the lanes' counts gives every lane its place in it).
+        // (One returning LDS atomic per id position that had a match anywhere in the wavefront: 8 us per trip, 106 us for 420 K products.)
+        uint32_t mine = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < kIdsPerLoad; ++j) {
-            const uint32_t id = (word[j / 2] >> (16 * (j % 2))) & 0xffffu;
-            if (id == b && i + j < total) queue[atomicAdd(&queued, 1u)] = i + j;      // (ids past `total` are leftovers of earlier calls)
+        for (uint32_t q = 0; q < kTripLoads; ++q) {
+            const uint32_t i = base + (q * 1024 + tid) * kIdsPerLoad;
+            const uint32_t word[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
+#pragma unroll
+            for (uint32_t j = 0; j < kIdsPerLoad; ++j) {
+                const uint32_t id = (word[j / 2] >> (16 * (j % 2))) & 0xffffu;
+                if (id == b && i + j < total) mine |= 1u << (q * kIdsPerLoad + j);      // (ids past `total` are leftovers of earlier calls)
+            }
+        }
+        const uint32_t count = __builtin_popcount(mine);
+        const uint32_t upto = wave_inclusive_scan(count);
+        uint32_t at = 0;
+        if (lane == kWaveLanes - 1 && upto) at = atomicAdd(&queued, upto);
+        at = __builtin_amdgcn_readlane(at, kWaveLanes - 1) + upto - count;
+        while (mine) {                                           // per lane: a handful of iterations at most
+            const uint32_t bit = __builtin_ctz(mine);
+            mine &= mine - 1;
+            const uint32_t idx = base + ((bit / kIdsPerLoad) * 1024 + tid) * kIdsPerLoad + bit % kIdsPerLoad;
+            if (at < kQueueEntries) queue[at] = idx;
+            else add_one(idx);                                   // the queue is full (a row block that takes most of the products): add it here
+            ++at;
         }
         __syncthreads();
-        const uint32_t n = queued;
-        __syncthreads();                                   // everybody has read the count before the next trip's pushes move it
-        if (n > kQueueEntries - kTripProducts || base + kTripProducts >= total) {
+        const uint32_t n = min(queued, kQueueEntries);
+        __syncthreads();                                         // everybody has read the count
+        if (n > kQueueEntries / 2 || base + kTripProducts >= total) {      // drain when the next trip might not fit, and at the end
             drain(n);
             __syncthreads();
             if (tid == 0) queued = 0;
             __syncthreads();
         }
-        w = ahead;
+#pragma unroll
+        for (uint32_t q = 0; q < kTripLoads; ++q) w[q] = ahead[q];
     }
     // no-return LDS atomics can outlive s_waitcnt lgkmcnt(0) (spmv_kernels.hip): a RETURNING atomic per wavefront, awaited
     const typename R::acc_t flushed = atomicAdd(acc + (tid / kWaveLanes), static_cast<typename R::acc_t>(0));
     asm volatile("" ::"v"(flushed));
     __syncthreads();
-    for (uint32_t i = tid; i < kBlockRows && row0 + i < num_rows; i += 1024) {
+    for (uint32_t i = tid; i < block_rows && row0 + i < num_rows; i += 1024) {
         uint32_t word = R::finish(acc[i]);
         if (kAdd) {
             const uint32_t old = y[row0 + i];
@@ -172,27 +244,35 @@ __global__ __launch_bounds__(256) void spmspv_scatter_x_kernel(const uint2* __re
 
 size_t spmspv_list_bytes(uint64_t capacity) { return ((size_t(capacity) * 2 + 15) & ~size_t(15)) + 16; }      // the block-id array, padded to whole loads
 
+// rows per block: 8192 unless the matrix has too few rows to give every other CU a block that way (mouse_gene: 45 K rows -> 512-row blocks)
+uint32_t spmspv_block_bits(uint32_t num_rows) {
+    uint32_t bits = kMaxBlockBits;
+    while (bits > kMinBlockBits && ((uint64_t(num_rows) + (1u << bits) - 1) >> bits) < 128) --bits;
+    return bits;
+}
+
 hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, const hs_idx_val_dev* x_entries,
                          uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& s, uint32_t call, bool add_to_y, uint32_t* y,
                          hipStream_t stream) {
     unsigned long long* counter = s.counters + (call & 1u);
     unsigned long long* counter_next = s.counters + ((call + 1u) & 1u);
     const uint32_t capacity = static_cast<uint32_t>(std::min<uint64_t>(s.capacity, 0xffffffffull));
-    const dim3 block(256);
+    const uint32_t block_bits = spmspv_block_bits(num_rows);
     if (x_count) {
-        const dim3 grid(std::min<uint32_t>((x_count + 3) / 4, 8192));       // 4 wavefronts per workgroup, one x entry each
+        const uint32_t columns = std::max<uint32_t>(1, std::min<uint32_t>(kExpandColumns, x_count / 512));      // >= 512 workgroups before they grow
+        const dim3 grid((x_count + columns - 1) / columns), block(kExpandThreads);
         const uint2* xe = reinterpret_cast<const uint2*>(x_entries);
         if (is_float)
             hipLaunchKernelGGL(spmspv_expand_kernel<true>, grid, block, 0, stream, indptr, row_indices, value_words, xe, x_count, num_cols, counter, s.counters + 2,
-                               capacity, s.keys, s.vals, s.blks);
+                               capacity, block_bits, columns, s.keys, s.vals, s.blks);
         else
             hipLaunchKernelGGL(spmspv_expand_kernel<false>, grid, block, 0, stream, indptr, row_indices, value_words, xe, x_count, num_cols, counter, s.counters + 2,
-                               capacity, s.keys, s.vals, s.blks);
+                               capacity, block_bits, columns, s.keys, s.vals, s.blks);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    const dim3 grid((num_rows + kBlockRows - 1) / kBlockRows);
-    const uint32_t lds = kBlockRows * 8u + kQueueEntries * 4u;      // accumulators + queue: 128 KiB
+    const dim3 grid((num_rows + (1u << block_bits) - 1) >> block_bits);
+    const uint32_t lds = (8u << block_bits) + kQueueEntries * 4u;      // accumulators + queue: 96 KiB at most
 #define X(F, A)                                                                                                                                                  \
     do {                                                                                                                                                         \
         static bool configured_on[64] = {};      /* the dynamic-LDS cap is a property of the function, per device */                                            \
@@ -200,11 +280,12 @@ hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* 
         (void)hipGetDevice(&dev_);                                                                                                                               \
         bool& configured = configured_on[dev_ >= 0 && dev_ < 64 ? dev_ : 0];                                                                                     \
         if (!configured) {                                                                                                                                       \
-            const hipError_t ce = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmspv_accumulate_kernel<F, A>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)); \
+            const hipError_t ce = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmspv_accumulate_kernel<F, A>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                      int((8u << kMaxBlockBits) + kQueueEntries * 4u));                                                          \
             if (ce != hipSuccess) return ce;                                                                                                                     \
             configured = true;                                                                                                                                   \
         }                                                                                                                                                        \
-        hipLaunchKernelGGL((spmspv_accumulate_kernel<F, A>), grid, dim3(1024), lds, stream, s.keys, s.vals, s.blks, counter, counter_next, capacity, y, num_rows); \
+        hipLaunchKernelGGL((spmspv_accumulate_kernel<F, A>), grid, dim3(1024), lds, stream, s.keys, s.vals, s.blks, counter, counter_next, capacity, block_bits, y, num_rows); \
     } while (0)
     if (is_float) { if (add_to_y) X(true, true); else X(true, false); }
     else { if (add_to_y) X(false, true); else X(false, false); }

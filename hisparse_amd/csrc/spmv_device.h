@@ -80,8 +80,13 @@ template <int kCtrl, int kRowMask>
 __device__ __forceinline__ double dpp_from(double v) {      // identity 0.0 = all-zero bits
     return __longlong_as_double(static_cast<long long>(dpp_from<kCtrl, kRowMask>(static_cast<unsigned long long>(__double_as_longlong(v)))));
 }
+// (the same sequence leaves the INCLUSIVE prefix sum in every lane: wave_inclusive_scan)
 template <typename T>
-__device__ __forceinline__ T wave_total_in_lane63(T v) {
+__device__ __forceinline__ T wave_inclusive_scan(T v);
+template <typename T>
+__device__ __forceinline__ T wave_total_in_lane63(T v) { return wave_inclusive_scan(v); }
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
     v += dpp_from<0x111, 0xf>(v);      // row_shr:1
     v += dpp_from<0x112, 0xf>(v);      // row_shr:2
     v += dpp_from<0x114, 0xf>(v);      // row_shr:4

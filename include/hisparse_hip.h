@@ -164,11 +164,14 @@ int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32
  *     products in LDS and writes its rows) -- no scan, no sort, no host synchronisation.  The result is a dense packed y of num_rows words:
  *     hs_read_spmspv_result.  An entry may name a column more than once (the products simply add up); a call whose products exceed the
  *     matrix's non-zero count is cut into passes.
- *     CROSSOVER: every row block's workgroup sweeps the whole product list, so the operator pays for a few per cent of the columns at most.
- *     Above `spmspv_crossover` (hs_set_option; default 0.02 = 2 % of the columns, measured on ogbl-ppa: profiles/r04_spmspv.txt; 0 = never)
- *     hs_spmspv runs the DENSE SpMV instead -- x scattered into a zero vector, one hs_run -- which is faster there, PROVIDED hs_load_matrix /
- *     hs_load_matrix_csr of this context holds the same matrix (same shape after padding; that it IS the same matrix is the caller's
- *     contract) and x names no column twice.  Otherwise the sparse path runs whatever the size.
+ *     CROSSOVER: every row block's workgroup sweeps the whole product list, so the operator pays for about one per cent of the columns at
+ *     most (measured, profiles/r04_spmspv.txt: ogbl-ppa 0.1 % of the columns 23 us, 1 % 85 us against 61-68 us for the dense SpMV; the
+ *     sparse path costs ~12 us + products / 5 G/s).  Beyond that the DENSE SpMV is faster, and hs_spmspv runs it instead -- x scattered
+ *     into a zero vector, one hs_run -- PROVIDED hs_load_matrix / hs_load_matrix_csr of this context holds the same matrix (same shape
+ *     after padding; that it IS the same matrix is the caller's contract) and x names no column twice.  The rule: the host knows the
+ *     call's product count exactly, and the dense SpMV of the loaded matrix is timed once (the first call that could use it: three
+ *     launches and one synchronisation); `spmspv_crossover` (hs_set_option: a fraction of the columns; 0 = never) replaces the rule,
+ *     `spmspv` = sparse | dense forces a path.  Without a matching dense matrix the sparse path runs whatever the size.
  *   hs_spmspv_device: the same with the pairs already in DEVICE memory (8-byte aligned): nothing but the two launches.  No index check
  *     (out-of-range columns are ignored), no dense dispatch, and the products must fit the list (true whenever no column is named twice);
  *     otherwise hs_read_spmspv_result reports HS_ERR_BAD_ARG.
