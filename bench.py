@@ -822,6 +822,51 @@ def main_distributed(args, rank, local_rank, world):
     # ---- timing: the exchange pattern asked for = `value`; the same SpMVs without any exchange alongside -------------------------
     elapsed = timed(args.gather, args.steps)
     compute_elapsed = timed("off", args.steps) if args.gather != "off" else elapsed
+    # ---- the same K steps with the gather done by PEER STORES instead of a collective (hs_push_result; hisparse_amd/peer_gather.py): every
+    #      rank's kernels write y into its slot of its own gather buffer and one small kernel pushes the slab into every peer's buffer over
+    #      xGMI.  Reported beside the RCCL figure; a failure here (IPC not available) is reported, not fatal.
+    push = None
+    if on_gpu and args.gather == "step":
+        try:
+            from hisparse_amd import peer_gather
+            pg = peer_gather.PeerGather(dist, rank, world, chunk, device_id=local_rank)
+            push_no = [0]
+
+            def push_step(_gather):
+                b = push_no[0] & 1
+                push_no[0] += 1
+                eng.bind_device_result(pg.my_slot(b))
+                eng.run()
+                eng.push_result(pg.targets(b), packets.num_rows)
+
+            saved_step = step
+            step = push_step
+            try:
+                push_elapsed = timed("push", args.steps)
+            finally:
+                step = saved_step
+            sync()
+            dist.barrier()
+            mine_rows = [None] * world
+            dist.all_gather_object(mine_rows, packets.num_rows)
+            ok = True
+            for b in (0, 1):      # both buffers against what RCCL gathered before the timing (same x, same matrix: the same y)
+                got = pg.read(b)
+                ref = gathered[0].cpu().numpy().view(np.uint32).reshape(world, chunk)
+                for r in range(world):
+                    ok = ok and bool(np.array_equal(got[r, :mine_rows[r]], ref[r, :mine_rows[r]]))
+            flag2 = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag2, op=dist.ReduceOp.MAX)
+            dist.barrier()
+            eng.bind_device_result(y_chunks[0].data_ptr())
+            pg.close()
+            push = {"ms_per_step": round(push_elapsed / args.steps * 1e3, 5), "ms_per_step_added": round((push_elapsed - compute_elapsed) / args.steps * 1e3, 5),
+                    "gathered_equals_rccl_gather_on_every_rank": flag2.item() == 0.0,
+                    "note": "hs_push_result: plain 16-byte stores into the peers' gather buffers (hipIpcOpenMemHandle), stream-ordered behind the SpMV; "
+                            "the ranks synchronise once around the K steps"}
+        except Exception as e:      # noqa: BLE001 -- the push path is an extra measurement
+            push = {"error": f"{type(e).__name__}: {e}"}
+            log(rank, f"peer-store gather skipped: {e}")
     tot = torch.tensor([float(nnz)], dtype=torch.float64, device=dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     total_nnz = float(tot.item())
@@ -875,6 +920,7 @@ def main_distributed(args, rank, local_rank, world):
             "same_workload_on_one_gpu": one_gpu,
             "exchange": {"pattern": args.gather, "bytes_per_rank_per_gather": int(chunk) * 4,
                          "ms_per_step_added": round((elapsed - compute_elapsed) / args.steps * 1e3, 5)},
+            "exchange_push": push,
             "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_rowblock_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": int(8 * nnz), "streamed_bytes_per_launch": int(stats["stream_bytes"]), "traffic": None,
