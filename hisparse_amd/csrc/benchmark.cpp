@@ -304,6 +304,10 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
             }
         }
     }
+    if (o.peer_gather && N - 1 > 8) {      // hs_push_result: at most 8 destinations (dst[8] below)
+        std::fprintf(stderr, "--peer-gather: at most 9 GPUs (a slab is pushed to 8 peers)\n");
+        std::exit(2);
+    }
     auto push_all = [&]() {
         for (int d = 0; d < N; ++d) {
             void* dst[8];

@@ -402,6 +402,13 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
         return fail(ctx, HS_ERR_UNSUPPORTED, "row block does not fit the LDS");
     }
 
+    // What the builder left on the device belongs to the context from here on: an early return below then leaks nothing --
+    // free_matrix (the next load, hs_destroy) gives it back; matrix_loaded stays false until the end.
+    if (tiles.d_image) { ctx->d_image = tiles.d_image; }
+    if (tiles.mfma.d_words) { ctx->d_mfma = reinterpret_cast<uint32_t*>(tiles.mfma.d_words); }
+    const bool image_on_device = tiles.d_image != nullptr, mfma_on_device = tiles.mfma.d_words != nullptr;
+    tiles.d_image = nullptr;
+    tiles.mfma.d_words = nullptr;
     // the dynamic-LDS cap is a property of the FUNCTION, not of this context: always raise it to the full 160 KiB, so that a
     // second context with a smaller matrix on the same device cannot lower it under a first one's launches
     HS_HIP(ctx, hisparse::dev::configure_spmv_kernels(hisparse::dev::kMaxLdsBytes));
@@ -410,25 +417,33 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
         if (e != hipSuccess || bytes == 0) return e;
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
-    if (tiles.d_image) ctx->d_image = tiles.d_image;      // built on the device, slack included
-    else HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_image), tiles.image.data(), tiles.image.size(), kImageSlackBytes));
+    if (!image_on_device)      // (built on the device: adopted above, slack included)
+        HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_image), tiles.image.data(), tiles.image.size(), kImageSlackBytes));
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_blocks), tiles.blocks.data(), tiles.blocks.size() * sizeof(Block), 0));
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_units), tiles.units.data(), tiles.units.size() * sizeof(Unit), 0));
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_part_heads), tiles.part_heads.data(), tiles.part_heads.size() * sizeof(uint32_t), 0));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
     if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
-    if (tiles.mfma.present()) {      // float BITMAP matrix: the second image for the SpMM on the matrix engine + its scratch
+    if (mfma_on_device || (tiles.mfma.words_bytes != 0 && !tiles.mfma.words.empty())) {      // float BITMAP matrix: the second image for the SpMM on the matrix engine + its scratch
+        // OPTIONAL: SpMV works without it.  If the image or its scratch cannot be had (out of memory), the matrix loads without a second
+        // image and hs_spmm takes the fused 4-column kernel instead.
         const hisparse::dev::MfmaImage& mi = tiles.mfma;
-        if (mi.d_words) ctx->d_mfma = reinterpret_cast<uint32_t*>(mi.d_words);      // built on the device
-        else HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_mfma), mi.words.data(), mi.words.size(), 0));
-        ctx->mfma_bytes = mi.words_bytes;
-        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_x), hisparse::dev::spmm_mfma_x_words(mi.groups) * 4));
-        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_partial), hisparse::dev::spmm_mfma_partial_words(mi.tiles, mi.chunks) * 4));
-        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_flag), 64));
-        HS_HIP(ctx, hipMemset(ctx->d_mfma_flag, 0, 64));
-        ctx->mfma_info.tiles = mi.tiles; ctx->mfma_info.groups = mi.groups; ctx->mfma_info.chunk = mi.chunk; ctx->mfma_info.chunks = mi.chunks;
-        ctx->mfma_info.offsets_word = mi.offsets_word; ctx->mfma_info.values_word = mi.values_word;
+        bool ok = mfma_on_device || upload(reinterpret_cast<void**>(&ctx->d_mfma), mi.words.data(), mi.words.size(), 0) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_x), hisparse::dev::spmm_mfma_x_words(mi.groups) * 4) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_partial), hisparse::dev::spmm_mfma_partial_words(mi.tiles, mi.chunks) * 4) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void**>(&ctx->d_mfma_flag), 64) == hipSuccess && hipMemset(ctx->d_mfma_flag, 0, 64) == hipSuccess;
+        if (ok) {
+            ctx->mfma_bytes = mi.words_bytes;
+            ctx->mfma_info.tiles = mi.tiles; ctx->mfma_info.groups = mi.groups; ctx->mfma_info.chunk = mi.chunk; ctx->mfma_info.chunks = mi.chunks;
+            ctx->mfma_info.offsets_word = mi.offsets_word; ctx->mfma_info.values_word = mi.values_word;
+        } else {
+            (void)hipGetLastError();
+            for (void* p : {static_cast<void*>(ctx->d_mfma), static_cast<void*>(ctx->d_mfma_x), static_cast<void*>(ctx->d_mfma_partial), static_cast<void*>(ctx->d_mfma_flag)})
+                if (p) (void)hipFree(p);
+            ctx->d_mfma = ctx->d_mfma_x = ctx->d_mfma_flag = nullptr;
+            ctx->d_mfma_partial = nullptr;
+        }
     }
     if (debug) std::fprintf(stderr, "load: descriptors + result buffers on the device after %.1f ms\n", since());
     ctx->num_rows = num_rows;
@@ -461,7 +476,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     s.lds_bytes = lds_bytes;
     s.num_compute_units = uint32_t(ctx->compute_units);
     s.load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    s.retiled_on_gpu = tiles.d_image != nullptr;
+    s.retiled_on_gpu = image_on_device;
     s.light_kernel = tiles.light ? 1u : 0u;
     return HS_OK;
 }

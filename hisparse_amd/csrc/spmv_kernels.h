@@ -62,7 +62,7 @@ uint32_t spmm_bitmap_max_block_rows(bool is_float, uint32_t vectors);   // rows 
 hipError_t launch_spmm_bitmap(bool is_float, const SpmmLaunch& a, hipStream_t stream);
 // SpMM on the matrix engine over the second image of a float BITMAP matrix (spmm_mfma.hip; stream_tiles.h: MfmaImage): 16 columns of X per
 // call.  Leaves y untouched (and sets *flag) when X holds a non-finite word: 0.0 x inf inside an MFMA would poison rows that do not touch
-// that column -- launch_spmm_exact then computes the 16 columns the way the PEs would.
+// that column -- the finish kernel (spmm_finish_kernel) then computes those 16 columns from the stored elements only, the way the PEs would.
 struct SpmmMfmaLaunch {
     const uint32_t* words;        // the MfmaImage on the device
     uint64_t offsets_word, values_word;
