@@ -83,7 +83,7 @@ def sources_sha16():
     return h.hexdigest()[:16]
 
 
-def read_traffic(config, stream_bytes):
+def read_traffic(config, stream_bytes, impl=None):
     """(HBM bytes per launch, provenance) of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json:
     FETCH_SIZE x 2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes).  The counters need their own rocprofv3 passes, so this
     is a COPY of a committed measurement, not something measured in this run: the provenance says which round, git commit and source
@@ -94,9 +94,14 @@ def read_traffic(config, stream_bytes):
             t = json.load(f)
     except (OSError, ValueError):
         return None, {"source": "profiles/hbm_traffic.json missing"}
-    e = t.get(config) if isinstance(t.get(config), dict) else None
+    e = None
+    for key in (config, f"{config}:{IMPL_NAMES[impl]}" if impl is not None else None):      # an entry counts for the numeric mode it was profiled in
+        c = t.get(key) if key and isinstance(t.get(key), dict) else None
+        if c and (impl is None or c.get("impl") is None or int(c.get("impl")) == int(impl)):
+            e = c
+            break
     if not e:
-        return None, {"source": "profiles/hbm_traffic.json has no entry for this configuration"}
+        return None, {"source": "profiles/hbm_traffic.json has no entry for this configuration and numeric mode"}
     prov = {"source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, copied, not measured in this run)",
             "round": e.get("round"), "git_head": e.get("git_head"), "csrc_sha16": e.get("csrc_sha16"),
             "sources_unchanged_since": e.get("csrc_sha16") == sources_sha16(), "profiled_stream_bytes": e.get("stream_bytes")}
@@ -264,7 +269,7 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         print(json.dumps({"error": "the CSR load path gives a different image or result than the CPSR path", "config": name}))
         sys.exit(1)
     spmm = spmm_probe(np, host, eng, impl, packets, rng, xw) if device.STREAM_FORMATS[stats["stream_format"]] == "bitmap" and with_spmm else None
-    traffic, traffic_from = read_traffic(name if not impl_override else f"{name}:{IMPL_NAMES[impl]}", stats["stream_bytes"])
+    traffic, traffic_from = read_traffic(name, stats["stream_bytes"], impl)
     res = {
         "workload": f"{name}, {IMPL_NAMES[impl]} IMPL, v={packets.vb_bank} o={packets.ob_bank}",
         "rows": true_rows, "cols": packets.num_cols, "nnz": int(nnz), "partitions": f"{packets.num_row_partitions}x{packets.num_col_partitions}",
