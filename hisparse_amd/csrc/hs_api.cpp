@@ -135,7 +135,8 @@ void free_matrix(hs_context* c) {
     if (c->d_y) (void)hipFree(c->d_y);
     if (c->d_partial) (void)hipFree(c->d_partial);
     c->d_partial = nullptr;
-    c->d_tickets = nullptr;      // (lives inside d_partial)
+    if (c->d_tickets) (void)hipFree(c->d_tickets);
+    c->d_tickets = nullptr;
     if (c->d_x_interleaved) (void)hipFree(c->d_x_interleaved);
     c->d_x_interleaved = nullptr;
     for (void* p : {static_cast<void*>(c->d_mfma), static_cast<void*>(c->d_mfma_x), static_cast<void*>(c->d_mfma_partial), static_cast<void*>(c->d_mfma_flag)})
@@ -201,6 +202,8 @@ hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     a.light = c->light;
     a.y_final = y_target(c);
     a.tickets = c->d_tickets;
+    a.slices = c->col_slices;
+    a.num_rows = c->num_rows;
     return a;
 }
 
@@ -431,16 +434,14 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_part_heads), tiles.part_heads.data(), tiles.part_heads.size() * sizeof(uint32_t), 0));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
-    // (+ the ticket words of a fused plan right behind the partial vectors: the kernel finds them at out + slices * num_rows)
-    if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), (size_t(tiles.col_slices) * num_rows + std::max<size_t>(tiles.num_ranges, 1)) * 4));
+    if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
     if (tiles.fused_combine) {
         // the plan placed every row range's slices on workgroups of one XCD by the rule "hardware workgroup b runs on XCD b % 8": check it on
         // this device once per context; if it does not hold the SAME image runs with the separate combine kernel (the placement is then
         // only a different, equally valid, assignment of blocks to workgroups)
         if (ctx->xcd_round_robin < 0) ctx->xcd_round_robin = hisparse::dev::xcd_dispatch_is_round_robin(ctx->stream) ? 1 : 0;
-        const char* mode = ctx_option(ctx, "HISPARSE_FUSED_COMBINE");      // "2": the same-XCD placement with the SEPARATE combine kernel (experiments)
-        if (ctx->xcd_round_robin == 1 && !(mode && std::atoi(mode) == 2)) {
-            ctx->d_tickets = ctx->d_partial + size_t(tiles.col_slices) * num_rows;
+        if (ctx->xcd_round_robin == 1) {
+            HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_tickets), std::max<size_t>(tiles.num_ranges, 1) * 4));
             HS_HIP(ctx, hipMemset(ctx->d_tickets, 0, std::max<size_t>(tiles.num_ranges, 1) * 4));
         }
     }

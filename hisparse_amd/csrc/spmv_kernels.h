@@ -28,7 +28,8 @@ struct SpmvLaunch {
     // fused slice combine (StreamTiles::fused_combine; row-block kernel only): tickets != nullptr -> the last block of a row range to finish adds the
     // `slices` partial vectors (out + k * num_rows) of its rows into y_final; no launch_combine_slices afterwards
     uint32_t* y_final = nullptr;
-    uint32_t* tickets = nullptr;  // one word per row range, zero between launches: MUST be out + slices * num_rows (the kernel derives it from there)
+    uint32_t* tickets = nullptr;  // one word per row range, zero between launches
+    uint32_t slices = 1, num_rows = 0;
     bool light = false;           // the LIGHT plan (StreamTiles::light): a PAIRS image consumed by spmv_light_kernel, 256-thread workgroups, lds_bytes = spmv_light_lds_bytes
 };
 

@@ -704,23 +704,21 @@ __device__ __forceinline__ void consumer_run(Consumer<kFloat>& c) {
 //   * every block stores its partial rows with plain stores (write-through L1 -> the shared L2), waits for their acknowledgement
 //     (s_waitcnt vmcnt(0)) and passes a workgroup barrier;
 //   * one lane draws a ticket for the row range with a relaxed agent-scope atomic (performed at the L2 / memory side: it bypasses L1);
-//   * the block that draws the LAST ticket re-arms the counter, invalidates ITS CU's L1 (one agent-scope acquire: buffer_inv sc1, no L2
-//     write-back anywhere) and adds the `slices` partial rows of its range with plain loads -- served by the L2 the other blocks wrote
-//     through -- in slice order: the same sums, in the same order, as combine_slices_kernel -- and writes y.
-// Nobody waits for anybody (no deadlock whatever the order the blocks run in), and no release fence (L2 write-back) is issued.  The same-XCD placement rests on
+//   * the block that draws the LAST ticket re-arms the counter and adds the `slices` partial rows of its range, read with agent-scope
+//     relaxed loads (global_load ... sc1: they bypass this CU's L1 and are served by the L2 the other blocks wrote through), in slice order
+//     -- the same sums, in the same order, as combine_slices_kernel -- and writes y.
+// Nobody waits for anybody (no deadlock whatever the order the blocks run in), and no fence is issued.  The same-XCD placement rests on
 // "hardware workgroup b runs on XCD b % 8", which hs_api.cpp verifies on the device (xcd_dispatch_is_round_robin: every workgroup reads
 // its XCC_ID) before a context may use a fused plan; otherwise, and for BITMAP's sliced plans, the separate kernel stays.
-// What the epilogue needs travels in the Block (slices, num_rows: scalar loads at the point of use) and in ONE extra kernel argument, the
-// final y (nullptr: this launch ends with the separate combine kernel); the ticket words sit behind the partial vectors, at
-// out + slices * num_rows.  (Five arguments held in scalar registers all kernel long cost every variant 22-42 spilled scalar registers.)
 struct FusedCombine {
     uint32_t* y;            // the final result
     const uint32_t* partial;// slices x num_rows partial words (this launch's `out`)
-    uint32_t* tickets;      // per row range
+    uint32_t* tickets;      // per row range; nullptr: no fused combine in this launch
     uint32_t slices, num_rows;
 };
 template <bool kFloat>
 __device__ __forceinline__ void fused_combine_rows(const FusedCombine& f, uint32_t range, uint32_t row0, uint32_t nrows, uint32_t tid, uint8_t* lds) {
+    if (!f.tickets) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wavefront's partial rows have reached the L2
     __syncthreads();                                           // ... and everybody else's of this block
     uint32_t* last = reinterpret_cast<uint32_t*>(lds);         // (the accumulators have been stored: their first word is free)
@@ -734,42 +732,38 @@ __device__ __forceinline__ void fused_combine_rows(const FusedCombine& f, uint32
     const bool mine = *last != 0;
     __syncthreads();                                           // (the word belongs to the next block's accumulators again)
     if (!mine) return;
-    // This CU's L1 may hold stale lines of the partial vectors (a previous launch's, or a block of another range this workgroup ran): one
-    // agent-scope ACQUIRE -- buffer_inv sc1: invalidates this CU's L1 and nothing else, ~1.5 us, paid by one block in `slices` -- and then
-    // plain coalesced loads, served by the L2 the sibling blocks wrote through.  (L1-bypassing loads instead -- sc1 or nt -- are issued
-    // lane by lane: 12 M dword requests on pokec, +128 us; measured, profiles/r04_fused_combine.txt.)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    // (kept small on purpose: four loads in flight per lane, no unrolling over rows -- an unrolled 8-slice version cost every row-block
-    // kernel 31-42 spilled scalar registers)
-    const size_t n = f.num_rows;
-#pragma unroll 1
-    for (uint32_t i = tid; i < nrows; i += kThreads) {
-        const uint32_t* p = f.partial + row0 + i;
-        // four words at a time (never more live registers than that: the kernels sit at their 96-register limit and the compiler would
-        // park an array of eight in the accumulator file -- the ring's registers)
-        uint32_t a = p[0], b = p[n], c = f.slices > 2 ? p[2 * n] : 0u, d = f.slices > 3 ? p[3 * n] : 0u;      // (a sliced plan has at least two)
-        uint32_t word;
-        if (kFloat) {
-            float sum = __uint_as_float(a) + __uint_as_float(b);      // slice order, like combine_slices_kernel (an absent slice is not added: -0.0 stays -0.0)
-            if (f.slices > 2) sum += __uint_as_float(c);
-            if (f.slices > 3) sum += __uint_as_float(d);
-            if (f.slices > 4) {                                       // wave-uniform
-                a = p[4 * n]; b = f.slices > 5 ? p[5 * n] : 0u; c = f.slices > 6 ? p[6 * n] : 0u; d = f.slices > 7 ? p[7 * n] : 0u;
-                sum += __uint_as_float(a);
-                if (f.slices > 5) sum += __uint_as_float(b);
-                if (f.slices > 6) sum += __uint_as_float(c);
-                if (f.slices > 7) sum += __uint_as_float(d);
-            }
-            word = __float_as_uint(sum);
-        } else {
-            unsigned long long sum = static_cast<unsigned long long>(a) + b + c + d;
-            if (f.slices > 4) {
-                a = p[4 * n]; b = f.slices > 5 ? p[5 * n] : 0u; c = f.slices > 6 ? p[6 * n] : 0u; d = f.slices > 7 ? p[7 * n] : 0u;
-                sum += static_cast<unsigned long long>(a) + b + c + d;
-            }
-            word = sum > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(sum);      // min(sum, MAX) == the PE's saturating sum (combine_slices_kernel)
+    // four rows per thread and trip, every slice's word of every one of them requested before the first is used (non-temporal loads: they
+    // bypass this CU's L1 like the sc1 form and, not being atomics, leave the compiler free to keep all of them in flight -- the first
+    // version read its 4-8 slices one dependent L2 round trip after the other: pokec's last blocks took 110 us over it)
+    constexpr uint32_t kRowsPerTrip = 4;
+    for (uint32_t i0 = tid; i0 < nrows; i0 += kThreads * kRowsPerTrip) {
+        uint32_t w[kRowsPerTrip][kMaxColSlices];
+#pragma unroll
+        for (uint32_t j = 0; j < kRowsPerTrip; ++j) {
+            const uint32_t i = min(i0 + j * kThreads, nrows - 1);
+#pragma unroll
+            for (uint32_t k = 0; k < kMaxColSlices; ++k)
+                w[j][k] = k < f.slices ? __builtin_nontemporal_load(f.partial + size_t(k) * f.num_rows + row0 + i) : 0u;
         }
-        f.y[row0 + i] = word;
+#pragma unroll
+        for (uint32_t j = 0; j < kRowsPerTrip; ++j) {
+            const uint32_t i = i0 + j * kThreads;
+            if (i >= nrows) break;
+            uint32_t word;
+            if (kFloat) {
+                float s = 0.0f;
+#pragma unroll
+                for (uint32_t k = 0; k < kMaxColSlices; ++k)
+                    if (k < f.slices) s += __uint_as_float(w[j][k]);      // slice order, like combine_slices_kernel
+                word = __float_as_uint(s);
+            } else {
+                unsigned long long s = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < kMaxColSlices; ++k) s += w[j][k];
+                word = s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s);      // min(sum, MAX) == the PE's saturating sum (combine_slices_kernel)
+            }
+            f.y[row0 + i] = word;
+        }
     }
 }
 
@@ -792,7 +786,7 @@ template <bool kFloat, int kRing, int kAblate, int kDepth, bool kOwner = false>
 __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const Unit* __restrict__ units, const uint32_t* __restrict__ x,
                                                                   uint32_t* __restrict__ out, int32_t row_part_filter, uint32_t ring,
-                                                                  uint32_t x_base, const uint32_t* __restrict__ part_heads, uint32_t* y_final) {
+                                                                  uint32_t x_base, const uint32_t* __restrict__ part_heads, FusedCombine fused) {
     using acc_t = typename Rows<kFloat>::acc_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     acc_t* ys = reinterpret_cast<acc_t*>(lds);                    // [nrows + 1] at LDS address 0: row addresses need no base add
@@ -927,10 +921,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
             timeline_stamp<kAblate>(block_no, wave, lane, 3);
             if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = reinterpret_cast<uint32_t*>(ys)[i];     // fp32 bits, or the saturated Q8.24 sum
             timeline_stamp<kAblate>(block_no, wave, lane, 4);
-            if (y_final && blk->ticket) {
-                const FusedCombine f{y_final, out, out + size_t(blk->slices) * blk->num_rows, blk->slices, blk->num_rows};
-                fused_combine_rows<kFloat>(f, blk->ticket - 1, blk->row0, nrows, tid, lds);
-            }
+            if (blk->ticket) fused_combine_rows<kFloat>(fused, blk->ticket - 1, blk->row0, nrows, tid, lds);
             if (!next) break;
             continue;
         }
@@ -943,10 +934,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
         // the accumulators are final (no barrier after the store: the last block's stores drain while the workgroup retires)
         if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = Rows<kFloat>::finish(ys[i]);
         timeline_stamp<kAblate>(block_no, wave, lane, 4);
-        if (y_final && blk->ticket) {
-            const FusedCombine f{y_final, out, out + size_t(blk->slices) * blk->num_rows, blk->slices, blk->num_rows};
-            fused_combine_rows<kFloat>(f, blk->ticket - 1, blk->row0, nrows, tid, lds);
-        }
+        if (blk->ticket) fused_combine_rows<kFloat>(fused, blk->ticket - 1, blk->row0, nrows, tid, lds);
         if (!next) break;
     }
 }
@@ -1287,7 +1275,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     }
     const int ring = a.format == kFormatDelta ? 1 : a.format == kFormatPairs24 ? 2 : 0;
     const dim3 grid(a.num_workgroups), block(kThreads);
-    uint32_t* const fused = a.tickets ? a.y_final : nullptr;      // the last block of a row range writes y itself (tickets behind the partial vectors)
+    const FusedCombine fused{a.y_final, a.out, a.tickets, a.slices, a.num_rows};
     const uint32_t x_base = a.lds_bytes - a.ring_buffers * kBufBytes;
     // profiling aids (libhisparse_hip_prof.so only): HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the
     // prefetch depth; read per launch, a tool may change them between launches.  The product library refuses to run with either set.

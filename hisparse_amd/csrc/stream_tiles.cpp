@@ -378,8 +378,6 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             }
             blk.out_offset = slices > 1 ? slice * num_rows + ranges[b].row0 : ranges[b].row0;
             blk.ticket = fused ? b + 1 : 0;
-            blk.slices = fused ? slices : 0;
-            blk.num_rows = fused ? num_rows : 0;
             blk.unit_begin = uint32_t(out.units.size());
             for (uint32_t k = 0; k < sub_tiles; ++k) {
                 if (slice_of[k] != slice) continue;

@@ -195,9 +195,7 @@ struct Block {
     uint32_t first_end[kConsumerWaves];     // == units[unit_begin].end_step
     uint32_t first_col0, first_ncols;       // == units[unit_begin].col0 / .ncols (0 / 0 for a block without units)
     uint32_t ticket;        // fused slice combine (StreamTiles::fused_combine): 1 + the block's row range = its slot in the ticket array; 0: none
-    uint32_t slices;        // ... the plan's column slices and the matrix's padded row count (the stride of the partial vectors): what the
-    uint32_t num_rows;      //     last block of a range needs to add them, read from the Block at that point (a kernel argument would hold scalar registers all kernel long)
-    uint32_t pad[11];
+    uint32_t pad[13];
 };
 struct Unit {
     uint32_t col0;          // first absolute column of the x sub-tile

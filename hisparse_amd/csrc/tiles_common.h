@@ -340,9 +340,8 @@ inline void assign_workgroups_same_xcd(StreamTiles& out, const std::vector<uint6
             for (uint32_t c = 0; c < 8; ++c) {
                 if (wgs_of_xcd[c].empty()) continue;
                 // per workgroup of the XCD: an XCD with fewer workgroups (groups not a multiple of 8) takes proportionally less
-                // (the WHOLE SpMV is what is balanced first -- hs_run launches every partition at once --, the partition second)
-                const double mine_c = double(xcd_load[c]) / wgs_of_xcd[c].size(), best = x < 8 ? double(xcd_load[x]) / wgs_of_xcd[x].size() : 0.0;
-                if (x == 8 || mine_c < best || (mine_c == best && part_xcd[c] < part_xcd[x])) x = c;
+                const double mine_c = double(part_xcd[c]) / wgs_of_xcd[c].size(), best = x < 8 ? double(part_xcd[x]) / wgs_of_xcd[x].size() : 0.0;
+                if (x == 8 || mine_c < best || (mine_c == best && xcd_load[c] < xcd_load[x])) x = c;
             }
             part_xcd[x] += range_weight[r];
             xcd_load[x] += range_weight[r];
@@ -351,7 +350,7 @@ inline void assign_workgroups_same_xcd(StreamTiles& out, const std::vector<uint6
             for (uint32_t b : blocks) {
                 uint32_t best = wgs_of_xcd[x][0];
                 for (uint32_t g : wgs_of_xcd[x])
-                    if (load[g] < load[best] || (load[g] == load[best] && part_load[g] < part_load[best])) best = g;
+                    if (part_load[g] < part_load[best] || (part_load[g] == part_load[best] && load[g] < load[best])) best = g;
                 mine[best].push_back(b);
                 part_load[best] += block_weight[b] + 16;
                 load[best] += block_weight[b] + 16;
