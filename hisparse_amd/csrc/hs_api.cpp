@@ -54,8 +54,6 @@ struct hs_context {
     uint32_t format = 0;           // StreamFormat of d_image
     bool light = false;            // the LIGHT plan: d_image is a PAIRS image run by spmv_light_kernel (stream_tiles.h)
     uint32_t* d_partial = nullptr;  // col_slices > 1: per-slice partial results, col_slices x num_rows words
-    uint32_t* d_tickets = nullptr;  // fused slice combine: one word per row range (zero between launches); nullptr: the separate combine kernel
-    int xcd_round_robin = -1;       // "workgroup b runs on XCD b % 8" on this device: -1 not probed yet, 0 no, 1 yes
     uint32_t max_block_rows = 0;
     uint32_t* d_x_interleaved = nullptr;   // fused SpMM over a BITMAP image: 4 columns of X as [column][vector] words (allocated on first use)
     // SpMM on the matrix engine (float BITMAP matrices): the second image + scratch (spmm_mfma.hip)
@@ -122,7 +120,7 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 // hs_set_option's keys (the HISPARSE_<KEY> environment switches the library understands); plan-time ones take effect at the next load
 const char* const kOptionKeys[] = {
     "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG", "FORMAT_THREADS",
-    "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS", "FUSED_COMBINE",
+    "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS",
     "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "ITERATE_COOPERATIVE",
 };
 
@@ -135,8 +133,6 @@ void free_matrix(hs_context* c) {
     if (c->d_y) (void)hipFree(c->d_y);
     if (c->d_partial) (void)hipFree(c->d_partial);
     c->d_partial = nullptr;
-    if (c->d_tickets) (void)hipFree(c->d_tickets);
-    c->d_tickets = nullptr;
     if (c->d_x_interleaved) (void)hipFree(c->d_x_interleaved);
     c->d_x_interleaved = nullptr;
     for (void* p : {static_cast<void*>(c->d_mfma), static_cast<void*>(c->d_mfma_x), static_cast<void*>(c->d_mfma_partial), static_cast<void*>(c->d_mfma_flag)})
@@ -200,10 +196,6 @@ hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     a.lds_bytes = c->lds_bytes;
     a.bitmap_x_groups = c->bitmap_x_groups;
     a.light = c->light;
-    a.y_final = y_target(c);
-    a.tickets = c->d_tickets;
-    a.slices = c->col_slices;
-    a.num_rows = c->num_rows;
     return a;
 }
 
@@ -226,9 +218,7 @@ int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1, const F
     const bool is_float = c->impl != HS_IMPL_FIXED;
     uint32_t* x = const_cast<uint32_t*>(x_source(c));
     const uint32_t n_fb = std::min(c->num_rows, c->num_cols);
-    if (c->col_slices > 1 && c->d_tickets) {      // fused slice combine: y is complete when the SpMV kernel ends
-        if (feedback) HS_HIP(c, hisparse::dev::launch_feedback(is_float, y_target(c), x, n_fb, feedback->scale, feedback->shift, c->stream));
-    } else if (c->col_slices > 1) {
+    if (c->col_slices > 1) {
         uint32_t lo = 0, hi = c->num_rows;
         if (filter >= 0) partition_rows(c, uint32_t(filter), lo, hi);
         HS_HIP(c, hisparse::dev::launch_combine_slices(is_float, c->d_partial, y_target(c), c->num_rows, c->col_slices, lo, hi, c->stream,
@@ -435,16 +425,6 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
     if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
-    if (tiles.fused_combine) {
-        // the plan placed every row range's slices on workgroups of one XCD by the rule "hardware workgroup b runs on XCD b % 8": check it on
-        // this device once per context; if it does not hold the SAME image runs with the separate combine kernel (the placement is then
-        // only a different, equally valid, assignment of blocks to workgroups)
-        if (ctx->xcd_round_robin < 0) ctx->xcd_round_robin = hisparse::dev::xcd_dispatch_is_round_robin(ctx->stream) ? 1 : 0;
-        if (ctx->xcd_round_robin == 1) {
-            HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_tickets), std::max<size_t>(tiles.num_ranges, 1) * 4));
-            HS_HIP(ctx, hipMemset(ctx->d_tickets, 0, std::max<size_t>(tiles.num_ranges, 1) * 4));
-        }
-    }
     if (mfma_on_device || (tiles.mfma.words_bytes != 0 && !tiles.mfma.words.empty())) {      // float BITMAP matrix: the second image for the SpMM on the matrix engine + its scratch
         // OPTIONAL: SpMV works without it.  If the image or its scratch cannot be had (out of memory), the matrix loads without a second
         // image and hs_spmm takes the fused 4-column kernel instead.
@@ -497,7 +477,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     s.num_compute_units = uint32_t(ctx->compute_units);
     s.load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     s.retiled_on_gpu = image_on_device;
-    s.light_kernel = (tiles.light ? 1u : 0u) | (ctx->d_tickets ? 2u : 0u);      // bit 1: fused slice combine (no combine launch)
+    s.light_kernel = tiles.light ? 1u : 0u;
     return HS_OK;
 }
 }  // namespace

@@ -25,11 +25,6 @@ struct SpmvLaunch {
     uint32_t num_workgroups;
     uint32_t lds_bytes;
     uint32_t bitmap_x_groups = 0; // BITMAP: lds_bytes ends with room for this many 64-column groups of x (0: x is read through L2)
-    // fused slice combine (StreamTiles::fused_combine; row-block kernel only): tickets != nullptr -> the last block of a row range to finish adds the
-    // `slices` partial vectors (out + k * num_rows) of its rows into y_final; no launch_combine_slices afterwards
-    uint32_t* y_final = nullptr;
-    uint32_t* tickets = nullptr;  // one word per row range, zero between launches
-    uint32_t slices = 1, num_rows = 0;
     bool light = false;           // the LIGHT plan (StreamTiles::light): a PAIRS image consumed by spmv_light_kernel, 256-thread workgroups, lds_bytes = spmv_light_lds_bytes
 };
 
@@ -86,9 +81,6 @@ struct SpmmMfmaLaunch {
 size_t spmm_mfma_x_words(uint32_t groups);
 size_t spmm_mfma_partial_words(uint32_t tiles, uint32_t chunks);
 hipError_t launch_spmm_mfma(const SpmmMfmaLaunch& a, hipStream_t stream);
-// Fused slice combine: is "hardware workgroup b runs on XCD b % 8" true on the current device?  (The plan puts all slices of a row range
-// on logical workgroups of one XCD by that rule; a context only uses a fused plan when this returns true.)  One small launch + a sync.
-bool xcd_dispatch_is_round_robin(hipStream_t stream);
 // BITMAP images (spmv_bitmap.hip); launch_spmv forwards to it when a.format == kFormatBitmap.
 hipError_t configure_bitmap_kernels(uint32_t lds_bytes);
 hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream);

@@ -694,88 +694,6 @@ __device__ __forceinline__ void consumer_run(Consumer<kFloat>& c) {
     }
 }
 
-// ---- fused slice combine (round 4) -----------------------------------------------------------------------------------------------------
-// A column-sliced plan used to end every SpMV with a second launch that adds the slices' partial vectors (combine_slices_kernel: 3-5 us of
-// launch, ramp and tail for a few MB -- 7 % of ogbl-ppa's step, a third of a small slab's).  Round 2 tried to fold it into this kernel twice and
-// lost both times: the blocks of a row range sat on DIFFERENT XCDs, whose L2s only agree after agent-scope release / acquire fences (L2
-// write-back + invalidate: +160 us with a fence per thread, +21 us with one pair per block), or after sc1 write-through stores of single
-// dwords (a fabric write each: +9 us).  What works is to not need either: the planner now puts ALL slices of a row range on workgroups of ONE
-// XCD (tiles_common.h: assign_workgroups_same_xcd), and within an XCD the L2 is the point of coherence --
-//   * every block stores its partial rows with plain stores (write-through L1 -> the shared L2), waits for their acknowledgement
-//     (s_waitcnt vmcnt(0)) and passes a workgroup barrier;
-//   * one lane draws a ticket for the row range with a relaxed agent-scope atomic (performed at the L2 / memory side: it bypasses L1);
-//   * the block that draws the LAST ticket re-arms the counter and adds the `slices` partial rows of its range, read with agent-scope
-//     relaxed loads (global_load ... sc1: they bypass this CU's L1 and are served by the L2 the other blocks wrote through), in slice order
-//     -- the same sums, in the same order, as combine_slices_kernel -- and writes y.
-// Nobody waits for anybody (no deadlock whatever the order the blocks run in), and no fence is issued.  The same-XCD placement rests on
-// "hardware workgroup b runs on XCD b % 8", which hs_api.cpp verifies on the device (xcd_dispatch_is_round_robin: every workgroup reads
-// its XCC_ID) before a context may use a fused plan; otherwise, and for BITMAP's sliced plans, the separate kernel stays.
-struct FusedCombine {
-    uint32_t* y;            // the final result
-    const uint32_t* partial;// slices x num_rows partial words (this launch's `out`)
-    uint32_t* tickets;      // per row range; nullptr: no fused combine in this launch
-    uint32_t slices, num_rows;
-};
-template <bool kFloat>
-__device__ __forceinline__ void fused_combine_rows(const FusedCombine& f, uint32_t range, uint32_t row0, uint32_t nrows, uint32_t tid, uint8_t* lds) {
-    if (!f.tickets) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wavefront's partial rows have reached the L2
-    __syncthreads();                                           // ... and everybody else's of this block
-    uint32_t* last = reinterpret_cast<uint32_t*>(lds);         // (the accumulators have been stored: their first word is free)
-    if (tid == 0) {
-        const uint32_t drawn = __hip_atomic_fetch_add(f.tickets + range, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool is_last = drawn + 1 == f.slices;
-        if (is_last) __hip_atomic_store(f.tickets + range, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
-        *last = is_last ? 1u : 0u;
-    }
-    __syncthreads();
-    const bool mine = *last != 0;
-    __syncthreads();                                           // (the word belongs to the next block's accumulators again)
-    if (!mine) return;
-    // four rows per thread and trip, every slice's word of every one of them requested before the first is used (non-temporal loads: they
-    // bypass this CU's L1 like the sc1 form and, not being atomics, leave the compiler free to keep all of them in flight -- the first
-    // version read its 4-8 slices one dependent L2 round trip after the other: pokec's last blocks took 110 us over it)
-    constexpr uint32_t kRowsPerTrip = 4;
-    for (uint32_t i0 = tid; i0 < nrows; i0 += kThreads * kRowsPerTrip) {
-        uint32_t w[kRowsPerTrip][kMaxColSlices];
-#pragma unroll
-        for (uint32_t j = 0; j < kRowsPerTrip; ++j) {
-            const uint32_t i = min(i0 + j * kThreads, nrows - 1);
-#pragma unroll
-            for (uint32_t k = 0; k < kMaxColSlices; ++k)
-                w[j][k] = k < f.slices ? __builtin_nontemporal_load(f.partial + size_t(k) * f.num_rows + row0 + i) : 0u;
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < kRowsPerTrip; ++j) {
-            const uint32_t i = i0 + j * kThreads;
-            if (i >= nrows) break;
-            uint32_t word;
-            if (kFloat) {
-                float s = 0.0f;
-#pragma unroll
-                for (uint32_t k = 0; k < kMaxColSlices; ++k)
-                    if (k < f.slices) s += __uint_as_float(w[j][k]);      // slice order, like combine_slices_kernel
-                word = __float_as_uint(s);
-            } else {
-                unsigned long long s = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < kMaxColSlices; ++k) s += w[j][k];
-                word = s > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(s);      // min(sum, MAX) == the PE's saturating sum (combine_slices_kernel)
-            }
-            f.y[row0 + i] = word;
-        }
-    }
-}
-
-// every workgroup's XCC_ID (xcd_dispatch_is_round_robin)
-__global__ void xcc_probe_kernel(uint32_t* __restrict__ xcc) {
-    if (threadIdx.x == 0) {
-        uint32_t id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-        xcc[blockIdx.x] = id & 0xfu;
-    }
-}
-
 // kDepth: element loads in flight per lane (kDepth x 512 B per wavefront).
 // kAblate (profiling builds only, HISPARSE_ABLATE): bit 0 = no LDS accumulate, bit 1 = no LDS gather,
 // bit 2 = no x sub-tile refill, bit 3 = no per-sub-tile barrier, bit 4 = no block prologue (zero + first sub-tile),
@@ -786,7 +704,7 @@ template <bool kFloat, int kRing, int kAblate, int kDepth, bool kOwner = false>
 __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const Unit* __restrict__ units, const uint32_t* __restrict__ x,
                                                                   uint32_t* __restrict__ out, int32_t row_part_filter, uint32_t ring,
-                                                                  uint32_t x_base, const uint32_t* __restrict__ part_heads, FusedCombine fused) {
+                                                                  uint32_t x_base, const uint32_t* __restrict__ part_heads) {
     using acc_t = typename Rows<kFloat>::acc_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     acc_t* ys = reinterpret_cast<acc_t*>(lds);                    // [nrows + 1] at LDS address 0: row addresses need no base add
@@ -921,7 +839,6 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
             timeline_stamp<kAblate>(block_no, wave, lane, 3);
             if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = reinterpret_cast<uint32_t*>(ys)[i];     // fp32 bits, or the saturated Q8.24 sum
             timeline_stamp<kAblate>(block_no, wave, lane, 4);
-            if (blk->ticket) fused_combine_rows<kFloat>(fused, blk->ticket - 1, blk->row0, nrows, tid, lds);
             if (!next) break;
             continue;
         }
@@ -934,7 +851,6 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
         // the accumulators are final (no barrier after the store: the last block's stores drain while the workgroup retires)
         if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = Rows<kFloat>::finish(ys[i]);
         timeline_stamp<kAblate>(block_no, wave, lane, 4);
-        if (blk->ticket) fused_combine_rows<kFloat>(fused, blk->ticket - 1, blk->row0, nrows, tid, lds);
         if (!next) break;
     }
 }
@@ -1275,7 +1191,6 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     }
     const int ring = a.format == kFormatDelta ? 1 : a.format == kFormatPairs24 ? 2 : 0;
     const dim3 grid(a.num_workgroups), block(kThreads);
-    const FusedCombine fused{a.y_final, a.out, a.tickets, a.slices, a.num_rows};
     const uint32_t x_base = a.lds_bytes - a.ring_buffers * kBufBytes;
     // profiling aids (libhisparse_hip_prof.so only): HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the
     // prefetch depth; read per launch, a tool may change them between launches.  The product library refuses to run with either set.
@@ -1315,7 +1230,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(A)                                                                                                                       \
     if (ablate == A) {                                                                                                             \
         hipLaunchKernelGGL((spmv_rowblock_kernel<false, 3, A, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
-                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads, fused);                                               \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
         return hipGetLastError();                                                                                                  \
     }
             HS_FOR_EACH_OWNER24_FIXED(X)
@@ -1325,7 +1240,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(A)                                                                                                                       \
     if (ablate == A && records == 3) {                                                                                             \
         hipLaunchKernelGGL((spmv_rowblock_kernel<true, 3, A, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
-                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads, fused);                                               \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
         return hipGetLastError();                                                                                                  \
     }
         HS_FOR_EACH_OWNER24_ABLATION(X)
@@ -1334,7 +1249,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(D)                                                                                                                       \
     if (records == D) {                                                                                                            \
         hipLaunchKernelGGL((spmv_rowblock_kernel<true, 3, 0, D, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
-                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads, fused);                                               \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
         return hipGetLastError();                                                                                                  \
     }
         HS_FOR_EACH_OWNER24_DEPTH(X)
@@ -1354,7 +1269,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(A)                                                                                                                      \
     if (!launched && ablate == A) {                                                                                               \
         hipLaunchKernelGGL((spmv_rowblock_kernel<true, false, A, 8, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks,  \
-                           a.units, a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads, fused);                        \
+                           a.units, a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                        \
         launched = true;                                                                                                          \
     }
         if (depth == 8) {
@@ -1377,28 +1292,13 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(F, T, A, D)                                                                                                           \
     if (!launched && is_float == F && ring == int(T) && ablate == A && depth == D) {                                     \
         hipLaunchKernelGGL((spmv_rowblock_kernel<F, T, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \
-                           a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads, fused);                   \
+                           a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                   \
         launched = true;                                                                                                        \
     }
     HS_FOR_EACH_VARIANT(X)
 #undef X
     if (!launched) return hipErrorInvalidValue;   // unknown HISPARSE_ABLATE / HISPARSE_DEPTH combination
     return hipGetLastError();
-}
-
-bool xcd_dispatch_is_round_robin(hipStream_t stream) {
-    constexpr uint32_t kProbe = 1024;      // four rounds of the 256 CUs
-    uint32_t* d = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&d), kProbe * 4) != hipSuccess) return false;
-    std::vector<uint32_t> xcc(kProbe, 0xffu);
-    hipLaunchKernelGGL(xcc_probe_kernel, dim3(kProbe), dim3(64), 0, stream, d);
-    const bool ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(xcc.data(), d, kProbe * 4, hipMemcpyDeviceToHost, stream) == hipSuccess &&
-                    hipStreamSynchronize(stream) == hipSuccess;
-    (void)hipFree(d);
-    if (!ok) return false;
-    for (uint32_t b = 0; b < kProbe; ++b)
-        if (xcc[b] != xcc[b % 8]) return false;      // the XCD of a workgroup follows from its id modulo 8 (whatever XCC the residue names)
-    return true;
 }
 
 hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_t* y, uint32_t num_rows, uint32_t slices, uint32_t row_lo,

@@ -279,19 +279,9 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     // every workgroup ends up with the same number of blocks
     const uint64_t per_round = std::max<uint32_t>(1, G / slices);
     const uint64_t rounds = std::max<uint64_t>(1, ((uint64_t(num_rows) + max_rows - 1) / max_rows + per_round - 1) / per_round);
-    uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(per_round * rounds, out.nnz / (light ? kLightMinBlockNnz : 4096u)));
-    // a sliced plan of the row-block kernel (fused slice combine, below): every XCD takes whole row ranges -- all slices of a range share one
-    // L2 -- so the range count is a multiple of 8 (one XCD with a range more than the others would set the kernel time)
-    if (slices > 1 && want_ranges >= 8 && !env_switch("HISPARSE_FUSED_COMBINE_ANY_RANGES")) want_ranges -= want_ranges % 8;
+    const uint64_t want_ranges = std::max<uint64_t>(1, std::min<uint64_t>(per_round * rounds, out.nnz / (light ? kLightMinBlockNnz : 4096u)));
     build_row_ranges_at_most(L, row_nnz, out.nnz, want_ranges, max_rows, ranges, range_nnz, out.nnz / 4096 >= per_round * rounds ? per_round : 0);
     const uint32_t NR = uint32_t(ranges.size());
-    // Fused slice combine (stream_tiles.h): the last block of a row range to finish adds the slices' partial rows itself -- no combine launch
-    // (3-5 us of every sliced step: 7 % of ogbl-ppa's, a third of a small slab's).  HISPARSE_FUSED_COMBINE=0 keeps the separate kernel.
-    bool fused = slices > 1;
-    if (const char* force = env_switch("HISPARSE_FUSED_COMBINE")) fused = fused && std::atoi(force) != 0;
-    if (const char* affinity = env_switch("HISPARSE_XCD_AFFINITY")) fused = fused && std::atoi(affinity) == 0;      // (the by-slice placement experiment wants the workgroups for itself)
-    out.fused_combine = fused;
-    out.num_ranges = NR;
     std::vector<uint32_t> block_of_row(num_rows);   // row -> row range
     for (uint32_t b = 0; b < NR; ++b) {
         std::fill(block_of_row.begin() + ranges[b].row0, block_of_row.begin() + ranges[b].row0 + ranges[b].nrows, b);
@@ -377,7 +367,6 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                 blk.flags = (ranges[b].nrows <= kDenseBlockRows && range_nnz[b] >= 64ull * ranges[b].nrows) ? kBlockDenseRows : 0u;
             }
             blk.out_offset = slices > 1 ? slice * num_rows + ranges[b].row0 : ranges[b].row0;
-            blk.ticket = fused ? b + 1 : 0;
             blk.unit_begin = uint32_t(out.units.size());
             for (uint32_t k = 0; k < sub_tiles; ++k) {
                 if (slice_of[k] != slice) continue;
@@ -639,9 +628,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         // slices' x.  Kept for experiments; the default stays the spread assignment.
         bool by_slice = false;
         if (const char* force = env_switch("HISPARSE_XCD_AFFINITY")) by_slice = std::atoi(force) != 0 && slices > 1 && G % 8 == 0 && NB >= G;
-        if (fused) {
-            assign_workgroups_same_xcd(out, block_nnz, G, RP, range_of_block, NR, mine);
-        } else if (by_slice) {
+        if (by_slice) {
             std::vector<uint32_t> slice_of_block(NB);
             for (uint32_t bi = 0; bi < NB; ++bi) slice_of_block[bi] = bi % slices;      // blocks were pushed range by range, slice by slice
             assign_workgroups_by_slice(out, block_nnz, G, RP, slice_of_block, mine);

@@ -194,8 +194,7 @@ struct Block {
     uint32_t total_steps[kConsumerWaves];   // == units[unit_end - 1].end_step
     uint32_t first_end[kConsumerWaves];     // == units[unit_begin].end_step
     uint32_t first_col0, first_ncols;       // == units[unit_begin].col0 / .ncols (0 / 0 for a block without units)
-    uint32_t ticket;        // fused slice combine (StreamTiles::fused_combine): 1 + the block's row range = its slot in the ticket array; 0: none
-    uint32_t pad[13];
+    uint32_t pad[14];
 };
 struct Unit {
     uint32_t col0;          // first absolute column of the x sub-tile
@@ -265,9 +264,6 @@ struct StreamTiles {
     uint32_t max_block_rows = 0;
     bool light = false;                  // the LIGHT plan (below): PAIRS image, one slice, up to kLightWorkgroupsPerCu x CUs small blocks, spmv_light_kernel
     uint32_t col_slices = 1;             // > 1: blocks write per-slice partial results, a combine pass adds them
-    bool fused_combine = false;          // col_slices > 1 in the row-block kernel: the LAST block of a row range to finish adds the slices' partial rows
-                                         // itself (all blocks of a range run on one XCD: one L2) -- no combine launch (spmv_kernels.hip; round 4)
-    uint32_t num_ranges = 0;             // row ranges (= ticket slots) of a fused plan
     uint32_t ring_buffers = kMaxXBuffers;
     StreamFormat format = kFormatPairs;
     uint64_t nnz = 0;

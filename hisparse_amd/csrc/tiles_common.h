@@ -307,69 +307,9 @@ inline void assign_workgroups_by_slice(StreamTiles& out, const std::vector<uint6
     (void)row_parts;
 }
 
-// Fused slice combine (round 4): ALL column slices of a row range go to workgroups of ONE XCD, so that the last of them to finish can add
-// the others' partial rows out of the L2 they share (spmv_kernels.hip: fused_combine).  Which logical workgroups share an XCD follows from
-// the kernels' own rule: hardware workgroup b runs on XCD b % 8; with a multiple of 8 workgroups the kernels renumber so that logical
-// workgroups [x * groups/8, (x+1) * groups/8) sit on XCD x, otherwise logical = hardware id.  (hs_api.cpp checks the b % 8 rule on the
-// device before it lets a context use a fused plan.)  Row partition by row partition: heaviest row range first, each to the XCD with the
-// least work in this partition; inside the XCD its blocks go, heaviest first, to the workgroup with the least work.
-inline void assign_workgroups_same_xcd(StreamTiles& out, const std::vector<uint64_t>& block_weight, uint32_t max_workgroups, uint32_t row_parts,
-                                       const std::vector<uint32_t>& range_of_block, uint32_t num_ranges, std::vector<std::vector<uint32_t>>& mine) {
-    const uint32_t NB = uint32_t(out.blocks.size());
-    const uint32_t groups = std::min<uint32_t>(std::max<uint32_t>(1, max_workgroups), std::max<uint32_t>(1, NB));
-    out.num_workgroups = groups;
-    mine.assign(groups, {});
-    const bool renumbered = groups % 8 == 0;
-    std::vector<std::vector<uint32_t>> wgs_of_xcd(8);
-    for (uint32_t g = 0; g < groups; ++g) wgs_of_xcd[renumbered ? g / (groups / 8) : g % 8].push_back(g);
-    std::vector<std::vector<uint32_t>> blocks_of_range(num_ranges);
-    std::vector<uint64_t> range_weight(num_ranges, 0);
-    for (uint32_t b = 0; b < NB; ++b) {
-        blocks_of_range[range_of_block[b]].push_back(b);
-        range_weight[range_of_block[b]] += block_weight[b] + 16;
-    }
-    std::vector<uint64_t> load(groups, 0), xcd_load(8, 0);
-    for (uint32_t rp = 0; rp < row_parts; ++rp) {
-        std::vector<uint32_t> order;
-        for (uint32_t r = 0; r < num_ranges; ++r)
-            if (!blocks_of_range[r].empty() && out.blocks[blocks_of_range[r][0]].row_part == rp) order.push_back(r);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return range_weight[a] > range_weight[b]; });
-        std::vector<uint64_t> part_xcd(8, 0), part_load(groups, 0);
-        for (uint32_t r : order) {
-            uint32_t x = 8;
-            for (uint32_t c = 0; c < 8; ++c) {
-                if (wgs_of_xcd[c].empty()) continue;
-                // per workgroup of the XCD: an XCD with fewer workgroups (groups not a multiple of 8) takes proportionally less
-                const double mine_c = double(part_xcd[c]) / wgs_of_xcd[c].size(), best = x < 8 ? double(part_xcd[x]) / wgs_of_xcd[x].size() : 0.0;
-                if (x == 8 || mine_c < best || (mine_c == best && xcd_load[c] < xcd_load[x])) x = c;
-            }
-            part_xcd[x] += range_weight[r];
-            xcd_load[x] += range_weight[r];
-            std::vector<uint32_t> blocks = blocks_of_range[r];
-            std::stable_sort(blocks.begin(), blocks.end(), [&](uint32_t a, uint32_t b) { return block_weight[a] > block_weight[b]; });
-            for (uint32_t b : blocks) {
-                uint32_t best = wgs_of_xcd[x][0];
-                for (uint32_t g : wgs_of_xcd[x])
-                    if (part_load[g] < part_load[best] || (part_load[g] == part_load[best] && load[g] < load[best])) best = g;
-                mine[best].push_back(b);
-                part_load[best] += block_weight[b] + 16;
-                load[best] += block_weight[b] + 16;
-            }
-        }
-    }
-}
-
 // Final block order: the first block of workgroup g sits at blocks[g] (ONE dependent load before the kernel's first
 // stream load), further blocks of a workgroup are chained through Block::next.  Fills wg_first / block_order / part_heads.
-inline void chain_blocks(StreamTiles& out, std::vector<std::vector<uint32_t>> mine, uint32_t row_parts) {
-    // A workgroup without a block (assign_workgroups_same_xcd: an XCD that got fewer blocks than it has workgroups) still starts at
-    // blocks[g]: it gets an empty block of its own -- no rows, no units -- so that every other workgroup keeps its number, i.e. its XCD.
-    for (auto& list : mine) {
-        if (!list.empty()) continue;
-        Block idle{};
-        list.push_back(uint32_t(out.blocks.size()));
-        out.blocks.push_back(idle);
-    }
+inline void chain_blocks(StreamTiles& out, const std::vector<std::vector<uint32_t>>& mine, uint32_t row_parts) {
     const uint32_t groups = out.num_workgroups, NB = uint32_t(out.blocks.size());
     std::vector<uint32_t> new_index(NB, 0);
     uint32_t tail = 0;

@@ -36,10 +36,7 @@ class Stats(C.Structure):
                 ("load_seconds", C.c_double), ("retiled_on_gpu", C.c_uint32), ("light_kernel", C.c_uint32)]
 
     def as_dict(self):
-        d = {name: getattr(self, name) for name, _ in self._fields_}
-        d["fused_combine"] = (d["light_kernel"] >> 1) & 1      # bit 1: a sliced plan whose SpMV kernel adds the slices itself (no combine launch)
-        d["light_kernel"] &= 1                                  # bit 0: the LIGHT plan (spmv_light_kernel)
-        return d
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 STREAM_FORMATS = ("pairs", "delta", "bitmap", "owner", "pairs24", "owner24")   # HS_STREAM_* (include/hisparse_hip.h)
@@ -48,7 +45,7 @@ CONSUMER_WAVES = 14
 BLOCK_DTYPE = np.dtype([("row0", "<u4"), ("nrows", "<u4"), ("row_part", "<u4"), ("unit_begin", "<u4"), ("unit_end", "<u4"),
                         ("flags", "<u4"), ("out_offset", "<u4"), ("next", "<u4"), ("wave_offset", "<u8", (CONSUMER_WAVES,)),
                         ("total_steps", "<u4", (CONSUMER_WAVES,)), ("first_end", "<u4", (CONSUMER_WAVES,)), ("first_col0", "<u4"),
-                        ("first_ncols", "<u4"), ("ticket", "<u4"), ("pad", "<u4", (13,))])
+                        ("first_ncols", "<u4"), ("pad", "<u4", (14,))])
 UNIT_DTYPE = np.dtype([("col0", "<u4"), ("ncols", "<u4"), ("end_step", "<u4", (CONSUMER_WAVES,))])
 
 

@@ -78,8 +78,7 @@ typedef struct {
     uint32_t stream_format;     /* HS_STREAM_PAIRS (8 B per element), HS_STREAM_DELTA (6 B per slot) or HS_STREAM_BITMAP (4 B + 1 bit per column) HS_STREAM_OWNER (8 B per element, float accumulators) or the 7-byte forms of PAIRS / OWNER, chosen per matrix */
     double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
     uint32_t retiled_on_gpu;    /* 1: the per-non-zero passes of the re-tiling ran on the device (gpu_tiles.h); 0: on the host */
-    uint32_t light_kernel;      /* bit 0: the LIGHT plan -- a small matrix run by the 256-thread single-launch kernel (spmv_light_kernel) over a PAIRS image;
-                                   bit 1: fused slice combine -- a column-sliced plan whose SpMV kernel adds the slices itself (no combine launch) */
+    uint32_t light_kernel;      /* 1: the LIGHT plan -- a small matrix run by the 256-thread single-launch kernel (spmv_light_kernel) over a PAIRS image */
 } hs_stats;
 
 const char* hs_strerror(int code);

@@ -470,45 +470,6 @@ def test_blocks_go_to_xcds_by_column_slice(impl, ob, monkeypatch):
     assert np.array_equal(y, want) if impl == 0 else cases.float_close(y, want)
 
 
-@pytest.mark.parametrize("impl,slices,G", [(0, 4, 64), (2, 5, 64), (0, 6, 252), (1, 7, 24)])
-def test_fused_combine_puts_every_row_range_on_one_xcd(impl, slices, G, monkeypatch):
-    """Round 4: a column-sliced plan of the row-block kernel carries a ticket per row range (Block::ticket = 1 + range) and ALL slices of a
-    range sit on workgroups of one XCD -- logical workgroups [x * G/8, (x+1) * G/8) when G is a multiple of 8 (the kernels renumber), the
-    residue class of the workgroup id otherwise -- so that the last block of a range to finish can add the others' partial rows out of
-    the L2 they share.  Every workgroup has a block (an idle one if need be: its number is its XCD), every real block runs once, chains
-    stay ordered by row partition, and y is what the oracle says."""
-    fmt = os.environ.get("HISPARSE_STREAM_FORMAT")
-    if fmt == "bitmap":
-        pytest.skip("BITMAP images have their own builder and keep the separate combine kernel")
-    if impl != 0 and fmt in ("pairs24",):
-        pytest.skip("fixed-point only form")
-    monkeypatch.setenv("HISPARSE_COL_SLICES", str(slices))
-    monkeypatch.setenv("HISPARSE_LIGHT", "0")
-    monkeypatch.setenv("HISPARSE_MAX_ROWS", "700")
-    csr = host.CSRMatrix.generate("powerlaw", 30000, 90000, a=400000, b=0.4, c=1.0 if impl == 0 else 2.0, seed=5)
-    cp = host.format_matrix(csr, impl, ob_bank=16 if impl != 2 else 8, skip_empty_rows=True)      # several row partitions
-    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 5, impl))
-    t = build(cp, impl, G)
-    assert t["col_slices"] == slices
-    blocks = t["blocks"]
-    real = blocks["ticket"] > 0
-    assert real.sum() >= slices and (np.bincount(blocks["ticket"][real]) [1:] == slices).all()      # every range: exactly `slices` blocks
-    groups = t["num_workgroups"]
-    xcd_of_wg = (lambda g: g // (groups // 8)) if groups % 8 == 0 else (lambda g: g % 8)
-    xcd_of_ticket = {}
-    for g in range(groups):
-        mine = t["block_order"][t["wg_first"][g]: t["wg_first"][g + 1]]
-        assert len(mine) >= 1                                         # (an idle block if nothing else)
-        assert (np.diff(blocks["row_part"][mine].astype(np.int64)) >= 0).all()
-        for b in mine:
-            if blocks["ticket"][b]:
-                assert xcd_of_ticket.setdefault(int(blocks["ticket"][b]), xcd_of_wg(g)) == xcd_of_wg(g)
-    assert sorted(np.concatenate([t["block_order"][t["wg_first"][g]: t["wg_first"][g + 1]] for g in range(groups)]).tolist()) == list(range(len(blocks)))
-    want = oracle_y(cp, impl, xw)
-    got = tile_emulator.run(t, impl, xw, cp.num_rows)
-    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
-
-
 def test_plans_of_small_and_narrow_matrices(monkeypatch):
     """Round-3 planner rules (stream_tiles.cpp, "tile plan"), each on the shape it was measured on, emulated against the oracle:
     a few-row PAIRS block puts many lanes of a step into one row (LDS atomics collide) -> one slice per sub-tile; a matrix of at most 16
@@ -521,8 +482,7 @@ def test_plans_of_small_and_narrow_matrices(monkeypatch):
     csr = host.CSRMatrix.generate("powerlaw", 11264, 45101, a=7.2e6, b=0.30, c=0.1, seed=44)
     cp = host.format_matrix(csr, 0, skip_empty_rows=True)
     t = build(cp, 0, 256)
-    # (40 row ranges, not 42: a sliced plan takes a multiple of 8 so that every XCD gets whole ranges -- the fused slice combine, round 4)
-    assert t["col_slices"] == 6 and len(t["blocks"]) == 240 and len(t["units"]) == 240
+    assert t["col_slices"] == 6 and len(t["blocks"]) == 252 and len(t["units"]) == 252
     xw = host.pack_vector(0, cases.random_x(cp.num_cols, 3, 0))
     assert np.array_equal(tile_emulator.run(t, 0, xw, cp.num_rows), oracle_y(cp, 0, xw))
     # 14 sub-tiles (gplus's shape, a tenth of its non-zeros): 7 slices = two sub-tiles each, not 6 or 8
