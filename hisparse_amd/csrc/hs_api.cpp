@@ -71,12 +71,13 @@ struct hs_context {
     uint32_t* d_csc_vals = nullptr;
     hisparse::dev::SpmspvScratch csc_scratch;      // the product list (rows, product words, row blocks) and its counters
     std::vector<uint32_t> csc_col_len;             // host copy of the column lengths: splits a host-side x whose products exceed the list
-    uint32_t spmspv_call = 0;                      // picks the product counter (spmspv.hip)
     uint32_t* d_csc_y = nullptr;                   // max(csc rows, the dense matrix's padded rows) words
     uint32_t csc_y_words = 0;
     hisparse::dev::hs_idx_val_dev* d_sx = nullptr; // hs_spmspv: the caller's IDX_VAL_T pairs on the device ...
-    hisparse::dev::hs_idx_val_dev* h_sx = nullptr; // ... and the pinned staging buffer they are copied from (asynchronously)
-    hipEvent_t sx_copied = nullptr;                // the staging buffer is free again
+    hisparse::dev::hs_idx_val_dev* h_sx = nullptr; // ... = this pinned, mapped staging buffer (two halves of sx_capacity entries, used in turn)
+    hipEvent_t sx_read[2] = {nullptr, nullptr};    // half h's kernels have read it: the host may write it again
+    uint32_t sx_turn = 0;
+    std::vector<uint8_t> sx_seen;                  // one bit per column, all zero between calls (the repeat check of hs_spmspv)
     uint32_t sx_capacity = 0;
     uint32_t* d_x_dense = nullptr;                 // dense dispatch: x scattered into a zero vector (num_cols words)
     uint32_t csc_rows = 0, csc_cols = 0;
@@ -151,13 +152,15 @@ void free_matrix(hs_context* c) {
 void free_csc(hs_context* c) {
     hisparse::dev::SpmspvScratch& w = c->csc_scratch;
     for (void* p : {static_cast<void*>(c->d_csc_indptr), static_cast<void*>(c->d_csc_rows), static_cast<void*>(c->d_csc_vals), static_cast<void*>(c->d_csc_y),
-                    static_cast<void*>(c->d_sx), static_cast<void*>(w.keys), static_cast<void*>(w.vals), static_cast<void*>(w.blks), static_cast<void*>(w.counters),
-                    static_cast<void*>(c->d_x_dense)})
+                    static_cast<void*>(w.keys), static_cast<void*>(w.vals), static_cast<void*>(w.bin_base), static_cast<void*>(w.cursors),
+                    static_cast<void*>(w.overflow), static_cast<void*>(c->d_x_dense)})
         if (p) (void)hipFree(p);
     if (c->h_sx) (void)hipHostFree(c->h_sx);
-    if (c->sx_copied) (void)hipEventDestroy(c->sx_copied);
+    for (hipEvent_t& e : c->sx_read) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
     c->h_sx = nullptr;
-    c->sx_copied = nullptr;
     c->d_csc_indptr = c->d_csc_rows = c->d_csc_vals = c->d_csc_y = c->d_x_dense = nullptr;
     c->d_sx = nullptr;
     w = hisparse::dev::SpmspvScratch();
@@ -635,7 +638,13 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* 
         if (indptr[c + 1] < indptr[c]) return fail(ctx, HS_ERR_BAD_MATRIX, "CSC indptr must be non-decreasing");
     for (uint64_t e = 0; e < nnz; ++e)
         if (row_indices[e] >= num_rows) return fail(ctx, HS_ERR_BAD_MATRIX, "CSC row index out of range");
-    if ((uint64_t(num_rows) + 8191) / 8192 > 65536) return fail(ctx, HS_ERR_UNSUPPORTED, "more than 65536 row blocks of 8192 rows");
+    const uint32_t bins = hisparse::dev::spmspv_bins(num_rows), block_bits = hisparse::dev::spmspv_block_bits(num_rows);
+    if (bins > hisparse::dev::spmspv_max_bins()) return fail(ctx, HS_ERR_UNSUPPORTED, "more than 2048 row blocks of 8192 rows (16.7 M rows)");
+    if (nnz > 0xfffffff0ull) return fail(ctx, HS_ERR_UNSUPPORTED, "more than 2^32 non-zeros");
+    // a bin per row block, as large as the block's share of the matrix: products of an x that names every column at most once always fit
+    std::vector<uint32_t> bin_base(size_t(bins) + 1, 0);
+    for (uint64_t e = 0; e < nnz; ++e) bin_base[(row_indices[e] >> block_bits) + 1]++;
+    for (uint32_t b = 0; b < bins; ++b) bin_base[b + 1] += bin_base[b];
     HS_HIP(ctx, hipSetDevice(ctx->device));
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_csc(ctx);
@@ -643,12 +652,15 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* 
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_rows), std::max<size_t>(nnz, 1) * 4));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_vals), std::max<size_t>(nnz, 1) * 4));
     hisparse::dev::SpmspvScratch& w = ctx->csc_scratch;
-    w.capacity = std::min<uint64_t>(std::max<uint64_t>(nnz, 1), 0xfffffff0ull);
+    w.capacity = std::max<uint64_t>(nnz, 1);
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.keys), size_t(w.capacity) * 4));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.vals), size_t(w.capacity) * 4));
-    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.blks), hisparse::dev::spmspv_list_bytes(w.capacity)));
-    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.counters), 3 * sizeof(unsigned long long)));
-    HS_HIP(ctx, hipMemset(w.counters, 0, 3 * sizeof(unsigned long long)));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.bin_base), (size_t(bins) + 1) * 4));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.cursors), size_t(bins) * 4));
+    HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&w.overflow), 4));
+    HS_HIP(ctx, hipMemcpy(w.bin_base, bin_base.data(), bin_base.size() * 4, hipMemcpyHostToDevice));
+    HS_HIP(ctx, hipMemset(w.cursors, 0, size_t(bins) * 4));
+    HS_HIP(ctx, hipMemset(w.overflow, 0, 4));
     // y: also large enough for the dense SpMV's padded rows (dense dispatch of hs_spmspv writes it directly)
     ctx->csc_y_words = std::max(num_rows, ctx->matrix_loaded ? ctx->num_rows : 0u);
     ctx->csc_y_words = std::max<uint32_t>(ctx->csc_y_words, uint32_t((uint64_t(num_rows) + ctx->geom.row_divisor - 1) / ctx->geom.row_divisor * ctx->geom.row_divisor));
@@ -665,7 +677,6 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* 
     ctx->csc_cols = num_cols;
     ctx->csc_nnz = nnz;
     ctx->dense_spmv_us = 0.0;
-    ctx->spmspv_call = 0;
     return HS_OK;
 }
 
@@ -674,8 +685,7 @@ namespace {
 // one pass: expand + accumulate over `count` device-resident entries
 int spmspv_pass(hs_context* ctx, const hisparse::dev::hs_idx_val_dev* x_dev, uint32_t count, bool add_to_y) {
     HS_HIP(ctx, hisparse::dev::launch_spmspv(ctx->impl != HS_IMPL_FIXED, ctx->d_csc_indptr, ctx->d_csc_rows, ctx->d_csc_vals, x_dev, count, ctx->csc_rows,
-                                             ctx->csc_cols, ctx->csc_scratch, ctx->spmspv_call, add_to_y, ctx->d_csc_y, ctx->stream));
-    ++ctx->spmspv_call;
+                                             ctx->csc_cols, ctx->csc_scratch, add_to_y, ctx->d_csc_y, ctx->stream));
     return HS_OK;
 }
 
@@ -715,53 +725,76 @@ int hs_spmspv_device(hs_context* ctx, const hs_idx_val* x_entries_dev, uint32_t 
 int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
     if (!ctx || (count && !x_entries)) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
     if (!ctx->d_csc_indptr) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix_csc has not been called");
-    for (uint32_t k = 0; k < count; ++k)
-        if (x_entries[k].index >= ctx->csc_cols) return fail(ctx, HS_ERR_BAD_ARG, "sparse vector index out of range");
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    // One pass over the entries: range check, repeat check (a bit per column, kept zero between calls) and this call's product count.
+    // A bin of the product list holds as many products as the matrix has non-zeros in that row block: an x that names a column more than once
+    // can ask for more.  Such a call is cut into passes of UNIQUE columns -- pass i takes the i-th occurrence of every column: each pass fits by
+    // construction -- y = first pass, y += the others (the sums are order-free: exact in fixed point, tolerance in float).  Repeats also rule
+    // the dense dispatch out (two entries of one column are two separately rounded products, not one product of their sum).
+    std::vector<uint32_t> pass_end;      // entries [pass_end[i-1], pass_end[i]) of the STAGED order form pass i
+    bool repeats = false;
+    uint64_t products = 0;
+    {
+        if (ctx->sx_seen.size() != (size_t(ctx->csc_cols) + 7) / 8) ctx->sx_seen.assign((size_t(ctx->csc_cols) + 7) / 8, 0);
+        uint8_t* seen = ctx->sx_seen.data();
+        uint32_t k = 0;
+        for (; k < count; ++k) {
+            const uint32_t col = x_entries[k].index;
+            if (col >= ctx->csc_cols) break;
+            repeats |= (seen[col >> 3] >> (col & 7)) & 1u;
+            seen[col >> 3] |= uint8_t(1u << (col & 7));
+            products += ctx->csc_col_len[col];
+        }
+        for (uint32_t j = 0; j < k; ++j) seen[x_entries[j].index >> 3] = 0;
+        if (k < count) return fail(ctx, HS_ERR_BAD_ARG, "sparse vector index out of range");
+    }
     if (count > ctx->sx_capacity) {
         HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_sx) (void)hipFree(ctx->d_sx);
         if (ctx->h_sx) (void)hipHostFree(ctx->h_sx);
         ctx->d_sx = ctx->h_sx = nullptr;
         ctx->sx_capacity = 0;
         const uint32_t cap = std::max<uint32_t>(count, 1024);
-        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_sx), size_t(cap) * 8));
-        HS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_sx), size_t(cap) * 8, hipHostMallocDefault));
-        if (!ctx->sx_copied) HS_HIP(ctx, hipEventCreateWithFlags(&ctx->sx_copied, hipEventDisableTiming));
+        // pinned AND mapped: the expand kernel reads the entries straight out of host memory (8 bytes per entry, once, coalesced) -- no copy
+        // command in front of it (an H2D of 46 KB put ~15 us between the call and its first kernel).  Two halves used in turn, so that the
+        // host fills one while the previous call's kernels may still be reading the other.
+        HS_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_sx), size_t(cap) * 2 * 8, hipHostMallocMapped));
+        HS_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_sx), ctx->h_sx, 0));
+        for (hipEvent_t& e : ctx->sx_read)
+            if (!e) HS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->sx_capacity = cap;
-    } else if (ctx->sx_copied && count) {
-        HS_HIP(ctx, hipEventSynchronize(ctx->sx_copied));      // the previous call's copy out of the staging buffer (long done, normally)
+        ctx->sx_turn = 0;
     }
-    // The product list holds as many products as the matrix has non-zeros: an x that names columns more than once can ask for more.  The
-    // host knows every column's length, so such a call is cut into passes that fit (y = first pass, y += the others).  Repeats also
-    // rule the dense dispatch out (two entries of one column are two separately rounded products, not one product of their sum).
-    std::vector<uint32_t> pass_end;      // entries [pass_end[i-1], pass_end[i]) form pass i
-    uint64_t in_pass = 0;
-    bool repeats = false;
-    {
-        std::vector<uint8_t> seen((size_t(ctx->csc_cols) + 7) / 8, 0);
-        for (uint32_t k = 0; k < count; ++k) {
-            const uint32_t col = x_entries[k].index, len = ctx->csc_col_len[col];
-            if (seen[col >> 3] & (1u << (col & 7))) repeats = true;
-            seen[col >> 3] |= uint8_t(1u << (col & 7));
-            if (in_pass + len > ctx->csc_scratch.capacity && in_pass) { pass_end.push_back(k); in_pass = 0; }
-            in_pass += len;
-        }
+    const uint32_t half = ctx->sx_turn & 1u;
+    ctx->sx_turn++;
+    if (count) HS_HIP(ctx, hipEventSynchronize(ctx->sx_read[half]));      // the call before last read this half (long done, normally; a never-recorded event is complete)
+    hisparse::dev::hs_idx_val_dev* const staged = ctx->h_sx + size_t(half) * ctx->sx_capacity;
+    const hisparse::dev::hs_idx_val_dev* const staged_dev = ctx->d_sx + size_t(half) * ctx->sx_capacity;
+    if (!repeats) {
+        if (count) std::memcpy(staged, x_entries, size_t(count) * sizeof(hs_idx_val));
         pass_end.push_back(count);
+    } else {
+        // occurrence number of every entry, then a stable counting sort by it into the staging buffer
+        std::vector<uint32_t> occurrence(count), seen_times(ctx->csc_cols, 0), per_pass;
+        for (uint32_t k = 0; k < count; ++k) {
+            occurrence[k] = seen_times[x_entries[k].index]++;
+            if (occurrence[k] >= per_pass.size()) per_pass.resize(occurrence[k] + 1, 0);
+            per_pass[occurrence[k]]++;
+        }
+        std::vector<uint32_t> at(per_pass.size(), 0);
+        for (size_t i = 1; i < per_pass.size(); ++i) at[i] = at[i - 1] + per_pass[i - 1];
+        for (size_t i = 0; i < per_pass.size(); ++i) pass_end.push_back(at[i] + per_pass[i]);
+        for (uint32_t k = 0; k < count; ++k) {
+            staged[at[occurrence[k]]].index = x_entries[k].index;
+            staged[at[occurrence[k]]].val = x_entries[k].val;
+            ++at[occurrence[k]];
+        }
     }
-    if (count) {
-        std::memcpy(ctx->h_sx, x_entries, size_t(count) * sizeof(hs_idx_val));
-        HS_HIP(ctx, hipMemcpyAsync(ctx->d_sx, ctx->h_sx, size_t(count) * sizeof(hs_idx_val), hipMemcpyHostToDevice, ctx->stream));
-        HS_HIP(ctx, hipEventRecord(ctx->sx_copied, ctx->stream));
-    }
-    // Above the crossover the dense SpMV is faster (it reads every non-zero once, coalesced; on the sparse path every row block's
-    // workgroup sweeps the whole product list): hisparse_hip.h.  The host knows this call's product count exactly (the columns' lengths),
-    // the sparse path costs ~12 us + products / 5 G/s (profiles/r04_spmspv.txt: ogbl-ppa, mouse_gene, pokec), and the dense SpMV of the
+    // Above the crossover the dense SpMV is faster (it reads every non-zero once, coalesced, at 6-8 bytes; the sparse path reads a column
+    // entry, writes its product into a bin and reads it again): hisparse_hip.h.  The host knows this call's product count exactly (the
+    // columns' lengths), the sparse path costs ~14 us + products / 45 G/s (profiles/r04_spmspv_binned.txt: ogbl-ppa, mouse_gene, pokec), and the dense SpMV of the
     // loaded matrix is TIMED once, on the first call that could use it (three launches on a zero vector and one synchronisation; hyper-
     // sparse matrices run at a third of the roofline, so no formula over the non-zero count would do).  `spmspv_crossover` (a fraction of
     // the columns) overrides the rule; `spmspv` = sparse | dense forces a path.
-    uint64_t products = 0;
-    for (uint32_t k = 0; k < count; ++k) products += ctx->csc_col_len[x_entries[k].index];
     const char* force = ctx_option(ctx, "HISPARSE_SPMSPV");
     const bool possible = !repeats && dense_dispatch_possible(ctx);
     bool want_dense = false;
@@ -770,7 +803,7 @@ int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
     } else if (const char* v = ctx_option(ctx, "HISPARSE_SPMSPV_CROSSOVER")) {
         const double crossover = std::atof(v);
         want_dense = crossover > 0.0 && double(count) > crossover * double(ctx->csc_cols);
-    } else if (possible && 12.0 + double(products) / 5000.0 > 30.0) {      // (below 30 us no dense SpMV of a matrix worth a CSC copy competes)
+    } else if (possible && 14.0 + double(products) / 45000.0 > 30.0) {      // (below 30 us no dense SpMV of a matrix worth a CSC copy competes)
         if (ctx->dense_spmv_us <= 0.0) {
             if (!ctx->d_x_dense) {
                 HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_x_dense), size_t(ctx->num_cols) * 4));
@@ -796,16 +829,20 @@ int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
             if (rc != HS_OK) return rc;
         }
         // + the scatter of x into the zero vector (a memset and a small kernel: ~8 us)
-        want_dense = ctx->dense_spmv_us > 0.0 && 12.0 + double(products) / 5000.0 > ctx->dense_spmv_us + 8.0;
+        want_dense = ctx->dense_spmv_us > 0.0 && 14.0 + double(products) / 45000.0 > ctx->dense_spmv_us + 8.0;
     }
-    if (want_dense && possible) return spmspv_dense(ctx, ctx->d_sx, count);
-    uint32_t begin = 0;
-    for (size_t i = 0; i < pass_end.size(); ++i) {
-        const int rc = spmspv_pass(ctx, ctx->d_sx + begin, pass_end[i] - begin, i != 0);
-        if (rc != HS_OK) return rc;
-        begin = pass_end[i];
+    int rc = HS_OK;
+    if (want_dense && possible) {
+        rc = spmspv_dense(ctx, staged_dev, count);
+    } else {
+        uint32_t begin = 0;
+        for (size_t i = 0; i < pass_end.size() && rc == HS_OK; ++i) {
+            rc = spmspv_pass(ctx, staged_dev + begin, pass_end[i] - begin, i != 0);
+            begin = pass_end[i];
+        }
     }
-    return HS_OK;
+    if (count && rc == HS_OK) HS_HIP(ctx, hipEventRecord(ctx->sx_read[half], ctx->stream));      // the kernels that read the staging buffer are behind this
+    return rc;
 }
 
 int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows) {
@@ -813,12 +850,13 @@ int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows) {
     if (!ctx->d_csc_indptr) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix_csc has not been called");
     if (num_rows != ctx->csc_rows) return fail(ctx, HS_ERR_BAD_ARG, "result length must equal the CSC matrix's row count");
     HS_HIP(ctx, hipSetDevice(ctx->device));
-    unsigned long long overflow = 0;
+    uint32_t overflow = 0;
     HS_HIP(ctx, hipMemcpyAsync(packed_y, ctx->d_csc_y, size_t(num_rows) * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HS_HIP(ctx, hipMemcpyAsync(&overflow, ctx->csc_scratch.counters + 2, sizeof(overflow), hipMemcpyDeviceToHost, ctx->stream));
+    HS_HIP(ctx, hipMemcpyAsync(&overflow, ctx->csc_scratch.overflow, sizeof(overflow), hipMemcpyDeviceToHost, ctx->stream));
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (overflow) {      // only hs_spmspv_device can get here: hs_spmspv cuts such a call into passes
-        HS_HIP(ctx, hipMemset(ctx->csc_scratch.counters + 2, 0, sizeof(overflow)));
+        HS_HIP(ctx, hipMemset(ctx->csc_scratch.overflow, 0, sizeof(overflow)));
+        HS_HIP(ctx, hipMemset(ctx->csc_scratch.cursors, 0, size_t(hisparse::dev::spmspv_bins(ctx->csc_rows)) * 4));
         return fail(ctx, HS_ERR_BAD_ARG, "hs_spmspv_device: the entries asked for more products than the matrix has non-zeros (columns named more than "
                                          "once): the result is incomplete; hs_spmspv with host entries splits such a call");
     }

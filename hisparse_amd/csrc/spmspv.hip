@@ -39,7 +39,6 @@ namespace {
 
 constexpr uint32_t kMaxBlockBits = 13;                    // a row block = at most 8192 rows: 64 KiB of 8-byte LDS accumulators
 constexpr uint32_t kMinBlockBits = 9;
-constexpr uint32_t kIdsPerLoad = 8;                       // block ids a lane reads at once (16 bytes)
 constexpr uint32_t kExpandColumns = 64;                   // x entries per workgroup of the expand kernel
 constexpr uint32_t kExpandThreads = 256;
 
@@ -49,25 +48,30 @@ __device__ __forceinline__ uint32_t product_word(uint32_t value_word, uint32_t x
     return q8_24_mul(value_word, x_word);
 }
 
-// counters: [0], [1] = product counts of the calls with even / odd call number (the other one is reset by this call's accumulate
-// kernel, so no memset sits between two calls), [2] = overflow flag (sticky until hs_read_spmspv_result reports it)
-//
-// EXPAND.  A workgroup takes 64 entries of x: lane c of its first wavefront reads entry c's column length, a DPP prefix sum places the 64
-// columns' products behind each other, ONE atomic on the device counter claims the room for all of them (an atomic per column was the
-// first version: 5762 atomics on one address took 115 of the 142 us of a 1 % selection of ogbl-ppa), and then all 256 threads walk the
-// workgroup's products FLAT -- product p belongs to the column whose prefix range holds p (binary search over the 65 prefix sums in LDS) --
-// so that a hub column of 60 K entries is spread over the workgroup like everything else and every store is coalesced.
+// EXPAND.  A workgroup takes up to 64 entries of x: lane c of its first wavefront reads entry c's column pointer, a DPP prefix sum lines the
+// columns' products up, and all 256 threads walk them FLAT -- product p belongs to the column whose prefix range holds p (binary search over
+// the prefix sums in LDS) -- so that a hub column of 60 K entries is spread over the workgroup like everything else.  TWICE: the first walk
+// counts the workgroup's products per ROW BLOCK in an LDS histogram; then one global atomic per (workgroup, non-empty block) claims a stretch
+// of that block's BIN; the second walk computes the products and writes each (row, product word) into its bin, at the claimed base + its
+// rank (a returning LDS atomic).  A bin's capacity is the number of non-zeros the matrix has in that row block -- x entries that name every
+// column at most once can never ask for more -- so the bins together are one list of nnz entries, and the accumulate kernel reads ITS bin and
+// nothing else.  (Round 4's first version wrote one unsorted list and had every row block's workgroup sweep the block ids of ALL products:
+// ~5 G products/s whatever the matrix, 86 us for 1 % of ogbl-ppa's columns; profiles/r04_spmspv.txt.)
+constexpr uint32_t kMaxBins = 2048;                       // LDS histogram + claims: 16 KiB
 template <bool kFloat>
 __global__ __launch_bounds__(kExpandThreads) void spmspv_expand_kernel(const uint32_t* __restrict__ indptr, const uint32_t* __restrict__ row_indices,
                                                                       const uint32_t* __restrict__ value_words, const uint2* __restrict__ x_entries,
-                                                                      uint32_t x_count, uint32_t num_cols, unsigned long long* __restrict__ counter,
-                                                                      unsigned long long* __restrict__ overflow, uint32_t capacity, uint32_t block_bits,
-                                                                      uint32_t columns, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                                      uint16_t* __restrict__ blks) {
+                                                                      uint32_t x_count, uint32_t num_cols, const uint32_t* __restrict__ bin_base,
+                                                                      uint32_t* __restrict__ cursors, uint32_t* __restrict__ overflow, uint32_t block_bits,
+                                                                      uint32_t bins, uint32_t columns, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     // columns (<= 64): entries of x per workgroup -- 64 when x has thousands of entries, fewer when it has few, so that a handful of LONG
     // columns (mouse_gene: 22 columns of 640 non-zeros) is still spread over many workgroups
-    __shared__ uint32_t s_lo[kExpandColumns], s_xw[kExpandColumns], s_pre[kExpandColumns + 1], s_base, s_ok;
-    const uint32_t tid = threadIdx.x, lane = tid & (kWaveLanes - 1);
+    __shared__ uint32_t s_lo[kExpandColumns], s_xw[kExpandColumns], s_pre[kExpandColumns + 1];
+    extern __shared__ uint32_t s_bins[];                   // [bins] histogram, then running rank; [bins] claimed base (absolute index into keys / vals)
+    uint32_t* hist = s_bins;
+    uint32_t* claim = s_bins + bins;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b = tid; b < bins; b += kExpandThreads) hist[b] = 0;
     if (tid < kExpandColumns) {
         const uint32_t k = blockIdx.x * columns + tid;
         uint32_t lo = 0, len = 0, xw = 0;
@@ -79,143 +83,83 @@ __global__ __launch_bounds__(kExpandThreads) void spmspv_expand_kernel(const uin
                 xw = entry.y;
             }
         }
-        const uint32_t incl = wave_inclusive_scan(len);    // (a workgroup's 64 columns stay below 2^32 products: capacity < 2^32)
+        const uint32_t incl = wave_inclusive_scan(len);    // (64 columns stay below 2^32 products: the matrix has fewer non-zeros than that)
         s_lo[tid] = lo;
         s_xw[tid] = xw;
         s_pre[tid + 1] = incl;
         if (tid == 0) s_pre[0] = 0;
-        if (lane == kWaveLanes - 1) {
-            uint32_t ok = 1, base = 0;
-            if (incl) {
-                const unsigned long long claimed = atomicAdd(counter, static_cast<unsigned long long>(incl));
-                if (claimed > capacity || incl > capacity - claimed) {      // the list is full (an x with repeated entries can ask for more than nnz products)
-                    atomicOr(overflow, 1ull);
-                    ok = 0;
-                }
-                base = static_cast<uint32_t>(claimed);
-            }
-            s_base = base;
-            s_ok = ok;
-        }
     }
     __syncthreads();
-    const uint32_t total = s_pre[kExpandColumns], base = s_base;
-    if (!s_ok) return;
-    for (uint32_t p = tid; p < total; p += kExpandThreads) {
-        uint32_t c = 0;                                    // the last column whose prefix is <= p
+    const uint32_t total = s_pre[kExpandColumns];
+    auto column_of = [&](uint32_t p) {                     // the last column whose prefix is <= p
+        uint32_t c = 0;
 #pragma unroll
         for (uint32_t step = kExpandColumns / 2; step; step >>= 1)
             if (s_pre[c + step] <= p) c += step;
-        const uint32_t e = s_lo[c] + (p - s_pre[c]);
-        const uint32_t row = row_indices[e];
-        keys[base + p] = row;
-        vals[base + p] = product_word<kFloat>(value_words[e], s_xw[c]);
-        blks[base + p] = static_cast<uint16_t>(row >> block_bits);
+        return c;
+    };
+    for (uint32_t p = tid; p < total; p += kExpandThreads) {
+        const uint32_t c = column_of(p);
+        atomicAdd(&hist[row_indices[s_lo[c] + (p - s_pre[c])] >> block_bits], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < bins; b += kExpandThreads) {
+        const uint32_t n = hist[b];
+        uint32_t at = 0xffffffffu;                         // "do not write": the bin is full
+        if (n) {
+            const uint32_t first = atomicAdd(&cursors[b], n), room = bin_base[b + 1] - bin_base[b];
+            if (first <= room && n <= room - first) at = bin_base[b] + first;
+            else atomicOr(overflow, 1u);                   // (an x that names a column more than once can ask for more than the bin holds)
+        }
+        claim[b] = at;
+        hist[b] = 0;                                       // from here on: the rank of the workgroup's next product in this bin
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < total; p += kExpandThreads) {
+        const uint32_t c = column_of(p), e = s_lo[c] + (p - s_pre[c]);
+        const uint32_t row = row_indices[e], b = row >> block_bits;
+        const uint32_t base = claim[b], rank = atomicAdd(&hist[b], 1u);
+        if (base != 0xffffffffu) {
+            keys[base + rank] = row;
+            vals[base + rank] = product_word<kFloat>(value_words[e], s_xw[c]);
+        }
     }
 }
 
-// ACCUMULATE.  One workgroup per row block of 2^block_bits rows (8192 at most; fewer for matrices of few rows, so that there are
-// workgroups enough).  kAdd: y += (a later pass of a call whose products did not fit the list at once; saturating / fp32 add).
-// The sweep over the block ids and the fetch of the matching products are DECOUPLED through a queue in LDS: a trip looks at 32 K products
-// (four 16-byte loads of ids per lane, the next trip's already in flight), the lanes that found one of their own push its index -- one LDS
-// atomic per wavefront and id position, the lanes' places from the ballot -- and the queue is drained after the trip: row and product word
-// of every entry loaded four at a time, one LDS add each.  (Fetching a match where it was found cost 8 dependent load round trips per
-// 8 ids; a trip per 8 K products with a barrier pair each left the id loads' latency exposed: 179 / 142 us for 420 K products,
-// profiles/r04_spmspv.txt.)  An entry that does not fit the queue any more is added on the spot.
-constexpr uint32_t kTripLoads = 4;
-constexpr uint32_t kTripProducts = 1024 * kIdsPerLoad * kTripLoads;      // 32768
-constexpr uint32_t kQueueEntries = 8192;                                 // 32 KiB
+// ACCUMULATE.  One workgroup per row block of 2^block_bits rows: its bin holds its products and nothing else -- cursors[b] of them, behind
+// bin_base[b] -- read four per lane at a time, added into 64-bit LDS accumulators (ds_add_u64 / ds_add_f64); every row of y is written
+// exactly once, so y needs no zeroing pass; the workgroup re-arms its own cursor for the next call.  kAdd: y += (a later pass of a call
+// whose x names columns more than once; saturating / fp32 add).
 template <bool kFloat, bool kAdd>
 __global__ __launch_bounds__(1024) void spmspv_accumulate_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                                const uint16_t* __restrict__ blks, const unsigned long long* __restrict__ counter,
-                                                                unsigned long long* __restrict__ counter_next, uint32_t capacity, uint32_t block_bits,
+                                                                const uint32_t* __restrict__ bin_base, uint32_t* __restrict__ cursors, uint32_t block_bits,
                                                                 uint32_t* __restrict__ y, uint32_t num_rows) {
     using R = Rows<kFloat>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     typename R::acc_t* acc = reinterpret_cast<typename R::acc_t*>(lds);                              // [block rows]
     const uint32_t block_rows = 1u << block_bits;
-    uint32_t* queue = reinterpret_cast<uint32_t*>(lds + block_rows * sizeof(typename R::acc_t));     // [kQueueEntries]
-    __shared__ uint32_t queued;
-    const uint32_t tid = threadIdx.x, lane = tid & (kWaveLanes - 1), b = blockIdx.x, row0 = b << block_bits;
-    const unsigned long long claimed = ((const __attribute__((address_space(4))) unsigned long long*)counter)[0];
-    const uint32_t total = claimed > capacity ? capacity : static_cast<uint32_t>(claimed);      // (beyond the capacity: the overflow flag is up and the call reports it)
-    const uint4* ids4 = reinterpret_cast<const uint4*>(blks);
-    const uint4 none = make_uint4(0, 0, 0, 0);
-    auto load_trip = [&](uint4 (&w)[kTripLoads], uint32_t base) {
-#pragma unroll
-        for (uint32_t q = 0; q < kTripLoads; ++q) {
-            const uint32_t i = base + (q * 1024 + tid) * kIdsPerLoad;
-            w[q] = i < total ? ids4[i / kIdsPerLoad] : none;      // (the allocation is padded to whole 16-byte words)
-        }
-    };
-    uint4 w[kTripLoads];
-    load_trip(w, 0);
+    const uint32_t tid = threadIdx.x, b = blockIdx.x, row0 = b << block_bits;
+    const uint32_t first = ((const __attribute__((address_space(4))) uint32_t*)bin_base)[b];
+    const uint32_t room = ((const __attribute__((address_space(4))) uint32_t*)bin_base)[b + 1] - first;
+    const uint32_t n = min(((const __attribute__((address_space(4))) uint32_t*)cursors)[b], room);
     for (uint32_t i = tid; i < block_rows; i += 1024) acc[i] = 0;
-    if (tid == 0) queued = 0;
-    if (b == 0 && tid == 0) *counter_next = 0;             // the next call's counter (nobody reads it before that call's expand kernel)
     __syncthreads();
-    auto add_one = [&](uint32_t idx) {
-        const uint32_t local = keys[idx] & (block_rows - 1u), v = vals[idx];
-        if (kFloat) R::add(acc, local, __uint_as_float(v));
-        else atomicAdd(acc + local, static_cast<unsigned long long>(v));
-    };
-    auto drain = [&](uint32_t n) {
-        for (uint32_t q = tid; q < n; q += 4 * 1024) {
-            uint32_t idx[4], key[4], val[4];
+    if (tid == 0) cursors[b] = 0;                          // (read above by every wavefront's scalar load, before the barrier)
+    for (uint32_t q = tid; q < n; q += 4 * 1024) {
+        uint32_t key[4], val[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) idx[k] = queue[min(q + k * 1024u, n - 1)];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { key[k] = keys[idx[k]]; val[k] = vals[idx[k]]; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (q + k * 1024u >= n) break;
-                const uint32_t local = key[k] & (block_rows - 1u);
-                if (kFloat) R::add(acc, local, __uint_as_float(val[k]));                                // ds_add_f64 of the fp32 product
-                else atomicAdd(acc + local, static_cast<unsigned long long>(val[k]));                   // ds_add_u64
-            }
-        }
-    };
-    for (uint32_t base = 0; base < total; base += kTripProducts) {
-        uint4 ahead[kTripLoads];
-        load_trip(ahead, base + kTripProducts);
-        // which of this lane's 32 ids are the block's own (bit q * 8 + j), how many, and where they go: ONE LDS atomic per wavefront and
-        // trip claims the wavefront's stretch of the queue (a DPP prefix sum of the lanes' counts gives every lane its place in it).
-        // (One returning LDS atomic per id position that had a match anywhere in the wavefront: 8 us per trip, 106 us for 420 K products.)
-        uint32_t mine = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < kTripLoads; ++q) {
-            const uint32_t i = base + (q * 1024 + tid) * kIdsPerLoad;
-            const uint32_t word[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
-#pragma unroll
-            for (uint32_t j = 0; j < kIdsPerLoad; ++j) {
-                const uint32_t id = (word[j / 2] >> (16 * (j % 2))) & 0xffffu;
-                if (id == b && i + j < total) mine |= 1u << (q * kIdsPerLoad + j);      // (ids past `total` are leftovers of earlier calls)
-            }
-        }
-        const uint32_t count = __builtin_popcount(mine);
-        const uint32_t upto = wave_inclusive_scan(count);
-        uint32_t at = 0;
-        if (lane == kWaveLanes - 1 && upto) at = atomicAdd(&queued, upto);
-        at = __builtin_amdgcn_readlane(at, kWaveLanes - 1) + upto - count;
-        while (mine) {                                           // per lane: a handful of iterations at most
-            const uint32_t bit = __builtin_ctz(mine);
-            mine &= mine - 1;
-            const uint32_t idx = base + ((bit / kIdsPerLoad) * 1024 + tid) * kIdsPerLoad + bit % kIdsPerLoad;
-            if (at < kQueueEntries) queue[at] = idx;
-            else add_one(idx);                                   // the queue is full (a row block that takes most of the products): add it here
-            ++at;
-        }
-        __syncthreads();
-        const uint32_t n = min(queued, kQueueEntries);
-        __syncthreads();                                         // everybody has read the count
-        if (n > kQueueEntries / 2 || base + kTripProducts >= total) {      // drain when the next trip might not fit, and at the end
-            drain(n);
-            __syncthreads();
-            if (tid == 0) queued = 0;
-            __syncthreads();
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = first + min(q + k * 1024u, n - 1);
+            key[k] = keys[i];
+            val[k] = vals[i];
         }
 #pragma unroll
-        for (uint32_t q = 0; q < kTripLoads; ++q) w[q] = ahead[q];
+        for (int k = 0; k < 4; ++k) {
+            if (q + k * 1024u >= n) break;
+            const uint32_t local = key[k] & (block_rows - 1u);
+            if (kFloat) R::add(acc, local, __uint_as_float(val[k]));                                // ds_add_f64 of the fp32 product
+            else atomicAdd(acc + local, static_cast<unsigned long long>(val[k]));                   // ds_add_u64
+        }
     }
     // no-return LDS atomics can outlive s_waitcnt lgkmcnt(0) (spmv_kernels.hip): a RETURNING atomic per wavefront, awaited
     const typename R::acc_t flushed = atomicAdd(acc + (tid / kWaveLanes), static_cast<typename R::acc_t>(0));
@@ -242,7 +186,6 @@ __global__ __launch_bounds__(256) void spmspv_scatter_x_kernel(const uint2* __re
 
 }  // namespace
 
-size_t spmspv_list_bytes(uint64_t capacity) { return ((size_t(capacity) * 2 + 15) & ~size_t(15)) + 16; }      // the block-id array, padded to whole loads
 
 // rows per block: 8192 unless the matrix has too few rows to give every other CU a block that way (mouse_gene: 45 K rows -> 512-row blocks)
 uint32_t spmspv_block_bits(uint32_t num_rows) {
@@ -250,29 +193,29 @@ uint32_t spmspv_block_bits(uint32_t num_rows) {
     while (bits > kMinBlockBits && ((uint64_t(num_rows) + (1u << bits) - 1) >> bits) < 128) --bits;
     return bits;
 }
+uint32_t spmspv_bins(uint32_t num_rows) { return uint32_t((uint64_t(num_rows) + (1u << spmspv_block_bits(num_rows)) - 1) >> spmspv_block_bits(num_rows)); }
+uint32_t spmspv_max_bins() { return kMaxBins; }
 
 hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, const hs_idx_val_dev* x_entries,
-                         uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& s, uint32_t call, bool add_to_y, uint32_t* y,
-                         hipStream_t stream) {
-    unsigned long long* counter = s.counters + (call & 1u);
-    unsigned long long* counter_next = s.counters + ((call + 1u) & 1u);
-    const uint32_t capacity = static_cast<uint32_t>(std::min<uint64_t>(s.capacity, 0xffffffffull));
-    const uint32_t block_bits = spmspv_block_bits(num_rows);
+                         uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& s, bool add_to_y, uint32_t* y, hipStream_t stream) {
+    const uint32_t block_bits = spmspv_block_bits(num_rows), bins = spmspv_bins(num_rows);
+    if (bins > kMaxBins) return hipErrorInvalidValue;
     if (x_count) {
         const uint32_t columns = std::max<uint32_t>(1, std::min<uint32_t>(kExpandColumns, x_count / 512));      // >= 512 workgroups before they grow
         const dim3 grid((x_count + columns - 1) / columns), block(kExpandThreads);
         const uint2* xe = reinterpret_cast<const uint2*>(x_entries);
+        const uint32_t lds = bins * 8u;
         if (is_float)
-            hipLaunchKernelGGL(spmspv_expand_kernel<true>, grid, block, 0, stream, indptr, row_indices, value_words, xe, x_count, num_cols, counter, s.counters + 2,
-                               capacity, block_bits, columns, s.keys, s.vals, s.blks);
+            hipLaunchKernelGGL(spmspv_expand_kernel<true>, grid, block, lds, stream, indptr, row_indices, value_words, xe, x_count, num_cols, s.bin_base, s.cursors,
+                               s.overflow, block_bits, bins, columns, s.keys, s.vals);
         else
-            hipLaunchKernelGGL(spmspv_expand_kernel<false>, grid, block, 0, stream, indptr, row_indices, value_words, xe, x_count, num_cols, counter, s.counters + 2,
-                               capacity, block_bits, columns, s.keys, s.vals, s.blks);
+            hipLaunchKernelGGL(spmspv_expand_kernel<false>, grid, block, lds, stream, indptr, row_indices, value_words, xe, x_count, num_cols, s.bin_base, s.cursors,
+                               s.overflow, block_bits, bins, columns, s.keys, s.vals);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    const dim3 grid((num_rows + (1u << block_bits) - 1) >> block_bits);
-    const uint32_t lds = (8u << block_bits) + kQueueEntries * 4u;      // accumulators + queue: 96 KiB at most
+    const dim3 grid(bins);
+    const uint32_t lds = 8u << block_bits;      // accumulators: 64 KiB at most
 #define X(F, A)                                                                                                                                                  \
     do {                                                                                                                                                         \
         static bool configured_on[64] = {};      /* the dynamic-LDS cap is a property of the function, per device */                                            \
@@ -281,11 +224,11 @@ hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* 
         bool& configured = configured_on[dev_ >= 0 && dev_ < 64 ? dev_ : 0];                                                                                     \
         if (!configured) {                                                                                                                                       \
             const hipError_t ce = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmspv_accumulate_kernel<F, A>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                      int((8u << kMaxBlockBits) + kQueueEntries * 4u));                                                          \
+                                                      int(8u << kMaxBlockBits));                                                                                 \
             if (ce != hipSuccess) return ce;                                                                                                                     \
             configured = true;                                                                                                                                   \
         }                                                                                                                                                        \
-        hipLaunchKernelGGL((spmspv_accumulate_kernel<F, A>), grid, dim3(1024), lds, stream, s.keys, s.vals, s.blks, counter, counter_next, capacity, block_bits, y, num_rows); \
+        hipLaunchKernelGGL((spmspv_accumulate_kernel<F, A>), grid, dim3(1024), lds, stream, s.keys, s.vals, s.bin_base, s.cursors, block_bits, y, num_rows);      \
     } while (0)
     if (is_float) { if (add_to_y) X(true, true); else X(true, false); }
     else { if (add_to_y) X(false, true); else X(false, false); }

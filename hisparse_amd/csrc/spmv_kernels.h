@@ -90,23 +90,25 @@ hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_
                                  uint32_t row_hi, hipStream_t stream, uint32_t* x_fb = nullptr, uint32_t n_fb = 0, uint32_t scale = 0,
                                  uint32_t shift = 0);
 
-// SpMSpV extension (spmspv.hip): y = A x for x given as x_count IDX_VAL_T pairs ON THE DEVICE over a CSC matrix.  Two launches: the
-// selected columns' products are expanded into a (row, product, row block) list -- one atomic per column on a device counter gives it its
-// place -- and one workgroup per block of 8192 rows accumulates its own in LDS and writes its rows of y.  No scan, no sort, no host
-// synchronisation.  Scratch, owned by the caller (hs_api.cpp):
+// SpMSpV extension (spmspv.hip): y = A x for x given as x_count IDX_VAL_T pairs ON THE DEVICE over a CSC matrix.  Two launches: EXPAND writes
+// the selected columns' products straight into per-row-block BINS (an LDS histogram per workgroup of 64 entries, one global atomic per workgroup
+// and non-empty bin claims the room), ACCUMULATE has one workgroup per row block add ITS bin in LDS and write its rows of y.  No scan, no sort,
+// no host synchronisation.  Scratch, owned by the caller (hs_api.cpp):
 struct hs_idx_val_dev { uint32_t index, val; };      // == hs_idx_val (hisparse_hip.h), IDX_VAL_T of spmv/libfpga/common.h:54
 struct SpmspvScratch {
-    uint32_t* keys = nullptr;                   // [capacity] rows of the expanded products
-    uint32_t* vals = nullptr;                   // [capacity] product words
-    uint16_t* blks = nullptr;                   // [capacity, padded: spmspv_list_bytes] row block of every product
-    uint64_t capacity = 0;                      // = the matrix's non-zeros (x without repeated entries never needs more)
-    unsigned long long* counters = nullptr;     // [0], [1]: product count of even / odd calls (zeroed at allocation, then by the kernels); [2]: overflow flag
+    uint32_t* keys = nullptr;                   // [nnz] rows of the products, bin by bin
+    uint32_t* vals = nullptr;                   // [nnz] product words
+    uint32_t* bin_base = nullptr;               // [bins + 1]: bin b = [bin_base[b], bin_base[b + 1]) = as many entries as the matrix has non-zeros in row block b
+    uint32_t* cursors = nullptr;                // [bins]: products in the bin (zero between calls: the accumulate kernel re-arms them)
+    uint32_t* overflow = nullptr;               // one word: a bin was asked for more than it holds (x named columns more than once)
+    uint64_t capacity = 0;                      // = the matrix's non-zeros
 };
-size_t spmspv_list_bytes(uint64_t capacity);
-// call: the context's SpMSpV call number (picks the counter).  add_to_y: y += instead of y = (further passes of one call).
+uint32_t spmspv_block_bits(uint32_t num_rows);  // log2 of the rows per block (13, less for matrices of few rows)
+uint32_t spmspv_bins(uint32_t num_rows);
+uint32_t spmspv_max_bins();
+// add_to_y: y += instead of y = (further passes of one call).
 hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* row_indices, const uint32_t* value_words, const hs_idx_val_dev* x_entries,
-                         uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& scratch, uint32_t call, bool add_to_y, uint32_t* y,
-                         hipStream_t stream);
+                         uint32_t x_count, uint32_t num_rows, uint32_t num_cols, const SpmspvScratch& scratch, bool add_to_y, uint32_t* y, hipStream_t stream);
 // x_dense[0, num_cols) = 0, then x_dense[index] = val for every entry (hs_spmspv's dense dispatch)
 hipError_t launch_spmspv_scatter_x(const hs_idx_val_dev* x_entries, uint32_t x_count, uint32_t num_cols, uint32_t* x_dense, hipStream_t stream);
 
