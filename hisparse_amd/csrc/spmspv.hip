@@ -8,18 +8,20 @@
 // Round 4: two launches, nothing else -- no scan, no sort, no host synchronisation, no H2D inside the call (round 3's path took a
 // hipCUB scan, a stream sync to learn the product count, a radix sort and an H2D before its first product: 53-205 us where the dense
 // SpMV takes 56):
-//   1. EXPAND: one wavefront per stored x entry claims room in the product list with ONE atomic on a device counter (its column's
-//      length), streams the column (row index + value word: two coalesced loads per 64 non-zeros), multiplies with the PE arithmetic of
-//      the numeric mode and writes, per product: the row (u32), the product word (u32) and the row BLOCK it falls in (u16, 8192 rows);
-//   2. ACCUMULATE: one workgroup per row block sweeps the 2-byte block ids of the whole list (16 bytes = 8 products per lane and load:
-//      the list is L2-resident and the ids are all a workgroup reads of the products that are not its own), fetches row and product
-//      of the matches, adds them into 64-bit LDS accumulators (ds_add_u64 / ds_add_f64: exact integer sums, double sums of the fp32
-//      products) and writes ITS rows of y -- every row exactly once, so y needs no zeroing pass and no finish pass.
-// The order of the list is whatever the atomics make it; the sums do not care (fixed point: exact; float: tolerance, as everywhere).
-// No memory-side atomic per product (they run at ~24 G/s on this chip): one per selected COLUMN.
-// Every workgroup of the second launch reads 2 bytes per product, so the cost grows with (row blocks x products): the operator pays
-// below a few per cent of the columns; above the measured crossover the caller's dense SpMV is faster and hs_spmspv dispatches to it
-// when it can (hs_api.cpp; hisparse_hip.h says so).
+//   1. EXPAND: a workgroup takes up to 64 entries of x, lines their columns' products up (DPP prefix sum of the column lengths) and walks
+//      them flat, twice: once to count its products per ROW BLOCK (LDS histogram), then -- after ONE global atomic per (workgroup, non-empty
+//      row block) has claimed a stretch of that block's BIN -- to compute the products with the PE arithmetic of the numeric mode and place
+//      (row, product word) in the bin;
+//   2. ACCUMULATE: one workgroup per row block reads ITS bin and nothing else, adds the products into 64-bit LDS accumulators (ds_add_u64
+//      / ds_add_f64: exact integer sums, double sums of the fp32 products), writes ITS rows of y -- every row exactly once, so y needs no
+//      zeroing pass and no finish pass -- and re-arms its bin's cursor for the next call.
+// A bin's capacity is the number of non-zeros the matrix holds in that row block (a histogram taken when the CSC image is loaded): entries
+// that name every column at most once can never overflow it, so the bins together are one list of nnz entries.  The order inside a bin is
+// whatever the atomics make it; the sums do not care (fixed point: exact; float: tolerance, as everywhere).  No memory-side atomic per
+// product (they run at ~24 G/s on this chip): one per (workgroup of 64 columns, row block touched).
+// Cost: ~12-18 us (two launches and two dependent chains: entry -> column pointer -> elements; cursor -> bin) + products / ~40 G/s (a column
+// entry is read, its product written and read again: 24 bytes per product at ~1 TB/s, mostly L2); above the crossover with the caller's
+// dense SpMV hs_spmspv dispatches to that when it can (hs_api.cpp; hisparse_hip.h says so).
 //   fixed: products rounded / saturated one by one (q8_24_mul), summed exactly in 64 bits, clamped once -- bit-identical to the
 //          saturating PE sum, in any order;
 //   float: one fp32 multiply per product, double sums per row block, rounded once: tolerance parity like every float path.

@@ -133,7 +133,7 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
  * environment spelling -- plan-time keys (take effect at the NEXT hs_load_matrix / hs_load_matrix_csr of this context): stream_format
  * (pairs|delta|owner|owner24|bitmap), col_slices, max_rows, row_runs, aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
  * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), plan_debug; call-time keys: spmm_fused, spmm_mfma,
- * spmspv (atomic|binned), spmspv_crossover, iterate_graph, iterate_cooperative.  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
+ * spmspv (sparse|dense), spmspv_crossover, iterate_graph, iterate_cooperative.  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
  * Options set here win over the environment variable of the same name, which stays as the fallback for tools and tests.  None of them
  * changes WHAT is computed.  The switches that do (HISPARSE_ABLATE, HISPARSE_DEPTH: profiling builds with parts of the work removed) are
  * not options: they exist only in libhisparse_hip_prof.so, and this library refuses to run (HS_ERR_BAD_ARG from hs_run, hs_run_partition,
@@ -158,23 +158,24 @@ int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32
  * y = A x for a SPARSE x: only the columns named by x's entries are read.
  *   hs_load_matrix_csc: CSCMatrix arrays (indptr[num_cols + 1], row index and value word per non-zero, value words in the context's
  *     numeric mode: hsf_csr_to_csc), independent of the matrix hs_load_matrix holds; validated, copied to the device.
- *   hs_spmspv: x as `count` IDX_VAL_T pairs in HOST memory.  Asynchronous: the pairs are copied through a pinned staging buffer of the
- *     context (the call returns once they are in it), two kernels follow on the context's stream -- EXPAND (one wavefront per entry writes
- *     its column's products into a list: one atomic per COLUMN claims the room) and ACCUMULATE (one workgroup per 8192 rows adds its own
- *     products in LDS and writes its rows) -- no scan, no sort, no host synchronisation.  The result is a dense packed y of num_rows words:
- *     hs_read_spmspv_result.  An entry may name a column more than once (the products simply add up); a call whose products exceed the
- *     matrix's non-zero count is cut into passes.
- *     CROSSOVER: every row block's workgroup sweeps the whole product list, so the operator pays for about one per cent of the columns at
- *     most (measured, profiles/r04_spmspv.txt: ogbl-ppa 0.1 % of the columns 23 us, 1 % 85 us against 61-68 us for the dense SpMV; the
- *     sparse path costs ~12 us + products / 5 G/s).  Beyond that the DENSE SpMV is faster, and hs_spmspv runs it instead -- x scattered
+ *   hs_spmspv: x as `count` IDX_VAL_T pairs in HOST memory.  Asynchronous: the pairs are checked and copied into a pinned, device-mapped
+ *     staging buffer of the context (two halves used in turn; the call returns once they are in it) and two kernels follow on the context's
+ *     stream -- EXPAND (a workgroup per 64 entries computes their columns' products and places each in the BIN of the row block it falls
+ *     in: one atomic per workgroup and row block claims the room) and ACCUMULATE (one workgroup per row block of 8192 rows adds ITS bin's
+ *     products in LDS and writes its rows) -- no scan, no sort, no copy command, no host synchronisation.  The result is a dense packed y of
+ *     num_rows words: hs_read_spmspv_result.  An entry may name a column more than once (the products simply add up): a bin holds as many
+ *     products as the matrix has non-zeros in its row block, so such a call is cut into passes of unique columns.
+ *     CROSSOVER: the sparse path costs ~14 us + products / 45 G/s (measured, profiles/r04_spmspv_binned.txt: ogbl-ppa 0.05 % / 0.1 % / 1 % /
+ *     5 % of the columns 16 / 22 / 26 / 59 us with host entries, against 63-68 us for the dense SpMV, which wins from ~6 %).  Beyond the
+ *     crossover hs_spmspv runs the DENSE SpMV instead -- x scattered
  *     into a zero vector, one hs_run -- PROVIDED hs_load_matrix / hs_load_matrix_csr of this context holds the same matrix (same shape
  *     after padding; that it IS the same matrix is the caller's contract) and x names no column twice.  The rule: the host knows the
  *     call's product count exactly, and the dense SpMV of the loaded matrix is timed once (the first call that could use it: three
  *     launches and one synchronisation); `spmspv_crossover` (hs_set_option: a fraction of the columns; 0 = never) replaces the rule,
  *     `spmspv` = sparse | dense forces a path.  Without a matching dense matrix the sparse path runs whatever the size.
- *   hs_spmspv_device: the same with the pairs already in DEVICE memory (8-byte aligned): nothing but the two launches.  No index check
- *     (out-of-range columns are ignored), no dense dispatch, and the products must fit the list (true whenever no column is named twice);
- *     otherwise hs_read_spmspv_result reports HS_ERR_BAD_ARG.
+ *   hs_spmspv_device: the same with the pairs already in DEVICE memory (8-byte aligned): nothing but the two launches (3-4 us less).  No
+ *     index check (out-of-range columns are ignored), no dense dispatch, and no column may be named twice (a bin that overflows drops the
+ *     excess and hs_read_spmspv_result reports HS_ERR_BAD_ARG).
  * Arithmetic as in hs_run: fixed = saturating sum of individually rounded / saturated products (bit-exact, order free);
  * float = fp32 products summed in double per row block, rounded once (tolerance). */
 typedef struct { uint32_t index; uint32_t val; } hs_idx_val;    /* IDX_VAL_T, spmv/libfpga/common.h:54 */
