@@ -84,6 +84,10 @@ hipError_t launch_spmm_mfma(const SpmmMfmaLaunch& a, hipStream_t stream);
 // BITMAP images (spmv_bitmap.hip); launch_spmv forwards to it when a.format == kFormatBitmap.
 hipError_t configure_bitmap_kernels(uint32_t lds_bytes);
 hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream);
+// SWEEP images (spmv_sweep.hip); launch_spmv forwards to it when a.format == kFormatSweep.
+uint32_t spmv_sweep_lds_bytes(uint32_t max_block_rows);       // accumulators only
+hipError_t configure_sweep_kernels(uint32_t lds_bytes);
+hipError_t launch_spmv_sweep(bool is_float, const SpmvLaunch& a, hipStream_t stream);
 // Column-sliced matrices only: y[r] = (saturating / fp32) sum of the `slices` partial vectors, rows [row_lo, row_hi);
 // with x_fb also x_fb[r] = scale (*) y[r] (+) shift for r < n_fb (hs_iterate's feedback folded into the same launch).
 hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_t* y, uint32_t num_rows, uint32_t slices, uint32_t row_lo,

@@ -1111,6 +1111,7 @@ const char* profiling_switch_error() {
 // wavefront), then the ring of x buffers.
 uint32_t spmv_light_lds_bytes(uint32_t max_block_rows) { return ((max_block_rows + 1) * kAccumulatorBytes + 15u) & ~15u; }
 uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t format) {
+    if (format == kFormatSweep) return spmv_sweep_lds_bytes(max_block_rows);
     const uint32_t acc = (format == kFormatOwner || format == kFormatOwner24) ? (max_block_rows + kConsumerWaves) * kOwnerAccumulatorBytes : (max_block_rows + 1) * kAccumulatorBytes;
     return ((acc + 15u) & ~15u) + ring_buffers * kBufBytes;
 }
@@ -1168,12 +1169,14 @@ hipError_t configure_spmv_kernels(uint32_t lds_bytes) {
 #define X(A) if ((e = configure_one<false, 3, A, 3, true>(lds_bytes)) != hipSuccess) return e;
     HS_FOR_EACH_OWNER24_FIXED(X)
 #undef X
+    if ((e = configure_sweep_kernels(lds_bytes)) != hipSuccess) return e;
     return configure_bitmap_kernels(lds_bytes);
 }
 
 hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.num_workgroups == 0) return hipSuccess;
     if (a.format == kFormatBitmap) return launch_spmv_bitmap(is_float, a, stream);
+    if (a.format == kFormatSweep) return launch_spmv_sweep(is_float, a, stream);
     if (a.light) {
         if (a.format != kFormatPairs) return hipErrorInvalidValue;
         int ablate = 0, depth_unused = 8;

@@ -1,0 +1,173 @@
+// spmv_sweep.hip — the SpMV kernel for SWEEP images (stream_tiles.h "SWEEP format"; builder: sweep_tiles.cpp).  gfx950.
+//
+// Same architecture as spmv_rowblock_kernel -- a workgroup owns a row range, the sums live in its LDS (the cluster's output buffer,
+// pe.h:121-135), the matrix streams past (spmv_cluster.h:73-98) -- with ONE difference: the vector is not staged.  The FPGA keeps the
+// current column partition of x in on-chip banks (vecbuf_access_unit.h:66-72,126-128); the row-block kernel does the same with 8192-column
+// sub-tiles in LDS, and on a hyper-sparse matrix pays ~2 100 clocks per (row range x sub-tile) unit for a flush, a barrier and a refill
+// that ~2 000 elements cannot hide.  Here x stays in L2 and every lane fetches its own word:
+//   * the block's elements come in (column, row) order, chunk k to wavefront k % 16 as its step k / 16: the 16 wavefronts move over the
+//     block's column slice together, once, and the 64 lanes of one gather touch a handful of 128-byte lines;
+//   * per wavefront EIGHT 512-byte chunks and EIGHT gathers are in flight, both in accumulator registers behind ONE counted wait per step:
+//     the gather for the chunk taken at step s - 8 is issued just before chunk s + ... (vmcnt retires in order), see step();
+//   * products go to 8-byte LDS accumulators with ds_add_u64 / ds_add_f64 (any lane may hit any row): exact 64-bit sums of the rounded
+//     Q8.24 products, clamped once / double sums of the fp32 products, rounded once -- the arithmetic of the other formats, bit for bit in
+//     fixed point;
+//   * nothing between the block's prologue and its epilogue: no units, no barriers, no refills.
+// Measured at block level before any builder existed (tools/gather_bench.hip, profiles/r04_gather_bench.txt): the stream runs at 5.3 TB/s
+// and a gathered line of x costs ~3.3 clocks per CU.
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+#include "spmv_device.h"
+#include "spmv_kernels.h"
+
+namespace hisparse {
+namespace dev {
+
+namespace {
+
+constexpr int kSweepThreads = kSweepWaves * kWaveLanes;
+constexpr int kSweepDepth = 8;      // chunks (and gathers) in flight per wavefront
+
+__device__ __forceinline__ const uint8_t* sweep_scalar_pointer(const void* p) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a));
+    return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// Ring: chunk slot K in a[2K : 2K+1] (value word, position word), gather slot K in a[16 + K].  hipcc never allocates accumulator registers
+// in this kernel; every asm statement that issues into the ring names all of them as clobbered, so nothing else is scheduled across.
+#define HS_SWEEP_RING "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", \
+                      "a18", "a19", "a20", "a21", "a22", "a23"
+
+template <int K>
+__device__ __forceinline__ void sweep_issue_chunk(const uint8_t* base, uint32_t off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %2, %3 nt" ::"n"(2 * K), "n"(2 * K + 1), "v"(off), "s"(base) : "memory", HS_SWEEP_RING);
+}
+template <int K>
+__device__ __forceinline__ void sweep_issue_gather(const uint8_t* x, uint32_t byte_off) {
+    asm volatile("s_nop 4\n\tglobal_load_dword a[%0], %1, %2" ::"n"(16 + K), "v"(byte_off), "s"(x) : "memory", HS_SWEEP_RING);
+}
+// one counted wait: chunk slot K (issued kSweepDepth steps ago) AND the gather issued just before it have landed
+template <int K>
+__device__ __forceinline__ void sweep_take(uint32_t& value, uint32_t& where, uint32_t& xv) {
+    asm volatile("s_waitcnt vmcnt(%6)\n\tv_accvgpr_read_b32 %0, a[%3]\n\tv_accvgpr_read_b32 %1, a[%4]\n\tv_accvgpr_read_b32 %2, a[%5]"
+                 : "=v"(value), "=v"(where), "=v"(xv) : "n"(2 * K), "n"(2 * K + 1), "n"(16 + K), "n"(2 * (kSweepDepth - 1)) : "memory");
+}
+
+struct SweepLane {
+    uint32_t value[kSweepDepth], row[kSweepDepth];      // the elements whose x words are on their way
+};
+
+// Step s of a wavefront (ring slot K = s % 8).  In flight on entry, oldest first: gather(s - 8), chunk(s), gather(s - 7), chunk(s + 1), ...
+// Waiting until 14 loads are left means chunk(s) and the gather before it have landed: add the element taken at step s - 8 (its x word
+// has just arrived), keep chunk(s)'s element, ask for ITS x word and for chunk(s + 8).
+template <bool kFloat, int K>
+__device__ __forceinline__ void sweep_step(SweepLane& st, const uint8_t* stream, const uint8_t* x, uint32_t s, uint32_t steps, uint32_t lane_off, uint32_t base,
+                                           typename Rows<kFloat>::acc_t* ys) {
+    using R = Rows<kFloat>;
+    uint32_t value, where, xv;
+    sweep_take<K>(value, where, xv);
+    R::add(ys, st.row[K], R::product(st.value[K], xv));      // (the first eight steps add 0 x x[0] to the spare accumulator)
+    st.value[K] = value;
+    st.row[K] = where >> 16;
+    sweep_issue_gather<K>(x, (base + (where & 0xffffu)) * 4u);
+    sweep_issue_chunk<K>(stream, min(s + kSweepDepth, steps - 1) * (kSweepWaves * kChunkBytes) + lane_off);
+}
+
+// prime, in the steady-state order: gather K (a dummy: its word is multiplied by 0), then chunk K
+template <int... Ks>
+__device__ __forceinline__ void sweep_prime(std::integer_sequence<int, Ks...>, const uint8_t* stream, const uint8_t* x, uint32_t pad_col, uint32_t steps, uint32_t lane_off) {
+    ((sweep_issue_gather<Ks>(x, pad_col * 4u), sweep_issue_chunk<Ks>(stream, min(uint32_t(Ks), steps - 1) * (kSweepWaves * kChunkBytes) + lane_off)), ...);
+}
+// one round of eight steps; steps at or beyond `end` are skipped (wave-uniform)
+template <bool kFloat, int... Ks>
+__device__ __forceinline__ void sweep_round(std::integer_sequence<int, Ks...>, SweepLane& st, const uint8_t* stream, const uint8_t* x, uint32_t s0, uint32_t steps,
+                                            uint32_t end, uint32_t lane_off, const uint32_t (&b)[kSweepDepth], typename Rows<kFloat>::acc_t* ys) {
+    ((s0 + Ks < end ? sweep_step<kFloat, Ks>(st, stream, x, s0 + Ks, steps, lane_off, b[Ks], ys) : (void)0), ...);
+}
+
+template <bool kFloat>
+__global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
+                                                                  const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
+                                                                  int32_t row_part_filter, const uint32_t* __restrict__ part_heads) {
+    using R = Rows<kFloat>;
+    using acc_t = typename R::acc_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    acc_t* ys = reinterpret_cast<acc_t*>(lds);                    // [nrows + 1]
+    const uint32_t tid = threadIdx.x, lane = tid & (kWaveLanes - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWaveLanes);
+    uint32_t wg = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // logical workgroups [k n/8, (k+1) n/8) on XCD k
+    uint32_t bi = wg;
+    if (row_part_filter >= 0) {
+        bi = ((const __attribute__((address_space(4))) uint32_t*)part_heads)[static_cast<uint32_t>(row_part_filter) * gridDim.x + wg];
+        if (bi == kNoBlock) return;
+    }
+    const uint8_t* xs = sweep_scalar_pointer(x);
+    const uint32_t lane_off = lane * 8u;
+    bool first_block = true;
+    for (uint32_t next = 0;; bi = next) {
+        const BlockTable blk = (BlockTable)(blocks + bi);
+        next = (row_part_filter >= 0 && (blk->flags & kBlockLastOfPartition)) ? 0u : blk->next;
+        const uint32_t nrows = blk->nrows, out0 = blk->out_offset, steps = blk->total_steps[0], pad_col = blk->first_col0;
+        const uint8_t* stream = sweep_scalar_pointer(image + blk->wave_offset[0] + uint64_t(wave) * kChunkBytes);
+        const __attribute__((address_space(4))) uint32_t* bases =
+            (const __attribute__((address_space(4))) uint32_t*)(image + blk->wave_offset[1]) + uint64_t(wave) * steps;
+        SweepLane st;
+#pragma unroll
+        for (int k = 0; k < kSweepDepth; ++k) { st.value[k] = 0; st.row[k] = nrows; }
+        if (steps) sweep_prime(std::make_integer_sequence<int, kSweepDepth>(), stream, xs, pad_col, steps, lane_off);
+        if (!first_block) __syncthreads();                        // the previous block's store has read the accumulators
+        first_block = false;
+        for (uint32_t i = tid; i <= nrows; i += kSweepThreads) ys[i] = 0;
+        __syncthreads();
+        if (steps) {
+            const uint32_t last = steps - 1;
+            uint32_t b[kSweepDepth];
+#pragma unroll
+            for (int k = 0; k < kSweepDepth; ++k) b[k] = bases[min(uint32_t(k), last)];
+            // steps 0 .. steps + 7: step s adds what step s - 8 took.  Steps s >= `steps` take the last chunk again (the clamped prefetch)
+            // and nobody adds that: the step that would runs at s + 8 >= steps + 8, which sweep_round skips
+            for (uint32_t s0 = 0; s0 < steps + kSweepDepth; s0 += kSweepDepth) {
+                uint32_t nb[kSweepDepth];
+#pragma unroll
+                for (int k = 0; k < kSweepDepth; ++k) nb[k] = bases[min(s0 + kSweepDepth + k, last)];
+                sweep_round<kFloat>(std::make_integer_sequence<int, kSweepDepth>(), st, stream, xs, s0, steps, steps + kSweepDepth, lane_off, b, ys);
+#pragma unroll
+                for (int k = 0; k < kSweepDepth; ++k) b[k] = nb[k];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory", HS_SWEEP_RING);
+        }
+        // no-return LDS atomics can outlive lgkmcnt(0) (spmv_rowblock_kernel): a returning one on the spare accumulator, awaited, cannot
+        const acc_t flushed = atomicAdd(ys + nrows, static_cast<acc_t>(0));
+        asm volatile("" ::"v"(flushed));
+        __syncthreads();
+        for (uint32_t i = tid; i < nrows; i += kSweepThreads) out[out0 + i] = R::finish(ys[i]);
+        if (!next) break;
+    }
+}
+
+}  // namespace
+
+uint32_t spmv_sweep_lds_bytes(uint32_t max_block_rows) { return ((max_block_rows + 1) * kAccumulatorBytes + 15u) & ~15u; }
+
+hipError_t configure_sweep_kernels(uint32_t lds_bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_sweep_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_sweep_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+}
+
+hipError_t launch_spmv_sweep(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
+    int ablate = 0, depth = 8;
+    if (!profiling_switches(ablate, depth) || ablate != 0) return hipErrorInvalidValue;      // no profiling builds of this kernel
+    const dim3 grid(a.num_workgroups), block(kSweepThreads);
+    if (is_float) hipLaunchKernelGGL(spmv_sweep_kernel<true>, grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads);
+    else hipLaunchKernelGGL(spmv_sweep_kernel<false>, grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads);
+    return hipGetLastError();
+}
+
+}  // namespace dev
+}  // namespace hisparse

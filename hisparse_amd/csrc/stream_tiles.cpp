@@ -120,8 +120,8 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             const std::string f(force);
             if (f == "bitmap") bitmap = true;
             else if (f == "pairs" || f == "delta") bitmap = false;
-            else if (f == "owner" || f == "owner24") bitmap = false;
-            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner, owner24 or bitmap"; return false; }
+            else if (f == "owner" || f == "owner24" || f == "sweep") bitmap = false;
+            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner, owner24, sweep or bitmap"; return false; }
         }
         if (bitmap) {
             // the per-non-zero passes of the BITMAP builder are kernels too (HISPARSE_BITMAP_BUILD=host: the host loops of round 2,
@@ -142,6 +142,18 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             }
         }
     }
+    // ---- SWEEP (stream_tiles.h): hyper-sparse matrices whose x is gathered from L2 instead of staged in LDS -- its own builder (host threads)
+    //      and kernel.  HISPARSE_STREAM_FORMAT=sweep forces it.
+    {
+        bool sweep = false;
+        if (const char* force = env_switch("HISPARSE_STREAM_FORMAT")) sweep = std::string(force) == "sweep";
+        if (sweep) {
+            const uint64_t nnz_keep = out.nnz;
+            out = StreamTiles();
+            out.nnz = nnz_keep;
+            return build_sweep_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error, csr);
+        }
+    }
     // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse; hyper-sparse float matrices: OWNER --
     {
         const double mean_gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 1e30;
@@ -157,7 +169,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             else if (f == "owner") out.format = is_float ? kFormatOwner : kFormatPairs;   // float accumulators only
             else if (f == "owner24") out.format = g_no_owner ? kFormatPairs : kFormatOwner24;
             else if (f == "bitmap") {}   // was tried above and is not representable (duplicate entries): automatic choice
-            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner, owner24 or bitmap"; return false; }
+            else if (!f.empty()) { error = "HISPARSE_STREAM_FORMAT must be pairs, delta, owner, owner24, sweep or bitmap"; return false; }
         }
     }
     // ---- LIGHT plan (stream_tiles.h): a small matrix is launch-bound in the row-block kernel -- one slice, up to 4 x CUs small blocks of a

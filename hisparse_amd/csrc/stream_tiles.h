@@ -101,7 +101,7 @@ constexpr uint64_t kDeltaMinSavedBytes = 23u << 20;           // DELTA must save
 constexpr uint64_t kDeltaMinSavedBytesFloat = 40u << 20;      // ... 6 us in the float modes (stream_tiles.cpp: the choice after the sort)
 constexpr double kDenseMeanGap = 320.0;                       // DELTA blocks denser than this (>= 24 elements per row and sub-tile) sum per lane in registers (kBlockDenseRows);
                                                               // sparser ones lose with it (400000 x 100000, gap 512: 89.8 vs 83.2 us), denser ones win big (40000^2, gap 64: 34.5 vs 53.0)
-enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1, kFormatBitmap = 2, kFormatOwner = 3, kFormatPairs24 = 4, kFormatOwner24 = 5 };
+enum StreamFormat : uint32_t { kFormatPairs = 0, kFormatDelta = 1, kFormatBitmap = 2, kFormatOwner = 3, kFormatPairs24 = 4, kFormatOwner24 = 5, kFormatSweep = 6 };
 // PAIRS24: PAIRS with a 24-bit position word -- 7 instead of 8 bytes per element.  A wavefront step is 448 bytes: 64 value dwords, then
 // 64 x 3 bytes (local_row << 13 | local_col, little endian), which the kernel reads as unaligned dwords at byte 256 + 3 * lane.
 // 11 bits of row: whenever no block has more than 2046 rows (nrows itself -- the spare accumulator -- must fit).  Opt-in
@@ -172,6 +172,18 @@ constexpr uint32_t kLightMaxUnits = 16;                       // sub-tiles of a 
 constexpr uint32_t kLightWorkgroupsPerCu = 4;                 // measured flat between 2 and 6 per CU (the kernel is compiled for 6: 85 registers); HISPARSE_LIGHT_WGS=1..6 for experiments
 constexpr uint32_t kLightMaxBlockRows = 3071;                 // 24 KiB of accumulators per workgroup: up to six of them per CU
 constexpr uint32_t kLightMinBlockNnz = 1024;                  // no block smaller than 16 chunks (unless the matrix is)
+// SWEEP format (round 4; hyper-sparse matrices, x NOT staged in LDS): a block = (row range x CONTIGUOUS column slice), its elements sorted by
+// (column, row) and stored in that order as 512-byte chunks of 64 x { u32 value word, u32 (local_row << 16 | column - chunk base) }; chunk k
+// of a block belongs to step k / 16 of wavefront k % 16, so the 16 wavefronts of the workgroup sweep the slice's columns together, once,
+// left to right.  The chunk bases (absolute column of the chunk's first element) sit in a table per block, [wavefront][step].  x[column] is
+// a per-lane global load (x is L2 / Infinity-Cache resident; column order makes the 64 lanes of one gather touch a handful of 128-byte lines),
+// products go to 8-byte LDS accumulators with atomics: no units, no x refills, no barriers between a block's prologue and epilogue.
+// Padding slots (the tail of a block's last step, and a chunk cut short because the next column lies more than 65535 beyond its base): value 0,
+// local_row = nrows (the spare accumulator), offset 0.  kernel: spmv_sweep.hip; builder: sweep_tiles.cpp; tools/gather_bench.hip is the
+// block-level measurement it was designed from.
+constexpr uint32_t kSweepWaves = 16;                          // all wavefronts stream (no loaders)
+constexpr uint32_t kSweepMaxBlockRows = kMaxLdsBytes / kAccumulatorBytes - 1;   // 20479: the LDS holds nothing but accumulators
+constexpr uint32_t kSweepColAlign = 32;                       // slices start on a 128-byte line of x
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit
 constexpr uint32_t kBlockLastOfPartition = 2u;                // Block::flags bit: the workgroup's last block of this row partition
@@ -201,6 +213,9 @@ struct Unit {
     uint32_t ncols;         // multiple of 8, <= kSubTileCols
     uint32_t end_step[kConsumerWaves];      // per wavefront: its stream position (in chunks / records, heads included) after this unit
 };
+// SWEEP images: a Block describes (row range x column slice) -- row0, nrows, row_part, flags, out_offset, next as above, wave_offset[0] = byte
+// offset of the block's first chunk, wave_offset[1] = byte offset of its chunk-base table (u32 [16][steps]), total_steps[0] = steps, first_col0 /
+// first_ncols = the slice's first column / column count; no units.
 // BITMAP images re-use the two tables: a Block describes (row range x column slice) -- row0, nrows, row_part, flags, out_offset, next as
 // above, first_col0 = first column of the slice, first_ncols = groups per row in the slice -- and its units [unit_begin, unit_end)
 // are kBitmapWaves RUN HEADERS of kBitmapRunSlots x 64 bytes, one per wavefront: a WaveSeg (same 64 bytes as a Unit) followed by a copy
@@ -262,6 +277,7 @@ struct StreamTiles {
                                          // (hs_run_partition starts there and stops at kBlockLastOfPartition)
     uint32_t num_workgroups = 0;
     uint32_t max_block_rows = 0;
+    uint64_t sweep_table_bytes = 0;      // SWEEP: bytes of the chunk-base tables at the end of the image (statistics)
     bool light = false;                  // the LIGHT plan (below): PAIRS image, one slice, up to kLightWorkgroupsPerCu x CUs small blocks, spmv_light_kernel
     uint32_t col_slices = 1;             // > 1: blocks write per-slice partial results, a combine pass adds them
     uint32_t ring_buffers = kMaxXBuffers;

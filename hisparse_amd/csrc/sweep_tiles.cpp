@@ -1,0 +1,260 @@
+// sweep_tiles.cpp — CPSR image (or CSR rows) -> SWEEP blocks (stream_tiles.h "SWEEP format"; kernel: spmv_sweep.hip).
+//
+// Hyper-sparse matrices (pokec: 19 non-zeros per row over 1.6 M columns) pay in the row-block kernel for every (row range x 8192-column
+// sub-tile) unit -- a flush, a barrier and a 32 KiB refill of x for ~2 000 elements.  SWEEP drops the units: the
+// vector stays in L2 and the elements of a block come in COLUMN order, so that the 64 lanes of one gather touch a handful of 128-byte
+// lines and the workgroup moves over its slice of x once, left to right (measured at block level first: tools/gather_bench.hip,
+// profiles/r04_gather_bench.txt).  What replaces the FPGA's column partitions (spmv/libfpga/vecbuf_access_unit.h:66-72: the vector buffer
+// holds one partition of x at a time) is the column slice; what replaces its output buffer (pe.h:121-135) is the block's LDS accumulators.
+// The CPSR image is decoded once (tiles_common.h: the same walk as the other formats), the rows are put back into column order, every
+// block's elements are sorted by (column, row) and cut into chunks of 64.  Host threads only -- the device builder (gpu_tiles.hip) does not
+// know this format.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <numeric>
+
+#include "hisparse/q8_24.h"
+#include "tiles_common.h"
+
+namespace hisparse {
+namespace dev {
+
+using namespace detail;
+
+namespace {
+
+// cost of a block in ns on one CU (tools/gather_bench.hip): 8 bytes per element at ~20 GB/s per CU, and a gathered 128-byte line of x
+// every ~3.3 clocks
+constexpr double kSweepNsPerElement = 0.39, kSweepNsPerLine = 1.36;
+
+struct Placed { uint64_t key; uint32_t value; };      // key = column << 16 | local row
+
+}  // namespace
+
+bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
+                       const std::vector<uint32_t>& row_nnz, uint32_t max_workgroups, StreamTiles& out, std::string& error, const CsrView* csr) {
+    const uint32_t num_rows = L.num_rows, num_cols = L.num_cols, RP = L.row_parts, CP = L.col_parts;
+    const uint32_t G = std::max<uint32_t>(1, max_workgroups);
+    auto chan = [&](uint32_t pc) { return static_cast<const MatPkt*>(channel[pc]); };
+    if (uint64_t(num_cols) * 4 >= (1ull << 32)) { error = "sweep: x does not fit a 32-bit byte offset"; return false; }
+    PhaseTimer timer;
+
+    // ---- rows back in CSR form: (absolute column, value word) per row, in column order -----------------------------------------
+    std::vector<uint64_t> row_ptr(size_t(num_rows) + 1, 0);
+    for (uint32_t r = 0; r < num_rows; ++r) row_ptr[r + 1] = row_ptr[r] + row_nnz[r];
+    const uint64_t nnz = row_ptr[num_rows];
+    const std::unique_ptr<uint64_t[]> elems_buf(new uint64_t[std::max<uint64_t>(nnz, 1)]);
+    uint64_t* const elems = elems_buf.get();               // column << 32 | value word
+    if (csr) {              // value words as csr_matrix_convert_from_float gives them (sw/data_loader.h:76-84)
+        const bool fixed = L.g->impl == IMPL_FIXED;
+        std::atomic<bool> bad_column(false);
+        parallel_for((csr->num_rows + 1023) / 1024, [&](size_t piece) {
+            for (uint32_t r = uint32_t(piece) * 1024; r < std::min<uint64_t>(csr->num_rows, (piece + 1) * 1024); ++r)
+                for (uint64_t e = csr->indptr[r], o = row_ptr[r]; e < csr->indptr[r + 1]; ++e, ++o) {
+                    if (csr->indices[e] >= csr->num_cols) bad_column = true;
+                    uint32_t word;
+                    if (fixed) word = q8_24_raw_from_double(double(csr->values[e]));
+                    else std::memcpy(&word, &csr->values[e], 4);
+                    elems[o] = (uint64_t(csr->indices[e]) << 32) | word;
+                }
+        });
+        if (bad_column) { error = "CSR column index outside the matrix"; return false; }
+    } else {
+        std::vector<uint32_t> cursor(num_rows, 0);
+        const uint32_t split = std::thread::hardware_concurrency() > 2 * RP * NUM_HBM_CHANNELS ? PACK_SIZE : 1;   // a task per packet lane where threads are plenty
+        std::vector<WalkResult> res(size_t(RP) * NUM_HBM_CHANNELS * split);
+        parallel_for(res.size(), [&](size_t w) {
+            const uint32_t lane = uint32_t(w % split), pc = uint32_t(w / split % NUM_HBM_CHANNELS), rp = uint32_t(w / split / NUM_HBM_CHANNELS);
+            for (uint32_t cp = 0; cp < CP && res[w].ok; ++cp) {
+                const uint64_t col_base = uint64_t(cp) * L.g->logical_vb;
+                WalkResult r = walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t val) {
+                    elems[row_ptr[row] + cursor[row]++] = ((col_base + col) << 32) | val;
+                }, split > 1 ? int(lane) : -1);
+                if (!r.ok) res[w] = r;
+            }
+        });
+        for (const auto& r : res)
+            if (!r.ok) { error = r.error; return false; }
+    }
+    parallel_for((num_rows + 1023) / 1024, [&](size_t piece) {      // (the reference does not require sorted CSR input; duplicates are legal here)
+        for (uint32_t r = uint32_t(piece) * 1024; r < std::min<uint64_t>(num_rows, (piece + 1) * 1024); ++r) {
+            uint64_t* e = elems + row_ptr[r];
+            if (!std::is_sorted(e, e + row_nnz[r])) std::sort(e, e + row_nnz[r]);
+        }
+    });
+    timer.lap("sweep: rows in column order");
+
+    // ---- plan: row ranges x contiguous column slices ----------------------------------------------------------------------------
+    // Every block gathers each 128-byte line of its slice of x about once, so the lines through the chip are (row ranges x |x| / 128)
+    // whatever the slice count; slices exist to fill the CUs when the LDS row cap allows fewer row ranges than there are workgroups,
+    // at the price of the combine pass (same model as stream_tiles.cpp).
+    uint32_t max_rows = kSweepMaxBlockRows;
+    if (const char* force = env_switch("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force)));
+    uint64_t by_cap = 0;
+    for (uint32_t rp = 0; rp < RP; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + max_rows - 1) / max_rows;
+    const uint32_t lines = (num_cols + kSweepColAlign - 1) / kSweepColAlign;
+    uint32_t slices = 1;
+    uint64_t want_ranges = 1;
+    {
+        const char* force_slices = env_switch("HISPARSE_COL_SLICES");
+        double best = 1e30;
+        for (uint32_t cs = 1; cs <= std::min<uint32_t>(kMaxColSlices, lines); ++cs) {
+            if (force_slices && uint32_t(std::atoi(force_slices)) != cs) continue;
+            if (uint64_t(cs) * num_rows > 0xffffffffull) continue;      // Block::out_offset is a 32-bit word offset
+            const uint64_t per_round = std::max<uint32_t>(1, G / cs);
+            const uint64_t rounds = std::max<uint64_t>(1, (by_cap + per_round - 1) / per_round);
+            const uint64_t ranges = std::min<uint64_t>(per_round * rounds, std::max<uint64_t>(by_cap, std::max<uint64_t>(1, nnz / 4096)));
+            const double blocks = double(ranges) * cs, blocks_per_wg = std::ceil(blocks / G);
+            const double block_ns = double(nnz) / blocks * kSweepNsPerElement + double(lines) / cs * kSweepNsPerLine;
+            const double combine_us = cs > 1 ? 3.5 + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
+            const double cost = blocks_per_wg * (block_ns * 1e-3 + 6.0) + combine_us;
+            if (env_switch("HISPARSE_PLAN_DEBUG")) std::fprintf(stderr, "sweep plan cs %u: ranges %llu block %.1f us combine %.1f => %.1f us\n", cs, (unsigned long long)ranges, block_ns * 1e-3, combine_us, cost);
+            if (cost < best) { best = cost; slices = cs; want_ranges = ranges; }
+        }
+        if (best == 1e30) { error = "sweep: no plan (HISPARSE_COL_SLICES out of range?)"; return false; }
+    }
+    std::vector<RowRange> ranges;
+    std::vector<uint64_t> range_nnz;
+    build_row_ranges_at_most(L, row_nnz, nnz, want_ranges, max_rows, ranges, range_nnz, std::max<uint32_t>(1, G / slices));
+    const uint32_t NR = uint32_t(ranges.size()), NB = NR * slices;
+
+    // slice boundaries (the same for every row range), on 128-byte lines of x, at equal block cost: elements + lines
+    std::vector<uint32_t> slice_col(slices + 1, 0);
+    {
+        std::vector<uint64_t> line_nnz(lines, 0);
+        std::mutex merge;
+        const size_t pieces = std::max<size_t>(1, std::min<size_t>(64, num_rows / 1024));
+        parallel_for(pieces, [&](size_t piece) {
+            std::vector<uint32_t> mine(lines, 0);
+            const uint64_t lo = row_ptr[uint64_t(num_rows) * piece / pieces], hi = row_ptr[uint64_t(num_rows) * (piece + 1) / pieces];
+            for (uint64_t e = lo; e < hi; ++e) mine[uint32_t(elems[e] >> 32) / kSweepColAlign]++;
+            std::lock_guard<std::mutex> lock(merge);
+            for (uint32_t l = 0; l < lines; ++l) line_nnz[l] += mine[l];
+        });
+        std::vector<double> upto(lines + 1, 0.0);
+        for (uint32_t l = 0; l < lines; ++l) upto[l + 1] = upto[l] + double(line_nnz[l]) / std::max<uint32_t>(1, NR) * kSweepNsPerElement + kSweepNsPerLine;
+        uint32_t line_before = 0;
+        for (uint32_t k = 1; k < slices; ++k) {
+            const uint32_t l = uint32_t(std::lower_bound(upto.begin(), upto.end(), upto[lines] * k / slices) - upto.begin());
+            line_before = std::max(line_before, std::min(l, lines));
+            slice_col[k] = uint32_t(std::min<uint64_t>(uint64_t(line_before) * kSweepColAlign, num_cols));
+        }
+        slice_col[slices] = num_cols;
+    }
+    timer.lap("sweep: plan");
+
+    // ---- blocks: elements sorted by (column, row), cut into chunks ---------------------------------------------------------------
+    out.nnz = nnz;
+    out.format = kFormatSweep;
+    out.col_slices = slices;
+    out.ring_buffers = 0;
+    out.light = false;
+    out.blocks.assign(NB, Block{});
+    out.units.assign(1, Unit{});             // (no units; one descriptor so that the table is never empty)
+    out.max_block_rows = 0;
+    for (const RowRange& rg : ranges) out.max_block_rows = std::max(out.max_block_rows, rg.nrows);
+    std::vector<std::vector<Placed>> sorted(NB);
+    std::vector<std::vector<uint32_t>> chunk_first(NB);      // index of every chunk's first element (+ the end)
+    parallel_for(NB, [&](size_t bi) {
+        const RowRange& rg = ranges[bi / slices];
+        const uint64_t c0 = slice_col[bi % slices], c1 = slice_col[bi % slices + 1];
+        std::vector<Placed>& mine = sorted[bi];
+        for (uint32_t r = 0; r < rg.nrows; ++r) {
+            const uint64_t* e = elems + row_ptr[rg.row0 + r];
+            const uint32_t n = row_nnz[rg.row0 + r];
+            const uint64_t* lo = slices == 1 ? e : std::lower_bound(e, e + n, c0 << 32);
+            const uint64_t* hi = slices == 1 ? e + n : std::lower_bound(lo, e + n, c1 << 32);
+            for (const uint64_t* p = lo; p < hi; ++p) mine.push_back(Placed{(*p >> 32) << 16 | r, uint32_t(*p)});
+        }
+        std::sort(mine.begin(), mine.end(), [](const Placed& a, const Placed& b) { return a.key != b.key ? a.key < b.key : a.value < b.value; });
+        // a chunk: up to 64 elements whose columns lie within 65535 of the first one's
+        std::vector<uint32_t>& first = chunk_first[bi];
+        for (uint32_t i = 0; i < mine.size();) {
+            first.push_back(i);
+            const uint64_t base = mine[i].key >> 16;
+            uint32_t j = i + 1;
+            while (j < mine.size() && j - i < kWaveLanes && (mine[j].key >> 16) - base <= 0xffffu) ++j;
+            i = j;
+        }
+        first.push_back(uint32_t(mine.size()));
+    });
+    timer.lap("sweep: sort blocks");
+
+    std::vector<uint64_t> block_weight(NB, 0), stream_at(NB, 0), table_at(NB, 0);
+    uint64_t stream_bytes = 0, table_bytes = 0;
+    for (uint32_t bi = 0; bi < NB; ++bi) {
+        const uint32_t chunks = uint32_t(chunk_first[bi].size()) - 1;
+        const uint32_t steps = (chunks + kSweepWaves - 1) / kSweepWaves;
+        if (uint64_t(steps) * kSweepWaves * kChunkBytes >= (1ull << 32)) { error = "sweep: a block's stream exceeds 4 GiB"; return false; }
+        const RowRange& rg = ranges[bi / slices];
+        Block& blk = out.blocks[bi];
+        blk.row0 = rg.row0;
+        blk.nrows = rg.nrows;
+        blk.row_part = rg.row_part;
+        blk.flags = 0;
+        blk.out_offset = slices > 1 ? (bi % slices) * num_rows + rg.row0 : rg.row0;
+        blk.total_steps[0] = steps;
+        blk.first_col0 = slice_col[bi % slices];
+        blk.first_ncols = slice_col[bi % slices + 1] - slice_col[bi % slices];
+        stream_at[bi] = stream_bytes;
+        stream_bytes += uint64_t(steps) * kSweepWaves * kChunkBytes;
+        table_at[bi] = table_bytes;
+        table_bytes += uint64_t(steps) * kSweepWaves * 4;
+        block_weight[bi] = steps;
+        out.elements += uint64_t(steps) * kSweepWaves * kWaveLanes;
+    }
+    for (uint32_t bi = 0; bi < NB; ++bi) {
+        out.blocks[bi].wave_offset[0] = stream_at[bi];
+        out.blocks[bi].wave_offset[1] = stream_bytes + table_at[bi];
+    }
+    out.image_bytes = stream_bytes + table_bytes;
+    out.sweep_table_bytes = table_bytes;
+    resize_zeroed(out.image, out.image_bytes);
+    parallel_for(NB, [&](size_t bi) {
+        const std::vector<Placed>& mine = sorted[bi];
+        const std::vector<uint32_t>& first = chunk_first[bi];
+        const uint32_t chunks = uint32_t(first.size()) - 1, steps = out.blocks[bi].total_steps[0], nrows = out.blocks[bi].nrows;
+        uint32_t* stream = reinterpret_cast<uint32_t*>(out.image.data() + stream_at[bi]);
+        uint32_t* table = reinterpret_cast<uint32_t*>(out.image.data() + stream_bytes + table_at[bi]);
+        const uint32_t pad_col = out.blocks[bi].first_ncols ? out.blocks[bi].first_col0 : 0u;     // (a column that exists: padding gathers x too)
+        for (uint32_t k = 0; k < steps * kSweepWaves; ++k) {
+            const uint32_t s = k / kSweepWaves, w = k % kSweepWaves;
+            const uint32_t lo = k < chunks ? first[k] : 0u, hi = k < chunks ? first[k + 1] : 0u;
+            const uint32_t base = hi > lo ? uint32_t(mine[lo].key >> 16) : (chunks ? uint32_t(mine.back().key >> 16) : pad_col);
+            table[size_t(w) * steps + s] = base;
+            uint32_t* chunk = stream + size_t(k) * (kChunkBytes / 4);
+            for (uint32_t l = 0; l < kWaveLanes; ++l) {
+                if (lo + l < hi) {
+                    const Placed& p = mine[lo + l];
+                    chunk[2 * l] = p.value;
+                    chunk[2 * l + 1] = uint32_t(p.key & 0xffffu) << 16 | uint32_t((p.key >> 16) - base);
+                } else {
+                    chunk[2 * l] = 0;
+                    chunk[2 * l + 1] = nrows << 16;
+                }
+            }
+        }
+    });
+    sorted.clear();
+    timer.lap("sweep: write image");
+
+    std::vector<std::vector<uint32_t>> mine;
+    if (slices > 1 && G % 8 == 0 && NB >= G) {      // an XCD works on one slice of x, two at most: its L2 holds it
+        std::vector<uint32_t> slice_of_block(NB);
+        for (uint32_t bi = 0; bi < NB; ++bi) slice_of_block[bi] = bi % slices;
+        assign_workgroups_by_slice(out, block_weight, G, RP, slice_of_block, mine);
+    } else {
+        assign_workgroups(out, block_weight, G, RP, mine);
+    }
+    chain_blocks(out, mine, RP);
+    timer.lap("sweep: workgroups");
+    return true;
+}
+
+}  // namespace dev
+}  // namespace hisparse

@@ -39,7 +39,7 @@ class Stats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
-STREAM_FORMATS = ("pairs", "delta", "bitmap", "owner", "pairs24", "owner24")   # HS_STREAM_* (include/hisparse_hip.h)
+STREAM_FORMATS = ("pairs", "delta", "bitmap", "owner", "pairs24", "owner24", "sweep")   # HS_STREAM_* (include/hisparse_hip.h)
 CONSUMER_WAVES = 14
 # device-side descriptors (hisparse_amd/csrc/stream_tiles.h)
 BLOCK_DTYPE = np.dtype([("row0", "<u4"), ("nrows", "<u4"), ("row_part", "<u4"), ("unit_begin", "<u4"), ("unit_end", "<u4"),

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 IMPLS = [0, 1, 2]
 
 
-@pytest.fixture(autouse=True, params=["pairs", "delta", "delta-lane-sums", "delta-no-lane-sums", "bitmap", "owner", "pairs24", "owner24", "light"])
+@pytest.fixture(autouse=True, params=["pairs", "delta", "delta-lane-sums", "delta-no-lane-sums", "bitmap", "owner", "pairs24", "owner24", "light", "sweep"])
 def stream_format(request, monkeypatch):
     # every parity test runs once per device stream format (hisparse_amd/csrc/stream_tiles.h); DELTA additionally with the
     # per-lane register sums of long-row blocks forced on and off (by default the block's density decides); BITMAP (normally
@@ -27,6 +27,7 @@ def stream_format(request, monkeypatch):
     # four steps with 24-bit position words (the default for hyper-sparse float matrices)
     # "light" (round 4): the small-matrix plan -- the PAIRS image cut into up to 4 x CUs blocks and run by spmv_light_kernel (one launch,
     # 256-thread workgroups, x gathered from L2); taken by every case of at most 16 x sub-tiles, plain PAIRS otherwise
+    # "sweep" (round 4): column-ordered blocks, x gathered from L2, no units (spmv_sweep.hip)
     monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "pairs" if request.param in ("pairs24", "light") else request.param.split("-")[0])
     monkeypatch.setenv("HISPARSE_LIGHT", "1" if request.param == "light" else "0")
     if request.param == "pairs24":

@@ -1,0 +1,121 @@
+"""The SWEEP format (hisparse_amd/csrc/sweep_tiles.cpp, stream_tiles.h) checked without a GPU: the image hs_load_matrix would upload is
+walked by the numpy emulation of spmv_sweep_kernel (tests/tile_emulator.py: column order inside a block, padding rules, slice bounds are
+asserted there) and compared with the oracle."""
+import numpy as np
+import pytest
+
+from hisparse_amd import device, host
+from oracle import oracle as orc
+
+import cases
+import tile_emulator
+
+
+def build(cp, impl, workgroups):
+    return device.build_tiles(cp, impl, cp.ob_bank, cp.vb_bank, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                              cp.num_col_partitions, workgroups)
+
+
+def oracle_y(cp, impl, xw):
+    return orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                    cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+
+
+@pytest.fixture(autouse=True)
+def forced(monkeypatch):
+    monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "sweep")
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("rows,cols,nnz,wgs,slices", [(60000, 90000, 200000, 16, None), (30000, 200000, 150000, 8, 4), (9000, 70000, 20000, 3, 2),
+                                                      (300, 50, 700, 4, None), (1000, 1000, 10000, 256, None)])
+def test_sweep_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypatch):
+    if slices:
+        monkeypatch.setenv("HISPARSE_COL_SLICES", str(slices))
+    csr = host.CSRMatrix.generate("powerlaw", rows, cols, a=nnz, b=0.5, c=1.0 if impl == 0 else 2.0, seed=12)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 12, impl) * (40.0 if impl == 0 else 1.0))      # fixed point: some rows saturate
+    t = build(cp, impl, wgs)
+    assert t["format"] == "sweep" and t["nnz"] == cp.nnz and t["elements"] >= cp.nnz
+    assert not slices or t["col_slices"] == slices
+    blocks = t["blocks"]
+    assert (blocks["nrows"] <= 20479).all() and t["max_block_rows"] == blocks["nrows"].max()
+    # streams of whole steps (16 chunks of 512 bytes) followed by the chunk-base tables (16 words per step)
+    steps = blocks["total_steps"][:, 0].astype(np.int64)
+    assert len(t["image"]) == steps.sum() * 16 * (512 + 4)
+    assert t["elements"] == steps.sum() * 16 * 64
+    # the slices of a row range are contiguous, disjoint, cover the columns and start on 128-byte lines of x
+    order = np.lexsort((blocks["first_col0"], blocks["row0"]))
+    per_range = t["col_slices"]
+    for b in range(0, len(blocks), per_range):
+        mine = blocks[order[b: b + per_range]]
+        assert (mine["row0"] == mine["row0"][0]).all() and mine["first_col0"][0] == 0
+        assert (mine["first_col0"] % 32 == 0).all()
+        assert np.array_equal(mine["first_col0"][1:], (mine["first_col0"] + mine["first_ncols"])[:-1])
+        assert mine["first_col0"][-1] + mine["first_ncols"][-1] == cp.num_cols
+        for k in range(per_range):
+            assert mine["out_offset"][k] == (k * cp.num_rows if per_range > 1 else 0) + mine["row0"][k]
+    got = tile_emulator.run(t, impl, xw, cp.num_rows)
+    want = oracle_y(cp, impl, xw)
+    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+    if impl == 0 and rows >= 9000:
+        assert (want == 0xFFFFFFFF).any()
+
+
+def test_sweep_row_partitions_and_partition_filter():
+    # float_pob-style small output banks: several row partitions, run one at a time like hs_run_partition; blocks never cross a partition
+    m = cases.random_csr(2500, 300, 0.03, 21, 0)
+    _, cp = cases.formatted(m, 0, 4, 1, True)
+    assert cp.num_row_partitions > 3
+    xw = host.pack_vector(0, cases.random_x(cp.num_cols, 21, 0))
+    t = build(cp, 0, 16)
+    assert t["format"] == "sweep"
+    for g in range(t["num_workgroups"]):
+        chain = t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]
+        parts = t["blocks"]["row_part"][chain]
+        assert (np.diff(parts.astype(np.int64)) >= 0).all()
+        last = (t["blocks"]["flags"][chain] & 2) != 0
+        assert np.array_equal(last, np.append(parts[1:] != parts[:-1], True))
+    full = tile_emulator.run(t, 0, xw, cp.num_rows)
+    y = np.zeros(cp.num_rows, dtype=np.uint32)
+    for j in range(cp.num_row_partitions):
+        y = tile_emulator.run(t, 0, xw, cp.num_rows, row_part_filter=j, y_init=y)
+    assert np.array_equal(y, full) and np.array_equal(full, oracle_y(cp, 0, xw))
+
+
+@pytest.mark.parametrize("impl", [0, 2])
+def test_sweep_column_gaps_beyond_16_bits_cut_the_chunk(impl):
+    """A chunk's 16-bit column offsets reach 65535 columns beyond its first element: a block whose columns lie further apart gets its
+    chunks cut short and padded (value 0, spare accumulator)."""
+    rows, cols = 64, 400000
+    rng = np.random.default_rng(5)
+    indptr = np.arange(0, rows * 3 + 1, 3, dtype=np.uint32)
+    indices = np.sort(rng.choice(cols, size=(rows, 3), replace=True), axis=1).astype(np.uint32).ravel()      # ~192 columns spread over 400 K: gaps of thousands, some > 65535 with 1 row range
+    data = rng.uniform(0.1, 1.0, rows * 3).astype(np.float32)
+    csr = host.CSRMatrix.from_arrays(rows, cols, indptr, indices, data)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 2, impl))
+    t = build(cp, impl, 64)      # few non-zeros: few blocks, each with columns far apart
+    assert t["format"] == "sweep"
+    steps = t["blocks"]["total_steps"][:, 0].astype(np.int64)
+    assert steps.sum() * 16 * 64 > 4 * cp.nnz      # (mostly padding: the cuts happened)
+    got, want = tile_emulator.run(t, impl, xw, cp.num_rows), oracle_y(cp, impl, xw)
+    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+
+
+def test_sweep_duplicates_and_empty_matrix():
+    # duplicate (row, column) entries are separate elements (their products add up); a matrix without non-zeros gives blocks without steps
+    indptr = np.array([0, 3, 3, 5], dtype=np.uint32)
+    indices = np.array([7, 7, 2, 0, 0], dtype=np.uint32)
+    data = np.array([1.0, 2.0, 0.5, 0.25, 0.25], dtype=np.float32)
+    csr = host.CSRMatrix.from_arrays(3, 10, indptr, indices, data)
+    cp = host.format_matrix(csr, 0, skip_empty_rows=False)
+    xw = host.pack_vector(0, np.arange(1, cp.num_cols + 1, dtype=np.float32) * 0.125)
+    t = build(cp, 0, 8)
+    got = tile_emulator.run(t, 0, xw, cp.num_rows)
+    assert np.array_equal(got, oracle_y(cp, 0, xw)) and orc.unpack_result(0, got)[0] == 3.0 * 1.0 + 0.5 * 0.375
+    empty = host.CSRMatrix.from_arrays(5, 9, np.zeros(6, dtype=np.uint32), np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.float32))
+    cpe = host.format_matrix(empty, 0, skip_empty_rows=False)
+    te = build(cpe, 0, 8)
+    assert te["format"] == "sweep" and te["nnz"] == 0 and (te["blocks"]["total_steps"][:, 0] == 0).all()
+    assert not tile_emulator.run(te, 0, host.pack_vector(0, np.ones(cpe.num_cols, dtype=np.float32)), cpe.num_rows).any()

@@ -199,6 +199,29 @@ def _block_bitmap(image, blk, units, x_words, ys, is_float):
     assert (covered == 1).all() or (covered == 0).all()
 
 
+def _block_sweep(image, blk, x_words, ys, is_float):
+    """SWEEP (stream_tiles.h): chunk k of the block = step k // 16 of wavefront k % 16, its base column in the table [wavefront][step];
+    the chunks, taken in order, hold the block's elements in non-decreasing column order inside the block's column slice."""
+    nrows, steps = int(blk["nrows"]), int(blk["total_steps"][0])
+    stream, table_at = int(blk["wave_offset"][0]), int(blk["wave_offset"][1])
+    col_lo, col_hi = int(blk["first_col0"]), int(blk["first_col0"]) + int(blk["first_ncols"])
+    table = image[table_at: table_at + steps * 16 * 4].view(np.uint32).reshape(16, steps) if steps else None
+    previous = -1
+    for k in range(steps * 16):
+        s, w = divmod(k, 16)
+        val, cr = _chunk(image, stream + k * CHUNK_BYTES, False)
+        row, col = (cr >> 16).astype(np.int64), int(table[w, s]) + (cr & 0xFFFF).astype(np.int64)
+        real = row < nrows
+        assert (row <= nrows).all() and (val[~real] == 0).all() and ((cr[~real] & 0xFFFF) == 0).all()      # padding: value 0 at the spare accumulator
+        assert (col < len(x_words)).all()                                                              # padding gathers x too
+        if real.any():
+            assert not real[np.argmin(real):].any() if not real.all() else True                        # padding only behind the elements
+            c = col[real]
+            assert (np.diff(c) >= 0).all() and c[0] >= previous and col_lo <= c[0] and c[-1] < col_hi
+            previous = int(c[-1])
+        _accumulate(ys, is_float, row, val, x_words[col])
+
+
 def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
     """Returns packed y words.  tiles: dict from hisparse_amd.device.build_tiles."""
     is_float = impl != 0
@@ -207,12 +230,13 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
     bitmap = tiles["format"] == "bitmap"
     owner = tiles["format"] in ("owner", "owner24")
     aux24 = tiles["format"] in ("pairs24", "owner24")
+    sweep = tiles["format"] == "sweep"
     y = np.zeros(num_rows, dtype=np.uint32) if y_init is None else y_init.copy()
     slices = int(tiles.get("col_slices", 1))
     out = y if slices == 1 else np.zeros(slices * num_rows, dtype=np.uint32)   # per-slice partial results
     touched = np.zeros(num_rows, dtype=bool)
     done = np.zeros(len(blocks), dtype=bool)
-    if not bitmap:
+    if not bitmap and not sweep:
         assert 2 <= tiles["ring_buffers"] <= 4
         assert (units["ncols"] % 8 == 0).all() and (units["ncols"] > 0).all() and (units["ncols"] <= SUB_TILE).all()
     for g in range(tiles["num_workgroups"]):
@@ -224,14 +248,18 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
             if row_part_filter >= 0 and int(blk["row_part"]) != row_part_filter:
                 continue
             nrows, row0, out0 = int(blk["nrows"]), int(blk["row0"]), int(blk["out_offset"])
-            if owner:
+            if sweep:
+                assert (nrows + 1) * 8 <= 160 * 1024                                                 # the LDS holds the accumulators and nothing else
+            elif owner:
                 assert (nrows + CONSUMERS) * 4 + tiles["ring_buffers"] * 32768 <= 160 * 1024     # float accumulators + the x ring
             else:
                 assert nrows <= (8191 if bitmap else (32 if slices == 1 else 96) * 1024 // 8 - 1)   # LDS plan of the kernels: 8-byte accumulators
             assert out0 % num_rows == row0 and out0 // num_rows < slices
             touched[row0: row0 + nrows] = True
             ys = np.zeros(nrows + 1, dtype=np.float64 if is_float else np.uint64)     # double sums of float products
-            if owner or (not bitmap and not delta):
+            if sweep:
+                _block_sweep(image, blk, x_words, ys, is_float)
+            elif owner or (not bitmap and not delta):
                 (_block_owner if owner else _block_pairs)(image, blk, units, x_words, ys, is_float, aux24)
             else:
                 (_block_bitmap if bitmap else _block_delta)(image, blk, units, x_words, ys, is_float)
