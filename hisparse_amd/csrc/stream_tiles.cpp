@@ -143,9 +143,12 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         }
     }
     // ---- SWEEP (stream_tiles.h): hyper-sparse matrices whose x is gathered from L2 instead of staged in LDS -- its own builder (host threads)
-    //      and kernel.  HISPARSE_STREAM_FORMAT=sweep forces it.
+    //      and kernel.  Automatic above kSweepMinMeanGap (stream_tiles.h has the measurements); HISPARSE_SWEEP=0|1 and
+    //      HISPARSE_STREAM_FORMAT=sweep force.
     {
-        bool sweep = false;
+        const double gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 0.0;
+        bool sweep = gap >= (is_float ? kSweepMinMeanGapFloat : kSweepMinMeanGap) && out.nnz >= kSweepMinNnz;
+        if (const char* force = env_switch("HISPARSE_SWEEP")) sweep = std::atoi(force) != 0;      // (1: whatever the matrix)
         if (const char* force = env_switch("HISPARSE_STREAM_FORMAT")) sweep = std::string(force) == "sweep";
         if (sweep) {
             const uint64_t nnz_keep = out.nnz;

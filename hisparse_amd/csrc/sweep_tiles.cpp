@@ -171,7 +171,23 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
             const uint64_t* hi = slices == 1 ? e + n : std::lower_bound(lo, e + n, c1 << 32);
             for (const uint64_t* p = lo; p < hi; ++p) mine.push_back(Placed{(*p >> 32) << 16 | r, uint32_t(*p)});
         }
-        std::sort(mine.begin(), mine.end(), [](const Placed& a, const Placed& b) { return a.key != b.key ? a.key < b.key : a.value < b.value; });
+        // (column, row) order: the elements were collected row by row, each row in (column, value) order, so a STABLE sort by column is
+        // enough -- least-significant-digit radix passes of 11 bits over column - c0 (two passes up to 4 M columns per slice; std::sort took
+        // 195 of the 323 ms pokec's load spent here)
+        {
+            uint32_t bits = 1;
+            while (bits < 32 && ((c1 - c0 - 1) >> bits) != 0) ++bits;
+            std::vector<Placed> other(mine.size());
+            std::vector<uint32_t> count(1u << 11);
+            for (uint32_t shift = 0; shift < bits && c1 > c0; shift += 11) {
+                std::fill(count.begin(), count.end(), 0u);
+                for (const Placed& e : mine) count[(((e.key >> 16) - c0) >> shift) & 2047u]++;
+                uint32_t at = 0;
+                for (uint32_t& c : count) { const uint32_t n = c; c = at; at += n; }
+                for (const Placed& e : mine) other[count[(((e.key >> 16) - c0) >> shift) & 2047u]++] = e;
+                mine.swap(other);
+            }
+        }
         // a chunk: up to 64 elements whose columns lie within 65535 of the first one's
         std::vector<uint32_t>& first = chunk_first[bi];
         for (uint32_t i = 0; i < mine.size();) {

@@ -59,7 +59,7 @@ enum {
 enum { HS_IMPL_FIXED = 0, HS_IMPL_FLOAT_POB = 1, HS_IMPL_FLOAT_STALL = 2 };
 
 /* device-private stream formats (hisparse_amd/csrc/stream_tiles.h) */
-enum { HS_STREAM_PAIRS = 0, HS_STREAM_DELTA = 1, HS_STREAM_BITMAP = 2, HS_STREAM_OWNER = 3, HS_STREAM_PAIRS24 = 4, HS_STREAM_OWNER24 = 5 };
+enum { HS_STREAM_PAIRS = 0, HS_STREAM_DELTA = 1, HS_STREAM_BITMAP = 2, HS_STREAM_OWNER = 3, HS_STREAM_PAIRS24 = 4, HS_STREAM_OWNER24 = 5, HS_STREAM_SWEEP = 6 };
 
 typedef struct hs_context hs_context;
 
@@ -75,7 +75,7 @@ typedef struct {
     uint32_t num_compute_units; /* of the device */
     uint32_t col_slices;        /* column slices (1 = none; > 1 adds the small combine pass) */
     uint32_t ring_buffers;      /* x sub-tile buffers in the LDS ring */
-    uint32_t stream_format;     /* HS_STREAM_PAIRS (8 B per element), HS_STREAM_DELTA (6 B per slot) or HS_STREAM_BITMAP (4 B + 1 bit per column) HS_STREAM_OWNER (8 B per element, float accumulators) or the 7-byte forms of PAIRS / OWNER, chosen per matrix */
+    uint32_t stream_format;     /* HS_STREAM_PAIRS (8 B per element), HS_STREAM_DELTA (6 B per slot) or HS_STREAM_BITMAP (4 B + 1 bit per column) HS_STREAM_OWNER (8 B per element, float accumulators) the 7-byte forms of PAIRS / OWNER, or HS_STREAM_SWEEP (8 B per element in column order, x gathered from L2: very sparse matrices), chosen per matrix */
     double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
     uint32_t retiled_on_gpu;    /* 1: the per-non-zero passes of the re-tiling ran on the device (gpu_tiles.h); 0: on the host */
     uint32_t light_kernel;      /* 1: the LIGHT plan -- a small matrix run by the 256-thread single-launch kernel (spmv_light_kernel) over a PAIRS image */
@@ -131,8 +131,9 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
 /* ---- tuning options (EXTENSION) ----------------------------------------------------------------------
  * The library's configuration surface.  key: the name of a tuning switch, case-insensitive, with or without the "HISPARSE_" prefix of its
  * environment spelling -- plan-time keys (take effect at the NEXT hs_load_matrix / hs_load_matrix_csr of this context): stream_format
- * (pairs|delta|owner|owner24|bitmap), col_slices, max_rows, row_runs, aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
- * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), plan_debug; call-time keys: spmm_fused, spmm_mfma,
+ * (pairs|delta|owner|owner24|sweep|bitmap), col_slices, max_rows, row_runs, aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
+ * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), sweep (0|1: the
+ * column-ordered format of very sparse matrices), plan_debug; call-time keys: spmm_fused, spmm_mfma,
  * spmspv (sparse|dense), spmspv_crossover, iterate_graph, iterate_cooperative.  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
  * Options set here win over the environment variable of the same name, which stays as the fallback for tools and tests.  None of them
  * changes WHAT is computed.  The switches that do (HISPARSE_ABLATE, HISPARSE_DEPTH: profiling builds with parts of the work removed) are

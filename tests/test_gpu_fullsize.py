@@ -94,7 +94,7 @@ def test_full_size_random_values_vs_oracle(name, record_property):
 def test_reference_sweep_full_size_fixed_point(name, paper_gops, record_property):
     """Every matrix of the reference's sweep (sw/bm.sh:3-17) at full size in the numeric mode of the paper's Table 3 (fixed point),
     random values, through the default planner: bit-exact against the oracle.  The out-of-sample test of the format / tile planner's
-    thresholds: pokec and ogbn-products (hyper-sparse -> OWNER24 with saturating accumulators), transformer-90 / -95 (below BITMAP's
+    thresholds: ogbn-products (hyper-sparse -> OWNER24 with saturating accumulators), pokec (sparser still -> SWEEP, round 4), transformer-90 / -95 (below BITMAP's
     density threshold -> dense-row element streams), hollywood (113 M non-zeros, two row partitions)."""
     cfg, csr = datasets.load(name)
     cp = host.format_matrix(csr, 0, skip_empty_rows=cfg.skip_empty_rows)

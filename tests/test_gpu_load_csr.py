@@ -33,7 +33,7 @@ def _both(csr, impl, vb=0, ob=0, skip=True):
     return cp, xw, y, sb
 
 
-@pytest.mark.parametrize("fmt", ["pairs", "delta", "owner", "owner24", "bitmap"])
+@pytest.mark.parametrize("fmt", ["pairs", "delta", "owner", "owner24", "bitmap", "sweep"])
 @pytest.mark.parametrize("impl", [0, 1, 2])
 def test_same_image_as_the_cpsr_path(monkeypatch, fmt, impl):
     monkeypatch.setenv("HISPARSE_STREAM_FORMAT", fmt)

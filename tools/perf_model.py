@@ -23,6 +23,7 @@ RAMP_US = 4.3               # a 1024-thread workgroup's wavefronts are started 2
 NEXT_BLOCK_US = 3.5         # the same for a workgroup's further blocks (descriptor, zeroing, first sub-tile; no launch ramp)
 STORE_US = 1.0              # result store of a block (+ the write latency at its end)
 SPREAD = 0.05               # workgroups finish up to 5 % of the main loop apart (dynamic: memory-system fairness, not step counts)
+SWEEP_NS_PER_ELEMENT, SWEEP_NS_PER_LINE = 0.33, 1.36      # SWEEP (tools/gather_bench.hip): 8 bytes at ~24 GB/s per CU; a gathered line of x every ~3.3 clocks
 CU_STREAM_B_PER_US = {"pairs": 25.8e3, "delta": 25.8e3, "owner": 26.5e3}   # one CU's 14 consumer rings while nothing else binds: 6.6-6.8 TB/s / 256
 # a (row block, x sub-tile) UNIT costs at least this much, however little it holds: end-of-unit flush + barrier + the loaders' refill issue
 # (8 LDS-DMA instructions, ~1000 clocks, tools/owner_profile.py) + its landing.  OWNER / OWNER24: pokec (<= 3 steps per wavefront and unit)
@@ -54,6 +55,17 @@ def model(name, cp=None, impl=None):
         stream_us = len(t["image"]) / 6.6e6                                   # what the bytes alone would need
         parts = {"launch": BITMAP_LAUNCH_US, "front (ramp, descriptor -> masks -> values)": BITMAP_FRONT_US,
                  "stream": max(run_us, stream_us), "tail (finish spread, row sums, store)": BITMAP_TAIL_US * per_wg}
+        return cp, impl, t, parts
+    if family == "sweep":      # no units: every element at one CU's stream rate + every 128-byte line of the block's slice of x gathered once
+        per = np.zeros(groups); nblocks = np.zeros(groups)
+        for g in range(groups):
+            for b in t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]:
+                blk = blocks[b]
+                nblocks[g] += 1
+                per[g] += int(blk["total_steps"][0]) * 16 * 64 * SWEEP_NS_PER_ELEMENT * 1e-3 + int(blk["first_ncols"]) / 32.0 * SWEEP_NS_PER_LINE * 1e-3
+        crit = int(np.argmax(per + nblocks * (NEXT_BLOCK_US + STORE_US)))
+        parts = {"launch": LAUNCH_US, "ramp + prologue": RAMP_US, "further blocks' prologues": NEXT_BLOCK_US * max(0.0, nblocks[crit] - 1),
+                 "stream": per[crit], "result stores": STORE_US * nblocks[crit], "finish spread": SPREAD * per[crit]}
         return cp, impl, t, parts
     # per workgroup: its blocks one after the other; a block's main loop is the slower of (its stream at one CU's rate) and (its units at
     # the per-unit floor, each unit as long as its slowest wavefront's steps)
