@@ -397,7 +397,8 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     if (debug) std::fprintf(stderr, "load: image built after %.1f ms\n", since());
     // (BITMAP: + the block's stretch of x behind the accumulators when the builder asks for it, spmv_bitmap.hip kXLds)
-    const uint32_t lds_bytes = tiles.light ? hisparse::dev::spmv_light_lds_bytes(tiles.max_block_rows)
+    const uint32_t lds_bytes = tiles.format == hisparse::dev::kFormatSweep ? hisparse::dev::spmv_sweep_lds_bytes(tiles.max_block_rows, ctx->impl != HS_IMPL_FIXED)
+                               : tiles.light ? hisparse::dev::spmv_light_lds_bytes(tiles.max_block_rows)
                                            : hisparse::dev::spmv_lds_bytes(tiles.max_block_rows, tiles.ring_buffers, tiles.format) +
                                                  tiles.bitmap_x_groups * hisparse::dev::kBitmapGroupCols * 4u;
     if (lds_bytes > hisparse::dev::kMaxLdsBytes) {

@@ -85,7 +85,7 @@ hipError_t launch_spmm_mfma(const SpmmMfmaLaunch& a, hipStream_t stream);
 hipError_t configure_bitmap_kernels(uint32_t lds_bytes);
 hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream);
 // SWEEP images (spmv_sweep.hip); launch_spmv forwards to it when a.format == kFormatSweep.
-uint32_t spmv_sweep_lds_bytes(uint32_t max_block_rows);       // accumulators only
+uint32_t spmv_sweep_lds_bytes(uint32_t max_block_rows, bool is_float);       // accumulators only: doubles / 32-bit sums + a carry bit per row
 hipError_t configure_sweep_kernels(uint32_t lds_bytes);
 hipError_t launch_spmv_sweep(bool is_float, const SpmvLaunch& a, hipStream_t stream);
 // Column-sliced matrices only: y[r] = (saturating / fp32) sum of the `slices` partial vectors, rows [row_lo, row_hi);

@@ -1111,7 +1111,6 @@ const char* profiling_switch_error() {
 // wavefront), then the ring of x buffers.
 uint32_t spmv_light_lds_bytes(uint32_t max_block_rows) { return ((max_block_rows + 1) * kAccumulatorBytes + 15u) & ~15u; }
 uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t format) {
-    if (format == kFormatSweep) return spmv_sweep_lds_bytes(max_block_rows);
     const uint32_t acc = (format == kFormatOwner || format == kFormatOwner24) ? (max_block_rows + kConsumerWaves) * kOwnerAccumulatorBytes : (max_block_rows + 1) * kAccumulatorBytes;
     return ((acc + 15u) & ~15u) + ring_buffers * kBufBytes;
 }

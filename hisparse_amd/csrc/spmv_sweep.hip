@@ -57,6 +57,41 @@ __device__ __forceinline__ void sweep_take(uint32_t& value, uint32_t& where, uin
                  : "=v"(value), "=v"(where), "=v"(xv) : "n"(2 * K), "n"(2 * K + 1), "n"(16 + K), "n"(2 * (kSweepDepth - 1)) : "memory");
 }
 
+// Row accumulators.  Float: doubles, ds_add_f64 (ds_add_f32 runs at a ninth of its rate on this part, stream_tiles.h) -- 8 bytes per row.
+// Fixed point: 4 bytes per row.  The saturating sum of unsigned products is min(exact sum, 2^32 - 1), so a wrapping 32-bit sum plus ONE BIT
+// "a carry happened" is exact: ds_add_rtn_u32 returns the old value, old + p < old is the carry, and the (rare) carry sets the row's bit in a
+// bitmap behind the accumulators with ds_or_b32.  Twice the rows per block of the 8-byte form = half the row ranges = half the lines of x
+// gathered per SpMV (sweep_tiles.cpp), which is what the format's cost is made of.  A wavefront takes a step every ~1 400 clocks: the LDS
+// round trip of the returning atomic is nowhere near its critical path.
+template <bool kFloat>
+struct SweepRows;
+template <>
+struct SweepRows<true> {
+    using acc_t = double;
+    static __device__ __forceinline__ uint32_t lds_words(uint32_t nrows) { return (nrows + 1) * 2; }
+    static __device__ __forceinline__ void add(uint8_t* lds, uint32_t, uint32_t row, uint32_t value, uint32_t xv) {
+        atomicAdd(reinterpret_cast<double*>(lds) + row, static_cast<double>(__uint_as_float(value) * __uint_as_float(xv)));
+    }
+    static __device__ __forceinline__ uint32_t finish(const uint8_t* lds, uint32_t, uint32_t row) {
+        return __float_as_uint(static_cast<float>(reinterpret_cast<const double*>(lds)[row]));
+    }
+};
+template <>
+struct SweepRows<false> {
+    static __device__ __forceinline__ uint32_t flag_word0(uint32_t nrows) { return nrows + 1; }      // the carry bitmap starts behind the nrows + 1 sums
+    static __device__ __forceinline__ uint32_t lds_words(uint32_t nrows) { return nrows + 1 + (nrows + 32) / 32; }
+    static __device__ __forceinline__ void add(uint8_t* lds, uint32_t nrows, uint32_t row, uint32_t value, uint32_t xv) {
+        uint32_t* acc = reinterpret_cast<uint32_t*>(lds);
+        const uint32_t p = q8_24_mul(value, xv);
+        const uint32_t old = atomicAdd(acc + row, p);                                             // ds_add_rtn_u32
+        if (old + p < old) atomicOr(acc + flag_word0(nrows) + (row >> 5), 1u << (row & 31u));    // AP_SAT (pe.h:72): once beyond 2^32 - 1, always
+    }
+    static __device__ __forceinline__ uint32_t finish(const uint8_t* lds, uint32_t nrows, uint32_t row) {
+        const uint32_t* acc = reinterpret_cast<const uint32_t*>(lds);
+        return ((acc[flag_word0(nrows) + (row >> 5)] >> (row & 31u)) & 1u) ? 0xffffffffu : acc[row];
+    }
+};
+
 struct SweepLane {
     uint32_t value[kSweepDepth], row[kSweepDepth];      // the elements whose x words are on their way
 };
@@ -64,16 +99,19 @@ struct SweepLane {
 // Step s of a wavefront (ring slot K = s % 8).  In flight on entry, oldest first: gather(s - 8), chunk(s), gather(s - 7), chunk(s + 1), ...
 // Waiting until 14 loads are left means chunk(s) and the gather before it have landed: add the element taken at step s - 8 (its x word
 // has just arrived), keep chunk(s)'s element, ask for ITS x word and for chunk(s + 8).
-template <bool kFloat, int K>
+// kAblate (libhisparse_hip_prof.so only, WRONG results): 1 = no LDS accumulation, 2 = the gather reads one line near the chunk's base
+// instead of the elements' columns (keeps the wait count)
+template <bool kFloat, int kAblate, int K>
 __device__ __forceinline__ void sweep_step(SweepLane& st, const uint8_t* stream, const uint8_t* x, uint32_t s, uint32_t steps, uint32_t lane_off, uint32_t base,
-                                           typename Rows<kFloat>::acc_t* ys) {
-    using R = Rows<kFloat>;
+                                           uint8_t* ys, uint32_t nrows) {
     uint32_t value, where, xv;
     sweep_take<K>(value, where, xv);
-    R::add(ys, st.row[K], R::product(st.value[K], xv));      // (the first eight steps add 0 x x[0] to the spare accumulator)
+    if (!(kAblate & 1)) SweepRows<kFloat>::add(ys, nrows, st.row[K], st.value[K], xv);      // (the first eight steps add 0 x x[..] to the spare accumulator)
+    else asm volatile("" ::"v"(xv), "v"(st.value[K]), "v"(st.row[K]));
     st.value[K] = value;
     st.row[K] = where >> 16;
-    sweep_issue_gather<K>(x, (base + (where & 0xffffu)) * 4u);
+    if (!(kAblate & 2)) sweep_issue_gather<K>(x, (base + (where & 0xffffu)) * 4u);
+    else sweep_issue_gather<K>(x, (base * 4u & ~127u) + (lane_off >> 1 & 127u));
     sweep_issue_chunk<K>(stream, min(s + kSweepDepth, steps - 1) * (kSweepWaves * kChunkBytes) + lane_off);
 }
 
@@ -83,20 +121,19 @@ __device__ __forceinline__ void sweep_prime(std::integer_sequence<int, Ks...>, c
     ((sweep_issue_gather<Ks>(x, pad_col * 4u), sweep_issue_chunk<Ks>(stream, min(uint32_t(Ks), steps - 1) * (kSweepWaves * kChunkBytes) + lane_off)), ...);
 }
 // one round of eight steps; steps at or beyond `end` are skipped (wave-uniform)
-template <bool kFloat, int... Ks>
+template <bool kFloat, int kAblate, int... Ks>
 __device__ __forceinline__ void sweep_round(std::integer_sequence<int, Ks...>, SweepLane& st, const uint8_t* stream, const uint8_t* x, uint32_t s0, uint32_t steps,
-                                            uint32_t end, uint32_t lane_off, const uint32_t (&b)[kSweepDepth], typename Rows<kFloat>::acc_t* ys) {
-    ((s0 + Ks < end ? sweep_step<kFloat, Ks>(st, stream, x, s0 + Ks, steps, lane_off, b[Ks], ys) : (void)0), ...);
+                                            uint32_t end, uint32_t lane_off, const uint32_t (&b)[kSweepDepth], uint8_t* ys, uint32_t nrows) {
+    ((s0 + Ks < end ? sweep_step<kFloat, kAblate, Ks>(st, stream, x, s0 + Ks, steps, lane_off, b[Ks], ys, nrows) : (void)0), ...);
 }
 
-template <bool kFloat>
+template <bool kFloat, int kAblate>
 __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
                                                                   int32_t row_part_filter, const uint32_t* __restrict__ part_heads) {
-    using R = Rows<kFloat>;
-    using acc_t = typename R::acc_t;
+    using R = SweepRows<kFloat>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    acc_t* ys = reinterpret_cast<acc_t*>(lds);                    // [nrows + 1]
+    uint8_t* ys = lds;                                            // nrows + 1 sums (+ the carry bitmap in fixed point)
     const uint32_t tid = threadIdx.x, lane = tid & (kWaveLanes - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWaveLanes);
     uint32_t wg = blockIdx.x;
@@ -122,7 +159,7 @@ __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t
         if (steps) sweep_prime(std::make_integer_sequence<int, kSweepDepth>(), stream, xs, pad_col, steps, lane_off);
         if (!first_block) __syncthreads();                        // the previous block's store has read the accumulators
         first_block = false;
-        for (uint32_t i = tid; i <= nrows; i += kSweepThreads) ys[i] = 0;
+        for (uint32_t i = tid, n = R::lds_words(nrows); i < n; i += kSweepThreads) reinterpret_cast<uint32_t*>(ys)[i] = 0;
         __syncthreads();
         if (steps) {
             const uint32_t last = steps - 1;
@@ -135,38 +172,57 @@ __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t
                 uint32_t nb[kSweepDepth];
 #pragma unroll
                 for (int k = 0; k < kSweepDepth; ++k) nb[k] = bases[min(s0 + kSweepDepth + k, last)];
-                sweep_round<kFloat>(std::make_integer_sequence<int, kSweepDepth>(), st, stream, xs, s0, steps, steps + kSweepDepth, lane_off, b, ys);
+                sweep_round<kFloat, kAblate>(std::make_integer_sequence<int, kSweepDepth>(), st, stream, xs, s0, steps, steps + kSweepDepth, lane_off, b, ys, nrows);
 #pragma unroll
                 for (int k = 0; k < kSweepDepth; ++k) b[k] = nb[k];
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory", HS_SWEEP_RING);
         }
         // no-return LDS atomics can outlive lgkmcnt(0) (spmv_rowblock_kernel): a returning one on the spare accumulator, awaited, cannot
-        const acc_t flushed = atomicAdd(ys + nrows, static_cast<acc_t>(0));
+        const uint32_t flushed = atomicOr(reinterpret_cast<uint32_t*>(ys) + R::lds_words(nrows) - 1, 0u);
         asm volatile("" ::"v"(flushed));
         __syncthreads();
-        for (uint32_t i = tid; i < nrows; i += kSweepThreads) out[out0 + i] = R::finish(ys[i]);
+        for (uint32_t i = tid; i < nrows; i += kSweepThreads) out[out0 + i] = R::finish(ys, nrows, i);
         if (!next) break;
     }
 }
 
 }  // namespace
 
-uint32_t spmv_sweep_lds_bytes(uint32_t max_block_rows) { return ((max_block_rows + 1) * kAccumulatorBytes + 15u) & ~15u; }
+uint32_t spmv_sweep_lds_bytes(uint32_t max_block_rows, bool is_float) {
+    const uint32_t words = is_float ? (max_block_rows + 1) * 2 : max_block_rows + 1 + (max_block_rows + 32) / 32;      // == SweepRows<>::lds_words
+    return (words * 4u + 15u) & ~15u;
+}
+
+#ifdef HISPARSE_PROFILING
+#define HS_FOR_EACH_SWEEP_VARIANT(X) X(0) X(1) X(2) X(3)
+#else
+#define HS_FOR_EACH_SWEEP_VARIANT(X) X(0)
+#endif
 
 hipError_t configure_sweep_kernels(uint32_t lds_bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_sweep_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_sweep_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    hipError_t e;
+#define X(A)                                                                                                                                         \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_sweep_kernel<false, A>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes))) != hipSuccess) return e; \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_sweep_kernel<true, A>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes))) != hipSuccess) return e;
+    HS_FOR_EACH_SWEEP_VARIANT(X)
+#undef X
+    return hipSuccess;
 }
 
 hipError_t launch_spmv_sweep(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     int ablate = 0, depth = 8;
-    if (!profiling_switches(ablate, depth) || ablate != 0) return hipErrorInvalidValue;      // no profiling builds of this kernel
+    if (!profiling_switches(ablate, depth)) return hipErrorInvalidValue;
     const dim3 grid(a.num_workgroups), block(kSweepThreads);
-    if (is_float) hipLaunchKernelGGL(spmv_sweep_kernel<true>, grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads);
-    else hipLaunchKernelGGL(spmv_sweep_kernel<false>, grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads);
-    return hipGetLastError();
+#define X(A)                                                                                                                                         \
+    if (ablate == A) {                                                                                                                               \
+        if (is_float) hipLaunchKernelGGL((spmv_sweep_kernel<true, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads); \
+        else hipLaunchKernelGGL((spmv_sweep_kernel<false, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads);       \
+        return hipGetLastError();                                                                                                                    \
+    }
+    HS_FOR_EACH_SWEEP_VARIANT(X)
+#undef X
+    return hipErrorInvalidValue;      // no such profiling build of this kernel
 }
 
 }  // namespace dev

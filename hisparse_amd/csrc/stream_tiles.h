@@ -177,12 +177,14 @@ constexpr uint32_t kLightMinBlockNnz = 1024;                  // no block smalle
 // of a block belongs to step k / 16 of wavefront k % 16, so the 16 wavefronts of the workgroup sweep the slice's columns together, once,
 // left to right.  The chunk bases (absolute column of the chunk's first element) sit in a table per block, [wavefront][step].  x[column] is
 // a per-lane global load (x is L2 / Infinity-Cache resident; column order makes the 64 lanes of one gather touch a handful of 128-byte lines),
-// products go to 8-byte LDS accumulators with atomics: no units, no x refills, no barriers between a block's prologue and epilogue.
+// products go to LDS accumulators with atomics (doubles; fixed point: 32-bit sums + a carry bit): no units, no x refills, no barriers between a block's prologue and epilogue.
 // Padding slots (the tail of a block's last step, and a chunk cut short because the next column lies more than 65535 beyond its base): value 0,
 // local_row = nrows (the spare accumulator), offset 0.  kernel: spmv_sweep.hip; builder: sweep_tiles.cpp; tools/gather_bench.hip is the
 // block-level measurement it was designed from.
 constexpr uint32_t kSweepWaves = 16;                          // all wavefronts stream (no loaders)
-constexpr uint32_t kSweepMaxBlockRows = kMaxLdsBytes / kAccumulatorBytes - 1;   // 20479: the LDS holds nothing but accumulators
+// the LDS holds nothing but accumulators: doubles in the float modes; fixed point: a wrapping 32-bit sum + a carry bit per row (spmv_sweep.hip)
+constexpr uint32_t kSweepMaxBlockRowsFloat = kMaxLdsBytes / kAccumulatorBytes - 1;                // 20479
+constexpr uint32_t kSweepMaxBlockRowsFixed = (kMaxLdsBytes / 4 - 2) * 32 / 33 - 1;                // 39716: (rows + 1) x 4 bytes + (rows + 32) / 32 x 4 bytes <= 160 KiB
 constexpr uint32_t kSweepColAlign = 32;                       // slices start on a 128-byte line of x
 // Chosen (unforced) for matrices sparser than this -- mean position gap rows x cols / nnz; OWNER24 pays per (row range x sub-tile) unit whatever
 // the unit holds, SWEEP per element and per line of x.  Measured on power-law squares of 1.0 / 1.6 / 2.4 M rows (tools/probe_sweep.py,

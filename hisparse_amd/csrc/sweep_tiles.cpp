@@ -28,9 +28,13 @@ using namespace detail;
 
 namespace {
 
-// cost of a block in ns on one CU (tools/gather_bench.hip): 8 bytes per element at ~20 GB/s per CU, and a gathered 128-byte line of x
-// every ~3.3 clocks
-constexpr double kSweepNsPerElement = 0.39, kSweepNsPerLine = 1.36;
+// cost of a block in ns on one CU (tools/gather_bench.hip, then fitted to pokec and ogbn-products: 73 / 210 us of kernel): 8 bytes per
+// element at ~24 GB/s per CU, a gathered 128-byte line of x every ~3.3 clocks, ~10 us per block for launch ramp, prologue, epilogue and the
+// spread between blocks; the combine pass as measured on 5- and 7-slice plans (9.4 / 8.5 us)
+// Round 4, profiling builds on the real matrices (profiles/r04_sweep_ablations.txt): the gathers cost pokec 23 us with 20 K-row blocks and 11 us
+// with 40 K-row blocks (per line), ogbn-products 38 us either way -- a floor of ~12 clocks per gather instruction, 0.085 ns per element; and
+// every slice is another rows x 4 bytes of partial sums written by the kernel and read back by the combine pass (~4 TB/s + ~8 TB/s).
+constexpr double kSweepNsPerElement = 0.33, kSweepNsPerLine = 1.36, kSweepGatherNsPerElement = 0.085, kSweepBlockUs = 10.0;
 
 struct Placed { uint64_t key; uint32_t value; };      // key = column << 16 | local row
 
@@ -93,7 +97,7 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
     // Every block gathers each 128-byte line of its slice of x about once, so the lines through the chip are (row ranges x |x| / 128)
     // whatever the slice count; slices exist to fill the CUs when the LDS row cap allows fewer row ranges than there are workgroups,
     // at the price of the combine pass (same model as stream_tiles.cpp).
-    uint32_t max_rows = kSweepMaxBlockRows;
+    uint32_t max_rows = L.g->impl == IMPL_FIXED ? kSweepMaxBlockRowsFixed : kSweepMaxBlockRowsFloat;
     if (const char* force = env_switch("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force)));
     uint64_t by_cap = 0;
     for (uint32_t rp = 0; rp < RP; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + max_rows - 1) / max_rows;
@@ -110,9 +114,9 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
             const uint64_t rounds = std::max<uint64_t>(1, (by_cap + per_round - 1) / per_round);
             const uint64_t ranges = std::min<uint64_t>(per_round * rounds, std::max<uint64_t>(by_cap, std::max<uint64_t>(1, nnz / 4096)));
             const double blocks = double(ranges) * cs, blocks_per_wg = std::ceil(blocks / G);
-            const double block_ns = double(nnz) / blocks * kSweepNsPerElement + double(lines) / cs * kSweepNsPerLine;
-            const double combine_us = cs > 1 ? 3.5 + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
-            const double cost = blocks_per_wg * (block_ns * 1e-3 + 6.0) + combine_us;
+            const double block_ns = double(nnz) / blocks * kSweepNsPerElement + std::max(double(lines) / cs * kSweepNsPerLine, double(nnz) / blocks * kSweepGatherNsPerElement);
+            const double combine_us = double(num_rows) * 4.0 * cs / 4e6 + (cs > 1 ? 2.0 + double(num_rows) * 4.0 * (cs + 1) / 8e6 : 0.0);
+            const double cost = blocks_per_wg * (block_ns * 1e-3 + kSweepBlockUs) + combine_us;
             if (env_switch("HISPARSE_PLAN_DEBUG")) std::fprintf(stderr, "sweep plan cs %u: ranges %llu block %.1f us combine %.1f => %.1f us\n", cs, (unsigned long long)ranges, block_ns * 1e-3, combine_us, cost);
             if (cost < best) { best = cost; slices = cs; want_ranges = ranges; }
         }

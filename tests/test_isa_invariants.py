@@ -111,7 +111,7 @@ def _hot_kernels(names):
             hot.append(n)
         elif "spmv_bitmap_kernel" in n and re.search(r"spmv_bitmap_kernelILb[01]ELi0E", n):
             hot.append(n)
-        elif "combine_slices_kernel" in n:
+        elif "combine_slices_kernel" in n or "spmv_sweep_kernel" in n or "spmv_light_kernel" in n:
             hot.append(n)
     return hot
 
@@ -156,6 +156,41 @@ def test_element_ring_lives_in_accumulator_registers_behind_counted_waits(shippe
         assert loads and reads, f"{n}: no ring found ({loads} loads, {reads} reads)"
 
 
+def test_sweep_ring_holds_chunks_and_gathers_behind_one_counted_wait(shipped):
+    """spmv_sweep_kernel (spmv_sweep.hip): eight chunks (a0..a15, dwordx2, nt) and eight gathers of x (a16..a23, dword) per wavefront in
+    accumulator registers the compiler allocates none of; every ring load behind `s_nop 4`; a step's three parked registers read behind
+    ONE counted wait that leaves the 14 younger loads in flight; LDS atomics for the row sums, no x staging (no LDS-DMA)."""
+    meta, code = shipped
+    names = [n for n in meta if "spmv_sweep_kernel" in n]
+    assert len(names) == 2, names      # fixed point and float
+    for n in names:
+        assert meta[n]["agpr_count"] == 24 and meta[n].get("private_segment_fixed_size", 0) == 0
+        body = code[n]
+        chunks = gathers = reads = 0
+        for k, ins in enumerate(body):
+            if not AGPR.search(ins.split(" ", 1)[1] if " " in ins else ""):
+                continue
+            prev = body[k - 1] if k else ""
+            if ins.startswith("global_load_dwordx2"):
+                chunks += 1
+                assert prev == "s_nop 4" and ins.endswith(" nt"), f"{n}: `{ins}` after `{prev}`"
+            elif ins.startswith("global_load_dword "):
+                gathers += 1
+                assert prev == "s_nop 4" and not ins.endswith(" nt"), f"{n}: `{ins}` after `{prev}`"      # x is meant to stay in L2
+            elif ins.startswith("v_accvgpr_read_b32"):
+                reads += 1
+                assert prev == "s_waitcnt vmcnt(14)" or prev.startswith("v_accvgpr_read_b32"), f"{n}: `{ins}` follows `{prev}`"
+            else:
+                raise AssertionError(f"{n}: `{ins}` touches an accumulator register outside the hand-written ring")
+        assert chunks >= 16 and gathers >= 16 and reads == 3 * 8, (n, chunks, gathers, reads)      # prime + steady state; 8 steps x 3 registers
+        # float: double sums; fixed point: wrapping 32-bit sums whose returned old value gives the carry, and a carry bit per row
+        if "ILb1E" in n:
+            assert any(i.startswith("ds_add_f64") for i in body)
+        else:
+            assert any(i.startswith("ds_add_rtn_u32") for i in body) and any(i.startswith("ds_or_b32") for i in body)
+        assert not any("global_load_lds" in i for i in body)
+
+
 def test_stream_loads_are_non_temporal_and_loaders_use_lds_dma(shipped):
     meta, code = shipped
     for n in meta:
@@ -195,6 +230,8 @@ def test_product_library_carries_no_profiling_instantiation(shipped):
     assert bitmap and all(int(m.group(2)) == 0 for m in bitmap)
     light = [re.search(r"spmv_light_kernelILb([01])ELi(\d+)E", n) for n in meta if "spmv_light_kernel" in n]
     assert all(m is None or int(m.group(2)) == 0 for m in light)
+    sweep = [re.search(r"spmv_sweep_kernelILb([01])ELi(\d+)E", n) for n in meta if "spmv_sweep_kernel" in n]
+    assert len(sweep) == 2 and all(int(m.group(2)) == 0 for m in sweep)
 
 
 def test_product_library_refuses_profiling_switches():

@@ -248,8 +248,8 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
             if row_part_filter >= 0 and int(blk["row_part"]) != row_part_filter:
                 continue
             nrows, row0, out0 = int(blk["nrows"]), int(blk["row0"]), int(blk["out_offset"])
-            if sweep:
-                assert (nrows + 1) * 8 <= 160 * 1024                                                 # the LDS holds the accumulators and nothing else
+            if sweep:      # the LDS holds the accumulators and nothing else: doubles / 32-bit sums + a carry bit per row
+                assert ((nrows + 1) * 8 if is_float else (nrows + 1) * 4 + (nrows + 32) // 32 * 4) <= 160 * 1024
             elif owner:
                 assert (nrows + CONSUMERS) * 4 + tiles["ring_buffers"] * 32768 <= 160 * 1024     # float accumulators + the x ring
             else:

@@ -20,6 +20,41 @@ __global__ __launch_bounds__(1024) void k(uint32_t iters, T* sink) {
     if (threadIdx.x == 0) sink[blockIdx.x] = acc[0];
 }
 
+// round 4 (SWEEP's fixed-point accumulators): a RETURNING 32-bit add whose old value gives the carry, + the rare ds_or_b32 of a carry bit
+template <int kRows, int kMode>      // 0: returning add, result unused late; 1: + carry check and ds_or_b32; 2: carry check deferred by one iteration
+__global__ __launch_bounds__(1024) void k_rtn(uint32_t iters, uint32_t* sink) {
+    __shared__ uint32_t acc[kRows + kRows / 32];
+    for (uint32_t i = threadIdx.x; i < kRows + kRows / 32; i += 1024) acc[i] = 0;
+    __syncthreads();
+    uint32_t h = threadIdx.x * 2654435761u + blockIdx.x * 40503u, keep = 0, prev_old = 0, prev_v = 0, prev_row = 0;
+    for (uint32_t i = 0; i < iters; ++i) {
+        h = h * 1664525u + 1013904223u;
+        const uint32_t row = (h >> 8) % kRows, v = (h >> 3) | 1u;
+        const uint32_t old = atomicAdd(&acc[row], v);
+        if (kMode == 0) keep ^= old;
+        if (kMode == 1 && old + v < old) atomicOr(&acc[kRows + (row >> 5)], 1u << (row & 31u));
+        if (kMode == 2) {
+            if (prev_old + prev_v < prev_old) atomicOr(&acc[kRows + (prev_row >> 5)], 1u << (prev_row & 31u));
+            prev_old = old; prev_v = v; prev_row = row;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sink[blockIdx.x] = acc[0] ^ keep ^ prev_old;
+}
+template <int kMode>
+void run_rtn(const char* name) {
+    uint32_t* sink; hipMalloc(&sink, 256 * 4);
+    const uint32_t iters = 2000;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((k_rtn<8192, kMode>), dim3(256), dim3(1024), 0, 0, iters, sink);
+    hipEventRecord(a);
+    hipLaunchKernelGGL((k_rtn<8192, kMode>), dim3(256), dim3(1024), 0, 0, iters, sink);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double per_cu = double(iters) * 1024;
+    printf("%-26s %8.1f us  %6.2f ns per wave-instruction (64 lanes)  %5.2f lanes/clk/CU @2.4GHz\n", name, ms * 1e3, ms * 1e6 / (per_cu / 64), per_cu / (ms * 1e-3 * 2.4e9));
+}
+
 template <typename T>
 void run(const char* name) {
     T* sink; hipMalloc(&sink, 256 * sizeof(T));
@@ -39,5 +74,8 @@ int main() {
     run<unsigned long long>("u64");
     run<float>("f32");
     run<double>("f64");
+    run_rtn<0>("u32 rtn");
+    run_rtn<1>("u32 rtn + carry bit");
+    run_rtn<2>("u32 rtn + deferred carry");
     return 0;
 }
