@@ -280,7 +280,7 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         "spin_up_steps": spun,
         "gibps_reference_formula": round(8.0 * nnz / 2 ** 30 / (elapsed / steps), 2),
         "hbm_roofline_fraction_whole_job": round(value / HBM_PEAK_GBS, 4),
-        "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_light_kernel" if stats.get("light_kernel") else "spmv_rowblock_kernel",
+        "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_sweep_kernel" if stats["stream_format"] == 6 else "spmv_light_kernel" if stats.get("light_kernel") else "spmv_rowblock_kernel",
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "kernel_ms": round(kernel_ms, 5), "kernel_ms_from": kernel_ms_how, "kernel_ms_event_pairs": round(kernel_ms_pairs, 5),
                      "step_ms_two_events_around_K_launches": round(step_ms_region, 5),
@@ -926,7 +926,7 @@ def main_distributed(args, rank, local_rank, world):
             "exchange": {"pattern": args.gather, "bytes_per_rank_per_gather": int(chunk) * 4,
                          "ms_per_step_added": round((elapsed - compute_elapsed) / args.steps * 1e3, 5)},
             "exchange_push": push,
-            "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_rowblock_kernel", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_sweep_kernel" if stats["stream_format"] == 6 else "spmv_rowblock_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": int(8 * nnz), "streamed_bytes_per_launch": int(stats["stream_bytes"]), "traffic": None,
                          "note": "rank 0's slab"},

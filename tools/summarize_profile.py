@@ -6,7 +6,7 @@ import sqlite3
 import sys
 
 out = sys.argv[1]
-KERNELS = ("spmv_rowblock_kernel", "spmv_bitmap_kernel", "spmv_light_kernel")     # the dominant kernel is whichever of these the matrix's plan runs
+KERNELS = ("spmv_rowblock_kernel", "spmv_bitmap_kernel", "spmv_light_kernel", "spmv_sweep_kernel")     # the dominant kernel is whichever of these the matrix's plan runs
 summary = {}
 
 
