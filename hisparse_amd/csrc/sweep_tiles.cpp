@@ -264,9 +264,22 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
     timer.lap("sweep: write image");
 
     std::vector<std::vector<uint32_t>> mine;
-    if (slices > 1 && G % 8 == 0 && NB >= G) {      // an XCD works on one slice of x, two at most: its L2 holds it
+    bool by_slice = slices > 1 && G % 8 == 0 && RP == 1;
+    if (const char* force = env_switch("HISPARSE_XCD_AFFINITY")) by_slice = by_slice && std::atoi(force) != 0;
+    if (by_slice) {
+        // An XCD works on one slice of x, two at most, so that its L2 (4 MiB) holds what its workgroups gather: pokec's x is 6.5 MB, and with
+        // the blocks of all slices on every XCD the gathers that miss L2 show up as 80 MB of fabric traffic per SpMV.  The rule needs a block
+        // for every workgroup (the kernels map workgroup -> XCD by index): a plan of 255 blocks gets an idle one (no rows, no steps).
         std::vector<uint32_t> slice_of_block(NB);
         for (uint32_t bi = 0; bi < NB; ++bi) slice_of_block[bi] = bi % slices;
+        while (out.blocks.size() < G) {
+            Block idle{};
+            idle.row_part = 0;
+            idle.wave_offset[1] = stream_bytes;
+            out.blocks.push_back(idle);
+            slice_of_block.push_back(uint32_t(out.blocks.size()) % slices);
+            block_weight.push_back(0);
+        }
         assign_workgroups_by_slice(out, block_weight, G, RP, slice_of_block, mine);
     } else {
         assign_workgroups(out, block_weight, G, RP, mine);

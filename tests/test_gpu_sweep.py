@@ -1,0 +1,121 @@
+"""The SWEEP format (round 4; stream_tiles.h, sweep_tiles.cpp, spmv_sweep.hip): column-ordered blocks, x gathered from L2, no units.  Chosen
+automatically for very sparse matrices (mean position gap >= 60 K fixed / 70 K float, > 2 M non-zeros); here: the automatic choice at that
+scale against the oracle, the reference's partition loop and chains of blocks per workgroup, fixed-point saturation through the 4-byte sums
+with a carry bit, non-finite x, iterate / SpMM on top of the image, and the image byte for byte against the CPU build of the same library.
+(tests/test_gpu_parity.py runs its whole case list through the format as "sweep"; tests/test_sweep_cpu.py checks the image on the CPU.)"""
+import numpy as np
+import pytest
+
+from hisparse_amd import device, host
+from oracle import oracle as orc
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(cp, impl, xw):
+    return orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions,
+                    cp.ob_bank, cp.vb_bank)
+
+
+def _check(impl, got, want):
+    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+
+
+@pytest.fixture(autouse=True)
+def _clean(monkeypatch):
+    for k in ("HISPARSE_STREAM_FORMAT", "HISPARSE_SWEEP", "HISPARSE_LIGHT", "HISPARSE_MAX_ROWS", "HISPARSE_COL_SLICES", "HISPARSE_XCD_AFFINITY"):
+        monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2])
+def test_very_sparse_matrices_take_sweep_and_match_the_oracle(impl):
+    # 700 K x 700 K, 5 M non-zeros: mean position gap 98 K -> SWEEP by the planner's own rule, in every numeric mode; a denser one stays OWNER24
+    csr = host.CSRMatrix.generate("powerlaw", 700000, 700000, a=5.0e6, b=0.4, c=1.0 if impl == 0 else 2.0, seed=21 + impl)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 3, impl) * (30.0 if impl == 0 else 1.0))      # fixed point: hub rows saturate
+    want = _oracle(cp, impl, xw)
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix(cp)
+        st = eng.stats()
+        assert device.STREAM_FORMATS[st["stream_format"]] == "sweep", st
+        assert st["lds_bytes"] <= 160 * 1024 and st["num_units"] == 1
+        eng.load_vector(xw)
+        eng.run()
+        _check(impl, eng.read_result(), want)
+        eng.run()                                                # accumulators (and carry bits) are re-armed by every launch
+        _check(impl, eng.read_result(), want)
+        tiles = eng.read_tiles()
+    if impl == 0:
+        assert (want == 0xFFFFFFFF).any() and (want != 0xFFFFFFFF).any()
+    built = device.build_tiles(cp, impl, cp.ob_bank, cp.vb_bank, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, st["num_compute_units"])
+    assert built["image"].tobytes() == tiles["image"].tobytes() and built["blocks"].tobytes() == tiles["blocks"].tobytes()
+    denser = host.CSRMatrix.generate("powerlaw", 300000, 300000, a=3.0e6, b=0.4, c=1.0, seed=5)      # gap 30 K
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix_csr(denser)
+        assert device.STREAM_FORMATS[eng.stats()["stream_format"]] in ("owner24", "owner")
+
+
+@pytest.mark.parametrize("impl", [0, 2])
+@pytest.mark.parametrize("slices", ["1", "3"])
+def test_partition_loop_and_block_chains(impl, slices, monkeypatch):
+    # small banks: many row partitions (hs_run_partition enters a workgroup's chain at the partition's head); HISPARSE_MAX_ROWS=40: far more
+    # blocks than workgroups, so every workgroup walks a chain of them (the LDS sums are zeroed and stored once per block)
+    monkeypatch.setenv("HISPARSE_SWEEP", "1")
+    monkeypatch.setenv("HISPARSE_MAX_ROWS", "40")
+    monkeypatch.setenv("HISPARSE_COL_SLICES", slices)
+    m = cases.random_csr(30000, 700, 0.02, 5, impl)
+    _, cp = cases.formatted(m, impl, 16, 8 if impl == 2 else 2, True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 8, impl))
+    want = _oracle(cp, impl, xw)
+    with device.SpmvEngine(impl, ob_bank=cp.ob_bank, vb_bank=cp.vb_bank) as eng:
+        eng.load_matrix(cp)
+        st = eng.stats()
+        assert device.STREAM_FORMATS[st["stream_format"]] == "sweep" and st["num_blocks"] > st["num_workgroups"] and st["col_slices"] == int(slices)
+        eng.load_vector(xw)
+        eng.run()
+        _check(impl, eng.read_result(), want)
+        eng.load_vector(np.zeros_like(xw))
+        eng.run()
+        assert not eng.read_result().any()
+        eng.load_vector(xw)
+        for j in range(cp.num_row_partitions):                  # the reference's launch loop (sw/benchmark.cpp:318-338)
+            eng.run_partition(j, cp.part_len(j))
+        _check(impl, eng.read_result(), want)
+
+
+def test_non_finite_x_reaches_only_the_rows_that_hold_the_column(monkeypatch):
+    # padding slots carry value 0 at the block's spare row and gather a real x word: 0 x inf = NaN must never land in a real row
+    monkeypatch.setenv("HISPARSE_SWEEP", "1")
+    impl = 1
+    m = cases.random_csr(3000, 5000, 0.004, 2, impl)
+    cp = host.format_matrix(host.CSRMatrix.from_scipy(m), impl, skip_empty_rows=True)
+    x = cases.random_x(cp.num_cols, 4, impl)
+    x[0] = np.inf
+    x[4097] = np.nan
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix(cp)
+        assert device.STREAM_FORMATS[eng.stats()["stream_format"]] == "sweep"
+        eng.load_vector(host.pack_vector(impl, x))
+        eng.run()
+        got = eng.read_result().view(np.float32)[:3000]
+    touched = np.asarray((m[:, [0, 4097]] != 0).sum(axis=1)).ravel() > 0
+    assert np.isfinite(got[~touched]).all() and not np.isfinite(got[touched]).any()
+
+
+def test_spmm_runs_over_a_sweep_image(monkeypatch):
+    # hs_spmm runs one SpMV per column over formats without a fused kernel (hs_iterate on a sliced sweep image: tests/test_gpu_parity.py's
+    # PageRank test under the "sweep" fixture -- the feedback is folded into the slice-combine launch)
+    monkeypatch.setenv("HISPARSE_SWEEP", "1")
+    monkeypatch.setenv("HISPARSE_COL_SLICES", "2")
+    for impl in (0, 1):
+        m = cases.random_csr(4096, 4096, 0.003, 9, impl)
+        cp = host.format_matrix(host.CSRMatrix.from_scipy(m), impl, skip_empty_rows=True)
+        with device.SpmvEngine(impl) as eng:
+            eng.load_matrix(cp)
+            assert device.STREAM_FORMATS[eng.stats()["stream_format"]] == "sweep" and eng.stats()["col_slices"] == 2
+            X = np.stack([host.pack_vector(impl, cases.random_x(cp.num_cols, 20 + j, impl)) for j in range(3)])
+            Y = eng.spmm(X)
+            for j in range(3):
+                _check(impl, Y[j], _oracle(cp, impl, X[j]))
