@@ -76,6 +76,21 @@ class GpuTiler {
                      const std::vector<uint64_t>& row_value_base, uint64_t image_bytes, uint64_t slack_bytes, const std::vector<BitmapRun>& runs,
                      std::vector<uint32_t>& run_prefix, std::vector<uint64_t>& run_heads, const MfmaImage* mfma, bool& duplicates);
     uint8_t* release_mfma() { uint8_t* p = d_mfma_; d_mfma_ = nullptr; return p; }
+    // ---- SWEEP (sweep_tiles.cpp plans: row ranges, column slices, the layout of streams and chunk-base tables; what touches every non-zero is here) ----
+    // non-zeros per 128-byte line of x (32 columns): the slice boundaries are cut at equal modelled cost
+    bool sweep_line_counts(uint32_t lines, std::vector<uint64_t>& line_nnz);
+    // Every element keyed (block = range x slices + slice) << 48 | column << 16 | local row and radix-sorted; block b then holds the sorted
+    // elements [block_start[b], block_start[b + 1]).  unsupported = some (row, column) occurs twice (the host orders those by value word) or a
+    // 64-element chunk would span more than 65535 columns (the host cuts such chunks short): the caller builds on the host then.
+    bool sweep_sort(const std::vector<uint32_t>& range_of_row, const std::vector<uint32_t>& range_row0, const std::vector<uint32_t>& slice_col,
+                    uint32_t num_blocks, std::vector<uint64_t>& block_start, bool& unsupported);
+    struct SweepBlock {             // one (row range, column slice) as sweep_tiles.cpp lays it out
+        uint64_t first;             // its first sorted element
+        uint64_t stream_at, table_at;   // byte offsets of its chunks / its chunk-base table in the image
+        uint64_t chunk0;            // chunks of all blocks in front of it
+        uint32_t count, steps, nrows, pad_col;
+    };
+    bool sweep_emit(const std::vector<SweepBlock>& blocks, uint64_t image_bytes, uint64_t slack_bytes);
     // hands the device image over (hipFree by the new owner)
     uint8_t* release_image() { uint8_t* p = d_image_; d_image_ = nullptr; return p; }
 

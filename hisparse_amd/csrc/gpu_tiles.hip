@@ -1106,5 +1106,175 @@ bool GpuTiler::bitmap_emit(uint32_t slices, uint32_t GR, const std::vector<uint3
     return ok;
 }
 
+// ---- SWEEP (sweep_tiles.cpp; kernel: spmv_sweep.hip) ---------------------------------------------------------------------------
+namespace {
+
+struct SweepSlices { uint32_t n; uint32_t col[kMaxColSlices + 1]; };
+
+__global__ __launch_bounds__(256) void sweep_lines_kernel(ElementSource src, uint32_t* __restrict__ line_nnz, uint32_t* err) {
+    visit_elements(src, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, err, [&](uint32_t, uint32_t col, uint32_t) { atomicAdd(line_nnz + col / kSweepColAlign, 1u); });
+}
+
+// (the order the elements arrive in does not matter: the sort key is the element's complete identity -- two equal keys are a duplicate entry,
+// which the host builder takes)
+__global__ __launch_bounds__(256) void sweep_keys_kernel(ElementSource src, const uint32_t* __restrict__ range_of_row, const uint32_t* __restrict__ range_row0,
+                                                        SweepSlices slices, unsigned long long* cursor, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                        uint32_t* err) {
+    visit_elements(src, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, err, [&](uint32_t row, uint32_t col, uint32_t val) {
+        const uint32_t range = range_of_row[row];
+        uint32_t k = 0;
+        while (k + 1 < slices.n && col >= slices.col[k + 1]) ++k;
+        const uint64_t at = atomicAdd(cursor, 1ull);
+        keys[at] = (uint64_t(range) * slices.n + k) << 48 | uint64_t(col) << 16 | (row - range_row0[range]);
+        vals[at] = val;
+    });
+}
+
+__global__ __launch_bounds__(256) void sweep_starts_kernel(const uint64_t* __restrict__ keys, uint64_t n, unsigned long long* __restrict__ block_start, uint32_t* flags) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t b = keys[i] >> 48;
+    if (i == 0 || (keys[i - 1] >> 48) != b) block_start[b] = i;
+    if (i + 1 < n && keys[i] == keys[i + 1]) flags[0] = 1u;
+}
+
+__global__ __launch_bounds__(256) void sweep_spans_kernel(const uint64_t* __restrict__ keys, uint64_t n, const unsigned long long* __restrict__ block_start, uint32_t* flags) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t first = block_start[keys[i] >> 48], chunk_first = i - (i - first) % kWaveLanes;
+    if (((keys[i] >> 16) & 0xffffffffull) - ((keys[chunk_first] >> 16) & 0xffffffffull) > 0xffffull) flags[1] = 1u;
+}
+
+// one thread per element slot of the image: chunk c of all blocks' chunks, lane l
+__global__ __launch_bounds__(256) void sweep_emit_kernel(const GpuTiler::SweepBlock* __restrict__ blocks, uint32_t num_blocks, uint64_t total_chunks,
+                                                        const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint8_t* __restrict__ image) {
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, c = t / kWaveLanes;
+    const uint32_t lane = uint32_t(t % kWaveLanes);
+    if (c >= total_chunks) return;
+    uint32_t lo = 0, hi = num_blocks;              // the last block with chunk0 <= c (blocks without chunks share their successor's chunk0: skipped by the search)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (blocks[mid].chunk0 <= c) lo = mid; else hi = mid;
+    }
+    const GpuTiler::SweepBlock& b = blocks[lo];
+    const uint32_t k = uint32_t(c - b.chunk0), s = k / kSweepWaves, w = k % kSweepWaves;
+    const uint64_t first = uint64_t(k) * kWaveLanes;
+    const uint32_t base = first < b.count ? uint32_t(keys[b.first + first] >> 16) : b.count ? uint32_t(keys[b.first + b.count - 1] >> 16) : b.pad_col;
+    uint32_t* slot = reinterpret_cast<uint32_t*>(image + b.stream_at + uint64_t(k) * kChunkBytes) + 2 * lane;
+    if (first + lane < b.count) {
+        const uint64_t key = keys[b.first + first + lane];
+        slot[0] = vals[b.first + first + lane];
+        slot[1] = uint32_t(key & 0xffffu) << 16 | (uint32_t(key >> 16) - base);
+    } else {
+        slot[0] = 0u;
+        slot[1] = b.nrows << 16;
+    }
+    if (lane == 0) reinterpret_cast<uint32_t*>(image + b.table_at)[size_t(w) * b.steps + s] = base;
+}
+
+}  // namespace
+
+bool GpuTiler::sweep_line_counts(uint32_t lines, std::vector<uint64_t>& line_nnz) {
+    ElementSource src{d_channels_, static_cast<const StreamGroup*>(d_groups_), d_advance_, d_indptr_, d_indices_, d_values_, total_, num_groups_, total_slots_,
+                      L_.num_rows, csr_ ? csr_->num_cols : L_.num_cols, uint32_t(geom_.logical_vb), uint32_t(geom_.impl == IMPL_FIXED), csr_ ? 1u : 0u};
+    const uint64_t threads = csr_ ? (total_ + kCsrSegment - 1) / kCsrSegment : total_slots_;
+    uint32_t* d_cnt = nullptr;
+    std::vector<uint32_t> cnt(lines, 0);
+    bool ok = check(hipMalloc(reinterpret_cast<void**>(&d_cnt), std::max<size_t>(size_t(lines) * 4, 16)), "hipMalloc(line counts)") &&
+              check(hipMemsetAsync(d_cnt, 0, std::max<size_t>(size_t(lines) * 4, 16), stream_), "hipMemset");
+    if (ok && threads) {
+        hipLaunchKernelGGL(sweep_lines_kernel, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, stream_, src, d_cnt, d_scalar_);
+        ok = check(hipGetLastError(), "sweep_lines_kernel");
+    }
+    uint32_t errw[3] = {0, 0, 0};
+    ok = ok && check(hipMemcpyAsync(cnt.data(), d_cnt, size_t(lines) * 4, hipMemcpyDeviceToHost, stream_), "read line counts") &&
+         check(hipMemcpyAsync(errw, d_scalar_, 12, hipMemcpyDeviceToHost, stream_), "read flags") && check(hipStreamSynchronize(stream_), "sweep line counts");
+    if (ok && errw[0]) ok = fail("CSR row " + std::to_string(uint64_t(errw[1]) * PACK_SIZE + errw[2]) + ": column index outside the matrix");
+    if (d_cnt) (void)hipFree(d_cnt);
+    line_nnz.assign(cnt.begin(), cnt.end());
+    return ok;
+}
+
+bool GpuTiler::sweep_sort(const std::vector<uint32_t>& range_of_row, const std::vector<uint32_t>& range_row0, const std::vector<uint32_t>& slice_col,
+                          uint32_t num_blocks, std::vector<uint64_t>& block_start, bool& unsupported) {
+    detail::PhaseTimer timer;
+    unsupported = false;
+    ElementSource src{d_channels_, static_cast<const StreamGroup*>(d_groups_), d_advance_, d_indptr_, d_indices_, d_values_, total_, num_groups_, total_slots_,
+                      L_.num_rows, csr_ ? csr_->num_cols : L_.num_cols, uint32_t(geom_.logical_vb), uint32_t(geom_.impl == IMPL_FIXED), csr_ ? 1u : 0u};
+    const uint64_t threads = csr_ ? (total_ + kCsrSegment - 1) / kCsrSegment : total_slots_;
+    SweepSlices sl{};
+    sl.n = uint32_t(slice_col.size()) - 1;
+    for (uint32_t k = 0; k <= sl.n; ++k) sl.col[k] = slice_col[k];
+    const size_t n = std::max<uint64_t>(total_, 1);
+    uint32_t *d_range = nullptr, *d_row0 = nullptr, *d_vals_in = nullptr, *d_flags = nullptr;
+    uint64_t* d_keys_in = nullptr;
+    unsigned long long *d_cursor = nullptr, *d_start = nullptr;
+    void* d_temp = nullptr;
+    bool ok = check(upload(&d_range, range_of_row, stream_), "upload row ranges") && check(upload(&d_row0, range_row0, stream_), "upload range rows") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_keys_in), n * 8), "hipMalloc(keys)") && check(hipMalloc(reinterpret_cast<void**>(&d_vals_in), n * 4), "hipMalloc(values)") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_keys_), n * 8), "hipMalloc(keys)") && check(hipMalloc(reinterpret_cast<void**>(&d_vals_), n * 4), "hipMalloc(values)") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_cursor), 8), "hipMalloc") && check(hipMemsetAsync(d_cursor, 0, 8, stream_), "hipMemset") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_flags), 16), "hipMalloc") && check(hipMemsetAsync(d_flags, 0, 16, stream_), "hipMemset") &&
+              check(hipMalloc(reinterpret_cast<void**>(&d_start), (size_t(num_blocks) + 1) * 8), "hipMalloc(block starts)") &&
+              check(hipMemsetAsync(d_start, 0xff, (size_t(num_blocks) + 1) * 8, stream_), "hipMemset");
+    if (ok && threads) {
+        hipLaunchKernelGGL(sweep_keys_kernel, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, stream_, src, d_range, d_row0, sl, d_cursor, d_keys_in, d_vals_in, d_scalar_);
+        ok = check(hipGetLastError(), "sweep_keys_kernel");
+    }
+    if (timer.on) { (void)hipStreamSynchronize(stream_); timer.lap("gpu: sweep keys"); }
+    if (ok && total_) {
+        uint32_t block_bits = 1;
+        while ((uint64_t(1) << block_bits) < num_blocks) ++block_bits;
+        size_t temp_bytes = 0;
+        const int end_bit = int(48 + block_bits);
+        ok = end_bit <= 64 && check(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_keys_in, d_keys_, d_vals_in, d_vals_, total_, 0, end_bit, stream_), "radix sort (size)") &&
+             check(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)), "hipMalloc(sort)") &&
+             check(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys_in, d_keys_, d_vals_in, d_vals_, total_, 0, end_bit, stream_), "radix sort");
+        if (ok) {
+            const dim3 grid(uint32_t((total_ + 255) / 256));
+            hipLaunchKernelGGL(sweep_starts_kernel, grid, dim3(256), 0, stream_, d_keys_, total_, d_start, d_flags);
+            hipLaunchKernelGGL(sweep_spans_kernel, grid, dim3(256), 0, stream_, d_keys_, total_, d_start, d_flags);
+            ok = check(hipGetLastError(), "sweep_starts_kernel");
+        }
+    }
+    std::vector<unsigned long long> starts(size_t(num_blocks) + 1, ~0ull);
+    uint32_t flags[4] = {0, 0, 0, 0};
+    unsigned long long placed = 0;
+    ok = ok && check(hipMemcpyAsync(starts.data(), d_start, starts.size() * 8, hipMemcpyDeviceToHost, stream_), "read block starts") &&
+         check(hipMemcpyAsync(flags, d_flags, 16, hipMemcpyDeviceToHost, stream_), "read flags") &&
+         check(hipMemcpyAsync(&placed, d_cursor, 8, hipMemcpyDeviceToHost, stream_), "read cursor") && check(hipStreamSynchronize(stream_), "sweep sort");
+    if (ok && placed != total_) ok = fail("gpu sweep: element count changed between passes");
+    timer.lap("gpu: sweep radix sort");
+    unsupported = ok && (flags[0] != 0 || flags[1] != 0);
+    block_start.assign(size_t(num_blocks) + 1, total_);
+    for (uint32_t b = num_blocks; b-- > 0;) block_start[b] = starts[b] == ~0ull ? block_start[b + 1] : starts[b];      // blocks without elements start where the next one does
+    for (void* p : {static_cast<void*>(d_range), static_cast<void*>(d_row0), static_cast<void*>(d_keys_in), static_cast<void*>(d_vals_in), static_cast<void*>(d_flags),
+                    static_cast<void*>(d_cursor), static_cast<void*>(d_start), d_temp})
+        if (p) (void)hipFree(p);
+    if (d_channels_) { (void)hipFree(d_channels_); d_channels_ = nullptr; }      // the source is not needed any more
+    for (void** p : {reinterpret_cast<void**>(&d_indptr_), reinterpret_cast<void**>(&d_indices_), reinterpret_cast<void**>(&d_values_)})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    return ok;
+}
+
+bool GpuTiler::sweep_emit(const std::vector<SweepBlock>& blocks, uint64_t image_bytes, uint64_t slack_bytes) {
+    detail::PhaseTimer timer;
+    const size_t bytes = std::max<uint64_t>(image_bytes + slack_bytes, 256);
+    const uint64_t total_chunks = blocks.empty() ? 0 : blocks.back().chunk0 + uint64_t(blocks.back().steps) * kSweepWaves;
+    SweepBlock* d_blocks = nullptr;
+    bool ok = check(hipMalloc(reinterpret_cast<void**>(&d_image_), bytes), "hipMalloc(image)") && check(upload(&d_blocks, blocks, stream_), "upload blocks");
+    if (ok && slack_bytes) ok = check(hipMemsetAsync(d_image_ + image_bytes, 0, slack_bytes, stream_), "hipMemset(slack)");
+    if (ok && total_chunks) {
+        hipLaunchKernelGGL(sweep_emit_kernel, dim3(uint32_t((total_chunks * kWaveLanes + 255) / 256)), dim3(256), 0, stream_, d_blocks, uint32_t(blocks.size()), total_chunks,
+                           d_keys_, d_vals_, d_image_);
+        ok = check(hipGetLastError(), "sweep_emit_kernel");
+    }
+    ok = ok && check(hipStreamSynchronize(stream_), "sweep emit");
+    timer.lap("gpu: sweep emit");
+    if (d_blocks) (void)hipFree(d_blocks);
+    if (!ok && d_image_) { (void)hipFree(d_image_); d_image_ = nullptr; }
+    return ok;
+}
+
 }  // namespace dev
 }  // namespace hisparse

@@ -154,7 +154,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             const uint64_t nnz_keep = out.nnz;
             out = StreamTiles();
             out.nnz = nnz_keep;
-            return build_sweep_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error, csr);
+            return build_sweep_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error, csr, gpu.get(), image_slack);
         }
     }
     // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse; hyper-sparse float matrices: OWNER --

@@ -7,8 +7,11 @@
 // profiles/r04_gather_bench.txt).  What replaces the FPGA's column partitions (spmv/libfpga/vecbuf_access_unit.h:66-72: the vector buffer
 // holds one partition of x at a time) is the column slice; what replaces its output buffer (pe.h:121-135) is the block's LDS accumulators.
 // The CPSR image is decoded once (tiles_common.h: the same walk as the other formats), the rows are put back into column order, every
-// block's elements are sorted by (column, row) and cut into chunks of 64.  Host threads only -- the device builder (gpu_tiles.hip) does not
-// know this format.
+// block's elements are sorted by (column, row) and cut into chunks of 64.  With a GpuTiler (gpu_tiles.h) the three things that touch every
+// non-zero -- the per-line counts behind the slice boundaries, the sort, the emit -- are kernels and the image never exists on the host; the
+// planning and the layout below are the same code for both, so the two leave the same bytes (tests/test_gpu_retile.py).  Two cases go to the
+// host loops even then: duplicate (row, column) entries (the host orders them by value word) and blocks whose columns lie so far apart that a
+// chunk must be cut short (more than 65535 columns inside 64 consecutive elements).
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -18,6 +21,7 @@
 #include <mutex>
 #include <numeric>
 
+#include "gpu_tiles.h"
 #include "hisparse/q8_24.h"
 #include "tiles_common.h"
 
@@ -41,19 +45,24 @@ struct Placed { uint64_t key; uint32_t value; };      // key = column << 16 | lo
 }  // namespace
 
 bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
-                       const std::vector<uint32_t>& row_nnz, uint32_t max_workgroups, StreamTiles& out, std::string& error, const CsrView* csr) {
+                       const std::vector<uint32_t>& row_nnz, uint32_t max_workgroups, StreamTiles& out, std::string& error, const CsrView* csr,
+                       GpuTiler* gpu, uint64_t image_slack) {
     const uint32_t num_rows = L.num_rows, num_cols = L.num_cols, RP = L.row_parts, CP = L.col_parts;
     const uint32_t G = std::max<uint32_t>(1, max_workgroups);
     auto chan = [&](uint32_t pc) { return static_cast<const MatPkt*>(channel[pc]); };
     if (uint64_t(num_cols) * 4 >= (1ull << 32)) { error = "sweep: x does not fit a 32-bit byte offset"; return false; }
     PhaseTimer timer;
 
-    // ---- rows back in CSR form: (absolute column, value word) per row, in column order -----------------------------------------
+    // ---- rows back in CSR form: (absolute column, value word) per row, in column order (host builder only) ------------------------
     std::vector<uint64_t> row_ptr(size_t(num_rows) + 1, 0);
     for (uint32_t r = 0; r < num_rows; ++r) row_ptr[r + 1] = row_ptr[r] + row_nnz[r];
     const uint64_t nnz = row_ptr[num_rows];
-    const std::unique_ptr<uint64_t[]> elems_buf(new uint64_t[std::max<uint64_t>(nnz, 1)]);
-    uint64_t* const elems = elems_buf.get();               // column << 32 | value word
+    std::unique_ptr<uint64_t[]> elems_buf;
+    uint64_t* elems = nullptr;                             // column << 32 | value word
+    auto rows_on_the_host = [&]() -> bool {
+    if (elems) return true;
+    elems_buf.reset(new uint64_t[std::max<uint64_t>(nnz, 1)]);
+    elems = elems_buf.get();
     if (csr) {              // value words as csr_matrix_convert_from_float gives them (sw/data_loader.h:76-84)
         const bool fixed = L.g->impl == IMPL_FIXED;
         std::atomic<bool> bad_column(false);
@@ -92,6 +101,9 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
         }
     });
     timer.lap("sweep: rows in column order");
+    return true;
+    };
+    if (!gpu && !rows_on_the_host()) return false;
 
     // ---- plan: row ranges x contiguous column slices ----------------------------------------------------------------------------
     // Every block gathers each 128-byte line of its slice of x about once, so the lines through the chip are (row ranges x |x| / 128)
@@ -131,6 +143,9 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
     std::vector<uint32_t> slice_col(slices + 1, 0);
     {
         std::vector<uint64_t> line_nnz(lines, 0);
+        if (gpu) {
+            if (!gpu->sweep_line_counts(lines, line_nnz)) { error = gpu->error(); return false; }
+        } else {
         std::mutex merge;
         const size_t pieces = std::max<size_t>(1, std::min<size_t>(64, num_rows / 1024));
         parallel_for(pieces, [&](size_t piece) {
@@ -140,6 +155,7 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
             std::lock_guard<std::mutex> lock(merge);
             for (uint32_t l = 0; l < lines; ++l) line_nnz[l] += mine[l];
         });
+        }
         std::vector<double> upto(lines + 1, 0.0);
         for (uint32_t l = 0; l < lines; ++l) upto[l + 1] = upto[l] + double(line_nnz[l]) / std::max<uint32_t>(1, NR) * kSweepNsPerElement + kSweepNsPerLine;
         uint32_t line_before = 0;
@@ -164,6 +180,22 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
     for (const RowRange& rg : ranges) out.max_block_rows = std::max(out.max_block_rows, rg.nrows);
     std::vector<std::vector<Placed>> sorted(NB);
     std::vector<std::vector<uint32_t>> chunk_first(NB);      // index of every chunk's first element (+ the end)
+    std::vector<uint64_t> block_start;                       // device builder: block bi = sorted elements [block_start[bi], block_start[bi + 1])
+    if (gpu && NB <= 65536) {
+        std::vector<uint32_t> range_of_row(num_rows), range_row0(NR);
+        for (uint32_t b = 0; b < NR; ++b) {
+            range_row0[b] = ranges[b].row0;
+            std::fill(range_of_row.begin() + ranges[b].row0, range_of_row.begin() + ranges[b].row0 + ranges[b].nrows, b);
+        }
+        bool unsupported = false;
+        if (!gpu->sweep_sort(range_of_row, range_row0, slice_col, NB, block_start, unsupported)) { error = gpu->error(); return false; }
+        if (unsupported) gpu = nullptr;
+        timer.lap("sweep: gpu sort");
+    } else {
+        gpu = nullptr;
+    }
+    if (!gpu) {
+    if (!rows_on_the_host()) return false;
     parallel_for(NB, [&](size_t bi) {
         const RowRange& rg = ranges[bi / slices];
         const uint64_t c0 = slice_col[bi % slices], c1 = slice_col[bi % slices + 1];
@@ -204,12 +236,13 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
         first.push_back(uint32_t(mine.size()));
     });
     timer.lap("sweep: sort blocks");
+    }
 
     std::vector<uint64_t> block_weight(NB, 0), stream_at(NB, 0), table_at(NB, 0);
     uint64_t stream_bytes = 0, table_bytes = 0;
     for (uint32_t bi = 0; bi < NB; ++bi) {
-        const uint32_t chunks = uint32_t(chunk_first[bi].size()) - 1;
-        const uint32_t steps = (chunks + kSweepWaves - 1) / kSweepWaves;
+        const uint64_t chunks = gpu ? (block_start[bi + 1] - block_start[bi] + kWaveLanes - 1) / kWaveLanes : chunk_first[bi].size() - 1;
+        const uint32_t steps = uint32_t(std::min<uint64_t>((chunks + kSweepWaves - 1) / kSweepWaves, 0xffffffffu));
         if (uint64_t(steps) * kSweepWaves * kChunkBytes >= (1ull << 32)) { error = "sweep: a block's stream exceeds 4 GiB"; return false; }
         const RowRange& rg = ranges[bi / slices];
         Block& blk = out.blocks[bi];
@@ -234,6 +267,25 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
     }
     out.image_bytes = stream_bytes + table_bytes;
     out.sweep_table_bytes = table_bytes;
+    if (gpu) {
+        std::vector<GpuTiler::SweepBlock> layout(NB);
+        uint64_t chunk0 = 0;
+        for (uint32_t bi = 0; bi < NB; ++bi) {
+            GpuTiler::SweepBlock& b = layout[bi];
+            b.first = block_start[bi];
+            b.count = uint32_t(block_start[bi + 1] - block_start[bi]);
+            b.steps = out.blocks[bi].total_steps[0];
+            b.nrows = out.blocks[bi].nrows;
+            b.pad_col = out.blocks[bi].first_ncols ? out.blocks[bi].first_col0 : 0u;
+            b.stream_at = stream_at[bi];
+            b.table_at = stream_bytes + table_at[bi];
+            b.chunk0 = chunk0;
+            chunk0 += uint64_t(b.steps) * kSweepWaves;
+        }
+        if (!gpu->sweep_emit(layout, out.image_bytes, image_slack)) { error = gpu->error(); return false; }
+        out.d_image = gpu->release_image();
+        timer.lap("sweep: gpu emit");
+    } else {
     resize_zeroed(out.image, out.image_bytes);
     parallel_for(NB, [&](size_t bi) {
         const std::vector<Placed>& mine = sorted[bi];
@@ -262,6 +314,7 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
     });
     sorted.clear();
     timer.lap("sweep: write image");
+    }
 
     std::vector<std::vector<uint32_t>> mine;
     bool by_slice = slices > 1 && G % 8 == 0 && RP == 1;

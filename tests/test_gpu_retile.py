@@ -13,7 +13,7 @@ import cases
 
 pytestmark = pytest.mark.gpu
 
-FORMATS = ["pairs", "delta", "owner", "pairs24", "owner24"]
+FORMATS = ["pairs", "delta", "owner", "pairs24", "owner24", "sweep"]
 
 
 def _set_format(monkeypatch, fmt):

@@ -104,6 +104,42 @@ def test_non_finite_x_reaches_only_the_rows_that_hold_the_column(monkeypatch):
     assert np.isfinite(got[~touched]).all() and not np.isfinite(got[touched]).any()
 
 
+def test_device_builder_hands_duplicates_and_wide_column_gaps_to_the_host_loops(monkeypatch):
+    """gpu_tiles.hip sorts and emits SWEEP images on the device (byte for byte the host builder's: tests/test_gpu_retile.py); two cases it
+    reports instead of building -- a (row, column) that occurs twice, and 64 consecutive elements of a block spanning more than 65535 columns
+    (the host cuts that chunk short) -- go through the host loops, and the SpMV is the same either way."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("HISPARSE_SWEEP", "1")
+    rng = np.random.default_rng(5)
+    rows, cols = 64, 400000
+    wide = sp.csr_matrix((rng.uniform(0.1, 1.0, rows * 3).astype(np.float32), (np.repeat(np.arange(rows), 3), rng.choice(cols, rows * 3, replace=False))), shape=(rows, cols))
+    wide.sort_indices()
+    dense_enough = cases.random_csr(3000, 5000, 0.004, 2, 0)
+    for m, expect_gpu in ((wide, False), (dense_enough, True)):
+        monkeypatch.setenv("HISPARSE_COL_SLICES", "1")      # (one slice: the 192 elements of `wide` lie ~2 000 columns apart, 64 of them span 130 K)
+        cp = host.format_matrix(host.CSRMatrix.from_scipy(m), 0, skip_empty_rows=True)
+        xw = host.pack_vector(0, cases.random_x(cp.num_cols, 4, 0))
+        with device.SpmvEngine(0) as eng:
+            eng.load_matrix(cp)
+            st = eng.stats()
+            assert device.STREAM_FORMATS[st["stream_format"]] == "sweep" and bool(st["retiled_on_gpu"]) == expect_gpu, st
+            eng.load_vector(xw)
+            eng.run()
+            _check(0, eng.read_result(), _oracle(cp, 0, xw))
+    monkeypatch.delenv("HISPARSE_COL_SLICES")
+    # duplicates: the CSR load path keeps them (two entries of one (row, column) are two products)
+    indptr = np.array([0, 3, 3, 5], dtype=np.uint32)
+    csr = host.CSRMatrix.from_arrays(3, 10, indptr, np.array([7, 7, 2, 0, 0], dtype=np.uint32), np.array([1.0, 2.0, 0.5, 0.25, 0.25], dtype=np.float32))
+    with device.SpmvEngine(0) as eng:
+        eng.load_matrix_csr(csr)
+        st = eng.stats()
+        assert device.STREAM_FORMATS[st["stream_format"]] == "sweep" and not st["retiled_on_gpu"]
+        eng.load_vector(host.pack_vector(0, np.arange(1, eng.num_cols + 1, dtype=np.float32) * 0.125))
+        eng.run()
+        y = orc.unpack_result(0, eng.read_result())
+    assert y[0] == 3.0 * 1.0 + 0.5 * 0.375 and y[1] == 0.0 and y[2] == 0.5 * 0.125
+
+
 def test_spmm_runs_over_a_sweep_image(monkeypatch):
     # hs_spmm runs one SpMV per column over formats without a fused kernel (hs_iterate on a sliced sweep image: tests/test_gpu_parity.py's
     # PageRank test under the "sweep" fixture -- the feedback is folded into the slice-combine launch)
