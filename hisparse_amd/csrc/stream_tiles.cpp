@@ -143,11 +143,32 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         }
     }
     // ---- SWEEP (stream_tiles.h): hyper-sparse matrices whose x is gathered from L2 instead of staged in LDS -- its own builder (host threads)
-    //      and kernel.  Automatic above kSweepMinMeanGap (stream_tiles.h has the measurements); HISPARSE_SWEEP=0|1 and
-    //      HISPARSE_STREAM_FORMAT=sweep force.
+    //      and kernel.  HISPARSE_SWEEP=0|1 and HISPARSE_STREAM_FORMAT=sweep force.
     {
+        // Unforced: wherever OWNER24 would be taken (mean position gap > kOwnerMinMeanGap) and SWEEP's plan is modelled faster than OWNER24's.
+        // OWNER24 pays ~1.2 us + 0.06 us per wavefront step for every (row range x sub-tile) unit whatever it holds (tools/perf_model.py:
+        // UNIT_FLOOR_US, fitted to the rocprofv3 kernels), and its planner cuts at least max_workgroups / 8 row ranges to fill the CUs; the
+        // estimate below lands 10 % under the measured steps on six matrices (pokec 87 / 95.5 us, ogbn-products 190 / 205, an 8-way slab of it
+        // 60.5 / 59.2, power-law squares 42.5 / 48, 86.6 / 99, 173 / 185), SWEEP's model within 3 %: hence the factor.  What the comparison
+        // reproduces (stream_tiles.h, "SWEEP format", has the tables): pokec -> SWEEP, ogbn-products -> OWNER24, ogbn-products cut into 8
+        // row slabs (same gap, a quarter of the row ranges: 59.2 -> 46.3 us) -> SWEEP.
         const double gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 0.0;
-        bool sweep = gap >= (is_float ? kSweepMinMeanGapFloat : kSweepMinMeanGap) && out.nnz >= kSweepMinNnz;
+        bool sweep = false;
+        if (gap > kOwnerMinMeanGap && out.nnz >= kSweepMinNnz && uint64_t(num_cols) * 4 < (1ull << 32)) {
+            uint32_t cs = 1, rows_cap = 0;
+            uint64_t want = 1;
+            const double sweep_us = sweep_plan(L, out.nnz, max_workgroups, cs, want, rows_cap);
+            const uint32_t cap = owner_max_block_rows(2), G = std::max<uint32_t>(1, max_workgroups);
+            uint64_t by_cap = 0;
+            for (uint32_t rp = 0; rp < RP; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + cap - 1) / cap;
+            const double ranges = double(std::max<uint64_t>(by_cap, G / kMaxColSlices));
+            const double units = ranges * double(CP) * S, per_wg = units / G, unit_steps = double(out.nnz) / units / (kConsumerWaves * kWaveLanes);
+            const double owner_slices = std::min<double>(kMaxColSlices, std::max(1.0, std::ceil(G / ranges)));
+            const double owner_combine = owner_slices > 1.0 ? 2.0 + double(num_rows) * 4.0 * (owner_slices + 1.0) / 8e6 : 0.0;
+            const double owner_us = 1.1 * (std::max(double(out.nnz) * 7.06 / 6.2e6, per_wg * (1.2 + 0.06 * unit_steps)) + 8.0 + owner_combine);
+            sweep = sweep_us < owner_us;
+            if (env_switch("HISPARSE_PLAN_DEBUG")) std::fprintf(stderr, "format: sweep %.1f us (%u slices) against owner24 %.1f us (%.0f units per workgroup) -> %s\n", sweep_us, cs, owner_us, per_wg, sweep ? "sweep" : "owner24");
+        }
         if (const char* force = env_switch("HISPARSE_SWEEP")) sweep = std::atoi(force) != 0;      // (1: whatever the matrix)
         if (const char* force = env_switch("HISPARSE_STREAM_FORMAT")) sweep = std::string(force) == "sweep";
         if (sweep) {

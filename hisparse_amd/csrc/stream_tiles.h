@@ -186,13 +186,12 @@ constexpr uint32_t kSweepWaves = 16;                          // all wavefronts 
 constexpr uint32_t kSweepMaxBlockRowsFloat = kMaxLdsBytes / kAccumulatorBytes - 1;                // 20479
 constexpr uint32_t kSweepMaxBlockRowsFixed = (kMaxLdsBytes / 4 - 2) * 32 / 33 - 1;                // 39716: (rows + 1) x 4 bytes + (rows + 32) / 32 x 4 bytes <= 160 KiB
 constexpr uint32_t kSweepColAlign = 32;                       // slices start on a 128-byte line of x
-// Chosen (unforced) for matrices sparser than this -- mean position gap rows x cols / nnz; OWNER24 pays per (row range x sub-tile) unit whatever
-// the unit holds, SWEEP per element and per line of x.  Measured on power-law squares of 1.0 / 1.6 / 2.4 M rows (tools/probe_sweep.py,
+// Chosen (unforced) where OWNER24 would be (mean position gap rows x cols / nnz above kOwnerMinMeanGap, more than kSweepMinNnz non-zeros) and its
+// plan is modelled faster (stream_tiles.cpp: "SWEEP"): OWNER24 pays per (row range x sub-tile) unit whatever the unit holds, SWEEP per element
+// and per line of x.  For square power-law matrices that comes out as a mean gap of ~60 K in fixed point, ~70 K in the float modes.  Measured on power-law squares of 1.0 / 1.6 / 2.4 M rows (tools/probe_sweep.py,
 // profiles/r04_sweep_vs_owner_synthetic.txt), whole step, SWEEP against OWNER24: gap 50 K +3 ... -3 % (fixed) / +5 ... +11 % (float), 70 K -6 ...
 // -13 % / +2 ... -7 %, 100 K -12 ... -24 % / -3 ... -20 %, 200 K -20 ... -38 % in both; pokec (gap 87 K) 95.5 -> 78.0 us fixed, 122.6 -> 88.3 us
 // float_pob; ogbn-products (48 K) stays OWNER24 (204 against 216 us).
-constexpr double kSweepMinMeanGap = 60000.0;
-constexpr double kSweepMinMeanGapFloat = 70000.0;
 constexpr uint64_t kSweepMinNnz = (2u << 20) + 1;             // smaller matrices: the LIGHT plan's (when x is short) or the row-block kernel's
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit

@@ -44,6 +44,36 @@ struct Placed { uint64_t key; uint32_t value; };      // key = column << 16 | lo
 
 }  // namespace
 
+// The plan: column slices x row ranges at the lowest modelled cost (microseconds; the model's terms are in the comment above).  Also what
+// build_stream_tiles compares with its estimate for OWNER24 when it chooses between the two formats.
+double sweep_plan(const Layout& L, uint64_t nnz, uint32_t max_workgroups, uint32_t& slices, uint64_t& want_ranges, uint32_t& max_rows) {
+    const uint32_t num_rows = L.num_rows, num_cols = L.num_cols, RP = L.row_parts;
+    const uint32_t G = std::max<uint32_t>(1, max_workgroups);
+    max_rows = L.g->impl == IMPL_FIXED ? kSweepMaxBlockRowsFixed : kSweepMaxBlockRowsFloat;
+    if (const char* force = env_switch("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force)));
+    uint64_t by_cap = 0;
+    for (uint32_t rp = 0; rp < RP; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + max_rows - 1) / max_rows;
+    const uint32_t lines = (num_cols + kSweepColAlign - 1) / kSweepColAlign;
+    const char* force_slices = env_switch("HISPARSE_COL_SLICES");
+    double best = 1e30;
+    slices = 1;
+    want_ranges = 1;
+    for (uint32_t cs = 1; cs <= std::min<uint32_t>(kMaxColSlices, std::max<uint32_t>(1, lines)); ++cs) {
+        if (force_slices && uint32_t(std::atoi(force_slices)) != cs) continue;
+        if (uint64_t(cs) * num_rows > 0xffffffffull) continue;      // Block::out_offset is a 32-bit word offset
+        const uint64_t per_round = std::max<uint32_t>(1, G / cs);
+        const uint64_t rounds = std::max<uint64_t>(1, (by_cap + per_round - 1) / per_round);
+        const uint64_t ranges = std::min<uint64_t>(per_round * rounds, std::max<uint64_t>(by_cap, std::max<uint64_t>(1, nnz / 4096)));
+        const double blocks = double(ranges) * cs, blocks_per_wg = std::ceil(blocks / G);
+        const double block_ns = double(nnz) / blocks * kSweepNsPerElement + std::max(double(lines) / cs * kSweepNsPerLine, double(nnz) / blocks * kSweepGatherNsPerElement);
+        const double combine_us = double(num_rows) * 4.0 * cs / 4e6 + (cs > 1 ? 2.0 + double(num_rows) * 4.0 * (cs + 1) / 8e6 : 0.0);
+        const double cost = blocks_per_wg * (block_ns * 1e-3 + kSweepBlockUs) + combine_us;
+        if (env_switch("HISPARSE_PLAN_DEBUG")) std::fprintf(stderr, "sweep plan cs %u: ranges %llu block %.1f us combine %.1f => %.1f us\n", cs, (unsigned long long)ranges, block_ns * 1e-3, combine_us, cost);
+        if (cost < best) { best = cost; slices = cs; want_ranges = ranges; }
+    }
+    return best;
+}
+
 bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
                        const std::vector<uint32_t>& row_nnz, uint32_t max_workgroups, StreamTiles& out, std::string& error, const CsrView* csr,
                        GpuTiler* gpu, uint64_t image_slack) {
@@ -109,31 +139,10 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
     // Every block gathers each 128-byte line of its slice of x about once, so the lines through the chip are (row ranges x |x| / 128)
     // whatever the slice count; slices exist to fill the CUs when the LDS row cap allows fewer row ranges than there are workgroups,
     // at the price of the combine pass (same model as stream_tiles.cpp).
-    uint32_t max_rows = L.g->impl == IMPL_FIXED ? kSweepMaxBlockRowsFixed : kSweepMaxBlockRowsFloat;
-    if (const char* force = env_switch("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force)));
-    uint64_t by_cap = 0;
-    for (uint32_t rp = 0; rp < RP; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + max_rows - 1) / max_rows;
-    const uint32_t lines = (num_cols + kSweepColAlign - 1) / kSweepColAlign;
-    uint32_t slices = 1;
+    uint32_t max_rows = 0, slices = 1;
     uint64_t want_ranges = 1;
-    {
-        const char* force_slices = env_switch("HISPARSE_COL_SLICES");
-        double best = 1e30;
-        for (uint32_t cs = 1; cs <= std::min<uint32_t>(kMaxColSlices, lines); ++cs) {
-            if (force_slices && uint32_t(std::atoi(force_slices)) != cs) continue;
-            if (uint64_t(cs) * num_rows > 0xffffffffull) continue;      // Block::out_offset is a 32-bit word offset
-            const uint64_t per_round = std::max<uint32_t>(1, G / cs);
-            const uint64_t rounds = std::max<uint64_t>(1, (by_cap + per_round - 1) / per_round);
-            const uint64_t ranges = std::min<uint64_t>(per_round * rounds, std::max<uint64_t>(by_cap, std::max<uint64_t>(1, nnz / 4096)));
-            const double blocks = double(ranges) * cs, blocks_per_wg = std::ceil(blocks / G);
-            const double block_ns = double(nnz) / blocks * kSweepNsPerElement + std::max(double(lines) / cs * kSweepNsPerLine, double(nnz) / blocks * kSweepGatherNsPerElement);
-            const double combine_us = double(num_rows) * 4.0 * cs / 4e6 + (cs > 1 ? 2.0 + double(num_rows) * 4.0 * (cs + 1) / 8e6 : 0.0);
-            const double cost = blocks_per_wg * (block_ns * 1e-3 + kSweepBlockUs) + combine_us;
-            if (env_switch("HISPARSE_PLAN_DEBUG")) std::fprintf(stderr, "sweep plan cs %u: ranges %llu block %.1f us combine %.1f => %.1f us\n", cs, (unsigned long long)ranges, block_ns * 1e-3, combine_us, cost);
-            if (cost < best) { best = cost; slices = cs; want_ranges = ranges; }
-        }
-        if (best == 1e30) { error = "sweep: no plan (HISPARSE_COL_SLICES out of range?)"; return false; }
-    }
+    const uint32_t lines = (num_cols + kSweepColAlign - 1) / kSweepColAlign;
+    if (sweep_plan(L, nnz, max_workgroups, slices, want_ranges, max_rows) >= 1e30) { error = "sweep: no plan (HISPARSE_COL_SLICES out of range?)"; return false; }
     std::vector<RowRange> ranges;
     std::vector<uint64_t> range_nnz;
     build_row_ranges_at_most(L, row_nnz, nnz, want_ranges, max_rows, ranges, range_nnz, std::max<uint32_t>(1, G / slices));

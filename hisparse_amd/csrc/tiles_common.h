@@ -397,6 +397,8 @@ bool build_bitmap_tiles(const detail::Layout& L, const void* const channel[NUM_H
                         const std::vector<uint32_t>& row_nnz, uint32_t max_workgroups, StreamTiles& out, std::string& error,
                         const CsrView* csr = nullptr, class GpuTiler* gpu = nullptr, uint64_t image_slack = 0);
 
+// sweep_tiles.cpp: the SWEEP plan (column slices, row ranges wanted, rows per block) and its modelled cost in microseconds
+double sweep_plan(const detail::Layout& L, uint64_t nnz, uint32_t max_workgroups, uint32_t& slices, uint64_t& want_ranges, uint32_t& max_rows);
 // sweep_tiles.cpp: the SWEEP builder (called by build_stream_tiles once the format is chosen; `row_nnz` from its pass 0; gpu: the per-non-zero
 // passes on the device)
 bool build_sweep_tiles(const detail::Layout& L, const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
