@@ -32,7 +32,7 @@ def test_reloads_do_not_leak_device_memory(monkeypatch):
     before = _free_bytes()
     for round_ in range(6):
         for impl, csr, cp in mats:
-            for fmt in ("", "pairs", "delta", "owner"):
+            for fmt in ("", "pairs", "delta", "owner", "sweep"):
                 if fmt:
                     monkeypatch.setenv("HISPARSE_STREAM_FORMAT", fmt)
                 else:
