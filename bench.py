@@ -20,10 +20,13 @@ four different ogbl-ppa-sized matrices (1.1 GB of images, more than the 256 MiB 
 `roofline.frac_mall_cold`.  `--config NAME` measures only that configuration; `--quick` skips the extras.
 
 N > 1 (BASELINE.json configs[4]): mouse_gene, ONE matrix split into N row slabs by non-zero count (`--scaling strong`;
-hisparse_amd/sharding.py), every rank formats and loads its slab and holds all of x.  Timed: K x { slab SpMV, all-gather of
-the y slabs over RCCL } (the gather of step k overlaps the SpMV of step k+1, double-buffered) = `value`; the same K SpMVs
-without any gather are timed too and reported as `compute_only`.  `--scaling weak` gives every rank a slab the size of the
-whole N = 1 matrix instead; `--gather final|off` changes the exchange.
+hisparse_amd/sharding.py), every rank formats and loads its slab and holds all of x.  Timed = `value`: K slab SpMVs and ONE final
+all-gather of the y slabs over RCCL (BASELINE.json's north_star: "a final RCCL gather over xGMI"; the reference too runs its NUM_RUNS
+launches and collects y once, sw/benchmark.cpp:318-346).  Timed alongside and reported in the same line: the same K SpMVs with y left
+sharded (`compute_only`), with an all-gather after EVERY SpMV as an iterative caller needs it (`exchange_every_step`: the gather of step
+k overlaps the SpMV of step k+1, double-buffered), and with that per-step gather done by peer stores instead of a collective
+(`exchange_push`).  `--scaling weak` gives every rank a slab the size of the whole N = 1 matrix instead; `--gather step|off` makes one
+of the other patterns the `value`.
 """
 import argparse
 import json
@@ -502,8 +505,9 @@ def main():
     ap.add_argument("--npz", default=None, help="real dataset file instead of the seeded stand-in")
     ap.add_argument("--impl", default=None, help="override the config's numeric mode")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong", help="N > 1: split ONE matrix (default) or one matrix-sized slab per rank")
-    ap.add_argument("--gather", choices=["step", "final", "off"], default="step",
-                    help="N > 1: all-gather the y slabs after every SpMV (default, overlapped), once after the timed SpMVs, or never")
+    ap.add_argument("--gather", choices=["step", "final", "off"], default="final",
+                    help="N > 1: what `value` times beside the K SpMVs: one all-gather of the y slabs at the end (default), one after every SpMV "
+                         "(overlapped with the next), or none; the other patterns are reported alongside")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="N > 1: nccl = RCCL over xGMI, one GPU per rank (the measurement).  gloo = the launcher / sharding self-test on host "
                          "memory: needs HISPARSE_HIP_LIB=<libhisparse_cpu.so> (the separate host-thread build of the C-ABI); never a measurement")
@@ -827,11 +831,12 @@ def main_distributed(args, rank, local_rank, world):
     # ---- timing: the exchange pattern asked for = `value`; the same SpMVs without any exchange alongside -------------------------
     elapsed = timed(args.gather, args.steps)
     compute_elapsed = timed("off", args.steps) if args.gather != "off" else elapsed
+    step_elapsed = elapsed if args.gather == "step" else timed("step", args.steps)      # an all-gather after every SpMV (iterative callers)
     # ---- the same K steps with the gather done by PEER STORES instead of a collective (hs_push_result; hisparse_amd/peer_gather.py): every
     #      rank's kernels write y into its slot of its own gather buffer and one small kernel pushes the slab into every peer's buffer over
     #      xGMI.  Reported beside the RCCL figure; a failure here (IPC not available) is reported, not fatal.
     push = None
-    if on_gpu and args.gather == "step":
+    if on_gpu:
         try:
             from hisparse_amd import peer_gather
             pg = peer_gather.PeerGather(dist, rank, world, chunk, device_id=local_rank)
@@ -925,6 +930,10 @@ def main_distributed(args, rank, local_rank, world):
             "same_workload_on_one_gpu": one_gpu,
             "exchange": {"pattern": args.gather, "bytes_per_rank_per_gather": int(chunk) * 4,
                          "ms_per_step_added": round((elapsed - compute_elapsed) / args.steps * 1e3, 5)},
+            "exchange_every_step": {"ms_per_step": round(step_elapsed / args.steps * 1e3, 5),
+                                    "ms_per_step_added": round((step_elapsed - compute_elapsed) / args.steps * 1e3, 5),
+                                    "value": round(8.0 * total_nnz / (step_elapsed / args.steps) / 1e9, 2), "unit": "GB/s",
+                                    "note": "all_gather_into_tensor(y) over RCCL after EVERY SpMV, the gather of step k overlapping the SpMV of step k + 1"},
             "exchange_push": push,
             "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_sweep_kernel" if stats["stream_format"] == 6 else "spmv_rowblock_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "kernel_ms": round(kernel_ms, 5),
