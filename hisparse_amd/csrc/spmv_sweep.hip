@@ -28,7 +28,10 @@ namespace dev {
 namespace {
 
 constexpr int kSweepThreads = kSweepWaves * kWaveLanes;
-constexpr int kSweepDepth = 8;      // chunks (and gathers) in flight per wavefront
+#ifndef HS_SWEEP_DEPTH
+#define HS_SWEEP_DEPTH 8            // (4, 6, 12 and 16 were measured too: -DHS_SWEEP_DEPTH=..., tools/r04/sweep_depth.sh, profiles/r04_sweep_ring_depth.txt)
+#endif
+constexpr int kSweepDepth = HS_SWEEP_DEPTH;      // chunks (and gathers) in flight per wavefront
 
 __device__ __forceinline__ const uint8_t* sweep_scalar_pointer(const void* p) {
     const uint64_t a = reinterpret_cast<uint64_t>(p);
@@ -37,10 +40,24 @@ __device__ __forceinline__ const uint8_t* sweep_scalar_pointer(const void* p) {
     return reinterpret_cast<const uint8_t*>((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
-// Ring: chunk slot K in a[2K : 2K+1] (value word, position word), gather slot K in a[16 + K].  hipcc never allocates accumulator registers
+// Ring: chunk slot K in a[2K : 2K+1] (value word, position word), gather slot K in a[2 kSweepDepth + K].  hipcc never allocates accumulator registers
 // in this kernel; every asm statement that issues into the ring names all of them as clobbered, so nothing else is scheduled across.
-#define HS_SWEEP_RING "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", \
-                      "a18", "a19", "a20", "a21", "a22", "a23"
+#define HS_SWEEP_RING8 "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", \
+                       "a18", "a19", "a20", "a21", "a22", "a23"
+#if HS_SWEEP_DEPTH == 4
+#define HS_SWEEP_RING "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11"
+#elif HS_SWEEP_DEPTH == 6
+#define HS_SWEEP_RING "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17"
+#elif HS_SWEEP_DEPTH == 8
+#define HS_SWEEP_RING HS_SWEEP_RING8
+#elif HS_SWEEP_DEPTH == 12
+#define HS_SWEEP_RING HS_SWEEP_RING8, "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35"
+#elif HS_SWEEP_DEPTH == 16
+#define HS_SWEEP_RING HS_SWEEP_RING8, "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", \
+                      "a42", "a43", "a44", "a45", "a46", "a47"
+#else
+#error "HS_SWEEP_DEPTH must be 4, 6, 8, 12 or 16"
+#endif
 
 template <int K>
 __device__ __forceinline__ void sweep_issue_chunk(const uint8_t* base, uint32_t off) {
@@ -48,13 +65,13 @@ __device__ __forceinline__ void sweep_issue_chunk(const uint8_t* base, uint32_t 
 }
 template <int K>
 __device__ __forceinline__ void sweep_issue_gather(const uint8_t* x, uint32_t byte_off) {
-    asm volatile("s_nop 4\n\tglobal_load_dword a[%0], %1, %2" ::"n"(16 + K), "v"(byte_off), "s"(x) : "memory", HS_SWEEP_RING);
+    asm volatile("s_nop 4\n\tglobal_load_dword a[%0], %1, %2" ::"n"(2 * kSweepDepth + K), "v"(byte_off), "s"(x) : "memory", HS_SWEEP_RING);
 }
 // one counted wait: chunk slot K (issued kSweepDepth steps ago) AND the gather issued just before it have landed
 template <int K>
 __device__ __forceinline__ void sweep_take(uint32_t& value, uint32_t& where, uint32_t& xv) {
     asm volatile("s_waitcnt vmcnt(%6)\n\tv_accvgpr_read_b32 %0, a[%3]\n\tv_accvgpr_read_b32 %1, a[%4]\n\tv_accvgpr_read_b32 %2, a[%5]"
-                 : "=v"(value), "=v"(where), "=v"(xv) : "n"(2 * K), "n"(2 * K + 1), "n"(16 + K), "n"(2 * (kSweepDepth - 1)) : "memory");
+                 : "=v"(value), "=v"(where), "=v"(xv) : "n"(2 * K), "n"(2 * K + 1), "n"(2 * kSweepDepth + K), "n"(2 * (kSweepDepth - 1)) : "memory");
 }
 
 // Row accumulators.  Float: doubles, ds_add_f64 (ds_add_f32 runs at a ninth of its rate on this part, stream_tiles.h) -- 8 bytes per row.
