@@ -5,7 +5,8 @@
 // current column partition of x in on-chip banks (vecbuf_access_unit.h:66-72,126-128); the row-block kernel does the same with 8192-column
 // sub-tiles in LDS, and on a hyper-sparse matrix pays ~2 100 clocks per (row range x sub-tile) unit for a flush, a barrier and a refill
 // that ~2 000 elements cannot hide.  Here x stays in L2 and every lane fetches its own word:
-//   * the block's elements come in (column, row) order, chunk k to wavefront k % 16 as its step k / 16: the 16 wavefronts move over the
+//   * the block's elements come in (column, row) order, chunk k to wavefront k % 8 as its step k / 8: the 8 wavefronts (512 threads; 16 were
+//     measured 4 % slower on pokec, 4 much slower in fixed point: profiles/r04_sweep_waves.txt) move over the
 //     block's column slice together, once, and the 64 lanes of one gather touch a handful of 128-byte lines;
 //   * per wavefront EIGHT 512-byte chunks and EIGHT gathers are in flight, both in accumulator registers behind ONE counted wait per step:
 //     the gather for the chunk taken at step s - 8 is issued just before chunk s + ... (vmcnt retires in order), see step();
@@ -80,15 +81,21 @@ __device__ __forceinline__ void sweep_take(uint32_t& value, uint32_t& where, uin
 // bitmap behind the accumulators with ds_or_b32.  Twice the rows per block of the 8-byte form = half the row ranges = half the lines of x
 // gathered per SpMV (sweep_tiles.cpp), which is what the format's cost is made of.  A wavefront takes a step every ~1 400 clocks: the LDS
 // round trip of the returning atomic is nowhere near its critical path.
+struct SweepLane {
+    uint32_t value[kSweepDepth], row[kSweepDepth];      // the elements whose x words are on their way
+    uint32_t carry_old = 0, carry_p = 0, carry_row = 0; // fixed point: the last add, whose carry is looked at one step later
+};
+
 template <bool kFloat>
 struct SweepRows;
 template <>
 struct SweepRows<true> {
     using acc_t = double;
     static __device__ __forceinline__ uint32_t lds_words(uint32_t nrows) { return (nrows + 1) * 2; }
-    static __device__ __forceinline__ void add(uint8_t* lds, uint32_t, uint32_t row, uint32_t value, uint32_t xv) {
+    static __device__ __forceinline__ void add(uint8_t* lds, uint32_t, SweepLane&, uint32_t row, uint32_t value, uint32_t xv) {
         atomicAdd(reinterpret_cast<double*>(lds) + row, static_cast<double>(__uint_as_float(value) * __uint_as_float(xv)));
     }
+    static __device__ __forceinline__ void settle(uint8_t*, uint32_t, SweepLane&) {}
     static __device__ __forceinline__ uint32_t finish(const uint8_t* lds, uint32_t, uint32_t row) {
         return __float_as_uint(static_cast<float>(reinterpret_cast<const double*>(lds)[row]));
     }
@@ -97,11 +104,18 @@ template <>
 struct SweepRows<false> {
     static __device__ __forceinline__ uint32_t flag_word0(uint32_t nrows) { return nrows + 1; }      // the carry bitmap starts behind the nrows + 1 sums
     static __device__ __forceinline__ uint32_t lds_words(uint32_t nrows) { return nrows + 1 + (nrows + 32) / 32; }
-    static __device__ __forceinline__ void add(uint8_t* lds, uint32_t nrows, uint32_t row, uint32_t value, uint32_t xv) {
-        uint32_t* acc = reinterpret_cast<uint32_t*>(lds);
-        const uint32_t p = q8_24_mul(value, xv);
-        const uint32_t old = atomicAdd(acc + row, p);                                             // ds_add_rtn_u32
-        if (old + p < old) atomicOr(acc + flag_word0(nrows) + (row >> 5), 1u << (row & 31u));    // AP_SAT (pe.h:72): once beyond 2^32 - 1, always
+    // The carry of an add is looked at ONE STEP LATER (settle), when the returning atomic has long come back: checked on the spot, the
+    // wavefront would sit out an LDS round trip in every step (tools/lds_atomic_bench.hip: 4.0 against 4.7 lanes/clk; it matters once a
+    // workgroup has only 8 wavefronts to hide it behind).
+    static __device__ __forceinline__ void settle(uint8_t* lds, uint32_t nrows, SweepLane& st) {
+        if (st.carry_old + st.carry_p < st.carry_old)                                             // AP_SAT (pe.h:72): once beyond 2^32 - 1, always
+            atomicOr(reinterpret_cast<uint32_t*>(lds) + flag_word0(nrows) + (st.carry_row >> 5), 1u << (st.carry_row & 31u));
+    }
+    static __device__ __forceinline__ void add(uint8_t* lds, uint32_t nrows, SweepLane& st, uint32_t row, uint32_t value, uint32_t xv) {
+        settle(lds, nrows, st);
+        st.carry_p = q8_24_mul(value, xv);
+        st.carry_row = row;
+        st.carry_old = atomicAdd(reinterpret_cast<uint32_t*>(lds) + row, st.carry_p);             // ds_add_rtn_u32
     }
     static __device__ __forceinline__ uint32_t finish(const uint8_t* lds, uint32_t nrows, uint32_t row) {
         const uint32_t* acc = reinterpret_cast<const uint32_t*>(lds);
@@ -109,9 +123,6 @@ struct SweepRows<false> {
     }
 };
 
-struct SweepLane {
-    uint32_t value[kSweepDepth], row[kSweepDepth];      // the elements whose x words are on their way
-};
 
 // Step s of a wavefront (ring slot K = s % 8).  In flight on entry, oldest first: gather(s - 8), chunk(s), gather(s - 7), chunk(s + 1), ...
 // Waiting until 14 loads are left means chunk(s) and the gather before it have landed: add the element taken at step s - 8 (its x word
@@ -123,7 +134,7 @@ __device__ __forceinline__ void sweep_step(SweepLane& st, const uint8_t* stream,
                                            uint8_t* ys, uint32_t nrows) {
     uint32_t value, where, xv;
     sweep_take<K>(value, where, xv);
-    if (!(kAblate & 1)) SweepRows<kFloat>::add(ys, nrows, st.row[K], st.value[K], xv);      // (the first eight steps add 0 x x[..] to the spare accumulator)
+    if (!(kAblate & 1)) SweepRows<kFloat>::add(ys, nrows, st, st.row[K], st.value[K], xv);      // (the first eight steps add 0 x x[..] to the spare accumulator)
     else asm volatile("" ::"v"(xv), "v"(st.value[K]), "v"(st.row[K]));
     st.value[K] = value;
     st.row[K] = where >> 16;
@@ -196,6 +207,8 @@ __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory", HS_SWEEP_RING);
         }
         // no-return LDS atomics can outlive lgkmcnt(0) (spmv_rowblock_kernel): a returning one on the spare accumulator, awaited, cannot
+        R::settle(ys, nrows, st);                                    // the last add's carry
+        st.carry_old = st.carry_p = 0;
         const uint32_t flushed = atomicOr(reinterpret_cast<uint32_t*>(ys) + R::lds_words(nrows) - 1, 0u);
         asm volatile("" ::"v"(flushed));
         __syncthreads();

@@ -174,14 +174,17 @@ constexpr uint32_t kLightMaxBlockRows = 3071;                 // 24 KiB of accum
 constexpr uint32_t kLightMinBlockNnz = 1024;                  // no block smaller than 16 chunks (unless the matrix is)
 // SWEEP format (round 4; hyper-sparse matrices, x NOT staged in LDS): a block = (row range x CONTIGUOUS column slice), its elements sorted by
 // (column, row) and stored in that order as 512-byte chunks of 64 x { u32 value word, u32 (local_row << 16 | column - chunk base) }; chunk k
-// of a block belongs to step k / 16 of wavefront k % 16, so the 16 wavefronts of the workgroup sweep the slice's columns together, once,
+// of a block belongs to step k / 8 of wavefront k % 8 (kSweepWaves), so the wavefronts of the workgroup sweep the slice's columns together, once,
 // left to right.  The chunk bases (absolute column of the chunk's first element) sit in a table per block, [wavefront][step].  x[column] is
 // a per-lane global load (x is L2 / Infinity-Cache resident; column order makes the 64 lanes of one gather touch a handful of 128-byte lines),
 // products go to LDS accumulators with atomics (doubles; fixed point: 32-bit sums + a carry bit): no units, no x refills, no barriers between a block's prologue and epilogue.
 // Padding slots (the tail of a block's last step, and a chunk cut short because the next column lies more than 65535 beyond its base): value 0,
 // local_row = nrows (the spare accumulator), offset 0.  kernel: spmv_sweep.hip; builder: sweep_tiles.cpp; tools/gather_bench.hip is the
 // block-level measurement it was designed from.
-constexpr uint32_t kSweepWaves = 16;                          // all wavefronts stream (no loaders)
+#ifndef HS_SWEEP_WAVES
+#define HS_SWEEP_WAVES 8                                      // (4 and 16 were measured too: -DHS_SWEEP_WAVES=..., tools/r04/sweep_waves.sh, profiles/r04_sweep_waves.txt)
+#endif
+constexpr uint32_t kSweepWaves = HS_SWEEP_WAVES;              // all wavefronts stream (no loaders)
 // the LDS holds nothing but accumulators: doubles in the float modes; fixed point: a wrapping 32-bit sum + a carry bit per row (spmv_sweep.hip)
 constexpr uint32_t kSweepMaxBlockRowsFloat = kMaxLdsBytes / kAccumulatorBytes - 1;                // 20479
 constexpr uint32_t kSweepMaxBlockRowsFixed = (kMaxLdsBytes / 4 - 2) * 32 / 33 - 1;                // 39716: (rows + 1) x 4 bytes + (rows + 32) / 32 x 4 bytes <= 160 KiB
@@ -223,7 +226,7 @@ struct Unit {
     uint32_t end_step[kConsumerWaves];      // per wavefront: its stream position (in chunks / records, heads included) after this unit
 };
 // SWEEP images: a Block describes (row range x column slice) -- row0, nrows, row_part, flags, out_offset, next as above, wave_offset[0] = byte
-// offset of the block's first chunk, wave_offset[1] = byte offset of its chunk-base table (u32 [16][steps]), total_steps[0] = steps, first_col0 /
+// offset of the block's first chunk, wave_offset[1] = byte offset of its chunk-base table (u32 [kSweepWaves][steps]), total_steps[0] = steps, first_col0 /
 // first_ncols = the slice's first column / column count; no units.
 // BITMAP images re-use the two tables: a Block describes (row range x column slice) -- row0, nrows, row_part, flags, out_offset, next as
 // above, first_col0 = first column of the slice, first_ncols = groups per row in the slice -- and its units [unit_begin, unit_end)

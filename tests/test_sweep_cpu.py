@@ -40,10 +40,11 @@ def test_sweep_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypa
     assert not slices or t["col_slices"] == slices
     blocks = t["blocks"]
     assert (blocks["nrows"] <= (39715 if impl == 0 else 20479)).all() and t["max_block_rows"] == blocks["nrows"].max()
-    # streams of whole steps (16 chunks of 512 bytes) followed by the chunk-base tables (16 words per step)
+    # streams of whole steps (one 512-byte chunk per wavefront) followed by the chunk-base tables (one word per wavefront and step)
+    W = tile_emulator.SWEEP_WAVES
     steps = blocks["total_steps"][:, 0].astype(np.int64)
-    assert len(t["image"]) == steps.sum() * 16 * (512 + 4)
-    assert t["elements"] == steps.sum() * 16 * 64
+    assert len(t["image"]) == steps.sum() * W * (512 + 4)
+    assert t["elements"] == steps.sum() * W * 64
     # the slices of a row range are contiguous, disjoint, cover the columns and start on 128-byte lines of x
     order = np.lexsort((blocks["first_col0"], blocks["row0"]))
     per_range = t["col_slices"]
@@ -98,7 +99,7 @@ def test_sweep_column_gaps_beyond_16_bits_cut_the_chunk(impl):
     t = build(cp, impl, 64)      # few non-zeros: few blocks, each with columns far apart
     assert t["format"] == "sweep"
     steps = t["blocks"]["total_steps"][:, 0].astype(np.int64)
-    assert steps.sum() * 16 * 64 > 4 * cp.nnz      # (mostly padding: the cuts happened)
+    assert steps.sum() * tile_emulator.SWEEP_WAVES * 64 > 4 * cp.nnz      # (mostly padding: the cuts happened)
     got, want = tile_emulator.run(t, impl, xw, cp.num_rows), oracle_y(cp, impl, xw)
     assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
 

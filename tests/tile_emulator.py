@@ -6,6 +6,7 @@ kernel's element semantics against the oracle without a GPU, for both stream for
 import numpy as np
 
 WAVE, CONSUMERS, SUB_TILE = 64, 14, 8192
+SWEEP_WAVES = 8              # SWEEP: wavefronts per workgroup (stream_tiles.h: kSweepWaves)
 CHUNK_BYTES = 512            # PAIRS: 64 x {u32 value, u32 row << 16 | col}
 RECORD_BYTES = 768           # DELTA: two slots per lane: 64 x {u32 value A, u32 value B}, then 64 x {u16 gap A, u16 gap B}
 BRIDGE = 0xFFFF
@@ -200,15 +201,15 @@ def _block_bitmap(image, blk, units, x_words, ys, is_float):
 
 
 def _block_sweep(image, blk, x_words, ys, is_float):
-    """SWEEP (stream_tiles.h): chunk k of the block = step k // 16 of wavefront k % 16, its base column in the table [wavefront][step];
+    """SWEEP (stream_tiles.h): chunk k of the block = step k // 8 of wavefront k % 8, its base column in the table [wavefront][step];
     the chunks, taken in order, hold the block's elements in non-decreasing column order inside the block's column slice."""
     nrows, steps = int(blk["nrows"]), int(blk["total_steps"][0])
     stream, table_at = int(blk["wave_offset"][0]), int(blk["wave_offset"][1])
     col_lo, col_hi = int(blk["first_col0"]), int(blk["first_col0"]) + int(blk["first_ncols"])
-    table = image[table_at: table_at + steps * 16 * 4].view(np.uint32).reshape(16, steps) if steps else None
+    table = image[table_at: table_at + steps * SWEEP_WAVES * 4].view(np.uint32).reshape(SWEEP_WAVES, steps) if steps else None
     previous = -1
-    for k in range(steps * 16):
-        s, w = divmod(k, 16)
+    for k in range(steps * SWEEP_WAVES):
+        s, w = divmod(k, SWEEP_WAVES)
         val, cr = _chunk(image, stream + k * CHUNK_BYTES, False)
         row, col = (cr >> 16).astype(np.int64), int(table[w, s]) + (cr & 0xFFFF).astype(np.int64)
         real = row < nrows

@@ -23,6 +23,7 @@ RAMP_US = 4.3               # a 1024-thread workgroup's wavefronts are started 2
 NEXT_BLOCK_US = 3.5         # the same for a workgroup's further blocks (descriptor, zeroing, first sub-tile; no launch ramp)
 STORE_US = 1.0              # result store of a block (+ the write latency at its end)
 SPREAD = 0.05               # workgroups finish up to 5 % of the main loop apart (dynamic: memory-system fairness, not step counts)
+SWEEP_WAVES = 8              # stream_tiles.h: kSweepWaves
 SWEEP_NS_PER_ELEMENT, SWEEP_NS_PER_LINE = 0.33, 1.36      # SWEEP (tools/gather_bench.hip): 8 bytes at ~24 GB/s per CU; a gathered line of x every ~3.3 clocks
 CU_STREAM_B_PER_US = {"pairs": 25.8e3, "delta": 25.8e3, "owner": 26.5e3}   # one CU's 14 consumer rings while nothing else binds: 6.6-6.8 TB/s / 256
 # a (row block, x sub-tile) UNIT costs at least this much, however little it holds: end-of-unit flush + barrier + the loaders' refill issue
@@ -62,7 +63,7 @@ def model(name, cp=None, impl=None):
             for b in t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]:
                 blk = blocks[b]
                 nblocks[g] += 1
-                per[g] += int(blk["total_steps"][0]) * 16 * 64 * SWEEP_NS_PER_ELEMENT * 1e-3 + int(blk["first_ncols"]) / 32.0 * SWEEP_NS_PER_LINE * 1e-3
+                per[g] += int(blk["total_steps"][0]) * SWEEP_WAVES * 64 * SWEEP_NS_PER_ELEMENT * 1e-3 + int(blk["first_ncols"]) / 32.0 * SWEEP_NS_PER_LINE * 1e-3
         crit = int(np.argmax(per + nblocks * (NEXT_BLOCK_US + STORE_US)))
         parts = {"launch": LAUNCH_US, "ramp + prologue": RAMP_US, "further blocks' prologues": NEXT_BLOCK_US * max(0.0, nblocks[crit] - 1),
                  "stream": per[crit], "result stores": STORE_US * nblocks[crit], "finish spread": SPREAD * per[crit]}
