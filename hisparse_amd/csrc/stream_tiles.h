@@ -155,7 +155,10 @@ constexpr double kOwnerMinMeanGap = 20000.0;                  // == kDeltaMaxMea
 constexpr double kBitmapMinDensity = 0.125;                   // below: < 8 of 64 lanes busy per step, PAIRS / DELTA win
 constexpr uint32_t kBitmapMinCols = 2048;                     // shorter rows: a wavefront's run per row is too short to pipeline
 constexpr uint32_t kBitmapGroupCols = 64;                     // one wavefront step
-constexpr uint32_t kBitmapWaves = 16;                         // all 16 wavefronts of the workgroup stream (no loader wavefronts)
+#ifndef HS_BITMAP_WAVES
+#define HS_BITMAP_WAVES 16                                    // (12 and 8 were measured slower, round 4: transformer-50 10.6 / 11.3 / 12.0 us, profiles/r04_bitmap_waves.txt)
+#endif
+constexpr uint32_t kBitmapWaves = HS_BITMAP_WAVES;            // all wavefronts of the workgroup stream (no loader wavefronts)
 constexpr uint32_t kBitmapMaxBlockRows = 8191;                // 64 KiB of 8-byte row accumulators
 constexpr uint32_t kBitmapMaxXLdsGroups = 576;                // a block's stretch of x is kept in LDS when it has at most this many groups (144 KiB) and its accumulators fit beside it
 constexpr uint32_t kBitmapSkew[4] = {170, 140, 65, 25};       // share of a wavefront by its place on its SIMD (wavefronts 0-3, 4-7, 8-11, 12-15): bitmap_tiles.cpp
