@@ -9,10 +9,10 @@
 //     measured 4 % slower on pokec, 4 much slower in fixed point: profiles/r04_sweep_waves.txt) move over the
 //     block's column slice together, once, and the 64 lanes of one gather touch a handful of 128-byte lines;
 //   * per wavefront EIGHT 512-byte chunks and EIGHT gathers are in flight, both in accumulator registers behind ONE counted wait per step:
-//     the gather for the chunk taken at step s - 8 is issued just before chunk s + ... (vmcnt retires in order), see step();
-//   * products go to 8-byte LDS accumulators with ds_add_u64 / ds_add_f64 (any lane may hit any row): exact 64-bit sums of the rounded
-//     Q8.24 products, clamped once / double sums of the fp32 products, rounded once -- the arithmetic of the other formats, bit for bit in
-//     fixed point;
+//     the gather for the chunk taken at step s is issued just before the load of chunk s + 8 (vmcnt retires in order), see sweep_step();
+//   * products go to LDS accumulators with atomics (any lane may hit any row): float -- double sums of the fp32 products (ds_add_f64), rounded
+//     once; fixed point -- a wrapping 32-bit sum of the rounded Q8.24 products (ds_add_rtn_u32) plus one carry bit per row, i.e. exactly the
+//     saturating sum (SweepRows below) -- the arithmetic of the other formats, bit for bit in fixed point;
 //   * nothing between the block's prologue and its epilogue: no units, no barriers, no refills.
 // Measured at block level before any builder existed (tools/gather_bench.hip, profiles/r04_gather_bench.txt): the stream runs at 5.3 TB/s
 // and a gathered line of x costs ~3.3 clocks per CU.
@@ -79,8 +79,7 @@ __device__ __forceinline__ void sweep_take(uint32_t& value, uint32_t& where, uin
 // Fixed point: 4 bytes per row.  The saturating sum of unsigned products is min(exact sum, 2^32 - 1), so a wrapping 32-bit sum plus ONE BIT
 // "a carry happened" is exact: ds_add_rtn_u32 returns the old value, old + p < old is the carry, and the (rare) carry sets the row's bit in a
 // bitmap behind the accumulators with ds_or_b32.  Twice the rows per block of the 8-byte form = half the row ranges = half the lines of x
-// gathered per SpMV (sweep_tiles.cpp), which is what the format's cost is made of.  A wavefront takes a step every ~1 400 clocks: the LDS
-// round trip of the returning atomic is nowhere near its critical path.
+// gathered per SpMV (sweep_tiles.cpp), which is what the format's cost is made of.
 struct SweepLane {
     uint32_t value[kSweepDepth], row[kSweepDepth];      // the elements whose x words are on their way
     uint32_t carry_old = 0, carry_p = 0, carry_row = 0; // fixed point: the last add, whose carry is looked at one step later
