@@ -120,3 +120,21 @@ def test_sweep_duplicates_and_empty_matrix():
     te = build(cpe, 0, 8)
     assert te["format"] == "sweep" and te["nnz"] == 0 and (te["blocks"]["total_steps"][:, 0] == 0).all()
     assert not tile_emulator.run(te, 0, host.pack_vector(0, np.ones(cpe.num_cols, dtype=np.float32)), cpe.num_rows).any()
+
+
+def test_planner_takes_sweep_where_its_plan_is_modelled_faster(monkeypatch):
+    """Unforced: SWEEP wherever OWNER24 would be taken and SWEEP's plan is modelled faster (stream_tiles.cpp) -- a very sparse square, and a row
+    slab of a matrix that stays OWNER24 as a whole (few row ranges: few lines of x to gather, while OWNER24's units cost what they cost)."""
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    sparse = host.CSRMatrix.generate("powerlaw", 1000000, 1000000, a=5.0e6, b=0.4, c=1.0, seed=3)          # mean position gap 200 K
+    denser = host.CSRMatrix.generate("powerlaw", 800000, 800000, a=2.0e7, b=0.4, c=1.0, seed=4)            # gap 32 K: OWNER24 ...
+    ip, ix, dv = denser.arrays()
+    cut = int(np.searchsorted(ip, ip[-1] // 8))                                                           # ... its first eighth of the non-zeros as a slab: SWEEP
+    slab = host.CSRMatrix.from_arrays(cut, denser.num_cols, ip[:cut + 1].copy(), ix[:ip[cut]].copy(), dv[:ip[cut]].copy())
+    for csr, want in ((sparse, "sweep"), (denser, "owner24"), (slab, "sweep")):
+        cp = host.format_matrix(csr, 0, skip_empty_rows=True)
+        t = build(cp, 0, 256)
+        assert t["format"] == want, (csr.num_rows, csr.nnz, t["format"])
+    monkeypatch.setenv("HISPARSE_SWEEP", "0")
+    cp = host.format_matrix(sparse, 0, skip_empty_rows=True)
+    assert build(cp, 0, 256)["format"] == "owner24"
