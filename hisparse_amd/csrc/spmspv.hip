@@ -203,7 +203,15 @@ hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* 
     const uint32_t block_bits = spmspv_block_bits(num_rows), bins = spmspv_bins(num_rows);
     if (bins > kMaxBins) return hipErrorInvalidValue;
     if (x_count) {
-        const uint32_t columns = std::max<uint32_t>(1, std::min<uint32_t>(kExpandColumns, x_count / 512));      // >= 512 workgroups before they grow
+        // Entries of x per workgroup: ~1500 products each (a workgroup claims room with one global atomic per row block it touches -- with a
+        // column or two per workgroup that is nearly an atomic per PRODUCT on 71 addresses: ogbl-ppa 0.1 % 18.3 us -- and walks its products
+        // twice, 256 threads wide -- with 64 long columns per workgroup that walk is the critical path: mouse_gene 1 % 34-87 us), but at
+        // least ~128 workgroups while x has the entries for it.  Measured over 16 ... 512 workgroups-before-growth on three matrices
+        // (profiles/r04_spmspv_expand_columns.txt): ogbl-ppa 0.1 % 18.3 -> 9.9 us, 1 % 22.7 -> 19.3, pokec 0.1 % 17.6 -> 11.0, 1 % 21.9 -> 17.8.
+        const double avg_len = num_cols ? double(s.capacity) / double(num_cols) : 1.0;
+        uint32_t columns = uint32_t(std::max(1.0, std::min<double>(kExpandColumns, 1500.0 / std::max(1.0, avg_len))));
+        columns = std::min<uint32_t>(kExpandColumns, std::max(columns, x_count / 512));      // (beyond ~512 workgroups the claims add up again: ogbl-ppa 5 %, 57 columns 57 us, 20 columns 70)
+        columns = std::min(columns, std::max<uint32_t>(1, x_count / 128));
         const dim3 grid((x_count + columns - 1) / columns), block(kExpandThreads);
         const uint2* xe = reinterpret_cast<const uint2*>(x_entries);
         const uint32_t lds = bins * 8u;

@@ -166,8 +166,9 @@ int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32
  *     products in LDS and writes its rows) -- no scan, no sort, no copy command, no host synchronisation.  The result is a dense packed y of
  *     num_rows words: hs_read_spmspv_result.  An entry may name a column more than once (the products simply add up): a bin holds as many
  *     products as the matrix has non-zeros in its row block, so such a call is cut into passes of unique columns.
- *     CROSSOVER: the sparse path costs ~14 us + products / 45 G/s (measured, profiles/r04_spmspv_binned.txt: ogbl-ppa 0.05 % / 0.1 % / 1 % /
- *     5 % of the columns 16 / 22 / 26 / 59 us with host entries, against 63-68 us for the dense SpMV, which wins from ~6 %).  Beyond the
+ *     CROSSOVER: the sparse path costs ~10-14 us + products / 45 G/s (measured, profiles/r04_spmspv_binned.txt: ogbl-ppa 0.05 % / 0.1 % / 1 % /
+ *     5 % of the columns 14 / 14 / 24 / 61 us with host entries -- 10 / 10 / 20 / 56 with device entries --, against 62-68 us for the dense SpMV,
+ *     which wins from ~6 %).  Beyond the
  *     crossover hs_spmspv runs the DENSE SpMV instead -- x scattered
  *     into a zero vector, one hs_run -- PROVIDED hs_load_matrix / hs_load_matrix_csr of this context holds the same matrix (same shape
  *     after padding; that it IS the same matrix is the caller's contract) and x names no column twice.  The rule: the host knows the
