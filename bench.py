@@ -1,32 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py — SpMV throughput of the MI355X hot path on the reference's benchmark matrices.
+"""bench.py -- SpMV throughput of the MI355X hot path on the reference's benchmark matrices.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--npz FILE]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--npz FILE] [--quick]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
           or simply `python bench.py --gpus N`: without a launcher's WORLD_SIZE in the environment the script starts its N ranks itself
-          (the same torch.distributed.run command line, master on 127.0.0.1) and fails loudly -- a JSON error line, exit code 2 --
-          when the machine shows fewer than N GPUs.  It never prints an `n_gpus: 1` line for a `--gpus N > 1` request.
+          and fails loudly (a JSON error line, exit code 2) when the machine shows fewer than N GPUs.
 
-A "step" is one full SpMV (every row partition) y = A x through the drop-in C-ABI, with the matrix (re-tiled at load
-time), x and y already resident in HBM.  Metric (BASELINE.json): the reference's "data throughput" of
-sw/benchmark.cpp:312-346 — 8 bytes per non-zero per SpMV — in decimal GB/s, plus GOPS (2 flops per non-zero), the GiB-based
-number the reference prints, and the fraction of the 8 TB/s HBM roofline.
+A "step" is one full SpMV (every row partition) y = A x through the drop-in C-ABI, with the matrix (re-tiled at load time), x and y
+already resident in HBM.  Metric (BASELINE.json): the reference's "data throughput" of sw/benchmark.cpp:312-346 -- 8 bytes per non-zero
+per SpMV -- in decimal GB/s, with GOPS (2 flops per non-zero) and the fraction of the 8 TB/s HBM roofline.
 
-N = 1 (default): the headline line is BASELINE.json configs[1] — ogbl-ppa (seeded stand-in, hisparse_amd/datasets.py),
-fixed-point IMPL, default banks — and it is the LAST line printed.  In front of it the same process measures the other
-single-GPU configurations (transformer-50 / float_pob, ogbn-products / float_stall, mouse_gene / fixed: each with its
-parity check against the oracle) and embeds them as `per_config`, and re-measures the headline matrix ROUND-ROBIN over
-four different ogbl-ppa-sized matrices (1.1 GB of images, more than the 256 MiB Infinity Cache holds) as
-`roofline.frac_mall_cold`.  `--config NAME` measures only that configuration; `--quick` skips the extras.
+OUTPUT.  The LAST line of stdout is one JSON object of < 4 KB (the driver keeps an 8 KB tail of stdout and of stderr): the headline
+configuration -- BASELINE.json configs[1], ogbl-ppa (seeded stand-in, hisparse_amd/datasets.py), fixed point, default banks -- with
+`roofline` and `cpu_baseline`.  The three fractions are named for what they divide:
+    roofline.frac               8 nnz / (average duration of the SpMV kernel) / 8 TB/s -- hs_time_kernel: ONE HIP event pair around K
+                                back-to-back launches of the kernel alone; the figure rocprofv3 --stats gives (profiles/)
+    roofline.frac_whole_step    8 nnz / (wall time per step: kernel + slice-combine pass + launch gaps) / 8 TB/s   (= value / 8000)
+    roofline.frac_event_pairs   the kernel inside whole steps, a HIP event pair around EVERY launch (each pair adds ~3 us)
+Everything else a default run measures (the other BASELINE configurations, the reference's whole sweep sw/bm.sh in all numeric modes,
+MALL-cold round-robin legs, the strong-scaling prediction: bench_extras.py) goes to `bench_details.json` next to this file and, one row
+per matrix, to stderr.  `--config NAME` measures only that configuration; `--quick` skips the extras.
 
 N > 1 (BASELINE.json configs[4]): mouse_gene, ONE matrix split into N row slabs by non-zero count (`--scaling strong`;
 hisparse_amd/sharding.py), every rank formats and loads its slab and holds all of x.  Timed = `value`: K slab SpMVs and ONE final
-all-gather of the y slabs over RCCL (BASELINE.json's north_star: "a final RCCL gather over xGMI"; the reference too runs its NUM_RUNS
-launches and collects y once, sw/benchmark.cpp:318-346).  Timed alongside and reported in the same line: the same K SpMVs with y left
-sharded (`compute_only`), with an all-gather after EVERY SpMV as an iterative caller needs it (`exchange_every_step`: the gather of step
-k overlaps the SpMV of step k+1, double-buffered), and with that per-step gather done by peer stores instead of a collective
-(`exchange_push`).  `--scaling weak` gives every rank a slab the size of the whole N = 1 matrix instead; `--gather step|off` makes one
-of the other patterns the `value`.
+all-gather of the y slabs over RCCL (`gather: final`, north_star's "a final RCCL gather over xGMI"; the reference too runs its NUM_RUNS
+launches and collects y once, sw/benchmark.cpp:318-346).  In the same line: the same K SpMVs with y left sharded (`compute_only`),
+with an all-gather after EVERY SpMV (`exchange_every_step`) and with that gather done by peer stores (`exchange_push`).
+`--backend gloo --share-gpu` is the DRY RUN of that path on one GPU: N processes on GPU 0, the HIP engine, host-staged gloo collectives.
 """
 import argparse
 import json
@@ -40,6 +40,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 IMPL_NAMES = ["fixed", "float_pob", "float_stall"]
 SPIN_UP_STEPS = 1000    # untimed, at least: the clocks have dropped during the CPU legs (oracle, formatting)
+LINE_LIMIT = 4000       # bytes of the final JSON line (the driver's tail holds 8000)
+DETAILS_FILE = os.path.join(ROOT, "bench_details.json")
 
 
 def spin_up(eng, batch=200, max_batches=40):
@@ -59,6 +61,7 @@ def spin_up(eng, batch=200, max_batches=40):
         if flat >= 3 and n >= SPIN_UP_STEPS:
             break
     return n
+
 
 
 def log(rank, *a):
@@ -120,42 +123,6 @@ def read_traffic(config, stream_bytes, impl=None):
     return e.get("hbm_bytes_per_launch"), prov
 
 
-def spmm_probe(np, host, eng, impl, packets, rng, xw, k=8, reps=100):
-    """Dense-row (BITMAP) images: hs_spmm_device with k columns of X resident in HBM -- the fused kernel streams the matrix once per 4
-    columns (spmm_bitmap.hip) -- next to k SpMVs; column 0 is checked against the SpMV kernel's own answer (bit for bit)."""
-    import ctypes as C
-    rt = C.CDLL("libamdhip64.so")
-    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    rt.hipFree.argtypes = [C.c_void_p]
-    X = rng.normal(size=(k, packets.num_cols)).astype(np.float32) if impl else rng.uniform(0.0, 2.0, (k, packets.num_cols)).astype(np.float32)
-    Xw = np.stack([host.pack_vector(impl, X[j]) for j in range(k)])
-    xd, yd = C.c_void_p(), C.c_void_p()
-    if rt.hipMalloc(C.byref(xd), Xw.nbytes) or rt.hipMalloc(C.byref(yd), k * packets.num_rows * 4) or rt.hipMemcpy(xd, Xw.ctypes.data, Xw.nbytes, 1):
-        return None
-    try:
-        for _ in range(20):
-            eng.spmm_device(xd.value, packets.num_cols, yd.value, packets.num_rows, k)
-        eng.sync()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            eng.spmm_device(xd.value, packets.num_cols, yd.value, packets.num_rows, k)
-        eng.sync()
-        us = (time.perf_counter() - t0) / reps * 1e6
-        y0 = np.empty(packets.num_rows, dtype=np.uint32)
-        rt.hipMemcpy(y0.ctypes.data, yd, y0.nbytes, 2)
-        eng.load_vector(Xw[0])
-        eng.run()
-        same = bool(np.array_equal(y0, eng.read_result()))
-        eng.load_vector(xw)            # the context's own vector as the caller left it
-    finally:
-        rt.hipFree(xd)
-        rt.hipFree(yd)
-    return {"k": k, "us_per_spmm": round(us, 2), "us_per_column": round(us / k, 2), "column_0_equals_spmv_bit_for_bit": same,
-            "note": "hs_spmm_device, X and Y resident; float BITMAP images: 5-16 columns per pass through the matrix engine (spmm_mfma.hip, sums in another "
-                    "order than the SpMV kernel: tolerance parity per column), fixed point: 4 columns per pass (spmm_bitmap.hip, bit for bit); reference: no SpMM"}
-
-
 def oracle_check(np, host, impl, packets, xw, y_gpu, seconds, exact=None):
     """(parity string, y of the oracle, seconds per oracle SpMV, repetitions, float error report or None) — oracle/cpu_ref.c, one
     thread, the same channel buffers.  exact: the float64 product (float modes), for the error of both against the exact result."""
@@ -194,6 +161,13 @@ PARITY_PINS = ("oracle/cpu_ref.c is pinned by the reference's own vectors where 
                "this repository's three independent restatements -- the reference holds no vector for them")
 
 
+
+
+def kernel_name(stats):
+    return ("spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_sweep_kernel" if stats["stream_format"] == 6
+            else "spmv_light_kernel" if stats.get("light_kernel") else "spmv_rowblock_kernel")
+
+
 def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0, npz=None, impl_override=None, cpu_seconds=0.0, rank=0, with_spmm=True):
     """One configuration on one GPU: load, parity against the oracle, K timed steps, HIP-event kernel time."""
     t0 = time.perf_counter()
@@ -213,9 +187,7 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
     eng.load_matrix(packets)
     eng.load_vector(xw)
     stats = eng.stats()
-    log(rank, f"{name}: {packets.num_rows}x{packets.num_cols}, nnz {nnz}, partitions {packets.num_row_partitions}x{packets.num_col_partitions}, "
-              f"generate {t_gen:.2f}s format {t_fmt:.2f}s device-load {stats['load_seconds']:.2f}s, CPSR {stats['cpsr_bytes']/1e6:.0f} MB -> "
-              f"{device.STREAM_FORMATS[stats['stream_format']]} stream {stats['stream_bytes']/1e6:.0f} MB")
+    fmt = device.STREAM_FORMATS[stats["stream_format"]] + (" (light kernel)" if stats.get("light_kernel") else "")
     eng.run()
     y_gpu = eng.read_result()
     exact = None
@@ -225,7 +197,8 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         exact = sp.csr_matrix((dv.astype(np.float64), ix.astype(np.int64), ip.astype(np.int64)), shape=(csr.num_rows, csr.num_cols)) @ x[:csr.num_cols].astype(np.float64)
         del ip, ix, dv
     parity, y_cpu, t_cpu, reps, float_error = oracle_check(np, host, impl, packets, xw, y_gpu, cpu_seconds, exact)
-    log(rank, f"{name}: oracle {t_cpu*1e3:.1f} ms per SpMV on 1 core; GPU result {parity}")
+    log(rank, f"{name}/{IMPL_NAMES[impl]}: {packets.num_rows}x{packets.num_cols} nnz {nnz} parts {packets.num_row_partitions}x{packets.num_col_partitions}; "
+              f"format {t_fmt:.2f}s load {stats['load_seconds']:.2f}s; CPSR {stats['cpsr_bytes']/1e6:.0f} MB -> {fmt} {stats['stream_bytes']/1e6:.0f} MB; oracle {t_cpu*1e3:.0f} ms: {short_parity(parity)}")
     if parity == "MISMATCH":
         print(json.dumps({"error": "GPU result does not match the oracle", "config": name}))
         sys.exit(1)
@@ -245,17 +218,14 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         eng.run()
         eng.sync()
     elapsed_sync = time.perf_counter() - t0
-    # Two HIP-event measurements, both reported; WHICH one prices the roofline is fixed by the plan, not by which came out smaller:
-    #   * one kernel per step (no slice-combine pass): two events around the K back-to-back launches / K -- an event pair around every
-    #     launch adds ~2 us to each, a fifth of a 14 us kernel (rocprofv3 agrees with the region figure);
-    #   * column-sliced plans (SpMV kernel + combine kernel per step): the event pair around every SpMV launch.
+    # HIP events, on the stream the kernels are launched on.  kernel_ms (prices roofline.frac): hs_time_kernel -- ONE event pair around
+    # K back-to-back launches of the SpMV kernel alone, / K = the average launch duration rocprofv3 --stats reports for it (plus the
+    # sub-microsecond dispatch gap).  Beside it: the kernel inside whole steps with an event pair around every launch (each pair adds
+    # ~3 us), and whole steps between two events.
+    kernel_ms = eng.time_kernel(min(warmup, 20), steps) / steps
     _, ev_kernel_ms = eng.time_runs(0, steps)
     region_ms, _ = eng.time_runs(0, steps, kernel=False)
     kernel_ms_pairs, step_ms_region = ev_kernel_ms / steps, region_ms / steps
-    if stats["col_slices"] == 1:
-        kernel_ms, kernel_ms_how = step_ms_region, "two HIP events around the K back-to-back launches / K (one kernel per step)"
-    else:
-        kernel_ms, kernel_ms_how = kernel_ms_pairs, "HIP event pair around every SpMV launch (the step has a second, slice-combine kernel)"
     ms = elapsed / steps * 1e3
     value = 8.0 * nnz / (elapsed / steps) / 1e9
     achieved = 8.0 * nnz / (kernel_ms * 1e-3) / 1e9
@@ -271,25 +241,30 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
     if not same or st2["stream_bytes"] != stats["stream_bytes"]:
         print(json.dumps({"error": "the CSR load path gives a different image or result than the CPSR path", "config": name}))
         sys.exit(1)
-    spmm = spmm_probe(np, host, eng, impl, packets, rng, xw) if device.STREAM_FORMATS[stats["stream_format"]] == "bitmap" and with_spmm else None
+    spmm = None
+    if with_spmm and device.STREAM_FORMATS[stats["stream_format"]] == "bitmap":
+        import bench_extras
+        spmm = bench_extras.spmm_probe(np, host, eng, impl, packets, rng, xw)
     traffic, traffic_from = read_traffic(name, stats["stream_bytes"], impl)
     res = {
+        "matrix": name, "impl": IMPL_NAMES[impl],
         "workload": f"{name}, {IMPL_NAMES[impl]} IMPL, v={packets.vb_bank} o={packets.ob_bank}",
         "rows": true_rows, "cols": packets.num_cols, "nnz": int(nnz), "partitions": f"{packets.num_row_partitions}x{packets.num_col_partitions}",
-        "stream_format": device.STREAM_FORMATS[stats["stream_format"]] + (" (light kernel)" if stats.get("light_kernel") else ""), "col_slices": stats["col_slices"],
+        "stream_format": fmt, "col_slices": stats["col_slices"],
         "ms_per_step": round(ms, 5), "value": round(value, 2), "unit": "GB/s", "gops": round(2.0 * nnz / (elapsed / steps) / 1e9, 2),
         "ms_per_step_synchronous": round(elapsed_sync / steps * 1e3, 5),
-        "value_synchronous": round(8.0 * nnz / (elapsed_sync / steps) / 1e9, 2),
         "spin_up_steps": spun,
         "gibps_reference_formula": round(8.0 * nnz / 2 ** 30 / (elapsed / steps), 2),
-        "hbm_roofline_fraction_whole_job": round(value / HBM_PEAK_GBS, 4),
-        "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_sweep_kernel" if stats["stream_format"] == 6 else "spmv_light_kernel" if stats.get("light_kernel") else "spmv_rowblock_kernel",
+        "frac_whole_step": round(value / HBM_PEAK_GBS, 4),
+        "roofline": {"bound": "hbm", "kernel": kernel_name(stats),
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "kernel_ms": round(kernel_ms, 5), "kernel_ms_from": kernel_ms_how, "kernel_ms_event_pairs": round(kernel_ms_pairs, 5),
-                     "step_ms_two_events_around_K_launches": round(step_ms_region, 5),
-                     "frac_event_pairs": round(8.0 * nnz / (kernel_ms_pairs * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(8 * nnz),
-                     "streamed_bytes_per_launch": int(stats["stream_bytes"]), "traffic": traffic, "traffic_provenance": traffic_from,
-                     "frac_rocprof": traffic_from.get("frac_rocprof"), "kernel_us_rocprof": traffic_from.get("kernel_us_rocprof")},
+                     "kernel_ms": round(kernel_ms, 5),
+                     "kernel_ms_from": "hs_time_kernel: one HIP event pair around K back-to-back launches of the kernel alone, / K",
+                     "frac_whole_step": round(value / HBM_PEAK_GBS, 4),
+                     "frac_event_pairs": round(8.0 * nnz / (kernel_ms_pairs * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "kernel_ms_event_pairs": round(kernel_ms_pairs, 5), "step_ms_two_events_around_K_steps": round(step_ms_region, 5),
+                     "algorithmic_bytes_per_launch": int(8 * nnz), "streamed_bytes_per_launch": int(stats["stream_bytes"]),
+                     "traffic": traffic, "traffic_from": traffic_from},
         "parity_vs_oracle": parity,
         "preprocess_s": {"format_csr2cpsr": round(t_fmt, 3), "device_load_retile": round(stats["load_seconds"], 3),
                          "device_load_from_csr_instead": round(st2["load_seconds"], 3)},
@@ -298,11 +273,23 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         res["float_error"] = float_error
     if spmm:
         res["spmm_extension"] = spmm
+    log(rank, f"{name}/{IMPL_NAMES[impl]}: step {ms*1e3:.1f} us = {value:.0f} GB/s = {value/HBM_PEAK_GBS*100:.1f} % whole step; kernel {kernel_ms*1e3:.1f} us = "
+              f"{achieved/HBM_PEAK_GBS*100:.1f} %; event pairs {kernel_ms_pairs*1e3:.1f} us")
     return res, dict(eng=eng, packets=packets, csr=csr, x=x, xw=xw, impl=impl, nnz=nnz, y_cpu=y_cpu, t_cpu=t_cpu, reps=reps, cfg=cfg)
 
 
+def short_parity(parity):
+    """the parity verdict in a few words (stderr rows): bit-exact | tol-ok | tol-ok, csim abs 1e-4 over on N rows | MISMATCH"""
+    if parity.startswith("bit-exact") or parity == "MISMATCH":
+        return parity
+    if "not met on" in parity:
+        return "tol-ok (csim abs 1e-4: over on " + parity.split("not met on ")[1].split(";")[0] + ")"
+    return "tol-ok"
+
+
 def cpu_baseline_for(np, host, ctx, rank):
-    """The reported CPU baseline: the oracle (csim-equivalent restatement) on one core + two context numbers."""
+    """(compact baseline for the line, the longer record for the details file): the oracle (csim-equivalent restatement) on one core, and
+    as context the same with one thread per cluster and a plain float32 CSR loop on the host cores."""
     from oracle import oracle as orc
     packets, impl, nnz, xw, x, csr, y_cpu = ctx["packets"], ctx["impl"], ctx["nnz"], ctx["xw"], ctx["x"], ctx["csr"], ctx["y_cpu"]
     t_cpu, reps = ctx["t_cpu"], ctx["reps"]
@@ -310,6 +297,7 @@ def cpu_baseline_for(np, host, ctx, rank):
     base = {"value": round(8.0 * nnz / t_cpu / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
             "sample": f"{reps} full SpMV(s) of the same matrix through oracle/cpu_ref.c (csim-equivalent restatement, 1 thread), {t_cpu*1e3:.1f} ms each",
             "gops": round(2.0 * nnz / t_cpu / 1e9, 4), "host_cpus": orc.usable_cores()}
+    more = {}
     try:   # context only: the same restatement with one host thread per cluster (the 16 clusters are independent)
         threads = min(16, orc.usable_cores())
         t0 = time.perf_counter()
@@ -317,7 +305,7 @@ def cpu_baseline_for(np, host, ctx, rank):
                                              packets.num_col_partitions, packets.ob_bank, packets.vb_bank, threads=threads)
         t_par = time.perf_counter() - t0
         if np.array_equal(y_par, y_cpu):
-            base["cpsr_one_thread_per_cluster"] = {"value": round(8.0 * nnz / t_par / 1e9, 3), "unit": "GB/s", "cores": threads,
+            more["cpsr_one_thread_per_cluster"] = {"value": round(8.0 * nnz / t_par / 1e9, 3), "unit": "GB/s", "cores": threads,
                                                    "gops": round(2.0 * nnz / t_par / 1e9, 3), "sample": f"1 SpMV, {t_par*1e3:.1f} ms"}
     except Exception as e:
         log(rank, f"per-cluster-thread baseline skipped: {e}")
@@ -335,128 +323,59 @@ def cpu_baseline_for(np, host, ctx, rank):
             if best is None or t_omp < best[0]:
                 best = (t_omp, threads)
         t_omp, threads = best
-        base["csr_openmp_best_thread_count"] = {"value": round(8.0 * nnz / t_omp / 1e9, 3), "unit": "GB/s", "cores": threads,
+        more["csr_openmp_best_thread_count"] = {"value": round(8.0 * nnz / t_omp / 1e9, 3), "unit": "GB/s", "cores": threads,
                                                 "gops": round(2.0 * nnz / t_omp / 1e9, 3),
                                                 "sample": f"5 float32 CSR SpMVs, {t_omp*1e3:.2f} ms each (best of 16 / 64 / all host threads)"}
+        base["csr_openmp"] = {"value": more["csr_openmp_best_thread_count"]["value"], "cores": threads}
     except Exception as e:  # the context number must never break the bench line
         log(rank, f"csr_openmp baseline skipped: {e}")
-    return base
+    return base, dict(base, **more)
 
 
-def mall_cold(np, datasets, device, host, first, steps, warmup, rank):
-    """The same configuration ROUND-ROBIN over several different matrices of the same shape (other seeds), enough of them that their
-    stream images add up to >= 640 MB -- two and a half times the 256 MiB Infinity Cache -- so that nothing of an image can be left in
-    it when its turn comes again (ogbl-ppa: 4 x 291 MB; transformer-50: 16 x 37 MB; mouse_gene: 4 x 186 MB; ogbn-products: 2 x 877 MB).
-    All contexts launch on one stream; the result is a whole-job number (kernel + combine pass, launch gaps included), next to the
-    same loop over ONE image.  Images so small that 24 of them stay under 300 MB cannot be cooled this way (reported as such)."""
-    cfg = first["cfg"]
-    image = max(1, first["eng"].stats()["stream_bytes"])
-    count = max(2, min(24, -(-640_000_000 // image)))
-    if count * image < 300_000_000 or cfg.kind not in ("powerlaw", "bernoulli", "rmat"):
-        return {"images": 1, "frac_whole_job_round_robin": None,
-                "note": f"a {image/1e6:.1f} MB image: 24 of them would still fit the 256 MiB Infinity Cache; it lives in the caches by nature"}
-    engines, nnzs = [first["eng"]], [first["nnz"]]
-    stream = first["eng"].get_stream()
-    for k in range(1, count):
-        csr = host.CSRMatrix.generate(cfg.kind, cfg.rows, cfg.cols, a=cfg.a, b=cfg.b, c=cfg.c, seed=cfg.seed + 1000 * k)
-        eng = device.SpmvEngine(first["impl"])
-        eng.load_matrix_csr(csr)                 # (byte for byte the image the CPSR path builds: checked for the first matrix in measure_single)
-        eng.load_vector(first["xw"])
-        eng.set_stream(stream)
-        engines.append(eng)
-        nnzs.append(eng.stats()["nnz"])
-        del csr
-    image_mb = sum(e.stats()["stream_bytes"] for e in engines) / 1e6
-
-    def timed(order):
-        for _ in range(max(1, SPIN_UP_STEPS // len(order))):
-            for e in order:
-                e.run()
-        first["eng"].sync()
-        for i in range(warmup):
-            order[i % len(order)].run()
-        first["eng"].sync()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            order[i % len(order)].run()
-        first["eng"].sync()
-        return (time.perf_counter() - t0) / steps
-
-    t_rr = timed(engines)                 # the images in turn
-    t_one = timed(engines[:1])            # the same loop over one image (warm Infinity Cache), for comparison on equal terms
-    mean_nnz = sum(nnzs[i % count] for i in range(steps)) / steps
-    for e in engines[1:]:
-        e.set_stream(None)
-        e.close()
-    log(rank, f"{cfg.name}: round-robin over {count} images ({image_mb:.0f} MB): {t_rr*1e6:.1f} us per SpMV; one image: {t_one*1e6:.1f} us")
-    return {"images": count, "image_megabytes_total": round(image_mb, 1), "ms_per_step_round_robin": round(t_rr * 1e3, 5),
-            "ms_per_step_one_image_same_loop": round(t_one * 1e3, 5),
-            "frac_whole_job_round_robin": round(8.0 * mean_nnz / t_rr / 1e9 / HBM_PEAK_GBS, 4),
-            "frac_whole_job_one_image": round(8.0 * first["nnz"] / t_one / 1e9 / HBM_PEAK_GBS, 4)}
-
-
-def quote_hbm_fraction(res):
-    """Which whole-job number may be called "fraction of the HBM roofline": an image below 256 MiB lives in the Infinity Cache between the
-    launches of a loop over ONE matrix, so for those the MALL-cold (round-robin over > 256 MiB of images) figure is the HBM number and the
-    warm one is a cache number; larger images: the warm loop (they lose 0-2 points cold)."""
+def summary_row(res):
+    """one stderr row per measured (matrix, numeric mode): what the driver's 8 KB stderr tail should still hold"""
     r = res["roofline"]
-    small = r["streamed_bytes_per_launch"] < 256 * 2 ** 20
     cold = r.get("frac_mall_cold")
-    if small and cold is not None:
-        res["hbm_roofline_fraction_quoted"] = cold
-        res["hbm_roofline_fraction_quoted_from"] = "whole job, MALL-cold round-robin (the image fits the 256 MiB Infinity Cache: the warm loop is a cache number)"
-    else:
-        res["hbm_roofline_fraction_quoted"] = res["hbm_roofline_fraction_whole_job"]
-        res["hbm_roofline_fraction_quoted_from"] = "whole job, one image" + (" (image below 256 MiB and no cold leg measured: an Infinity-Cache number)" if small else "")
+    return (f"{res['matrix']}/{res['impl']}".ljust(28) + f"{res['stream_format'][:18]:<19}{res['col_slices']:>2} {res['ms_per_step']*1e3:8.1f} {res['value']:7.0f} "
+            f"{res['gops']:6.0f} {res['frac_whole_step']*100:6.1f} {r['frac']*100:6.1f} " + (f"{cold*100:6.1f}" if cold is not None else "     -") + "  " + short_parity(res["parity_vs_oracle"]))
 
 
-def predict_scaling(np, datasets, device, host, sharding, name, steps, rank, ways=(2, 4, 8)):
-    """Strong-scaling evidence that ONE GPU can give: for N in 2, 4, 8 every row slab of the N-way split
-    (sharding.split_rows_by_nnz, exactly what rank r of `bench.py --gpus N` loads) is timed on this GPU; the slowest slab bounds the
-    N-GPU compute-only step, so  efficiency(N) = t(unsplit) / (N x max slab time).  No collective is involved or predicted."""
-    cfg, full = datasets.load(name)
-    impl = host.impl_id(cfg.impl)
-    granule = 128 * (8 if impl == host.IMPL_FLOAT_STALL else 1)
-    indptr, indices, data = full.arrays()
-    rng = np.random.default_rng(2024)
-    cols8 = (full.num_cols + 7) // 8 * 8
-    x = rng.uniform(0.0, 2.0, cols8).astype(np.float32) if impl == host.IMPL_FIXED else rng.normal(size=cols8).astype(np.float32)
-    xw = host.pack_vector(impl, x)
+SUMMARY_HEAD = "matrix/impl".ljust(28) + "format".ljust(19) + "sl  us/step    GB/s   GOPS  %step %kernl  %cold  parity"
 
-    def step_us(csr):
-        with device.SpmvEngine(impl) as eng:
-            eng.load_matrix_csr(csr)
-            eng.load_vector(xw)
-            st = eng.stats()
-            for _ in range(SPIN_UP_STEPS // 2):
-                eng.run()
-            eng.sync()
-            best = 1e9
-            for _ in range(3):
-                region_ms, _ = eng.time_runs(5, steps, kernel=False)
-                best = min(best, region_ms / steps)
-            return best * 1e3, st
 
-    t_whole, st_whole = step_us(full)
-    out = {"workload": f"{name}, {IMPL_NAMES[impl]} IMPL", "nnz": int(full.nnz), "unsplit_us": round(t_whole, 2),
-           "unsplit_plan": f"{device.STREAM_FORMATS[st_whole['stream_format']]}, {st_whole['col_slices']} slices, {st_whole['num_blocks']} blocks", "splits": []}
-    for n in ways:
-        bounds = sharding.split_rows_by_nnz(indptr, n, granule)
-        slabs = []
-        for r in range(n):
-            lo, hi = bounds[r], bounds[r + 1]
-            if hi == lo:
-                continue
-            ip, ix, dv = sharding.slab_arrays(indptr, indices, data, lo, hi)
-            t, st = step_us(host.CSRMatrix.from_arrays(hi - lo, full.num_cols, ip, ix, dv))
-            slabs.append({"rank": r, "rows": int(hi - lo), "nnz": int(ip[-1]), "us": round(t, 2),
-                          "plan": f"{device.STREAM_FORMATS[st['stream_format']]}, {st['col_slices']} slices, {st['num_blocks']} blocks"})
-        worst = max(s["us"] for s in slabs)
-        out["splits"].append({"n_gpus": n, "max_slab_us": worst, "mean_slab_us": round(sum(s["us"] for s in slabs) / len(slabs), 2),
-                              "predicted_compute_only_efficiency": round(t_whole / (n * worst), 4),
-                              "roofline_us_per_slab": round(8.0 * full.nnz / n / (HBM_PEAK_GBS * 1e9) * 1e6, 2), "slabs": slabs})
-        log(rank, f"{name} split {n} ways: slowest slab {worst:.1f} us against {t_whole:.1f} us unsplit -> predicted compute-only efficiency {t_whole / (n * worst) * 100:.0f} %")
-    return out
+def emit(out, details, rows, scaling=None):
+    """details -> bench_details.json; one row per matrix + the scaling prediction -> stderr; the compact line -> stdout, LAST."""
+    try:
+        with open(DETAILS_FILE, "w") as f:
+            json.dump(details, f, indent=1)
+        out["details"] = os.path.basename(DETAILS_FILE)
+        gp = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(gp):      # a gpurun call merges only this directory back
+            with open(os.path.join(gp, "bench_details.json"), "w") as f:
+                json.dump(details, f, indent=1)
+    except OSError as e:
+        log(0, f"details file not written: {e}")
+    if rows:
+        log(0, "summary (% of the 8 TB/s HBM roofline: whole step / kernel alone / whole step MALL-cold)")
+        log(0, SUMMARY_HEAD)
+        for r in rows:
+            log(0, r)
+    for s in scaling or []:
+        log(0, f"strong-scaling prediction {s['workload']}: unsplit {s['unsplit_us']} us; " + "; ".join(
+            f"{sp['n_gpus']} GPUs: slowest slab {sp['max_slab_us']} us -> {sp['predicted_compute_only_efficiency']*100:.0f} %"
+            + (f" (graph replay {sp['max_slab_us_graph']} us -> {sp['predicted_compute_only_efficiency_graph']*100:.0f} %)" if "max_slab_us_graph" in sp else "")
+            for sp in s["splits"]))
+    line = json.dumps(out)
+    if len(line) > LINE_LIMIT:      # never again a line the driver's tail cannot hold: drop the optional keys, longest first
+        for key in sorted((k for k in out if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                                        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_vs_oracle")),
+                          key=lambda k: -len(json.dumps(out[k]))):
+            del out[key]
+            line = json.dumps(out)
+            if len(line) <= LINE_LIMIT:
+                break
+    sys.stderr.flush()
+    print(line, flush=True)
 
 
 def fail(message, **extra):
@@ -496,6 +415,7 @@ def self_launch(args):
     sys.exit(0)
 
 
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -509,8 +429,10 @@ def main():
                     help="N > 1: what `value` times beside the K SpMVs: one all-gather of the y slabs at the end (default), one after every SpMV "
                          "(overlapped with the next), or none; the other patterns are reported alongside")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
-                    help="N > 1: nccl = RCCL over xGMI, one GPU per rank (the measurement).  gloo = the launcher / sharding self-test on host "
-                         "memory: needs HISPARSE_HIP_LIB=<libhisparse_cpu.so> (the separate host-thread build of the C-ABI); never a measurement")
+                    help="N > 1: nccl = RCCL over xGMI, one GPU per rank (the measurement).  gloo = self-tests, never a measurement: with "
+                         "--share-gpu the DRY RUN of the N-rank path on GPU 0 (HIP engine, host-staged collectives); without it the launcher / "
+                         "sharding self-test on host memory, which needs HISPARSE_HIP_LIB=<libhisparse_cpu.so>")
+    ap.add_argument("--share-gpu", action="store_true", help="--backend gloo: all N ranks open GPU 0 with the HIP library (dry run of the multi-GPU path on one GPU)")
     ap.add_argument("--quick", action="store_true", help="N = 1: headline only (no per-config runs, no round-robin leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -537,143 +459,74 @@ def main():
         return main_distributed(args, rank, local_rank, world)
 
     import numpy as np
-    from hisparse_amd import datasets, device, host
-
-    from hisparse_amd import sharding
-
-    def bm_entry(name, paper_gops, res, impl="fixed"):
-        """one line of the reference's sweep (sw/bm.sh) next to the paper's U280 figure for the same matrix and numeric mode (Table 3: fixed
-        point; Table 7: float_pob = "PB", float_stall = "RI")"""
-        row = {"matrix": name, "impl": impl, "nnz": res["nnz"], "partitions": res["partitions"], "stream_format": res["stream_format"], "col_slices": res["col_slices"],
-               "ms_per_step": res["ms_per_step"], "ms_per_step_synchronous": res["ms_per_step_synchronous"], "value": res["value"], "unit": "GB/s", "gops": res["gops"],
-               "hbm_roofline_fraction_whole_job": res["hbm_roofline_fraction_whole_job"], "frac": res["roofline"]["frac"], "frac_kernel": res["roofline"]["frac"],
-               "frac_rocprof": res["roofline"].get("frac_rocprof"), "frac_mall_cold": res["roofline"].get("frac_mall_cold"),
-               "kernel_ms": res["roofline"]["kernel_ms"], "streamed_bytes_per_launch": res["roofline"]["streamed_bytes_per_launch"],
-               "image_fits_infinity_cache": res["roofline"]["streamed_bytes_per_launch"] < 256 * 2 ** 20,
-               "parity_vs_oracle": res["parity_vs_oracle"],
-               "paper_gops_u280": paper_gops, "paper_table": "Table 3" if impl == "fixed" else "Table 7", "gops_vs_paper": round(res["gops"] / paper_gops, 1) if paper_gops else None}
-        if impl == "fixed":
-            row["paper_table3_gops_u280_fixed"] = paper_gops
-        if "float_error" in res:
-            row["float_error"] = res["float_error"]
-        return row
-
-    def float_sweep(already):
-        """The matrices the paper quotes in all three numeric modes (Table 7) in float_pob (o = 1024: 8 x the row partitions) and float_stall
-        (F = 8), each checked against the oracle at full size inside measure_single; `already`: (name, impl) -> res measured above."""
-        rows = []
-        for name, fx, pb, ri in datasets.BM_FLOAT:
-            for impl_name, paper in (("float_pob", pb), ("float_stall", ri)):
-                res = already.get((name, impl_name))
-                if res is None:
-                    res, ctx = measure_single(np, datasets, device, host, name, sub_steps, sub_warm, impl_override=impl_name, rank=rank, with_spmm=False)
-                    ctx["eng"].close()
-                    del ctx
-                fixed = already.get((name, "fixed"))
-                row = bm_entry(name, paper, res, impl_name)
-                if fixed is not None:      # VERDICT round 3, item 5: each within 5 points of the fixed-point figure, or a named cause
-                    row["fixed_point_fraction_whole_job"] = fixed["hbm_roofline_fraction_whole_job"]
-                    row["points_vs_fixed_point"] = round((res["hbm_roofline_fraction_whole_job"] - fixed["hbm_roofline_fraction_whole_job"]) * 100, 1)
-                rows.append(row)
-                log(rank, f"bm {name}/{impl_name}: {res['ms_per_step']*1e3:.1f} us per SpMV = {res['gops']:.0f} GOPS, {res['hbm_roofline_fraction_whole_job']*100:.1f} % of the HBM roofline "
-                          f"(paper {paper} GOPS); {res['parity_vs_oracle']}")
-        return rows
+    from hisparse_amd import datasets, device, host, sharding
+    import bench_extras
 
     sub_steps = max(20, min(args.steps, 200))
     sub_warm = min(args.warmup, 20)
     if args.predict_scaling:      # only the strong-scaling prediction (bench.py --predict-scaling [--config mouse_gene])
-        print(json.dumps({"predict_scaling": predict_scaling(np, datasets, device, host, sharding, args.config or "mouse_gene", sub_steps, rank)}), flush=True)
+        pred = bench_extras.predict_scaling(np, datasets, device, host, sharding, args.config or "mouse_gene", sub_steps, rank)
+        emit({"predict_scaling": {"workload": pred["workload"], "unsplit_us": pred["unsplit_us"],
+                                  "splits": [{k: v for k, v in sp.items() if k != "slabs"} for sp in pred["splits"]]}}, {"predict_scaling": pred}, [], [pred])
         return
-    if args.config == "bm":       # only the reference's sweep (sw/bm.sh runs it in the mode of its bitstream: --impl), the whole list as the last line
+    if args.config == "bm":       # only the reference's sweep (sw/bm.sh runs it in the mode of its bitstream: --impl)
         sweep_impl = args.impl or "fixed"
         paper7 = {n: {"fixed": fx, "float_pob": pb, "float_stall": ri} for n, fx, pb, ri in datasets.BM_FLOAT}
-        rows = []
+        rows, table = [], []
         for name, paper in datasets.BM_LIST:
             res, ctx = measure_single(np, datasets, device, host, name, sub_steps, sub_warm, impl_override=sweep_impl, rank=rank, with_spmm=False)
             ctx["eng"].close()
             del ctx
-            quoted = paper if sweep_impl == "fixed" else paper7.get(name, {}).get(sweep_impl)
-            rows.append(bm_entry(name, quoted, res, sweep_impl))
-            log(rank, f"bm {name}/{sweep_impl}: {res['ms_per_step']*1e3:.1f} us per SpMV = {res['gops']:.0f} GOPS ({res['hbm_roofline_fraction_whole_job']*100:.1f} % of the HBM roofline), paper {quoted}")
-        print(json.dumps({"metric": f"SpMV GBPS / GOPS per matrix of sw/bm.sh, {sweep_impl} IMPL, 1 x MI355X", "bm_list": rows}), flush=True)
+            rows.append(bench_extras.bm_entry(name, paper if sweep_impl == "fixed" else paper7.get(name, {}).get(sweep_impl), res, sweep_impl))
+            table.append(summary_row(res))
+        emit({"metric": f"SpMV GBPS / GOPS per matrix of sw/bm.sh, {sweep_impl} IMPL, 1 x MI355X",
+              "bm_list": [{k: r[k] for k in ("matrix", "ms_per_step", "value", "gops", "frac_whole_step", "frac")} for r in rows]}, {"bm_list": rows}, table)
         return
 
     headline = args.config or "ogbl_ppa"
-    per_config, bm_rows, scaling, scaling_more, float_rows = [], {}, None, [], []
+    details, table, scaling, bm_rows = {}, [], None, {}
     if not args.config and not args.quick:
-        # the three other single-GPU configurations of BASELINE.json + the second ogbl-ppa stand-in (symmetric R-MAT, SURVEY.md 8d),
-        # each also round-robin over enough images to be Infinity-Cache-cold
-        measured = {}      # (matrix, numeric mode) -> result, for the float sweep below
-        for name in ("transformer_50", "ogbn_products", "mouse_gene", "ogbl_ppa_rmat"):
-            res, ctx = measure_single(np, datasets, device, host, name, sub_steps, sub_warm, cpu_seconds=0.0, rank=rank)
-            cold = mall_cold(np, datasets, device, host, ctx, sub_steps, sub_warm, rank)
-            res["roofline"]["frac_mall_cold"] = cold["frac_whole_job_round_robin"]
-            res["roofline"]["mall_cold"] = cold
-            quote_hbm_fraction(res)
-            ctx["eng"].close()
-            del ctx
-            per_config.append(res)
-            if name == "mouse_gene":
-                bm_rows[name] = res
-            measured[(name, res["workload"].split(", ")[1].split(" ")[0])] = res
-            log(rank, f"{name}: {res['ms_per_step']*1e3:.1f} us per SpMV, kernel {res['roofline']['kernel_ms']*1e3:.1f} us = {res['roofline']['frac']*100:.1f} % of the HBM roofline")
-        # the rest of the reference's sweep (sw/bm.sh:3-17), in the numeric mode of the paper's Table 3
-        for name, _ in datasets.BM_LIST:
-            if name in ("ogbl_ppa", "mouse_gene"):
-                continue
-            res, ctx = measure_single(np, datasets, device, host, name, sub_steps, sub_warm, impl_override="fixed", rank=rank, with_spmm=False)
-            ctx["eng"].close()
-            del ctx
-            bm_rows[name] = res
-            measured[(name, "fixed")] = res
-            log(rank, f"bm {name}/fixed: {res['ms_per_step']*1e3:.1f} us per SpMV = {res['gops']:.0f} GOPS, {res['hbm_roofline_fraction_whole_job']*100:.1f} % of the HBM roofline")
-        # ... and the float modes of the sweep on the matrices the paper quotes in all three (Table 7; sw/bm.sh:19-35)
-        float_rows = float_sweep(measured)
-        scaling = predict_scaling(np, datasets, device, host, sharding, "mouse_gene", sub_steps, rank)
-        # the larger graphs, where row slabs are still 15-25 us of streaming (8-way split only: 1 + 8 loads each)
-        scaling_more = [predict_scaling(np, datasets, device, host, sharding, name, sub_steps, rank, ways=(8,)) for name in ("hollywood", "ogbn_products")]
+        suite, measured = bench_extras.run_suite(np, datasets, device, host, sharding, sub_steps, sub_warm, rank)
+        bm_rows = suite.pop("bm_rows")
+        details.update(suite)
+        scaling = suite["strong_scaling_prediction"]
+        table = [summary_row(r) for r in measured.values()]
     res, ctx = measure_single(np, datasets, device, host, headline, args.steps, args.warmup, npz=args.npz, impl_override=args.impl,
                               cpu_seconds=0.0 if args.no_cpu_baseline else args.cpu_seconds, rank=rank)
-    cpu_baseline = None if args.no_cpu_baseline else cpu_baseline_for(np, host, ctx, rank)
+    cpu_line, cpu_full = (None, None) if args.no_cpu_baseline else cpu_baseline_for(np, host, ctx, rank)
     if not args.quick and not args.npz:
-        cold = mall_cold(np, datasets, device, host, ctx, args.steps, args.warmup, rank)
+        cold = bench_extras.mall_cold(np, datasets, device, host, ctx, args.steps, args.warmup, rank)
         res["roofline"]["frac_mall_cold"] = cold["frac_whole_job_round_robin"]
-        res["roofline"]["mall_cold"] = cold
-        quote_hbm_fraction(res)
+        res["mall_cold"] = cold
+        bench_extras.quote_hbm_fraction(res)
     ctx["eng"].close()
     impl = ctx["impl"]
-    bm_rows[headline] = res
+    table.append(summary_row(res))
+    r = res["roofline"]
+    tf = r["traffic_from"]
+    roofline = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "kernel_ms_from", "frac_whole_step", "frac_event_pairs",
+                                  "algorithmic_bytes_per_launch", "streamed_bytes_per_launch", "traffic")}
+    roofline["frac_mall_cold"] = r.get("frac_mall_cold")
+    roofline["traffic_from"] = (f"{tf.get('source', '')}: round {tf.get('round')}, commit {tf.get('git_head')}, kernel sources unchanged since: {tf.get('sources_unchanged_since')}; "
+                                f"rocprofv3 kernel avg then {tf.get('kernel_us_rocprof')} us")[:400]
     out = {
-        "metric": "SpMV GBPS (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346; GOPS and % of the HBM roofline alongside)",
-        "value": res["value"], "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "spin_up_steps": res.get("spin_up_steps", SPIN_UP_STEPS),
+        "metric": "SpMV GBPS (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346)",
+        "value": res["value"], "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "u32 Q8.24 fixed point (u64 accumulate)" if impl == host.IMPL_FIXED else "f32",
+        "dtype": "u32 (Q8.24 fixed point, u64 row sums)" if impl == host.IMPL_FIXED else "f32",
         "data": "synthetic" if not args.npz else "file",
-        "config": {"workload": res["workload"], "rows": res["rows"], "cols": res["cols"], "nnz_per_gpu": res["nnz"], "nnz_total": res["nnz"],
-                   "partitions": res["partitions"], "stream_format": res["stream_format"], "parallelism": "row-slab x1"},
-        "gops": res["gops"], "gibps_reference_formula": res["gibps_reference_formula"],
-        "hbm_roofline_fraction_whole_job": res["hbm_roofline_fraction_whole_job"],
-        "hbm_roofline_fraction_quoted": res.get("hbm_roofline_fraction_quoted", res["hbm_roofline_fraction_whole_job"]),
-        "hbm_roofline_fraction_quoted_from": res.get("hbm_roofline_fraction_quoted_from", "whole job, one image"),
-        "ms_per_step_synchronous": res["ms_per_step_synchronous"], "value_synchronous": res["value_synchronous"],
-        "roofline": res["roofline"], "cpu_baseline": cpu_baseline, "parity_vs_oracle": res["parity_vs_oracle"], "parity_pins": PARITY_PINS,
-        "preprocess_s": res["preprocess_s"],
+        "config": {"workload": res["workload"], "rows": res["rows"], "cols": res["cols"], "nnz": res["nnz"],
+                   "partitions": res["partitions"], "stream_format": res["stream_format"], "col_slices": res["col_slices"], "parallelism": "row-slab x1"},
+        "gops": res["gops"], "gibps_reference_formula": res["gibps_reference_formula"], "ms_per_step_synchronous": res["ms_per_step_synchronous"],
+        "roofline": roofline, "cpu_baseline": cpu_line, "parity_vs_oracle": res["parity_vs_oracle"],
     }
     if "float_error" in res:
-        out["float_error"] = res["float_error"]
-    if "spmm_extension" in res:
-        out["spmm_extension"] = res["spmm_extension"]
-    if per_config:
-        out["per_config"] = per_config
-    if len(bm_rows) == len(datasets.BM_LIST):
-        out["bm_list"] = [bm_entry(name, paper, bm_rows[name]) for name, paper in datasets.BM_LIST]
-    if float_rows:
-        out["bm_list_float"] = float_rows
-    if scaling:
-        out["strong_scaling_prediction"] = scaling
-    if scaling_more:
-        out["strong_scaling_prediction_more"] = scaling_more
-    print(json.dumps(out), flush=True)
+        out["float_error"] = {k: res["float_error"][k] for k in ("max_abs_err_vs_csim", "max_abs_y", "rows_over_csim_absolute_1e-4")}
+    details["headline"] = dict(res, cpu_baseline=cpu_full, parity_pins=PARITY_PINS)
+    if len(bm_rows) + 1 == len(datasets.BM_LIST):
+        bm_rows[headline] = res
+        details["bm_list"] = [bench_extras.bm_entry(name, paper, bm_rows[name]) for name, paper in datasets.BM_LIST]
+    emit(out, details, table, scaling)
 
 
 def main_distributed(args, rank, local_rank, world):
@@ -684,25 +537,37 @@ def main_distributed(args, rank, local_rank, world):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    on_gpu = args.backend == "nccl"
+    rccl = args.backend == "nccl"
+    dry = args.backend == "gloo" and args.share_gpu      # N processes on GPU 0: everything of the N-rank path except RCCL itself
+    on_gpu = rccl or dry
+    gpu_id = local_rank if rccl else 0
+    if args.share_gpu and rccl:
+        if rank == 0:
+            fail("--share-gpu is the dry run over gloo (RCCL cannot run several ranks on one GPU): add --backend gloo")
+        sys.exit(2)
     if on_gpu:
         have = visible_gpus()
-        if local_rank >= have:
+        if gpu_id >= have:
             if rank == 0:
-                fail(f"{world} ranks over RCCL need {world} GPUs, {have} visible", n_gpus_requested=world, gpus_visible=have)
+                fail(f"{world} ranks over RCCL need {world} GPUs, {have} visible" if rccl else "--share-gpu needs one GPU, none visible", n_gpus_requested=world, gpus_visible=have)
             sys.exit(2)
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(gpu_id)
+        if os.path.basename(device._LIB_PATH) == "libhisparse_cpu.so":
+            if rank == 0:
+                fail("a GPU run with HISPARSE_HIP_LIB pointing at the host-thread library")
+            sys.exit(2)
     elif os.path.basename(device._LIB_PATH) == "libhisparse_hip.so":
         if rank == 0:
-            fail("--backend gloo is the launcher / sharding self-test on host memory: point HISPARSE_HIP_LIB at libhisparse_cpu.so "
-                 "(the HIP library has no host path and writes y to device memory)")
+            fail("--backend gloo without --share-gpu is the launcher / sharding self-test on host memory: point HISPARSE_HIP_LIB at "
+                 "libhisparse_cpu.so (the HIP library has no host path and writes y to device memory)")
         sys.exit(2)
     dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     dist.barrier()
     n_gpus = world
     name = args.config or "mouse_gene"
-    dev = f"cuda:{local_rank}" if on_gpu else "cpu"
-    spin_up_steps = SPIN_UP_STEPS if on_gpu else 0
+    dev = f"cuda:{gpu_id}" if on_gpu else "cpu"
+    ctl = dev if rccl else "cpu"                          # where the control-plane reductions (timings, flags) live
+    spin_up_steps = SPIN_UP_STEPS if rccl else (100 if dry else 0)
     cuda_sync = torch.cuda.synchronize if on_gpu else (lambda: None)
 
     # ---- workload: this rank's row slab ---------------------------------------------------------------------------------
@@ -710,7 +575,7 @@ def main_distributed(args, rank, local_rank, world):
     cfg = datasets.CONFIGS[name]
     impl = host.impl_id(args.impl or cfg.impl)
     granule = 128 * (8 if impl == host.IMPL_FLOAT_STALL else 1)
-    full_rows = None
+    full_rows, whole = None, None
     if args.scaling == "strong":
         _, full = datasets.load(name, path=args.npz)
         indptr, indices, data = full.arrays()
@@ -737,9 +602,7 @@ def main_distributed(args, rank, local_rank, world):
     rng = np.random.default_rng(2024)
     x = rng.uniform(0.0, 2.0, packets.num_cols).astype(np.float32) if impl == host.IMPL_FIXED else rng.normal(size=packets.num_cols).astype(np.float32)
     xw = host.pack_vector(impl, x)
-    if args.scaling != "strong":
-        whole = None
-    eng = device.SpmvEngine(impl, device_id=local_rank if on_gpu else 0)
+    eng = device.SpmvEngine(impl, device_id=gpu_id)
     eng.load_matrix(packets)
     eng.load_vector(xw)
     stats = eng.stats()
@@ -752,6 +615,9 @@ def main_distributed(args, rank, local_rank, world):
     chunk = max(rows_all)
     y_chunks = [torch.zeros(chunk, dtype=torch.int32, device=dev) for _ in range(2)]
     gathered = [torch.zeros(chunk * world, dtype=torch.int32, device=dev) for _ in range(2)]
+    if dry:      # host staging buffers of the gloo collective
+        stage_in = torch.zeros(chunk, dtype=torch.int32).pin_memory()
+        stage_out = torch.zeros(chunk * world, dtype=torch.int32).pin_memory()
     if on_gpu:
         main_stream = torch.cuda.Stream(device=dev)     # the legacy default stream has handle 0 = "the library's private stream"
         torch.cuda.set_stream(main_stream)
@@ -759,6 +625,16 @@ def main_distributed(args, rank, local_rank, world):
         eng.set_stream(main_stream.cuda_stream)
     pending = [None, None]
     step_no = [0]
+
+    def all_gather(dst, src, async_op=False):
+        """the y exchange: RCCL on device memory; in the dry run the same call pattern staged through host memory over gloo (synchronous)"""
+        if not dry:
+            return dist.all_gather_into_tensor(dst, src, async_op=async_op)
+        stage_in.copy_(src, non_blocking=True)
+        main_stream.synchronize()
+        dist.all_gather_into_tensor(stage_out, stage_in)
+        dst.copy_(stage_out, non_blocking=True)
+        return None
 
     def run_into(y_tensor):
         """one slab SpMV whose result lands in y_tensor: the kernels write straight into it (hs_bind_device_result); the host-memory
@@ -780,7 +656,7 @@ def main_distributed(args, rank, local_rank, world):
             pending[cur].wait()              # the gather that read this slab two steps ago (stream-level wait, no host sync)
             pending[cur] = None
         run_into(y_chunks[cur])
-        pending[cur] = dist.all_gather_into_tensor(gathered[cur], y_chunks[cur], async_op=True)
+        pending[cur] = all_gather(gathered[cur], y_chunks[cur], async_op=True)
 
     def sync():
         for i in (0, 1):
@@ -803,29 +679,33 @@ def main_distributed(args, rank, local_rank, world):
         for _ in range(steps):
             step(gather)
         if gather == "final":
-            dist.all_gather_into_tensor(gathered[0], y_chunks[0])
+            all_gather(gathered[0], y_chunks[0])
         sync()
         cuda_sync()
         dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     # ---- correctness of what is about to be timed: this rank's slab against the oracle, and the gathered buffer ------------------
     run_into(y_chunks[0])
-    dist.all_gather_into_tensor(gathered[0], y_chunks[0])
+    all_gather(gathered[0], y_chunks[0])
     sync()
     y_gpu = y_chunks[0][:packets.num_rows].cpu().numpy().view(np.uint32)
-    mine = gathered[0][rank * chunk: rank * chunk + packets.num_rows].cpu().numpy().view(np.uint32)
-    if not np.array_equal(mine, y_gpu):
+    everyone = gathered[0].cpu().numpy().view(np.uint32).reshape(world, chunk)
+    if not np.array_equal(everyone[rank, :packets.num_rows], y_gpu):
         print(json.dumps({"error": "all-gathered y differs from the local slab", "rank": rank}))
         sys.exit(1)
     parity, _, t_cpu, _, _ = oracle_check(np, host, impl, packets, xw, y_gpu, 0.0)
-    flag = torch.tensor([1.0 if parity == "MISMATCH" else 0.0], dtype=torch.float64, device=dev)
+    # ... and every OTHER rank's slot of the gathered buffer against that rank's own checksum (the layout the consumer of the gather sees)
+    sums = [None] * world
+    dist.all_gather_object(sums, int(y_gpu.astype(np.uint64).sum()))
+    layout_ok = all(int(everyone[r, :rows_all[r]].astype(np.uint64).sum()) == sums[r] for r in range(world))
+    flag = torch.tensor([1.0 if parity == "MISMATCH" or not layout_ok else 0.0], dtype=torch.float64, device=ctl)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     if flag.item() > 0:
         if rank == 0:
-            print(json.dumps({"error": "a rank's slab does not match the oracle", "config": name}))
+            print(json.dumps({"error": "a rank's slab does not match the oracle, or the gathered layout is wrong", "config": name}))
         sys.exit(1)
 
     # ---- timing: the exchange pattern asked for = `value`; the same SpMVs without any exchange alongside -------------------------
@@ -839,7 +719,7 @@ def main_distributed(args, rank, local_rank, world):
     if on_gpu:
         try:
             from hisparse_amd import peer_gather
-            pg = peer_gather.PeerGather(dist, rank, world, chunk, device_id=local_rank)
+            pg = peer_gather.PeerGather(dist, rank, world, chunk, device_id=gpu_id)
             push_no = [0]
 
             def push_step(_gather):
@@ -857,39 +737,33 @@ def main_distributed(args, rank, local_rank, world):
                 step = saved_step
             sync()
             dist.barrier()
-            mine_rows = [None] * world
-            dist.all_gather_object(mine_rows, packets.num_rows)
             ok = True
-            for b in (0, 1):      # both buffers against what RCCL gathered before the timing (same x, same matrix: the same y)
+            for b in (0, 1):      # both buffers against what the collective gathered before the timing (same x, same matrix: the same y)
                 got = pg.read(b)
-                ref = gathered[0].cpu().numpy().view(np.uint32).reshape(world, chunk)
                 for r in range(world):
-                    ok = ok and bool(np.array_equal(got[r, :mine_rows[r]], ref[r, :mine_rows[r]]))
-            flag2 = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=dev)
+                    ok = ok and bool(np.array_equal(got[r, :rows_all[r]], everyone[r, :rows_all[r]]))
+            flag2 = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=ctl)
             dist.all_reduce(flag2, op=dist.ReduceOp.MAX)
             dist.barrier()
             eng.bind_device_result(y_chunks[0].data_ptr())
             pg.close()
             push = {"ms_per_step": round(push_elapsed / args.steps * 1e3, 5), "ms_per_step_added": round((push_elapsed - compute_elapsed) / args.steps * 1e3, 5),
-                    "gathered_equals_rccl_gather_on_every_rank": flag2.item() == 0.0,
-                    "note": "hs_push_result: plain 16-byte stores into the peers' gather buffers (hipIpcOpenMemHandle), stream-ordered behind the SpMV; "
-                            "the ranks synchronise once around the K steps"}
+                    "equals_collective_on_every_rank": flag2.item() == 0.0}
         except Exception as e:      # noqa: BLE001 -- the push path is an extra measurement
-            push = {"error": f"{type(e).__name__}: {e}"}
+            push = {"error": f"{type(e).__name__}: {e}"[:200]}
             log(rank, f"peer-store gather skipped: {e}")
-    tot = torch.tensor([float(nnz)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(nnz)], dtype=torch.float64, device=ctl)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     total_nnz = float(tot.item())
     if on_gpu:
         eng.set_stream(None)
-    _, ev_kernel_ms = eng.time_runs(0, args.steps)
-    kernel_ms = ev_kernel_ms / args.steps
+    kernel_ms = eng.time_kernel(min(args.warmup, 20), args.steps) / args.steps
     dist.barrier()
     # strong scaling: the SAME matrix, unsplit, on rank 0's GPU alone -- the N = 1 point the N-GPU numbers of this workload belong to
     # (bench.py --gpus 1 without a launcher measures the ogbl-ppa headline instead)
     one_gpu = None
     if whole is not None:
-        with device.SpmvEngine(impl, device_id=local_rank if on_gpu else 0) as eng1:
+        with device.SpmvEngine(impl, device_id=gpu_id) as eng1:
             eng1.load_matrix_csr(whole)
             eng1.load_vector(xw)
             for _ in range(spin_up_steps + args.warmup):
@@ -900,8 +774,7 @@ def main_distributed(args, rank, local_rank, world):
                 eng1.run()
             eng1.sync()
             one = (time.perf_counter() - t1) / args.steps
-            one_gpu = {"n_gpus": 1, "ms_per_step": round(one * 1e3, 5), "value": round(8.0 * whole.nnz / one / 1e9, 2), "unit": "GB/s",
-                       "note": "the same matrix unsplit on rank 0's GPU, y in HBM (no exchange); measured while the other ranks wait"}
+            one_gpu = {"n_gpus": 1, "ms_per_step": round(one * 1e3, 5), "value": round(8.0 * whole.nnz / one / 1e9, 2), "unit": "GB/s"}
         del whole
     dist.barrier()
 
@@ -910,39 +783,35 @@ def main_distributed(args, rank, local_rank, world):
         per_step = elapsed / args.steps
         value = 8.0 * total_nnz / per_step / 1e9
         achieved = 8.0 * nnz / (kernel_ms * 1e-3) / 1e9
-        gather_text = {"step": " + all_gather(y) over RCCL every step (overlapped with the next SpMV)", "final": " + one final all_gather(y) over RCCL", "off": ""}[args.gather]
+        gather_text = {"step": " + all_gather(y) every step (overlapped with the next SpMV)", "final": " + one final all_gather(y)", "off": ""}[args.gather]
+        backend = ("nccl (RCCL)" if rccl else f"gloo, {world} processes sharing GPU 0, HIP engine, host-staged collectives: DRY RUN of the N-rank path, NOT a measurement" if dry
+                   else f"gloo on host memory with {os.path.basename(device._LIB_PATH)}: launcher self-test, NOT a measurement")
         out = {
-            "metric": "SpMV GBPS (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346; GOPS and % of the HBM roofline alongside)",
-            "value": round(value, 2), "unit": "GB/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "spin_up_steps": spin_up_steps,
+            "metric": "SpMV GBPS (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346)",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(per_step * 1e3, 5), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "backend": "nccl (RCCL)" if on_gpu else f"gloo on host memory with {os.path.basename(device._LIB_PATH)}: launcher self-test, NOT a measurement",
-            "dtype": "u32 Q8.24 fixed point (u64 accumulate)" if impl == host.IMPL_FIXED else "f32",
+            "backend": backend, "gather": args.gather,
+            "dtype": "u32 (Q8.24 fixed point, u64 row sums)" if impl == host.IMPL_FIXED else "f32",
             "data": "synthetic" if not args.npz else "file",
             "config": {"workload": f"{name}, {IMPL_NAMES[impl]} IMPL, v={packets.vb_bank} o={packets.ob_bank}", "rows": full_rows or true_rows * n_gpus,
                        "cols": packets.num_cols, "nnz_per_gpu": int(nnz), "nnz_total": int(total_nnz), "slab_rows_rank0": true_rows,
                        "parallelism": f"row-slab x{n_gpus}, balanced by non-zeros" + gather_text},
             "gops": round(2.0 * total_nnz / per_step / 1e9, 2),
-            "gibps_reference_formula": round(8.0 * total_nnz / 2 ** 30 / per_step, 2),
-            "hbm_roofline_fraction_whole_job": round(value / (HBM_PEAK_GBS * n_gpus), 4),
+            "frac_whole_step": round(value / (HBM_PEAK_GBS * n_gpus), 4),
             "compute_only": {"ms_per_step": round(compute_elapsed / args.steps * 1e3, 5), "value": round(8.0 * total_nnz / (compute_elapsed / args.steps) / 1e9, 2),
-                             "unit": "GB/s", "hbm_roofline_fraction": round(8.0 * total_nnz / (compute_elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4),
-                             "note": "the same K slab SpMVs with y left sharded in HBM, like the reference leaves it (sw/benchmark.cpp:318-338)"},
+                             "frac_whole_step": round(8.0 * total_nnz / (compute_elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * n_gpus), 4)},
             "same_workload_on_one_gpu": one_gpu,
-            "exchange": {"pattern": args.gather, "bytes_per_rank_per_gather": int(chunk) * 4,
-                         "ms_per_step_added": round((elapsed - compute_elapsed) / args.steps * 1e3, 5)},
+            "exchange": {"bytes_per_rank_per_gather": int(chunk) * 4, "ms_per_step_added": round((elapsed - compute_elapsed) / args.steps * 1e3, 5)},
             "exchange_every_step": {"ms_per_step": round(step_elapsed / args.steps * 1e3, 5),
-                                    "ms_per_step_added": round((step_elapsed - compute_elapsed) / args.steps * 1e3, 5),
-                                    "value": round(8.0 * total_nnz / (step_elapsed / args.steps) / 1e9, 2), "unit": "GB/s",
-                                    "note": "all_gather_into_tensor(y) over RCCL after EVERY SpMV, the gather of step k overlapping the SpMV of step k + 1"},
+                                    "value": round(8.0 * total_nnz / (step_elapsed / args.steps) / 1e9, 2)},
             "exchange_push": push,
-            "roofline": {"bound": "hbm", "kernel": "spmv_bitmap_kernel" if stats["stream_format"] == 2 else "spmv_sweep_kernel" if stats["stream_format"] == 6 else "spmv_rowblock_kernel", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": kernel_name(stats), "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "kernel_ms": round(kernel_ms, 5),
-                         "algorithmic_bytes_per_launch": int(8 * nnz), "streamed_bytes_per_launch": int(stats["stream_bytes"]), "traffic": None,
-                         "note": "rank 0's slab"},
+                         "kernel_ms_from": "hs_time_kernel on rank 0's slab: one HIP event pair around K back-to-back launches of the kernel alone, / K",
+                         "algorithmic_bytes_per_launch": int(8 * nnz), "streamed_bytes_per_launch": int(stats["stream_bytes"]), "traffic": None},
             "cpu_baseline": None if args.no_cpu_baseline else {"value": round(8.0 * nnz / t_cpu / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
                                                                "sample": f"rank 0's slab, 1 SpMV through oracle/cpu_ref.c (1 thread), {t_cpu*1e3:.1f} ms"},
-            "parity_vs_oracle": parity + " (every rank's slab)",
-            "preprocess_s": {"format_csr2cpsr": round(t_fmt, 3), "device_load_retile": round(stats["load_seconds"], 3)},
+            "parity_vs_oracle": parity + " (every rank's slab; gathered layout checked on every rank)",
         }
     eng.close()
     dist.barrier()
@@ -955,7 +824,8 @@ def main_distributed(args, rank, local_rank, world):
         except OSError:
             pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        details = dict(out, preprocess_s={"format_csr2cpsr": round(t_fmt, 3), "device_load_retile": round(stats["load_seconds"], 3)}, slab_rows=rows_all)
+        emit(out, {"distributed": details}, [])
 
 
 if __name__ == "__main__":

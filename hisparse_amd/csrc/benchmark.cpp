@@ -20,6 +20,13 @@
 //                                  per row partition (:318-338) instead of one launch for the whole SpMV
 //   --runs K                       NUM_RUNS (default 50, :29)
 //   --dump-x FILE / --dump-y FILE  raw little-endian u32 value words of the packed x / y (for the parity test)
+//   --verify [--verify-eps E]      the check of the reference's hardware harness (sw/host.cpp:33-74,370; spmv_csim/csim.cpp:143-184): y is read
+//                                  back, converted to float, and compared with a float32 CSR loop over the matrix as loaded (before the
+//                                  conversion to the device's value type) and the float x, |difference| < 1e-4 ABSOLUTE (E replaces it);
+//                                  prints the verdict, the first failing row and the largest difference; exit code 3 on failure
+//   --share-gpu                    with --gpus N: all N contexts on ONE device (the [device] argument) -- the dry run of the row-slab path on a
+//                                  single-GPU machine: slabs, streams, result binding and the gather by peer stores (hs_push_result) all run;
+//                                  only RCCL is left out (it cannot place two ranks on one device).  Never a measurement.
 //   --gpus N [--no-gather] [--peer-gather]   (--peer-gather: also time the gather as peer stores over xGMI, hs_push_result, no collective)
 //   --gpus N [--no-gather]         shard the matrix by row slabs (hisparse/row_sharding.h) over devices 0..N-1 of this node:
 //                                  one hs_context per device, this one host thread issuing to the N streams, and one
@@ -29,6 +36,7 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +70,9 @@ struct Options {
     bool gather = true;
     bool peer_gather = false;   // --peer-gather: ALSO time the gather as peer stores over xGMI (hs_push_result) instead of ncclAllGather
     bool sharded = false;   // take the multi-GPU path even with one GPU (exercises RCCL on a single-GPU box)
+    bool share_gpu = false; // --gpus N on ONE device: N contexts, N streams, gather by peer stores; no RCCL (dry run of the N-GPU path)
+    bool verify = false;    // read y back and check it against a float CSR loop (sw/host.cpp:33-74)
+    double verify_eps = 1e-4;
 };
 
 struct benchmark_result {
@@ -125,6 +136,46 @@ std::vector<uint32_t> make_vector(int impl, uint32_t num_cols) {
     std::vector<uint32_t> vector(num_cols);
     hisparse::pack_vector(impl, vector_f.data(), vector_f.size(), vector.data());
     return vector;
+}
+
+// ---- --verify: the reference harness's own check (sw/host.cpp:33-74,370; spmv_csim/csim.cpp:143-184), restated ---------------------------
+// compute_ref: ref[row] += mat.adj_data[i] * vector[idx] in float32 over the float matrix and the float vector; verify: every
+// |float(kernel result) - ref| < epsilon (absolute, 1e-4).  float(VAL_T): Q8.24 raw / 2^24, or the fp32 bits themselves.
+// The vector is given as packed words (what the device multiplied by) and converted back: for rand() % 2 that is exact in both modes.
+float word_to_float(int impl, uint32_t w) {
+    if (impl == hisparse::IMPL_FIXED) return float(double(w) / 16777216.0);
+    float f;
+    std::memcpy(&f, &w, 4);
+    return f;
+}
+bool verify_result(const Options& o, const spmv::io::CSRMatrix<float>& mat, const std::vector<uint32_t>& x_words, const std::vector<uint32_t>& y_words) {
+    std::vector<float> x(x_words.size());
+    for (size_t i = 0; i < x.size(); ++i) x[i] = word_to_float(o.impl, x_words[i]);
+    uint64_t bad = 0, first_bad = 0;
+    double worst = 0.0;
+    uint32_t worst_row = 0;
+    float first_ref = 0, first_got = 0;
+    for (uint32_t row = 0; row < mat.num_rows; ++row) {
+        float ref = 0.0f;
+        for (uint32_t i = mat.adj_indptr[row]; i < mat.adj_indptr[row + 1]; ++i) ref += mat.adj_data[i] * x[mat.adj_indices[i]];
+        const float got = row < y_words.size() ? word_to_float(o.impl, y_words[row]) : 0.0f;
+        const double d = std::fabs(double(got) - double(ref));
+        if (d > worst || d != d) { worst = d; worst_row = row; }
+        if (!(d < o.verify_eps)) {
+            if (!bad) { first_bad = row; first_ref = ref; first_got = got; }
+            ++bad;
+        }
+    }
+    if (bad) {
+        std::cout << "Error: Result mismatch" << std::endl;
+        std::cout << "  i = " << first_bad << "  Reference result = " << first_ref << "  Kernel result = " << first_got << std::endl;
+        std::cout << "INFO : verify FAILED: " << bad << " of " << mat.num_rows << " rows differ by " << o.verify_eps << " or more (largest difference " << worst
+                  << " at row " << worst_row << ")" << std::endl;
+        return false;
+    }
+    std::cout << "INFO : verify PASSED: " << mat.num_rows << " rows within " << o.verify_eps << " absolute of the float32 CSR loop (largest difference " << worst
+              << " at row " << worst_row << ")" << std::endl;
+    return true;
 }
 
 struct DeviceSlab {   // one device's share of the matrix
@@ -217,6 +268,7 @@ benchmark_result spmv_benchmark(const Options& o, spmv::io::CSRMatrix<float>& ex
     dump_words(o.dump_x, vector);
     dump_words(o.dump_y, result);
     hs_destroy(ctx);
+    if (o.verify && !verify_result(o, ext_matrix, vector, result)) std::exit(3);
     return res;
 }
 
@@ -225,13 +277,15 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
     using clock = std::chrono::steady_clock;
     benchmark_result res{};
     const int N = o.gpus;
+    const bool share = o.share_gpu;                       // dry run: every slab on device o.device, no RCCL
+    auto dev_of = [&](int d) { return share ? o.device : d; };
     int visible = 0;
     hip_check(hipGetDeviceCount(&visible), "hipGetDeviceCount");
-    if (N > visible) {
+    if (share ? o.device >= visible : N > visible) {
         std::cout << "ERROR : --gpus " << N << " but only " << visible << " device(s) visible" << std::endl;
         std::exit(EXIT_FAILURE);
     }
-    std::cout << "INFO : Test started (" << N << " GPUs, row slabs)" << std::endl;
+    std::cout << "INFO : Test started (" << N << (share ? " row slabs sharing ONE GPU: dry run of the multi-GPU path, not a measurement)" : " GPUs, row slabs)") << std::endl;
     const auto t0 = clock::now();
     hisparse::Geometry g = hisparse::make_geometry(o.impl, o.ob_bank_size, o.vb_bank_size);
     const uint32_t true_rows = ext_matrix.num_rows;
@@ -262,13 +316,13 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
     std::vector<uint32_t*> gathered(N, nullptr);   // per device: N chunks; the device's own slab is written in place at chunk d
     std::vector<ncclComm_t> comm(N);
     for (int d = 0; d < N; ++d) devlist[d] = d;
-    nccl_check(ncclCommInitAll(comm.data(), N, devlist.data()), "ncclCommInitAll");
+    if (!share) nccl_check(ncclCommInitAll(comm.data(), N, devlist.data()), "ncclCommInitAll");
     for (int d = 0; d < N; ++d) {
-        hip_check(hipSetDevice(d), "hipSetDevice");
+        hip_check(hipSetDevice(dev_of(d)), "hipSetDevice");
         hip_check(hipStreamCreateWithFlags(&stream[d], hipStreamNonBlocking), "hipStreamCreate");
         hip_check(hipMalloc(reinterpret_cast<void**>(&gathered[d]), size_t(chunk) * N * 4), "hipMalloc");
         hip_check(hipMemset(gathered[d], 0, size_t(chunk) * N * 4), "hipMemset");
-        load_slab(slab[d], o, d, vector);
+        load_slab(slab[d], o, dev_of(d), vector);
         check(hs_set_stream(slab[d].ctx, stream[d]), slab[d].ctx, "hs_set_stream");
         check(hs_bind_device_result(slab[d].ctx, gathered[d] + size_t(d) * chunk), slab[d].ctx, "hs_bind_device_result");
     }
@@ -288,10 +342,11 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
     // the others' streams when its slab has been pushed.  With one device (--sharded) the "peer" is a second buffer on the same device.
     std::vector<hipEvent_t> pushed(N, nullptr);
     std::vector<uint32_t*> loopback(N, nullptr);
-    if (o.peer_gather) {
+    const bool peer_gather = o.peer_gather || share;      // sharing one device: the peer stores ARE the gather
+    if (peer_gather) {
         for (int d = 0; d < N; ++d) {
-            hip_check(hipSetDevice(d), "hipSetDevice");
-            for (int p = 0; p < N; ++p)
+            hip_check(hipSetDevice(dev_of(d)), "hipSetDevice");
+            for (int p = 0; p < N && !share; ++p)
                 if (p != d) {
                     const hipError_t e = hipDeviceEnablePeerAccess(p, 0);
                     if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hip_check(e, "hipDeviceEnablePeerAccess");
@@ -304,7 +359,7 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
             }
         }
     }
-    if (o.peer_gather && N - 1 > 8) {      // hs_push_result: at most 8 destinations (dst[8] below)
+    if (peer_gather && N - 1 > 8) {      // hs_push_result: at most 8 destinations (dst[8] below)
         std::fprintf(stderr, "--peer-gather: at most 9 GPUs (a slab is pushed to 8 peers)\n");
         std::exit(2);
     }
@@ -316,18 +371,18 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
                 if (p != d) dst[n++] = gathered[p] + size_t(d) * chunk;
             if (N == 1) dst[n++] = loopback[d];
             check(hs_push_result(slab[d].ctx, dst, n, chunk), slab[d].ctx, "hs_push_result");
-            hip_check(hipSetDevice(d), "hipSetDevice");
+            hip_check(hipSetDevice(dev_of(d)), "hipSetDevice");
             hip_check(hipEventRecord(pushed[d], stream[d]), "hipEventRecord");
         }
         for (int d = 0; d < N; ++d) {      // nobody goes on (e.g. to an SpMV that reads the gathered y as its x) before every slab has arrived
-            hip_check(hipSetDevice(d), "hipSetDevice");
+            hip_check(hipSetDevice(dev_of(d)), "hipSetDevice");
             for (int p = 0; p < N; ++p)
                 if (p != d) hip_check(hipStreamWaitEvent(stream[d], pushed[p], 0), "hipStreamWaitEvent");
         }
     };
     auto sync_all = [&]() {
         for (int d = 0; d < N; ++d) {
-            hip_check(hipSetDevice(d), "hipSetDevice");
+            hip_check(hipSetDevice(dev_of(d)), "hipSetDevice");
             hip_check(hipStreamSynchronize(stream[d]), "hipStreamSynchronize");
         }
     };
@@ -346,11 +401,15 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
     fill_result(compute_only, double(nnz_total), compute_ms);
     std::cout << "  compute only (y left sharded, like the reference leaves it in HBM): " << compute_only << std::endl;
     if (o.gather) {
-        const double both_ms = timed(1);
-        fill_result(res, double(nnz_total), both_ms);
-        std::cout << "  compute + one all-gather of y per SpMV (RCCL, " << chunk * 4.0 / 1e3 << " kB per rank): " << res << std::endl;
-        std::cout << "  all-gather cost per SpMV: " << (both_ms - compute_ms) * 1e3 << " us" << std::endl;
-        if (o.peer_gather) {
+        if (!share) {
+            const double both_ms = timed(1);
+            fill_result(res, double(nnz_total), both_ms);
+            std::cout << "  compute + one all-gather of y per SpMV (RCCL, " << chunk * 4.0 / 1e3 << " kB per rank): " << res << std::endl;
+            std::cout << "  all-gather cost per SpMV: " << (both_ms - compute_ms) * 1e3 << " us" << std::endl;
+        } else {
+            res = compute_only;
+        }
+        if (peer_gather) {
             const double peer_ms = timed(2);
             benchmark_result peer = res;
             fill_result(peer, double(nnz_total), peer_ms);
@@ -364,9 +423,9 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
             bool same = true;
             for (int d = 0; d < N && same; ++d) {
                 const int reader = N == 1 ? 0 : (d + 1) % N;
-                hip_check(hipSetDevice(reader), "hipSetDevice");
+                hip_check(hipSetDevice(dev_of(reader)), "hipSetDevice");
                 hip_check(hipMemcpy(a.data(), N == 1 ? loopback[d] : gathered[reader] + size_t(d) * chunk, size_t(chunk) * 4, hipMemcpyDeviceToHost), "hipMemcpy");
-                hip_check(hipSetDevice(d), "hipSetDevice");
+                hip_check(hipSetDevice(dev_of(d)), "hipSetDevice");
                 hip_check(hipMemcpy(b.data(), gathered[d] + size_t(d) * chunk, size_t(chunk) * 4, hipMemcpyDeviceToHost), "hipMemcpy");
                 same = a == b;
             }
@@ -380,26 +439,30 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
 
     // y in natural row order from device 0's gathered buffer (or slab by slab without the gather)
     spmv_all();
-    if (o.gather) gather_all();
+    if (o.gather) { if (share) push_all(); else gather_all(); }
     sync_all();
     std::vector<uint32_t> result(true_rows, 0), tmp(chunk);
     for (int d = 0; d < N; ++d) {
         const int src = o.gather ? 0 : d;
-        hip_check(hipSetDevice(src), "hipSetDevice");
+        hip_check(hipSetDevice(dev_of(src)), "hipSetDevice");
         hip_check(hipMemcpy(tmp.data(), gathered[src] + size_t(d) * chunk, size_t(chunk) * 4, hipMemcpyDeviceToHost), "hipMemcpy");
         std::copy(tmp.begin(), tmp.begin() + (bounds[d + 1] - bounds[d]), result.begin() + bounds[d]);
     }
     dump_words(o.dump_x, vector);
     dump_words(o.dump_y, result);
     for (int d = 0; d < N; ++d) {
-        hip_check(hipSetDevice(d), "hipSetDevice");
+        hip_check(hipSetDevice(dev_of(d)), "hipSetDevice");
         check(hs_set_stream(slab[d].ctx, nullptr), slab[d].ctx, "hs_set_stream");
         hs_destroy(slab[d].ctx);
-        ncclCommDestroy(comm[d]);
+        if (!share) ncclCommDestroy(comm[d]);
         if (pushed[d]) hip_check(hipEventDestroy(pushed[d]), "hipEventDestroy");
         if (loopback[d]) hip_check(hipFree(loopback[d]), "hipFree");
         hip_check(hipFree(gathered[d]), "hipFree");
         hip_check(hipStreamDestroy(stream[d]), "hipStreamDestroy");
+    }
+    if (o.verify) {      // the assembled y against the float CSR loop over the UNSPLIT matrix
+        std::vector<uint32_t> x_true(vector.begin(), vector.begin() + std::min<size_t>(vector.size(), padded_cols));
+        if (!verify_result(o, ext_matrix, x_true, result)) std::exit(3);
     }
     return res;
 }
@@ -422,6 +485,9 @@ bool parse_args(int argc, char** argv, Options& o) {
         else if (a == "--no-gather") o.gather = false;
         else if (a == "--peer-gather") o.peer_gather = true;
         else if (a == "--sharded") o.sharded = true;
+        else if (a == "--share-gpu") o.share_gpu = true;
+        else if (a == "--verify") o.verify = true;
+        else if (a == "--verify-eps") { o.verify = true; o.verify_eps = std::atof(need("--verify-eps").c_str()); }
         else if (a == "--device") o.device = std::atoi(need("--device").c_str());
         else if (a.rfind("--", 0) == 0) { std::cout << "ERROR : unknown option " << a << std::endl; return false; }
         else pos.push_back(a);
@@ -446,7 +512,7 @@ int main(int argc, char** argv) {
     Options o;
     if (!parse_args(argc, argv, o)) {
         std::cout << "Usage: " << argv[0] << " <fixed|float_pob|float_stall> <dataset.npz | synth:kind:rows:cols:a:b:c:seed> <v> <o> [device]"
-                  << " [--values literal|intent|keep] [--from-csr] [--partition-loop] [--runs K] [--dump-x FILE] [--dump-y FILE] [--gpus N [--no-gather] [--peer-gather] [--sharded]]" << std::endl;
+                  << " [--values literal|intent|keep] [--from-csr] [--partition-loop] [--runs K] [--dump-x FILE] [--dump-y FILE] [--gpus N [--no-gather] [--peer-gather] [--sharded] [--share-gpu]] [--verify [--verify-eps E]]" << std::endl;
         return 0;
     }
     std::cout << "------ Running benchmark on " << o.dataset << std::endl;
@@ -488,7 +554,7 @@ int main(int argc, char** argv) {
         // the intent of that line, a small non-degenerate constant, so that the result is worth reading back
         for (auto& x : mat_f.adj_data) x = 1.0f / float(mat_f.num_cols);
     }
-    std::cout << (o.gpus > 1 || o.sharded ? spmv_benchmark_multi(o, mat_f, true) : spmv_benchmark(o, mat_f, true)) << std::endl;
+    std::cout << (o.gpus > 1 || o.sharded || o.share_gpu ? spmv_benchmark_multi(o, mat_f, true) : spmv_benchmark(o, mat_f, true)) << std::endl;
     std::cout << "===== Benchmark Finished =====" << std::endl;
     return 0;
 }

@@ -283,6 +283,8 @@ int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* 
     return HS_OK;
 }
 
+int hs_time_kernel(hs_context* ctx, int warmup, int runs, float* kernel_ms) { return hs_time_runs(ctx, warmup, runs, nullptr, kernel_ms); }
+
 // ---- not part of this backend: device-memory hooks and the extensions ---------------------------------------------------------
 #define HS_CPU_UNSUPPORTED(ctx) return fail(ctx, HS_ERR_UNSUPPORTED, std::string(__func__) + " is not part of the CPU backend (libhisparse_cpu.so)")
 int hs_set_option(hs_context* ctx, const char*, const char*) { HS_CPU_UNSUPPORTED(ctx); }
@@ -299,6 +301,7 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t*, const uint32_t*, const 
 int hs_spmspv(hs_context* ctx, const hs_idx_val*, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_spmspv_device(hs_context* ctx, const hs_idx_val*, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_read_spmspv_result(hs_context* ctx, void*, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
+int hs_spmspv_status(hs_context* ctx, uint32_t*, void**) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_spmm_device(hs_context* ctx, const void*, uint64_t, void*, uint64_t, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_spmm(hs_context* ctx, const void*, uint32_t, uint32_t, void*, uint32_t) { HS_CPU_UNSUPPORTED(ctx); }
 int hs_debug_read_tiles(hs_context* ctx, void*, uint64_t, void*, void*) { HS_CPU_UNSUPPORTED(ctx); }

@@ -54,6 +54,7 @@ struct hs_context {
     uint32_t format = 0;           // StreamFormat of d_image
     bool light = false;            // the LIGHT plan: d_image is a PAIRS image run by spmv_light_kernel (stream_tiles.h)
     uint32_t* d_partial = nullptr;  // col_slices > 1: per-slice partial results, col_slices x num_rows words
+    uint32_t* d_arrivals = nullptr; // col_slices > 1 with the combine folded into the SpMV kernel (spmv_device.h: SliceJoin): one zeroed word per row
     uint32_t max_block_rows = 0;
     uint32_t* d_x_interleaved = nullptr;   // fused SpMM over a BITMAP image: 4 columns of X as [column][vector] words (allocated on first use)
     // SpMM on the matrix engine (float BITMAP matrices): the second image + scratch (spmm_mfma.hip)
@@ -120,9 +121,9 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 
 // hs_set_option's keys (the HISPARSE_<KEY> environment switches the library understands); plan-time ones take effect at the next load
 const char* const kOptionKeys[] = {
-    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG", "FORMAT_THREADS",
+    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
     "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS", "SWEEP",
-    "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "ITERATE_COOPERATIVE",
+    "SLICE_JOIN", "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH",
 };
 
 void free_matrix(hs_context* c) {
@@ -134,6 +135,8 @@ void free_matrix(hs_context* c) {
     if (c->d_y) (void)hipFree(c->d_y);
     if (c->d_partial) (void)hipFree(c->d_partial);
     c->d_partial = nullptr;
+    if (c->d_arrivals) (void)hipFree(c->d_arrivals);
+    c->d_arrivals = nullptr;
     if (c->d_x_interleaved) (void)hipFree(c->d_x_interleaved);
     c->d_x_interleaved = nullptr;
     for (void* p : {static_cast<void*>(c->d_mfma), static_cast<void*>(c->d_mfma_x), static_cast<void*>(c->d_mfma_partial), static_cast<void*>(c->d_mfma_flag)})
@@ -191,6 +194,10 @@ hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     a.part_heads = c->d_part_heads;
     a.x = x_source(c);
     a.out = c->col_slices > 1 ? c->d_partial : y_target(c);
+    a.join_arrivals = c->d_arrivals;
+    a.y_final = y_target(c);
+    a.num_rows = c->num_rows;
+    a.col_slices = c->col_slices;
     a.row_part_filter = filter;
     a.ring_buffers = c->ring_buffers;
     a.format = c->format;
@@ -221,7 +228,7 @@ int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1, const F
     const bool is_float = c->impl != HS_IMPL_FIXED;
     uint32_t* x = const_cast<uint32_t*>(x_source(c));
     const uint32_t n_fb = std::min(c->num_rows, c->num_cols);
-    if (c->col_slices > 1) {
+    if (c->col_slices > 1 && !c->d_arrivals) {
         uint32_t lo = 0, hi = c->num_rows;
         if (filter >= 0) partition_rows(c, uint32_t(filter), lo, hi);
         HS_HIP(c, hisparse::dev::launch_combine_slices(is_float, c->d_partial, y_target(c), c->num_rows, c->col_slices, lo, hi, c->stream,
@@ -428,7 +435,31 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_part_heads), tiles.part_heads.data(), tiles.part_heads.size() * sizeof(uint32_t), 0));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
-    if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
+    if (tiles.col_slices > 1) {
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
+        // The combine of the column slices inside the SpMV kernel (spmv_device.h: SliceJoin) needs what all three builders produce: every row
+        // range appears in exactly col_slices blocks of the same height.  Checked, not assumed; otherwise (or with HISPARSE_SLICE_JOIN=0) the
+        // separate combine launch stays.
+        const char* opt = hisparse::dev::detail::option_lookup(&ctx->options, "HISPARSE_SLICE_JOIN");
+        // OPT-IN: measured (profiles/r05_slice_join_ab.txt) the join costs a workgroup ~10 us at the END of its block -- ticket round trip, then
+        // three dependent passes over the partials from the memory side -- where the combine launch costs a step 3.7 us (ogbl-ppa 55.3 ->
+        // 61.6 us, gplus 19.8 -> 26.6, pokec 75.7 -> 89.9): balanced plans finish all their blocks together, so the tail is fully exposed.
+        bool join = opt && std::atoi(opt) != 0 && num_rows < (1u << 30);      // (the join addresses a row by a 32-bit byte offset)
+        if (join) {
+            std::vector<uint32_t> seen(num_rows, 0), height(num_rows, 0);
+            for (const Block& b : tiles.blocks) {
+                if (b.nrows == 0) continue;      // idle blocks (SWEEP: a block for every workgroup) store nothing and take no ticket
+                if (b.row0 >= num_rows || (seen[b.row0] && height[b.row0] != b.nrows) || b.out_offset % num_rows != b.row0) { join = false; break; }
+                seen[b.row0]++;
+                height[b.row0] = b.nrows;
+            }
+            for (uint32_t r = 0; join && r < num_rows; ++r) join = seen[r] == 0 || seen[r] == tiles.col_slices;
+        }
+        if (join) {
+            HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_arrivals), size_t(num_rows) * 4));
+            HS_HIP(ctx, hipMemset(ctx->d_arrivals, 0, size_t(num_rows) * 4));
+        }
+    }
     if (mfma_on_device || (tiles.mfma.words_bytes != 0 && !tiles.mfma.words.empty())) {      // float BITMAP matrix: the second image for the SpMM on the matrix engine + its scratch
         // OPTIONAL: SpMV works without it.  If the image or its scratch cannot be had (out of memory), the matrix loads without a second
         // image and hs_spmm takes the fused 4-column kernel instead.
@@ -482,6 +513,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     s.load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     s.retiled_on_gpu = image_on_device;
     s.light_kernel = tiles.light ? 1u : 0u;
+    s.slice_join = ctx->d_arrivals ? 1u : 0u;
     return HS_OK;
 }
 }  // namespace
@@ -799,12 +831,17 @@ int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
     const char* force = ctx_option(ctx, "HISPARSE_SPMSPV");
     const bool possible = !repeats && dense_dispatch_possible(ctx);
     bool want_dense = false;
-    if (force) {
+    // The dense dispatch is OPT-IN: the CSC matrix is independent of the matrix hs_load_matrix holds -- a caller may keep
+    // A for SpMV and A^T (or anything else of the same shape) as CSC -- and only the caller knows that the two are the same matrix.  It says
+    // so with `spmspv` = auto (the rule below) | dense (always), or by setting `spmspv_crossover`; without one of them every call takes the
+    // sparse path over the CSC arrays, whatever its size.
+    const bool automatic = force && std::string(force) == "auto";
+    if (force && !automatic) {
         want_dense = std::string(force) == "dense";
     } else if (const char* v = ctx_option(ctx, "HISPARSE_SPMSPV_CROSSOVER")) {
         const double crossover = std::atof(v);
         want_dense = crossover > 0.0 && double(count) > crossover * double(ctx->csc_cols);
-    } else if (possible && 14.0 + double(products) / 45000.0 > 30.0) {      // (below 30 us no dense SpMV of a matrix worth a CSC copy competes)
+    } else if (automatic && possible && 14.0 + double(products) / 45000.0 > 30.0) {      // (below 30 us no dense SpMV of a matrix worth a CSC copy competes)
         if (ctx->dense_spmv_us <= 0.0) {
             if (!ctx->d_x_dense) {
                 HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_x_dense), size_t(ctx->num_cols) * 4));
@@ -860,6 +897,18 @@ int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows) {
         HS_HIP(ctx, hipMemset(ctx->csc_scratch.cursors, 0, size_t(hisparse::dev::spmspv_bins(ctx->csc_rows)) * 4));
         return fail(ctx, HS_ERR_BAD_ARG, "hs_spmspv_device: the entries asked for more products than the matrix has non-zeros (columns named more than "
                                          "once): the result is incomplete; hs_spmspv with host entries splits such a call");
+    }
+    return HS_OK;
+}
+
+int hs_spmspv_status(hs_context* ctx, uint32_t* overflowed, void** overflow_word_dev) {
+    if (!ctx) return HS_ERR_BAD_ARG;
+    if (!ctx->d_csc_indptr) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix_csc has not been called");
+    if (overflow_word_dev) *overflow_word_dev = ctx->csc_scratch.overflow;
+    if (overflowed) {
+        HS_HIP(ctx, hipSetDevice(ctx->device));
+        HS_HIP(ctx, hipMemcpyAsync(overflowed, ctx->csc_scratch.overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return HS_OK;
 }
@@ -1096,6 +1145,28 @@ int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* 
         *kernel_ms = sum;
     }
     return HS_OK;
+}
+
+int hs_time_kernel(hs_context* ctx, int warmup, int runs, float* kernel_ms) {
+    int rc = check_ready(ctx);
+    if (rc != HS_OK) return rc;
+    if (warmup < 0 || runs <= 0 || !kernel_ms) return fail(ctx, HS_ERR_BAD_ARG, "need warmup >= 0, runs > 0 and an output pointer");
+    if (const char* why = hisparse::dev::profiling_switch_error()) return fail(ctx, HS_ERR_BAD_ARG, why);
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    const bool is_float = ctx->impl != HS_IMPL_FIXED;
+    const hisparse::dev::SpmvLaunch args = launch_args(ctx, -1);
+    for (int i = 0; i < warmup; ++i) HS_HIP(ctx, hisparse::dev::launch_spmv(is_float, args, ctx->stream));
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    struct Guard { hipEvent_t* e; ~Guard() { for (int i = 0; i < 2; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } guard{ev};
+    HS_HIP(ctx, hipEventCreate(&ev[0]));
+    HS_HIP(ctx, hipEventCreate(&ev[1]));
+    HS_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+    for (int i = 0; i < runs; ++i) HS_HIP(ctx, hisparse::dev::launch_spmv(is_float, args, ctx->stream));
+    HS_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
+    HS_HIP(ctx, hipEventSynchronize(ev[1]));
+    HS_HIP(ctx, hipEventElapsedTime(kernel_ms, ev[0], ev[1]));
+    // column-sliced plans: the launches above left partial sums only; one whole step puts y back in order
+    return enqueue(ctx, -1, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -143,10 +143,19 @@ __global__ __launch_bounds__(1024) void spmspv_accumulate_kernel(const uint32_t*
     const uint32_t tid = threadIdx.x, b = blockIdx.x, row0 = b << block_bits;
     const uint32_t first = ((const __attribute__((address_space(4))) uint32_t*)bin_base)[b];
     const uint32_t room = ((const __attribute__((address_space(4))) uint32_t*)bin_base)[b + 1] - first;
-    const uint32_t n = min(((const __attribute__((address_space(4))) uint32_t*)cursors)[b], room);
+    // The cursor is read with an ORDINARY load by one thread and handed round through LDS: it is rewritten below, so it must not be read
+    // through the constant address space (an invariant load the compiler may move across the barrier and the store).  A bin that was asked
+    // for more than it holds (hs_spmspv_device with a column named twice: the expand kernel dropped whole claims and raised the overflow
+    // word) has slots below `room` that nobody wrote: such a bin contributes NOTHING -- zeros, never an earlier call's products.
+    __shared__ uint32_t s_count;
+    if (tid == 0) {
+        const uint32_t claimed = *reinterpret_cast<volatile uint32_t*>(cursors + b);
+        s_count = claimed <= room ? claimed : 0u;
+        cursors[b] = 0;                                    // re-armed for the next call
+    }
     for (uint32_t i = tid; i < block_rows; i += 1024) acc[i] = 0;
     __syncthreads();
-    if (tid == 0) cursors[b] = 0;                          // (read above by every wavefront's scalar load, before the barrier)
+    const uint32_t n = s_count;
     for (uint32_t q = tid; q < n; q += 4 * 1024) {
         uint32_t key[4], val[4];
 #pragma unroll

@@ -338,8 +338,8 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
             Block idle{};
             idle.row_part = 0;
             idle.wave_offset[1] = stream_bytes;
+            slice_of_block.push_back(uint32_t(out.blocks.size()) % slices);      // (the index the idle block is about to get)
             out.blocks.push_back(idle);
-            slice_of_block.push_back(uint32_t(out.blocks.size()) % slices);
             block_weight.push_back(0);
         }
         assign_workgroups_by_slice(out, block_weight, G, RP, slice_of_block, mine);

@@ -19,7 +19,6 @@
 #include <cstring>
 #include <exception>
 #include <map>
-#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -32,22 +31,22 @@ namespace dev {
 namespace detail {
 
 // Tuning switches.  The configuration surface of the library is hs_set_option(ctx, key, value) (hisparse_hip.h): a context's options are
-// in force while ITS matrix is planned and built (OptionScope, taken by hs_load_matrix* under a process-wide lock: the builders run on
-// worker threads, so the scope cannot be thread-local).  The environment variable HISPARSE_<KEY> remains as the fallback for tools and
-// tests; set-but-empty counts as not set (HISPARSE_MAX_ROWS= used to mean "one row per block").
+// in force while ITS matrix is planned and built.  The scope is per THREAD (OptionScope, taken by hs_load_matrix* on the calling thread)
+// and handed to the worker threads task by task (parallel_for below sets it around every task it runs): loads of different contexts -- on
+// different devices, from different host threads -- neither wait for each other nor see each other's options, and a caller outside any
+// scope (tiles_capi builders, tools) sees the environment only.  (Until round 4 this was one process-wide pointer under a process-wide
+// mutex held for the whole load.)  The environment variable HISPARSE_<KEY> remains as the fallback for tools and tests; set-but-empty
+// counts as not set (HISPARSE_MAX_ROWS= used to mean "one row per block").  A context's map must not change while its load runs (calls
+// on one context never overlap: hisparse_hip.h).
 using OptionMap = std::map<std::string, std::string>;
 inline const OptionMap*& active_options() {
-    static const OptionMap* active = nullptr;
+    static thread_local const OptionMap* active = nullptr;
     return active;
 }
-inline std::mutex& options_mutex() {
-    static std::mutex m;
-    return m;
-}
 struct OptionScope {
-    std::unique_lock<std::mutex> lock;
-    explicit OptionScope(const OptionMap* options) : lock(options_mutex()) { active_options() = options; }
-    ~OptionScope() { active_options() = nullptr; }
+    const OptionMap* const saved;
+    explicit OptionScope(const OptionMap* options) : saved(active_options()) { active_options() = options; }
+    ~OptionScope() { active_options() = saved; }
     OptionScope(const OptionScope&) = delete;
     OptionScope& operator=(const OptionScope&) = delete;
 };
@@ -75,7 +74,12 @@ struct PhaseTimer {   // HISPARSE_PLAN_DEBUG=1: wall time of the load-time passe
 template <typename Fn>
 void parallel_for(size_t n, Fn fn) {
     const unsigned hw = std::thread::hardware_concurrency();
-    hisparse::pooled_for(n, hw ? hw : 1u, fn);
+    const OptionMap* const options = active_options();      // the caller's scope travels with every task
+    auto scoped = [&fn, options](size_t i) {
+        const OptionScope scope(options);
+        fn(i);
+    };
+    hisparse::pooled_for(n, hw ? hw : 1u, scoped);
 }
 
 // v = n zero bytes, filled (and first touched) by many threads

@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
     "hs_load_matrix_csr", "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
-    "hs_bind_device_vector", "hs_bind_device_result", "hs_push_result", "hs_set_option", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_spmspv_device", "hs_read_spmspv_result", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_debug_read_tiles", "hs_debug_read_mfma_image", "hs_tiles_build", "hs_tiles_info",
+    "hs_bind_device_vector", "hs_bind_device_result", "hs_push_result", "hs_set_option", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_spmspv_device", "hs_read_spmspv_result", "hs_spmspv_status", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_time_kernel", "hs_debug_read_tiles", "hs_debug_read_mfma_image", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
 
@@ -33,7 +33,7 @@ class Stats(C.Structure):
     _fields_ = [("nnz", C.c_uint64), ("cpsr_bytes", C.c_uint64), ("stream_bytes", C.c_uint64), ("stream_elements", C.c_uint64),
                 ("num_blocks", C.c_uint32), ("num_units", C.c_uint32), ("num_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("num_compute_units", C.c_uint32), ("col_slices", C.c_uint32), ("ring_buffers", C.c_uint32), ("stream_format", C.c_uint32),
-                ("load_seconds", C.c_double), ("retiled_on_gpu", C.c_uint32), ("light_kernel", C.c_uint32)]
+                ("load_seconds", C.c_double), ("retiled_on_gpu", C.c_uint32), ("light_kernel", C.c_uint32), ("slice_join", C.c_uint32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -83,8 +83,10 @@ def lib():
         l.hs_spmspv.argtypes = [vp, vp, u32]
         l.hs_spmspv_device.argtypes = [vp, vp, u32]
         l.hs_read_spmspv_result.argtypes = [vp, vp, u32]
+        l.hs_spmspv_status.argtypes = [vp, C.POINTER(u32), C.POINTER(vp)]
         l.hs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.hs_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
         l.hs_debug_read_tiles.argtypes = [vp, vp, u64, vp, vp]
         l.hs_debug_read_mfma_image.argtypes = [vp, vp, u64, C.POINTER(u64)]
         l.hs_load_matrix_csr.argtypes = [vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(u32)]
@@ -317,6 +319,12 @@ class SpmvEngine:
         total, kern = C.c_float(), C.c_float()
         self._check(lib().hs_time_runs(self._h, warmup, runs, C.byref(total), C.byref(kern) if kernel else None))
         return total.value, (kern.value if kernel else None)
+
+    def time_kernel(self, warmup, runs):
+        """hs_time_kernel: ms for `runs` back-to-back launches of the SpMV kernel alone (one HIP event pair around the loop)."""
+        kern = C.c_float()
+        self._check(lib().hs_time_kernel(self._h, warmup, runs, C.byref(kern)))
+        return kern.value
 
 
 def build_tiles(packets, impl, ob_bank, vb_bank, num_rows, num_cols, num_row_partitions, num_col_partitions, max_workgroups):

@@ -73,12 +73,13 @@ typedef struct {
     uint32_t num_workgroups;    /* grid size of the SpMV kernel */
     uint32_t lds_bytes;         /* dynamic LDS per workgroup (two x sub-tile buffers + row accumulators) */
     uint32_t num_compute_units; /* of the device */
-    uint32_t col_slices;        /* column slices (1 = none; > 1 adds the small combine pass) */
+    uint32_t col_slices;        /* column slices (1 = none; > 1: per-slice partial results are combined, see slice_join) */
     uint32_t ring_buffers;      /* x sub-tile buffers in the LDS ring */
     uint32_t stream_format;     /* HS_STREAM_PAIRS (8 B per element), HS_STREAM_DELTA (6 B per slot) or HS_STREAM_BITMAP (4 B + 1 bit per column) HS_STREAM_OWNER (8 B per element, float accumulators) the 7-byte forms of PAIRS / OWNER, or HS_STREAM_SWEEP (8 B per element in column order, x gathered from L2: very sparse matrices), chosen per matrix */
     double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
     uint32_t retiled_on_gpu;    /* 1: the per-non-zero passes of the re-tiling ran on the device (gpu_tiles.h); 0: on the host */
     uint32_t light_kernel;      /* 1: the LIGHT plan -- a small matrix run by the 256-thread single-launch kernel (spmv_light_kernel) over a PAIRS image */
+    uint32_t slice_join;        /* col_slices > 1 -- 1: the partial results of the column slices are added up INSIDE the SpMV kernel (the last block of a row range to finish writes y: one launch per SpMV); 0: by a second, small launch */
 } hs_stats;
 
 const char* hs_strerror(int code);
@@ -134,7 +135,7 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
  * (pairs|delta|owner|owner24|sweep|bitmap), col_slices, max_rows, row_runs, aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
  * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), sweep (0|1: the
  * column-ordered format of very sparse matrices), plan_debug; call-time keys: spmm_fused, spmm_mfma,
- * spmspv (sparse|dense), spmspv_crossover, iterate_graph, iterate_cooperative.  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
+ * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph, slice_join (0|1: the combine of the column slices inside the SpMV kernel).  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
  * Options set here win over the environment variable of the same name, which stays as the fallback for tools and tests.  None of them
  * changes WHAT is computed.  The switches that do (HISPARSE_ABLATE, HISPARSE_DEPTH: profiling builds with parts of the work removed) are
  * not options: they exist only in libhisparse_hip_prof.so, and this library refuses to run (HS_ERR_BAD_ARG from hs_run, hs_run_partition,
@@ -158,7 +159,7 @@ int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32
  * conversion csr2csc, sw/data_loader.h:109-144 -- but has no kernel) --------------------------------------
  * y = A x for a SPARSE x: only the columns named by x's entries are read.
  *   hs_load_matrix_csc: CSCMatrix arrays (indptr[num_cols + 1], row index and value word per non-zero, value words in the context's
- *     numeric mode: hsf_csr_to_csc), independent of the matrix hs_load_matrix holds; validated, copied to the device.
+ *     numeric mode: hsf_csr_to_csc), independent of the matrix hs_load_matrix holds (see DENSE DISPATCH below); validated, copied to the device.
  *   hs_spmspv: x as `count` IDX_VAL_T pairs in HOST memory.  Asynchronous: the pairs are checked and copied into a pinned, device-mapped
  *     staging buffer of the context (two halves used in turn; the call returns once they are in it) and two kernels follow on the context's
  *     stream -- EXPAND (a workgroup per 64 entries computes their columns' products and places each in the BIN of the row block it falls
@@ -168,16 +169,18 @@ int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32
  *     products as the matrix has non-zeros in its row block, so such a call is cut into passes of unique columns.
  *     CROSSOVER: the sparse path costs ~10-14 us + products / 45 G/s (measured, profiles/r04_spmspv_binned.txt: ogbl-ppa 0.05 % / 0.1 % / 1 % /
  *     5 % of the columns 14 / 14 / 24 / 61 us with host entries -- 10 / 10 / 20 / 56 with device entries --, against 62-68 us for the dense SpMV,
- *     which wins from ~6 %).  Beyond the
- *     crossover hs_spmspv runs the DENSE SpMV instead -- x scattered
- *     into a zero vector, one hs_run -- PROVIDED hs_load_matrix / hs_load_matrix_csr of this context holds the same matrix (same shape
- *     after padding; that it IS the same matrix is the caller's contract) and x names no column twice.  The rule: the host knows the
- *     call's product count exactly, and the dense SpMV of the loaded matrix is timed once (the first call that could use it: three
- *     launches and one synchronisation); `spmspv_crossover` (hs_set_option: a fraction of the columns; 0 = never) replaces the rule,
- *     `spmspv` = sparse | dense forces a path.  Without a matching dense matrix the sparse path runs whatever the size.
+ *     which wins from ~6 %).
+ *     DENSE DISPATCH (opt-in).  The CSC matrix is independent of the matrix hs_load_matrix / hs_load_matrix_csr holds: a context may keep A for
+ *     SpMV and A^T, or any other matrix of the same shape, as CSC, and by default hs_spmspv ALWAYS multiplies by the CSC matrix (the sparse
+ *     path, whatever the size of x).  A caller who has loaded the SAME matrix both ways may say so -- hs_set_option(ctx, "spmspv", "auto") --
+ *     and hs_spmspv then answers calls beyond the crossover with the dense SpMV of the loaded matrix instead (x scattered into a zero vector,
+ *     one hs_run), provided the shapes match after padding and x names no column twice.  The rule: the host knows the call's product count
+ *     exactly, and the dense SpMV of the loaded matrix is timed once (the first call that could use it: three launches and one
+ *     synchronisation).  `spmspv_crossover` (a fraction of the columns; 0 = never) replaces the rule and is the same declaration;
+ *     `spmspv` = sparse | dense forces a path.  That the two ARE the same matrix is the caller's contract under every one of these options.
  *   hs_spmspv_device: the same with the pairs already in DEVICE memory (8-byte aligned): nothing but the two launches (3-4 us less).  No
- *     index check (out-of-range columns are ignored), no dense dispatch, and no column may be named twice (a bin that overflows drops the
- *     excess and hs_read_spmspv_result reports HS_ERR_BAD_ARG).
+ *     index check (out-of-range columns are ignored), no dense dispatch, and no column may be named twice (a bin that overflows contributes
+ *     nothing -- its rows come out zero -- and hs_read_spmspv_result reports HS_ERR_BAD_ARG; hs_spmspv_status tells without a read-back).
  * Arithmetic as in hs_run: fixed = saturating sum of individually rounded / saturated products (bit-exact, order free);
  * float = fp32 products summed in double per row block, rounded once (tolerance). */
 typedef struct { uint32_t index; uint32_t val; } hs_idx_val;    /* IDX_VAL_T, spmv/libfpga/common.h:54 */
@@ -186,6 +189,11 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* 
 int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count);
 int hs_spmspv_device(hs_context* ctx, const hs_idx_val* x_entries_dev, uint32_t count);
 int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows);
+/* For callers that consume the SpMSpV result ON THE DEVICE (hs_device_... of d_csc_y is not exported: they bind their own y) and never call
+ * hs_read_spmspv_result: *overflowed (may be NULL; waits for the stream) = 1 when a hs_spmspv_device call since the last
+ * hs_read_spmspv_result asked a bin for more products than it holds (a column named twice) -- the rows of such a row block are then ZERO,
+ * never an earlier call's products; *overflow_word_dev (may be NULL) = the device address of that word, for a kernel of the caller's to test. */
+int hs_spmspv_status(hs_context* ctx, uint32_t* overflowed, void** overflow_word_dev);
 
 /* ---- load straight from CSR (EXTENSION, SURVEY.md section 8(f)-1: the pre-processing on the GPU) ------------------------------------
  * The reference's driver turns CSRMatrix<float> (sw/data_loader.h:19-31) into CPSR on the host (csr2cpsr + packet assembly,
@@ -223,6 +231,12 @@ int hs_get_stats(const hs_context* ctx, hs_stats* stats);
  * whole loop).  kernel_ms: sum over the runs of the duration of the SpMV kernel
  * (spmv_rowblock_kernel) alone, from per-launch event pairs.  Either output may be NULL. */
 int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* kernel_ms);
+/* The dominant kernel ALONE: `runs` back-to-back launches of the SpMV kernel of hs_run (without the slice-combine pass of a
+ * column-sliced plan) after `warmup` untimed ones, ONE HIP event pair around the whole loop on the stream they are launched on;
+ * *kernel_ms = the elapsed time of the `runs` launches (divide by runs: the average launch duration rocprofv3 --stats reports,
+ * plus the sub-microsecond dispatch gap).  No per-launch events, which add ~3 us to each launch.  Ends with one whole hs_run so that
+ * y holds the product again. */
+int hs_time_kernel(hs_context* ctx, int warmup, int runs, float* kernel_ms);
 
 /* What hs_load_matrix left on the device: the image (stats.stream_bytes), Block[] (num_blocks x 320 B) and Unit[] (num_units x 64 B).
  * Tests compare this with hs_tiles_build (the host builder) byte for byte.  Any pointer may be NULL. */

@@ -50,3 +50,95 @@ def test_gloo_backend_refuses_the_hip_library():
     rc, line, text = _bench(["--gpus", "2", "--backend", "gloo", "--config", "ppa_small", "--steps", "1", "--warmup", "0"])
     assert rc == 2, text
     assert line is not None and "error" in line
+
+
+# ---- the driver keeps the last 8 000 characters of stdout and of stderr: the final line must fit, whole ----------
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline", "parity_vs_oracle")
+
+
+def _tail_holds_the_line(stdout, stderr, line_text):
+    assert len(line_text) < 6000, len(line_text)
+    assert stdout.rstrip("\n").endswith(line_text)                 # the JSON object is the LAST line of stdout ...
+    assert line_text in stdout[-8000:]                              # ... whole inside the driver's stdout tail ...
+    assert line_text in (stdout[-8000:] + "\n---- stderr ----\n" + stderr[-8000:])[-16100:]
+
+
+def test_distributed_line_is_compact_and_complete():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HISPARSE_HIP_LIB"] = CPU_LIB
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "ppa_small", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout + p.stderr
+    last = [l for l in p.stdout.splitlines() if l.strip()][-1]
+    line = json.loads(last)
+    _tail_holds_the_line(p.stdout, p.stderr, last)
+    for key in REQUIRED:
+        assert key in line, key
+    assert line["gather"] == "final"
+    for key in ("bound", "kernel", "achieved", "peak", "frac", "kernel_ms", "traffic", "algorithmic_bytes_per_launch"):
+        assert key in line["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in line["cpu_baseline"], key
+
+
+def test_emit_never_prints_a_line_the_tail_cannot_hold(capsys, tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "DETAILS_FILE", str(tmp_path / "bench_details.json"))
+    out = {k: 1 for k in REQUIRED}
+    out["roofline"] = {"bound": "hbm", "frac": 0.8}
+    out["notes"] = "x" * 20000                      # an optional key that would blow the line up
+    out["more"] = {"a": list(range(500))}
+    bench.emit(out, {"everything": ["y" * 1000] * 40}, [bench.SUMMARY_HEAD])
+    cap = capsys.readouterr()
+    last = cap.out.strip().splitlines()[-1]
+    line = json.loads(last)
+    assert len(last) <= bench.LINE_LIMIT
+    assert "notes" not in line and all(k in line for k in REQUIRED)
+    assert line["details"] == "bench_details.json"
+    assert json.load(open(tmp_path / "bench_details.json"))["everything"][0].startswith("y")
+
+
+@__import__("pytest").mark.gpu
+def test_default_single_gpu_run_fits_the_drivers_tail():
+    """the driver's own command line; the whole default run (every configuration, the sweeps) with its stderr rows"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    last = [l for l in p.stdout.splitlines() if l.strip()][-1]
+    line = json.loads(last)
+    _tail_holds_the_line(p.stdout, p.stderr, last)
+    for key in REQUIRED:
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["parity_vs_oracle"] == "bit-exact" and "ogbl_ppa" in line["config"]["workload"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and 0.3 < r["frac"] <= 1.0 and r["frac_whole_step"] <= r["frac"] * 1.02
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
+    # one row per matrix of the sweep inside the stderr tail, and the details next to the script
+    tail = p.stderr[-8000:]
+    for name in ("transformer_95/fixed", "pokec/fixed", "ogbn_products/float_stall", "mouse_gene/fixed", "ogbl_ppa/fixed"):
+        assert name in tail, name
+    det = json.load(open(os.path.join(ROOT, "bench_details.json")))
+    assert len(det["bm_list"]) == 12 and len(det["per_config"]) == 4 and det["strong_scaling_prediction"]
+
+
+@__import__("pytest").mark.gpu
+@__import__("pytest").mark.parametrize("n", [2, 8])
+def test_n_rank_dry_run_on_one_gpu(n):
+    """main_distributed with N processes sharing GPU 0 -- set_device, the HIP engine, stream binding,
+    hs_bind_device_result, slab parity against the oracle, the gathered layout, the peer-store gather over IPC handles, the JSON line --
+    everything of `bench.py --gpus N` except RCCL (gloo, host-staged)."""
+    rc, line, text = _bench(["--gpus", str(n), "--backend", "gloo", "--share-gpu", "--config", "mouse_gene", "--steps", "20", "--warmup", "5"], timeout=1200)
+    assert rc == 0, text[-3000:]
+    assert line["n_gpus"] == n and "DRY RUN" in line["backend"] and line["gather"] == "final"
+    assert line["parity_vs_oracle"].startswith("bit-exact")
+    assert line["config"]["nnz_total"] == 28967291 or line["config"]["nnz_total"] > 2.8e7
+    assert line["same_workload_on_one_gpu"]["n_gpus"] == 1
+    assert line["compute_only"]["ms_per_step"] > 0 and line["exchange_every_step"]["ms_per_step"] > 0
+    assert line["roofline"]["kernel_ms"] > 0
+    push = line["exchange_push"]
+    assert push is not None and ("error" in push or push["equals_collective_on_every_rank"]), push
+    last = [l for l in text.splitlines() if l.startswith("{")][-1]
+    assert len(last) < 6000

@@ -142,3 +142,39 @@ def test_from_csr_gives_the_same_y(tmp_path, impl_name, impl, v, o):
     a, b = np.fromfile(ya, dtype=np.uint32), np.fromfile(yb, dtype=np.uint32)
     assert a.size == b.size and a.any()
     assert np.array_equal(a, b) if impl == 0 else np.allclose(a.view(np.float32), b.view(np.float32), rtol=1e-5, atol=1e-5)
+
+
+# ---- round 5: the harness's own check in the C++ driver, and the N-slab dry run on one GPU ------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl_name,impl,v,o", [("fixed", 0, 4, 8), ("float_pob", 1, 4, 1), ("float_stall", 2, 4, 8)])
+def test_verify_passes_and_fails_with_an_exit_code(tmp_path, impl_name, impl, v, o):
+    """--verify = compute_ref + verify of sw/host.cpp:33-74 (float32 CSR loop, absolute 1e-4), own code in benchmark.cpp (not the oracle)."""
+    m, path = _matrix(tmp_path, impl)
+    r = run(impl_name, path, v, o, "--values", "keep", "--verify")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "INFO : verify PASSED" in r.stdout and RESULT_LINE.search(r.stdout)
+    r = run(impl_name, path, v, o, "--values", "keep", "--from-csr", "--verify")
+    assert r.returncode == 0 and "INFO : verify PASSED" in r.stdout, r.stdout
+    # an epsilon no fixed-point / float32 result can meet: the reference's failure lines, the first failing row, exit code 3
+    r = run(impl_name, path, v, o, "--values", "keep", "--verify-eps", "1e-30")
+    assert r.returncode == 3, r.stdout
+    assert "Error: Result mismatch" in r.stdout and re.search(r"i = \d+  Reference result = \S+  Kernel result = \S+", r.stdout)
+    assert "INFO : verify FAILED" in r.stdout and "Benchmark Finished" not in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 8])
+def test_n_slabs_sharing_one_gpu(tmp_path, n):
+    """--gpus N --share-gpu: the row-slab path with N contexts on ONE device -- the split, N streams, hs_bind_device_result into the gather
+    buffers and the gather by peer stores all execute with N > 1 (only RCCL is left out); y assembled from device 0's gather buffer must be
+    the oracle's and pass the driver's own --verify."""
+    m, path = _matrix(tmp_path, 0, rows=20000, cols=3000, density=0.004, seed=9)
+    xf, yf = tmp_path / "x.bin", tmp_path / "y.bin"
+    r = run("fixed", path, 4, 8, "--values", "keep", "--gpus", n, "--share-gpu", "--verify", "--dump-x", xf, "--dump-y", yf)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"({n} row slabs sharing ONE GPU" in r.stdout and r.stdout.count("  slab ") == n
+    assert "compute only" in r.stdout and "pushed slabs identical to their sources" in r.stdout and "INFO : verify PASSED" in r.stdout
+    x = np.fromfile(xf, dtype=np.uint32)
+    cp, want = _oracle_y(m, 0, 4096, 8192, x)
+    y = np.fromfile(yf, dtype=np.uint32)
+    assert y.size == 20000 and np.array_equal(y, want[:20000])

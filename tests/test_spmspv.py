@@ -67,10 +67,7 @@ def test_csc_conversion_and_oracle_against_the_spmv_oracle(impl):
 def test_device_spmspv_matches_oracle_and_dense_spmv(impl, rows, cols, density, x_nnz, path, monkeypatch):
     # "sparse": the two-launch path (expand into the product list, one workgroup per row block accumulates its own) whatever the size;
     # "dense": the dispatch to the dense SpMV of the same matrix loaded on the same context; "auto": the library's choice by the crossover
-    if path == "auto":
-        monkeypatch.delenv("HISPARSE_SPMSPV", raising=False)
-    else:
-        monkeypatch.setenv("HISPARSE_SPMSPV", path)
+    monkeypatch.setenv("HISPARSE_SPMSPV", path)      # (the dense dispatch is opt-in: "auto" declares that both loads hold the same matrix)
     m, csr, (indptr, ridx, words), xi, xv, xw = _case(impl, rows, cols, density, 9, x_nnz)
     want = orc.spmspv(impl, indptr, ridx, words, rows, cols, xi, xw)
     with device.SpmvEngine(impl) as eng:
@@ -89,6 +86,28 @@ def test_device_spmspv_matches_oracle_and_dense_spmv(impl, rows, cols, density, 
             assert np.array_equal(got, _dense_spmv_oracle(m, impl, xi, xv))
     else:
         assert cases.float_close(got, want) and cases.float_close(again, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl", [0, 1])
+def test_csc_matrix_is_independent_of_the_dense_matrix_by_default(impl, monkeypatch):
+    # A for SpMV and a DIFFERENT matrix of the same shape as CSC on one context -- a large x (every column: far beyond
+    # any crossover) must still be multiplied by the CSC matrix; only spmspv = auto | dense (the caller's declaration that the two are the
+    # same matrix) may answer with the dense SpMV
+    monkeypatch.delenv("HISPARSE_SPMSPV", raising=False)
+    monkeypatch.delenv("HISPARSE_SPMSPV_CROSSOVER", raising=False)
+    rows, cols = 40000, 30000
+    m_a, csr_a, _, _, _, _ = _case(impl, rows, cols, 0.004, 5, 10)
+    m_b, csr_b, (indptr, ridx, words), xi, xv, xw = _case(impl, rows, cols, 0.004, 6, cols)       # x names every column: 4.8 M products
+    want_b = orc.spmspv(impl, indptr, ridx, words, rows, cols, xi, xw)
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix_csr(csr_a)                     # same shape, other matrix
+        eng.load_matrix_csc(indptr, ridx, words, rows)
+        got = eng.spmspv(xi, xw)
+        assert np.array_equal(got, want_b) if impl == 0 else cases.float_close(got, want_b)
+        eng.set_option("spmspv", "dense")              # the declaration (here: a false one) switches to the dense matrix
+        other = eng.spmspv(xi, xw)
+        assert not np.array_equal(other, got)
 
 
 @pytest.mark.gpu
@@ -138,9 +157,15 @@ def test_device_resident_entries_and_the_overflow_report():
             assert np.array_equal(eng.read_spmspv_result(), want)
             assert rt.hipMemcpy(d, every.ctypes.data, every.nbytes, 1) == 0
             eng.spmspv_device(d.value, cols * 3)
+            # a consumer on the device never reads y back through the library: hs_spmspv_status tells
+            flag, word = C.c_uint32(7), C.c_void_p()
+            assert device.lib().hs_spmspv_status(eng._h, C.byref(flag), C.byref(word)) == 0 and flag.value == 1 and word.value
+            seen = C.c_uint32(0)
+            assert rt.hipMemcpy(C.byref(seen), word, 4, 2) == 0 and seen.value == 1
             with pytest.raises(device.DeviceError) as e:
                 eng.read_spmspv_result()
             assert "more products" in str(e.value)
+            assert device.lib().hs_spmspv_status(eng._h, C.byref(flag), None) == 0 and flag.value == 0
             assert rt.hipMemcpy(d, pairs.ctypes.data, pairs.nbytes, 1) == 0
             eng.spmspv_device(d.value, len(xi))                    # the flag is cleared, the next call is fine
             assert np.array_equal(eng.read_spmspv_result(), want)
