@@ -370,7 +370,8 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
             for (int p = 0; p < N; ++p)
                 if (p != d) dst[n++] = gathered[p] + size_t(d) * chunk;
             if (N == 1) dst[n++] = loopback[d];
-            check(hs_push_result(slab[d].ctx, dst, n, chunk), slab[d].ctx, "hs_push_result");
+            // (the slab's OWN padded rows: the chunk is the tallest slab's, and a context pushes no more than it holds -- found by the --share-gpu dry run)
+            check(hs_push_result(slab[d].ctx, dst, n, slab[d].packets.num_rows), slab[d].ctx, "hs_push_result");
             hip_check(hipSetDevice(dev_of(d)), "hipSetDevice");
             hip_check(hipEventRecord(pushed[d], stream[d]), "hipEventRecord");
         }

@@ -54,7 +54,6 @@ struct hs_context {
     uint32_t format = 0;           // StreamFormat of d_image
     bool light = false;            // the LIGHT plan: d_image is a PAIRS image run by spmv_light_kernel (stream_tiles.h)
     uint32_t* d_partial = nullptr;  // col_slices > 1: per-slice partial results, col_slices x num_rows words
-    uint32_t* d_arrivals = nullptr; // col_slices > 1 with the combine folded into the SpMV kernel (spmv_device.h: SliceJoin): one zeroed word per row
     uint32_t max_block_rows = 0;
     uint32_t* d_x_interleaved = nullptr;   // fused SpMM over a BITMAP image: 4 columns of X as [column][vector] words (allocated on first use)
     // SpMM on the matrix engine (float BITMAP matrices): the second image + scratch (spmm_mfma.hip)
@@ -123,7 +122,7 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 const char* const kOptionKeys[] = {
     "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
     "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS", "SWEEP",
-    "SLICE_JOIN", "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH",
+    "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH",
 };
 
 void free_matrix(hs_context* c) {
@@ -135,8 +134,6 @@ void free_matrix(hs_context* c) {
     if (c->d_y) (void)hipFree(c->d_y);
     if (c->d_partial) (void)hipFree(c->d_partial);
     c->d_partial = nullptr;
-    if (c->d_arrivals) (void)hipFree(c->d_arrivals);
-    c->d_arrivals = nullptr;
     if (c->d_x_interleaved) (void)hipFree(c->d_x_interleaved);
     c->d_x_interleaved = nullptr;
     for (void* p : {static_cast<void*>(c->d_mfma), static_cast<void*>(c->d_mfma_x), static_cast<void*>(c->d_mfma_partial), static_cast<void*>(c->d_mfma_flag)})
@@ -194,10 +191,6 @@ hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     a.part_heads = c->d_part_heads;
     a.x = x_source(c);
     a.out = c->col_slices > 1 ? c->d_partial : y_target(c);
-    a.join_arrivals = c->d_arrivals;
-    a.y_final = y_target(c);
-    a.num_rows = c->num_rows;
-    a.col_slices = c->col_slices;
     a.row_part_filter = filter;
     a.ring_buffers = c->ring_buffers;
     a.format = c->format;
@@ -228,7 +221,7 @@ int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1, const F
     const bool is_float = c->impl != HS_IMPL_FIXED;
     uint32_t* x = const_cast<uint32_t*>(x_source(c));
     const uint32_t n_fb = std::min(c->num_rows, c->num_cols);
-    if (c->col_slices > 1 && !c->d_arrivals) {
+    if (c->col_slices > 1) {
         uint32_t lo = 0, hi = c->num_rows;
         if (filter >= 0) partition_rows(c, uint32_t(filter), lo, hi);
         HS_HIP(c, hisparse::dev::launch_combine_slices(is_float, c->d_partial, y_target(c), c->num_rows, c->col_slices, lo, hi, c->stream,
@@ -435,31 +428,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_part_heads), tiles.part_heads.data(), tiles.part_heads.size() * sizeof(uint32_t), 0));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
-    if (tiles.col_slices > 1) {
-        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
-        // The combine of the column slices inside the SpMV kernel (spmv_device.h: SliceJoin) needs what all three builders produce: every row
-        // range appears in exactly col_slices blocks of the same height.  Checked, not assumed; otherwise (or with HISPARSE_SLICE_JOIN=0) the
-        // separate combine launch stays.
-        const char* opt = hisparse::dev::detail::option_lookup(&ctx->options, "HISPARSE_SLICE_JOIN");
-        // OPT-IN: measured (profiles/r05_slice_join_ab.txt) the join costs a workgroup ~10 us at the END of its block -- ticket round trip, then
-        // three dependent passes over the partials from the memory side -- where the combine launch costs a step 3.7 us (ogbl-ppa 55.3 ->
-        // 61.6 us, gplus 19.8 -> 26.6, pokec 75.7 -> 89.9): balanced plans finish all their blocks together, so the tail is fully exposed.
-        bool join = opt && std::atoi(opt) != 0 && num_rows < (1u << 30);      // (the join addresses a row by a 32-bit byte offset)
-        if (join) {
-            std::vector<uint32_t> seen(num_rows, 0), height(num_rows, 0);
-            for (const Block& b : tiles.blocks) {
-                if (b.nrows == 0) continue;      // idle blocks (SWEEP: a block for every workgroup) store nothing and take no ticket
-                if (b.row0 >= num_rows || (seen[b.row0] && height[b.row0] != b.nrows) || b.out_offset % num_rows != b.row0) { join = false; break; }
-                seen[b.row0]++;
-                height[b.row0] = b.nrows;
-            }
-            for (uint32_t r = 0; join && r < num_rows; ++r) join = seen[r] == 0 || seen[r] == tiles.col_slices;
-        }
-        if (join) {
-            HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_arrivals), size_t(num_rows) * 4));
-            HS_HIP(ctx, hipMemset(ctx->d_arrivals, 0, size_t(num_rows) * 4));
-        }
-    }
+    if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
     if (mfma_on_device || (tiles.mfma.words_bytes != 0 && !tiles.mfma.words.empty())) {      // float BITMAP matrix: the second image for the SpMM on the matrix engine + its scratch
         // OPTIONAL: SpMV works without it.  If the image or its scratch cannot be had (out of memory), the matrix loads without a second
         // image and hs_spmm takes the fused 4-column kernel instead.
@@ -513,7 +482,6 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     s.load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     s.retiled_on_gpu = image_on_device;
     s.light_kernel = tiles.light ? 1u : 0u;
-    s.slice_join = ctx->d_arrivals ? 1u : 0u;
     return HS_OK;
 }
 }  // namespace

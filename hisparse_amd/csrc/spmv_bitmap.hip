@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
                                                                 const Unit* __restrict__ units, const uint32_t* __restrict__ x, uint32_t num_cols,
                                                                 uint32_t* __restrict__ out, int32_t row_part_filter,
                                                                 const uint32_t* __restrict__ part_heads, uint64_t* __restrict__ timeline,
-                                                                uint32_t x_lds_offset, SliceJoin join) {
+                                                                uint32_t x_lds_offset) {
     using R = Rows<kFloat>;
     using acc_t = typename R::acc_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -303,7 +303,6 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
         __syncthreads();
         stamp(6, nrows);
         for (uint32_t i = tid; i < nrows; i += kBmThreads) out[out0 + i] = R::finish(ys[i]);
-        if (join.arrivals && nrows) join_slices<kFloat, kBmThreads>(join, out, blk->row0, nrows, tid, reinterpret_cast<uint32_t*>(lds));     // column-sliced plan: the last block of the row range writes y
         if (kAblate & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(7, nrows); }
         if (!next) break;
     }
@@ -336,7 +335,6 @@ hipError_t configure_bitmap_kernels(uint32_t lds_bytes) {
 hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.num_workgroups == 0) return hipSuccess;
     const dim3 grid(a.num_workgroups), block(kBmThreads);
-    const SliceJoin join = slice_join(a);
     int ablate = 0, depth_unused = 8;       // read per launch (profiling library only): a process may switch profiling builds between runs
     if (!profiling_switches(ablate, depth_unused)) return hipErrorInvalidValue;
     // timeline build: HISPARSE_ABLATE=64 HISPARSE_TIMELINE_OUT=file -> every launch is synchronised and its per-wavefront
@@ -356,7 +354,7 @@ hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t st
 #define X(F, A)                                                                                                                                  \
     if (!launched && a.bitmap_x_groups && is_float == F && ablate == A) {                                                                        \
         hipLaunchKernelGGL((spmv_bitmap_kernel<F, A, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.num_cols, a.out, \
-                           a.row_part_filter, a.part_heads, timeline, x_lds_offset, join);                                                             \
+                           a.row_part_filter, a.part_heads, timeline, x_lds_offset);                                                             \
         launched = true;                                                                                                                         \
     }
     HS_FOR_EACH_BITMAP_XLDS_VARIANT(X)
@@ -364,7 +362,7 @@ hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t st
 #define X(F, A)                                                                                                                                  \
     if (!launched && is_float == F && ablate == A) {                                                                                             \
         hipLaunchKernelGGL((spmv_bitmap_kernel<F, A>), grid, block, a.bitmap_x_groups ? x_lds_offset : a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.num_cols, a.out, \
-                           a.row_part_filter, a.part_heads, timeline, 0u, join);                                                                       \
+                           a.row_part_filter, a.part_heads, timeline, 0u);                                                                       \
         launched = true;                                                                                                                         \
     }
     HS_FOR_EACH_BITMAP_VARIANT(X)

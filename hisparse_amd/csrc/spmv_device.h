@@ -5,8 +5,6 @@
 
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 #include "stream_tiles.h"
 
 namespace hisparse {
@@ -121,127 +119,6 @@ __device__ __forceinline__ T segmented_run_sums(T v, uint32_t row, bool& is_last
     const uint32_t next_row = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(row), 0x130, 0xf, 0xf, false));   // wave_shl:1 (lane 63: none)
     is_last = next_row != row;
     return v;
-}
-
-
-// ---- column-sliced plans: the slice-combine pass folded into the SpMV kernel ("last arriver") ------------------------------------
-// A column-sliced plan has `slices` blocks per row range, each writing its partial sums to partial[slice * num_rows + row].  Until round 4
-// a second launch (combine_slices_kernel) added them up: 5-7 us per SpMV (a kernel boundary + one pass over the partials), 9 % of an
-// ogbl-ppa step, 23 % of gplus, and the second of the two launches a small row slab of a multi-GPU split is bound by.  Here every block,
-// after storing its partial rows, takes a ticket from the row range's arrival counter (one release atomic at agent scope: the block's
-// stores are written back behind it); the block that draws the LAST ticket re-arms the counter, reads all `slices` partial vectors of the
-// range with sc1 loads (they come from the memory side, not from this XCD's L2, which may hold an older copy of lines another XCD wrote)
-// and writes y.  The sum is taken in slice order from 0.0f / 0 exactly as the combine kernel takes it, so the result is bit for bit the
-// same -- in the float modes too, whichever block arrives last.  Counters: one word per row (indexed by the range's first row), zero
-// between launches.
-struct SliceJoin {
-    uint32_t* arrivals = nullptr;      // nullptr: no join (one slice, or the combine launch does it)
-    uint32_t* y = nullptr;             // the final result vector
-    uint32_t num_rows = 0;             // stride between the partial vectors
-    uint32_t slices = 0;
-};
-
-template <typename Launch>
-inline SliceJoin slice_join(const Launch& a) {
-    SliceJoin j;
-    if (a.join_arrivals && a.col_slices > 1) {
-        j.arrivals = a.join_arrivals;
-        j.y = a.y_final;
-        j.num_rows = a.num_rows;
-        j.slices = a.col_slices;
-    }
-    return j;
-}
-
-typedef uint32_t join_v4 __attribute__((ext_vector_type(4)));
-
-// One pass of the join over kN (<= 4) partial vectors starting at `p0` (stride_words apart): adds them, in slice order, to the running sums
-// of the thread's four rows.  The loads are hand-placed -- global_load_dwordx4 ... sc1 into VECTOR registers ("=&v"), awaited inside the same
-// asm block: left to the compiler, the row-block kernels (96 vector registers) parked these loads in the accumulator registers their
-// element ring lives in (tests/test_isa_invariants.py).
-// (scalar base per partial vector + one 32-bit vector offset: five address registers less than four 64-bit vector addresses; `s_nop 4`:
-// the hazard recogniser does not look into inline asm -- scalar base written, then used by a vector memory instruction)
-template <int kN>
-__device__ __forceinline__ void join_load(const uint32_t* p0, size_t stride_words, uint32_t byte_off, join_v4 (&p)[4]);
-template <>
-__device__ __forceinline__ void join_load<1>(const uint32_t* p0, size_t, uint32_t off, join_v4 (&p)[4]) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(p[0]) : "v"(off), "s"(p0) : "memory");
-}
-template <>
-__device__ __forceinline__ void join_load<2>(const uint32_t* p0, size_t st, uint32_t off, join_v4 (&p)[4]) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3 sc1\n\tglobal_load_dwordx4 %1, %2, %4 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(p[0]), "=&v"(p[1]) : "v"(off), "s"(p0), "s"(p0 + st) : "memory");
-}
-template <>
-__device__ __forceinline__ void join_load<3>(const uint32_t* p0, size_t st, uint32_t off, join_v4 (&p)[4]) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %3, %4 sc1\n\tglobal_load_dwordx4 %1, %3, %5 sc1\n\tglobal_load_dwordx4 %2, %3, %6 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]) : "v"(off), "s"(p0), "s"(p0 + st), "s"(p0 + 2 * st) : "memory");
-}
-template <>
-__device__ __forceinline__ void join_load<4>(const uint32_t* p0, size_t st, uint32_t off, join_v4 (&p)[4]) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5 sc1\n\tglobal_load_dwordx4 %1, %4, %6 sc1\n\tglobal_load_dwordx4 %2, %4, %7 sc1\n\t"
-                 "global_load_dwordx4 %3, %4, %8 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]) : "v"(off), "s"(p0), "s"(p0 + st), "s"(p0 + 2 * st), "s"(p0 + 3 * st) : "memory");
-}
-template <bool kFloat, int kN, typename Sum>
-__device__ __forceinline__ void join_pass(const uint32_t* p0, size_t stride_words, uint32_t byte_off, Sum (&s)[4]) {
-    join_v4 p[4];
-    join_load<kN>(p0, stride_words, byte_off, p);
-#pragma unroll
-    for (int k = 0; k < kN; ++k) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if constexpr (kFloat) s[c] += __uint_as_float(p[k][c]);
-            else s[c] = __builtin_elementwise_add_sat(s[c], p[k][c]);      // saturating adds of non-negative terms: min(sum, 2^32 - 1) in any order
-        }
-    }
-}
-
-// Call with the whole workgroup, after the block's partial rows have been stored to partial[out0 + i] (out0 = slice * num_rows + row0).
-// lds_word: any LDS word the block no longer needs.
-template <bool kFloat, int kBlockThreads>
-__device__ __forceinline__ void join_slices(const SliceJoin& j, uint32_t* __restrict__ partial, uint32_t row0, uint32_t nrows, uint32_t tid,
-                                            uint32_t* lds_word) {
-    // element-ring loads a kernel may still have in flight (clamped prefetches past the block's last step) land before the compiler
-    // gets to use any register for the loads below
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                       // every wavefront's partial stores have been issued and acknowledged
-    if (tid == 0) {
-        const uint32_t ticket = __hip_atomic_fetch_add(j.arrivals + row0, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t last = ticket + 1u == j.slices;
-        if (last) __hip_atomic_store(j.arrivals + row0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
-        *reinterpret_cast<volatile uint32_t*>(lds_word) = last;
-    }
-    __syncthreads();
-    const uint32_t last = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(lds_word));
-    if (!last) return;
-    using Sum = typename std::conditional<kFloat, float, uint32_t>::type;
-    const uint32_t first = row0 & ~3u, quads = (row0 + nrows - first + 3u) / 4u;                // aligned groups of four rows covering the range
-    for (uint32_t q = tid; q < quads; q += kBlockThreads) {
-        const uint32_t r = first + q * 4u;
-        Sum s[4] = {0, 0, 0, 0};
-        for (uint32_t k0 = 0; k0 < j.slices; k0 += 4u) {
-            const uint32_t n = min(4u, j.slices - k0);
-            const uint32_t* p0 = partial + static_cast<size_t>(k0) * j.num_rows;      // wave-uniform: a scalar register pair
-            if (n == 4) join_pass<kFloat, 4>(p0, j.num_rows, r * 4u, s);
-            else if (n == 3) join_pass<kFloat, 3>(p0, j.num_rows, r * 4u, s);
-            else if (n == 2) join_pass<kFloat, 2>(p0, j.num_rows, r * 4u, s);
-            else join_pass<kFloat, 1>(p0, j.num_rows, r * 4u, s);
-        }
-        uint32_t w[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if constexpr (kFloat) w[c] = __float_as_uint(s[c]);
-            else w[c] = s[c];
-        }
-        if (r >= row0 && r + 4u <= row0 + nrows) {
-            *reinterpret_cast<uint4*>(j.y + r) = make_uint4(w[0], w[1], w[2], w[3]);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (r + c >= row0 && r + c < row0 + nrows) j.y[r + c] = w[c];
-        }
-    }
 }
 
 }  // namespace

@@ -25,12 +25,6 @@ struct SpmvLaunch {
     uint32_t num_workgroups;
     uint32_t lds_bytes;
     uint32_t bitmap_x_groups = 0; // BITMAP: lds_bytes ends with room for this many 64-column groups of x (0: x is read through L2)
-    // column-sliced plans with the combine folded into the kernel (spmv_device.h: SliceJoin): `out` holds the partials, the last block of a
-    // row range to finish adds them up and writes `y_final`.  join_arrivals == nullptr: the caller runs launch_combine_slices instead.
-    uint32_t* join_arrivals = nullptr;   // one zeroed word per row (indexed by a row range's first row)
-    uint32_t* y_final = nullptr;
-    uint32_t num_rows = 0;
-    uint32_t col_slices = 1;
     bool light = false;           // the LIGHT plan (StreamTiles::light): a PAIRS image consumed by spmv_light_kernel, 256-thread workgroups, lds_bytes = spmv_light_lds_bytes
 };
 

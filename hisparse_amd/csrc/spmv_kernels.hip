@@ -704,7 +704,7 @@ template <bool kFloat, int kRing, int kAblate, int kDepth, bool kOwner = false>
 __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const Unit* __restrict__ units, const uint32_t* __restrict__ x,
                                                                   uint32_t* __restrict__ out, int32_t row_part_filter, uint32_t ring,
-                                                                  uint32_t x_base, const uint32_t* __restrict__ part_heads, SliceJoin join) {
+                                                                  uint32_t x_base, const uint32_t* __restrict__ part_heads) {
     using acc_t = typename Rows<kFloat>::acc_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     acc_t* ys = reinterpret_cast<acc_t*>(lds);                    // [nrows + 1] at LDS address 0: row addresses need no base add
@@ -838,7 +838,6 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
             __syncthreads();
             timeline_stamp<kAblate>(block_no, wave, lane, 3);
             if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = reinterpret_cast<uint32_t*>(ys)[i];     // fp32 bits, or the saturated Q8.24 sum
-            if (join.arrivals && nrows) join_slices<kFloat, kThreads>(join, out, blk->row0, nrows, tid, reinterpret_cast<uint32_t*>(lds));
             timeline_stamp<kAblate>(block_no, wave, lane, 4);
             if (!next) break;
             continue;
@@ -851,7 +850,6 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
         timeline_stamp<kAblate>(block_no, wave, lane, 3);
         // the accumulators are final (no barrier after the store: the last block's stores drain while the workgroup retires)
         if (!(kAblate & 32)) for (uint32_t i = tid; i < nrows; i += kThreads) out[out0 + i] = Rows<kFloat>::finish(ys[i]);
-        if (join.arrivals && nrows) join_slices<kFloat, kThreads>(join, out, blk->row0, nrows, tid, reinterpret_cast<uint32_t*>(lds));     // column-sliced plan: the last block of the row range writes y
         timeline_stamp<kAblate>(block_no, wave, lane, 4);
         if (!next) break;
     }
@@ -1196,7 +1194,6 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     const int ring = a.format == kFormatDelta ? 1 : a.format == kFormatPairs24 ? 2 : 0;
     const dim3 grid(a.num_workgroups), block(kThreads);
     const uint32_t x_base = a.lds_bytes - a.ring_buffers * kBufBytes;
-    const SliceJoin join = slice_join(a);
     // profiling aids (libhisparse_hip_prof.so only): HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the
     // prefetch depth; read per launch, a tool may change them between launches.  The product library refuses to run with either set.
     int ablate = 0, depth = 8;
@@ -1235,7 +1232,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(A)                                                                                                                       \
     if (ablate == A) {                                                                                                             \
         hipLaunchKernelGGL((spmv_rowblock_kernel<false, 3, A, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
-                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads, join);                                               \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
         return hipGetLastError();                                                                                                  \
     }
             HS_FOR_EACH_OWNER24_FIXED(X)
@@ -1245,7 +1242,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(A)                                                                                                                       \
     if (ablate == A && records == 3) {                                                                                             \
         hipLaunchKernelGGL((spmv_rowblock_kernel<true, 3, A, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
-                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads, join);                                               \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
         return hipGetLastError();                                                                                                  \
     }
         HS_FOR_EACH_OWNER24_ABLATION(X)
@@ -1254,7 +1251,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(D)                                                                                                                       \
     if (records == D) {                                                                                                            \
         hipLaunchKernelGGL((spmv_rowblock_kernel<true, 3, 0, D, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
-                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads, join);                                               \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
         return hipGetLastError();                                                                                                  \
     }
         HS_FOR_EACH_OWNER24_DEPTH(X)
@@ -1274,7 +1271,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(A)                                                                                                                      \
     if (!launched && ablate == A) {                                                                                               \
         hipLaunchKernelGGL((spmv_rowblock_kernel<true, false, A, 8, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks,  \
-                           a.units, a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads, join);                        \
+                           a.units, a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                        \
         launched = true;                                                                                                          \
     }
         if (depth == 8) {
@@ -1297,7 +1294,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(F, T, A, D)                                                                                                           \
     if (!launched && is_float == F && ring == int(T) && ablate == A && depth == D) {                                     \
         hipLaunchKernelGGL((spmv_rowblock_kernel<F, T, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \
-                           a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads, join);                   \
+                           a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                   \
         launched = true;                                                                                                        \
     }
     HS_FOR_EACH_VARIANT(X)

@@ -157,7 +157,7 @@ __device__ __forceinline__ void sweep_round(std::integer_sequence<int, Ks...>, S
 template <bool kFloat, int kAblate>
 __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
-                                                                  int32_t row_part_filter, const uint32_t* __restrict__ part_heads, SliceJoin join) {
+                                                                  int32_t row_part_filter, const uint32_t* __restrict__ part_heads) {
     using R = SweepRows<kFloat>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* ys = lds;                                            // nrows + 1 sums (+ the carry bitmap in fixed point)
@@ -212,7 +212,6 @@ __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t
         asm volatile("" ::"v"(flushed));
         __syncthreads();
         for (uint32_t i = tid; i < nrows; i += kSweepThreads) out[out0 + i] = R::finish(ys, nrows, i);
-        if (join.arrivals && nrows) join_slices<kFloat, kSweepThreads>(join, out, blk->row0, nrows, tid, reinterpret_cast<uint32_t*>(lds));     // column-sliced plan: the last block of the row range writes y
         if (!next) break;
     }
 }
@@ -244,11 +243,10 @@ hipError_t launch_spmv_sweep(bool is_float, const SpmvLaunch& a, hipStream_t str
     int ablate = 0, depth = 8;
     if (!profiling_switches(ablate, depth)) return hipErrorInvalidValue;
     const dim3 grid(a.num_workgroups), block(kSweepThreads);
-    const SliceJoin join = slice_join(a);
 #define X(A)                                                                                                                                         \
     if (ablate == A) {                                                                                                                               \
-        if (is_float) hipLaunchKernelGGL((spmv_sweep_kernel<true, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads, join); \
-        else hipLaunchKernelGGL((spmv_sweep_kernel<false, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads, join);       \
+        if (is_float) hipLaunchKernelGGL((spmv_sweep_kernel<true, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads); \
+        else hipLaunchKernelGGL((spmv_sweep_kernel<false, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads);       \
         return hipGetLastError();                                                                                                                    \
     }
     HS_FOR_EACH_SWEEP_VARIANT(X)

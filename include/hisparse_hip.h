@@ -73,13 +73,12 @@ typedef struct {
     uint32_t num_workgroups;    /* grid size of the SpMV kernel */
     uint32_t lds_bytes;         /* dynamic LDS per workgroup (two x sub-tile buffers + row accumulators) */
     uint32_t num_compute_units; /* of the device */
-    uint32_t col_slices;        /* column slices (1 = none; > 1: per-slice partial results are combined, see slice_join) */
+    uint32_t col_slices;        /* column slices (1 = none; > 1 adds the small combine pass) */
     uint32_t ring_buffers;      /* x sub-tile buffers in the LDS ring */
     uint32_t stream_format;     /* HS_STREAM_PAIRS (8 B per element), HS_STREAM_DELTA (6 B per slot) or HS_STREAM_BITMAP (4 B + 1 bit per column) HS_STREAM_OWNER (8 B per element, float accumulators) the 7-byte forms of PAIRS / OWNER, or HS_STREAM_SWEEP (8 B per element in column order, x gathered from L2: very sparse matrices), chosen per matrix */
     double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
     uint32_t retiled_on_gpu;    /* 1: the per-non-zero passes of the re-tiling ran on the device (gpu_tiles.h); 0: on the host */
     uint32_t light_kernel;      /* 1: the LIGHT plan -- a small matrix run by the 256-thread single-launch kernel (spmv_light_kernel) over a PAIRS image */
-    uint32_t slice_join;        /* col_slices > 1 -- 1: the partial results of the column slices are added up INSIDE the SpMV kernel (the last block of a row range to finish writes y: one launch per SpMV); 0: by a second, small launch */
 } hs_stats;
 
 const char* hs_strerror(int code);
@@ -135,7 +134,7 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
  * (pairs|delta|owner|owner24|sweep|bitmap), col_slices, max_rows, row_runs, aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
  * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), sweep (0|1: the
  * column-ordered format of very sparse matrices), plan_debug; call-time keys: spmm_fused, spmm_mfma,
- * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph, slice_join (0|1: the combine of the column slices inside the SpMV kernel).  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
+ * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph.  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
  * Options set here win over the environment variable of the same name, which stays as the fallback for tools and tests.  None of them
  * changes WHAT is computed.  The switches that do (HISPARSE_ABLATE, HISPARSE_DEPTH: profiling builds with parts of the work removed) are
  * not options: they exist only in libhisparse_hip_prof.so, and this library refuses to run (HS_ERR_BAD_ARG from hs_run, hs_run_partition,
