@@ -122,9 +122,9 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
             uint32_t live = rg.nrows;
             while (live > 0 && row_nnz[rg.row0 + live - 1] == 0) --live;
             if (live == 0 || live == rg.nrows) { cut.push_back(rg); cut_nnz.push_back(range_nnz[i]); continue; }
-            cut.push_back(RowRange{rg.row0, live, rg.row_part});
+            cut.push_back(RowRange{rg.row0, live, rg.row_part, L.part_of_row(rg.row0 + live - 1)});
             cut_nnz.push_back(range_nnz[i]);
-            cut.push_back(RowRange{rg.row0 + live, rg.nrows - live, rg.row_part});
+            cut.push_back(RowRange{rg.row0 + live, rg.nrows - live, L.part_of_row(rg.row0 + live), rg.last_part});
             cut_nnz.push_back(0);
         }
         ranges.swap(cut);
@@ -237,6 +237,7 @@ bool build_bitmap_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANN
         blk.row0 = rg.row0;
         blk.nrows = rg.nrows;
         blk.row_part = rg.row_part;
+        blk.last_part = rg.last_part;
         blk.flags = 0;
         blk.out_offset = slices > 1 ? k * num_rows + rg.row0 : rg.row0;
         blk.unit_begin = uint32_t(bi * kBitmapWaves * kBitmapRunSlots);

@@ -54,6 +54,9 @@ struct hs_context {
     uint32_t format = 0;           // StreamFormat of d_image
     bool light = false;            // the LIGHT plan: d_image is a PAIRS image run by spmv_light_kernel (stream_tiles.h)
     uint32_t* d_partial = nullptr;  // col_slices > 1: per-slice partial results, col_slices x num_rows words
+    bool crossing_blocks = false;   // some row block reaches over a row-partition border (tiles_common.h: Layout::cross_parts)
+    uint32_t* d_partition_y = nullptr;   // hs_run_partition on a one-slice plan with such blocks: the kernel writes here (num_rows words,
+                                         // allocated on first use), the partition's own rows are then copied into y
     uint32_t max_block_rows = 0;
     uint32_t* d_x_interleaved = nullptr;   // fused SpMM over a BITMAP image: 4 columns of X as [column][vector] words (allocated on first use)
     // SpMM on the matrix engine (float BITMAP matrices): the second image + scratch (spmm_mfma.hip)
@@ -120,7 +123,7 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 
 // hs_set_option's keys (the HISPARSE_<KEY> environment switches the library understands); plan-time ones take effect at the next load
 const char* const kOptionKeys[] = {
-    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
+    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
     "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS", "SWEEP",
     "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH",
 };
@@ -134,6 +137,9 @@ void free_matrix(hs_context* c) {
     if (c->d_y) (void)hipFree(c->d_y);
     if (c->d_partial) (void)hipFree(c->d_partial);
     c->d_partial = nullptr;
+    if (c->d_partition_y) (void)hipFree(c->d_partition_y);
+    c->d_partition_y = nullptr;
+    c->crossing_blocks = false;
     if (c->d_x_interleaved) (void)hipFree(c->d_x_interleaved);
     c->d_x_interleaved = nullptr;
     for (void* p : {static_cast<void*>(c->d_mfma), static_cast<void*>(c->d_mfma_x), static_cast<void*>(c->d_mfma_partial), static_cast<void*>(c->d_mfma_flag)})
@@ -215,9 +221,23 @@ void partition_rows(const hs_context* c, uint32_t j, uint32_t& lo, uint32_t& hi)
 struct Feedback { uint32_t scale, shift; };
 int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1, const Feedback* feedback = nullptr) {
     if (const char* why = hisparse::dev::profiling_switch_error()) return fail(c, HS_ERR_BAD_ARG, why);
+    hisparse::dev::SpmvLaunch args = launch_args(c, filter);
+    // One partition of a plan whose row blocks reach over partition borders: the blocks that intersect the partition run (Block::next_part)
+    // and compute rows of its neighbours too.  "Rows of other partitions keep their previous contents" (hisparse_hip.h): a column-sliced
+    // plan combines the partition's rows only (below); a one-slice plan writes to a side buffer and the partition's rows are copied over.
+    const bool side_y = filter >= 0 && c->crossing_blocks && c->col_slices == 1;
+    if (side_y) {
+        if (!c->d_partition_y) HS_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->d_partition_y), size_t(c->num_rows) * 4));
+        args.out = c->d_partition_y;
+    }
     if (k0) HS_HIP(c, hipEventRecord(k0, c->stream));
-    HS_HIP(c, hisparse::dev::launch_spmv(c->impl != HS_IMPL_FIXED, launch_args(c, filter), c->stream));
+    HS_HIP(c, hisparse::dev::launch_spmv(c->impl != HS_IMPL_FIXED, args, c->stream));
     if (k1) HS_HIP(c, hipEventRecord(k1, c->stream));
+    if (side_y) {
+        uint32_t lo = 0, hi = 0;
+        partition_rows(c, uint32_t(filter), lo, hi);
+        HS_HIP(c, hipMemcpyAsync(y_target(c) + lo, c->d_partition_y + lo, size_t(hi - lo) * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
     const bool is_float = c->impl != HS_IMPL_FIXED;
     uint32_t* x = const_cast<uint32_t*>(x_source(c));
     const uint32_t n_fb = std::min(c->num_rows, c->num_cols);
@@ -458,6 +478,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     ctx->lds_bytes = lds_bytes;
     ctx->bitmap_x_groups = tiles.bitmap_x_groups;
     ctx->col_slices = tiles.col_slices;
+    for (const Block& b : tiles.blocks) ctx->crossing_blocks = ctx->crossing_blocks || b.last_part != b.row_part;
     ctx->max_block_rows = tiles.max_block_rows;
     ctx->ring_buffers = tiles.ring_buffers;
     ctx->format = tiles.format;

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
     uint32_t staged_col0 = 0, staged_groups = 0;      // kXLds: the stretch of x the LDS holds
     for (uint32_t next = 0;; bi = next) {
         const BlockTable blk = (BlockTable)(blocks + bi);
-        next = (row_part_filter >= 0 && (blk->flags & kBlockLastOfPartition)) ? 0u : blk->next;
+        next = (row_part_filter >= 0 && blk->next_part > static_cast<uint32_t>(row_part_filter)) ? 0u : blk->next;
         const uint32_t nrows = blk->nrows, out0 = blk->out_offset;
         // the block's 16 wavefront runs sit at units[16 bi ..] (the builder stores them in final block order): descriptor and run
         // are fetched side by side, one dependent round trip before the first mask load instead of two

@@ -720,8 +720,8 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
 
     // The workgroup's first block is blocks[wg]; further ones are chained through Block::next (0 = none).  Everything a
     // consumer wavefront needs before its first stream load sits in the Block itself: ONE dependent load per block.
-    // hs_run_partition: only the blocks of one row partition -- the workgroup's chain is ordered by partition, part_heads says
-    // where this partition's stretch begins and kBlockLastOfPartition where it ends.
+    // hs_run_partition: only the blocks that reach into one row partition -- the workgroup's chain is in row order, part_heads says
+    // where this partition's stretch begins, and it goes on while the next block begins in this partition or before (Block::next_part).
     uint32_t bi = wg;
     if (row_part_filter >= 0) {
         bi = ((const __attribute__((address_space(4))) uint32_t*)part_heads)[static_cast<uint32_t>(row_part_filter) * gridDim.x + wg];
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
     uint32_t block_no = 0;      // timeline build only
     for (uint32_t next = 0;; bi = next, ++block_no) {
         const BlockTable blk = (BlockTable)(blocks + bi);
-        next = (row_part_filter >= 0 && (blk->flags & kBlockLastOfPartition)) ? 0u : blk->next;
+        next = (row_part_filter >= 0 && blk->next_part > static_cast<uint32_t>(row_part_filter)) ? 0u : blk->next;
         const uint32_t nrows = blk->nrows, out0 = blk->out_offset;
         const UnitTable unit = (UnitTable)(units + blk->unit_begin);
         const uint32_t U = blk->unit_end - blk->unit_begin;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(kLightThreads, 6) void spmv_light_kernel(const uint
     bool first_block = true;
     for (uint32_t next = 0;; bi = next) {
         const BlockTable blk = (BlockTable)(blocks + bi);
-        next = (row_part_filter >= 0 && (blk->flags & kBlockLastOfPartition)) ? 0u : blk->next;
+        next = (row_part_filter >= 0 && blk->next_part > static_cast<uint32_t>(row_part_filter)) ? 0u : blk->next;
         const uint32_t nrows = blk->nrows, out0 = blk->out_offset, ub = blk->unit_begin;
         const uint32_t U = blk->unit_end - ub;
         const uint8_t* chunks = scalar_pointer(image + blk->wave_offset[0]);      // chunk g of the block at g * 512 (scalar base + 32-bit offset: a block's stream stays below 4 GiB)

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t
     bool first_block = true;
     for (uint32_t next = 0;; bi = next) {
         const BlockTable blk = (BlockTable)(blocks + bi);
-        next = (row_part_filter >= 0 && (blk->flags & kBlockLastOfPartition)) ? 0u : blk->next;
+        next = (row_part_filter >= 0 && blk->next_part > static_cast<uint32_t>(row_part_filter)) ? 0u : blk->next;
         const uint32_t nrows = blk->nrows, out0 = blk->out_offset, steps = blk->total_steps[0], pad_col = blk->first_col0;
         const uint8_t* stream = sweep_scalar_pointer(image + blk->wave_offset[0] + uint64_t(wave) * kChunkBytes);
         const __attribute__((address_space(4))) uint32_t* bases =

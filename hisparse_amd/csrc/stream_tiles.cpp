@@ -71,6 +71,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     L.F = geom.interleave;
     L.sub_width = uint32_t(std::min<uint64_t>(kSubTileCols, geom.logical_vb));
     L.subs_per_cp = uint32_t((geom.logical_vb + L.sub_width - 1) / L.sub_width);
+    if (const char* cross = env_switch("HISPARSE_CROSS_PARTITIONS")) L.cross_parts = std::atoi(cross) != 0;
     const uint32_t F = L.F, CP = num_col_partitions, RP = num_row_partitions, S = L.subs_per_cp;
     const bool is_float = geom.impl != IMPL_FIXED;
     const uint64_t header_pkts = uint64_t(RP) * CP * (1 + F);
@@ -338,6 +339,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     std::vector<uint32_t> cnt(size_t(NR) * slots_per_range, 0);
     auto slot = [&](uint32_t b, uint32_t cp, uint32_t s, uint32_t pc) { return size_t(b) * slots_per_range + (size_t(cp) * S + s) * NUM_HBM_CHANNELS + pc; };
     std::vector<WalkResult> res1(size_t(RP) * CP * NUM_HBM_CHANNELS);
+    const size_t walk_tasks = L.cross_parts ? size_t(CP) * NUM_HBM_CHANNELS : res1.size();      // host passes 1 and 2 (see pass 1)
     if (gpu) {      // totals per (range, sub-tile); the per-source-channel split only serves the host's scatter
         std::vector<uint32_t> totals;
         if (!gpu->count_tiles(block_of_row, NR, totals)) { error = gpu->error(); return false; }
@@ -345,11 +347,14 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             for (uint32_t cp = 0; cp < CP; ++cp)
                 for (uint32_t sub = 0; sub < S; ++sub) cnt[slot(b, cp, sub, 0)] = totals[(size_t(b) * CP + cp) * S + sub];
     } else {
-    parallel_for(res1.size(), [&](size_t w) {
-        const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP), rp = uint32_t(w / NUM_HBM_CHANNELS / CP);
-        res1[w] = walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t) {
-            cnt[slot(block_of_row[row], cp, col / L.sub_width, pc)]++;
-        });
+    // (row ranges that cross partition borders: the counters of a (range, sub-tile, channel) are fed from two row partitions, so one task
+    //  takes ALL row partitions of its (column partition, channel), one after the other)
+    parallel_for(walk_tasks, [&](size_t w) {
+        const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP);
+        for (uint32_t rp = L.cross_parts ? 0u : uint32_t(w / NUM_HBM_CHANNELS / CP), rp_end = L.cross_parts ? RP : rp + 1; rp < rp_end; ++rp)
+            res1[(size_t(rp) * CP + cp) * NUM_HBM_CHANNELS + pc] = walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t) {
+                cnt[slot(block_of_row[row], cp, col / L.sub_width, pc)]++;
+            });
     });
     for (const auto& r : res1)
         if (!r.ok) { error = r.error; return false; }
@@ -388,6 +393,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             blk.row0 = ranges[b].row0;
             blk.nrows = ranges[b].nrows;
             blk.row_part = ranges[b].row_part;
+            blk.last_part = ranges[b].last_part;
             if (delta) {   // long rows: position gaps well inside a row (HISPARSE_ROW_RUNS=0|1 forces, for the tests)
                 // (over the rows that HAVE non-zeros: the padding rows at the end of a float_stall matrix would make the last block look sparse)
                 uint32_t live_rows = 0;
@@ -456,14 +462,15 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         }
     } else {
     scratch.resize(scratch_elems);
-    parallel_for(res1.size(), [&](size_t w) {
-        const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP), rp = uint32_t(w / NUM_HBM_CHANNELS / CP);
-        walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t val) {
-            const uint32_t b = block_of_row[row], s = col / L.sub_width;
-            const UnitPlan& up = plans[unit_of[(size_t(b) * CP + cp) * S + s]];
-            const uint32_t pos = (row - ranges[b].row0) * kSubTileCols + (col - s * L.sub_width);
-            scratch[up.scratch + cnt[slot(b, cp, s, pc)]++] = (uint64_t(pos) << 32) | val;
-        });
+    parallel_for(walk_tasks, [&](size_t w) {
+        const uint32_t pc = uint32_t(w % NUM_HBM_CHANNELS), cp = uint32_t((w / NUM_HBM_CHANNELS) % CP);
+        for (uint32_t rp = L.cross_parts ? 0u : uint32_t(w / NUM_HBM_CHANNELS / CP), rp_end = L.cross_parts ? RP : rp + 1; rp < rp_end; ++rp)
+            walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t val) {
+                const uint32_t b = block_of_row[row], s = col / L.sub_width;
+                const UnitPlan& up = plans[unit_of[(size_t(b) * CP + cp) * S + s]];
+                const uint32_t pos = (row - ranges[b].row0) * kSubTileCols + (col - s * L.sub_width);
+                scratch[up.scratch + cnt[slot(b, cp, s, pc)]++] = (uint64_t(pos) << 32) | val;
+            });
     });
     std::vector<uint32_t>().swap(cnt);
 

@@ -201,14 +201,14 @@ constexpr uint32_t kSweepColAlign = 32;                       // slices start on
 constexpr uint64_t kSweepMinNnz = (2u << 20) + 1;             // smaller matrices: the LIGHT plan's (when x is short) or the row-block kernel's
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit
-constexpr uint32_t kBlockLastOfPartition = 2u;                // Block::flags bit: the workgroup's last block of this row partition
+constexpr uint32_t kBlockLastOfPartition = 2u;                // Block::flags bit: the workgroup's next block (if any) begins in a LATER row partition than this one ends in
 constexpr uint32_t kNoBlock = 0xffffffffu;
 
 // Mirrored in the kernel source (read through scalar loads).
 struct Block {
     uint32_t row0;          // first row (absolute, padded numbering)
     uint32_t nrows;         // <= max_block_rows(); local row nrows is the spare accumulator padding elements hit (OWNER: nrows + wave)
-    uint32_t row_part;      // row partition (hs_run_partition filter)
+    uint32_t row_part;      // row partition of the block's first row (hs_run_partition runs the blocks with row_part <= filter <= last_part)
     uint32_t unit_begin;    // units [unit_begin, unit_end), consumed in this order
     uint32_t unit_end;
     uint32_t flags;         // kBlockDenseRows: long rows.  PAIRS: chunks are dealt linearly and mostly hold ONE row (wavefront-wide
@@ -221,7 +221,9 @@ struct Block {
     uint32_t total_steps[kConsumerWaves];   // == units[unit_end - 1].end_step
     uint32_t first_end[kConsumerWaves];     // == units[unit_begin].end_step
     uint32_t first_col0, first_ncols;       // == units[unit_begin].col0 / .ncols (0 / 0 for a block without units)
-    uint32_t pad[14];
+    uint32_t last_part;     // row partition of the block's LAST row (>= row_part: since round 5 a row range may cross partition borders)
+    uint32_t next_part;     // row_part of the workgroup's next block, 0xffffffff: none -- a run of partition p (hs_run_partition) goes on while next_part <= p
+    uint32_t pad[12];
 };
 struct Unit {
     uint32_t col0;          // first absolute column of the x sub-tile

@@ -47,12 +47,11 @@ struct Placed { uint64_t key; uint32_t value; };      // key = column << 16 | lo
 // The plan: column slices x row ranges at the lowest modelled cost (microseconds; the model's terms are in the comment above).  Also what
 // build_stream_tiles compares with its estimate for OWNER24 when it chooses between the two formats.
 double sweep_plan(const Layout& L, uint64_t nnz, uint32_t max_workgroups, uint32_t& slices, uint64_t& want_ranges, uint32_t& max_rows) {
-    const uint32_t num_rows = L.num_rows, num_cols = L.num_cols, RP = L.row_parts;
+    const uint32_t num_rows = L.num_rows, num_cols = L.num_cols;
     const uint32_t G = std::max<uint32_t>(1, max_workgroups);
     max_rows = L.g->impl == IMPL_FIXED ? kSweepMaxBlockRowsFixed : kSweepMaxBlockRowsFloat;
     if (const char* force = env_switch("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force)));
-    uint64_t by_cap = 0;
-    for (uint32_t rp = 0; rp < RP; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + max_rows - 1) / max_rows;
+    const uint64_t by_cap = detail::ranges_by_cap(L, max_rows);
     const uint32_t lines = (num_cols + kSweepColAlign - 1) / kSweepColAlign;
     const char* force_slices = env_switch("HISPARSE_COL_SLICES");
     double best = 1e30;
@@ -258,6 +257,7 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
         blk.row0 = rg.row0;
         blk.nrows = rg.nrows;
         blk.row_part = rg.row_part;
+        blk.last_part = rg.last_part;
         blk.flags = 0;
         blk.out_offset = slices > 1 ? (bi % slices) * num_rows + rg.row0 : rg.row0;
         blk.total_steps[0] = steps;

@@ -94,6 +94,13 @@ inline void resize_zeroed(ImageBytes& v, size_t n) {
 struct Layout {
     const Geometry* g;
     uint32_t num_rows, num_cols, row_parts, col_parts, F;
+    // Row ranges may CROSS row-partition borders (round 5).  The reference's partitions are the size of its on-chip output banks
+    // (131 072 rows in float_pob: 19 of them on ogbn-products) -- a bank the GPU does not have; cutting every range at their borders cost
+    // 16-50 % more (row range x sub-tile) units and uneven rounds of blocks.  hs_run_partition still runs one partition at a time: the
+    // blocks that INTERSECT it (Block::row_part <= p <= Block::last_part), results kept for the partition's rows only (hs_api.cpp).
+    // HISPARSE_CROSS_PARTITIONS=0: ranges end at the borders again.
+    bool cross_parts = true;
+    uint32_t part_of_row(uint32_t row) const { return uint32_t(row / g->logical_ob); }
     uint32_t sub_width;     // columns per x sub-tile
     uint32_t subs_per_cp;   // sub-tiles per column partition
     uint32_t rows_in_part(uint32_t rp) const {
@@ -185,7 +192,7 @@ struct UnitPlan {           // host-side companion of a device Unit
     uint32_t own_last[kConsumerWaves] = {}; // ... and of its last one
 };
 
-struct RowRange { uint32_t row0, nrows, row_part; };
+struct RowRange { uint32_t row0, nrows, row_part, last_part; };      // row_part / last_part: row partition of the first / last row
 
 // OWNER: cut one unit's n sorted elements into the 14 wavefronts' shares (stream_tiles.h).  Rows may only change hands BETWEEN units
 // (the unit barrier orders the accumulator writes), so the cut is made per unit, for equal work: the unit's ceil(n / 64) chunks are
@@ -252,10 +259,15 @@ inline void assign_workgroups(StreamTiles& out, const std::vector<uint64_t>& blo
     mine.assign(groups, {});
     std::vector<uint64_t> load(groups, 0), part_load(groups, 0);
     std::vector<std::vector<uint32_t>> by_rank(groups);
+    // blocks that cross partition borders: ONE balance over the whole SpMV (what hs_run launches), every workgroup's blocks then in
+    // row order, which is partition order; hs_run_partition finds the blocks of a partition spread as they fall
+    bool crossing = false;
+    for (uint32_t b = 0; b < NB; ++b) crossing = crossing || out.blocks[b].last_part != out.blocks[b].row_part;
+    if (crossing) row_parts = 1;
     for (uint32_t rp = 0; rp < row_parts; ++rp) {
         std::vector<uint32_t> order;
         for (uint32_t b = 0; b < NB; ++b)
-            if (out.blocks[b].row_part == rp) order.push_back(b);
+            if (crossing || out.blocks[b].row_part == rp) order.push_back(b);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return block_weight[a] > block_weight[b]; });
         std::fill(part_load.begin(), part_load.end(), 0);
         for (uint32_t b : order) {
@@ -269,6 +281,7 @@ inline void assign_workgroups(StreamTiles& out, const std::vector<uint64_t>& blo
     }
     for (uint32_t i = 0; i < groups; ++i) {
         const uint32_t g = groups % 8 == 0 ? (i % 8) * (groups / 8) + i / 8 : i;
+        if (crossing) std::stable_sort(by_rank[i].begin(), by_rank[i].end(), [&](uint32_t a, uint32_t b) { return out.blocks[a].row0 < out.blocks[b].row0; });
         mine[g].swap(by_rank[i]);
     }
 }
@@ -306,7 +319,7 @@ inline void assign_workgroups_by_slice(StreamTiles& out, const std::vector<uint6
             load[best] += block_weight[b] + 16;
         }
         for (uint32_t g = x * per_xcd; g < (x + 1) * per_xcd; ++g)
-            std::stable_sort(mine[g].begin(), mine[g].end(), [&](uint32_t a, uint32_t b) { return out.blocks[a].row_part < out.blocks[b].row_part; });
+            std::stable_sort(mine[g].begin(), mine[g].end(), [&](uint32_t a, uint32_t b) { return out.blocks[a].row0 < out.blocks[b].row0; });      // row order = partition order
     }
     (void)row_parts;
 }
@@ -329,11 +342,15 @@ inline void chain_blocks(StreamTiles& out, const std::vector<std::vector<uint32_
         out.wg_first[g] = uint32_t(out.block_order.size());
         for (size_t k = 0; k < mine[g].size(); ++k) {
             Block blk = out.blocks[mine[g][k]];
-            const bool last_of_part = k + 1 == mine[g].size() || out.blocks[mine[g][k + 1]].row_part != blk.row_part;
-            const bool first_of_part = k == 0 || out.blocks[mine[g][k - 1]].row_part != blk.row_part;
+            // the chain is in partition order (blocks inside partitions: sorted by row_part; crossing blocks: sorted by row0).  A run of
+            // partition p starts at the first block that reaches p (part_heads) and goes on while the next block begins in p or before
+            // (the kernels test next_part <= p: several column slices of one crossing row range may follow each other)
+            const bool last_of_part = k + 1 == mine[g].size() || out.blocks[mine[g][k + 1]].row_part > blk.last_part;
             blk.next = k + 1 < mine[g].size() ? new_index[mine[g][k + 1]] : 0u;
+            blk.next_part = k + 1 < mine[g].size() ? out.blocks[mine[g][k + 1]].row_part : 0xffffffffu;
             if (last_of_part) blk.flags |= kBlockLastOfPartition;
-            if (first_of_part) out.part_heads[size_t(blk.row_part) * groups + g] = new_index[mine[g][k]];
+            for (uint32_t p = blk.row_part; p <= blk.last_part && p < row_parts; ++p)
+                if (blk.nrows && out.part_heads[size_t(p) * groups + g] == kNoBlock) out.part_heads[size_t(p) * groups + g] = new_index[mine[g][k]];
             moved[new_index[mine[g][k]]] = blk;
             out.block_order.push_back(new_index[mine[g][k]]);
         }
@@ -345,15 +362,16 @@ inline void chain_blocks(StreamTiles& out, const std::vector<std::vector<uint32_
 // Row ranges of roughly `target` non-zeros each, at most max_rows rows, never across a row partition.
 inline void build_row_ranges(const Layout& L, const std::vector<uint32_t>& row_nnz, uint64_t target, uint32_t max_rows,
                              std::vector<RowRange>& ranges, std::vector<uint64_t>& range_nnz) {
-    for (uint32_t rp = 0; rp < L.row_parts; ++rp) {
-        const uint32_t lo = uint32_t(uint64_t(rp) * L.g->logical_ob), hi = lo + L.rows_in_part(rp);
+    const uint32_t stretches = L.cross_parts ? 1u : L.row_parts;      // crossing: the rows are ONE stretch
+    for (uint32_t rp = 0; rp < stretches; ++rp) {
+        const uint32_t lo = L.cross_parts ? 0u : uint32_t(uint64_t(rp) * L.g->logical_ob), hi = L.cross_parts ? L.num_rows : lo + L.rows_in_part(rp);
         uint32_t r0 = lo;
         uint64_t acc = 0;
         for (uint32_t r = lo; r < hi; ++r) {
             // close the range BEFORE a row that would overshoot the target by more than the range undershoots now
             const uint64_t with = acc + row_nnz[r];
             if (r > r0 && (r - r0 == max_rows || (with > target && with - target > target - std::min(acc, target)))) {
-                ranges.push_back(RowRange{r0, r - r0, rp});
+                ranges.push_back(RowRange{r0, r - r0, L.part_of_row(r0), L.part_of_row(r - 1)});
                 range_nnz.push_back(acc);
                 r0 = r;
                 acc = 0;
@@ -361,7 +379,7 @@ inline void build_row_ranges(const Layout& L, const std::vector<uint32_t>& row_n
             acc += row_nnz[r];
         }
         if (hi > r0) {
-            ranges.push_back(RowRange{r0, hi - r0, rp});
+            ranges.push_back(RowRange{r0, hi - r0, L.part_of_row(r0), L.part_of_row(hi - 1)});
             range_nnz.push_back(acc);
         }
     }
@@ -374,11 +392,18 @@ inline void build_row_ranges(const Layout& L, const std::vector<uint32_t>& row_n
 // 19 x 6 = 114 ranges on ogbn-products where 2 x 51 were wanted -- the count is raised to the next multiple of round_to (the ranges one
 // round of workgroups takes), so that every workgroup gets the same number of (smaller) blocks instead of a third of them one block more:
 // 570 blocks over 256 workgroups ran 335.7 us, the round-3 figure of the same matrix in float_stall's 3 partitions 206.8 (round 4).
+// ranges the row cap alone forces
+inline uint64_t ranges_by_cap(const Layout& L, uint32_t max_rows) {
+    if (L.cross_parts) return (uint64_t(L.num_rows) + max_rows - 1) / max_rows;
+    uint64_t by_cap = 0;
+    for (uint32_t rp = 0; rp < L.row_parts; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + max_rows - 1) / max_rows;
+    return by_cap;
+}
+
 inline void build_row_ranges_at_most(const Layout& L, const std::vector<uint32_t>& row_nnz, uint64_t nnz, uint64_t want, uint32_t max_rows,
                                      std::vector<RowRange>& ranges, std::vector<uint64_t>& range_nnz, uint64_t round_to = 0) {
     if (round_to) {
-        uint64_t by_cap = 0;
-        for (uint32_t rp = 0; rp < L.row_parts; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + max_rows - 1) / max_rows;
+        const uint64_t by_cap = ranges_by_cap(L, max_rows);
         if (by_cap > want) want = (by_cap + round_to - 1) / round_to * round_to;
     }
     uint64_t target = std::max<uint64_t>(1, (nnz + want - 1) / want);
@@ -387,9 +412,7 @@ inline void build_row_ranges_at_most(const Layout& L, const std::vector<uint32_t
         range_nnz.clear();
         build_row_ranges(L, row_nnz, target, max_rows, ranges, range_nnz);
         if (ranges.size() <= want) return;
-        uint64_t by_cap = 0;                      // ranges the row cap alone forces
-        for (uint32_t rp = 0; rp < L.row_parts; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + max_rows - 1) / max_rows;
-        if (by_cap > want) return;
+        if (ranges_by_cap(L, max_rows) > want) return;      // the row cap alone forces more
         target += std::max<uint64_t>(1, target / 128);
     }
 }

@@ -45,7 +45,7 @@ CONSUMER_WAVES = 14
 BLOCK_DTYPE = np.dtype([("row0", "<u4"), ("nrows", "<u4"), ("row_part", "<u4"), ("unit_begin", "<u4"), ("unit_end", "<u4"),
                         ("flags", "<u4"), ("out_offset", "<u4"), ("next", "<u4"), ("wave_offset", "<u8", (CONSUMER_WAVES,)),
                         ("total_steps", "<u4", (CONSUMER_WAVES,)), ("first_end", "<u4", (CONSUMER_WAVES,)), ("first_col0", "<u4"),
-                        ("first_ncols", "<u4"), ("pad", "<u4", (14,))])
+                        ("first_ncols", "<u4"), ("last_part", "<u4"), ("next_part", "<u4"), ("pad", "<u4", (12,))])
 UNIT_DTYPE = np.dtype([("col0", "<u4"), ("ncols", "<u4"), ("end_step", "<u4", (CONSUMER_WAVES,))])
 
 

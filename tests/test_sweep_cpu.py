@@ -63,24 +63,29 @@ def test_sweep_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypa
         assert (want == 0xFFFFFFFF).any()
 
 
-def test_sweep_row_partitions_and_partition_filter():
-    # float_pob-style small output banks: several row partitions, run one at a time like hs_run_partition; blocks never cross a partition
+@pytest.mark.parametrize("cross", [0, 1])
+def test_sweep_row_partitions_and_partition_filter(cross, monkeypatch):
+    # float_pob-style small output banks: several row partitions, run one at a time like hs_run_partition; cross = 1 (default since
+    # round 5): blocks may reach over partition borders, cross = 0: they end there
+    monkeypatch.setenv("HISPARSE_CROSS_PARTITIONS", str(cross))
     m = cases.random_csr(2500, 300, 0.03, 21, 0)
     _, cp = cases.formatted(m, 0, 4, 1, True)
     assert cp.num_row_partitions > 3
     xw = host.pack_vector(0, cases.random_x(cp.num_cols, 21, 0))
     t = build(cp, 0, 16)
     assert t["format"] == "sweep"
+    blocks = t["blocks"]
+    assert (blocks["last_part"] != blocks["row_part"]).any() == bool(cross)
     for g in range(t["num_workgroups"]):
         chain = t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]
-        parts = t["blocks"]["row_part"][chain]
+        parts = blocks["row_part"][chain]
         assert (np.diff(parts.astype(np.int64)) >= 0).all()
-        last = (t["blocks"]["flags"][chain] & 2) != 0
-        assert np.array_equal(last, np.append(parts[1:] != parts[:-1], True))
+        last = (blocks["flags"][chain] & 2) != 0
+        assert np.array_equal(last, np.append(parts[1:] > blocks["last_part"][chain][:-1], True))
     full = tile_emulator.run(t, 0, xw, cp.num_rows)
     y = np.zeros(cp.num_rows, dtype=np.uint32)
     for j in range(cp.num_row_partitions):
-        y = tile_emulator.run(t, 0, xw, cp.num_rows, row_part_filter=j, y_init=y)
+        y = tile_emulator.run(t, 0, xw, cp.num_rows, row_part_filter=j, y_init=y, rows_per_part=128 * cp.ob_bank)
     assert np.array_equal(y, full) and np.array_equal(full, oracle_y(cp, 0, xw))
 
 

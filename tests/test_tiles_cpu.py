@@ -178,28 +178,43 @@ def test_delta_bridges(stream_format):
         assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
 
 
-def test_many_row_partitions_and_partition_filter():
-    # float_pob-style small output banks: several row partitions, run one at a time like hs_run_partition
+@pytest.mark.parametrize("cross", [0, 1])
+def test_many_row_partitions_and_partition_filter(cross, monkeypatch):
+    # float_pob-style small output banks: several row partitions, run one at a time like hs_run_partition.
+    # cross = 1 (the default since round 5): row ranges are cut by non-zeros and the LDS cap alone and may reach over partition borders;
+    # cross = 0: they end at the borders, and every partition is balanced over the workgroups by itself
+    monkeypatch.setenv("HISPARSE_CROSS_PARTITIONS", str(cross))
     m = cases.random_csr(2500, 300, 0.03, 21, 0)
     _, cp = cases.formatted(m, 0, 4, 1, True)
     assert cp.num_row_partitions > 3
     xw = host.pack_vector(0, cases.random_x(cp.num_cols, 21, 0))
     t = build(cp, 0, 16)
-    # a workgroup's chain visits the row partitions in order, every partition's stretch ends with the last-of-partition flag,
-    # and each partition is spread over the workgroups (block counts per workgroup differ by at most one)
+    blocks = t["blocks"]
+    crossing = (blocks["last_part"] != blocks["row_part"]).any()
+    assert crossing == bool(cross)
+    assert (blocks["row_part"] == blocks["row0"] // (128 * cp.ob_bank)).all()
+    assert (blocks["last_part"][blocks["nrows"] > 0] == ((blocks["row0"] + blocks["nrows"] - 1) // (128 * cp.ob_bank))[blocks["nrows"] > 0]).all()
+    # a workgroup's chain visits the row partitions in order; the last-of-partition flag: the next block begins beyond where this one ends
     for g in range(t["num_workgroups"]):
         chain = t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]
-        parts = t["blocks"]["row_part"][chain]
+        parts = blocks["row_part"][chain]
         assert (np.diff(parts.astype(np.int64)) >= 0).all()
-        last = (t["blocks"]["flags"][chain] & 2) != 0
-        assert np.array_equal(last, np.append(parts[1:] != parts[:-1], True))
-    for p in range(cp.num_row_partitions):
-        per_wg = [int((t["blocks"]["row_part"][t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]] == p).sum()) for g in range(t["num_workgroups"])]
+        last = (blocks["flags"][chain] & 2) != 0
+        assert np.array_equal(last, np.append(parts[1:] > blocks["last_part"][chain][:-1], True))
+    if not cross:      # each partition spread over the workgroups (block counts per workgroup differ by at most one)
+        for p in range(cp.num_row_partitions):
+            per_wg = [int((blocks["row_part"][t["block_order"][t["wg_first"][g]:t["wg_first"][g + 1]]] == p).sum()) for g in range(t["num_workgroups"])]
+            assert max(per_wg) - min(per_wg) <= 1
+    else:              # the whole SpMV spread over the workgroups
+        per_wg = [int(t["wg_first"][g + 1] - t["wg_first"][g]) for g in range(t["num_workgroups"])]
         assert max(per_wg) - min(per_wg) <= 1
     full = tile_emulator.run(t, 0, xw, cp.num_rows)
     y = np.zeros(cp.num_rows, dtype=np.uint32)
     for j in range(cp.num_row_partitions):
-        y = tile_emulator.run(t, 0, xw, cp.num_rows, row_part_filter=j, y_init=y)
+        before = y.copy()
+        y = tile_emulator.run(t, 0, xw, cp.num_rows, row_part_filter=j, y_init=y, rows_per_part=128 * cp.ob_bank)
+        lo, hi = j * 128 * cp.ob_bank, min(cp.num_rows, (j + 1) * 128 * cp.ob_bank)
+        assert np.array_equal(y[:lo], before[:lo]) and np.array_equal(y[hi:], before[hi:])      # rows of other partitions keep their contents
     assert np.array_equal(y, full) and np.array_equal(full, oracle_y(cp, 0, xw))
 
 
@@ -466,7 +481,7 @@ def test_blocks_go_to_xcds_by_column_slice(impl, ob, monkeypatch):
     assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
     y = np.zeros(cp.num_rows, dtype=np.uint32)
     for j in range(cp.num_row_partitions):      # the reference's launch loop: one row partition at a time
-        y = tile_emulator.run(t, impl, xw, cp.num_rows, row_part_filter=j, y_init=y)
+        y = tile_emulator.run(t, impl, xw, cp.num_rows, row_part_filter=j, y_init=y, rows_per_part=128 * cp.ob_bank)
     assert np.array_equal(y, want) if impl == 0 else cases.float_close(y, want)
 
 

@@ -223,8 +223,11 @@ def _block_sweep(image, blk, x_words, ys, is_float):
         _accumulate(ys, is_float, row, val, x_words[col])
 
 
-def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
-    """Returns packed y words.  tiles: dict from hisparse_amd.device.build_tiles."""
+def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None, rows_per_part=None):
+    """Returns packed y words.  tiles: dict from hisparse_amd.device.build_tiles.
+    row_part_filter >= 0 (hs_run_partition; needs rows_per_part = 128 x ob_bank): every workgroup starts at the first block of its chain
+    that reaches into the partition (part_heads) and goes on while the next block begins in the partition or before (Block::next_part);
+    only the partition's own rows receive results -- blocks may reach over partition borders since round 5."""
     is_float = impl != 0
     image, blocks, units = tiles["image"], tiles["blocks"], tiles["units"]
     delta = tiles["format"] == "delta"
@@ -234,20 +237,40 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
     sweep = tiles["format"] == "sweep"
     y = np.zeros(num_rows, dtype=np.uint32) if y_init is None else y_init.copy()
     slices = int(tiles.get("col_slices", 1))
-    out = y if slices == 1 else np.zeros(slices * num_rows, dtype=np.uint32)   # per-slice partial results
+    filtered = row_part_filter >= 0
+    if filtered:
+        assert rows_per_part, "a partition run needs rows_per_part"
+        part_lo, part_hi = row_part_filter * rows_per_part, min(num_rows, (row_part_filter + 1) * rows_per_part)
+    # one slice: the kernel writes y itself (a partition run: a side buffer, the partition's rows copied over); slices: per-slice partials
+    out = (y if not filtered else np.zeros(num_rows, dtype=np.uint32)) if slices == 1 else np.zeros(slices * num_rows, dtype=np.uint32)
     touched = np.zeros(num_rows, dtype=bool)
     done = np.zeros(len(blocks), dtype=bool)
     if not bitmap and not sweep:
         assert 2 <= tiles["ring_buffers"] <= 4
         assert (units["ncols"] % 8 == 0).all() and (units["ncols"] > 0).all() and (units["ncols"] <= SUB_TILE).all()
     for g in range(tiles["num_workgroups"]):
-        for q in range(tiles["wg_first"][g], tiles["wg_first"][g + 1]):
-            b = int(tiles["block_order"][q])
+        chain = [int(b) for b in tiles["block_order"][tiles["wg_first"][g]: tiles["wg_first"][g + 1]]]
+        for k, b in enumerate(chain):      # the chain the kernel follows through Block::next
             assert not done[b]
             done[b] = True
-            blk = blocks[b]
-            if row_part_filter >= 0 and int(blk["row_part"]) != row_part_filter:
+            assert int(blocks[b]["next"]) == (chain[k + 1] if k + 1 < len(chain) else 0)
+            assert int(blocks[b]["next_part"]) == (int(blocks[chain[k + 1]]["row_part"]) if k + 1 < len(chain) else 0xFFFFFFFF)
+        if filtered:
+            p = row_part_filter
+            start = next((k for k, b in enumerate(chain) if int(blocks[b]["nrows"]) and int(blocks[b]["row_part"]) <= p <= int(blocks[b]["last_part"])), None)
+            if start is None:
                 continue
+            stop = start
+            while int(blocks[chain[stop]]["next_part"]) <= p:
+                stop += 1
+            todo = chain[start: stop + 1]
+            # nothing of the partition lies outside the stretch the kernel walks
+            for b in chain[:start] + chain[stop + 1:]:
+                assert not (int(blocks[b]["nrows"]) and int(blocks[b]["row_part"]) <= p <= int(blocks[b]["last_part"]))
+        else:
+            todo = chain
+        for b in todo:
+            blk = blocks[b]
             nrows, row0, out0 = int(blk["nrows"]), int(blk["row0"]), int(blk["out_offset"])
             if sweep:      # the LDS holds the accumulators and nothing else: doubles / 32-bit sums + a carry bit per row
                 assert ((nrows + 1) * 8 if is_float else (nrows + 1) * 4 + (nrows + 32) // 32 * 4) <= 160 * 1024
@@ -269,7 +292,10 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
             else:
                 out[out0: out0 + nrows] = np.minimum(ys[:nrows], np.uint64(0xFFFFFFFF)).astype(np.uint32)
     assert done.all()
-    if slices > 1:   # combine_slices_kernel
+    if filtered:
+        touched[:part_lo] = False
+        touched[part_hi:] = False
+    if slices > 1:   # combine_slices_kernel (a partition run: over the partition's rows only)
         parts = out.reshape(slices, num_rows)[:, touched]
         if is_float:
             acc = np.zeros(parts.shape[1], dtype=np.float32)
@@ -278,4 +304,6 @@ def run(tiles, impl, x_words, num_rows, row_part_filter=-1, y_init=None):
             y[touched] = acc.view(np.uint32)
         else:
             y[touched] = np.minimum(parts.astype(np.uint64).sum(axis=0), np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    elif filtered:
+        y[part_lo:part_hi] = out[part_lo:part_hi]
     return y
