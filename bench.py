@@ -218,6 +218,20 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         eng.run()
         eng.sync()
     elapsed_sync = time.perf_counter() - t0
+    # the same K steps replayed from ONE captured hipGraph (hs_run_batch, batch_graph = 1): the step with the host's enqueue rate out of
+    # the picture -- reported beside the plain loop, never `value`
+    ms_graph = None
+    try:
+        eng.set_option("batch_graph", "1")
+        eng.run_batch(steps)
+        eng.sync()
+        t0 = time.perf_counter()
+        eng.run_batch(steps)
+        eng.sync()
+        ms_graph = (time.perf_counter() - t0) / steps * 1e3
+        eng.set_option("batch_graph", None)
+    except Exception as e:      # noqa: BLE001
+        log(rank, f"{name}: graph replay skipped: {e}")
     # HIP events, on the stream the kernels are launched on.  kernel_ms (prices roofline.frac): hs_time_kernel -- ONE event pair around
     # K back-to-back launches of the SpMV kernel alone, / K = the average launch duration rocprofv3 --stats reports for it (plus the
     # sub-microsecond dispatch gap).  Beside it: the kernel inside whole steps with an event pair around every launch (each pair adds
@@ -253,6 +267,7 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         "stream_format": fmt, "col_slices": stats["col_slices"],
         "ms_per_step": round(ms, 5), "value": round(value, 2), "unit": "GB/s", "gops": round(2.0 * nnz / (elapsed / steps) / 1e9, 2),
         "ms_per_step_synchronous": round(elapsed_sync / steps * 1e3, 5),
+        "ms_per_step_graph_replay": round(ms_graph, 5) if ms_graph else None,
         "spin_up_steps": spun,
         "gibps_reference_formula": round(8.0 * nnz / 2 ** 30 / (elapsed / steps), 2),
         "frac_whole_step": round(value / HBM_PEAK_GBS, 4),
@@ -274,7 +289,7 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
     if spmm:
         res["spmm_extension"] = spmm
     log(rank, f"{name}/{IMPL_NAMES[impl]}: step {ms*1e3:.1f} us = {value:.0f} GB/s = {value/HBM_PEAK_GBS*100:.1f} % whole step; kernel {kernel_ms*1e3:.1f} us = "
-              f"{achieved/HBM_PEAK_GBS*100:.1f} %; event pairs {kernel_ms_pairs*1e3:.1f} us")
+              f"{achieved/HBM_PEAK_GBS*100:.1f} %; event pairs {kernel_ms_pairs*1e3:.1f} us" + (f"; graph replay {ms_graph*1e3:.1f} us per step" if ms_graph else ""))
     return res, dict(eng=eng, packets=packets, csr=csr, x=x, xw=xw, impl=impl, nnz=nnz, y_cpu=y_cpu, t_cpu=t_cpu, reps=reps, cfg=cfg)
 
 
@@ -518,6 +533,7 @@ def main():
         "config": {"workload": res["workload"], "rows": res["rows"], "cols": res["cols"], "nnz": res["nnz"],
                    "partitions": res["partitions"], "stream_format": res["stream_format"], "col_slices": res["col_slices"], "parallelism": "row-slab x1"},
         "gops": res["gops"], "gibps_reference_formula": res["gibps_reference_formula"], "ms_per_step_synchronous": res["ms_per_step_synchronous"],
+        "ms_per_step_graph_replay": res["ms_per_step_graph_replay"],
         "roofline": roofline, "cpu_baseline": cpu_line, "parity_vs_oracle": res["parity_vs_oracle"],
     }
     if "float_error" in res:

@@ -129,6 +129,8 @@ def predict_scaling(np, datasets, device, host, sharding, name, steps, rank, way
     xw = host.pack_vector(impl, x)
 
     def step_us(csr):
+        """(plain: K back-to-back steps enqueued from the library's C loop between two HIP events, best of 3; graph: the same K steps
+        replayed from ONE captured hipGraph -- hs_run_batch with batch_graph = 1 -- between two host synchronisations, best of 3)"""
         with device.SpmvEngine(impl) as eng:
             eng.load_matrix_csr(csr)
             eng.load_vector(xw)
@@ -140,10 +142,24 @@ def predict_scaling(np, datasets, device, host, sharding, name, steps, rank, way
             for _ in range(3):
                 region_ms, _ = eng.time_runs(5, steps, kernel=False)
                 best = min(best, region_ms / steps)
-            return best * 1e3, st
+            graph = None
+            try:
+                eng.set_option("batch_graph", "1")
+                eng.run_batch(steps)                 # capture + instantiate, untimed
+                eng.sync()
+                graph = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    eng.run_batch(steps)
+                    eng.sync()
+                    graph = min(graph, (time.perf_counter() - t0) / steps * 1e3)
+            except Exception as e:      # noqa: BLE001 -- the graph leg is an extra measurement
+                B.log(rank, f"graph replay skipped: {e}")
+            return best * 1e3, (graph * 1e3 if graph is not None else None), st
 
-    t_whole, st_whole = step_us(full)
+    t_whole, t_whole_graph, st_whole = step_us(full)
     out = {"workload": f"{name}, {B.IMPL_NAMES[impl]} IMPL", "nnz": int(full.nnz), "unsplit_us": round(t_whole, 2),
+           "unsplit_us_graph": round(t_whole_graph, 2) if t_whole_graph else None,
            "unsplit_plan": f"{device.STREAM_FORMATS[st_whole['stream_format']]}, {st_whole['col_slices']} slices, {st_whole['num_blocks']} blocks", "splits": []}
     for n in ways:
         bounds = sharding.split_rows_by_nnz(indptr, n, granule)
@@ -153,12 +169,16 @@ def predict_scaling(np, datasets, device, host, sharding, name, steps, rank, way
             if hi == lo:
                 continue
             ip, ix, dv = sharding.slab_arrays(indptr, indices, data, lo, hi)
-            t, st = step_us(host.CSRMatrix.from_arrays(hi - lo, full.num_cols, ip, ix, dv))
-            slabs.append({"rank": r, "rows": int(hi - lo), "nnz": int(ip[-1]), "us": round(t, 2),
+            t, tg, st = step_us(host.CSRMatrix.from_arrays(hi - lo, full.num_cols, ip, ix, dv))
+            slabs.append({"rank": r, "rows": int(hi - lo), "nnz": int(ip[-1]), "us": round(t, 2), "us_graph": round(tg, 2) if tg else None,
                           "plan": f"{device.STREAM_FORMATS[st['stream_format']]}, {st['col_slices']} slices, {st['num_blocks']} blocks"})
         worst = max(s["us"] for s in slabs)
+        split = {}
+        if t_whole_graph and all(s["us_graph"] for s in slabs):      # every step replayed from a captured hipGraph: the host's enqueue rate is out of the picture
+            worst_graph = max(s["us_graph"] for s in slabs)
+            split = {"max_slab_us_graph": worst_graph, "predicted_compute_only_efficiency_graph": round(min(t_whole, t_whole_graph) / (n * worst_graph), 4)}
         out["splits"].append({"n_gpus": n, "max_slab_us": worst, "mean_slab_us": round(sum(s["us"] for s in slabs) / len(slabs), 2),
-                              "predicted_compute_only_efficiency": round(t_whole / (n * worst), 4),
+                              "predicted_compute_only_efficiency": round(t_whole / (n * worst), 4), **split,
                               "roofline_us_per_slab": round(8.0 * full.nnz / n / (B.HBM_PEAK_GBS * 1e9) * 1e6, 2), "slabs": slabs})
         B.log(rank, f"{name} split {n} ways: slowest slab {worst:.1f} us against {t_whole:.1f} us unsplit -> predicted compute-only efficiency {t_whole / (n * worst) * 100:.0f} %")
     return out

@@ -264,6 +264,20 @@ benchmark_result spmv_benchmark(const Options& o, spmv::io::CSRMatrix<float>& ex
     std::cout << "  device-side: " << ev_ms / o.runs << " ms per SpMV back-to-back, kernel alone " << k_ms / o.runs << " ms = "
               << nnz * 8.0 / (k_ms / o.runs * 1e-3) / 1e9 << " GB/s = " << nnz * 8.0 / (k_ms / o.runs * 1e-3) / 8e12 * 100
               << " % of the 8 TB/s HBM roofline" << std::endl;
+    if (!o.partition_loop) {      // the NUM_RUNS loop as ONE call (hs_run_batch): enqueued from the library's C loop, and replayed from a captured hipGraph
+        double batch_ms[2] = {0, 0};
+        for (int graph = 0; graph < 2; ++graph) {
+            check(hs_set_option(ctx, "batch_graph", graph ? "1" : "0"), ctx, "hs_set_option");
+            check(hs_run_batch(ctx, o.runs), ctx, "hs_run_batch");      // untimed: warm-up / capture + instantiate
+            check(hs_sync(ctx), ctx, "hs_sync");
+            const auto a = clock::now();
+            check(hs_run_batch(ctx, o.runs), ctx, "hs_run_batch");
+            check(hs_sync(ctx), ctx, "hs_sync");
+            batch_ms[graph] = std::chrono::duration<double, std::milli>(clock::now() - a).count() / o.runs;
+        }
+        std::cout << "  hs_run_batch(" << o.runs << "), one sync at the end: " << batch_ms[0] << " ms per SpMV enqueued from a C loop, " << batch_ms[1]
+                  << " ms per SpMV replayed from one hipGraph" << std::endl;
+    }
     check(hs_read_result(ctx, result.data(), packets.num_rows), ctx, "hs_read_result");
     dump_words(o.dump_x, vector);
     dump_words(o.dump_y, result);

@@ -283,6 +283,11 @@ int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* 
     return HS_OK;
 }
 
+int hs_run_batch(hs_context* ctx, uint32_t steps) {
+    for (uint32_t i = 0; i < steps; ++i)
+        if (int rc = hs_run(ctx)) return rc;
+    return HS_OK;
+}
 int hs_time_kernel(hs_context* ctx, int warmup, int runs, float* kernel_ms) { return hs_time_runs(ctx, warmup, runs, nullptr, kernel_ms); }
 
 // ---- not part of this backend: device-memory hooks and the extensions ---------------------------------------------------------

@@ -54,6 +54,13 @@ struct hs_context {
     uint32_t format = 0;           // StreamFormat of d_image
     bool light = false;            // the LIGHT plan: d_image is a PAIRS image run by spmv_light_kernel (stream_tiles.h)
     uint32_t* d_partial = nullptr;  // col_slices > 1: per-slice partial results, col_slices x num_rows words
+    // hs_run_batch with `batch_graph`: the captured step sequence, kept while nothing it bakes in changes
+    hipGraph_t batch_graph = nullptr;
+    hipGraphExec_t batch_exec = nullptr;
+    uint32_t batch_steps = 0;
+    const void* batch_x = nullptr;
+    void* batch_y = nullptr;
+    hipStream_t batch_stream = nullptr;
     bool crossing_blocks = false;   // some row block reaches over a row-partition border (tiles_common.h: Layout::cross_parts)
     uint32_t* d_partition_y = nullptr;   // hs_run_partition on a one-slice plan with such blocks: the kernel writes here (num_rows words,
                                          // allocated on first use), the partition's own rows are then copied into y
@@ -125,10 +132,19 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 const char* const kOptionKeys[] = {
     "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
     "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS", "SWEEP",
-    "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH",
+    "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "BATCH_GRAPH",
 };
 
+void drop_batch_graph(hs_context* c) {
+    if (c->batch_exec) (void)hipGraphExecDestroy(c->batch_exec);
+    if (c->batch_graph) (void)hipGraphDestroy(c->batch_graph);
+    c->batch_exec = nullptr;
+    c->batch_graph = nullptr;
+    c->batch_steps = 0;
+}
+
 void free_matrix(hs_context* c) {
+    drop_batch_graph(c);
     if (c->d_image) (void)hipFree(c->d_image);
     if (c->d_blocks) (void)hipFree(c->d_blocks);
     if (c->d_units) (void)hipFree(c->d_units);
@@ -335,6 +351,7 @@ int hs_destroy(hs_context* ctx) {
     free_matrix(ctx);
     free_csc(ctx);
     if (ctx->d_x) (void)hipFree(ctx->d_x);
+    drop_batch_graph(ctx);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return HS_OK;
@@ -587,6 +604,39 @@ int hs_run(hs_context* ctx) {
     if (rc != HS_OK) return rc;
     HS_HIP(ctx, hipSetDevice(ctx->device));
     return enqueue(ctx, -1, nullptr, nullptr);
+}
+
+int hs_run_batch(hs_context* ctx, uint32_t steps) {
+    int rc = check_ready(ctx);
+    if (rc != HS_OK) return rc;
+    if (steps == 0) return HS_OK;
+    HS_HIP(ctx, hipSetDevice(ctx->device));
+    const char* opt = ctx_option(ctx, "HISPARSE_BATCH_GRAPH");
+    if (!(opt && std::atoi(opt) != 0)) {      // plain: the launches of `steps` SpMVs enqueued from this C loop
+        for (uint32_t i = 0; i < steps; ++i)
+            if ((rc = enqueue(ctx, -1, nullptr, nullptr)) != HS_OK) return rc;
+        return HS_OK;
+    }
+    // graph replay: the same launches captured once into a hipGraph (per step count, vector, result target and stream) and replayed
+    // with ONE runtime call -- what the step costs when the host's enqueue rate is out of the picture
+    if (const char* why = hisparse::dev::profiling_switch_error()) return fail(ctx, HS_ERR_BAD_ARG, why);
+    if (!ctx->batch_exec || ctx->batch_steps != steps || ctx->batch_x != x_source(ctx) || ctx->batch_y != y_target(ctx) || ctx->batch_stream != ctx->stream) {
+        drop_batch_graph(ctx);
+        hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamBeginCapture (the legacy default stream cannot be captured)");
+        for (uint32_t i = 0; i < steps && rc == HS_OK; ++i) rc = enqueue(ctx, -1, nullptr, nullptr);
+        e = hipStreamEndCapture(ctx->stream, &ctx->batch_graph);
+        if (rc != HS_OK) { drop_batch_graph(ctx); return rc; }
+        if (e != hipSuccess || !ctx->batch_graph) { drop_batch_graph(ctx); return hip_fail(ctx, e, "hipStreamEndCapture"); }
+        e = hipGraphInstantiate(&ctx->batch_exec, ctx->batch_graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { drop_batch_graph(ctx); return hip_fail(ctx, e, "hipGraphInstantiate"); }
+        ctx->batch_steps = steps;
+        ctx->batch_x = x_source(ctx);
+        ctx->batch_y = y_target(ctx);
+        ctx->batch_stream = ctx->stream;
+    }
+    HS_HIP(ctx, hipGraphLaunch(ctx->batch_exec, ctx->stream));
+    return HS_OK;
 }
 
 int hs_run_partition(hs_context* ctx, uint32_t row_part_id, uint32_t part_len) {

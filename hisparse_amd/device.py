@@ -17,7 +17,7 @@ _lib = None
 
 EXPORTS = [
     "hs_strerror", "hs_last_error", "hs_create", "hs_destroy", "hs_load_matrix", "hs_load_vector", "hs_run",
-    "hs_load_matrix_csr", "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
+    "hs_load_matrix_csr", "hs_run_batch", "hs_run_partition", "hs_sync", "hs_read_result", "hs_set_stream", "hs_get_stream", "hs_device_vector", "hs_device_result",
     "hs_bind_device_vector", "hs_bind_device_result", "hs_push_result", "hs_set_option", "hs_feedback", "hs_iterate", "hs_load_matrix_csc", "hs_spmspv", "hs_spmspv_device", "hs_read_spmspv_result", "hs_spmspv_status", "hs_spmm", "hs_spmm_device", "hs_get_stats", "hs_time_runs", "hs_time_kernel", "hs_debug_read_tiles", "hs_debug_read_mfma_image", "hs_tiles_build", "hs_tiles_info",
     "hs_tiles_copy", "hs_tiles_free", "hs_tiles_last_error",
 ]
@@ -86,6 +86,7 @@ def lib():
         l.hs_spmspv_status.argtypes = [vp, C.POINTER(u32), C.POINTER(vp)]
         l.hs_get_stats.argtypes = [vp, C.POINTER(Stats)]
         l.hs_time_runs.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.hs_run_batch.argtypes = [vp, u32]
         l.hs_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
         l.hs_debug_read_tiles.argtypes = [vp, vp, u64, vp, vp]
         l.hs_debug_read_mfma_image.argtypes = [vp, vp, u64, C.POINTER(u64)]
@@ -191,6 +192,10 @@ class SpmvEngine:
 
     def run(self):
         self._check(lib().hs_run(self._h))
+
+    def run_batch(self, steps):
+        """hs_run_batch: `steps` SpMVs from one call (option batch_graph = 1: replayed from a captured hipGraph)."""
+        self._check(lib().hs_run_batch(self._h, int(steps)))
 
     def run_partition(self, row_part_id, part_len):
         self._check(lib().hs_run_partition(self._h, row_part_id, part_len))

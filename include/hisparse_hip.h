@@ -103,6 +103,12 @@ int hs_load_vector(hs_context* ctx, const void* packed_x, uint32_t num_cols);
 
 /* One full SpMV (every row partition) in one launch sequence; asynchronous. */
 int hs_run(hs_context* ctx);
+/* EXTENSION: `steps` x hs_run from ONE call -- the reference's NUM_RUNS loop (sw/benchmark.cpp:315-343) as a unit.  A step of a small
+ * matrix is two launches of a few microseconds each, and how fast the HOST enqueues them then decides the step time (a Python loop over
+ * hs_run: one ctypes call + two launches per step).  Default: the launches are enqueued from a C loop.  hs_set_option "batch_graph" = 1:
+ * the step sequence is captured once into a hipGraph (per step count, vector, result target and stream; re-captured when one of them
+ * changes, dropped by hs_load_matrix) and replayed with one hipGraphLaunch.  Same kernels, same results; asynchronous like hs_run. */
+int hs_run_batch(hs_context* ctx, uint32_t steps);
 /* One row partition, with the reference's scalar arguments; part_len = rows per cluster
  * (checked against the geometry).  Rows of other partitions keep their previous contents. */
 int hs_run_partition(hs_context* ctx, uint32_t row_part_id, uint32_t part_len);
@@ -134,7 +140,7 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
  * (pairs|delta|owner|owner24|sweep|bitmap), col_slices, max_rows, cross_partitions (0: row blocks end at the reference's row-partition borders), row_runs, aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
  * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), sweep (0|1: the
  * column-ordered format of very sparse matrices), plan_debug; call-time keys: spmm_fused, spmm_mfma,
- * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph.  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
+ * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph, batch_graph (hs_run_batch).  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
  * Options set here win over the environment variable of the same name, which stays as the fallback for tools and tests.  None of them
  * changes WHAT is computed.  The switches that do (HISPARSE_ABLATE, HISPARSE_DEPTH: profiling builds with parts of the work removed) are
  * not options: they exist only in libhisparse_hip_prof.so, and this library refuses to run (HS_ERR_BAD_ARG from hs_run, hs_run_partition,

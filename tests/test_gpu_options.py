@@ -66,3 +66,50 @@ def test_product_library_does_not_run_with_a_profiling_switch_in_the_environment
         monkeypatch.delenv("HISPARSE_ABLATE")
         eng.run()
         assert np.array_equal(eng.read_result(), want)
+
+
+def test_run_batch_plain_and_graph_replay_give_the_same_words():
+    """hs_run_batch (round 5): K steps from one call -- enqueued from the library's C loop, or (batch_graph = 1) replayed from a captured
+    hipGraph that is re-captured when the vector / result target changes and dropped by the next load."""
+    import ctypes as C
+    for impl in (0, 1):
+        cp, xw = _case(impl)
+        with device.SpmvEngine(impl) as eng:
+            eng.set_option("col_slices", "3")                    # a step of two launches
+            eng.load_matrix(cp)
+            eng.load_vector(xw)
+            eng.run()
+            want = eng.read_result()
+            for graph in ("0", "1"):
+                eng.set_option("batch_graph", graph)
+                for k in (1, 7, 7, 20):
+                    eng.run_batch(k)
+                    assert np.array_equal(eng.read_result(), want)
+            # another vector: the captured graph baked the old one in only through the context's own buffer, which is overwritten in place
+            x2 = host.pack_vector(impl, cases.random_x(cp.num_cols, 6, impl))
+            eng.load_vector(x2)
+            eng.run()
+            want2 = eng.read_result()
+            eng.run_batch(7)
+            assert np.array_equal(eng.read_result(), want2) and not np.array_equal(want2, want)
+            # a bound result buffer: re-capture with the new target
+            rt = C.CDLL("libamdhip64.so")
+            rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            rt.hipFree.argtypes = [C.c_void_p]
+            buf = C.c_void_p()
+            assert rt.hipMalloc(C.byref(buf), cp.num_rows * 4) == 0
+            try:
+                eng.bind_device_result(buf.value)
+                eng.run_batch(7)
+                eng.sync()
+                y = np.empty(cp.num_rows, dtype=np.uint32)
+                assert rt.hipMemcpy(y.ctypes.data, buf, y.nbytes, 2) == 0
+                assert np.array_equal(y, want2)
+                eng.bind_device_result(None)
+            finally:
+                rt.hipFree(buf)
+            eng.load_matrix(cp)                                  # drops the graph
+            eng.load_vector(xw)
+            eng.run_batch(3)
+            assert np.array_equal(eng.read_result(), want)
