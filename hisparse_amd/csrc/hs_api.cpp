@@ -61,6 +61,15 @@ struct hs_context {
     const void* batch_x = nullptr;
     void* batch_y = nullptr;
     hipStream_t batch_stream = nullptr;
+    // Column-sliced plans, hs_run after hs_run on the library's own stream: the combine pass of a step is CARRIED into the SpMV kernel of the
+    // next one (spmv_device.h: CarriedCombine) -- enqueue() below.  `pending`: the set of partial vectors whose sum has not been written to
+    // its y yet; flush_combine() launches the stand-alone combine for it, and every entry point that could observe y, its target or the
+    // stream does that first, so the stream-order contract of hisparse_hip.h holds unchanged.
+    bool carry_combine = false;     // plan-time decision (load_matrix_impl): two sets of partial vectors exist
+    bool stream_shared = false;     // hs_get_stream was called: somebody else may order work against the stream -- every step completes in itself
+    int pending = -1;
+    uint32_t* pending_y = nullptr;
+    uint32_t carry_turn = 0;
     bool crossing_blocks = false;   // some row block reaches over a row-partition border (tiles_common.h: Layout::cross_parts)
     uint32_t* d_partition_y = nullptr;   // hs_run_partition on a one-slice plan with such blocks: the kernel writes here (num_rows words,
                                          // allocated on first use), the partition's own rows are then copied into y
@@ -132,7 +141,7 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 const char* const kOptionKeys[] = {
     "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
     "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS", "SWEEP",
-    "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "BATCH_GRAPH",
+    "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "BATCH_GRAPH", "CARRY_COMBINE",
 };
 
 void drop_batch_graph(hs_context* c) {
@@ -153,6 +162,8 @@ void free_matrix(hs_context* c) {
     if (c->d_y) (void)hipFree(c->d_y);
     if (c->d_partial) (void)hipFree(c->d_partial);
     c->d_partial = nullptr;
+    c->carry_combine = false;
+    c->pending = -1;
     if (c->d_partition_y) (void)hipFree(c->d_partition_y);
     c->d_partition_y = nullptr;
     c->crossing_blocks = false;
@@ -192,6 +203,25 @@ void free_csc(hs_context* c) {
     c->csc_rows = c->csc_cols = 0;
     c->csc_nnz = 0;
 }
+
+// The result of the last carried step, if any, goes to its y now (one combine_slices_kernel launch on the context's stream).
+int flush_combine(hs_context* c) {
+    if (c && c->pending >= 0) {
+        const uint32_t* partial = c->d_partial + size_t(c->pending) * c->col_slices * c->num_rows;
+        const hipError_t e = hisparse::dev::launch_combine_slices(c->impl != HS_IMPL_FIXED, partial, c->pending_y, c->num_rows, c->col_slices, 0, c->num_rows, c->stream);
+        c->pending = -1;
+        if (e != hipSuccess) return hip_fail(c, e, "combine_slices_kernel");
+    }
+    return HS_OK;
+}
+#define HS_FLUSH(ctx)                                  \
+    do {                                               \
+        if ((ctx) && (ctx)->pending >= 0) {            \
+            (void)hipSetDevice((ctx)->device);         \
+            const int rc_flush_ = flush_combine(ctx);  \
+            if (rc_flush_ != HS_OK) return rc_flush_;  \
+        }                                              \
+    } while (0)
 
 uint32_t* y_target(hs_context* c) { return c->y_bound ? c->y_bound : c->d_y; }
 const uint32_t* x_source(hs_context* c) { return c->x_bound ? c->x_bound : c->d_x; }
@@ -237,6 +267,25 @@ void partition_rows(const hs_context* c, uint32_t j, uint32_t& lo, uint32_t& hi)
 struct Feedback { uint32_t scale, shift; };
 int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1, const Feedback* feedback = nullptr) {
     if (const char* why = hisparse::dev::profiling_switch_error()) return fail(c, HS_ERR_BAD_ARG, why);
+    if (c->carry_combine && c->col_slices > 1 && filter < 0 && !k0 && !k1 && !feedback && c->stream == c->own_stream && !c->stream_shared) {
+        // this step's partial rows go to the set the previous step did NOT use; the previous step's are added up by this launch's
+        // workgroups before they start on their blocks; this step's own sum is owed (pending) until the next hs_run or a flush
+        hisparse::dev::SpmvLaunch a = launch_args(c, filter);
+        const uint32_t b = c->carry_turn++ & 1u;
+        const size_t set = size_t(c->col_slices) * c->num_rows;
+        a.out = c->d_partial + b * set;
+        if (c->pending >= 0) {
+            a.carry_partial = c->d_partial + size_t(c->pending) * set;
+            a.carry_y = c->pending_y;
+            a.carry_rows = c->num_rows;
+            a.carry_slices = c->col_slices;
+        }
+        HS_HIP(c, hisparse::dev::launch_spmv(c->impl != HS_IMPL_FIXED, a, c->stream));
+        c->pending = int(b);
+        c->pending_y = y_target(c);
+        return HS_OK;
+    }
+    if (int rc = flush_combine(c)) return rc;
     hisparse::dev::SpmvLaunch args = launch_args(c, filter);
     // One partition of a plan whose row blocks reach over partition borders: the blocks that intersect the partition run (Block::next_part)
     // and compute rows of its neighbours too.  "Rows of other partitions keep their previous contents" (hisparse_hip.h): a column-sliced
@@ -369,6 +418,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     if (num_row_partitions != (num_rows + g.logical_ob - 1) / g.logical_ob || num_col_partitions != (num_cols + g.logical_vb - 1) / g.logical_vb)
         return fail(ctx, HS_ERR_BAD_ARG, "partition counts do not match the dimensions and the bank sizes of this context");
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_matrix(ctx);
     const auto t0 = std::chrono::steady_clock::now();
@@ -465,7 +515,19 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_part_heads), tiles.part_heads.data(), tiles.part_heads.size() * sizeof(uint32_t), 0));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
-    if (tiles.col_slices > 1) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(tiles.col_slices) * num_rows * 4));
+    if (tiles.col_slices > 1) {
+        // the combine pass carried into the next step's kernel (hs_context::carry_combine); `carry_combine` = 0 | 1 decides otherwise
+        // Measured (profiles/r05_carry_combine_ab.txt, whole step): ogbl-ppa 55.4 -> 53.5 us, the R-MAT stand-in 60.0 -> 57.8, gplus 20.2 ->
+        // 19.8, hollywood 137.0 -> 135.1, ogbn-products 206 -> 204 -- the row-block kernels' workgroups ramp up over 2-4 us and the first
+        // wavefronts add the previous step's partial rows up meanwhile -- but pokec 73.5 -> 76.0: a SWEEP workgroup has no such ramp, and
+        // 33 MB of partial rows in front of every launch cost more than the 6.8 us combine launch they replace.  Hence: on by itself for
+        // the row-block and BITMAP kernels, for SWEEP only while a set of partial vectors stays below 8 MB.
+        const char* opt = ctx_option(ctx, "HISPARSE_CARRY_COMBINE");
+        const bool carry = opt ? std::atoi(opt) != 0
+                               : (tiles.format != hisparse::dev::kFormatSweep || uint64_t(tiles.col_slices) * num_rows * 4 <= (8u << 20));
+        HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(carry ? 2 : 1) * tiles.col_slices * num_rows * 4));
+        ctx->carry_combine = carry;
+    }
     if (mfma_on_device || (tiles.mfma.words_bytes != 0 && !tiles.mfma.words.empty())) {      // float BITMAP matrix: the second image for the SpMM on the matrix engine + its scratch
         // OPTIONAL: SpMV works without it.  If the image or its scratch cannot be had (out of memory), the matrix loads without a second
         // image and hs_spmm takes the fused 4-column kernel instead.
@@ -622,9 +684,11 @@ int hs_run_batch(hs_context* ctx, uint32_t steps) {
     if (const char* why = hisparse::dev::profiling_switch_error()) return fail(ctx, HS_ERR_BAD_ARG, why);
     if (!ctx->batch_exec || ctx->batch_steps != steps || ctx->batch_x != x_source(ctx) || ctx->batch_y != y_target(ctx) || ctx->batch_stream != ctx->stream) {
         drop_batch_graph(ctx);
+        HS_FLUSH(ctx);                                       // the graph owes nothing when it begins ...
         hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamBeginCapture (the legacy default stream cannot be captured)");
         for (uint32_t i = 0; i < steps && rc == HS_OK; ++i) rc = enqueue(ctx, -1, nullptr, nullptr);
+        if (rc == HS_OK) rc = flush_combine(ctx);            // ... and nothing when it ends (a carried plan: K kernels + one combine)
         e = hipStreamEndCapture(ctx->stream, &ctx->batch_graph);
         if (rc != HS_OK) { drop_batch_graph(ctx); return rc; }
         if (e != hipSuccess || !ctx->batch_graph) { drop_batch_graph(ctx); return hip_fail(ctx, e, "hipStreamEndCapture"); }
@@ -635,6 +699,7 @@ int hs_run_batch(hs_context* ctx, uint32_t steps) {
         ctx->batch_y = y_target(ctx);
         ctx->batch_stream = ctx->stream;
     }
+    HS_FLUSH(ctx);
     HS_HIP(ctx, hipGraphLaunch(ctx->batch_exec, ctx->stream));
     return HS_OK;
 }
@@ -656,6 +721,7 @@ int hs_feedback(hs_context* ctx, uint32_t scale_word, uint32_t shift_word) {
     int rc = check_ready(ctx);
     if (rc != HS_OK) return rc;
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     HS_HIP(ctx, hisparse::dev::launch_feedback(ctx->impl != HS_IMPL_FIXED, y_target(ctx), const_cast<uint32_t*>(x_source(ctx)),
                                                std::min(ctx->num_rows, ctx->num_cols), scale_word, shift_word, ctx->stream));
     return HS_OK;
@@ -666,6 +732,7 @@ int hs_iterate(hs_context* ctx, uint32_t iterations, uint32_t scale_word, uint32
     if (rc != HS_OK) return rc;
     if (iterations == 0) return HS_OK;
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     const Feedback feedback{scale_word, shift_word};
     auto one_iteration = [&]() -> int { return enqueue(ctx, -1, nullptr, nullptr, &feedback); };
     // One iteration = 2-3 small launches, enqueued from this C loop far faster than the GPU retires them, so plain
@@ -718,6 +785,7 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* 
     for (uint64_t e = 0; e < nnz; ++e) bin_base[(row_indices[e] >> block_bits) + 1]++;
     for (uint32_t b = 0; b < bins; ++b) bin_base[b + 1] += bin_base[b];
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_csc(ctx);
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_csc_indptr), (size_t(num_cols) + 1) * 4));
@@ -791,6 +859,7 @@ int hs_spmspv_device(hs_context* ctx, const hs_idx_val* x_entries_dev, uint32_t 
     if (!ctx->d_csc_indptr) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix_csc has not been called");
     if (reinterpret_cast<uintptr_t>(x_entries_dev) & 7u) return fail(ctx, HS_ERR_BAD_ARG, "device entries must be 8-byte aligned");
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     return spmspv_pass(ctx, reinterpret_cast<const hisparse::dev::hs_idx_val_dev*>(x_entries_dev), count, false);
 }
 
@@ -798,6 +867,7 @@ int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
     if (!ctx || (count && !x_entries)) return fail(ctx, HS_ERR_BAD_ARG, "null argument");
     if (!ctx->d_csc_indptr) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix_csc has not been called");
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     // One pass over the entries: range check, repeat check (a bit per column, kept zero between calls) and this call's product count.
     // A bin of the product list holds as many products as the matrix has non-zeros in that row block: an x that names a column more than once
     // can ask for more.  Such a call is cut into passes of UNIQUE columns -- pass i takes the i-th occurrence of every column: each pass fits by
@@ -927,6 +997,7 @@ int hs_read_spmspv_result(hs_context* ctx, void* packed_y, uint32_t num_rows) {
     if (!ctx->d_csc_indptr) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix_csc has not been called");
     if (num_rows != ctx->csc_rows) return fail(ctx, HS_ERR_BAD_ARG, "result length must equal the CSC matrix's row count");
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     uint32_t overflow = 0;
     HS_HIP(ctx, hipMemcpyAsync(packed_y, ctx->d_csc_y, size_t(num_rows) * 4, hipMemcpyDeviceToHost, ctx->stream));
     HS_HIP(ctx, hipMemcpyAsync(&overflow, ctx->csc_scratch.overflow, sizeof(overflow), hipMemcpyDeviceToHost, ctx->stream));
@@ -946,6 +1017,7 @@ int hs_spmspv_status(hs_context* ctx, uint32_t* overflowed, void** overflow_word
     if (overflow_word_dev) *overflow_word_dev = ctx->csc_scratch.overflow;
     if (overflowed) {
         HS_HIP(ctx, hipSetDevice(ctx->device));
+        HS_FLUSH(ctx);
         HS_HIP(ctx, hipMemcpyAsync(overflowed, ctx->csc_scratch.overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -955,6 +1027,7 @@ int hs_spmspv_status(hs_context* ctx, uint32_t* overflowed, void** overflow_word
 int hs_sync(hs_context* ctx) {
     if (!ctx) return HS_ERR_BAD_ARG;
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HS_OK;
 }
@@ -964,6 +1037,7 @@ int hs_read_result(hs_context* ctx, void* packed_y, uint32_t num_rows) {
     if (!ctx->matrix_loaded) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix has not been called");
     if (num_rows != ctx->num_rows) return fail(ctx, HS_ERR_BAD_ARG, "result length must equal the padded row count");
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     HS_HIP(ctx, hipMemcpyAsync(packed_y, y_target(ctx), size_t(num_rows) * 4, hipMemcpyDeviceToHost, ctx->stream));
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HS_OK;
@@ -987,6 +1061,7 @@ int hs_set_option(hs_context* ctx, const char* key, const char* value) {
 int hs_set_stream(hs_context* ctx, void* hip_stream) {
     if (!ctx) return HS_ERR_BAD_ARG;
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     // work already enqueued must not be overtaken by work on the new stream; a caller-owned stream may be gone by now,
     // so only the library's own stream is synchronised by handle
     if (ctx->stream == ctx->own_stream) HS_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
@@ -997,6 +1072,8 @@ int hs_set_stream(hs_context* ctx, void* hip_stream) {
 
 int hs_get_stream(hs_context* ctx, void** hip_stream) {
     if (!ctx || !hip_stream) return HS_ERR_BAD_ARG;
+    HS_FLUSH(ctx);
+    ctx->stream_shared = true;      // whoever holds the handle may order work against it: from now on every step completes in itself
     *hip_stream = ctx->stream;
     return HS_OK;
 }
@@ -1011,6 +1088,7 @@ int hs_device_vector(hs_context* ctx, void** x_dev) {
 int hs_device_result(hs_context* ctx, void** y_dev) {
     if (!ctx || !y_dev) return HS_ERR_BAD_ARG;
     if (!ctx->matrix_loaded) return fail(ctx, HS_ERR_NOT_LOADED, "hs_load_matrix has not been called");
+    HS_FLUSH(ctx);
     *y_dev = ctx->d_y;
     return HS_OK;
 }
@@ -1025,6 +1103,7 @@ int hs_bind_device_vector(hs_context* ctx, const void* x_dev) {
 int hs_bind_device_result(hs_context* ctx, void* y_dev) {
     if (!ctx) return HS_ERR_BAD_ARG;
     if (y_dev && (reinterpret_cast<uintptr_t>(y_dev) & 15u)) return fail(ctx, HS_ERR_BAD_ARG, "device result must be 16-byte aligned");
+    if (static_cast<uint32_t*>(y_dev) != ctx->y_bound) HS_FLUSH(ctx);      // (an owed sum belongs to the old target)
     ctx->y_bound = static_cast<uint32_t*>(y_dev);
     return HS_OK;
 }
@@ -1038,6 +1117,7 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
     for (uint32_t k = 0; k < n_dst; ++k)
         if (!dst[k] || (reinterpret_cast<uintptr_t>(dst[k]) & 15u)) return fail(ctx, HS_ERR_BAD_ARG, "destinations must be 16-byte aligned device pointers");
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     HS_HIP(ctx, hisparse::dev::launch_push_result(y_target(ctx), dst, n_dst, num_words, ctx->stream));
     return HS_OK;
 }
@@ -1139,6 +1219,7 @@ int hs_spmm(hs_context* ctx, const void* packed_x, uint32_t num_cols, uint32_t k
     HS_HIP(ctx, hipMemcpy2DAsync(b.x, size_t(ldx) * 4, packed_x, size_t(num_cols) * 4, size_t(num_cols) * 4, k, hipMemcpyHostToDevice, ctx->stream));
     int rc = hs_spmm_device(ctx, b.x, ldx, b.y, ldy, k);
     if (rc != HS_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    HS_FLUSH(ctx);
     HS_HIP(ctx, hipMemcpy2DAsync(packed_y, size_t(num_rows) * 4, b.y, size_t(ldy) * 4, size_t(num_rows) * 4, k, hipMemcpyDeviceToHost, ctx->stream));
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HS_OK;
@@ -1157,6 +1238,7 @@ int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* 
     HS_HIP(ctx, hipSetDevice(ctx->device));
     for (int i = 0; i < warmup; ++i)
         if ((rc = enqueue(ctx, -1, nullptr, nullptr)) != HS_OK) return rc;
+    HS_FLUSH(ctx);
     HS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     struct Events {   // destroyed on every return path
         std::vector<hipEvent_t> ev;
@@ -1169,6 +1251,7 @@ int hs_time_runs(hs_context* ctx, int warmup, int runs, float* total_ms, float* 
     HS_HIP(ctx, hipEventRecord(begin, ctx->stream));
     for (int i = 0; i < runs; ++i)
         if ((rc = enqueue(ctx, -1, kernel_ms ? k[size_t(i) * 2] : nullptr, kernel_ms ? k[size_t(i) * 2 + 1] : nullptr)) != HS_OK) return rc;
+    HS_FLUSH(ctx);                                     // (the last step's sum may still be owed)
     HS_HIP(ctx, hipEventRecord(end, ctx->stream));
     HS_HIP(ctx, hipEventSynchronize(end));
     float ms = 0.0f;
@@ -1192,19 +1275,30 @@ int hs_time_kernel(hs_context* ctx, int warmup, int runs, float* kernel_ms) {
     if (warmup < 0 || runs <= 0 || !kernel_ms) return fail(ctx, HS_ERR_BAD_ARG, "need warmup >= 0, runs > 0 and an output pointer");
     if (const char* why = hisparse::dev::profiling_switch_error()) return fail(ctx, HS_ERR_BAD_ARG, why);
     HS_HIP(ctx, hipSetDevice(ctx->device));
+    HS_FLUSH(ctx);
     const bool is_float = ctx->impl != HS_IMPL_FIXED;
     const hisparse::dev::SpmvLaunch args = launch_args(ctx, -1);
-    for (int i = 0; i < warmup; ++i) HS_HIP(ctx, hisparse::dev::launch_spmv(is_float, args, ctx->stream));
+    // a plan whose combine pass is carried into the next step's kernel: the kernel as it runs in consecutive steps, i.e. with that work in it
+    const bool carried = ctx->carry_combine && ctx->col_slices > 1 && ctx->stream == ctx->own_stream && !ctx->stream_shared;
+    auto launch = [&]() -> int {
+        if (carried) return enqueue(ctx, -1, nullptr, nullptr);
+        HS_HIP(ctx, hisparse::dev::launch_spmv(is_float, args, ctx->stream));
+        return HS_OK;
+    };
+    for (int i = 0; i < warmup; ++i)
+        if ((rc = launch()) != HS_OK) return rc;
     hipEvent_t ev[2] = {nullptr, nullptr};
     struct Guard { hipEvent_t* e; ~Guard() { for (int i = 0; i < 2; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } guard{ev};
     HS_HIP(ctx, hipEventCreate(&ev[0]));
     HS_HIP(ctx, hipEventCreate(&ev[1]));
     HS_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
-    for (int i = 0; i < runs; ++i) HS_HIP(ctx, hisparse::dev::launch_spmv(is_float, args, ctx->stream));
+    for (int i = 0; i < runs; ++i)
+        if ((rc = launch()) != HS_OK) return rc;
     HS_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
     HS_HIP(ctx, hipEventSynchronize(ev[1]));
     HS_HIP(ctx, hipEventElapsedTime(kernel_ms, ev[0], ev[1]));
-    // column-sliced plans: the launches above left partial sums only; one whole step puts y back in order
+    // column-sliced plans: the launches above left partial sums only; one whole step (or the owed combine) puts y back in order
+    if (carried) return flush_combine(ctx);
     return enqueue(ctx, -1, nullptr, nullptr);
 }
 

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
                                                                 const Unit* __restrict__ units, const uint32_t* __restrict__ x, uint32_t num_cols,
                                                                 uint32_t* __restrict__ out, int32_t row_part_filter,
                                                                 const uint32_t* __restrict__ part_heads, uint64_t* __restrict__ timeline,
-                                                                uint32_t x_lds_offset) {
+                                                                uint32_t x_lds_offset, CarriedCombine carry) {
     using R = Rows<kFloat>;
     using acc_t = typename R::acc_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(kBmThreads) void spmv_bitmap_kernel(const uint8_t* 
     stamp(0, wave);
     uint32_t wg = blockIdx.x;                                     // same XCD-aware remap as spmv_rowblock_kernel
     if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (carry.partial) carried_combine<kFloat, kBmThreads>(carry, blockIdx.x, gridDim.x, tid);      // y of the PREVIOUS step (spmv_device.h)
     uint32_t bi = wg;
     if (row_part_filter >= 0) {
         bi = ((const __attribute__((address_space(4))) uint32_t*)part_heads)[static_cast<uint32_t>(row_part_filter) * gridDim.x + wg];
@@ -335,6 +336,7 @@ hipError_t configure_bitmap_kernels(uint32_t lds_bytes) {
 hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     if (a.num_workgroups == 0) return hipSuccess;
     const dim3 grid(a.num_workgroups), block(kBmThreads);
+    const CarriedCombine carry = carried(a);
     int ablate = 0, depth_unused = 8;       // read per launch (profiling library only): a process may switch profiling builds between runs
     if (!profiling_switches(ablate, depth_unused)) return hipErrorInvalidValue;
     // timeline build: HISPARSE_ABLATE=64 HISPARSE_TIMELINE_OUT=file -> every launch is synchronised and its per-wavefront
@@ -354,7 +356,7 @@ hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t st
 #define X(F, A)                                                                                                                                  \
     if (!launched && a.bitmap_x_groups && is_float == F && ablate == A) {                                                                        \
         hipLaunchKernelGGL((spmv_bitmap_kernel<F, A, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.num_cols, a.out, \
-                           a.row_part_filter, a.part_heads, timeline, x_lds_offset);                                                             \
+                           a.row_part_filter, a.part_heads, timeline, x_lds_offset, carry);                                                             \
         launched = true;                                                                                                                         \
     }
     HS_FOR_EACH_BITMAP_XLDS_VARIANT(X)
@@ -362,7 +364,7 @@ hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t st
 #define X(F, A)                                                                                                                                  \
     if (!launched && is_float == F && ablate == A) {                                                                                             \
         hipLaunchKernelGGL((spmv_bitmap_kernel<F, A>), grid, block, a.bitmap_x_groups ? x_lds_offset : a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.num_cols, a.out, \
-                           a.row_part_filter, a.part_heads, timeline, 0u);                                                                       \
+                           a.row_part_filter, a.part_heads, timeline, 0u, carry);                                                                       \
         launched = true;                                                                                                                         \
     }
     HS_FOR_EACH_BITMAP_VARIANT(X)

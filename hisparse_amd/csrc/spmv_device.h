@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "stream_tiles.h"
 
 namespace hisparse {
@@ -119,6 +121,64 @@ __device__ __forceinline__ T segmented_run_sums(T v, uint32_t row, bool& is_last
     const uint32_t next_row = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(row), 0x130, 0xf, 0xf, false));   // wave_shl:1 (lane 63: none)
     is_last = next_row != row;
     return v;
+}
+
+
+// ---- column-sliced plans: the combine pass of step k carried into the SpMV kernel of step k + 1 (round 5) ---------------------------
+// A column-sliced step is SpMV kernel (per-slice partial rows) + combine_slices_kernel (y = their sum): a second launch of 2.5-5 us for
+// 2-10 MB of traffic.  Four attempts to fold it into the SAME kernel lost to the cross-workgroup hand-over they need at the kernel's tail
+// (DESIGN.md).  This one needs none: when hs_run follows hs_run, the partial rows of step k are complete and visible when the kernel of
+// step k + 1 STARTS (a kernel boundary lies between them), so that kernel's workgroups -- each a stripe of the rows, by workgroup index --
+// add them up and write y(k) first, while their own descriptor and first stream loads travel; step k + 1 writes the OTHER set of partial
+// vectors.  The host launches the stand-alone combine only for the LAST step of such a run (hs_api.cpp: flush_combine).  Sums in slice
+// order from 0.0f / saturating adds, exactly as combine_slices_kernel: the same words.
+struct CarriedCombine {
+    const uint32_t* partial = nullptr;      // the previous step's partial vectors (nullptr: nothing to carry)
+    uint32_t* y = nullptr;                  // where that step's result goes
+    uint32_t num_rows = 0;                  // stride between the partial vectors, and the rows to combine (a multiple of 128)
+    uint32_t slices = 0;
+};
+
+template <typename Launch>
+inline CarriedCombine carried(const Launch& a) {
+    CarriedCombine c;
+    if (a.carry_partial && a.carry_slices > 1 && a.row_part_filter < 0) {
+        c.partial = a.carry_partial;
+        c.y = a.carry_y;
+        c.num_rows = a.carry_rows;
+        c.slices = a.carry_slices;
+    }
+    return c;
+}
+
+template <bool kFloat, int kBlockThreads>
+__device__ __forceinline__ void carried_combine(const CarriedCombine& c, uint32_t wg, uint32_t groups, uint32_t tid) {
+    using Sum = typename std::conditional<kFloat, float, uint32_t>::type;
+    const uint32_t quads = c.num_rows / 4u, per = (quads + groups - 1u) / groups;
+    const uint32_t q_end = min(quads, (wg + 1u) * per);
+    for (uint32_t q = wg * per + tid; q < q_end; q += kBlockThreads) {
+        const uint4* p = reinterpret_cast<const uint4*>(c.partial) + q;
+        Sum s[4] = {0, 0, 0, 0};
+        for (uint32_t k0 = 0; k0 < c.slices; k0 += 4u) {      // at most four 16-byte loads in flight per thread (the row-block kernels' register budget)
+            uint4 v[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) v[k] = p[static_cast<size_t>(min(k0 + k, c.slices - 1u)) * quads];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                if (k0 + k >= c.slices) break;
+                const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (kFloat) s[j] += __uint_as_float(w[j]);
+                    else s[j] = __builtin_elementwise_add_sat(s[j], w[j]);      // saturating adds of non-negative terms: min(sum, 2^32 - 1) in any order
+                }
+            }
+        }
+        uint4 out;
+        if constexpr (kFloat) out = make_uint4(__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3]));
+        else out = make_uint4(s[0], s[1], s[2], s[3]);
+        reinterpret_cast<uint4*>(c.y)[q] = out;
+    }
 }
 
 }  // namespace

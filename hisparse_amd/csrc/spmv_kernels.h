@@ -25,6 +25,11 @@ struct SpmvLaunch {
     uint32_t num_workgroups;
     uint32_t lds_bytes;
     uint32_t bitmap_x_groups = 0; // BITMAP: lds_bytes ends with room for this many 64-column groups of x (0: x is read through L2)
+    // column-sliced plans, hs_run after hs_run: the PREVIOUS step's partial vectors, added up into carry_y by this launch's workgroups before
+    // they start on their own blocks (spmv_device.h: CarriedCombine); carry_partial == nullptr: nothing to carry
+    const uint32_t* carry_partial = nullptr;
+    uint32_t* carry_y = nullptr;
+    uint32_t carry_rows = 0, carry_slices = 0;
     bool light = false;           // the LIGHT plan (StreamTiles::light): a PAIRS image consumed by spmv_light_kernel, 256-thread workgroups, lds_bytes = spmv_light_lds_bytes
 };
 

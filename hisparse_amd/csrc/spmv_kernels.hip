@@ -704,7 +704,7 @@ template <bool kFloat, int kRing, int kAblate, int kDepth, bool kOwner = false>
 __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const Unit* __restrict__ units, const uint32_t* __restrict__ x,
                                                                   uint32_t* __restrict__ out, int32_t row_part_filter, uint32_t ring,
-                                                                  uint32_t x_base, const uint32_t* __restrict__ part_heads) {
+                                                                  uint32_t x_base, const uint32_t* __restrict__ part_heads, CarriedCombine carry) {
     using acc_t = typename Rows<kFloat>::acc_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     acc_t* ys = reinterpret_cast<acc_t*>(lds);                    // [nrows + 1] at LDS address 0: row addresses need no base add
@@ -717,6 +717,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
     // blocks, same x sub-tiles at about the same time) then share an L2.  Speed only, never correctness.
     uint32_t wg = blockIdx.x;
     if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (carry.partial) carried_combine<kFloat, kThreads>(carry, blockIdx.x, gridDim.x, tid);      // y of the PREVIOUS step (spmv_device.h)
 
     // The workgroup's first block is blocks[wg]; further ones are chained through Block::next (0 = none).  Everything a
     // consumer wavefront needs before its first stream load sits in the Block itself: ONE dependent load per block.
@@ -1194,6 +1195,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     const int ring = a.format == kFormatDelta ? 1 : a.format == kFormatPairs24 ? 2 : 0;
     const dim3 grid(a.num_workgroups), block(kThreads);
     const uint32_t x_base = a.lds_bytes - a.ring_buffers * kBufBytes;
+    const CarriedCombine carry = carried(a);
     // profiling aids (libhisparse_hip_prof.so only): HISPARSE_ABLATE removes parts of the work (wrong results), HISPARSE_DEPTH picks the
     // prefetch depth; read per launch, a tool may change them between launches.  The product library refuses to run with either set.
     int ablate = 0, depth = 8;
@@ -1232,7 +1234,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(A)                                                                                                                       \
     if (ablate == A) {                                                                                                             \
         hipLaunchKernelGGL((spmv_rowblock_kernel<false, 3, A, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
-                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads, carry);                                               \
         return hipGetLastError();                                                                                                  \
     }
             HS_FOR_EACH_OWNER24_FIXED(X)
@@ -1242,7 +1244,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(A)                                                                                                                       \
     if (ablate == A && records == 3) {                                                                                             \
         hipLaunchKernelGGL((spmv_rowblock_kernel<true, 3, A, 3, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
-                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads, carry);                                               \
         return hipGetLastError();                                                                                                  \
     }
         HS_FOR_EACH_OWNER24_ABLATION(X)
@@ -1251,7 +1253,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(D)                                                                                                                       \
     if (records == D) {                                                                                                            \
         hipLaunchKernelGGL((spmv_rowblock_kernel<true, 3, 0, D, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units, a.x, a.out, \
-                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                                               \
+                           a.row_part_filter, a.ring_buffers, x_base, a.part_heads, carry);                                               \
         return hipGetLastError();                                                                                                  \
     }
         HS_FOR_EACH_OWNER24_DEPTH(X)
@@ -1271,7 +1273,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(A)                                                                                                                      \
     if (!launched && ablate == A) {                                                                                               \
         hipLaunchKernelGGL((spmv_rowblock_kernel<true, false, A, 8, true>), grid, block, a.lds_bytes, stream, a.image, a.blocks,  \
-                           a.units, a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                        \
+                           a.units, a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads, carry);                        \
         launched = true;                                                                                                          \
     }
         if (depth == 8) {
@@ -1294,7 +1296,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #define X(F, T, A, D)                                                                                                           \
     if (!launched && is_float == F && ring == int(T) && ablate == A && depth == D) {                                     \
         hipLaunchKernelGGL((spmv_rowblock_kernel<F, T, A, D>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.units,    \
-                           a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads);                   \
+                           a.x, a.out, a.row_part_filter, a.ring_buffers, x_base, a.part_heads, carry);                   \
         launched = true;                                                                                                        \
     }
     HS_FOR_EACH_VARIANT(X)

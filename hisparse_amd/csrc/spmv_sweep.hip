@@ -157,7 +157,7 @@ __device__ __forceinline__ void sweep_round(std::integer_sequence<int, Ks...>, S
 template <bool kFloat, int kAblate>
 __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
-                                                                  int32_t row_part_filter, const uint32_t* __restrict__ part_heads) {
+                                                                  int32_t row_part_filter, const uint32_t* __restrict__ part_heads, CarriedCombine carry) {
     using R = SweepRows<kFloat>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* ys = lds;                                            // nrows + 1 sums (+ the carry bitmap in fixed point)
@@ -165,6 +165,7 @@ __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid / kWaveLanes);
     uint32_t wg = blockIdx.x;
     if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // logical workgroups [k n/8, (k+1) n/8) on XCD k
+    if (carry.partial) carried_combine<kFloat, kSweepThreads>(carry, blockIdx.x, gridDim.x, tid);   // y of the PREVIOUS step (spmv_device.h)
     uint32_t bi = wg;
     if (row_part_filter >= 0) {
         bi = ((const __attribute__((address_space(4))) uint32_t*)part_heads)[static_cast<uint32_t>(row_part_filter) * gridDim.x + wg];
@@ -243,10 +244,11 @@ hipError_t launch_spmv_sweep(bool is_float, const SpmvLaunch& a, hipStream_t str
     int ablate = 0, depth = 8;
     if (!profiling_switches(ablate, depth)) return hipErrorInvalidValue;
     const dim3 grid(a.num_workgroups), block(kSweepThreads);
+    const CarriedCombine carry = carried(a);
 #define X(A)                                                                                                                                         \
     if (ablate == A) {                                                                                                                               \
-        if (is_float) hipLaunchKernelGGL((spmv_sweep_kernel<true, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads); \
-        else hipLaunchKernelGGL((spmv_sweep_kernel<false, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads);       \
+        if (is_float) hipLaunchKernelGGL((spmv_sweep_kernel<true, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads, carry); \
+        else hipLaunchKernelGGL((spmv_sweep_kernel<false, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads, carry);       \
         return hipGetLastError();                                                                                                                    \
     }
     HS_FOR_EACH_SWEEP_VARIANT(X)

@@ -101,7 +101,15 @@ int hs_load_matrix(hs_context* ctx, const void* const channel[HS_NUM_CHANNELS], 
 /* packed_x: num_cols value words (PACKED_VAL_T[num_cols/8]) in natural order. */
 int hs_load_vector(hs_context* ctx, const void* packed_x, uint32_t num_cols);
 
-/* One full SpMV (every row partition) in one launch sequence; asynchronous. */
+/* One full SpMV (every row partition) in one launch sequence; asynchronous.
+ * Column-sliced plans (hs_stats.col_slices > 1: the SpMV kernel leaves per-slice partial rows, a small combine pass adds them up):
+ * when hs_run follows hs_run on the library's own stream, the combine pass of the earlier
+ * call is done by the LATER call's kernel as its first act (a second set of partial vectors takes the later call's own), and the
+ * stand-alone combine is launched only when something else follows -- every other entry point (hs_sync, hs_read_result, hs_feedback,
+ * hs_run_partition, hs_bind_device_result with another target, hs_set_stream, ...) launches it first, so the order of effects on the
+ * stream is exactly that of "kernel, combine" per call.  With a caller-owned stream (hs_set_stream), or once hs_get_stream has handed the
+ * stream out, every call completes in itself.  Chosen per matrix at load time (hs_api.cpp: always for the row-block and BITMAP kernels,
+ * for SWEEP images while the partial rows stay below 8 MB); hs_set_option "carry_combine" = 0 | 1 decides otherwise. */
 int hs_run(hs_context* ctx);
 /* EXTENSION: `steps` x hs_run from ONE call -- the reference's NUM_RUNS loop (sw/benchmark.cpp:315-343) as a unit.  A step of a small
  * matrix is two launches of a few microseconds each, and how fast the HOST enqueues them then decides the step time (a Python loop over
@@ -140,7 +148,7 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
  * (pairs|delta|owner|owner24|sweep|bitmap), col_slices, max_rows, cross_partitions (0: row blocks end at the reference's row-partition borders), row_runs, aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
  * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), sweep (0|1: the
  * column-ordered format of very sparse matrices), plan_debug; call-time keys: spmm_fused, spmm_mfma,
- * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph, batch_graph (hs_run_batch).  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
+ * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph, batch_graph (hs_run_batch); carry_combine (0|1, plan-time: see hs_run).  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
  * Options set here win over the environment variable of the same name, which stays as the fallback for tools and tests.  None of them
  * changes WHAT is computed.  The switches that do (HISPARSE_ABLATE, HISPARSE_DEPTH: profiling builds with parts of the work removed) are
  * not options: they exist only in libhisparse_hip_prof.so, and this library refuses to run (HS_ERR_BAD_ARG from hs_run, hs_run_partition,
