@@ -682,18 +682,29 @@ def main_distributed(args, rank, local_rank, world):
         cuda_sync()
         eng.sync()
 
+    def run_steps(gather, n):
+        """n slab SpMVs: with an exchange after every step, one hs_run at a time (each must be complete in stream order before its gather);
+        otherwise as ONE batch (hs_run_batch: the reference's NUM_RUNS loop as a unit -- enqueued from the library's C loop, the steps of a
+        column-sliced slab carrying each other's combine pass, the last one settled before the call returns)"""
+        if gather in ("final", "off") and on_gpu and step is plain_step:
+            if n:
+                eng.bind_device_result(y_chunks[0].data_ptr())
+                eng.run_batch(n)
+            return
+        for _ in range(n):
+            step(gather)
+
+    plain_step = step
+
     def timed(gather, steps):
-        for _ in range(spin_up_steps):
-            step(gather)
+        run_steps(gather, spin_up_steps)
         sync()
-        for _ in range(args.warmup):
-            step(gather)
+        run_steps(gather, args.warmup)
         sync()
         dist.barrier()
         cuda_sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step(gather)
+        run_steps(gather, steps)
         if gather == "final":
             all_gather(gathered[0], y_chunks[0])
         sync()

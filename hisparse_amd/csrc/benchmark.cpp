@@ -406,7 +406,11 @@ benchmark_result spmv_benchmark_multi(const Options& o, spmv::io::CSRMatrix<floa
         for (int i = 0; i < 5; ++i) step();
         sync_all();
         const auto a = clock::now();
-        for (unsigned i = 0; i < o.runs; ++i) step();
+        if (how == 0) {      // no exchange between the steps: every slab's NUM_RUNS loop as one batch (hs_run_batch), the devices side by side
+            for (int d = 0; d < N; ++d) check(hs_run_batch(slab[d].ctx, o.runs), slab[d].ctx, "hs_run_batch");
+        } else {
+            for (unsigned i = 0; i < o.runs; ++i) step();
+        }
         sync_all();
         return std::chrono::duration<double, std::milli>(clock::now() - a).count() / o.runs;
     };

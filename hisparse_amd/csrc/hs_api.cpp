@@ -66,6 +66,7 @@ struct hs_context {
     // its y yet; flush_combine() launches the stand-alone combine for it, and every entry point that could observe y, its target or the
     // stream does that first, so the stream-order contract of hisparse_hip.h holds unchanged.
     bool carry_combine = false;     // plan-time decision (load_matrix_impl): two sets of partial vectors exist
+    bool in_batch = false;          // inside hs_run_batch: the batch settles its own last step before it returns, whatever stream it runs on
     bool stream_shared = false;     // hs_get_stream was called: somebody else may order work against the stream -- every step completes in itself
     int pending = -1;
     uint32_t* pending_y = nullptr;
@@ -267,7 +268,7 @@ void partition_rows(const hs_context* c, uint32_t j, uint32_t& lo, uint32_t& hi)
 struct Feedback { uint32_t scale, shift; };
 int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1, const Feedback* feedback = nullptr) {
     if (const char* why = hisparse::dev::profiling_switch_error()) return fail(c, HS_ERR_BAD_ARG, why);
-    if (c->carry_combine && c->col_slices > 1 && filter < 0 && !k0 && !k1 && !feedback && c->stream == c->own_stream && !c->stream_shared) {
+    if (c->carry_combine && c->col_slices > 1 && filter < 0 && !k0 && !k1 && !feedback && ((c->stream == c->own_stream && !c->stream_shared) || c->in_batch)) {
         // this step's partial rows go to the set the previous step did NOT use; the previous step's are added up by this launch's
         // workgroups before they start on their blocks; this step's own sum is owed (pending) until the next hs_run or a flush
         hisparse::dev::SpmvLaunch a = launch_args(c, filter);
@@ -674,10 +675,19 @@ int hs_run_batch(hs_context* ctx, uint32_t steps) {
     if (steps == 0) return HS_OK;
     HS_HIP(ctx, hipSetDevice(ctx->device));
     const char* opt = ctx_option(ctx, "HISPARSE_BATCH_GRAPH");
+    // A batch is one unit in stream order: inside it the steps carry each other's combine pass (enqueue), and the last step's is launched
+    // before the call returns -- also on a caller-owned stream, where single hs_run calls must each complete in themselves.
+    struct InBatch {
+        hs_context* c;
+        const bool own;
+        explicit InBatch(hs_context* ctx) : c(ctx), own(ctx->stream == ctx->own_stream && !ctx->stream_shared) { c->in_batch = true; }
+        ~InBatch() { c->in_batch = false; }
+        int settle() { return own ? HS_OK : flush_combine(c); }      // (on the library's own stream the sum may stay owed: every entry point settles it)
+    } batch(ctx);
     if (!(opt && std::atoi(opt) != 0)) {      // plain: the launches of `steps` SpMVs enqueued from this C loop
         for (uint32_t i = 0; i < steps; ++i)
             if ((rc = enqueue(ctx, -1, nullptr, nullptr)) != HS_OK) return rc;
-        return HS_OK;
+        return batch.settle();
     }
     // graph replay: the same launches captured once into a hipGraph (per step count, vector, result target and stream) and replayed
     // with ONE runtime call -- what the step costs when the host's enqueue rate is out of the picture

@@ -30,7 +30,7 @@ namespace {
 
 constexpr int kSweepThreads = kSweepWaves * kWaveLanes;
 #ifndef HS_SWEEP_DEPTH
-#define HS_SWEEP_DEPTH 8            // (4, 6, 12 and 16 were measured too: -DHS_SWEEP_DEPTH=..., tools/r04/sweep_depth.sh, profiles/r04_sweep_ring_depth.txt)
+#define HS_SWEEP_DEPTH 8            // (4, 6, 12 and 16 were measured too: -DHS_SWEEP_DEPTH=..., tools/history/r04/sweep_depth.sh, profiles/r04_sweep_ring_depth.txt)
 #endif
 constexpr int kSweepDepth = HS_SWEEP_DEPTH;      // chunks (and gathers) in flight per wavefront
 

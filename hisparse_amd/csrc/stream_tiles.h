@@ -185,7 +185,7 @@ constexpr uint32_t kLightMinBlockNnz = 1024;                  // no block smalle
 // local_row = nrows (the spare accumulator), offset 0.  kernel: spmv_sweep.hip; builder: sweep_tiles.cpp; tools/gather_bench.hip is the
 // block-level measurement it was designed from.
 #ifndef HS_SWEEP_WAVES
-#define HS_SWEEP_WAVES 8                                      // (4 and 16 were measured too: -DHS_SWEEP_WAVES=..., tools/r04/sweep_waves.sh, profiles/r04_sweep_waves.txt)
+#define HS_SWEEP_WAVES 8                                      // (4 and 16 were measured too: -DHS_SWEEP_WAVES=..., tools/history/r04/sweep_waves.sh, profiles/r04_sweep_waves.txt)
 #endif
 constexpr uint32_t kSweepWaves = HS_SWEEP_WAVES;              // all wavefronts stream (no loaders)
 // the LDS holds nothing but accumulators: doubles in the float modes; fixed point: a wrapping 32-bit sum + a carry bit per row (spmv_sweep.hip)

@@ -67,7 +67,7 @@ CONFIGS = {
     "mouse_gene_slab2": Config("mouse_gene_slab2", "fixed", 22550, 45101, "powerlaw", 14483645, 0.30, 0.1, 44, ""),
     "mouse_gene_slab4": Config("mouse_gene_slab4", "fixed", 11275, 45101, "powerlaw", 7241822, 0.30, 0.1, 44, ""),
     # ogbn-products / pokec with the same rows and non-zeros over 1/2 and 1/4 of the columns: twice / four times the non-zeros per (row range,
-    # x sub-tile) unit -- what heavier units would buy the OWNER path (tools/r03/heavy_units.sh; experiments only)
+    # x sub-tile) unit -- what heavier units would buy the OWNER path (tools/history/r03/heavy_units.sh; experiments only)
     "ogbn_half_cols": Config("ogbn_half_cols", "float_stall", 2449029, 1224514, "powerlaw", 123718280, 0.43, 1.0, 43, ""),
     "ogbn_quarter_cols": Config("ogbn_quarter_cols", "float_stall", 2449029, 612257, "powerlaw", 123718280, 0.43, 1.0, 43, ""),
     "pokec_quarter_cols": Config("pokec_quarter_cols", "fixed", 1632803, 408200, "powerlaw", 30622564, 0.30, 1.0, 47, ""),

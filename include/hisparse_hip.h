@@ -115,7 +115,9 @@ int hs_run(hs_context* ctx);
  * matrix is two launches of a few microseconds each, and how fast the HOST enqueues them then decides the step time (a Python loop over
  * hs_run: one ctypes call + two launches per step).  Default: the launches are enqueued from a C loop.  hs_set_option "batch_graph" = 1:
  * the step sequence is captured once into a hipGraph (per step count, vector, result target and stream; re-captured when one of them
- * changes, dropped by hs_load_matrix) and replayed with one hipGraphLaunch.  Same kernels, same results; asynchronous like hs_run. */
+ * changes, dropped by hs_load_matrix) and replayed with one hipGraphLaunch.  Same kernels, same results; asynchronous like hs_run.
+ * A batch is ONE unit in stream order: inside it the steps of a column-sliced plan carry each other's combine pass (see hs_run) also on a
+ * caller-owned stream, and the last step's combine is enqueued before the call returns. */
 int hs_run_batch(hs_context* ctx, uint32_t steps);
 /* One row partition, with the reference's scalar arguments; part_len = rows per cluster
  * (checked against the geometry).  Rows of other partitions keep their previous contents. */

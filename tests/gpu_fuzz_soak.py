@@ -30,7 +30,7 @@ def run(n_cases=200, seed=1, profile=None, verbose=True):
         vb = int(rng.choice([1, 2, 16, 64, 4096])); ob = int(rng.choice([1, 2, 8, 64])) * (8 if impl == 2 else 1)
         skip = bool(rng.integers(0, 2))
         fmt = str(rng.choice(["pairs", "delta", "bitmap", "owner", "owner24", "sweep", "auto", "auto"]))      # auto: the planner's own choice of format (and, with slices "", of the tile plan)
-        if os.environ.get("HISPARSE_STREAM_FORMAT_ONLY"):      # a whole run in one format (tools/r04/long_soak2.sh: sweep)
+        if os.environ.get("HISPARSE_STREAM_FORMAT_ONLY"):      # a whole run in one format (tools/history/r04/long_soak2.sh: sweep)
             fmt = os.environ["HISPARSE_STREAM_FORMAT_ONLY"]
         if fmt.startswith("owner") and density > 0.003:
             fmt = "pairs"      # OWNER sums in fp32 like csim; forced onto long rows its rounding (not a defect) would trip the float64 re-check
