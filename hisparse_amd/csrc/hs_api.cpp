@@ -140,7 +140,7 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 
 // hs_set_option's keys (the HISPARSE_<KEY> environment switches the library understands); plan-time ones take effect at the next load
 const char* const kOptionKeys[] = {
-    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
+    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG", "PLAN_COMBINE_US",
     "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS", "SWEEP",
     "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "BATCH_GRAPH", "CARRY_COMBINE",
 };
@@ -518,14 +518,15 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
     if (tiles.col_slices > 1) {
         // the combine pass carried into the next step's kernel (hs_context::carry_combine); `carry_combine` = 0 | 1 decides otherwise
-        // Measured (profiles/r05_carry_combine_ab.txt, whole step): ogbl-ppa 55.4 -> 53.5 us, the R-MAT stand-in 60.0 -> 57.8, gplus 20.2 ->
-        // 19.8, hollywood 137.0 -> 135.1, ogbn-products 206 -> 204 -- the row-block kernels' workgroups ramp up over 2-4 us and the first
-        // wavefronts add the previous step's partial rows up meanwhile -- but pokec 73.5 -> 76.0: a SWEEP workgroup has no such ramp, and
-        // 33 MB of partial rows in front of every launch cost more than the 6.8 us combine launch they replace.  Hence: on by itself for
-        // the row-block and BITMAP kernels, for SWEEP only while a set of partial vectors stays below 8 MB.
+        // Measured (profiles/r05_carry_combine_ab.txt, three boxes, whole step): where a step is a few microseconds -- one rank's slab of
+        // mouse_gene split 8 ways: 10.1 -> 8.6 us, the second launch WAS a third of it -- carrying wins every time.  On the large images it
+        // is a wash that depends on the box and the run (ogbl-ppa 55.4 -> 53.5 / 54.2 / 57.0 us, hollywood 137.0 -> 135.1 / 139.1, the R-MAT
+        // stand-in 60.0 -> 57.8 / 62.0, ogbn-products 206 -> 204; pokec's SWEEP kernel 73.5 -> 76.0: 33 MB of partial rows in front of every
+        // launch): the partial rows a workgroup adds up were written by OTHER XCDs and come back from the memory side while nothing else of
+        // the workgroup can start.  Hence: on by itself for images below 48 MiB, the launch-bound regime; `carry_combine` = 0 | 1 decides otherwise.
         const char* opt = ctx_option(ctx, "HISPARSE_CARRY_COMBINE");
-        const bool carry = opt ? std::atoi(opt) != 0
-                               : (tiles.format != hisparse::dev::kFormatSweep || uint64_t(tiles.col_slices) * num_rows * 4 <= (8u << 20));
+        const uint64_t image_bytes = image_on_device ? tiles.image_bytes : uint64_t(tiles.image.size());
+        const bool carry = opt ? std::atoi(opt) != 0 : image_bytes < (48u << 20);
         HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(carry ? 2 : 1) * tiles.col_slices * num_rows * 4));
         ctx->carry_combine = carry;
     }

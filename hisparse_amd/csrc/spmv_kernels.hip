@@ -717,7 +717,6 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
     // blocks, same x sub-tiles at about the same time) then share an L2.  Speed only, never correctness.
     uint32_t wg = blockIdx.x;
     if ((gridDim.x & 7u) == 0) wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if (carry.partial) carried_combine<kFloat, kThreads>(carry, blockIdx.x, gridDim.x, tid);      // y of the PREVIOUS step (spmv_device.h)
 
     // The workgroup's first block is blocks[wg]; further ones are chained through Block::next (0 = none).  Everything a
     // consumer wavefront needs before its first stream load sits in the Block itself: ONE dependent load per block.
@@ -748,6 +747,9 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
                 consumer_begin<kFloat, kRing, kDepth, kOwner>(c, image + blk->wave_offset[wave], unit, U, wave, lane, xs, ring, ys, nrows, blk->total_steps[wave],
                                                                blk->first_end[wave]);
         }
+        // y of the PREVIOUS step (spmv_device.h: CarriedCombine), once per launch, HERE: the consumers' first stream loads (and the block
+        // descriptor behind them) are already travelling, so the round trip of the partial rows overlaps theirs instead of preceding it
+        if (carry.partial && block_no == 0) carried_combine<kFloat, kThreads>(carry, blockIdx.x, gridDim.x, tid);
         // Prologue.  (Measured in round 3, timeline build HISPARSE_ABLATE=512: 4.3 us pass between a workgroup's first wavefront
         // entering and this barrier, and most of that is the LAUNCH ramp -- the 16 wavefronts of a 1024-thread workgroup are started
         // 2 - 4 us apart, the loaders last -- not this code: letting the loaders DMA sub-tile 0 while only the consumers zero changed
