@@ -140,7 +140,7 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 
 // hs_set_option's keys (the HISPARSE_<KEY> environment switches the library understands); plan-time ones take effect at the next load
 const char* const kOptionKeys[] = {
-    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG", "PLAN_COMBINE_US",
+    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
     "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS", "SWEEP",
     "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "BATCH_GRAPH", "CARRY_COMBINE",
 };

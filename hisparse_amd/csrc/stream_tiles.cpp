@@ -293,10 +293,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                 const bool pairs_likely = !delta || (!format_forced && double(out.nnz) * 1.6 < double(is_float ? kDeltaMinSavedBytesFloat : kDeltaMinSavedBytes));
                 const double conflict_us = (!owner && pairs_likely && lanes_per_row > 1.0 && per_row_and_tile >= 16.0)
                                                ? double(out.nnz) / G / kWaveLanes * (lanes_per_row - 1.0) * 2.0 / 2400.0 : 0.0;
-                // the combine pass: its traffic + (a launch of its own: 3.5 us) -- or, carried into the next step's kernel (hs_api.cpp), ~1 us of
-                // that kernel's ramp.  HISPARSE_PLAN_COMBINE_US: the fixed part, for experiments.
-                const char* combine_fixed = env_switch("HISPARSE_PLAN_COMBINE_US");
-                const double combine_us = cs > 1 ? (combine_fixed ? std::atof(combine_fixed) : 3.5) + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
+                const double combine_us = cs > 1 ? 3.5 + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
                 const double cost = volume_us + latency_us + conflict_us + 8.0 * blocks_per_wg + combine_us;
                 if (detail::env_switch("HISPARSE_PLAN_DEBUG"))
                     std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f conflicts %.1f blocks/wg %.1f combine %.1f => %.1f us\n", cs, cap, ring, ranges,
