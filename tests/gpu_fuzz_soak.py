@@ -76,6 +76,16 @@ def run(n_cases=200, seed=1, profile=None, verbose=True):
             if not ok:
                 bad = np.nonzero(got != want)[0] if impl == 0 else np.nonzero(~np.isclose(got.view(np.float32), want.view(np.float32), rtol=1e-4, atol=1e-4))[0]
                 bad_runs.append((r, len(bad), bad[:6].tolist()))
+        # consecutive launches without anything in between: column-sliced plans carry the combine pass of one step into the next step's
+        # kernel (round 5, hs_api.cpp: enqueue / flush_combine) -- every burst length ends on either set of partial vectors
+        for burst in (2, 3):
+            for _ in range(burst):
+                eng.run()
+            got = eng.read_result()
+            ok = np.array_equal(got, want) if impl == 0 else (cases.float_close(got, want) or
+                                                              (exact is not None and np.allclose(got.view(np.float32).astype(np.float64), exact, rtol=1e-4, atol=1e-4)))
+            if not ok:
+                bad_runs.append((f"burst of {burst}", int((got != want).sum()), []))
         # the reference's literal launch sequence, one row partition at a time, must give the same vector
         for j in range(cp.num_row_partitions):
             eng.run_partition(j, cp.part_len(j))
