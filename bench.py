@@ -7,7 +7,8 @@
           and fails loudly (a JSON error line, exit code 2) when the machine shows fewer than N GPUs.
 
 A "step" is one full SpMV (every row partition) y = A x through the drop-in C-ABI, with the matrix (re-tiled at load time), x and y
-already resident in HBM.  Metric (BASELINE.json): the reference's "data throughput" of sw/benchmark.cpp:312-346 -- 8 bytes per non-zero
+already resident in HBM; the K timed steps are enqueued by one hs_run_batch(K) call (the reference's NUM_RUNS loop as a unit) and
+followed by one synchronisation.  Metric (BASELINE.json): the reference's "data throughput" of sw/benchmark.cpp:312-346 -- 8 bytes per non-zero
 per SpMV -- in decimal GB/s, with GOPS (2 flops per non-zero) and the fraction of the 8 TB/s HBM roofline.
 
 OUTPUT.  The LAST line of stdout is one JSON object of < 4 KB (the driver keeps an 8 KB tail of stdout and of stderr): the headline
@@ -206,11 +207,17 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
     for _ in range(warmup):
         eng.run()
     eng.sync()
+    # the timed region: K steps = the reference's NUM_RUNS loop, enqueued by ONE hs_run_batch call (the library's C loop: a Python loop
+    # over hs_run adds a ctypes call per step, which a 6 us step of a small matrix feels), one synchronisation at the end
     t0 = time.perf_counter()
-    for _ in range(steps):
-        eng.run()
+    eng.run_batch(steps)
     eng.sync()
     elapsed = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(steps):                                   # the same K steps as K hs_run calls from Python, beside it
+        eng.run()
+    eng.sync()
+    elapsed_python = time.perf_counter() - t0
     # the reference's own step: queue.finish() after every launch (sw/benchmark.cpp:331-337), so its spmv_time_ms is a LATENCY -- the same
     # K SpMVs with a host synchronisation after each one, beside the pipelined figure above (which is `value`)
     t0 = time.perf_counter()
@@ -267,6 +274,7 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         "stream_format": fmt, "col_slices": stats["col_slices"],
         "ms_per_step": round(ms, 5), "value": round(value, 2), "unit": "GB/s", "gops": round(2.0 * nnz / (elapsed / steps) / 1e9, 2),
         "ms_per_step_synchronous": round(elapsed_sync / steps * 1e3, 5),
+        "ms_per_step_python_loop": round(elapsed_python / steps * 1e3, 5),
         "ms_per_step_graph_replay": round(ms_graph, 5) if ms_graph else None,
         "spin_up_steps": spun,
         "gibps_reference_formula": round(8.0 * nnz / 2 ** 30 / (elapsed / steps), 2),
