@@ -25,7 +25,9 @@ def line(key):
     r = e.get("roofline", e)
     frac, step, cold = r["frac"], e.get("frac_whole_step", r.get("frac_whole_step")), r.get("frac_mall_cold")
     kernel_us, step_us = r["kernel_ms"] * 1e3, e["ms_per_step"] * 1e3
-    p = t.get(key[0]) if key[1] in ("fixed", None) or t.get(key[0], {}).get("impl") == ["fixed", "float_pob", "float_stall"].index(key[1]) else None
+    p = t.get(key[0])
+    if p is not None and p.get("impl") is not None and int(p["impl"]) != ["fixed", "float_pob", "float_stall"].index(key[1]):
+        p = None      # (profiled in another numeric mode)
     prof = traffic = "—"
     if p and p.get("round") == tag:
         prof = f"{p['kernel_avg_us']:.1f} / {p.get('kernel_steady_median_us', p['kernel_avg_us']):.1f} µs = {p['roofline_frac_rocprof'] * 100:.1f} %"
