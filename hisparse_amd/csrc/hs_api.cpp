@@ -526,7 +526,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
         // the workgroup can start.  Hence: on by itself for images below 48 MiB, the launch-bound regime; `carry_combine` = 0 | 1 decides otherwise.
         const char* opt = ctx_option(ctx, "HISPARSE_CARRY_COMBINE");
         const uint64_t image_bytes = image_on_device ? tiles.image_bytes : uint64_t(tiles.image.size());
-        const bool carry = opt ? std::atoi(opt) != 0 : image_bytes < (48u << 20);
+        const bool carry = opt ? std::atoi(opt) != 0 : image_bytes < hisparse::dev::kCarryMaxImageBytes;
         HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_partial), size_t(carry ? 2 : 1) * tiles.col_slices * num_rows * 4));
         ctx->carry_combine = carry;
     }

@@ -108,6 +108,8 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     }
 
     timer.lap("pass 0 (row counts)");
+    bool prefer_sliced_delta = false, sliced_delta_possible = false;      // (decided in the BITMAP / LIGHT blocks below)
+    double sliced_delta_us = 0.0;
     // ---- dense-row matrices (pruned-NN layers): BITMAP rows, their own builder and kernel (stream_tiles.h) --------------
     {
         // density of the rows that hold anything (padding rows and empty rows cost a mask per group and nothing else -- as long as
@@ -117,6 +119,28 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         const double density = live_rows ? double(out.nnz) / (double(live_rows) * double(num_cols)) : 0.0;
         const double mask_bytes = double(num_rows) * double((num_cols + kBitmapGroupCols - 1) / kBitmapGroupCols) * 8.0;
         bool bitmap = density >= kBitmapMinDensity && num_cols >= kBitmapMinCols && mask_bytes <= 2.0 * double(out.nnz);
+        // Round 5: SMALL dense-row layers in FIXED point as a sliced DELTA plan.  With the combine pass carried into the next step's kernel
+        // (hs_api.cpp) a plan of one column slice per x sub-tile is ONE launch without x refills and unit barriers, and its lanes sum their
+        // rows in registers (kBlockDenseRows): measured on the 512 x 33 288 pruned-NN layers (profiles/r05_sliced_delta_vs_bitmap.txt, fixed
+        // point, whole step): 10 % dense 7.9 us against 8.6 (LIGHT), 20 % 9.5 against 11.8 (BITMAP), 30 % 11.4 against 12.2, 40 % 12.9 against
+        // 12.5, 5 % 7.1 against 5.9 (LIGHT) -- ~6.3 us + 1.0 us per million non-zeros, where the BITMAP kernel pays for every 64-column group
+        // whatever it holds (~5 us + 7.5 ns per step and CU) and the LIGHT kernel 3.1 us + 3.2 us per million.  The float modes lose with it
+        // everywhere (their BITMAP kernel is 2 us faster, their DELTA path 1-2 us slower) and keep their plans.
+        {
+            const uint32_t live_tiles = (num_cols + kSubTileCols - 1) / kSubTileCols;
+            const double scale = 256.0 / std::max<uint32_t>(1, max_workgroups);
+            sliced_delta_us = 6.3 + double(out.nnz) * 1.0e-6 * scale;
+            sliced_delta_possible = !is_float && live_tiles >= 2 && live_tiles <= kMaxColSlices && density >= 0.04 && num_cols >= kBitmapMinCols &&
+                                    double(out.nnz) * 7.0 < double(kCarryMaxImageBytes) && RP == 1 && out.nnz >= (1u << 20);      // (measured between 0.85 and 8.5 M non-zeros)
+            const double bitmap_us = 5.0 + double(num_rows) * double((num_cols + kBitmapGroupCols - 1) / kBitmapGroupCols) / std::max<uint32_t>(1, max_workgroups) * 7.5e-3;
+            if (bitmap && sliced_delta_possible && sliced_delta_us < 0.97 * bitmap_us && !env_switch("HISPARSE_STREAM_FORMAT")) {
+                bitmap = false;
+                prefer_sliced_delta = true;
+            }
+            if (env_switch("HISPARSE_PLAN_DEBUG"))
+                std::fprintf(stderr, "format: dense rows (density %.3f): bitmap %.1f us, sliced delta %.1f us (%s) -> %s\n", density, bitmap_us, sliced_delta_us,
+                             sliced_delta_possible ? "possible" : "not possible", prefer_sliced_delta ? "sliced delta" : bitmap ? "bitmap" : "element streams");
+        }
         if (const char* force = env_switch("HISPARSE_STREAM_FORMAT")) {
             const std::string f(force);
             if (f == "bitmap") bitmap = true;
@@ -187,6 +211,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         // point too since round 3: saturating 32-bit accumulators (spmv_kernels.hip: OwnerOps) -- pokec in PAIRS, with 8-byte atomic
         // accumulators, 12287-row blocks and 26 600 units of 1 150 elements, ran at 24 % of the roofline
         if (mean_gap > kOwnerMinMeanGap && out.nnz >= 4096 && !g_no_owner) out.format = kFormatOwner24;
+        if (prefer_sliced_delta) out.format = kFormatDelta;
         if (const char* force = env_switch("HISPARSE_STREAM_FORMAT")) {
             const std::string f(force);
             if (f == "pairs") out.format = kFormatPairs;
@@ -204,7 +229,12 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     {
         const char* forced = env_switch("HISPARSE_STREAM_FORMAT");
         const bool fits = out.nnz > 0 && uint64_t(CP) * S <= kLightMaxUnits && num_rows < (1u << 31);
-        light = fits && !forced && out.nnz <= kLightMaxNnz;
+        light = fits && !forced && out.nnz <= kLightMaxNnz && !prefer_sliced_delta;
+        if (light && sliced_delta_possible && sliced_delta_us < 0.97 * (3.1 + double(out.nnz) * 3.2e-6 * 256.0 / std::max<uint32_t>(1, max_workgroups))) {
+            light = false;                       // (10 %-dense layers: see the BITMAP block above)
+            prefer_sliced_delta = true;
+            out.format = kFormatDelta;
+        }
         if (const char* force = env_switch("HISPARSE_LIGHT")) light = std::atoi(force) != 0 && fits && (!forced || std::string(forced) == "pairs");
         if (const char* force_slices = env_switch("HISPARSE_COL_SLICES")) light = light && std::atoi(force_slices) <= 1;      // a forced sliced plan is the row-block kernel's
         if (light) out.format = kFormatPairs;
@@ -213,7 +243,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     bool delta = out.format == kFormatDelta;
     const bool owner = out.format == kFormatOwner || out.format == kFormatOwner24;
     bool owner24 = out.format == kFormatOwner24;      // may still fall back to the 8-byte form (below)
-    const bool format_forced = env_switch("HISPARSE_STREAM_FORMAT") != nullptr;
+    const bool format_forced = env_switch("HISPARSE_STREAM_FORMAT") != nullptr || prefer_sliced_delta;      // (the sliced DELTA plan of a dense-row layer is DELTA for its per-lane row sums, not for its bytes)
     const uint32_t acc_bytes = owner ? kOwnerAccumulatorBytes : kAccumulatorBytes;
     const uint32_t spare_rows = owner ? kConsumerWaves : 1u;     // accumulators behind the block's rows that padding elements aim at
 
@@ -293,7 +323,10 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                 const bool pairs_likely = !delta || (!format_forced && double(out.nnz) * 1.6 < double(is_float ? kDeltaMinSavedBytesFloat : kDeltaMinSavedBytes));
                 const double conflict_us = (!owner && pairs_likely && lanes_per_row > 1.0 && per_row_and_tile >= 16.0)
                                                ? double(out.nnz) / G / kWaveLanes * (lanes_per_row - 1.0) * 2.0 / 2400.0 : 0.0;
-                const double combine_us = cs > 1 ? 3.5 + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
+                // the combine pass: a launch of its own (3.5 us) + its traffic -- or ~1 us of the NEXT step's kernel where the image is small
+                // enough for the carried combine (hs_api.cpp; stream_tiles.h: kCarryMaxImageBytes)
+                const bool carried = double(out.nnz) * 8.1 < double(kCarryMaxImageBytes);
+                const double combine_us = cs > 1 ? (carried ? 1.0 : 3.5) + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
                 const double cost = volume_us + latency_us + conflict_us + 8.0 * blocks_per_wg + combine_us;
                 if (detail::env_switch("HISPARSE_PLAN_DEBUG"))
                     std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f conflicts %.1f blocks/wg %.1f combine %.1f => %.1f us\n", cs, cap, ring, ranges,

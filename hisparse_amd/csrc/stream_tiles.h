@@ -81,6 +81,9 @@ constexpr uint32_t kMinXBuffers = 2;
 constexpr uint32_t kAccumulatorBytes = 8;
 constexpr uint32_t max_block_rows(bool sliced) { return (sliced ? 96u : 32u) * 1024u / kAccumulatorBytes - 1u; }
 constexpr uint32_t kMaxColSlices = 8;
+// Column-sliced plans whose image stays below this carry the combine pass of a step into the next step's kernel (hs_api.cpp: one launch per
+// step in a run of hs_run calls); the planner prices the combine pass of such a plan at ~1 us instead of a launch of its own (3.5 us).
+constexpr uint64_t kCarryMaxImageBytes = 48ull << 20;
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 // PAIRS format
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements
