@@ -43,6 +43,8 @@ struct Rows<false> {
     using sum_t = unsigned long long;   // a lane's private sum over a row run
     static __device__ __forceinline__ sum_t widen(prod_t p) { return p; }
     static __device__ __forceinline__ void add_sum(acc_t* ys, uint32_t row, sum_t v) { atomicAdd(ys + row, v); }
+    using lane_t = unsigned long long;  // DELTA dense rows: a lane's sum over its run inside ONE unit (exact)
+    static __device__ __forceinline__ void add_lane(acc_t* ys, uint32_t row, lane_t v) { atomicAdd(ys + row, v); }
 };
 template <>
 struct Rows<true> {
@@ -56,6 +58,11 @@ struct Rows<true> {
     using sum_t = double;               // a lane's private sum over a row run
     static __device__ __forceinline__ sum_t widen(prod_t p) { return static_cast<double>(p); }
     static __device__ __forceinline__ void add_sum(acc_t* ys, uint32_t row, sum_t v) { atomicAdd(ys + row, v); }
+    // DELTA dense rows: a lane's sum over its run inside ONE unit -- a hundred products at most -- is taken in fp32 like the float PEs'
+    // running sums (pe-pob.h:62-71, pe-stall.h:137-141) and joins the row's DOUBLE accumulator when the row or the unit changes: one
+    // full-rate v_add_f32 per element instead of a conversion and a half-rate v_add_f64
+    using lane_t = float;
+    static __device__ __forceinline__ void add_lane(acc_t* ys, uint32_t row, lane_t v) { atomicAdd(ys + row, static_cast<double>(v)); }
 };
 
 // Sum over the 64 lanes of a wavefront (result valid in every lane).

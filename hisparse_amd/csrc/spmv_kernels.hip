@@ -227,7 +227,7 @@ struct Consumer {
     uint32_t run_row = kNoRow; // PAIRS dense rows: row whose products are being summed in registers ...
     prod_t run_sum = 0;        // ... and this lane's share of that sum
     uint32_t lane_row = 0;     // DELTA dense rows: the row this LANE is on (its run of consecutive elements rarely leaves it) ...
-    typename Rows<kFloat>::sum_t lane_sum = 0;   // ... and the lane's private sum on it, flushed to LDS when the row changes
+    typename Rows<kFloat>::lane_t lane_sum = 0;  // ... and the lane's private sum on it, flushed to LDS when the row or the unit changes
     typename OwnerSum<kFloat>::type own_sum = 0;   // OWNER: the lane's sum on lane_row (4-byte accumulators touched by this wavefront only: fp32, or saturating Q8.24)
     uint32_t spare = 0;        // OWNER: the wavefront's own spare accumulator (local row nrows + wave)
     uint32_t row_base = 0;     // OWNER24: first local row of the wavefront's share of the current unit (rows are stored relative to it)
@@ -268,7 +268,7 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
             c.run_row = Consumer<kFloat>::kNoRow;
         }
         if (kDelta && kDense) {        // every lane hands its private row sum over before the sub-tile changes
-            R::add_sum(c.ys, c.lane_row, c.lane_sum);
+            R::add_lane(c.ys, c.lane_row, c.lane_sum);
             c.lane_row = c.nrows;      // the spare accumulator: the next flush of an idle lane adds 0 there
             c.lane_sum = 0;
         }
@@ -307,11 +307,11 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
                 // Dense rows: a lane's run of consecutive sorted elements stays on one row for many steps (and the lanes
                 // of one instruction would collide on the few rows there are): sum in a register, touch LDS on row changes.
                 if (row != c.lane_row) {       // per lane (exec-masked)
-                    R::add_sum(c.ys, c.lane_row, c.lane_sum);
+                    R::add_lane(c.ys, c.lane_row, c.lane_sum);
                     c.lane_row = row;
                     c.lane_sum = 0;
                 }
-                c.lane_sum += R::widen(prod);
+                c.lane_sum += prod;
             } else {
                 R::add(c.ys, row, prod);
             }
