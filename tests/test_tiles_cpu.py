@@ -523,3 +523,29 @@ def test_plans_of_small_and_narrow_matrices(monkeypatch):
     assert not (t["blocks"]["flags"] & 1).any()
     xw = host.pack_vector(0, cases.random_x(cp.num_cols, 4, 0))
     assert np.array_equal(tile_emulator.run(t, 0, xw, cp.num_rows), oracle_y(cp, 0, xw))
+
+
+def test_small_fixed_point_dense_row_layers_take_the_sliced_delta_plan(monkeypatch):
+    """Round 5 planner rule (stream_tiles.cpp): a pruned-NN layer of 10-30 % density in FIXED point -- 1 ... 5.5 M non-zeros, 2 ... 8 x
+    sub-tiles -- runs as DELTA with one column slice per sub-tile (combine carried into the next step's kernel: one launch), where the
+    fitted cost beats BITMAP's and LIGHT's; the float modes keep BITMAP.  The emulated kernel must still match the oracle."""
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT", raising=False)
+    for name in ("HISPARSE_LIGHT", "HISPARSE_COL_SLICES", "HISPARSE_ROW_RUNS"):
+        monkeypatch.delenv(name, raising=False)
+    csr = host.CSRMatrix.generate("bernoulli", 512, 33288, b=0.2, c=0.05, seed=80)      # transformer-80's shape and density
+    for impl, want_format, want_slices in ((0, "delta", 5), (1, "bitmap", 1)):
+        cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+        t = build(cp, impl, 256)
+        assert t["format"] == want_format and t["col_slices"] == want_slices, (impl, t["format"], t["col_slices"])
+        if impl == 0:
+            assert (t["blocks"]["flags"] & 1).all()                     # per-lane row sums (kBlockDenseRows) in every block
+            assert len(t["image"]) < 48 << 20                           # below the carried-combine limit (stream_tiles.h: kCarryMaxImageBytes)
+            units_per_block = (t["blocks"]["unit_end"] - t["blocks"]["unit_begin"]).max()
+            assert units_per_block == 1                                 # a slice per sub-tile: no x refills, no unit barriers
+            xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 80, impl))
+            got = tile_emulator.run(t, impl, xw, cp.num_rows)
+            assert np.array_equal(got, oracle_y(cp, impl, xw))
+    # below a million non-zeros the measured range ends: LIGHT, as before
+    small = host.CSRMatrix.generate("bernoulli", 512, 33288, b=0.05, c=0.05, seed=95)
+    t = build(host.format_matrix(small, 0, skip_empty_rows=True), 0, 256)
+    assert t["format"] == "pairs" and t["col_slices"] == 1
