@@ -32,7 +32,7 @@ $(LIBDIR)/libhisparse_host.so: $(CSRC)/host_capi.cpp $(HOST_HDRS) | $(LIBDIR)
 
 # One object per translation unit (an edit of one kernel file recompiles that file only); objects live in build/ (git-ignored, and listed in
 # .gpurunignore: the GPU box needs the libraries, not the objects).
-HIP_UNITS := hs_api.cpp tiles_capi.cpp stream_tiles.cpp bitmap_tiles.cpp sweep_tiles.cpp spmv_kernels.hip spmv_bitmap.hip spmv_sweep.hip spmspv.hip spmm_bitmap.hip spmm_mfma.hip gpu_tiles.hip
+HIP_UNITS := hs_api.cpp tiles_capi.cpp stream_tiles.cpp bitmap_tiles.cpp sweep_tiles.cpp spmv_kernels.hip spmv_bitmap.hip spmv_sweep.hip spmspv.hip spmm_bitmap.hip spmm_mfma.hip spmm_sweep.hip gpu_tiles.hip
 OBJDIR    := $(ROOT)/build
 HIP_OBJS  := $(addprefix $(OBJDIR)/prod/,$(addsuffix .o,$(HIP_UNITS)))
 PROF_OBJS := $(addprefix $(OBJDIR)/prof/,$(addsuffix .o,$(HIP_UNITS)))

@@ -75,6 +75,12 @@ struct hs_context {
     uint32_t* d_partition_y = nullptr;   // hs_run_partition on a one-slice plan with such blocks: the kernel writes here (num_rows words,
                                          // allocated on first use), the partition's own rows are then copied into y
     uint32_t max_block_rows = 0;
+    // SpMM over a SWEEP image planned for it (spmm_sweep.hip; option spmm_vectors = 4): X interleaved [column][4], the four result columns
+    // (per column slice) before the combine pass, and after it
+    uint32_t spmm_vectors = 1;
+    uint32_t* d_spmm_x4 = nullptr;
+    uint32_t* d_spmm_partial = nullptr;
+    uint32_t* d_spmm_y = nullptr;
     uint32_t* d_x_interleaved = nullptr;   // fused SpMM over a BITMAP image: 4 columns of X as [column][vector] words (allocated on first use)
     // SpMM on the matrix engine (float BITMAP matrices): the second image + scratch (spmm_mfma.hip)
     uint32_t* d_mfma = nullptr;
@@ -140,7 +146,7 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 
 // hs_set_option's keys (the HISPARSE_<KEY> environment switches the library understands); plan-time ones take effect at the next load
 const char* const kOptionKeys[] = {
-    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
+    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "SPMM_VECTORS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
     "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS", "SWEEP",
     "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "BATCH_GRAPH", "CARRY_COMBINE",
 };
@@ -170,6 +176,11 @@ void free_matrix(hs_context* c) {
     c->crossing_blocks = false;
     if (c->d_x_interleaved) (void)hipFree(c->d_x_interleaved);
     c->d_x_interleaved = nullptr;
+    for (uint32_t** p : {&c->d_spmm_x4, &c->d_spmm_partial, &c->d_spmm_y}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    c->spmm_vectors = 1;
     for (void* p : {static_cast<void*>(c->d_mfma), static_cast<void*>(c->d_mfma_x), static_cast<void*>(c->d_mfma_partial), static_cast<void*>(c->d_mfma_flag)})
         if (p) (void)hipFree(p);
     c->d_mfma = c->d_mfma_x = c->d_mfma_flag = nullptr;
@@ -559,6 +570,12 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     ctx->lds_bytes = lds_bytes;
     ctx->bitmap_x_groups = tiles.bitmap_x_groups;
     ctx->col_slices = tiles.col_slices;
+    ctx->spmm_vectors = tiles.spmm_vectors;
+    if (tiles.spmm_vectors == 4) {
+        const uint32_t need = hisparse::dev::spmm_sweep_lds_bytes(tiles.max_block_rows, ctx->impl != HS_IMPL_FIXED);
+        if (need > hisparse::dev::kMaxLdsBytes) ctx->spmm_vectors = 1;      // (cannot happen with the planner's row cap; the k-SpMV path then)
+        else HS_HIP(ctx, hisparse::dev::configure_spmm_sweep_kernels(hisparse::dev::kMaxLdsBytes));
+    }
     for (const Block& b : tiles.blocks) ctx->crossing_blocks = ctx->crossing_blocks || b.last_part != b.row_part;
     ctx->max_block_rows = tiles.max_block_rows;
     ctx->ring_buffers = tiles.ring_buffers;
@@ -1201,6 +1218,37 @@ int hs_spmm_device(hs_context* ctx, const void* x_dev, uint64_t ldx, void* y_dev
                 HS_HIP(ctx, hisparse::dev::launch_spmm_bitmap(is_float, a, ctx->stream));
                 j += group;
             }
+        }
+    }
+    // SWEEP images planned for it (option spmm_vectors = 4 at load time): four columns per pass through the matrix (spmm_sweep.hip); the
+    // last pass may carry fewer (its missing columns are zero vectors whose results are not copied out)
+    if (fused_enabled && ctx->format == hisparse::dev::kFormatSweep && ctx->spmm_vectors == 4 && k - j >= 2) {
+        if (int frc = flush_combine(ctx)) return frc;
+        const size_t rows = ctx->num_rows;
+        if (!ctx->d_spmm_x4) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_spmm_x4), size_t(ctx->num_cols) * 16 + 64));
+        if (!ctx->d_spmm_y) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_spmm_y), rows * 16));
+        if (ctx->col_slices > 1 && !ctx->d_spmm_partial) HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_spmm_partial), size_t(ctx->col_slices) * rows * 16));
+        while (j < k) {
+            const uint32_t vectors = std::min<uint32_t>(4, k - j);
+            hisparse::dev::SpmmSweepLaunch a;
+            a.image = ctx->d_image;
+            a.blocks = ctx->d_blocks;
+            a.x = static_cast<const uint32_t*>(x_dev) + size_t(j) * ldx;
+            a.ldx = ldx;
+            a.x4 = ctx->d_spmm_x4;
+            a.out = ctx->col_slices > 1 ? ctx->d_spmm_partial : ctx->d_spmm_y;
+            a.vectors = vectors;
+            a.num_rows = ctx->num_rows;
+            a.num_cols = ctx->num_cols;
+            a.num_workgroups = ctx->num_workgroups;
+            a.max_block_rows = ctx->max_block_rows;
+            HS_HIP(ctx, hisparse::dev::launch_spmm_sweep(is_float, a, ctx->stream));
+            if (ctx->col_slices > 1)      // the four vectors' partial rows lie back to back inside a slice: ONE combine over 4 x rows "rows"
+                HS_HIP(ctx, hisparse::dev::launch_combine_slices(is_float, ctx->d_spmm_partial, ctx->d_spmm_y, uint32_t(4 * rows), ctx->col_slices, 0,
+                                                                 uint32_t(4 * rows), ctx->stream));
+            HS_HIP(ctx, hipMemcpy2DAsync(static_cast<uint32_t*>(y_dev) + size_t(j) * ldy, size_t(ldy) * 4, ctx->d_spmm_y, rows * 4, rows * 4, vectors,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+            j += vectors;
         }
     }
     for (; j < k && rc == HS_OK; ++j) {

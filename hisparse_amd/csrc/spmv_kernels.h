@@ -86,6 +86,22 @@ struct SpmmMfmaLaunch {
 size_t spmm_mfma_x_words(uint32_t groups);
 size_t spmm_mfma_partial_words(uint32_t tiles, uint32_t chunks);
 hipError_t launch_spmm_mfma(const SpmmMfmaLaunch& a, hipStream_t stream);
+// SpMM over a SWEEP image planned for it (spmm_sweep.hip; hs_set_option "spmm_vectors" = 4 before the load): up to four columns of X per call.
+struct SpmmSweepLaunch {
+    const uint8_t* image;
+    const Block* blocks;
+    const uint32_t* x;            // column j of X at x + j * ldx words
+    uint64_t ldx;
+    uint32_t* x4;                 // scratch: num_cols x 4 words, 16-byte aligned ([column][vector])
+    uint32_t* out;                // [column slice][vector][row] words: one slice = the four result columns back to back
+    uint32_t vectors;             // 1 .. 4 columns really there (the others are zero vectors)
+    uint32_t num_rows, num_cols;
+    uint32_t num_workgroups;
+    uint32_t max_block_rows;
+};
+uint32_t spmm_sweep_lds_bytes(uint32_t max_block_rows, bool is_float);
+hipError_t configure_spmm_sweep_kernels(uint32_t lds_bytes);
+hipError_t launch_spmm_sweep(bool is_float, const SpmmSweepLaunch& a, hipStream_t stream);
 // BITMAP images (spmv_bitmap.hip); launch_spmv forwards to it when a.format == kFormatBitmap.
 hipError_t configure_bitmap_kernels(uint32_t lds_bytes);
 hipError_t launch_spmv_bitmap(bool is_float, const SpmvLaunch& a, hipStream_t stream);

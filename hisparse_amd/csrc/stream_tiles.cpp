@@ -194,13 +194,19 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             sweep = sweep_us < owner_us;
             if (env_switch("HISPARSE_PLAN_DEBUG")) std::fprintf(stderr, "format: sweep %.1f us (%u slices) against owner24 %.1f us (%.0f units per workgroup) -> %s\n", sweep_us, cs, owner_us, per_wg, sweep ? "sweep" : "owner24");
         }
+        // "spmm_vectors" = 4: the caller wants the four-vector SpMM kernel, which runs SWEEP images only (spmm_sweep.hip)
+        const char* spmm = env_switch("HISPARSE_SPMM_VECTORS");
+        const bool for_spmm = spmm && std::atoi(spmm) == 4 && out.nnz > 0 && uint64_t(num_cols) * 16 < (1ull << 32);
+        if (for_spmm) sweep = true;
         if (const char* force = env_switch("HISPARSE_SWEEP")) sweep = std::atoi(force) != 0;      // (1: whatever the matrix)
         if (const char* force = env_switch("HISPARSE_STREAM_FORMAT")) sweep = std::string(force) == "sweep";
         if (sweep) {
             const uint64_t nnz_keep = out.nnz;
             out = StreamTiles();
             out.nnz = nnz_keep;
-            return build_sweep_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error, csr, gpu.get(), image_slack);
+            if (!build_sweep_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error, csr, gpu.get(), image_slack)) return false;
+            out.spmm_vectors = for_spmm ? 4u : 1u;
+            return true;
         }
     }
     // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse; hyper-sparse float matrices: OWNER --

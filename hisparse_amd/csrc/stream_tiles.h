@@ -298,6 +298,7 @@ struct StreamTiles {
     uint32_t num_workgroups = 0;
     uint32_t max_block_rows = 0;
     uint64_t sweep_table_bytes = 0;      // SWEEP: bytes of the chunk-base tables at the end of the image (statistics)
+    uint32_t spmm_vectors = 1;           // 4: a SWEEP image planned for spmm_sweep.hip (rows per block / 4; HISPARSE_SPMM_VECTORS=4)
     bool light = false;                  // the LIGHT plan (below): PAIRS image, one slice, up to kLightWorkgroupsPerCu x CUs small blocks, spmv_light_kernel
     uint32_t col_slices = 1;             // > 1: blocks write per-slice partial results, a combine pass adds them
     uint32_t ring_buffers = kMaxXBuffers;

@@ -50,6 +50,8 @@ double sweep_plan(const Layout& L, uint64_t nnz, uint32_t max_workgroups, uint32
     const uint32_t num_rows = L.num_rows, num_cols = L.num_cols;
     const uint32_t G = std::max<uint32_t>(1, max_workgroups);
     max_rows = L.g->impl == IMPL_FIXED ? kSweepMaxBlockRowsFixed : kSweepMaxBlockRowsFloat;
+    // an image planned for the four-vector SpMM kernel (spmm_sweep.hip): four sets of accumulators per block, so a quarter of the rows
+    if (const char* v = env_switch("HISPARSE_SPMM_VECTORS")) if (std::atoi(v) == 4) max_rows = std::max(1u, max_rows / 4u - 1u);
     if (const char* force = env_switch("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force)));
     const uint64_t by_cap = detail::ranges_by_cap(L, max_rows);
     const uint32_t lines = (num_cols + kSweepColAlign - 1) / kSweepColAlign;

@@ -147,7 +147,7 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
 /* ---- tuning options (EXTENSION) ----------------------------------------------------------------------
  * The library's configuration surface.  key: the name of a tuning switch, case-insensitive, with or without the "HISPARSE_" prefix of its
  * environment spelling -- plan-time keys (take effect at the NEXT hs_load_matrix / hs_load_matrix_csr of this context): stream_format
- * (pairs|delta|owner|owner24|sweep|bitmap), col_slices, max_rows, cross_partitions (0: row blocks end at the reference's row-partition borders), row_runs, aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
+ * (pairs|delta|owner|owner24|sweep|bitmap), col_slices, max_rows, cross_partitions (0: row blocks end at the reference's row-partition borders), spmm_vectors (4: plan the image for the four-column SpMM kernel, see hs_spmm), row_runs, aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
  * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), sweep (0|1: the
  * column-ordered format of very sparse matrices), plan_debug; call-time keys: spmm_fused, spmm_mfma,
  * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph, batch_graph (hs_run_batch); carry_combine (0|1, plan-time: see hs_run).  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
@@ -231,6 +231,10 @@ int hs_load_matrix_csr(hs_context* ctx, uint32_t num_rows, uint32_t num_cols, co
  *   BITMAP images (dense rows -- the pruned-NN layers, which meet batches of activations in practice), one column slice: FUSED, 4
  *     then 2 columns at a time (spmm_bitmap.hip): masks and values are streamed once per group, x interleaved [column][vector];
  *     transformer-50: 6.3 us per column against 13.5 us for an SpMV (profiles/r02_spmm_bitmap.txt).  HISPARSE_SPMM_FUSED=0 turns it off.
+ *   SWEEP images PLANNED for it -- hs_set_option "spmm_vectors" = 4 before the load (any element-stream matrix then takes the SWEEP format
+ *     with a quarter of the rows per block; hs_run works on it as on any image, a little slower than on the planner's own choice) --: FOUR
+ *     columns per pass through the matrix (spmm_sweep.hip: X interleaved [column][4], one 16-byte gather per element, four sets of row
+ *     accumulators); ogbl-ppa, 16 columns: 598 us against 895 as 16 SpMVs, mouse_gene 338 against 571 (profiles/r05_spmm_sweep.txt).
  *   every other image, and a last odd column: one SpMV launch per column over the resident image (the matrix is streamed k times).
  * The context's own vector / result and its bindings are left as they were.
  *   hs_spmm_device: X and Y in device memory, column j at x_dev + j * ldx words / y_dev + j * ldy words; 16-byte aligned, ldx and ldy

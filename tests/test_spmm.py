@@ -197,3 +197,88 @@ def test_spmm_on_the_matrix_engine(monkeypatch, impl, rows, cols, density, k):
     assert np.isfinite(y3[~touching]).all() and cases.float_close(Ybad[3][~touching], Y[3][~touching], rtol=1e-5, atol=1e-5)
     for j in (0, k - 1):
         assert cases.float_close(Ybad[j], Y[j], rtol=1e-5, atol=1e-5)
+
+
+# ---- round 5: four columns per pass over an element-stream (graph) image planned for it (spmm_sweep.hip; option spmm_vectors = 4) -------
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("k", [2, 4, 7, 16])
+@pytest.mark.parametrize("slices", ["", "3"])
+def test_spmm_four_vectors_per_pass_over_a_sweep_image(impl, k, slices):
+    """Every column of Y against the oracle's SpMV of that column (bit-exact in fixed point, tolerance in float); the same image still
+    answers hs_run; strides wider than the vectors; the context's own vector / result untouched."""
+    csr = host.CSRMatrix.generate("powerlaw", 60000, 90000, a=1500000, b=0.4, c=1.0 if impl == 0 else 2.0, seed=29)
+    ip, ix, dv = csr.arrays()
+    if impl != 0:
+        dv = (dv - 1.0).astype(np.float32)
+    import scipy.sparse as sp
+    m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(60000, 90000))
+    v, o = host.default_banks(impl)
+    _, cp = cases.formatted(m, impl, v, o, True)
+    X = np.stack([host.pack_vector(impl, cases.random_x(cp.num_cols, 300 + j, impl)) for j in range(k)])
+    own = host.pack_vector(impl, cases.random_x(cp.num_cols, 299, impl))
+    with device.SpmvEngine(impl) as eng:
+        eng.set_option("spmm_vectors", "4")
+        if slices:
+            eng.set_option("col_slices", slices)
+        eng.load_matrix(cp)
+        st = eng.stats()
+        assert device.STREAM_FORMATS[st["stream_format"]] == "sweep"
+        if slices:
+            assert st["col_slices"] == int(slices)
+        eng.load_vector(own)
+        eng.run()
+        before = eng.read_result()
+        assert np.array_equal(before, _oracle(cp, impl, own)) if impl == 0 else cases.float_close(before, _oracle(cp, impl, own))
+        Y = eng.spmm(X)
+        assert np.array_equal(eng.read_result(), before)
+        again = eng.spmm(X)
+        eng.set_option("spmm_fused", "0")                          # the same columns as k SpMVs over the same image
+        loop = eng.spmm(X)
+    for j in range(k):
+        want = _oracle(cp, impl, X[j])
+        if impl == 0:
+            assert np.array_equal(Y[j], want), (j, np.nonzero(Y[j] != want)[0][:8])
+            assert np.array_equal(again[j], want) and np.array_equal(loop[j], want)
+        else:
+            assert cases.float_close(Y[j], want) and cases.float_close(again[j], want) and cases.float_close(loop[j], want)
+
+
+def test_spmm_sweep_saturation_and_strided_device_buffers():
+    """fixed point: a row whose sum passes 2^32 - 1 saturates per vector (the carry bit of ITS accumulator set); device pointers with
+    leading dimensions wider than the vectors"""
+    hip = _Hip()
+    impl, k = 0, 5
+    rows, cols = 20000, 30000
+    rng = np.random.default_rng(3)
+    import scipy.sparse as sp
+    m = sp.random(rows, cols, density=0.002, random_state=np.random.RandomState(3), format="csr", dtype=np.float32)
+    m.data = rng.uniform(0.0, 2.0, m.nnz).astype(np.float32)
+    m = m.tolil()
+    m[7, :3000] = 1.9                                            # 3000 x 1.9 x (x up to 2) >> 256: saturates for the columns with large x
+    m = m.tocsr()
+    m.sort_indices()
+    _, cp = cases.formatted(m, impl, *host.default_banks(impl), True)
+    ldx, ldy = cp.num_cols + 12, cp.num_rows + 4
+    X = np.zeros((k, ldx), dtype=np.uint32)
+    for j in range(k):
+        xf = cases.random_x(cp.num_cols, 40 + j, impl)
+        if j % 2:
+            xf[:] = 0.0                                          # every other column: y = 0, no saturation anywhere
+        X[j, :cp.num_cols] = host.pack_vector(impl, xf)
+    xd = hip.upload(X)
+    yd = hip.upload(np.full((k, ldy), 0xdeadbeef, dtype=np.uint32))
+    try:
+        with device.SpmvEngine(impl) as eng:
+            eng.set_option("spmm_vectors", "4")
+            eng.load_matrix(cp)
+            eng.spmm_device(xd, ldx, yd, ldy, k)
+            eng.sync()
+            Y = hip.download(yd, (k, ldy))
+    finally:
+        hip.free(xd)
+        hip.free(yd)
+    assert (Y[:, cp.num_rows:] == 0xdeadbeef).all()               # nothing written beyond a column's rows
+    for j in range(k):
+        want = _oracle(cp, impl, np.ascontiguousarray(X[j, :cp.num_cols]))
+        assert np.array_equal(Y[j, :cp.num_rows], want)
+        assert (want[7] == 0xFFFFFFFF) == (j % 2 == 0)
