@@ -18,6 +18,8 @@ configuration -- BASELINE.json configs[1], ogbl-ppa (seeded stand-in, hisparse_a
                                 back-to-back launches of the kernel alone; the figure rocprofv3 --stats gives (profiles/)
     roofline.frac_whole_step    8 nnz / (wall time per step: kernel + slice-combine pass + launch gaps) / 8 TB/s   (= value / 8000)
     roofline.frac_event_pairs   the kernel inside whole steps, a HIP event pair around EVERY launch (each pair adds ~3 us)
+`roofline.traffic` = HBM bytes per launch from two short rocprofv3 counter passes run BY this script (bench_extras.live_traffic; the
+committed copy of profiles/hbm_traffic.json beside it and as the fallback).
 Everything else a default run measures (the other BASELINE configurations, the reference's whole sweep sw/bm.sh in all numeric modes,
 MALL-cold round-robin legs, the strong-scaling prediction: bench_extras.py) goes to `bench_details.json` next to this file and, one row
 per matrix, to stderr.  `--config NAME` measures only that configuration; `--quick` skips the extras.
@@ -532,6 +534,14 @@ def main():
     roofline["frac_mall_cold"] = r.get("frac_mall_cold")
     roofline["traffic_from"] = (f"{tf.get('source', '')}: round {tf.get('round')}, commit {tf.get('git_head')}, kernel sources unchanged since: {tf.get('sources_unchanged_since')}; "
                                 f"rocprofv3 kernel avg then {tf.get('kernel_us_rocprof')} us")[:400]
+    if not args.quick and not args.npz:      # the counters of THIS run (two short rocprofv3 passes); the committed copy stays as the fallback and beside it
+        live, how = bench_extras.live_traffic(headline, IMPL_NAMES[impl], r["kernel"], rank)
+        if live is not None:
+            roofline["traffic_committed_copy"] = roofline["traffic"]
+            roofline["traffic"], roofline["traffic_from"] = round(live, 1), how
+        else:
+            log(rank, f"{headline}: live counter passes not available ({how}): roofline.traffic is the committed copy")
+            roofline["traffic_from"] = (roofline["traffic_from"] + f" [live passes: {how}]")[:480]
     out = {
         "metric": "SpMV GBPS (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346)",
         "value": res["value"], "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,

@@ -7,6 +7,7 @@ run live here and are written to `bench_details.json` (+ one row per matrix on s
   * strong_scaling_prediction  every row slab of the 2-/4-/8-way split timed on this one GPU (no collective involved or predicted)
 Each configuration goes through bench.measure_single, i.e. is checked against the oracle before it is timed.
 """
+import os
 import time
 
 import bench as B
@@ -183,6 +184,47 @@ def predict_scaling(np, datasets, device, host, sharding, name, steps, rank, way
         B.log(rank, f"{name} split {n} ways: slowest slab {worst:.1f} us against {t_whole:.1f} us unsplit -> predicted compute-only efficiency {t_whole / (n * worst) * 100:.0f} %")
     return out
 
+
+
+def live_traffic(name, impl_name, kernel, rank, launches=30, timeout=150):
+    """HBM bytes per launch of the dominant kernel, MEASURED in this run: two rocprofv3 counter passes (their own runs, --kernel-trace
+    only beside --pmc, as MI355X_MICROARCH.md prescribes) of tools/traffic_probe.py -- the same configuration, loaded the same way, a few
+    launches -- FETCH_SIZE x 1024 x 2 (gfx950 counts the 128-byte requests of a wide streaming read at 64 bytes) + WRITE_SIZE x 1024,
+    medians over the launches.  (bytes, provenance) or (None, why): the caller then falls back to the committed copy."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import sys
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="hisparse_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    medians = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            sub = os.path.join(out, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", sub, "-o", counter.lower(), "--", sys.executable,
+                   os.path.join(B.ROOT, "tools", "traffic_probe.py"), name, impl_name, str(launches)]
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
+            hits = glob.glob(os.path.join(sub, "**", "*.db"), recursive=True)
+            if p.returncode != 0 or not hits:
+                return None, f"rocprofv3 --pmc {counter} failed (exit {p.returncode})"
+            vals = sorted(v for (v,) in sqlite3.connect(hits[0]).execute(
+                "select value from counters_collection where counter_name = ? and kernel_name like ?", (counter, f"%{kernel}%")))
+            if len(vals) < launches // 2:
+                return None, f"rocprofv3 --pmc {counter}: {len(vals)} samples of {kernel}"
+            medians[counter] = vals[len(vals) // 2]
+    except (subprocess.TimeoutExpired, OSError, sqlite3.Error) as e:
+        return None, f"{type(e).__name__}: {e}"[:160]
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    total = medians["FETCH_SIZE"] * 1024.0 * 2.0 + medians["WRITE_SIZE"] * 1024.0
+    B.log(rank, f"{name}: HBM traffic per launch measured in this run: FETCH_SIZE {medians['FETCH_SIZE']:.0f} KiB x 2 + WRITE_SIZE {medians['WRITE_SIZE']:.0f} KiB = {total/1e6:.1f} MB")
+    return total, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/traffic_probe.py, medians of {launches} launches; "
+                   "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of wide streaming reads) + WRITE_SIZE KiB x 1024")
 
 
 def bm_entry(name, paper_gops, res, impl="fixed"):
