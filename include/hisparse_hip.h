@@ -109,7 +109,7 @@ int hs_load_vector(hs_context* ctx, const void* packed_x, uint32_t num_cols);
  * hs_run_partition, hs_bind_device_result with another target, hs_set_stream, ...) launches it first, so the order of effects on the
  * stream is exactly that of "kernel, combine" per call.  With a caller-owned stream (hs_set_stream), or once hs_get_stream has handed the
  * stream out, every call completes in itself.  Chosen per matrix at load time (hs_api.cpp: images below 48 MiB, where the second launch is a
- * large part of the step); hs_set_option "carry_combine" = 0 | 1 decides otherwise. */
+ * large part of the step, and OWNER images); hs_set_option "carry_combine" = 0 | 1 decides otherwise. */
 int hs_run(hs_context* ctx);
 /* EXTENSION: `steps` x hs_run from ONE call -- the reference's NUM_RUNS loop (sw/benchmark.cpp:315-343) as a unit.  A step of a small
  * matrix is two launches of a few microseconds each, and how fast the HOST enqueues them then decides the step time (a Python loop over
