@@ -809,7 +809,7 @@ int hs_load_matrix_csc(hs_context* ctx, const uint32_t* indptr, const uint32_t* 
     for (uint64_t e = 0; e < nnz; ++e)
         if (row_indices[e] >= num_rows) return fail(ctx, HS_ERR_BAD_MATRIX, "CSC row index out of range");
     const uint32_t bins = hisparse::dev::spmspv_bins(num_rows), block_bits = hisparse::dev::spmspv_block_bits(num_rows);
-    if (bins > hisparse::dev::spmspv_max_bins()) return fail(ctx, HS_ERR_UNSUPPORTED, "more than 2048 row blocks of 8192 rows (16.7 M rows)");
+    if (bins > hisparse::dev::spmspv_max_bins()) return fail(ctx, HS_ERR_UNSUPPORTED, "more than 16 384 row blocks of 16 384 rows (268 M rows)");
     if (nnz > 0xfffffff0ull) return fail(ctx, HS_ERR_UNSUPPORTED, "more than 2^32 non-zeros");
     // a bin per row block, as large as the block's share of the matrix: products of an x that names every column at most once always fit
     std::vector<uint32_t> bin_base(size_t(bins) + 1, 0);

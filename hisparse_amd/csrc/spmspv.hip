@@ -39,7 +39,9 @@ namespace dev {
 
 namespace {
 
-constexpr uint32_t kMaxBlockBits = 13;                    // a row block = at most 8192 rows: 64 KiB of 8-byte LDS accumulators
+constexpr uint32_t kMaxBlockBits = 13;                    // a row block = 8192 rows at most (64 KiB of 8-byte LDS accumulators) ...
+constexpr uint32_t kHugeBlockBits = 14;                   // ... 16 384 (128 KiB) once the matrix has more than 16.7 M rows
+constexpr uint32_t kSmallBins = 2048;                     // bins an expand workgroup counts in 16 KiB of LDS; beyond: up to kMaxBins in 128 KiB
 constexpr uint32_t kMinBlockBits = 9;
 constexpr uint32_t kExpandColumns = 64;                   // x entries per workgroup of the expand kernel
 constexpr uint32_t kExpandThreads = 256;
@@ -59,7 +61,7 @@ __device__ __forceinline__ uint32_t product_word(uint32_t value_word, uint32_t x
 // column at most once can never ask for more -- so the bins together are one list of nnz entries, and the accumulate kernel reads ITS bin and
 // nothing else.  (Round 4's first version wrote one unsorted list and had every row block's workgroup sweep the block ids of ALL products:
 // ~5 G products/s whatever the matrix, 86 us for 1 % of ogbl-ppa's columns; profiles/r04_spmspv.txt.)
-constexpr uint32_t kMaxBins = 2048;                       // LDS histogram + claims: 16 KiB
+constexpr uint32_t kMaxBins = 16384;                      // LDS histogram + claims: 8 bytes per bin, 128 KiB at most -> 268 M rows
 template <bool kFloat>
 __global__ __launch_bounds__(kExpandThreads) void spmspv_expand_kernel(const uint32_t* __restrict__ indptr, const uint32_t* __restrict__ row_indices,
                                                                       const uint32_t* __restrict__ value_words, const uint2* __restrict__ x_entries,
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(256) void spmspv_scatter_x_kernel(const uint2* __re
 uint32_t spmspv_block_bits(uint32_t num_rows) {
     uint32_t bits = kMaxBlockBits;
     while (bits > kMinBlockBits && ((uint64_t(num_rows) + (1u << bits) - 1) >> bits) < 128) --bits;
+    if (((uint64_t(num_rows) + (1u << bits) - 1) >> bits) > kSmallBins) bits = kHugeBlockBits;      // > 16.7 M rows
     return bits;
 }
 uint32_t spmspv_bins(uint32_t num_rows) { return uint32_t((uint64_t(num_rows) + (1u << spmspv_block_bits(num_rows)) - 1) >> spmspv_block_bits(num_rows)); }
@@ -224,6 +227,19 @@ hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* 
         const dim3 grid((x_count + columns - 1) / columns), block(kExpandThreads);
         const uint2* xe = reinterpret_cast<const uint2*>(x_entries);
         const uint32_t lds = bins * 8u;
+        if (lds > 48u * 1024u) {                 // > 6144 bins (100 M rows): the histogram needs the function's dynamic-LDS cap raised
+            static bool raised_on[64] = {};
+            int dev_ = 0;
+            (void)hipGetDevice(&dev_);
+            bool& raised = raised_on[dev_ >= 0 && dev_ < 64 ? dev_ : 0];
+            if (!raised) {
+                hipError_t ce = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmspv_expand_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxBins * 8u));
+                if (ce == hipSuccess)
+                    ce = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmspv_expand_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxBins * 8u));
+                if (ce != hipSuccess) return ce;
+                raised = true;
+            }
+        }
         if (is_float)
             hipLaunchKernelGGL(spmspv_expand_kernel<true>, grid, block, lds, stream, indptr, row_indices, value_words, xe, x_count, num_cols, s.bin_base, s.cursors,
                                s.overflow, block_bits, bins, columns, s.keys, s.vals);
@@ -234,7 +250,7 @@ hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* 
         if (e != hipSuccess) return e;
     }
     const dim3 grid(bins);
-    const uint32_t lds = 8u << block_bits;      // accumulators: 64 KiB at most
+    const uint32_t lds = 8u << block_bits;      // accumulators: 64 KiB (128 KiB above 16.7 M rows)
 #define X(F, A)                                                                                                                                                  \
     do {                                                                                                                                                         \
         static bool configured_on[64] = {};      /* the dynamic-LDS cap is a property of the function, per device */                                            \
@@ -243,7 +259,7 @@ hipError_t launch_spmspv(bool is_float, const uint32_t* indptr, const uint32_t* 
         bool& configured = configured_on[dev_ >= 0 && dev_ < 64 ? dev_ : 0];                                                                                     \
         if (!configured) {                                                                                                                                       \
             const hipError_t ce = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmspv_accumulate_kernel<F, A>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                      int(8u << kMaxBlockBits));                                                                                 \
+                                                      int(8u << kHugeBlockBits));                                                                                 \
             if (ce != hipSuccess) return ce;                                                                                                                     \
             configured = true;                                                                                                                                   \
         }                                                                                                                                                        \

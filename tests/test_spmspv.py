@@ -132,6 +132,34 @@ def test_repeated_entries_add_up_and_oversized_calls_are_split(impl):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("rows", [20_000_000, 40_000_000, 120_000_000])
+def test_matrices_taller_than_2048_row_blocks(impl, rows):
+    # more than 2048 row blocks of 8192 rows used to be refused.  Above 16.7 M rows a block is 16 384 rows
+    # (20 M: 1221 bins), above 33.5 M the expand kernel counts more than 2048 bins (40 M: 2442), above 100 M in more than 48 KiB of LDS
+    # (120 M: 7325 bins).  A tall thin CSC matrix written out by hand: rows spread over the whole height, first and last row included.
+    cols, per_col = 300, 400
+    rng = np.random.default_rng(rows % 1000 + impl)
+    stride = rows // per_col                              # one row per stratum: ascending and distinct inside a column
+    ridx = np.arange(per_col, dtype=np.int64)[None, :] * stride + rng.integers(0, stride, size=(cols, per_col), dtype=np.int64)
+    ridx[0, 0], ridx[-1, -1] = 0, rows - 1
+    indptr = (np.arange(cols + 1) * per_col).astype(np.uint32)
+    vals = cases.random_x(cols * per_col, 9, impl)
+    words = host.pack_vector(impl, vals)
+    ridx = ridx.reshape(-1).astype(np.uint32)
+    xi = np.arange(0, cols, 2, dtype=np.uint32)
+    xw = host.pack_vector(impl, cases.random_x(len(xi), 3, impl))
+    want = orc.spmspv(impl, indptr, ridx, words, rows, cols, xi, xw)
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix_csc(indptr, ridx, words, rows)
+        got = eng.spmspv(xi, xw)
+        again = eng.spmspv(xi, xw)                       # cursors re-armed
+    assert got.shape == (rows,) and np.count_nonzero(want) > 0
+    assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+    assert np.array_equal(again, got)
+
+
+@pytest.mark.gpu
 def test_device_resident_entries_and_the_overflow_report():
     import ctypes as C
     impl, rows, cols = 0, 50000, 40000
