@@ -216,6 +216,15 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
     eng.run_batch(steps)
     eng.sync()
     elapsed = time.perf_counter() - t0
+    # K steps of a small matrix are over in 0.1-0.3 ms, of which the final synchronisation and the first launch's latency are 20-70 us:
+    # where K steps took under 2 ms, the same loop over enough steps for ~5 ms is reported BESIDE it (never `value`)
+    long_steps, ms_long = 0, None
+    if elapsed < 2e-3:
+        long_steps = int(min(5000, max(steps * 2, 5e-3 / (elapsed / steps))))
+        t0 = time.perf_counter()
+        eng.run_batch(long_steps)
+        eng.sync()
+        ms_long = (time.perf_counter() - t0) / long_steps * 1e3
     t0 = time.perf_counter()
     for _ in range(steps):                                   # the same K steps as K hs_run calls from Python, beside it
         eng.run()
@@ -279,6 +288,7 @@ def measure_single(np, datasets, device, host, name, steps, warmup, device_id=0,
         "ms_per_step_synchronous": round(elapsed_sync / steps * 1e3, 5),
         "ms_per_step_python_loop": round(elapsed_python / steps * 1e3, 5),
         "ms_per_step_graph_replay": round(ms_graph, 5) if ms_graph else None,
+        "ms_per_step_long_run": round(ms_long, 5) if ms_long else None, "long_run_steps": long_steps or None,
         "spin_up_steps": spun,
         "gibps_reference_formula": round(8.0 * nnz / 2 ** 30 / (elapsed / steps), 2),
         "frac_whole_step": round(value / HBM_PEAK_GBS, 4),
@@ -362,8 +372,9 @@ def summary_row(res):
     """one stderr row per measured (matrix, numeric mode): what the driver's 8 KB stderr tail should still hold"""
     r = res["roofline"]
     cold = r.get("frac_mall_cold")
+    long_run = f"  [{res['ms_per_step_long_run']*1e3:.1f} us/step over {res['long_run_steps']} steps]" if res.get("ms_per_step_long_run") else ""
     return (f"{res['matrix']}/{res['impl']}".ljust(28) + f"{res['stream_format'][:18]:<19}{res['col_slices']:>2} {res['ms_per_step']*1e3:8.1f} {res['value']:7.0f} "
-            f"{res['gops']:6.0f} {res['frac_whole_step']*100:6.1f} {r['frac']*100:6.1f} " + (f"{cold*100:6.1f}" if cold is not None else "     -") + "  " + short_parity(res["parity_vs_oracle"]))
+            f"{res['gops']:6.0f} {res['frac_whole_step']*100:6.1f} {r['frac']*100:6.1f} " + (f"{cold*100:6.1f}" if cold is not None else "     -") + "  " + short_parity(res["parity_vs_oracle"]) + long_run)
 
 
 SUMMARY_HEAD = "matrix/impl".ljust(28) + "format".ljust(19) + "sl  us/step    GB/s   GOPS  %step %kernl  %cold  parity"

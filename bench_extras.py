@@ -232,7 +232,8 @@ def bm_entry(name, paper_gops, res, impl="fixed"):
     point; Table 7: float_pob = "PB", float_stall = "RI")"""
     r = res["roofline"]
     row = {"matrix": name, "impl": impl, "nnz": res["nnz"], "partitions": res["partitions"], "stream_format": res["stream_format"], "col_slices": res["col_slices"],
-           "ms_per_step": res["ms_per_step"], "ms_per_step_synchronous": res["ms_per_step_synchronous"], "value": res["value"], "unit": "GB/s", "gops": res["gops"],
+           "ms_per_step": res["ms_per_step"], "ms_per_step_long_run": res.get("ms_per_step_long_run"), "long_run_steps": res.get("long_run_steps"),
+           "ms_per_step_synchronous": res["ms_per_step_synchronous"], "value": res["value"], "unit": "GB/s", "gops": res["gops"],
            "frac_whole_step": res["frac_whole_step"], "frac": r["frac"], "frac_event_pairs": r["frac_event_pairs"], "frac_mall_cold": r.get("frac_mall_cold"),
            "kernel_ms": r["kernel_ms"], "streamed_bytes_per_launch": r["streamed_bytes_per_launch"],
            "image_fits_infinity_cache": r["streamed_bytes_per_launch"] < 256 * 2 ** 20, "parity_vs_oracle": res["parity_vs_oracle"],

@@ -278,7 +278,7 @@ struct DevicePlan {        // what the emit kernels need of a UnitPlan + its blo
     uint64_t first_slot[kConsumerWaves];
     uint64_t wave_offset[kConsumerWaves];
     uint32_t n, chunks, base, nrows, flags;
-    uint32_t start_step[kConsumerWaves], run_len[kConsumerWaves];
+    uint32_t start_step[kConsumerWaves], run_len[kConsumerWaves], lane_stride[kConsumerWaves];
     uint32_t own_begin[kConsumerWaves + 1];
     uint32_t row_base[kConsumerWaves];     // OWNER24: first local row of the wavefront's share of this unit
 };
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void emit_delta_kernel(const DevicePlan* __res
             uint8_t* r = rec + uint64_t(j / 2) * kRecordBytes;
             uint32_t* value_word = reinterpret_cast<uint32_t*>(r) + 2 * l + j % 2;
             uint16_t* gap_word = reinterpret_cast<uint16_t*>(r + kWaveLanes * 8) + 2 * l + j % 2;
-            const uint64_t s0 = p.first_slot[w] + uint64_t(l) * run;
+            const uint64_t s0 = p.first_slot[w] + uint64_t(l) * p.lane_stride[w];
             if (j == 0) {
                 uint32_t head = scratch_pos;
                 if (s0 < p.slots) head = s0 == 0 ? first_pos : delta_slot(p, keys, vals, bridges, s0 - 1).after;
@@ -889,7 +889,7 @@ bool make_device_plans(const std::vector<UnitPlan>& plans, const std::vector<uin
             for (uint32_t w = 0; w < kConsumerWaves; ++w) { d.wave_offset[w] = blk.wave_offset[w]; d.row_base[w] = up.own_row[w]; }
         }
         for (uint32_t w = 0; w < kConsumerWaves; ++w) {
-            d.first_slot[w] = up.first_slot[w]; d.start_step[w] = up.start_step[w]; d.run_len[w] = up.run_len[w]; d.own_begin[w] = up.own_begin[w];
+            d.first_slot[w] = up.first_slot[w]; d.start_step[w] = up.start_step[w]; d.run_len[w] = up.run_len[w]; d.lane_stride[w] = up.lane_stride[w]; d.own_begin[w] = up.own_begin[w];
         }
         d.own_begin[kConsumerWaves] = up.own_begin[kConsumerWaves];
     }

@@ -122,14 +122,16 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         // Round 5: SMALL dense-row layers in FIXED point as a sliced DELTA plan.  With the combine pass carried into the next step's kernel
         // (hs_api.cpp) a plan of one column slice per x sub-tile is ONE launch without x refills and unit barriers, and its lanes sum their
         // rows in registers (kBlockDenseRows): measured on the 512 x 33 288 pruned-NN layers (profiles/r05_sliced_delta_vs_bitmap.txt, fixed
-        // point, whole step): 10 % dense 7.9 us against 8.6 (LIGHT), 20 % 9.5 against 11.8 (BITMAP), 30 % 11.4 against 12.2, 40 % 12.9 against
-        // 12.5, 5 % 7.1 against 5.9 (LIGHT) -- ~6.3 us + 1.0 us per million non-zeros, where the BITMAP kernel pays for every 64-column group
-        // whatever it holds (~5 us + 7.5 ns per step and CU) and the LIGHT kernel 3.1 us + 3.2 us per million.  The float modes lose with it
-        // everywhere (their BITMAP kernel is 2 us faster, their DELTA path 1-2 us slower) and keep their plans.
+        // point, whole step; with the lane-major dealing of the runs, "after the dealing" there): 10 % dense 7.5 us against 8.6 (LIGHT), 20 % 9.0
+        // against 11.9 (BITMAP), 30 % 11.0 against 12.0, 40 % 12.5 against 12.4, 5 % 6.9 against 5.9 (LIGHT) -- ~5.8 us + 1.0 us per million
+        // non-zeros, where the BITMAP kernel pays for every 64-column group
+        // whatever it holds (~5 us + 7.5 ns per step and CU) and the LIGHT kernel 3.1 us + 3.2 us per million.  The float modes keep their
+        // plans: their BITMAP kernel is 2 us faster and their DELTA path 1 us slower, which leaves 0.4-0.5 us at 10 % and 20 % density and a
+        // loss everywhere else.
         {
             const uint32_t live_tiles = (num_cols + kSubTileCols - 1) / kSubTileCols;
             const double scale = 256.0 / std::max<uint32_t>(1, max_workgroups);
-            sliced_delta_us = 6.3 + double(out.nnz) * 1.0e-6 * scale;
+            sliced_delta_us = 5.8 + double(out.nnz) * 1.0e-6 * scale;
             sliced_delta_possible = !is_float && live_tiles >= 2 && live_tiles <= kMaxColSlices && density >= 0.04 && num_cols >= kBitmapMinCols &&
                                     double(out.nnz) * 7.0 < double(kCarryMaxImageBytes) && RP == 1 && out.nnz >= (1u << 20);      // (measured between 0.85 and 8.5 M non-zeros)
             const double bitmap_us = 5.0 + double(num_rows) * double((num_cols + kBitmapGroupCols - 1) / kBitmapGroupCols) / std::max<uint32_t>(1, max_workgroups) * 7.5e-3;
@@ -530,9 +532,9 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
 
     // DELTA or PAIRS, now that every unit's slots are known (automatic choice only):
     //  * DELTA pays for every position gap beyond 16 bits with a bridge slot.  A graph whose gaps are heavy-tailed (R-MAT: a quarter
-    //    of the rows empty, hubs of 10^5 non-zeros) needs one for every 25th element although its MEAN gap looks fine, and its
-    //    lanes' runs are unevenly filled: measured 82 us against 60 us in PAIRS on the R-MAT ogbl-ppa stand-in, where the
-    //    Chung-Lu stand-in (0.4 % bridges) is faster in DELTA.  So: more than 2 % bridge slots -> PAIRS.
+    //    of the rows empty, hubs of 10^5 non-zeros) needs one for every 25th element although its MEAN gap looks fine: 4 % more slots
+    //    and still 11 % fewer bytes than PAIRS (58.5-58.9 us against 59.4-59.8; what made it 82-85 us through round 4 was the dealing of
+    //    the runs, see first_slot above, not the bridges).  More than 5 % bridge slots -> PAIRS.
     //  * DELTA's 6-byte slots only pay when the stream is what bounds the kernel.  Measured over 20 shapes (tools/probe_synth.py,
     //    40000^2 and 400000 x 100000 power-law matrices at mean gaps 16 ... 4096, ogbl-ppa, mouse_gene):
     //    t(DELTA) - t(PAIRS) = (bytes saved) / 6.5 TB/s - c with c = 3.5 us fixed point, 6 us float (more instructions per element,
@@ -551,7 +553,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         const double units_per_block = double(plans.size()) / std::max<uint32_t>(1, NB);
         const uint64_t min_saved = is_float ? kDeltaMinSavedBytesFloat
                                             : std::min<uint64_t>(kDeltaMinSavedBytes, uint64_t((1.0 + 0.18 * units_per_block) * 6.5e6));
-        if (double(slots) > 1.02 * double(out.nnz) || pairs_bytes < delta_bytes + min_saved) {
+        if (double(slots) > 1.05 * double(out.nnz) || pairs_bytes < delta_bytes + min_saved) {
             delta = false;
             out.format = kFormatPairs;
             for (UnitPlan& up : plans) up.slots = up.n;
@@ -640,6 +642,9 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     };
 
     // ---- per block: deal every unit's 64-slot chunks to the consumer wavefronts round-robin; lay out the streams -------
+    // DELTA runs are dealt lane-major ("spread"; HISPARSE_DELTA_DEAL=wave: rounds 1-4's dealing, kept for the A/B): see first_slot below
+    bool delta_spread = true;
+    if (const char* deal = env_switch("HISPARSE_DELTA_DEAL")) delta_spread = std::string(deal) != "wave";
     std::vector<uint64_t> block_nnz(NB, 0);   // weight of a block for the workgroup assignment
     uint64_t image_bytes = 0;
     for (uint32_t bi = 0; bi < NB; ++bi) {
@@ -672,7 +677,14 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             uint64_t first = 0;
             for (uint32_t w = 0; w < kConsumerWaves; ++w) {
                 up.run_len[w] = run[w];
-                up.first_slot[w] = first;
+                // DELTA: which run of the position-sorted unit lane l of wavefront w walks.  "spread": runs are dealt lane-major (run
+                // l * 14 + w), so the 64 lanes of a wavefront sit a 64th of the unit apart, like PAIRS' chunks.  "wave" (rounds 1-4): the
+                // wavefront owns a contiguous 1/14 of the unit, its lanes consecutive runs of it -- then a hub row of a heavy-tailed
+                // graph (R-MAT: 850 of a unit's 10 K elements in ONE row) holds ALL 64 lanes of a wavefront on one accumulator, step after
+                // step: 64 ds_add_u64 on one address.  Measured (profiles/r05_delta_dealing.txt, whole step): R-MAT ogbl-ppa 85.1 -> 58.9 us
+                // (PAIRS: 59.4-59.8), transformer-80 10.9 -> 9.9-10.2, mouse_gene 34.2 -> 33.9, gplus 20.1 -> 19.9, ogbl-ppa / hollywood equal.
+                up.first_slot[w] = delta_spread ? first / kWaveLanes : first;
+                up.lane_stride[w] = delta_spread ? chunks : run[w];
                 first += uint64_t(run[w]) * kWaveLanes;
                 up.start_step[w] = up.start_record[w] = pos[w];
                 // DELTA: one head record (absolute positions) in front of the wavefront's records of this unit
@@ -837,7 +849,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             auto gap_at = [&](uint32_t q, uint32_t l) -> uint16_t& { return reinterpret_cast<uint16_t*>(rec + uint64_t(q / 2) * kRecordBytes + kWaveLanes * 8)[2 * l + q % 2]; };
             const uint32_t slots_in_records = (up.run_len[w] + 2) / 2 * 2;      // head + run, rounded up to whole records
             for (uint32_t l = 0; l < kWaveLanes; ++l) {
-                const uint64_t s0 = up.first_slot[w] + uint64_t(l) * up.run_len[w];
+                const uint64_t s0 = up.first_slot[w] + uint64_t(l) * up.lane_stride[w];
                 // position BEFORE the run's first slot; slot 0 carries gap 0 from the first element's own position
                 value_at(0, l) = s0 >= up.slots ? scratch_pos : (s0 == 0 ? uint32_t(e[0] >> 32) : after[s0 - 1]);
                 for (uint32_t j = 0; j < up.run_len[w]; ++j) {

@@ -35,7 +35,9 @@
 //       wavefront adds it up in registers.  Bytes read per SpMV = the reference's "8 bytes per non-zero"
 //       throughput definition (sw/benchmark.cpp:312-314) plus < 2 % chunk padding.
 //
-//     DELTA (6 bytes per slot): lane l of wavefront w owns run_len consecutive slots of the sorted unit.
+//     DELTA (6 bytes per slot): lane l of wavefront w owns run_len consecutive slots of the sorted unit -- the runs are dealt
+//       lane-major (run l * 14 + w), so the lanes of one wavefront sit a 64th of the unit apart, like the lanes of a PAIRS chunk
+//       (round 5; a contiguous 1/14 of the unit per wavefront put all 64 lanes on ONE accumulator wherever a graph has hub rows).
 //       A slot = a u32 value word + a u16 GAP: the distance from the lane's previous position.  A 768-byte record holds TWO
 //       consecutive slots of every lane (kRecordBytes below).  Every (unit, wavefront) run starts with a HEAD slot whose value
 //       words are the lanes' absolute start positions.  Gap 0xffff = BRIDGE: no element, advance 65535 (value word 0);
@@ -44,7 +46,7 @@
 //       On ogbl-ppa this is 6.85 bytes per non-zero all in (heads, bridges, padding, dead slots) instead of 8.03.
 //
 //     DELTA is tried when the mean position gap rows*cols/nnz lies in [kDeltaMinMeanGap, kDeltaMaxMeanGap] (hyper-sparse matrices
-//     would need a bridge for every other gap) and kept when, after the sort, it needs at most 2 % bridge slots AND saves more
+//     would need a bridge for every other gap) and kept when, after the sort, it needs at most 5 % bridge slots AND saves more
 //     than kDeltaMinSavedBytes of stream against PAIRS: its slots cost more instructions and a head record per unit and
 //     wavefront, which only pays when the stream bounds the kernel (stream_tiles.cpp has the measurements).  Inside a DELTA matrix,
 //     blocks whose rows are long (block gap < kDenseMeanGap) are flagged kBlockDenseRows: there every lane sums its run in a

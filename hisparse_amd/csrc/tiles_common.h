@@ -185,6 +185,7 @@ struct UnitPlan {           // host-side companion of a device Unit
     uint64_t slots = 0;     // elements + bridge slots
     uint32_t run_len[kConsumerWaves];      // slots per lane of wavefront w in this unit
     uint64_t first_slot[kConsumerWaves];   // first slot of lane 0 of wavefront w
+    uint32_t lane_stride[kConsumerWaves];  // DELTA: slots from the run of lane l to the run of lane l + 1 of wavefront w
     uint32_t start_record[kConsumerWaves]; // record index of the unit's head record in wavefront w's stream
     // OWNER
     uint32_t own_begin[kConsumerWaves + 1]; // wavefront w owns sorted elements [own_begin[w], own_begin[w + 1]) of the unit

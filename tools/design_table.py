@@ -35,7 +35,11 @@ def line(key):
     fmt = e["stream_format"] + (f", {e['col_slices']} slices" if e.get("col_slices", 1) > 1 else "")
     parity = e["parity_vs_oracle"]
     parity = "bit-exact" if parity.startswith("bit-exact") else ("tolerance" + (" (csim abs 1e-4: " + parity.split("not met on ")[1].split(";")[0] + " over)" if "not met on" in parity else ""))
-    return f"| {key[0]} / {key[1]} | {fmt} | {kernel_us:.1f} µs = {pct(frac)} % | {step_us:.1f} µs = {pct(step)} % | {pct(cold)} | {prof} | {traffic} | {parity} |"
+    long_run = ""
+    if e.get("ms_per_step_long_run"):      # K = 20 steps of a small matrix carry the final synchronisation: the same loop over thousands of steps beside it
+        lus = e["ms_per_step_long_run"] * 1e3
+        long_run = f" ({lus:.1f} µs = {8.0 * e['nnz'] / (lus * 1e-6) / 8e12 * 100:.1f} % over {e['long_run_steps']} steps)"
+    return f"| {key[0]} / {key[1]} | {fmt} | {kernel_us:.1f} µs = {pct(frac)} % | {step_us:.1f} µs = {pct(step)} %{long_run} | {pct(cold)} | {prof} | {traffic} | {parity} |"
 
 
 order = [("ogbl_ppa", "fixed"), ("transformer_50", "float_pob"), ("ogbn_products", "float_stall"), ("mouse_gene", "fixed"), ("ogbl_ppa_rmat", "fixed"),
