@@ -47,40 +47,60 @@ class PeerGatherError(RuntimeError):
 class PeerGather:
     """`buffers` gather buffers of world x chunk_words 32-bit words on this rank's device; slot r of every buffer belongs to rank r."""
 
-    def __init__(self, dist, rank, world, chunk_words, device_id, buffers=2):
+    def __init__(self, dist, rank, world, chunk_words, device_id, buffers=2, runtime=None):
         if chunk_words % 4:
             raise PeerGatherError("chunk_words must be a multiple of 4 (hs_push_result stores 16 bytes per lane)")
         if world - 1 > 8:
             raise PeerGatherError("hs_push_result takes at most 8 destinations")
-        self.rt, self.rank, self.world, self.chunk, self.device_id = _runtime(), rank, world, chunk_words, device_id
-        self._check(self.rt.hipSetDevice(device_id), "hipSetDevice")
+        self.rt, self.rank, self.world, self.chunk, self.device_id = runtime or _runtime(), rank, world, chunk_words, device_id      # (runtime: the tests' stand-in)
         self.bytes = world * chunk_words * 4
         self.mine, self.peers = [], []       # [buffer] -> own base pointer; [buffer][rank] -> that rank's base pointer as seen from here
-        handles = []
-        for _ in range(buffers):
-            p = C.c_void_p()
-            self._check(self.rt.hipMalloc(C.byref(p), self.bytes), "hipMalloc")
-            self._check(self.rt.hipMemset(p, 0, self.bytes), "hipMemset")
-            self.mine.append(p.value)
-            h = _IpcHandle()
-            self._check(self.rt.hipIpcGetMemHandle(C.byref(h), p), "hipIpcGetMemHandle")
-            handles.append(C.string_at(C.byref(h), HANDLE_BYTES))
-        everyone = [None] * world
-        dist.all_gather_object(everyone, handles)
         self._opened = []
-        for b in range(buffers):
-            row = []
-            for r in range(world):
-                if r == rank:
-                    row.append(self.mine[b])
-                    continue
-                h = _IpcHandle()
-                C.memmove(C.byref(h), everyone[r][b], HANDLE_BYTES)
+        # Set-up is COLLECTIVE-SAFE: a rank whose allocation / export / open fails still takes part in both object collectives and every
+        # rank raises together afterwards -- a rank that left early would leave the others waiting in a collective for ever (and with them
+        # the bench line this helper is only an extra of).
+        handles, err = [], None
+        try:
+            self._check(self.rt.hipSetDevice(device_id), "hipSetDevice")
+            for _ in range(buffers):
                 p = C.c_void_p()
-                self._check(self.rt.hipIpcOpenMemHandle(C.byref(p), h, LAZY_PEER_ACCESS), f"hipIpcOpenMemHandle(rank {r})")
-                self._opened.append(p.value)
-                row.append(p.value)
-            self.peers.append(row)
+                self._check(self.rt.hipMalloc(C.byref(p), self.bytes), "hipMalloc")
+                self.mine.append(p.value)
+                self._check(self.rt.hipMemset(p, 0, self.bytes), "hipMemset")
+                h = _IpcHandle()
+                self._check(self.rt.hipIpcGetMemHandle(C.byref(h), p), "hipIpcGetMemHandle")
+                handles.append(C.string_at(C.byref(h), HANDLE_BYTES))
+        except PeerGatherError as e:
+            err = f"rank {rank}: {e}"
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (handles, err))
+        self._raise_together([e for _, e in everyone])
+        try:
+            for b in range(buffers):
+                row = []
+                for r in range(world):
+                    if r == rank:
+                        row.append(self.mine[b])
+                        continue
+                    h = _IpcHandle()
+                    C.memmove(C.byref(h), everyone[r][0][b], HANDLE_BYTES)
+                    p = C.c_void_p()
+                    self._check(self.rt.hipIpcOpenMemHandle(C.byref(p), h, LAZY_PEER_ACCESS), f"hipIpcOpenMemHandle(rank {r})")
+                    self._opened.append(p.value)
+                    row.append(p.value)
+                self.peers.append(row)
+        except PeerGatherError as e:
+            err = f"rank {rank}: {e}"
+        opened = [None] * world
+        dist.all_gather_object(opened, err)
+        self._raise_together(opened)
+
+    def _raise_together(self, errors):
+        """every rank holds the same list: the first error anywhere ends the set-up on all of them"""
+        first = next((e for e in errors if e), None)
+        if first:
+            self.close()
+            raise PeerGatherError(first)
 
     def _check(self, rc, what):
         if rc != 0:

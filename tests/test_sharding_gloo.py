@@ -111,3 +111,70 @@ def test_cpp_and_python_row_splits_agree():
                 assert all(b % granule == 0 for b in got[1:-1] if b != rows)
                 if rows >= parts * granule:
                     assert all(b > a for a, b in zip(got, got[1:]))      # nobody is left without rows
+
+
+class _FakeHip:
+    """A stand-in for the HIP runtime of hisparse_amd/peer_gather.py (no GPU here): host buffers, handles = the buffer's address; rank
+    `fail_rank` cannot open its peers' handles (two GPUs without peer access)."""
+
+    def __init__(self, rank, fail_rank, fail_in):
+        import ctypes as C
+        self.C, self.rank, self.fail = C, rank, (rank == fail_rank, fail_in)
+        self.keep = []
+
+    def hipSetDevice(self, _):
+        return 0
+
+    def hipMalloc(self, pp, n):
+        buf = self.C.create_string_buffer(n)
+        self.keep.append(buf)
+        pp._obj.value = self.C.addressof(buf)
+        return 101 if self.fail == (True, "malloc") else 0
+
+    def hipMemset(self, *_):
+        return 0
+
+    def hipIpcGetMemHandle(self, ph, p):
+        return 0
+
+    def hipIpcOpenMemHandle(self, pp, h, flags):
+        pp._obj.value = 0x1000
+        return 17 if self.fail == (True, "open") else 0
+
+    def hipIpcCloseMemHandle(self, _):
+        return 0
+
+    def hipFree(self, _):
+        return 0
+
+    def hipGetErrorString(self, rc):
+        return f"fake error {rc}".encode()
+
+
+def _peer_setup_worker(rank, world, port, fail_in, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from hisparse_amd import peer_gather
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        pg = peer_gather.PeerGather(dist, rank, world, 64, device_id=0, runtime=_FakeHip(rank, 1 if fail_in else -1, fail_in))
+        outcome = f"ok {len(pg.targets(0))}"
+    except peer_gather.PeerGatherError as e:
+        outcome = f"error {e}"
+    dist.barrier()                       # every rank is still in step with the others, whatever happened
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(outcome)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_in", [None, "malloc", "open"])
+def test_peer_gather_setup_fails_on_every_rank_together(tmp_path, fail_in):
+    # bench_dist.py treats the peer-store gather as an extra: when ONE rank cannot allocate, export or open a buffer, every rank must leave
+    # the set-up with the same error -- a rank that raised before a collective used to leave the others waiting in it
+    import torch.multiprocessing as mp
+    mp.spawn(_peer_setup_worker, args=(2, _free_port(), fail_in, str(tmp_path)), nprocs=2, join=True)
+    got = [open(tmp_path / f"rank{r}.txt").read() for r in range(2)]
+    if fail_in is None:
+        assert got == ["ok 1", "ok 1"]
+    else:
+        assert all(g.startswith("error rank 1: ") for g in got) and got[0] == got[1]
