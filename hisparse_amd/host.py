@@ -18,7 +18,7 @@ IMPL_NAMES = {"fixed": IMPL_FIXED, "float_pob": IMPL_FLOAT_POB, "float_stall": I
 PACK_SIZE = 8
 NUM_HBM_CHANNELS = 16
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhisparse_host.so")
+_LIB_PATH = os.environ.get("HISPARSE_HOST_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhisparse_host.so")      # (the override: tools/sanitize/run.sh)
 
 
 class HostError(RuntimeError):
