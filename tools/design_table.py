@@ -49,7 +49,7 @@ order = [("ogbl_ppa", "fixed"), ("transformer_50", "float_pob"), ("ogbn_products
          ("pokec", "float_pob"), ("pokec", "float_stall"), ("ogbn_products", "float_pob")]
 table = [f"**Round 5** (`profiles/{tag}_bench_n1.json` + `profiles/{tag}_bench_details.json` = ONE default `bench.py --gpus 1 --steps 20 --warmup 5` run, the driver's command line, one box, "
          f"every row checked against the oracle in the same run; rocprofv3 column and HBM traffic: `profiles/{tag}_<config>_rocprofv3_summary.txt`, `profiles/hbm_traffic.json`, "
-         "another box of the same build — boxes differ by ± 2–3 %).  The first five rows are BASELINE.json's configurations (+ the R-MAT stand-in), the rest the reference's sweep `sw/bm.sh` in all numeric modes:",
+         "another box of the same build — boxes differ by ± 2–3 %; one box in ~45 ran everything 8–35 % slower, `profiles/r05_slow_box_note.txt`).  The first five rows are BASELINE.json's configurations (+ the R-MAT stand-in), the rest the reference's sweep `sw/bm.sh` in all numeric modes:",
          "",
          "| matrix / IMPL | image | kernel alone (`roofline.frac`) | whole step (`value`) | whole step, MALL-cold % | rocprofv3 kernel avg / steady | HBM traffic vs 8·nnz | parity |",
          "|---|---|---|---|---|---|---|---|"]
