@@ -15,7 +15,7 @@ HIPFLAGS  := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -ffp
 HOST_HDRS := $(wildcard include/hisparse/*.h) include/hisparse_host.h
 HIP_HDRS  := include/hisparse_hip.h $(wildcard $(CSRC)/*.h) include/hisparse/common.h
 
-.PHONY: all host hip cpu oracle benchmark clean prof
+.PHONY: all host hip cpu oracle benchmark clean prof variant
 all: host hip cpu oracle benchmark
 
 host: $(LIBDIR)/libhisparse_host.so
@@ -53,6 +53,17 @@ $(LIBDIR)/libhisparse_hip_prof.so: $(PROF_OBJS) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(PROF_OBJS) -pthread
 ifeq ($(HISPARSE_PROFILING),1)
 all: prof
+endif
+
+# An A/B variant of the product library: make variant NAME=<name> DEFS=-D<switch>=<value> -> libhisparse_hip_<name>.so
+# (tools select it with HISPARSE_HIP_LIB, like the profiling library)
+ifdef NAME
+VAR_OBJS := $(addprefix $(OBJDIR)/$(NAME)/,$(addsuffix .o,$(HIP_UNITS)))
+$(OBJDIR)/$(NAME)/%.o: $(CSRC)/% $(HIP_HDRS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -x hip -c -o $@ $<
+variant: $(VAR_OBJS) | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $(LIBDIR)/libhisparse_hip_$(NAME).so $(VAR_OBJS) -pthread
 endif
 
 # the same C-ABI on host threads for machines without a GPU: a separate library a driver links INSTEAD (never a fallback of the HIP one)

@@ -753,7 +753,9 @@ __global__ __launch_bounds__(kThreads) void spmv_rowblock_kernel(const uint8_t* 
         // Prologue.  (Measured in round 3, timeline build HISPARSE_ABLATE=512: 4.3 us pass between a workgroup's first wavefront
         // entering and this barrier, and most of that is the LAUNCH ramp -- the 16 wavefronts of a 1024-thread workgroup are started
         // 2 - 4 us apart, the loaders last -- not this code: letting the loaders DMA sub-tile 0 while only the consumers zero changed
-        // nothing, same box: ogbl-ppa 57.5 / 57.4 us, mouse_gene 38.5 / 38.2 us.)
+        // nothing, same box: ogbl-ppa 57.5 / 57.4 us, mouse_gene 38.5 / 38.2 us.  Round 5: the copy of sub-tile 0 by the FIRST 256 threads
+        // only, eight loads each -- the wavefronts that enter first -- is slower everywhere, +0.4 ... +1.1 us per step on eight
+        // configurations: profiles/r05_early_fill_ab.txt.)
         if (kOwner) {
             if (!(kAblate & 16)) for (uint32_t i = tid; i < nrows + kConsumerWaves; i += kThreads) reinterpret_cast<float*>(ys)[i] = 0.0f;
         } else
