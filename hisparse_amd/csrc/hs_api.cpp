@@ -148,7 +148,7 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 const char* const kOptionKeys[] = {
     "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "SPMM_VECTORS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
     "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS", "SWEEP",
-    "DELTA_DEAL", "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "BATCH_GRAPH", "CARRY_COMBINE",
+    "DELTA_DEAL", "POW2_SLICES", "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "BATCH_GRAPH", "CARRY_COMBINE",
 };
 
 void drop_batch_graph(hs_context* c) {

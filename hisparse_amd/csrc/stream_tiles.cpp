@@ -279,14 +279,18 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         const double sub_tiles = double(CP) * S;
         double best = 1e30;
         for (uint32_t cs = 1; cs <= kMaxColSlices; ++cs) {
-            // unforced: 1, 2, 4, 8 -- and everything in between for OWNER, where the x volume decides: ogbn-products runs 241 us in 5
-            // slices (102 ranges of 24 K rows, 2 blocks per workgroup) against 280 in 2 (127 ranges) and 275 in 4; ogbl-ppa gains
-            // 1 us of kernel in 5 and loses it in the combine pass, the R-MAT stand-in is 3 us slower
-            // (a matrix of at most sixteen sub-tiles: every count -- a slice per sub-tile (or two) is the plan without x refills and
+            // unforced: every count the cost model likes.  (Through round 4 only 1, 2, 4, 8 for matrices of more than sixteen sub-tiles -- everything
+            // in between for OWNER, where the x volume decides: ogbn-products runs 241 us in 5 slices (102 ranges of 24 K rows, 2 blocks per
+            // workgroup) against 280 in 2 (127 ranges) and 275 in 4 -- because five slices had measured as a wash on ogbl-ppa and 3 us slower on
+            // its R-MAT stand-in, a PAIRS image then.  Measured again in round 5 (profiles/r05_any_slice_count.txt, whole step, alternating):
+            // ogbl-ppa 55.2-56.0 us in 4 slices, 54.0-54.5 in 5 (51 row ranges x 5 = 255 blocks: fewer, longer units); the R-MAT stand-in
+            // 58.4-59.0 -> 55.2-55.4; hollywood keeps 2, its slabs and ogbl-ppa's keep 8 (a 2-way slab takes 5 or 7: +-1 %).
+            // HISPARSE_POW2_SLICES=1 brings the old rule back for the A/B.)
+            // (a matrix of at most sixteen sub-tiles: a slice per sub-tile (or two) is the plan without x refills and
             // unit barriers (gplus, 14 sub-tiles: 23.7 us in 7 slices, 26.1 in 8), and a power of two above the sub-tile count would leave
             // whole slices, i.e. workgroups, empty)
             const uint32_t live_tiles = (num_cols + kSubTileCols - 1) / kSubTileCols;
-            if (force_slices ? uint32_t(std::atoi(force_slices)) != cs : (!owner && (cs & (cs - 1)) != 0 && live_tiles > 2 * kMaxColSlices)) continue;
+            if (force_slices ? uint32_t(std::atoi(force_slices)) != cs : (!owner && (cs & (cs - 1)) != 0 && live_tiles > 2 * kMaxColSlices && env_switch("HISPARSE_POW2_SLICES"))) continue;
             if (cs > 1 && uint64_t(CP) * S < cs) continue;                                    // fewer sub-tiles than slices
             if (!force_slices && !owner && live_tiles <= kMaxColSlices && cs > live_tiles) continue;
             for (const Shape& shape : (cs > 1 || owner) ? std::vector<Shape>(sliced, sliced + 2) : std::vector<Shape>(whole, whole + 1)) {
@@ -336,10 +340,13 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                 // enough for the carried combine (hs_api.cpp; stream_tiles.h: kCarryMaxImageBytes)
                 const bool carried = double(out.nnz) * 8.1 < double(kCarryMaxImageBytes);
                 const double combine_us = cs > 1 ? (carried ? 1.0 : 3.5) + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
-                const double cost = volume_us + latency_us + conflict_us + 8.0 * blocks_per_wg + combine_us;
+                // workgroup slots that get no block (7 slices x 36 row ranges = 252 blocks on 256 workgroups): the stream they would have taken
+                // is the others' -- what tells 7 slices from 8 on mid-size wide matrices (profiles/r05_any_slice_count.txt)
+                const double idle_us = double(out.nnz) * 8.0 / 6.2e6 * (std::ceil(blocks_per_wg) / std::max(1e-9, blocks_per_wg) - 1.0);
+                const double cost = volume_us + latency_us + conflict_us + 8.0 * blocks_per_wg + combine_us + idle_us;
                 if (detail::env_switch("HISPARSE_PLAN_DEBUG"))
-                    std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f conflicts %.1f blocks/wg %.1f combine %.1f => %.1f us\n", cs, cap, ring, ranges,
-                                 volume_us, latency_us, conflict_us, blocks_per_wg, combine_us, cost);
+                    std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f conflicts %.1f blocks/wg %.2f idle %.2f combine %.1f => %.2f us\n", cs, cap, ring, ranges,
+                                 volume_us, latency_us, conflict_us, blocks_per_wg, idle_us, combine_us, cost);
                 if (cost < best) { best = cost; slices = cs; max_rows = cap; }
             }
         }

@@ -147,7 +147,7 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
 /* ---- tuning options (EXTENSION) ----------------------------------------------------------------------
  * The library's configuration surface.  key: the name of a tuning switch, case-insensitive, with or without the "HISPARSE_" prefix of its
  * environment spelling -- plan-time keys (take effect at the NEXT hs_load_matrix / hs_load_matrix_csr of this context): stream_format
- * (pairs|delta|owner|owner24|sweep|bitmap), col_slices, max_rows, cross_partitions (0: row blocks end at the reference's row-partition borders), spmm_vectors (4: plan the image for the four-column SpMM kernel, see hs_spmm), row_runs, delta_deal (wave: the dealing of DELTA runs of rounds 1-4), aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
+ * (pairs|delta|owner|owner24|sweep|bitmap), col_slices, max_rows, cross_partitions (0: row blocks end at the reference's row-partition borders), spmm_vectors (4: plan the image for the four-column SpMM kernel, see hs_spmm), row_runs, delta_deal (wave: the dealing of DELTA runs of rounds 1-4), pow2_slices (1: column-slice counts 1, 2, 4, 8 only for matrices of more than sixteen sub-tiles, the rule of rounds 1-4), aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
  * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), sweep (0|1: the
  * column-ordered format of very sparse matrices), plan_debug; call-time keys: spmm_fused, spmm_mfma,
  * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph, batch_graph (hs_run_batch); carry_combine (0|1, plan-time: see hs_run).  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
