@@ -1109,7 +1109,7 @@ bool GpuTiler::bitmap_emit(uint32_t slices, uint32_t GR, const std::vector<uint3
 // ---- SWEEP (sweep_tiles.cpp; kernel: spmv_sweep.hip) ---------------------------------------------------------------------------
 namespace {
 
-struct SweepSlices { uint32_t n; uint32_t col[kMaxColSlices + 1]; };
+struct SweepSlices { uint32_t n; uint32_t col[kMaxSweepSlices + 1]; };
 
 __global__ __launch_bounds__(256) void sweep_lines_kernel(ElementSource src, uint32_t* __restrict__ line_nnz, uint32_t* err) {
     visit_elements(src, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, err, [&](uint32_t, uint32_t col, uint32_t) { atomicAdd(line_nnz + col / kSweepColAlign, 1u); });

@@ -876,7 +876,7 @@ __device__ __forceinline__ uint32_t feedback_word(uint32_t y, uint32_t scale, ui
 
 // x_fb != nullptr: also feeds the combined rows below n_fb back into x (one launch less per iteration of hs_iterate).
 // Four rows per thread (row counts, partition bounds and n_fb are multiples of 8): 16-byte loads and stores.
-// kSlices: the number of partial vectors (2 .. kMaxColSlices), a template parameter so that all kSlices loads of a thread are in flight
+// kSlices: the number of partial vectors (2 .. kMaxSweepSlices), a template parameter so that all kSlices loads of a thread are in flight
 // together -- with a run-time loop they went out one memory round trip after the other (4.9 us for ogbl-ppa's 4 x 2.3 MB).
 template <bool kFloat, int kSlices>
 __global__ __launch_bounds__(256) void combine_slices_kernel(const uint32_t* __restrict__ partial, uint32_t* __restrict__ y,
@@ -1319,11 +1319,11 @@ hipError_t launch_combine_slices(bool is_float, const uint32_t* partial, uint32_
         if (is_float) hipLaunchKernelGGL((combine_slices_kernel<true, N>), grid, block, 0, stream, partial, y, num_rows, row_lo, row_hi, x_fb, n_fb, scale, shift); \
         else hipLaunchKernelGGL((combine_slices_kernel<false, N>), grid, block, 0, stream, partial, y, num_rows, row_lo, row_hi, x_fb, n_fb, scale, shift);         \
         break;
-        X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+        X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 #undef X
         default: return hipErrorInvalidValue;
     }
-    static_assert(kMaxColSlices == 8, "combine_slices_kernel is instantiated for 2 .. 8 slices");
+    static_assert(kMaxColSlices <= 16 && kMaxSweepSlices == 16, "combine_slices_kernel is instantiated for 2 .. 16 slices");
     return hipGetLastError();
 }
 

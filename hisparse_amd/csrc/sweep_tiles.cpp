@@ -59,13 +59,17 @@ double sweep_plan(const Layout& L, uint64_t nnz, uint32_t max_workgroups, uint32
     double best = 1e30;
     slices = 1;
     want_ranges = 1;
-    for (uint32_t cs = 1; cs <= std::min<uint32_t>(kMaxColSlices, std::max<uint32_t>(1, lines)); ++cs) {
+    for (uint32_t cs = 1; cs <= std::min<uint32_t>(kMaxSweepSlices, std::max<uint32_t>(1, lines)); ++cs) {
         if (force_slices && uint32_t(std::atoi(force_slices)) != cs) continue;
         if (uint64_t(cs) * num_rows > 0xffffffffull) continue;      // Block::out_offset is a 32-bit word offset
         const uint64_t per_round = std::max<uint32_t>(1, G / cs);
         const uint64_t rounds = std::max<uint64_t>(1, (by_cap + per_round - 1) / per_round);
         const uint64_t ranges = std::min<uint64_t>(per_round * rounds, std::max<uint64_t>(by_cap, std::max<uint64_t>(1, nnz / 4096)));
         const double blocks = double(ranges) * cs, blocks_per_wg = std::ceil(blocks / G);
+        // more than eight slices (round 5): measured on one rank's slab of an 8-way split (profiles/r05_sweep_16_slices.txt) -- ogbn-products
+        // (60 K elements per block) 46.2 -> 43.6 us in 16 slices, pokec (15 K per block) 22.2 -> 23.3: with so little in a block the x lines
+        // it saves are not what the block waits for, and every slice is another set of partial rows.  So only where a block holds >= 32 K.
+        if (cs > kMaxColSlices && !force_slices && double(nnz) / blocks < 32768.0) continue;
         const double block_ns = double(nnz) / blocks * kSweepNsPerElement + std::max(double(lines) / cs * kSweepNsPerLine, double(nnz) / blocks * kSweepGatherNsPerElement);
         const double combine_us = double(num_rows) * 4.0 * cs / 4e6 + (cs > 1 ? 2.0 + double(num_rows) * 4.0 * (cs + 1) / 8e6 : 0.0);
         const double cost = blocks_per_wg * (block_ns * 1e-3 + kSweepBlockUs) + combine_us;

@@ -87,6 +87,39 @@ def test_partition_loop_and_block_chains(impl, slices, monkeypatch):
         _check(impl, eng.read_result(), want)
 
 
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("slices", ["11", "16"])
+def test_more_than_eight_column_slices(impl, slices, monkeypatch):
+    # round 5: SWEEP images may be cut into up to 16 column slices (a short, wide matrix -- one rank's slab -- wants few row ranges, each of
+    # which sweeps all of x, and many slices): the kernel's partial rows, the combine pass over 11 / 16 of them, the carried combine
+    # (bursts of launches), the device-built image against the host builder's
+    monkeypatch.setenv("HISPARSE_SWEEP", "1")
+    monkeypatch.setenv("HISPARSE_COL_SLICES", slices)
+    csr = host.CSRMatrix.generate("powerlaw", 30000, 400000, a=1.2e6, b=0.4, c=1.0 if impl == 0 else 2.0, seed=31 + impl)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 9, impl))
+    want = _oracle(cp, impl, xw)
+    for carry in ("0", "1"):
+        monkeypatch.setenv("HISPARSE_CARRY_COMBINE", carry)
+        with device.SpmvEngine(impl) as eng:
+            eng.load_matrix(cp)
+            st = eng.stats()
+            assert device.STREAM_FORMATS[st["stream_format"]] == "sweep" and st["col_slices"] == int(slices)
+            eng.load_vector(xw)
+            eng.run()
+            _check(impl, eng.read_result(), want)
+            eng.run_batch(3)                                    # three consecutive launches: the carried combine when it is on
+            _check(impl, eng.read_result(), want)
+            if carry == "0":
+                built = eng.read_tiles()
+                monkeypatch.setenv("HISPARSE_RETILE", "host")
+                with device.SpmvEngine(impl) as host_built:
+                    host_built.load_matrix(cp)
+                    ref = host_built.read_tiles()
+                monkeypatch.delenv("HISPARSE_RETILE")
+                assert built["image"].tobytes() == ref["image"].tobytes() and built["blocks"].tobytes() == ref["blocks"].tobytes()
+
+
 def test_non_finite_x_reaches_only_the_rows_that_hold_the_column(monkeypatch):
     # padding slots carry value 0 at the block's spare row and gather a real x word: 0 x inf = NaN must never land in a real row
     monkeypatch.setenv("HISPARSE_SWEEP", "1")

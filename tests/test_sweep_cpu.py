@@ -27,7 +27,7 @@ def forced(monkeypatch):
 
 
 @pytest.mark.parametrize("impl", [0, 1, 2])
-@pytest.mark.parametrize("rows,cols,nnz,wgs,slices", [(60000, 90000, 200000, 16, None), (30000, 200000, 150000, 8, 4), (9000, 70000, 20000, 3, 2),
+@pytest.mark.parametrize("rows,cols,nnz,wgs,slices", [(60000, 90000, 200000, 16, None), (30000, 200000, 150000, 8, 4), (9000, 70000, 20000, 3, 2), (20000, 400000, 300000, 24, 12), (8000, 300000, 100000, 16, 16),
                                                       (300, 50, 700, 4, None), (1000, 1000, 10000, 256, None)])
 def test_sweep_structure_and_parity(impl, rows, cols, nnz, wgs, slices, monkeypatch):
     if slices:
