@@ -278,7 +278,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         const Shape whole[1] = {{max_block_rows(false), kMaxXBuffers}};                                       // 4095 rows, ring 4
         const double sub_tiles = double(CP) * S;
         double best = 1e30;
-        for (uint32_t cs = 1; cs <= kMaxColSlices; ++cs) {
+        for (uint32_t cs = 1; cs <= (force_slices ? kMaxForcedColSlices : kMaxColSlices); ++cs) {
             // unforced: every count the cost model likes.  (Through round 4 only 1, 2, 4, 8 for matrices of more than sixteen sub-tiles -- everything
             // in between for OWNER, where the x volume decides: ogbn-products runs 241 us in 5 slices (102 ranges of 24 K rows, 2 blocks per
             // workgroup) against 280 in 2 (127 ranges) and 275 in 4 -- because five slices had measured as a wash on ogbl-ppa and 3 us slower on
@@ -427,8 +427,8 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         }
         std::iota(by_weight.begin(), by_weight.end(), 0u);
         std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t x, uint32_t y) { return tile_nnz[x] > tile_nnz[y]; });
-        uint64_t slice_load[kMaxColSlices] = {0};
-        uint32_t slice_tiles[kMaxColSlices] = {0};
+        uint64_t slice_load[kMaxForcedColSlices] = {0};
+        uint32_t slice_tiles[kMaxForcedColSlices] = {0};
         for (uint32_t k : by_weight) {
             uint32_t best = 0;
             for (uint32_t c = 1; c < slices; ++c)

@@ -83,6 +83,7 @@ constexpr uint32_t kMinXBuffers = 2;
 constexpr uint32_t kAccumulatorBytes = 8;
 constexpr uint32_t max_block_rows(bool sliced) { return (sliced ? 96u : 32u) * 1024u / kAccumulatorBytes - 1u; }
 constexpr uint32_t kMaxColSlices = 8;
+constexpr uint32_t kMaxForcedColSlices = 16;   // HISPARSE_COL_SLICES / col_slices may ask the row-block planner for up to this many (the combine pass is instantiated for 2 .. 16)
 constexpr uint32_t kMaxSweepSlices = 16;      // SWEEP images (round 5): a short, wide matrix -- one rank's slab -- wants few row ranges (every range sweeps all of x) and many slices
 // Column-sliced plans whose image stays below this carry the combine pass of a step into the next step's kernel (hs_api.cpp: one launch per
 // step in a run of hs_run calls); the planner prices the combine pass of such a plan at ~1 us instead of a launch of its own (3.5 us).

@@ -133,6 +133,22 @@ def test_column_slices(impl, slices, monkeypatch):
     _run_case(impl, m, vb=v, ob=o, skip=True, seed=17)
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("slices", [12, 16])
+def test_column_slices_beyond_eight(impl, slices, monkeypatch):
+    # a forced plan of more than eight column slices (stream_tiles.h: kMaxForcedColSlices; the planner itself stops at eight for row-block
+    # images): 18 sub-tiles of x, the combine pass instantiated for up to 16 partial vectors
+    monkeypatch.setenv("HISPARSE_COL_SLICES", str(slices))
+    csr = host.CSRMatrix.generate("powerlaw", 20000, 140000, a=1200000, b=0.4, c=1.0 if impl == 0 else 2.0, seed=19)
+    ip, ix, dv = csr.arrays()
+    if impl != 0:
+        dv = (dv - 1.0).astype(np.float32)
+    import scipy.sparse as sp
+    m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(20000, 140000))
+    v, o = host.default_banks(impl)
+    _run_case(impl, m, vb=v, ob=o, skip=True, seed=19)
+
+
 def test_repeated_runs_stay_exact():
     # soak: the hand-counted waits of the stream ring must hold on every launch, not just most (a compiler-inserted
     # register copy ahead of a wait once made one record in a few million wrong, on some launches only)
