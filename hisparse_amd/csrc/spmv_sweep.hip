@@ -69,10 +69,10 @@ __device__ __forceinline__ void sweep_issue_gather(const uint8_t* x, uint32_t by
     asm volatile("s_nop 4\n\tglobal_load_dword a[%0], %1, %2" ::"n"(2 * kSweepDepth + K), "v"(byte_off), "s"(x) : "memory", HS_SWEEP_RING);
 }
 // one counted wait: chunk slot K (issued kSweepDepth steps ago) AND the gather issued just before it have landed
-template <int K>
+template <int K, bool kNoGather = false>
 __device__ __forceinline__ void sweep_take(uint32_t& value, uint32_t& where, uint32_t& xv) {
     asm volatile("s_waitcnt vmcnt(%6)\n\tv_accvgpr_read_b32 %0, a[%3]\n\tv_accvgpr_read_b32 %1, a[%4]\n\tv_accvgpr_read_b32 %2, a[%5]"
-                 : "=v"(value), "=v"(where), "=v"(xv) : "n"(2 * K), "n"(2 * K + 1), "n"(2 * kSweepDepth + K), "n"(2 * (kSweepDepth - 1)) : "memory");
+                 : "=v"(value), "=v"(where), "=v"(xv) : "n"(2 * K), "n"(2 * K + 1), "n"(2 * kSweepDepth + K), "n"((kNoGather ? 1 : 2) * (kSweepDepth - 1)) : "memory");
 }
 
 // Row accumulators.  Float: doubles, ds_add_f64 (ds_add_f32 runs at a ninth of its rate on this part, stream_tiles.h) -- 8 bytes per row.
@@ -127,31 +127,74 @@ struct SweepRows<false> {
 // Waiting until 14 loads are left means chunk(s) and the gather before it have landed: add the element taken at step s - 8 (its x word
 // has just arrived), keep chunk(s)'s element, ask for ITS x word and for chunk(s + 8).
 // kAblate (libhisparse_hip_prof.so only, WRONG results): 1 = no LDS accumulation, 2 = the gather reads one line near the chunk's base
-// instead of the elements' columns (keeps the wait count)
+// instead of the elements' columns (keeps the wait count), 4 = no zeroing of the accumulators and no result store (the block's prologue and
+// epilogue), 8 = no gather at all (one load per step, the wait count halved)
 template <bool kFloat, int kAblate, int K>
 __device__ __forceinline__ void sweep_step(SweepLane& st, const uint8_t* stream, const uint8_t* x, uint32_t s, uint32_t steps, uint32_t lane_off, uint32_t base,
                                            uint8_t* ys, uint32_t nrows) {
     uint32_t value, where, xv;
-    sweep_take<K>(value, where, xv);
+    sweep_take<K, (kAblate & 8) != 0>(value, where, xv);
     if (!(kAblate & 1)) SweepRows<kFloat>::add(ys, nrows, st, st.row[K], st.value[K], xv);      // (the first eight steps add 0 x x[..] to the spare accumulator)
     else asm volatile("" ::"v"(xv), "v"(st.value[K]), "v"(st.row[K]));
     st.value[K] = value;
     st.row[K] = where >> 16;
-    if (!(kAblate & 2)) sweep_issue_gather<K>(x, (base + (where & 0xffffu)) * 4u);
+    if (kAblate & 8) {}
+    else if (!(kAblate & 2)) sweep_issue_gather<K>(x, (base + (where & 0xffffu)) * 4u);
+    else if (kAblate & 16) sweep_issue_gather<K>(x, lane_off >> 1 & 127u);       // (16, with 2: always the same line of x)
     else sweep_issue_gather<K>(x, (base * 4u & ~127u) + (lane_off >> 1 & 127u));
     sweep_issue_chunk<K>(stream, min(s + kSweepDepth, steps - 1) * (kSweepWaves * kChunkBytes) + lane_off);
 }
 
 // prime, in the steady-state order: gather K (a dummy: its word is multiplied by 0), then chunk K
-template <int... Ks>
+template <bool kNoGather = false, int... Ks>
 __device__ __forceinline__ void sweep_prime(std::integer_sequence<int, Ks...>, const uint8_t* stream, const uint8_t* x, uint32_t pad_col, uint32_t steps, uint32_t lane_off) {
-    ((sweep_issue_gather<Ks>(x, pad_col * 4u), sweep_issue_chunk<Ks>(stream, min(uint32_t(Ks), steps - 1) * (kSweepWaves * kChunkBytes) + lane_off)), ...);
+    (((kNoGather ? (void)0 : sweep_issue_gather<Ks>(x, pad_col * 4u)), sweep_issue_chunk<Ks>(stream, min(uint32_t(Ks), steps - 1) * (kSweepWaves * kChunkBytes) + lane_off)), ...);
 }
 // one round of eight steps; steps at or beyond `end` are skipped (wave-uniform)
 template <bool kFloat, int kAblate, int... Ks>
 __device__ __forceinline__ void sweep_round(std::integer_sequence<int, Ks...>, SweepLane& st, const uint8_t* stream, const uint8_t* x, uint32_t s0, uint32_t steps,
                                             uint32_t end, uint32_t lane_off, const uint32_t (&b)[kSweepDepth], uint8_t* ys, uint32_t nrows) {
     ((s0 + Ks < end ? sweep_step<kFloat, kAblate, Ks>(st, stream, x, s0 + Ks, steps, lane_off, b[Ks], ys, nrows) : (void)0), ...);
+}
+
+// A block's prologue and epilogue.  Up to 39 716 rows on 512 threads is ~78 trips per thread: one ds_write_b32 per trip, and -- in the epilogue --
+// a read of the row's carry word, a branch, a read of its sum and a 4-byte store per trip, each waiting for the one before, measured 9-10 us of
+// pokec's 67 (profiles/r05_sweep_ablate.txt).  Now 16-byte LDS writes, and eight rows' reads in flight per thread before the first of their stores.
+__device__ __forceinline__ void sweep_zero_rows(uint8_t* ys, uint32_t words, uint32_t tid) {
+    uint4* q = reinterpret_cast<uint4*>(ys);
+    const uint32_t quads = words / 4u;
+    for (uint32_t i = tid; i < quads; i += kSweepThreads) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < (words & 3u)) reinterpret_cast<uint32_t*>(ys)[quads * 4u + tid] = 0u;
+}
+template <bool kFloat>
+__device__ __forceinline__ void sweep_store_rows(const uint8_t* ys, uint32_t nrows, uint32_t* __restrict__ out, uint32_t tid) {
+    constexpr uint32_t kRowsInFlight = 8;
+    const uint32_t* acc = reinterpret_cast<const uint32_t*>(ys);
+    for (uint32_t base = tid; base < nrows; base += kRowsInFlight * kSweepThreads) {
+        if constexpr (kFloat) {
+            double v[kRowsInFlight];
+#pragma unroll
+            for (uint32_t k = 0; k < kRowsInFlight; ++k) v[k] = reinterpret_cast<const double*>(ys)[min(base + k * kSweepThreads, nrows)];      // (row nrows: the spare accumulator)
+#pragma unroll
+            for (uint32_t k = 0; k < kRowsInFlight; ++k)
+                if (base + k * kSweepThreads < nrows) out[base + k * kSweepThreads] = __float_as_uint(static_cast<float>(v[k]));
+        } else {
+            uint32_t sum[kRowsInFlight], flags[kRowsInFlight];
+            const uint32_t flag0 = SweepRows<false>::flag_word0(nrows);
+#pragma unroll
+            for (uint32_t k = 0; k < kRowsInFlight; ++k) {
+                const uint32_t row = min(base + k * kSweepThreads, nrows);
+                sum[k] = acc[row];
+                flags[k] = acc[flag0 + (row >> 5)];
+            }
+            asm volatile("" ::: "memory");      // all sixteen reads are issued before the first result is looked at
+#pragma unroll
+            for (uint32_t k = 0; k < kRowsInFlight; ++k) {
+                const uint32_t row = base + k * kSweepThreads;
+                if (row < nrows) out[row] = ((flags[k] >> (row & 31u)) & 1u) ? 0xffffffffu : sum[k];      // AP_SAT (pe.h:72), as SweepRows<false>::finish
+            }
+        }
+    }
 }
 
 template <bool kFloat, int kAblate>
@@ -184,10 +227,10 @@ __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t
         SweepLane st;
 #pragma unroll
         for (int k = 0; k < kSweepDepth; ++k) { st.value[k] = 0; st.row[k] = nrows; }
-        if (steps) sweep_prime(std::make_integer_sequence<int, kSweepDepth>(), stream, xs, pad_col, steps, lane_off);
+        if (steps) sweep_prime<(kAblate & 8) != 0>(std::make_integer_sequence<int, kSweepDepth>(), stream, xs, pad_col, steps, lane_off);
         if (!first_block) __syncthreads();                        // the previous block's store has read the accumulators
         first_block = false;
-        for (uint32_t i = tid, n = R::lds_words(nrows); i < n; i += kSweepThreads) reinterpret_cast<uint32_t*>(ys)[i] = 0;
+        if (!(kAblate & 4)) sweep_zero_rows(ys, R::lds_words(nrows), tid);
         __syncthreads();
         if (steps) {
             const uint32_t last = steps - 1;
@@ -212,7 +255,7 @@ __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t
         const uint32_t flushed = atomicOr(reinterpret_cast<uint32_t*>(ys) + R::lds_words(nrows) - 1, 0u);
         asm volatile("" ::"v"(flushed));
         __syncthreads();
-        for (uint32_t i = tid; i < nrows; i += kSweepThreads) out[out0 + i] = R::finish(ys, nrows, i);
+        if (!(kAblate & 4)) sweep_store_rows<kFloat>(ys, nrows, out + out0, tid);
         if (!next) break;
     }
 }
@@ -225,7 +268,7 @@ uint32_t spmv_sweep_lds_bytes(uint32_t max_block_rows, bool is_float) {
 }
 
 #ifdef HISPARSE_PROFILING
-#define HS_FOR_EACH_SWEEP_VARIANT(X) X(0) X(1) X(2) X(3)
+#define HS_FOR_EACH_SWEEP_VARIANT(X) X(0) X(1) X(2) X(3) X(4) X(7) X(9) X(13) X(18) X(23)
 #else
 #define HS_FOR_EACH_SWEEP_VARIANT(X) X(0)
 #endif
