@@ -8,8 +8,9 @@
 //   * the block's elements come in (column, row) order, chunk k to wavefront k % 8 as its step k / 8: the 8 wavefronts (512 threads; 16 were
 //     measured 4 % slower on pokec, 4 much slower in fixed point: profiles/r04_sweep_waves.txt) move over the
 //     block's column slice together, once, and the 64 lanes of one gather touch a handful of 128-byte lines;
-//   * per wavefront EIGHT 512-byte chunks and EIGHT gathers are in flight, both in accumulator registers behind ONE counted wait per step:
-//     the gather for the chunk taken at step s is issued just before the load of chunk s + 8 (vmcnt retires in order), see sweep_step();
+//   * per wavefront FOUR 512-byte chunks and FOUR gathers are in flight (kSweepDepth; eight of each until round 5 -- see HS_SWEEP_DEPTH below), both in
+//     accumulator registers behind ONE counted wait per step: the gather for the chunk taken at step s is issued just before the load of chunk
+//     s + kSweepDepth (vmcnt retires in order), see sweep_step();
 //   * products go to LDS accumulators with atomics (any lane may hit any row): float -- double sums of the fp32 products (ds_add_f64), rounded
 //     once; fixed point -- a wrapping 32-bit sum of the rounded Q8.24 products (ds_add_rtn_u32) plus one carry bit per row, i.e. exactly the
 //     saturating sum (SweepRows below) -- the arithmetic of the other formats, bit for bit in fixed point;
@@ -30,7 +31,10 @@ namespace {
 
 constexpr int kSweepThreads = kSweepWaves * kWaveLanes;
 #ifndef HS_SWEEP_DEPTH
-#define HS_SWEEP_DEPTH 8            // (4, 6, 12 and 16 were measured too: -DHS_SWEEP_DEPTH=..., tools/history/r04/sweep_depth.sh, profiles/r04_sweep_ring_depth.txt)
+#define HS_SWEEP_DEPTH 4            // round 5, measured again on the kernel alone (pokec, fixed / float_pob, profiles/r05_sweep_ring_depth.txt): 2: 83.6 / 78.0 us,
+                                    // 3: 65.4 / 69.2, 4: 61.4 / 70.5, 6: 64.2 / 71.7, 8: 64.6 / 74.1, 12: 68.2 / 74.6, 16: 70.5 / 77.9 -- and 16 wavefronts x 2 deep = 8 x 4
+                                    // deep (61.2 / 70.4): what counts is 16 KB of stream in flight per CU, beyond it the gathers' lines of x lose the L1.
+                                    // (round 4 had read "flat from 4 to 8" on whole steps of the 8-byte-accumulator kernel: profiles/r04_sweep_ring_depth.txt)
 #endif
 constexpr int kSweepDepth = HS_SWEEP_DEPTH;      // chunks (and gathers) in flight per wavefront
 
@@ -45,7 +49,11 @@ __device__ __forceinline__ const uint8_t* sweep_scalar_pointer(const void* p) {
 // in this kernel; every asm statement that issues into the ring names all of them as clobbered, so nothing else is scheduled across.
 #define HS_SWEEP_RING8 "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", \
                        "a18", "a19", "a20", "a21", "a22", "a23"
-#if HS_SWEEP_DEPTH == 4
+#if HS_SWEEP_DEPTH == 2
+#define HS_SWEEP_RING "a0", "a1", "a2", "a3", "a4", "a5"
+#elif HS_SWEEP_DEPTH == 3
+#define HS_SWEEP_RING "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8"
+#elif HS_SWEEP_DEPTH == 4
 #define HS_SWEEP_RING "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11"
 #elif HS_SWEEP_DEPTH == 6
 #define HS_SWEEP_RING "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17"
@@ -57,7 +65,7 @@ __device__ __forceinline__ const uint8_t* sweep_scalar_pointer(const void* p) {
 #define HS_SWEEP_RING HS_SWEEP_RING8, "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", \
                       "a42", "a43", "a44", "a45", "a46", "a47"
 #else
-#error "HS_SWEEP_DEPTH must be 4, 6, 8, 12 or 16"
+#error "HS_SWEEP_DEPTH must be 2, 3, 4, 6, 8, 12 or 16"
 #endif
 
 template <int K>
@@ -123,9 +131,9 @@ struct SweepRows<false> {
 };
 
 
-// Step s of a wavefront (ring slot K = s % 8).  In flight on entry, oldest first: gather(s - 8), chunk(s), gather(s - 7), chunk(s + 1), ...
-// Waiting until 14 loads are left means chunk(s) and the gather before it have landed: add the element taken at step s - 8 (its x word
-// has just arrived), keep chunk(s)'s element, ask for ITS x word and for chunk(s + 8).
+// Step s of a wavefront (ring slot K = s % D, D = kSweepDepth).  In flight on entry, oldest first: gather(s - D), chunk(s), gather(s - D + 1), chunk(s + 1), ...
+// Waiting until 2 (D - 1) loads are left means chunk(s) and the gather before it have landed: add the element taken at step s - D (its x word
+// has just arrived), keep chunk(s)'s element, ask for ITS x word and for chunk(s + D).
 // kAblate (libhisparse_hip_prof.so only, WRONG results): 1 = no LDS accumulation, 2 = the gather reads one line near the chunk's base
 // instead of the elements' columns (keeps the wait count), 4 = no zeroing of the accumulators and no result store (the block's prologue and
 // epilogue), 8 = no gather at all (one load per step, the wait count halved)
