@@ -25,7 +25,11 @@ namespace {
 
 constexpr int kVecs = 4;
 constexpr int kThreads = kSweepWaves * kWaveLanes;
-constexpr int kDepth = 8;
+#ifndef HS_SPMM_DEPTH
+#define HS_SPMM_DEPTH 3      // round 5 (profiles/r05_sweep_ring_depth.txt), k = 16, us per SpMM, ogbl-ppa / pokec: depth 8: 600 / 991, 6: 573 / 965, 4: 566 / 947,
+#endif                       // 3: 544 / 933, 2: 588 / 902 -- as in spmv_sweep.hip, more in flight costs the gathers their L1 lines
+static_assert(HS_SPMM_DEPTH >= 2 && HS_SPMM_DEPTH <= 8, "the ring's register numbers hold up to eight slots");
+constexpr int kDepth = HS_SPMM_DEPTH;      // chunks (and 16-byte gathers) in flight per wavefront; the ring's register numbers below allow up to 8
 
 #define HS_SPMM_RING "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", \
                      "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42",   \

@@ -44,7 +44,10 @@ namespace {
 
 constexpr int kThreads = kWaveLanes * kWavesPerWorkgroup;       // 1024
 constexpr int kLightThreads = 256;                               // the LIGHT kernel's workgroup (up to four per CU)
-constexpr int kLightBatch = 8;                                   // chunks in flight per wavefront
+#ifndef HS_LIGHT_BATCH
+#define HS_LIGHT_BATCH 4      // round 5 (profiles/r05_sweep_ring_depth.txt): 16: 9.4 us, 8: 5.9-6.1, 4: 5.65, 3: 5.7, 2: 5.8 on transformer-95; the same layer at 10 % density
+#endif                        // (LIGHT forced) 11.8 / 8.5-9.1 / 7.35 / 7.6 / 8.0 -- fewer chunks in flight leave the gathered lines of x in the L1
+constexpr int kLightBatch = HS_LIGHT_BATCH;                      // chunks in flight per wavefront
 constexpr uint32_t kBufBytes = kSubTileCols * 4u;               // one x buffer of the LDS ring (32 KiB)
 
 // Copy one x sub-tile into an LDS buffer with kStride cooperating threads (t = 0 .. kStride-1).
