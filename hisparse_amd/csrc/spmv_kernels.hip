@@ -936,7 +936,7 @@ __global__ __launch_bounds__(256) void push_result_kernel(const uint32_t* __rest
 // the whole vector sits in L2, and a column-sliced plan pays a second launch for the combine pass -- 10-16 us for 1-4 us of bytes.  This
 // kernel runs the SAME PAIRS image (stream_tiles.h: chunks of 64 x { value word, local_row << 16 | local_col }, stored block by block in
 // dealing order, i.e. the chunks of a block are contiguous and unit by unit) with
-//   * 256-thread workgroups, up to six per CU, every wavefront a consumer of a CONSECUTIVE quarter of the block's chunks, eight in flight;
+//   * 256-thread workgroups, up to six per CU, every wavefront a consumer of a CONSECUTIVE quarter of the block's chunks, kLightBatch (four) in flight;
 //     a lane therefore walks consecutive sorted elements and sums in a register while its row stays the same;
 //   * no x ring, no loader wavefronts, no unit barriers: x[col0(unit) + local_col] is a plain gather (the vector is L2-resident at this
 //     size); a unit is only the place where col0 changes, found per chunk from the block's (<= kLightMaxUnits) unit ends held in registers;
