@@ -68,9 +68,12 @@ __device__ __forceinline__ const uint8_t* sweep_scalar_pointer(const void* p) {
 #error "HS_SWEEP_DEPTH must be 2, 3, 4, 6, 8, 12 or 16"
 #endif
 
+#ifndef HS_SWEEP_STREAM_POLICY
+#define HS_SWEEP_STREAM_POLICY "nt"      // cache-policy bits of the stream loads (A/B builds: -DHS_SWEEP_STREAM_POLICY='"sc1 nt"' ...)
+#endif
 template <int K>
 __device__ __forceinline__ void sweep_issue_chunk(const uint8_t* base, uint32_t off) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %2, %3 nt" ::"n"(2 * K), "n"(2 * K + 1), "v"(off), "s"(base) : "memory", HS_SWEEP_RING);
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %2, %3 " HS_SWEEP_STREAM_POLICY ::"n"(2 * K), "n"(2 * K + 1), "v"(off), "s"(base) : "memory", HS_SWEEP_RING);
 }
 template <int K>
 __device__ __forceinline__ void sweep_issue_gather(const uint8_t* x, uint32_t byte_off) {
