@@ -65,6 +65,7 @@ struct hs_context {
     // next one (spmv_device.h: CarriedCombine) -- enqueue() below.  `pending`: the set of partial vectors whose sum has not been written to
     // its y yet; flush_combine() launches the stand-alone combine for it, and every entry point that could observe y, its target or the
     // stream does that first, so the stream-order contract of hisparse_hip.h holds unchanged.
+    bool stream_resident = false;   // plan-time decision (load_matrix_impl): SWEEP stream loads without the non-temporal hint (the image fits the Infinity Cache)
     bool carry_combine = false;     // plan-time decision (load_matrix_impl): two sets of partial vectors exist
     bool in_batch = false;          // inside hs_run_batch: the batch settles its own last step before it returns, whatever stream it runs on
     bool stream_shared = false;     // hs_get_stream was called: somebody else may order work against the stream -- every step completes in itself
@@ -146,7 +147,7 @@ const char* ctx_option(const hs_context* c, const char* name) { return hisparse:
 
 // hs_set_option's keys (the HISPARSE_<KEY> environment switches the library understands); plan-time ones take effect at the next load
 const char* const kOptionKeys[] = {
-    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "SPMM_VECTORS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "RETILE", "PLAN_DEBUG",
+    "STREAM_FORMAT", "COL_SLICES", "MAX_ROWS", "CROSS_PARTITIONS", "SPMM_VECTORS", "ROW_RUNS", "AUX_BITS", "XCD_AFFINITY", "STREAM_RESIDENT", "RETILE", "PLAN_DEBUG",
     "BITMAP_SKEW", "BITMAP_X_LDS", "BITMAP_BUILD", "WALK_LANES", "NO_MFMA_IMAGE", "MFMA_CHUNK", "LIGHT", "LIGHT_WGS", "SWEEP",
     "DELTA_DEAL", "POW2_SLICES", "SPMM_FUSED", "SPMM_MFMA", "SPMSPV", "SPMSPV_CROSSOVER", "ITERATE_GRAPH", "BATCH_GRAPH", "CARRY_COMBINE",
 };
@@ -263,6 +264,7 @@ hisparse::dev::SpmvLaunch launch_args(hs_context* c, int32_t filter) {
     a.lds_bytes = c->lds_bytes;
     a.bitmap_x_groups = c->bitmap_x_groups;
     a.light = c->light;
+    a.stream_resident = c->stream_resident;
     return a;
 }
 
@@ -527,6 +529,15 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     HS_HIP(ctx, upload(reinterpret_cast<void**>(&ctx->d_part_heads), tiles.part_heads.data(), tiles.part_heads.size() * sizeof(uint32_t), 0));
     HS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_y), size_t(num_rows) * 4));
     HS_HIP(ctx, hipMemset(ctx->d_y, 0, size_t(num_rows) * 4));  // the host zero-initialises y (sw/benchmark.cpp:217-222)
+    {
+        // SWEEP images that fit the 256 MiB Infinity Cache are streamed WITHOUT the non-temporal hint: repeated SpMVs of one matrix -- the
+        // reference's benchmark loop, an iterative caller -- then read most of the image from the cache (profiles/r05_sweep_stream_policy.txt: one
+        // rank's slab of ogbn-products split 8 ways, 124 MB: 39.5 -> 32.0 us; pokec, 247 MB: 61.1 -> 59.6-60.8 fixed, 69.3-70.3 -> 66.3-67.7 float_pob).
+        // Larger images keep `nt` (a plain read loop over 1 GiB: 7.1 TB/s with it, 6.0 without: profiles/r02_hbm_read_bench.txt).  `stream_resident` = 0 | 1 decides otherwise.
+        const char* opt = ctx_option(ctx, "HISPARSE_STREAM_RESIDENT");
+        const uint64_t image_bytes = image_on_device ? tiles.image_bytes : uint64_t(tiles.image.size());
+        ctx->stream_resident = opt ? std::atoi(opt) != 0 : image_bytes <= hisparse::dev::kResidentMaxImageBytes;
+    }
     if (tiles.col_slices > 1) {
         // the combine pass carried into the next step's kernel (hs_context::carry_combine); `carry_combine` = 0 | 1 decides otherwise
         // Measured (profiles/r05_carry_combine_ab.txt, three boxes, whole step): where a step is a few microseconds -- one rank's slab of

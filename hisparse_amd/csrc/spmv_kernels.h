@@ -30,6 +30,7 @@ struct SpmvLaunch {
     const uint32_t* carry_partial = nullptr;
     uint32_t* carry_y = nullptr;
     uint32_t carry_rows = 0, carry_slices = 0;
+    bool stream_resident = false; // the image is small enough to stay in the 256 MiB Infinity Cache from one step to the next: SWEEP stream loads WITHOUT the non-temporal hint (spmv_sweep.hip)
     bool light = false;           // the LIGHT plan (StreamTiles::light): a PAIRS image consumed by spmv_light_kernel, 256-thread workgroups, lds_bytes = spmv_light_lds_bytes
 };
 

@@ -68,12 +68,12 @@ __device__ __forceinline__ const uint8_t* sweep_scalar_pointer(const void* p) {
 #error "HS_SWEEP_DEPTH must be 2, 3, 4, 6, 8, 12 or 16"
 #endif
 
-#ifndef HS_SWEEP_STREAM_POLICY
-#define HS_SWEEP_STREAM_POLICY "nt"      // cache-policy bits of the stream loads (A/B builds: -DHS_SWEEP_STREAM_POLICY='"sc1 nt"' ...)
-#endif
-template <int K>
+// kNt: the non-temporal hint on the stream loads -- right for an image that cannot stay in the Infinity Cache anyway, wrong for one that can
+// (SpmvLaunch::stream_resident: `sc1` instead, the policy that measured best of five, profiles/r05_sweep_stream_policy.txt)
+template <int K, bool kNt>
 __device__ __forceinline__ void sweep_issue_chunk(const uint8_t* base, uint32_t off) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %2, %3 " HS_SWEEP_STREAM_POLICY ::"n"(2 * K), "n"(2 * K + 1), "v"(off), "s"(base) : "memory", HS_SWEEP_RING);
+    if constexpr (kNt) asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %2, %3 nt" ::"n"(2 * K), "n"(2 * K + 1), "v"(off), "s"(base) : "memory", HS_SWEEP_RING);
+    else asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %2, %3 sc1" ::"n"(2 * K), "n"(2 * K + 1), "v"(off), "s"(base) : "memory", HS_SWEEP_RING);
 }
 template <int K>
 __device__ __forceinline__ void sweep_issue_gather(const uint8_t* x, uint32_t byte_off) {
@@ -140,7 +140,7 @@ struct SweepRows<false> {
 // kAblate (libhisparse_hip_prof.so only, WRONG results): 1 = no LDS accumulation, 2 = the gather reads one line near the chunk's base
 // instead of the elements' columns (keeps the wait count), 4 = no zeroing of the accumulators and no result store (the block's prologue and
 // epilogue), 8 = no gather at all (one load per step, the wait count halved)
-template <bool kFloat, int kAblate, int K>
+template <bool kFloat, int kAblate, bool kNt, int K>
 __device__ __forceinline__ void sweep_step(SweepLane& st, const uint8_t* stream, const uint8_t* x, uint32_t s, uint32_t steps, uint32_t lane_off, uint32_t base,
                                            uint8_t* ys, uint32_t nrows) {
     uint32_t value, where, xv;
@@ -153,19 +153,19 @@ __device__ __forceinline__ void sweep_step(SweepLane& st, const uint8_t* stream,
     else if (!(kAblate & 2)) sweep_issue_gather<K>(x, (base + (where & 0xffffu)) * 4u);
     else if (kAblate & 16) sweep_issue_gather<K>(x, lane_off >> 1 & 127u);       // (16, with 2: always the same line of x)
     else sweep_issue_gather<K>(x, (base * 4u & ~127u) + (lane_off >> 1 & 127u));
-    sweep_issue_chunk<K>(stream, min(s + kSweepDepth, steps - 1) * (kSweepWaves * kChunkBytes) + lane_off);
+    sweep_issue_chunk<K, kNt>(stream, min(s + kSweepDepth, steps - 1) * (kSweepWaves * kChunkBytes) + lane_off);
 }
 
 // prime, in the steady-state order: gather K (a dummy: its word is multiplied by 0), then chunk K
-template <bool kNoGather = false, int... Ks>
+template <bool kNoGather, bool kNt, int... Ks>
 __device__ __forceinline__ void sweep_prime(std::integer_sequence<int, Ks...>, const uint8_t* stream, const uint8_t* x, uint32_t pad_col, uint32_t steps, uint32_t lane_off) {
-    (((kNoGather ? (void)0 : sweep_issue_gather<Ks>(x, pad_col * 4u)), sweep_issue_chunk<Ks>(stream, min(uint32_t(Ks), steps - 1) * (kSweepWaves * kChunkBytes) + lane_off)), ...);
+    (((kNoGather ? (void)0 : sweep_issue_gather<Ks>(x, pad_col * 4u)), sweep_issue_chunk<Ks, kNt>(stream, min(uint32_t(Ks), steps - 1) * (kSweepWaves * kChunkBytes) + lane_off)), ...);
 }
 // one round of eight steps; steps at or beyond `end` are skipped (wave-uniform)
-template <bool kFloat, int kAblate, int... Ks>
+template <bool kFloat, int kAblate, bool kNt, int... Ks>
 __device__ __forceinline__ void sweep_round(std::integer_sequence<int, Ks...>, SweepLane& st, const uint8_t* stream, const uint8_t* x, uint32_t s0, uint32_t steps,
                                             uint32_t end, uint32_t lane_off, const uint32_t (&b)[kSweepDepth], uint8_t* ys, uint32_t nrows) {
-    ((s0 + Ks < end ? sweep_step<kFloat, kAblate, Ks>(st, stream, x, s0 + Ks, steps, lane_off, b[Ks], ys, nrows) : (void)0), ...);
+    ((s0 + Ks < end ? sweep_step<kFloat, kAblate, kNt, Ks>(st, stream, x, s0 + Ks, steps, lane_off, b[Ks], ys, nrows) : (void)0), ...);
 }
 
 // A block's prologue and epilogue.  Up to 39 716 rows on 512 threads is ~78 trips per thread: one ds_write_b32 per trip, and -- in the epilogue --
@@ -208,7 +208,7 @@ __device__ __forceinline__ void sweep_store_rows(const uint8_t* ys, uint32_t nro
     }
 }
 
-template <bool kFloat, int kAblate>
+template <bool kFloat, int kAblate, bool kNt>
 __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t* __restrict__ image, const Block* __restrict__ blocks,
                                                                   const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
                                                                   int32_t row_part_filter, const uint32_t* __restrict__ part_heads, CarriedCombine carry) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t
         SweepLane st;
 #pragma unroll
         for (int k = 0; k < kSweepDepth; ++k) { st.value[k] = 0; st.row[k] = nrows; }
-        if (steps) sweep_prime<(kAblate & 8) != 0>(std::make_integer_sequence<int, kSweepDepth>(), stream, xs, pad_col, steps, lane_off);
+        if (steps) sweep_prime<(kAblate & 8) != 0, kNt>(std::make_integer_sequence<int, kSweepDepth>(), stream, xs, pad_col, steps, lane_off);
         if (!first_block) __syncthreads();                        // the previous block's store has read the accumulators
         first_block = false;
         if (!(kAblate & 4)) sweep_zero_rows(ys, R::lds_words(nrows), tid);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kSweepThreads) void spmv_sweep_kernel(const uint8_t
                 uint32_t nb[kSweepDepth];
 #pragma unroll
                 for (int k = 0; k < kSweepDepth; ++k) nb[k] = bases[min(s0 + kSweepDepth + k, last)];
-                sweep_round<kFloat, kAblate>(std::make_integer_sequence<int, kSweepDepth>(), st, stream, xs, s0, steps, steps + kSweepDepth, lane_off, b, ys, nrows);
+                sweep_round<kFloat, kAblate, kNt>(std::make_integer_sequence<int, kSweepDepth>(), st, stream, xs, s0, steps, steps + kSweepDepth, lane_off, b, ys, nrows);
 #pragma unroll
                 for (int k = 0; k < kSweepDepth; ++k) b[k] = nb[k];
             }
@@ -286,11 +286,12 @@ uint32_t spmv_sweep_lds_bytes(uint32_t max_block_rows, bool is_float) {
 
 hipError_t configure_sweep_kernels(uint32_t lds_bytes) {
     hipError_t e;
-#define X(A)                                                                                                                                         \
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_sweep_kernel<false, A>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes))) != hipSuccess) return e; \
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_sweep_kernel<true, A>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes))) != hipSuccess) return e;
+#define Y(F, A, N)                                                                                                                                   \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_sweep_kernel<F, A, N>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes))) != hipSuccess) return e;
+#define X(A) Y(false, A, true) Y(true, A, true) Y(false, A, false) Y(true, A, false)
     HS_FOR_EACH_SWEEP_VARIANT(X)
 #undef X
+#undef Y
     return hipSuccess;
 }
 
@@ -299,14 +300,16 @@ hipError_t launch_spmv_sweep(bool is_float, const SpmvLaunch& a, hipStream_t str
     if (!profiling_switches(ablate, depth)) return hipErrorInvalidValue;
     const dim3 grid(a.num_workgroups), block(kSweepThreads);
     const CarriedCombine carry = carried(a);
+#define Y(F, A, N) hipLaunchKernelGGL((spmv_sweep_kernel<F, A, N>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads, carry)
 #define X(A)                                                                                                                                         \
     if (ablate == A) {                                                                                                                               \
-        if (is_float) hipLaunchKernelGGL((spmv_sweep_kernel<true, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads, carry); \
-        else hipLaunchKernelGGL((spmv_sweep_kernel<false, A>), grid, block, a.lds_bytes, stream, a.image, a.blocks, a.x, a.out, a.row_part_filter, a.part_heads, carry);       \
+        if (a.stream_resident) { if (is_float) Y(true, A, false); else Y(false, A, false); }                                                         \
+        else { if (is_float) Y(true, A, true); else Y(false, A, true); }                                                                             \
         return hipGetLastError();                                                                                                                    \
     }
     HS_FOR_EACH_SWEEP_VARIANT(X)
 #undef X
+#undef Y
     return hipErrorInvalidValue;      // no such profiling build of this kernel
 }
 

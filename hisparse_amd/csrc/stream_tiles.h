@@ -88,6 +88,7 @@ constexpr uint32_t kMaxSweepSlices = 16;      // SWEEP images (round 5): a short
 // Column-sliced plans whose image stays below this carry the combine pass of a step into the next step's kernel (hs_api.cpp: one launch per
 // step in a run of hs_run calls); the planner prices the combine pass of such a plan at ~1 us instead of a launch of its own (3.5 us).
 constexpr uint64_t kCarryMaxImageBytes = 48ull << 20;
+constexpr uint64_t kResidentMaxImageBytes = 256ull << 20;   // SWEEP images up to the size of the Infinity Cache are streamed without the non-temporal hint (hs_api.cpp: stream_resident)
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 // PAIRS format
 constexpr uint32_t kChunkBytes = kWaveLanes * 8;              // one wavefront step: 64 elements

@@ -120,6 +120,28 @@ def test_more_than_eight_column_slices(impl, slices, monkeypatch):
                 assert built["image"].tobytes() == ref["image"].tobytes() and built["blocks"].tobytes() == ref["blocks"].tobytes()
 
 
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("resident", ["0", "1"])
+def test_stream_policy_does_not_change_the_result(impl, resident, monkeypatch):
+    # SWEEP images that fit the Infinity Cache are streamed without the non-temporal hint (hs_api.cpp: stream_resident; its own instantiation
+    # of the kernel): both instantiations against the oracle, single launches and a burst
+    monkeypatch.setenv("HISPARSE_SWEEP", "1")
+    monkeypatch.setenv("HISPARSE_STREAM_RESIDENT", resident)
+    csr = host.CSRMatrix.generate("powerlaw", 120000, 120000, a=1.5e6, b=0.4, c=1.0 if impl == 0 else 2.0, seed=41 + impl)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 11, impl))
+    want = _oracle(cp, impl, xw)
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix(cp)
+        assert device.STREAM_FORMATS[eng.stats()["stream_format"]] == "sweep"
+        eng.load_vector(xw)
+        for _ in range(3):
+            eng.run()
+            _check(impl, eng.read_result(), want)
+        eng.run_batch(3)
+        _check(impl, eng.read_result(), want)
+
+
 def test_non_finite_x_reaches_only_the_rows_that_hold_the_column(monkeypatch):
     # padding slots carry value 0 at the block's spare row and gather a real x word: 0 x inf = NaN must never land in a real row
     monkeypatch.setenv("HISPARSE_SWEEP", "1")
