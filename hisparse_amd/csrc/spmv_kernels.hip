@@ -101,6 +101,9 @@ __device__ __forceinline__ void dma_wait() {
 //   * the stream base is a loop-invariant SGPR pair, the per-step address a 32-bit vector offset (no 64-bit vector
 //     address arithmetic per step); s_nop 4 keeps 5 wait states between any scalar write of the base and its use;
 //   * `nt`: every element is read exactly once per SpMV, so it should not displace x in the L2 (measured: -8 %).
+#ifndef HS_ROWBLOCK_STREAM_POLICY
+#define HS_ROWBLOCK_STREAM_POLICY "nt"      // cache-policy bits of the row-block kernels' stream loads.  A/B builds: make variant NAME=rb_sc1 DEFS='-DHS_ROWBLOCK_STREAM_POLICY="\"sc1\""' --
+#endif                                      // the SWEEP kernel gained 2-19 % without `nt` on images that fit the Infinity Cache (spmv_sweep.hip); not yet measured here
 #define HS_RING_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", \
                       "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"
 constexpr int kMaxDepth = 16;
@@ -114,7 +117,7 @@ struct Ring<0> {   // PAIRS: one dwordx2 per lane and step
     static constexpr uint32_t kLaneBytes = 8;
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %2, %3 nt" ::"n"(2 * K), "n"(2 * K + 1), "v"(byte_off + lane_off), "s"(base)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %2, %3 " HS_ROWBLOCK_STREAM_POLICY ::"n"(2 * K), "n"(2 * K + 1), "v"(byte_off + lane_off), "s"(base)
                      : "memory", HS_RING_AGPRS);
     }
     template <int K, int kDepth>
@@ -137,7 +140,7 @@ struct Ring<1> {    // DELTA: a record = two slots per lane: {value A, value B} 
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
         static_assert(2 * K + 1 < kMaxDepth && K + kMaxDepth < 2 * kMaxDepth, "values in a0..a15, gap words in a16..a23: ring depth <= 8");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %3, %5 nt\n\tglobal_load_dword a[%2], %4, %5 offset:512 nt" ::"n"(2 * K), "n"(2 * K + 1),
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %3, %5 " HS_ROWBLOCK_STREAM_POLICY "\n\tglobal_load_dword a[%2], %4, %5 offset:512 " HS_ROWBLOCK_STREAM_POLICY ::"n"(2 * K), "n"(2 * K + 1),
                      "n"(K + kMaxDepth), "v"(byte_off + lane_off), "v"(byte_off + lane_off / 2), "s"(base)
                      : "memory", HS_RING_AGPRS);
     }
@@ -154,7 +157,7 @@ struct Ring<2> {    // 24-bit position words: a 448-byte step = 64 value dwords,
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
         // the position word is read as an UNALIGNED dword at byte 256 + 3 * lane (its top byte belongs to the next lane)
-        asm volatile("s_nop 4\n\tglobal_load_dword a[%0], %2, %4 nt\n\tglobal_load_dword a[%1], %3, %4 offset:256 nt" ::"n"(K),
+        asm volatile("s_nop 4\n\tglobal_load_dword a[%0], %2, %4 " HS_ROWBLOCK_STREAM_POLICY "\n\tglobal_load_dword a[%1], %3, %4 offset:256 " HS_ROWBLOCK_STREAM_POLICY ::"n"(K),
                      "n"(K + kMaxDepth), "v"(byte_off + lane_off), "v"(byte_off + lane_off - lane_off / 4), "s"(base)
                      : "memory", HS_RING_AGPRS);
     }
@@ -180,7 +183,7 @@ struct Ring<3> {    // OWNER24: a record = FOUR steps per lane: the 4 value word
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane16, uint32_t lane12) {
         static_assert(K < 4 && 16 + 4 * K + 2 < 2 * kMaxDepth, "a0..a15: values of four records, a16..a30: their position words");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 a[%0:%1], %4, %6 nt\n\tglobal_load_dwordx3 a[%2:%3], %5, %6 offset:1024 nt" ::"n"(4 * K), "n"(4 * K + 3),
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 a[%0:%1], %4, %6 " HS_ROWBLOCK_STREAM_POLICY "\n\tglobal_load_dwordx3 a[%2:%3], %5, %6 offset:1024 " HS_ROWBLOCK_STREAM_POLICY ::"n"(4 * K), "n"(4 * K + 3),
                      "n"(16 + 4 * K), "n"(16 + 4 * K + 2), "v"(byte_off + lane16), "v"(byte_off + lane12), "s"(base)
                      : "memory", HS_RING_AGPRS);
     }
