@@ -197,6 +197,16 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             sweep = sweep_us < owner_us;
             if (env_switch("HISPARSE_PLAN_DEBUG")) std::fprintf(stderr, "format: sweep %.1f us (%u slices) against owner24 %.1f us (%.0f units per workgroup) -> %s\n", sweep_us, cs, owner_us, per_wg, sweep ? "sweep" : "owner24");
         }
+        // Short, wide, moderately sparse slabs whose image stays in the Infinity Cache (round 5, the round's last measurement,
+        // profiles/r05_hollywood_slab_sweep.txt): one rank's slab of hollywood split 8 ways -- 133 K rows x 1.07 M columns, gap 10 K, 113 MB -- runs
+        // 25.4-25.8 us as a SWEEP image (9 slices; ring depth 4, streamed without `nt`) against 31.0 us under the row-block planner's choice (PAIRS, 8
+        // slices x 16 units per block of 3.4 K elements: a barrier and an x refill per unit).  Fixed point only, >= 6 columns per row and a gap
+        // above kSweepSlabMinMeanGap: what was measured, no further; the float modes and the 4-way slabs keep their plans until they are.
+        if (!sweep && !is_float && gap > kSweepSlabMinMeanGap && gap <= kOwnerMinMeanGap && out.nnz >= kSweepMinNnz && uint64_t(num_cols) >= 6ull * num_rows &&
+            double(out.nnz) * 8.1 <= double(kResidentMaxImageBytes) && uint64_t(num_cols) * 4 < (1ull << 32)) {
+            sweep = true;
+            if (env_switch("HISPARSE_PLAN_DEBUG")) std::fprintf(stderr, "format: sweep for a short, wide slab (gap %.0f, %u x %u)\n", gap, num_rows, num_cols);
+        }
         // "spmm_vectors" = 4: the caller wants the four-vector SpMM kernel, which runs SWEEP images only (spmm_sweep.hip)
         const char* spmm = env_switch("HISPARSE_SPMM_VECTORS");
         const bool for_spmm = spmm && std::atoi(spmm) == 4 && out.nnz > 0 && uint64_t(num_cols) * 16 < (1ull << 32);

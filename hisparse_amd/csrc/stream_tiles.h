@@ -206,6 +206,7 @@ constexpr uint32_t kSweepColAlign = 32;                       // slices start on
 // profiles/r04_sweep_vs_owner_synthetic.txt), whole step, SWEEP against OWNER24: gap 50 K +3 ... -3 % (fixed) / +5 ... +11 % (float), 70 K -6 ...
 // -13 % / +2 ... -7 %, 100 K -12 ... -24 % / -3 ... -20 %, 200 K -20 ... -38 % in both; pokec (gap 87 K) 95.5 -> 78.0 us fixed, 122.6 -> 88.3 us
 // float_pob; ogbn-products (48 K) stays OWNER24 (204 against 216 us).
+constexpr double kSweepSlabMinMeanGap = 8000.0;                // short, wide fixed-point slabs that fit the Infinity Cache take SWEEP from this mean gap on (stream_tiles.cpp)
 constexpr uint64_t kSweepMinNnz = (2u << 20) + 1;             // smaller matrices: the LIGHT plan's (when x is short) or the row-block kernel's
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit

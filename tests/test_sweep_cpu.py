@@ -143,3 +143,21 @@ def test_planner_takes_sweep_where_its_plan_is_modelled_faster(monkeypatch):
     monkeypatch.setenv("HISPARSE_SWEEP", "0")
     cp = host.format_matrix(sparse, 0, skip_empty_rows=True)
     assert build(cp, 0, 256)["format"] == "owner24"
+
+
+def test_planner_takes_sweep_for_short_wide_slabs_that_fit_the_infinity_cache(monkeypatch):
+    """Round 5 (stream_tiles.cpp): a fixed-point row slab of >= 6 columns per row, mean position gap in (8 K, 20 K], > 2 M non-zeros and an image below
+    256 MiB -- one rank's slab of hollywood split 8 ways -- is a SWEEP image; the same shape in a float mode, a denser one and a squarer one keep
+    the row-block planner's choice; the emulated kernel agrees with the oracle on the slab."""
+    monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
+    slab = host.CSRMatrix.generate("powerlaw", 50000, 400000, a=2.2e6, b=0.4, c=1.0, seed=5)             # gap 9.1 K, 8 columns per row
+    cp = host.format_matrix(slab, 0, skip_empty_rows=True)
+    t = build(cp, 0, 256)
+    assert t["format"] == "sweep", t["format"]
+    xw = host.pack_vector(0, cases.random_x(cp.num_cols, 5, 0))
+    assert np.array_equal(tile_emulator.run(t, 0, xw, cp.num_rows), oracle_y(cp, 0, xw))
+    assert build(host.format_matrix(slab, 1, skip_empty_rows=True), 1, 256)["format"] != "sweep"         # float modes: not measured, not switched
+    denser = host.CSRMatrix.generate("powerlaw", 50000, 400000, a=4.0e6, b=0.4, c=1.0, seed=6)           # gap 5 K
+    assert build(host.format_matrix(denser, 0, skip_empty_rows=True), 0, 256)["format"] != "sweep"
+    squarer = host.CSRMatrix.generate("powerlaw", 100000, 400000, a=4.2e6, b=0.4, c=1.0, seed=7)         # gap 9.5 K, 4 columns per row
+    assert build(host.format_matrix(squarer, 0, skip_empty_rows=True), 0, 256)["format"] != "sweep"
