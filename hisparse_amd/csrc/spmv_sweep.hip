@@ -33,7 +33,7 @@ constexpr int kSweepThreads = kSweepWaves * kWaveLanes;
 #ifndef HS_SWEEP_DEPTH
 #define HS_SWEEP_DEPTH 4            // round 5, measured again on the kernel alone (pokec, fixed / float_pob, profiles/r05_sweep_ring_depth.txt): 2: 83.6 / 78.0 us,
                                     // 3: 65.4 / 69.2, 4: 61.4 / 70.5, 6: 64.2 / 71.7, 8: 64.6 / 74.1, 12: 68.2 / 74.6, 16: 70.5 / 77.9 -- and 16 wavefronts x 2 deep = 8 x 4
-                                    // deep (61.2 / 70.4): what counts is 16 KB of stream in flight per CU, beyond it the gathers' lines of x lose the L1.
+                                    // deep (61.2 / 70.4): what counts is 16 KB of stream in flight per CU (beyond it, presumably, the gathers' lines of x lose the 32 KB L1: not isolated).
                                     // (round 4 had read "flat from 4 to 8" on whole steps of the 8-byte-accumulator kernel: profiles/r04_sweep_ring_depth.txt)
 #endif
 constexpr int kSweepDepth = HS_SWEEP_DEPTH;      // chunks (and gathers) in flight per wavefront
