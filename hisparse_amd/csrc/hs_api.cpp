@@ -279,9 +279,17 @@ void partition_rows(const hs_context* c, uint32_t j, uint32_t& lo, uint32_t& hi)
 // Enqueue one SpMV (filter < 0) or one row partition; optional events bracket the kernel.  `feedback` (hs_iterate): also
 // x = scale (*) y (+) shift afterwards -- folded into the combine launch of a column-sliced matrix, its own launch otherwise.
 struct Feedback { uint32_t scale, shift; };
+// x [num_cols words) and a result vector [num_rows words) share memory: the carried combine writes y(k) from inside step k+1's kernel while
+// other workgroups of that kernel read x -- in-place y = A*y stays well defined only with the stand-alone combine
+bool x_aliases(const hs_context* c, const uint32_t* x, const uint32_t* y) {
+    if (!x || !y) return false;
+    const uintptr_t x0 = reinterpret_cast<uintptr_t>(x), x1 = x0 + size_t(c->num_cols) * 4, y0 = reinterpret_cast<uintptr_t>(y), y1 = y0 + size_t(c->num_rows) * 4;
+    return x0 < y1 && y0 < x1;
+}
 int enqueue(hs_context* c, int32_t filter, hipEvent_t k0, hipEvent_t k1, const Feedback* feedback = nullptr) {
     if (const char* why = hisparse::dev::profiling_switch_error()) return fail(c, HS_ERR_BAD_ARG, why);
-    if (c->carry_combine && c->col_slices > 1 && filter < 0 && !k0 && !k1 && !feedback && ((c->stream == c->own_stream && !c->stream_shared) || c->in_batch)) {
+    if (c->carry_combine && c->col_slices > 1 && filter < 0 && !k0 && !k1 && !feedback && ((c->stream == c->own_stream && !c->stream_shared) || c->in_batch) &&
+        !x_aliases(c, x_source(c), y_target(c)) && !(c->pending >= 0 && x_aliases(c, x_source(c), c->pending_y))) {
         // this step's partial rows go to the set the previous step did NOT use; the previous step's are added up by this launch's
         // workgroups before they start on their blocks; this step's own sum is owed (pending) until the next hs_run or a flush
         hisparse::dev::SpmvLaunch a = launch_args(c, filter);
@@ -718,7 +726,10 @@ int hs_run_batch(hs_context* ctx, uint32_t steps) {
     } batch(ctx);
     if (!(opt && std::atoi(opt) != 0)) {      // plain: the launches of `steps` SpMVs enqueued from this C loop
         for (uint32_t i = 0; i < steps; ++i)
-            if ((rc = enqueue(ctx, -1, nullptr, nullptr)) != HS_OK) return rc;
+            if ((rc = enqueue(ctx, -1, nullptr, nullptr)) != HS_OK) {
+                (void)batch.settle();      // a caller-owned stream is never left owing a sum, also not on the error path
+                return rc;
+            }
         return batch.settle();
     }
     // graph replay: the same launches captured once into a hipGraph (per step count, vector, result target and stream) and replayed
@@ -732,10 +743,12 @@ int hs_run_batch(hs_context* ctx, uint32_t steps) {
         for (uint32_t i = 0; i < steps && rc == HS_OK; ++i) rc = enqueue(ctx, -1, nullptr, nullptr);
         if (rc == HS_OK) rc = flush_combine(ctx);            // ... and nothing when it ends (a carried plan: K kernels + one combine)
         e = hipStreamEndCapture(ctx->stream, &ctx->batch_graph);
-        if (rc != HS_OK) { drop_batch_graph(ctx); return rc; }
-        if (e != hipSuccess || !ctx->batch_graph) { drop_batch_graph(ctx); return hip_fail(ctx, e, "hipStreamEndCapture"); }
+        // nothing was EXECUTED during the capture: whatever the captured steps recorded as owed does not exist (a dropped graph must not
+        // leave a stale `pending` for the next entry point's flush to combine)
+        if (rc != HS_OK) { ctx->pending = -1; drop_batch_graph(ctx); return rc; }
+        if (e != hipSuccess || !ctx->batch_graph) { ctx->pending = -1; drop_batch_graph(ctx); return hip_fail(ctx, e, "hipStreamEndCapture"); }
         e = hipGraphInstantiate(&ctx->batch_exec, ctx->batch_graph, nullptr, nullptr, 0);
-        if (e != hipSuccess) { drop_batch_graph(ctx); return hip_fail(ctx, e, "hipGraphInstantiate"); }
+        if (e != hipSuccess) { ctx->pending = -1; drop_batch_graph(ctx); return hip_fail(ctx, e, "hipGraphInstantiate"); }
         ctx->batch_steps = steps;
         ctx->batch_x = x_source(ctx);
         ctx->batch_y = y_target(ctx);
@@ -887,7 +900,8 @@ int spmspv_dense(hs_context* ctx, const hisparse::dev::hs_idx_val_dev* x_dev, ui
     uint32_t* saved_y = ctx->y_bound;
     ctx->x_bound = ctx->d_x_dense;
     ctx->y_bound = ctx->d_csc_y;
-    const int rc = enqueue(ctx, -1, nullptr, nullptr);
+    int rc = enqueue(ctx, -1, nullptr, nullptr);
+    if (rc == HS_OK) rc = flush_combine(ctx);      // never leave a sum owed to a transient target
     ctx->x_bound = saved_x;
     ctx->y_bound = saved_y;
     if (rc == HS_OK) ++ctx->spmspv_dense_dispatches;
@@ -1007,12 +1021,17 @@ int hs_spmspv(hs_context* ctx, const hs_idx_val* x_entries, uint32_t count) {
             if (rc == HS_OK && hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) {
                 (void)hipEventRecord(t0, ctx->stream);
                 for (int i = 0; i < 3 && rc == HS_OK; ++i) rc = enqueue(ctx, -1, nullptr, nullptr);
+                // A carried plan owes the last step's sum to d_csc_y here; if the rule below then takes the SPARSE path, that combine would
+                // run after spmspv_pass and overwrite its y with A*0: settle it inside the timed region
+                if (rc == HS_OK) rc = flush_combine(ctx);
                 (void)hipEventRecord(t1, ctx->stream);
                 float ms = 0.0f;
                 if (rc == HS_OK && hipEventSynchronize(t1) == hipSuccess && hipEventElapsedTime(&ms, t0, t1) == hipSuccess) ctx->dense_spmv_us = std::max(1.0, double(ms) * 1000.0 / 3.0);
             }
             if (t0) (void)hipEventDestroy(t0);
             if (t1) (void)hipEventDestroy(t1);
+            if (rc == HS_OK) rc = flush_combine(ctx);      // (the event creation failed: the warm step's sum is still owed)
+            else ctx->pending = -1;
             ctx->x_bound = saved_x;
             ctx->y_bound = saved_y;
             if (rc != HS_OK) return rc;
@@ -1097,6 +1116,7 @@ int hs_set_option(hs_context* ctx, const char* key, const char* value) {
     if (!known) return fail(ctx, HS_ERR_BAD_ARG, "unknown option '" + std::string(key) + "'");
     if (value && *value) ctx->options["HISPARSE_" + k] = value;
     else ctx->options.erase("HISPARSE_" + k);
+    drop_batch_graph(ctx);      // the captured batch bakes in whatever enqueue() read at capture time: any option change invalidates it
     return HS_OK;
 }
 
@@ -1138,6 +1158,7 @@ int hs_device_result(hs_context* ctx, void** y_dev) {
 int hs_bind_device_vector(hs_context* ctx, const void* x_dev) {
     if (!ctx) return HS_ERR_BAD_ARG;
     if (x_dev && (reinterpret_cast<uintptr_t>(x_dev) & 15u)) return fail(ctx, HS_ERR_BAD_ARG, "device vector must be 16-byte aligned");
+    if (static_cast<const uint32_t*>(x_dev) != ctx->x_bound) drop_batch_graph(ctx);
     ctx->x_bound = static_cast<const uint32_t*>(x_dev);
     return HS_OK;
 }
@@ -1145,7 +1166,10 @@ int hs_bind_device_vector(hs_context* ctx, const void* x_dev) {
 int hs_bind_device_result(hs_context* ctx, void* y_dev) {
     if (!ctx) return HS_ERR_BAD_ARG;
     if (y_dev && (reinterpret_cast<uintptr_t>(y_dev) & 15u)) return fail(ctx, HS_ERR_BAD_ARG, "device result must be 16-byte aligned");
-    if (static_cast<uint32_t*>(y_dev) != ctx->y_bound) HS_FLUSH(ctx);      // (an owed sum belongs to the old target)
+    if (static_cast<uint32_t*>(y_dev) != ctx->y_bound) {
+        HS_FLUSH(ctx);      // (an owed sum belongs to the old target)
+        drop_batch_graph(ctx);
+    }
     ctx->y_bound = static_cast<uint32_t*>(y_dev);
     return HS_OK;
 }
@@ -1270,6 +1294,10 @@ int hs_spmm_device(hs_context* ctx, const void* x_dev, uint64_t ldx, void* y_dev
         ctx->y_bound = static_cast<uint32_t*>(y_dev) + size_t(j) * ldy;
         rc = enqueue(ctx, -1, nullptr, nullptr);
     }
+    // the last column's sum is not left owed to the caller's memory: an event or a device-wide synchronisation then completes Y, and the
+    // caller may free y_dev
+    if (rc == HS_OK) rc = flush_combine(ctx);
+    else ctx->pending = -1;
     ctx->x_bound = x_saved;
     ctx->y_bound = y_saved;
     return rc;

@@ -109,7 +109,12 @@ int hs_load_vector(hs_context* ctx, const void* packed_x, uint32_t num_cols);
  * hs_run_partition, hs_bind_device_result with another target, hs_set_stream, ...) launches it first, so the order of effects on the
  * stream is exactly that of "kernel, combine" per call.  With a caller-owned stream (hs_set_stream), or once hs_get_stream has handed the
  * stream out, every call completes in itself.  Chosen per matrix at load time (hs_api.cpp: images below 48 MiB, where the second launch is a
- * large part of the step, and OWNER images); hs_set_option "carry_combine" = 0 | 1 decides otherwise. */
+ * large part of the step, and OWNER images); hs_set_option "carry_combine" = 0 | 1 decides otherwise.
+ * CONSEQUENCE for callers that look at y through a device pointer (hs_device_result, hs_bind_device_result) on the library's own stream:
+ * y of the last hs_run is complete only after an entry point of THIS library has settled it -- hs_sync, hs_read_result, hs_push_result,
+ * hs_get_stream (from then on every call completes in itself) -- not after hipDeviceSynchronize / an event alone.  Transient targets are
+ * never left owed: hs_spmm_device, hs_spmspv's dense dispatch and its one-time timing settle before they return.  x and y that share
+ * memory (in-place y = A*y) never take the carried path. */
 int hs_run(hs_context* ctx);
 /* EXTENSION: `steps` x hs_run from ONE call -- the reference's NUM_RUNS loop (sw/benchmark.cpp:315-343) as a unit.  A step of a small
  * matrix is two launches of a few microseconds each, and how fast the HOST enqueues them then decides the step time (a Python loop over

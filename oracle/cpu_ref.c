@@ -177,7 +177,16 @@ static int top_wrapper_threads(int impl, const void* const ch[C], const uint32_t
                         uint32_t* q = &ob[(size_t)pe * used + addr];
                         *q = q_add(*q, q_mul(val, xv)); /* pe.h:64,72 */
                     } else {
-                        const unsigned d = impl == IMPL_FLOAT_POB ? (arrivals[pe]++ % POB_DEPTH) : 0u; /* pe-pob.h:62-71 */
+                        /* float_pob: which of the DEP_DISTANCE = 7 partial buffers a product lands in.  NOT the reference's rule word for
+                           word: pe-pob.h:71 advances pb_idx once per pipeline CYCLE, outside `if (valid)` (:61-69), i.e. also in
+                           cycles where the PE's input stream is empty -- which buffer an arrival meets depends on the shuffle
+                           arbiter's cycle-level back-pressure, which neither csim (C simulation: a dataflow process runs after
+                           its producers, so read_nb finds every payload waiting until EOD) nor this restatement models.  Here the
+                           index advances once per ARRIVAL at the PE -- what the reference's loop does under C simulation.  The
+                           difference can only change the ASSOCIATION of one fp32 row sum (same products, same 7-way split of a
+                           sum that the dump adds up again, pe-pob.h:91-95), never the set of terms: it is inside the float
+                           contract's tolerance by construction, and irrelevant in fixed point. */
+                        const unsigned d = impl == IMPL_FLOAT_POB ? (arrivals[pe]++ % POB_DEPTH) : 0u;
                         uint32_t* q = &ob[((size_t)d * P + pe) * used + addr];
                         volatile float incr = bits2f(val) * bits2f(xv); /* separate multiply, then add (pe-pob.h:63-65, pe-stall.h:52,138) */
                         *q = f2bits(bits2f(*q) + incr);

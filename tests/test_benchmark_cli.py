@@ -189,3 +189,37 @@ def test_n_slabs_sharing_one_gpu(tmp_path, n):
     cp, want = _oracle_y(m, 0, 4096, 8192, x)
     y = np.fromfile(yf, dtype=np.uint32)
     assert y.size == 20000 and np.array_equal(y, want[:20000])
+
+
+# ---- round 6: the reference's own eight dataset cases of csim (spmv_csim/csim.cpp:481-591) ---------------------------------------------------
+# Every one of them overwrites the values with `1 / mat_f.num_cols` -- INTEGER division, i.e. 0.0f (csim.cpp:485; sw/benchmark.cpp:411 does the
+# same) -- so what csim really asserts on gplus / ogbl_ppa / pokec / hollywood / ogbn_products / mouse_gene / transformer_50_t / transformer_95_t
+# is: the full-size matrix goes through the formatter and the partition-by-partition launch loop (top_wrapper, csim.cpp:22-46) and y comes out
+# ALL ZERO against compute_ref.  Here: the stand-ins of the same shapes (datasets.py; the files themselves are absent), `--values literal`,
+# `--partition-loop`, `--verify` (the harness's own check), y dumped and asserted to be all-zero words.  Every matrix in one numeric mode
+# (cycling), mouse_gene and transformer_95 in all three.
+_CSIM_CASES = ["gplus", "ogbl_ppa", "pokec", "hollywood", "ogbn_products", "mouse_gene", "transformer_50", "transformer_95"]
+_MODES = [("fixed", 4, 8), ("float_pob", 4, 1), ("float_stall", 4, 8)]
+
+
+def _csim_literal_params():
+    out = [(name, _MODES[k % 3]) for k, name in enumerate(_CSIM_CASES)]
+    for name in ("mouse_gene", "transformer_95"):
+        out += [(name, m) for m in _MODES if (name, m) not in out]
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode", _csim_literal_params(), ids=lambda p: p if isinstance(p, str) else p[0])
+def test_csim_dataset_cases_with_the_reference_literal_values(tmp_path, name, mode):
+    from hisparse_amd import datasets
+    impl_name, v, o = mode
+    c = datasets.CONFIGS[name]
+    spec = f"synth:{c.kind}:{c.rows}:{c.cols}:{c.a}:{c.b}:{c.c}:{c.seed}"
+    yf = tmp_path / "y.bin"
+    r = run(impl_name, spec, v, o, "--values", "literal", "--partition-loop", "--runs", 2, "--verify", "--dump-y", yf, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert RESULT_LINE.search(r.stdout) and "INFO : verify PASSED" in r.stdout
+    assert int(re.search(r"row_partitions: (\d+)", r.stdout).group(1)) >= 1
+    y = np.fromfile(yf, dtype=np.uint32)
+    assert y.size >= c.rows and not y.any(), f"{int((y != 0).sum())} non-zero words in a product with an all-zero matrix"

@@ -177,3 +177,94 @@ def test_bound_result_buffers_receive_their_own_step():
     finally:
         for b in bufs:
             rt.hipFree(b)
+
+
+def test_spmspv_auto_timing_block_leaves_nothing_owed():
+    # spmspv = auto times the dense SpMV once, on a zero vector, with y swapped to the SpMSpV result buffer.  On a
+    # carried column-sliced plan that left a sum owed to that buffer; when the rule then took the SPARSE path, the owed combine ran after
+    # spmspv_pass and overwrote y with A*0.  The FIRST auto call must give the oracle's words, whichever path the rule takes.
+    impl = 0
+    rows, cols = 200000, 200000
+    g = host.CSRMatrix.generate("powerlaw", rows, cols, a=20e6, b=0.3, c=1.0, seed=23)       # ~100 non-zeros per column: 8000 entries of x
+    indptr, ridx, words = host.csr_to_csc(g, impl)                                              # -> ~800 K products (beyond the 30 us gate)
+    rng = np.random.default_rng(4)
+    xi = np.sort(rng.choice(cols, size=8000, replace=False)).astype(np.uint32)
+    xw = host.pack_vector(impl, cases.random_x(len(xi), 4, impl))
+    want = orc.spmspv(impl, indptr, ridx, words, rows, cols, xi, xw)
+    assert want.any()
+    for path in ("auto", "dense"):
+        with device.SpmvEngine(impl) as eng:
+            eng.set_option("stream_format", "pairs")
+            eng.set_option("col_slices", "4")
+            eng.set_option("carry_combine", "1")
+            eng.set_option("spmspv", path)
+            eng.load_matrix_csr(g)
+            assert eng.stats()["col_slices"] == 4
+            eng.load_matrix_csc(indptr, ridx, words, rows)
+            first = eng.spmspv(xi, xw)
+            second = eng.spmspv(xi, xw)
+        assert np.array_equal(first, want), (path, int((first != want).sum()))
+        assert np.array_equal(second, want), path
+
+
+def test_spmm_device_and_in_place_vectors_on_a_carried_plan():
+    # ADVICE round 5 (medium / low): hs_spmm_device's k-SpMV path must not leave the last column's sum owed to the CALLER's memory (a
+    # device-wide synchronisation completes Y; the caller may free it), and x bound to the same memory as y never takes the carried path
+    impl = 0
+    m, cp = _setup(impl, rows=70016, cols=70016)       # 547 x 128: the padded row and column counts coincide
+    xs = [host.pack_vector(impl, cases.random_x(cp.num_cols, s, impl)) for s in (11, 12, 13)]
+    wants = [_oracle(impl, cp, xw) for xw in xs]
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    k, n = len(xs), cp.num_rows
+    assert cp.num_cols == n and n % 4 == 0
+    xd, yd = C.c_void_p(), C.c_void_p()
+    assert rt.hipMalloc(C.byref(xd), k * n * 4 + 64) == 0 and rt.hipMalloc(C.byref(yd), k * n * 4) == 0
+    try:
+        with _engine(impl, cp, "pairs", 4, True) as eng:
+            X = np.ascontiguousarray(np.stack(xs))
+            assert rt.hipMemcpy(xd, X.ctypes.data, X.nbytes, 1) == 0
+            lib = device.lib()
+            assert lib.hs_spmm_device(eng._h, xd, C.c_uint64(n), yd, C.c_uint64(n), C.c_uint32(k)) == 0
+            assert rt.hipDeviceSynchronize() == 0                    # NOT hs_sync: nothing may still be owed to yd
+            Y = np.empty((k, n), dtype=np.uint32)
+            assert rt.hipMemcpy(Y.ctypes.data, yd, Y.nbytes, 2) == 0
+            for j in range(k):
+                assert np.array_equal(Y[j], wants[j]), j
+            # in place: y = A*x with x and y the same buffer, three times; the oracle iterates the same way
+            eng.bind_device_vector(xd.value)
+            eng.bind_device_result(xd.value)
+            want = xs[0]
+            for _ in range(3):
+                eng.run()
+                want = _oracle(impl, cp, want)
+            eng.sync()
+            y = np.empty(n, dtype=np.uint32)
+            assert rt.hipMemcpy(y.ctypes.data, xd, y.nbytes, 2) == 0
+            assert np.array_equal(y, want)
+            eng.bind_device_vector(None)
+            eng.bind_device_result(None)
+    finally:
+        rt.hipFree(xd)
+        rt.hipFree(yd)
+
+
+def test_batch_graph_is_dropped_when_bindings_or_options_change():
+    # the cached hs_run_batch graph bakes in x, y and every option enqueue() reads
+    impl = 0
+    m, cp = _setup(impl)
+    xa = host.pack_vector(impl, cases.random_x(cp.num_cols, 2, impl))
+    want = _oracle(impl, cp, xa)
+    with _engine(impl, cp, "delta", 4, True) as eng:
+        eng.set_option("batch_graph", "1")
+        eng.load_vector(xa)
+        eng.run_batch(3)
+        assert np.array_equal(eng.read_result(), want)
+        eng.set_option("batch_graph", "1")          # any option change: re-captured, same result
+        eng.run_batch(3)
+        assert np.array_equal(eng.read_result(), want)
+        eng.set_option("batch_graph", "0")
+        eng.run_batch(3)
+        assert np.array_equal(eng.read_result(), want)
