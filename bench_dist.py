@@ -15,6 +15,29 @@ import time
 import bench as B
 
 
+def one_gpu_prediction(name, impl_name, n):
+    """What ONE GPU predicted for this split (bench.py's default run / --predict-scaling: every slab of the N-way split timed on one GPU,
+    bench_extras.predict_scaling), so that the first real N-GPU run can be read against it slab by slab.  Looked up in the details file a
+    1-GPU run of this checkout left behind, then in the committed copies under profiles/ (newest round first); None when nobody predicted it."""
+    import glob
+    paths = [B.DETAILS_FILE] + sorted(glob.glob(os.path.join(B.ROOT, "profiles", "r*_bench_details.json")), reverse=True)
+    for path in paths:
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for pred in d.get("strong_scaling_prediction") or []:
+            if pred.get("workload") != f"{name}, {impl_name} IMPL":
+                continue
+            for sp in pred.get("splits", []):
+                if sp.get("n_gpus") == n:
+                    return {"source": os.path.relpath(path, B.ROOT), "unsplit_us": pred.get("unsplit_us"), "max_slab_us": sp.get("max_slab_us"),
+                            "predicted_compute_only_efficiency": sp.get("predicted_compute_only_efficiency"),
+                            "slabs": [{k: sl.get(k) for k in ("rank", "rows", "nnz", "us", "plan")} for sl in sp.get("slabs", [])]}
+    return None
+
+
 def main_distributed(args, rank, local_rank, world):
     import numpy as np
     import torch
@@ -50,7 +73,7 @@ def main_distributed(args, rank, local_rank, world):
     dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     dist.barrier()
     n_gpus = world
-    name = args.config or "mouse_gene"
+    name = getattr(args, "scale_matrix", None) or args.config or "mouse_gene"
     dev = f"cuda:{gpu_id}" if on_gpu else "cpu"
     ctl = dev if rccl else "cpu"                          # where the control-plane reductions (timings, flags) live
     spin_up_steps = B.SPIN_UP_STEPS if rccl else (100 if dry else 0)
@@ -252,9 +275,25 @@ def main_distributed(args, rank, local_rank, world):
     tot = torch.tensor([float(nnz)], dtype=torch.float64, device=ctl)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     total_nnz = float(tot.item())
+    # every rank's own slab on its own clock, no barrier around it: K steps as one batch between two local synchronisations -- the quantity
+    # the one-GPU prediction (bench_extras.predict_scaling) times per slab, so the two can be compared slab by slab; the barrier-timed
+    # `compute_only` above is the slowest of these plus whatever the ranks' skew adds
+    sync()
+    local_best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run_steps("off", args.steps)
+        sync()
+        local_best = min(local_best, (time.perf_counter() - t0) / args.steps)
     if on_gpu:
         eng.set_stream(None)
     kernel_ms = eng.time_kernel(min(args.warmup, 20), args.steps) / args.steps
+    plan = {"rank": rank, "rows": int(true_rows), "padded_rows": int(packets.num_rows), "nnz": int(nnz),
+            "plan": f"{device.STREAM_FORMATS[stats['stream_format']]}" + (" (light kernel)" if stats.get("light_kernel") else "") +
+                    f", {stats['col_slices']} slices, {stats['num_blocks']} blocks",
+            "image_mb": round(stats["stream_bytes"] / 1e6, 1), "local_step_us": round(local_best * 1e6, 2), "kernel_us": round(kernel_ms * 1e3, 2)}
+    plans = [None] * world
+    dist.all_gather_object(plans, plan)
     dist.barrier()
     # strong scaling: the SAME matrix, unsplit, on rank 0's GPU alone -- the N = 1 point the N-GPU numbers of this workload belong to
     # (bench.py --gpus 1 without a launcher measures the ogbl-ppa headline instead)
@@ -302,6 +341,13 @@ def main_distributed(args, rank, local_rank, world):
             "exchange_every_step": {"ms_per_step": round(step_elapsed / args.steps * 1e3, 5),
                                     "value": round(8.0 * total_nnz / (step_elapsed / args.steps) / 1e9, 2)},
             "exchange_push": push,
+            # one entry per rank: [rows, nnz, plan, local step us (own clock, no barrier), kernel us]; beside it what ONE GPU predicted for the same slabs
+            "per_rank": [[p["rows"], p["nnz"], p["plan"], p["local_step_us"], p["kernel_us"]] for p in plans],
+            "slowest_rank_local_step_us": max(p["local_step_us"] for p in plans),
+            "one_gpu_prediction": (lambda q: None if q is None else {"source": q["source"], "unsplit_us": q["unsplit_us"], "max_slab_us": q["max_slab_us"],
+                                                                     "slab_us": [sl["us"] for sl in q["slabs"]],
+                                                                     "predicted_compute_only_efficiency": q["predicted_compute_only_efficiency"]})(
+                one_gpu_prediction(name, B.IMPL_NAMES[impl], n_gpus)) if args.scaling == "strong" else None,
             "roofline": {"bound": "hbm", "kernel": B.kernel_name(stats), "achieved": round(achieved, 2),
                          "peak": B.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / B.HBM_PEAK_GBS, 4), "kernel_ms": round(kernel_ms, 5),
                          "kernel_ms_from": "hs_time_kernel on rank 0's slab: one HIP event pair around K back-to-back launches of the kernel alone, / K",
@@ -321,5 +367,13 @@ def main_distributed(args, rank, local_rank, world):
         except OSError:
             pass
         sys.stdout.flush()
-        details = dict(out, preprocess_s={"format_csr2cpsr": round(t_fmt, 3), "device_load_retile": round(stats["load_seconds"], 3)}, slab_rows=rows_all)
-        B.emit(out, {"distributed": details}, [])
+        details = dict(out, preprocess_s={"format_csr2cpsr": round(t_fmt, 3), "device_load_retile": round(stats["load_seconds"], 3)}, slab_rows=rows_all,
+                       per_rank_plans=plans, one_gpu_prediction_full=one_gpu_prediction(name, B.IMPL_NAMES[impl], n_gpus) if args.scaling == "strong" else None)
+        keep = {}
+        try:      # a 1-GPU run of this checkout left its predictions in the details file: the N-rank record must not erase what it is read against
+            with open(B.DETAILS_FILE) as f:
+                old = json.load(f)
+            keep = {k: old[k] for k in ("strong_scaling_prediction",) if k in old}
+        except (OSError, ValueError):
+            pass
+        B.emit(out, dict(keep, distributed=details), [])

@@ -227,6 +227,45 @@ def live_traffic(name, impl_name, kernel, rank, launches=30, timeout=150):
                    "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count of wide streaming reads) + WRITE_SIZE KiB x 1024")
 
 
+def live_kernel_trace(name, impl_name, kernel, rank, launches=400, timeout=150):
+    """The dominant kernel's launch duration as rocprofv3 sees it, IN this run: one `rocprofv3 --kernel-trace --stats` pass (no counters) over
+    tools/traffic_probe.py in batch mode -- the same configuration, `launches` back-to-back launches from hs_run_batch.  Returns
+    ({"avg_us": average over ALL its dispatches in that process -- the figure `--stats` prints --, "steady_median_us": median of the second
+    half, "calls": n, "combine_avg_us": the slice-combine kernel's average or None}, how) or (None, why)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import sys
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="hisparse_ktrace_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--stats", "-d", out, "-o", "stats", "--", sys.executable, os.path.join(B.ROOT, "tools", "traffic_probe.py"),
+               name, impl_name, str(launches), "batch"]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+        hits = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+        if p.returncode != 0 or not hits:
+            return None, f"rocprofv3 --kernel-trace --stats failed (exit {p.returncode})"
+        d = sqlite3.connect(hits[0])
+        durs = [(e - s) / 1000.0 for s, e in d.execute("select start, end from kernels where name like ? order by start", (f"%{kernel}%",))]
+        if len(durs) < launches // 2:
+            return None, f"rocprofv3 --kernel-trace: {len(durs)} dispatches of {kernel}"
+        comb = [(e - s) / 1000.0 for s, e in d.execute("select start, end from kernels where name like '%combine_slices_kernel%'")]
+        steady = sorted(durs[len(durs) // 2:])
+        res = {"avg_us": round(sum(durs) / len(durs), 3), "steady_median_us": round(steady[len(steady) // 2], 3), "calls": len(durs),
+               "combine_avg_us": round(sum(comb) / len(comb), 3) if comb else None}
+    except (subprocess.TimeoutExpired, OSError, sqlite3.Error) as e:
+        return None, f"{type(e).__name__}: {e}"[:160]
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    B.log(rank, f"{name}: rocprofv3 --kernel-trace --stats in this run: {kernel} average {res['avg_us']:.2f} us over {res['calls']} dispatches, steady median {res['steady_median_us']:.2f} us"
+                + (f"; combine_slices_kernel {res['combine_avg_us']:.2f} us" if res["combine_avg_us"] else ""))
+    return res, f"rocprofv3 --kernel-trace --stats over tools/traffic_probe.py ({launches} back-to-back launches in 4 batches), this run"
+
+
 def bm_entry(name, paper_gops, res, impl="fixed"):
     """one line of the reference's sweep (sw/bm.sh) next to the paper's U280 figure for the same matrix and numeric mode (Table 3: fixed
     point; Table 7: float_pob = "PB", float_stall = "RI")"""

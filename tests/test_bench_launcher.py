@@ -44,6 +44,17 @@ def test_self_launch_two_ranks_over_gloo():
     assert "NOT a measurement" in line["backend"]
     assert line["config"]["nnz_total"] > line["config"]["nnz_per_gpu"] > 0
     assert line["same_workload_on_one_gpu"]["n_gpus"] == 1
+    # round 6: one entry per rank -- rows, non-zeros, plan, the slab on its own clock, kernel -- to read a real run against the prediction
+    assert len(line["per_rank"]) == 2 and sum(p[1] for p in line["per_rank"]) == line["config"]["nnz_total"]
+    assert all(p[3] > 0 and p[4] > 0 and isinstance(p[2], str) for p in line["per_rank"])
+    assert line["slowest_rank_local_step_us"] == max(p[3] for p in line["per_rank"])
+    assert line["one_gpu_prediction"] is None          # nobody predicted ppa_small
+
+
+def test_scale_matrix_names_the_matrix_to_shard():
+    rc, line, text = _bench(["--gpus", "2", "--backend", "gloo", "--scale-matrix", "gplus", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], {"HISPARSE_HIP_LIB": CPU_LIB}, timeout=900)
+    assert rc == 0, text
+    assert line["config"]["workload"].startswith("gplus, fixed IMPL") and line["config"]["nnz_total"] > 1.3e7
 
 
 def test_gloo_backend_refuses_the_hip_library():
@@ -115,6 +126,11 @@ def test_default_single_gpu_run_fits_the_drivers_tail():
     r = line["roofline"]
     assert r["bound"] == "hbm" and 0.3 < r["frac"] <= 1.0 and r["frac_whole_step"] <= r["frac"] * 1.02
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
+    # round 6: `frac` is the all-launch average (what rocprofv3 --stats prints), the steady state rides beside it, and the line says how many launches a step is
+    assert r["frac"] <= r["frac_steady"] <= 1.0 and r["kernel_ms"] >= r["kernel_ms_steady"] and r["launches_per_step"] == (2 if line["config"]["col_slices"] > 1 else 1)
+    live = r.get("rocprofv3_live")
+    if live:      # the live rocprofv3 --kernel-trace --stats pass agrees with the HIP-event average within 4 %
+        assert abs(live["kernel_avg_us"] - r["kernel_ms"] * 1e3) < 0.04 * live["kernel_avg_us"], (live, r["kernel_ms"])
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
     # one row per matrix of the sweep inside the stderr tail, and the details next to the script
     tail = p.stderr[-8000:]
@@ -146,6 +162,9 @@ def test_n_rank_dry_run_on_one_gpu(n):
     assert line["same_workload_on_one_gpu"]["n_gpus"] == 1
     assert line["compute_only"]["ms_per_step"] > 0 and line["exchange_every_step"]["ms_per_step"] > 0
     assert line["roofline"]["kernel_ms"] > 0
+    assert len(line["per_rank"]) == n and sum(p[1] for p in line["per_rank"]) == line["config"]["nnz_total"]
+    pred = line["one_gpu_prediction"]                  # the committed one-GPU prediction for mouse_gene split n ways rides beside the measured slabs
+    assert pred is not None and len(pred["slab_us"]) == n and pred["max_slab_us"] == max(pred["slab_us"])
     push = line["exchange_push"]
     assert push is not None and ("error" in push or push["equals_collective_on_every_rank"]), push
     last = [l for l in text.splitlines() if l.startswith("{")][-1]

@@ -178,3 +178,73 @@ def test_peer_gather_setup_fails_on_every_rank_together(tmp_path, fail_in):
         assert got == ["ok 1", "ok 1"]
     else:
         assert all(g.startswith("error rank 1: ") for g in got) and got[0] == got[1]
+
+
+def _worker8(rank, world, port, rows, out_path):
+    """world_size 8 over gloo, fewer granules than ranks: some ranks own NO rows (bench_dist.py refuses such a run; the layout helpers and
+    the collective must still be right for a caller that keeps the ranks in) and the slabs that exist are unequal (the last one is short)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from hisparse_amd import host, sharding
+    from oracle import oracle as orc
+    import cases
+
+    impl, granule, cols = 0, 128, 304
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    m = cases.random_csr(rows, cols, 0.03, 5, impl)
+    x = cases.random_x(cols, 5, impl)
+    bounds = sharding.split_rows_by_nnz(m.indptr, world, granule)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    y = np.zeros(0, dtype=np.uint32)
+    if hi > lo:
+        ip, ix, dv = sharding.slab_arrays(m.indptr, m.indices, m.data, lo, hi)
+        cp = host.format_matrix(host.CSRMatrix.from_arrays(hi - lo, cols, ip, ix, dv), impl, vb_bank=16, ob_bank=8, skip_empty_rows=True)
+        xw = host.pack_vector(impl, np.concatenate([x, np.zeros(cp.num_cols - cols, dtype=np.float32)]))
+        y = orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                     cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+        assert y.size == sharding.padded_rows(hi - lo, granule)
+    slab_rows = [None] * world
+    dist.all_gather_object(slab_rows, hi - lo)
+    assert slab_rows == [bounds[i + 1] - bounds[i] for i in range(world)]          # every rank computed the same split
+    layout = sharding.gather_layout(slab_rows, granule)
+    chunk = layout[0]
+    mine = torch.zeros(chunk, dtype=torch.int32)
+    mine[:y.size] = torch.from_numpy(y.view(np.int32))
+    gathered = torch.zeros(chunk * world, dtype=torch.int32)
+    dist.all_gather_into_tensor(gathered, mine)
+    whole = sharding.assemble(gathered.numpy().view(np.uint32), layout)
+    sums = [None] * world
+    dist.all_gather_object(sums, int(whole.astype(np.uint64).sum()))
+    assert len(set(sums)) == 1                                                      # ... and holds the same assembled y
+    if rank == world - 1:
+        np.save(out_path, np.concatenate([np.asarray(slab_rows, dtype=np.uint32), whole]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows", [700, 1500])
+def test_eight_ranks_with_empty_and_unequal_slabs(tmp_path, rows):
+    # 700 rows = 5 granules + 60 rows over 8 ranks: two ranks own nothing, the last slab is short; 1500 rows: every rank owns rows, unequal counts
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hisparse_amd import host, sharding
+    from oracle import oracle as orc
+    import cases
+
+    out = str(tmp_path / "y.npy")
+    mp.spawn(_worker8, args=(8, _free_port(), rows, out), nprocs=8, join=True)
+    got = np.load(out)
+    slab_rows, y = got[:8].astype(np.int64), got[8:]
+    assert slab_rows.sum() == rows and y.shape == (rows,)
+    if rows == 700:
+        assert (slab_rows == 0).sum() == 2 and slab_rows.max() == 128 and 60 in slab_rows
+    else:
+        assert (slab_rows > 0).all() and len(set(slab_rows.tolist())) > 1
+    m = cases.random_csr(rows, 304, 0.03, 5, 0)
+    cp = host.format_matrix(host.CSRMatrix.from_scipy(m), 0, vb_bank=16, ob_bank=8, skip_empty_rows=True)
+    xw = host.pack_vector(0, np.concatenate([cases.random_x(304, 5, 0), np.zeros(cp.num_cols - 304, dtype=np.float32)]))
+    want = orc.spmv(0, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions,
+                    cp.num_col_partitions, cp.ob_bank, cp.vb_bank)[:rows]
+    assert np.array_equal(y, want)
