@@ -542,9 +542,16 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
         // reference's benchmark loop, an iterative caller -- then read most of the image from the cache (profiles/r05_sweep_stream_policy.txt: one
         // rank's slab of ogbn-products split 8 ways, 124 MB: 39.5 -> 32.0 us; pokec, 247 MB: 61.1 -> 59.6-60.8 fixed, 69.3-70.3 -> 66.3-67.7 float_pob).
         // Larger images keep `nt` (a plain read loop over 1 GiB: 7.1 TB/s with it, 6.0 without: profiles/r02_hbm_read_bench.txt).  `stream_resident` = 0 | 1 decides otherwise.
+        // Round 6: the row-block kernels' PAIRS / DELTA streams too (spmv_kernels.hip: Ring<kRing | 4>), by their own rule (stream_tiles.h:
+        // kRowblockResidentMaxImageBytes): up to 1.25 x the cache where the blocks walk several units, tiny images whatever their shape; pure one-unit
+        // streams and everything larger keep `nt` (hollywood: +13 % without it).  OWNER / OWNER24 / BITMAP / LIGHT images are not affected.
         const char* opt = ctx_option(ctx, "HISPARSE_STREAM_RESIDENT");
         const uint64_t image_bytes = image_on_device ? tiles.image_bytes : uint64_t(tiles.image.size());
-        ctx->stream_resident = opt ? std::atoi(opt) != 0 : image_bytes <= hisparse::dev::kResidentMaxImageBytes;
+        const bool rowblock_stream = (tiles.format == hisparse::dev::kFormatPairs || tiles.format == hisparse::dev::kFormatDelta) && !tiles.light;
+        ctx->stream_resident = opt ? std::atoi(opt) != 0
+                               : rowblock_stream ? image_bytes <= hisparse::dev::kRowblockResidentMaxImageBytes &&
+                                                       (tiles.units.size() > tiles.blocks.size() || image_bytes <= hisparse::dev::kRowblockResidentSmallImageBytes)
+                                                 : image_bytes <= hisparse::dev::kResidentMaxImageBytes;
     }
     if (tiles.col_slices > 1) {
         // the combine pass carried into the next step's kernel (hs_context::carry_combine); `carry_combine` = 0 | 1 decides otherwise
@@ -623,6 +630,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
     s.load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     s.retiled_on_gpu = image_on_device;
     s.light_kernel = tiles.light ? 1u : 0u;
+    s.stream_resident = ctx->stream_resident && (tiles.format == hisparse::dev::kFormatSweep || ((tiles.format == hisparse::dev::kFormatPairs || tiles.format == hisparse::dev::kFormatDelta) && !tiles.light)) ? 1u : 0u;
     return HS_OK;
 }
 }  // namespace

@@ -101,24 +101,44 @@ __device__ __forceinline__ void dma_wait() {
 //   * the stream base is a loop-invariant SGPR pair, the per-step address a 32-bit vector offset (no 64-bit vector
 //     address arithmetic per step); s_nop 4 keeps 5 wait states between any scalar write of the base and its use;
 //   * `nt`: every element is read exactly once per SpMV, so it should not displace x in the L2 (measured: -8 %).
+//   * round 6: ... unless the image stays in the 256 MiB Infinity Cache from one SpMV to the next AND the blocks walk several (row range x
+//     sub-tile) units: then `sc1` without `nt` (the policy the SWEEP kernel takes for such images, spmv_sweep.hip) shortens the drained
+//     pipeline's refill at every unit border -- ogbl-ppa's 8-way slabs 16.8 -> 15.3 us, its 2-way slabs 34.8 -> 32.1, ogbl-ppa itself
+//     (313 MB) 54.2 -> 53.4, mouse_gene 33.8 -> 33.4, the sliced DELTA plans of the pruned-NN layers -2.5 % -- while a pure stream keeps `nt`:
+//     hollywood (872 MB) 137.5 -> 155 us without it, ogbn-products 203 -> 208, and the one-unit-per-block slabs of mouse_gene 12.4 -> 12.9 /
+//     20.0 -> 20.9 (profiles/r06_rowblock_stream_policy*.txt).  A plan-time choice (hs_api.cpp: stream_resident), a template parameter
+//     here: bit 2 of kRing.
 #ifndef HS_ROWBLOCK_STREAM_POLICY
-#define HS_ROWBLOCK_STREAM_POLICY "nt"      // cache-policy bits of the row-block kernels' stream loads.  A/B builds: make variant NAME=rb_sc1 DEFS='-DHS_ROWBLOCK_STREAM_POLICY="\"sc1\""' --
-#endif                                      // the SWEEP kernel gained 2-19 % without `nt` on images that fit the Infinity Cache (spmv_sweep.hip); not yet measured here
+#define HS_ROWBLOCK_STREAM_POLICY "nt"      // the stream loads of an image that is streamed from HBM every time
+#endif
+#ifndef HS_ROWBLOCK_RESIDENT_POLICY
+#define HS_ROWBLOCK_RESIDENT_POLICY "sc1"   // ... and of one that stays in the Infinity Cache (kRing & 4)
+#endif
+// one asm statement per cache policy, chosen at compile time (the policy is part of the instruction text)
+#define HS_BY_POLICY(kRes, STATEMENT)                                 \
+    do {                                                              \
+        if constexpr (kRes) { STATEMENT(HS_ROWBLOCK_RESIDENT_POLICY); } \
+        else { STATEMENT(HS_ROWBLOCK_STREAM_POLICY); }                \
+    } while (0)
 #define HS_RING_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", \
                       "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"
 constexpr int kMaxDepth = 16;
 constexpr int kOwner24Depth = 3;     // OWNER24: records in flight per wavefront (5.25 KiB)
 
-// kRing: 0 = PAIRS / OWNER with 32-bit position words, 1 = DELTA, 2 = PAIRS / OWNER with 24-bit position words
+// kRing & 3: 0 = PAIRS / OWNER with 32-bit position words, 1 = DELTA, 2 = PAIRS / OWNER with 24-bit position words, 3 = OWNER24 records;
+// kRing & 4: the image stays in the Infinity Cache (stream loads with HS_ROWBLOCK_RESIDENT_POLICY instead of `nt`)
+template <int kFmt, bool kRes>
+struct RingT;
 template <int kRing>
-struct Ring;
-template <>
-struct Ring<0> {   // PAIRS: one dwordx2 per lane and step
+using Ring = RingT<(kRing & 3), (kRing & 4) != 0>;
+template <bool kRes>
+struct RingT<0, kRes> {   // PAIRS: one dwordx2 per lane and step
     static constexpr uint32_t kLaneBytes = 8;
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %2, %3 " HS_ROWBLOCK_STREAM_POLICY ::"n"(2 * K), "n"(2 * K + 1), "v"(byte_off + lane_off), "s"(base)
-                     : "memory", HS_RING_AGPRS);
+#define HS_ISSUE(P) asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %2, %3 " P ::"n"(2 * K), "n"(2 * K + 1), "v"(byte_off + lane_off), "s"(base) : "memory", HS_RING_AGPRS)
+        HS_BY_POLICY(kRes, HS_ISSUE);
+#undef HS_ISSUE
     }
     template <int K, int kDepth>
     static __device__ __forceinline__ void take(uint32_t& value, uint32_t& where) {
@@ -134,15 +154,18 @@ struct Ring<0> {   // PAIRS: one dwordx2 per lane and step
                      : "n"(2 * K), "n"(2 * K + 1), "n"(2 * K + 2), "n"(2 * K + 3), "n"(kDepth - 2) : "memory");
     }
 };
-template <>
-struct Ring<1> {    // DELTA: a record = two slots per lane: {value A, value B} as one dwordx2, {gap A, gap B} as one dword
+template <bool kRes>
+struct RingT<1, kRes> {    // DELTA: a record = two slots per lane: {value A, value B} as one dwordx2, {gap A, gap B} as one dword
     static constexpr uint32_t kLaneBytes = 8;
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
         static_assert(2 * K + 1 < kMaxDepth && K + kMaxDepth < 2 * kMaxDepth, "values in a0..a15, gap words in a16..a23: ring depth <= 8");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %3, %5 " HS_ROWBLOCK_STREAM_POLICY "\n\tglobal_load_dword a[%2], %4, %5 offset:512 " HS_ROWBLOCK_STREAM_POLICY ::"n"(2 * K), "n"(2 * K + 1),
-                     "n"(K + kMaxDepth), "v"(byte_off + lane_off), "v"(byte_off + lane_off / 2), "s"(base)
-                     : "memory", HS_RING_AGPRS);
+#define HS_ISSUE(P)                                                                                                                                         \
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 a[%0:%1], %3, %5 " P "\n\tglobal_load_dword a[%2], %4, %5 offset:512 " P ::"n"(2 * K), "n"(2 * K + 1),     \
+                 "n"(K + kMaxDepth), "v"(byte_off + lane_off), "v"(byte_off + lane_off / 2), "s"(base)                                                     \
+                 : "memory", HS_RING_AGPRS)
+        HS_BY_POLICY(kRes, HS_ISSUE);
+#undef HS_ISSUE
     }
     // value A, value B, gaps (A in the low half, B in the high half)
     template <int K, int kDepth>
@@ -151,15 +174,18 @@ struct Ring<1> {    // DELTA: a record = two slots per lane: {value A, value B} 
                      : "=v"(value_a), "=v"(value_b), "=v"(gaps) : "n"(2 * K), "n"(2 * K + 1), "n"(K + kMaxDepth), "n"(2 * (kDepth - 1)) : "memory");
     }
 };
-template <>
-struct Ring<2> {    // 24-bit position words: a 448-byte step = 64 value dwords, then 64 x 3 bytes (local_row << 13 | local_col)
+template <bool kRes>
+struct RingT<2, kRes> {    // 24-bit position words: a 448-byte step = 64 value dwords, then 64 x 3 bytes (local_row << 13 | local_col)
     static constexpr uint32_t kLaneBytes = 4;
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane_off) {
         // the position word is read as an UNALIGNED dword at byte 256 + 3 * lane (its top byte belongs to the next lane)
-        asm volatile("s_nop 4\n\tglobal_load_dword a[%0], %2, %4 " HS_ROWBLOCK_STREAM_POLICY "\n\tglobal_load_dword a[%1], %3, %4 offset:256 " HS_ROWBLOCK_STREAM_POLICY ::"n"(K),
-                     "n"(K + kMaxDepth), "v"(byte_off + lane_off), "v"(byte_off + lane_off - lane_off / 4), "s"(base)
-                     : "memory", HS_RING_AGPRS);
+#define HS_ISSUE(P)                                                                                                                       \
+    asm volatile("s_nop 4\n\tglobal_load_dword a[%0], %2, %4 " P "\n\tglobal_load_dword a[%1], %3, %4 offset:256 " P ::"n"(K),           \
+                 "n"(K + kMaxDepth), "v"(byte_off + lane_off), "v"(byte_off + lane_off - lane_off / 4), "s"(base)                        \
+                 : "memory", HS_RING_AGPRS)
+        HS_BY_POLICY(kRes, HS_ISSUE);
+#undef HS_ISSUE
     }
     template <int K, int kDepth>
     static __device__ __forceinline__ void take(uint32_t& value, uint32_t& where) {
@@ -177,15 +203,18 @@ struct Ring<2> {    // 24-bit position words: a 448-byte step = 64 value dwords,
         where1 &= 0xffffffu;
     }
 };
-template <>
-struct Ring<3> {    // OWNER24: a record = FOUR steps per lane: the 4 value words as one dwordx4, the 4 x 24-bit position words as one dwordx3
+template <bool kRes>
+struct RingT<3, kRes> {    // OWNER24: a record = FOUR steps per lane: the 4 value words as one dwordx4, the 4 x 24-bit position words as one dwordx3
     // ring slot K (K < 4 records in flight): values in a[4K : 4K+3], position words in a[16+4K : 16+4K+2] (even-aligned tuples)
     template <int K>
     static __device__ __forceinline__ void issue(const uint8_t* base, uint32_t byte_off, uint32_t lane16, uint32_t lane12) {
         static_assert(K < 4 && 16 + 4 * K + 2 < 2 * kMaxDepth, "a0..a15: values of four records, a16..a30: their position words");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 a[%0:%1], %4, %6 " HS_ROWBLOCK_STREAM_POLICY "\n\tglobal_load_dwordx3 a[%2:%3], %5, %6 offset:1024 " HS_ROWBLOCK_STREAM_POLICY ::"n"(4 * K), "n"(4 * K + 3),
-                     "n"(16 + 4 * K), "n"(16 + 4 * K + 2), "v"(byte_off + lane16), "v"(byte_off + lane12), "s"(base)
-                     : "memory", HS_RING_AGPRS);
+#define HS_ISSUE(P)                                                                                                                                          \
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 a[%0:%1], %4, %6 " P "\n\tglobal_load_dwordx3 a[%2:%3], %5, %6 offset:1024 " P ::"n"(4 * K), "n"(4 * K + 3), \
+                 "n"(16 + 4 * K), "n"(16 + 4 * K + 2), "v"(byte_off + lane16), "v"(byte_off + lane12), "s"(base)                                            \
+                 : "memory", HS_RING_AGPRS)
+        HS_BY_POLICY(kRes, HS_ISSUE);
+#undef HS_ISSUE
     }
     template <int K, int kDepth>
     static __device__ __forceinline__ void take(uint32_t (&v)[4], uint32_t (&w)[3]) {
@@ -263,7 +292,7 @@ __device__ __forceinline__ void timeline_stamp(uint32_t k, uint32_t wave, uint32
 template <bool kFloat, int kRing, int kAblate, int kDepth, bool kDense, int K>
 __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
     using R = Rows<kFloat>;
-    constexpr bool kDelta = kRing == 1, k24 = kRing == 2;
+    constexpr bool kDelta = (kRing & 3) == 1, k24 = (kRing & 3) == 2;      // (kRing & 4: the cache policy of the stream loads, Ring<>)
     constexpr uint32_t kStride = kDelta ? kRecordBytes : k24 ? kWaveStrideBytes24 : kWaveStrideBytes;
     constexpr uint32_t kColMask = k24 ? kSubTileCols - 1u : 0xffffu, kRowShift = k24 ? kOwnerColBits : 16u;
     const uint32_t s = c.base + K;
@@ -294,7 +323,7 @@ __device__ __forceinline__ bool consume_step(Consumer<kFloat>& c) {
         // valid row of the block; fixed-point padding is (gap 0, value 0); float padding is a bridge whose row is clamped to the
         // spare accumulator ys[nrows] (0 * x could be NaN for a non-finite x, so float bridge slots add a literal 0).
         uint32_t value_a, value_b, gaps;
-        Ring<1>::template take_record<K, kDepth>(value_a, value_b, gaps);
+        Ring<kRing>::template take_record<K, kDepth>(value_a, value_b, gaps);
         auto slot = [&](uint32_t value, uint32_t gap) {
             c.pos += gap;
             uint32_t row = c.pos / kSubTileCols;
@@ -659,7 +688,7 @@ __device__ __forceinline__ void consumer_begin(Consumer<kFloat>& c, const uint8_
                                                uint32_t lane, const uint32_t* xs, uint32_t ring, typename Rows<kFloat>::acc_t* ys, uint32_t nrows,
                                                uint32_t total, uint32_t first_end) {
     static_assert(kDepth <= kMaxDepth, "the ring lives in a0..a31");
-    constexpr bool kDelta = kRing == 1, k24 = kRing == 2;
+    constexpr bool kDelta = (kRing & 3) == 1, k24 = (kRing & 3) == 2;      // (kRing & 4: the cache policy of the stream loads, Ring<>)
     constexpr uint32_t kStride = kDelta ? kRecordBytes : kOwner ? kChunkBytes : k24 ? kWaveStrideBytes24 : kWaveStrideBytes;
     c.stream = scalar_pointer(stream);
     c.unit = unit; c.U = U; c.wave = wave; c.lane = lane; c.ring = ring; c.nrows = nrows;
@@ -1147,8 +1176,10 @@ uint32_t spmv_lds_bytes(uint32_t max_block_rows, uint32_t ring_buffers, uint32_t
 #endif
 
 // (float, ring format, ablate, depth): the product variants first, then the profiling builds (fixed point only)
+// (ring 4 / 5: PAIRS / DELTA images that stay in the Infinity Cache -- the same kernels with `sc1` stream loads instead of `nt`)
 #define HS_FOR_EACH_PRODUCT_VARIANT(X)                                                                           \
-    X(true, 0, 0, 8) X(true, 1, 0, 8) X(false, 0, 0, 8) X(false, 1, 0, 8) X(true, 2, 0, 8) X(false, 2, 0, 8)
+    X(true, 0, 0, 8) X(true, 1, 0, 8) X(false, 0, 0, 8) X(false, 1, 0, 8) X(true, 2, 0, 8) X(false, 2, 0, 8)      \
+    X(true, 4, 0, 8) X(true, 5, 0, 8) X(false, 4, 0, 8) X(false, 5, 0, 8)
 #ifndef HISPARSE_PROFILING
 #define HS_FOR_EACH_VARIANT(X) HS_FOR_EACH_PRODUCT_VARIANT(X)
 #else
@@ -1202,7 +1233,7 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
 #undef X
         return hipErrorInvalidValue;
     }
-    const int ring = a.format == kFormatDelta ? 1 : a.format == kFormatPairs24 ? 2 : 0;
+    int ring = a.format == kFormatDelta ? 1 : a.format == kFormatPairs24 ? 2 : 0;
     const dim3 grid(a.num_workgroups), block(kThreads);
     const uint32_t x_base = a.lds_bytes - a.ring_buffers * kBufBytes;
     const CarriedCombine carry = carried(a);
@@ -1210,6 +1241,9 @@ hipError_t launch_spmv(bool is_float, const SpmvLaunch& a, hipStream_t stream) {
     // prefetch depth; read per launch, a tool may change them between launches.  The product library refuses to run with either set.
     int ablate = 0, depth = 8;
     if (!profiling_switches(ablate, depth)) return hipErrorInvalidValue;
+    // PAIRS / DELTA images the plan found resident in the Infinity Cache: the `sc1` instantiation (Ring<kRing | 4>); OWNER / OWNER24 / PAIRS24
+    // images and the profiling builds keep `nt`
+    if (a.stream_resident && ring < 2 && ablate == 0 && depth == 8 && (a.format == kFormatPairs || a.format == kFormatDelta)) ring |= 4;
     bool launched = false;
     // timeline build: HISPARSE_ABLATE=512 HISPARSE_TIMELINE_OUT=file -> the launch is synchronised and its timestamps (workgroups x
     // kTimelineBlocks x 2 wavefronts x kTimelineStamps u64, 100 MHz) overwrite the file (tools/rowblock_timeline.py)

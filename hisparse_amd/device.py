@@ -33,7 +33,7 @@ class Stats(C.Structure):
     _fields_ = [("nnz", C.c_uint64), ("cpsr_bytes", C.c_uint64), ("stream_bytes", C.c_uint64), ("stream_elements", C.c_uint64),
                 ("num_blocks", C.c_uint32), ("num_units", C.c_uint32), ("num_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("num_compute_units", C.c_uint32), ("col_slices", C.c_uint32), ("ring_buffers", C.c_uint32), ("stream_format", C.c_uint32),
-                ("load_seconds", C.c_double), ("retiled_on_gpu", C.c_uint32), ("light_kernel", C.c_uint32)]
+                ("load_seconds", C.c_double), ("retiled_on_gpu", C.c_uint32), ("light_kernel", C.c_uint32), ("stream_resident", C.c_uint32), ("reserved0", C.c_uint32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

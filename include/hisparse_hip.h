@@ -79,6 +79,8 @@ typedef struct {
     double load_seconds;        /* wall time of the last hs_load_matrix (decode + re-tile + H2D) */
     uint32_t retiled_on_gpu;    /* 1: the per-non-zero passes of the re-tiling ran on the device (gpu_tiles.h); 0: on the host */
     uint32_t light_kernel;      /* 1: the LIGHT plan -- a small matrix run by the 256-thread single-launch kernel (spmv_light_kernel) over a PAIRS image */
+    uint32_t stream_resident;   /* 1: the plan found the image resident in the 256 MiB Infinity Cache across consecutive SpMVs and streams it WITHOUT the non-temporal hint (SWEEP images up to the cache size; PAIRS / DELTA images by the rule of stream_tiles.h: kRowblockResidentMaxImageBytes); option "stream_resident" = 0 | 1 decides otherwise */
+    uint32_t reserved0;
 } hs_stats;
 
 const char* hs_strerror(int code);
@@ -155,7 +157,7 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
  * (pairs|delta|owner|owner24|sweep|bitmap), col_slices, max_rows, cross_partitions (0: row blocks end at the reference's row-partition borders), spmm_vectors (4: plan the image for the four-column SpMM kernel, see hs_spmm), row_runs, delta_deal (wave: the dealing of DELTA runs of rounds 1-4), pow2_slices (1: column-slice counts 1, 2, 4, 8 only for matrices of more than sixteen sub-tiles, the rule of rounds 1-4), aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
  * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), sweep (0|1: the
  * column-ordered format of very sparse matrices), plan_debug; call-time keys: spmm_fused, spmm_mfma,
- * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph, batch_graph (hs_run_batch); carry_combine (0|1, plan-time: see hs_run), stream_resident (0|1, plan-time: SWEEP images streamed without the non-temporal hint; default: images up to 256 MiB, the Infinity Cache).  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
+ * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph, batch_graph (hs_run_batch); carry_combine (0|1, plan-time: see hs_run), stream_resident (0|1, plan-time: SWEEP and PAIRS / DELTA images streamed without the non-temporal hint; default: SWEEP images up to 256 MiB, the Infinity Cache; PAIRS / DELTA images up to 320 MiB whose blocks walk several units, or up to 32 MiB: hs_stats.stream_resident says what the plan took).  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
  * Options set here win over the environment variable of the same name, which stays as the fallback for tools and tests.  None of them
  * changes WHAT is computed.  The switches that do (HISPARSE_ABLATE, HISPARSE_DEPTH: profiling builds with parts of the work removed) are
  * not options: they exist only in libhisparse_hip_prof.so, and this library refuses to run (HS_ERR_BAD_ARG from hs_run, hs_run_partition,

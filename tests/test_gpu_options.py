@@ -113,3 +113,51 @@ def test_run_batch_plain_and_graph_replay_give_the_same_words():
             eng.load_vector(xw)
             eng.run_batch(3)
             assert np.array_equal(eng.read_result(), want)
+
+
+# ---- round 6: the row-block kernels' stream loads with or without the non-temporal hint (plan-time, hs_stats.stream_resident) ----------------
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("fmt,slices", [("pairs", 1), ("pairs", 4), ("delta", 1), ("delta", 3)])
+def test_rowblock_stream_policy_does_not_change_the_result(impl, fmt, slices):
+    """Ring<kRing | 4> (spmv_kernels.hip): the `sc1` instantiation of the PAIRS / DELTA kernels for images that stay in the Infinity Cache, and
+    the `nt` one, against the oracle -- single launches, a burst (the carried combine on sliced plans) and the partition loop."""
+    from oracle import oracle as orc
+    rows, cols = 40000, 70000
+    g = host.CSRMatrix.generate("powerlaw", rows, cols, a=2.2e6, b=0.35, c=1.0 if impl == 0 else 2.0, seed=71 + impl)
+    cp = host.format_matrix(g, impl, skip_empty_rows=True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 13, impl))
+    want = orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+    got = {}
+    for resident in ("0", "1"):
+        with device.SpmvEngine(impl) as eng:
+            eng.set_option("stream_format", fmt)
+            eng.set_option("col_slices", str(slices))
+            eng.set_option("light", "0")
+            eng.set_option("stream_resident", resident)
+            eng.load_matrix(cp)
+            st = eng.stats()
+            assert device.STREAM_FORMATS[st["stream_format"]] == fmt and st["col_slices"] == slices and st["stream_resident"] == int(resident)
+            eng.load_vector(xw)
+            eng.run()
+            one = eng.read_result()
+            eng.run_batch(4)
+            burst = eng.read_result()
+            for j in range(cp.num_row_partitions):
+                eng.run_partition(j, cp.part_len(j))
+            parts = eng.read_result()
+        for y in (one, burst, parts):
+            assert np.array_equal(y, want) if impl == 0 else cases.float_close(y, want)
+        got[resident] = one
+    assert np.array_equal(got["0"], got["1"])          # the cache policy of a load cannot change a bit, float modes included
+
+
+def test_stream_resident_is_a_plan_time_choice_by_format_and_size():
+    # what the plan takes by itself: a small multi-unit PAIRS / DELTA image -> resident; OWNER24 / BITMAP / LIGHT images never (their kernels have one policy)
+    cp, xw = _case()
+    for fmt, light, want in (("pairs", "0", 1), ("delta", "0", 1), ("owner24", "0", 0), ("pairs", "1", 0)):
+        with device.SpmvEngine(0) as eng:
+            eng.set_option("stream_format", fmt)
+            eng.set_option("light", light)
+            eng.load_matrix(cp)
+            st = eng.stats()
+            assert st["stream_resident"] == want, (fmt, light, st)

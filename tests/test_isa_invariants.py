@@ -191,17 +191,27 @@ def test_sweep_ring_holds_chunks_and_gathers_behind_one_counted_wait(shipped):
         assert not any("global_load_lds" in i for i in body)
 
 
-def test_stream_loads_are_non_temporal_and_loaders_use_lds_dma(shipped):
+def test_stream_loads_carry_their_plans_cache_policy_and_loaders_use_lds_dma(shipped):
+    """kRing & 4 (round 6): the PAIRS / DELTA instantiations for images that stay in the Infinity Cache stream with `sc1`, every other
+    row-block instantiation with `nt` -- all stream loads of one kernel with the same policy, and each policy exists for fixed and float."""
     meta, code = shipped
+    seen = set()
     for n in meta:
         m = ROWBLOCK.search(n)
         if not m or int(m.group(3)) != 0:
             continue
+        ring = int(m.group(2))
+        assert ring in (0, 1, 2, 3, 4, 5), f"{n}: unknown ring format"
+        policy = " sc1" if ring & 4 else " nt"
+        seen.add((int(m.group(1)), ring))
         body = code[n]
         stream = [i for i in body if i.startswith("global_load_dword") and AGPR.search(i.split(" ", 1)[1])]
-        assert stream and all(i.endswith(" nt") for i in stream), f"{n}: stream loads without the nt policy"
+        assert stream and all(i.endswith(policy) for i in stream), f"{n}: stream loads without the{policy} policy"
         assert any("global_load_lds_dwordx4" in i for i in body), f"{n}: the x ring is not refilled by LDS-DMA"
         assert any(i.startswith("s_setprio") for i in body), f"{n}: loader wavefronts without raised priority"
+    for is_float in (0, 1):
+        for ring in (0, 1, 4, 5):
+            assert (is_float, ring) in seen, f"no row-block kernel for float={is_float}, ring={ring}"
 
 
 def test_spmm_kernel_uses_the_matrix_engine(shipped):
@@ -226,6 +236,7 @@ def test_product_library_carries_no_profiling_instantiation(shipped):
         is_float, ring, ablate, depth, owner = (int(g) for g in m.groups())
         assert ablate == 0, f"profiling instantiation in the product library: {m.group(0)}"
         assert depth == (3 if ring == 3 else 8), f"experimental prefetch depth in the product library: {m.group(0)}"
+        assert ring in (0, 1, 2, 3, 4, 5) and not (owner and ring & 4), f"unexpected ring format: {m.group(0)}"
     bitmap = [re.search(r"spmv_bitmap_kernelILb([01])ELi(\d+)E", n) for n in meta if "spmv_bitmap_kernel" in n]
     assert bitmap and all(int(m.group(2)) == 0 for m in bitmap)
     light = [re.search(r"spmv_light_kernelILb([01])ELi(\d+)E", n) for n in meta if "spmv_light_kernel" in n]

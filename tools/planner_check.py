@@ -1,0 +1,216 @@
+"""Out-of-sample check of the load-time planner: over matrices from generator families NONE of the planner's
+thresholds was fitted on -- banded, block-diagonal, R-MAT with other quadrant probabilities, wide bipartite, tall-narrow, Erdos-Renyi,
+hub rows over a sparse body, dense-row layers of other shapes, and 2- / 4- / 8-way row slabs of some of them -- is the plan the library
+takes BY ITSELF within x % of the best plan that can be FORCED (hs_set_option stream_format / col_slices / light)?
+
+    python tools/planner_check.py [--quick] [--only NAME,...] [--json FILE]
+
+Per matrix: the planner's own choice, every element / bitmap format forced (the planner still picks the slice count for it), and the
+planner's format at half / twice its slice count; each variant: load, a result check against the planner's own y (bit-exact in fixed
+point, tolerance in float), whole-step time = best of 3 x K back-to-back steps between two HIP events.  The reference's analogue is its
+design-space sweep, performance_model/design_space_exp.cpp:496-547.  tests/test_gpu_planner.py runs a subset of this and asserts the ratio."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hisparse_amd import device, host  # noqa: E402
+
+FIXED, POB, STALL = 0, 1, 2
+
+
+def _csr(rows, cols, r, c, seed, impl):
+    """scipy CSR from coordinate draws (duplicates dropped), values uniform (0, 1) in fixed point, N(0, 1) otherwise"""
+    import scipy.sparse as sp
+    key = np.unique(r.astype(np.int64) * cols + c.astype(np.int64))
+    r, c = (key // cols).astype(np.int64), (key % cols).astype(np.int64)
+    rng = np.random.default_rng(seed + 1)
+    v = (rng.uniform(0.0, 1.0, key.size) if impl == FIXED else rng.normal(size=key.size)).astype(np.float32)
+    m = sp.csr_matrix((v, (r, c)), shape=(rows, cols))
+    m.sort_indices()
+    return m
+
+
+def banded(n, per_row, half_width, seed, impl):
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(n, dtype=np.int64), per_row)
+    c = np.clip(r + rng.integers(-half_width, half_width + 1, r.size), 0, n - 1)
+    return _csr(n, n, r, c, seed, impl)
+
+
+def block_diagonal(n, block, density, seed, impl):
+    rng = np.random.default_rng(seed)
+    per_row = max(1, int(block * density))
+    r = np.repeat(np.arange(n, dtype=np.int64), per_row)
+    c = np.minimum((r // block) * block + rng.integers(0, block, r.size), n - 1)
+    return _csr(n, n, r, c, seed, impl)
+
+
+def rmat(scale, edges, a, b, c, seed, impl, symmetric=False):
+    rng = np.random.default_rng(seed)
+    n = 1 << scale
+    i = np.zeros(edges, dtype=np.int64)
+    j = np.zeros(edges, dtype=np.int64)
+    for _ in range(scale):
+        u = rng.random(edges)
+        q = (u >= a).astype(np.int64) + (u >= a + b) + (u >= a + b + c)
+        i = (i << 1) | (q >> 1)
+        j = (j << 1) | (q & 1)
+    perm = rng.permutation(n)                      # scrambled ids: hubs spread over the rows
+    i, j = perm[i], perm[j]
+    if symmetric:
+        i, j = np.concatenate([i, j]), np.concatenate([j, i])
+    return _csr(n, n, i, j, seed, impl)
+
+
+def uniform(rows, cols, per_row, seed, impl):
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(rows, dtype=np.int64), per_row)
+    return _csr(rows, cols, r, rng.integers(0, cols, r.size), seed, impl)
+
+
+def hubs(n, per_row, hub_rows, hub_nnz, seed, impl):
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(n, dtype=np.int64), per_row)
+    c = rng.integers(0, n, r.size)
+    hr = np.repeat(rng.choice(n, hub_rows, replace=False), hub_nnz)
+    return _csr(n, n, np.concatenate([r, hr]), np.concatenate([c, rng.integers(0, n, hr.size)]), seed, impl)
+
+
+def dense_rows(rows, cols, density, seed, impl):
+    rng = np.random.default_rng(seed)
+    per_row = int(cols * density)
+    r = np.repeat(np.arange(rows, dtype=np.int64), per_row)
+    return _csr(rows, cols, r, rng.integers(0, cols, r.size), seed, impl)
+
+
+def slab(m, ways, which=0):
+    """rows [which, which + 1) / ways of m by row count (a rank's slab keeps all columns)"""
+    lo, hi = m.shape[0] * which // ways // 128 * 128, m.shape[0] * (which + 1) // ways // 128 * 128
+    return m[lo:hi]
+
+
+# (name, numeric mode, builder) -- none of these shapes, degree laws or densities is among the matrices the planner's constants were measured on
+# (hisparse_amd/datasets.py: Chung-Lu squares with beta .3-.45, one symmetric R-MAT .57/.19/.19, Bernoulli 512 x 33 288 layers)
+CASES = [
+    ("banded_400k_d40_w2k", FIXED, lambda: banded(400_000, 40, 2_000, 1, FIXED)),
+    ("banded_1m_d12_w50k", STALL, lambda: banded(1_000_000, 12, 50_000, 2, STALL)),
+    ("blockdiag_200k_b512_p10", FIXED, lambda: block_diagonal(200_000, 512, 0.10, 3, FIXED)),
+    ("blockdiag_600k_b64_p50", POB, lambda: block_diagonal(600_000, 64, 0.5, 4, POB)),
+    ("rmat19_45_15_15", FIXED, lambda: rmat(19, 20_000_000, 0.45, 0.15, 0.15, 5, FIXED)),
+    ("rmat21_70_10_10", STALL, lambda: rmat(21, 30_000_000, 0.70, 0.10, 0.10, 6, STALL)),
+    ("rmat20_sym_50_20_20", FIXED, lambda: rmat(20, 12_000_000, 0.50, 0.20, 0.20, 7, FIXED, symmetric=True)),
+    ("bipartite_20k_x_2m_200", FIXED, lambda: uniform(20_000, 2_000_000, 200, 8, FIXED)),
+    ("bipartite_100k_x_4m_60", POB, lambda: uniform(100_000, 4_000_000, 60, 9, POB)),
+    ("tall_2m_x_50k_10", FIXED, lambda: uniform(2_000_000, 50_000, 10, 10, FIXED)),
+    ("tall_3m_x_8k_6", STALL, lambda: uniform(3_000_000, 8_192, 6, 11, STALL)),
+    ("er_300k_30", FIXED, lambda: uniform(300_000, 300_000, 30, 12, FIXED)),
+    ("er_1500k_8", POB, lambda: uniform(1_500_000, 1_500_000, 8, 13, POB)),
+    ("hubs_500k_15_plus_50x200k", FIXED, lambda: hubs(500_000, 15, 50, 200_000, 14, FIXED)),
+    ("dense_1024_x_16k_35", POB, lambda: dense_rows(1024, 16_384, 0.35, 15, POB)),
+    ("dense_2048_x_8k_15", FIXED, lambda: dense_rows(2048, 8_192, 0.15, 16, FIXED)),
+    ("dense_256_x_64k_8", FIXED, lambda: dense_rows(256, 65_536, 0.08, 17, FIXED)),
+    ("dense_4096_x_4k_60", STALL, lambda: dense_rows(4096, 4_096, 0.60, 18, STALL)),
+    ("slab2_of_rmat19", FIXED, lambda: slab(rmat(19, 20_000_000, 0.45, 0.15, 0.15, 5, FIXED), 2)),
+    ("slab8_of_rmat19", FIXED, lambda: slab(rmat(19, 20_000_000, 0.45, 0.15, 0.15, 5, FIXED), 8, 3)),
+    ("slab4_of_banded_400k", FIXED, lambda: slab(banded(400_000, 40, 2_000, 1, FIXED), 4, 1)),
+    ("slab8_of_er_300k", FIXED, lambda: slab(uniform(300_000, 300_000, 30, 12, FIXED), 8, 5)),
+    ("slab4_of_bipartite_100k", POB, lambda: slab(uniform(100_000, 4_000_000, 60, 9, POB), 4, 2)),
+    ("slab8_of_tall_2m", FIXED, lambda: slab(uniform(2_000_000, 50_000, 10, 10, FIXED), 8, 7)),
+]
+QUICK = ("banded_400k_d40_w2k", "blockdiag_600k_b64_p50", "rmat19_45_15_15", "bipartite_20k_x_2m_200", "tall_3m_x_8k_6", "er_1500k_8",
+         "dense_2048_x_8k_15", "slab8_of_rmat19", "slab4_of_bipartite_100k")
+FORMATS = ("pairs", "delta", "owner24", "sweep", "bitmap")
+
+
+def time_plan(impl, csr, xw, options, steps, want=None):
+    """(whole-step us, plan string, y) of one variant, or (None, why, None) when the library refuses the forced plan"""
+    try:
+        with device.SpmvEngine(impl) as eng:
+            for k, v in options.items():
+                eng.set_option(k, v)
+            eng.load_matrix_csr(csr)
+            st = eng.stats()
+            eng.load_vector(xw)
+            eng.run()
+            y = eng.read_result()
+            if want is not None:
+                same = np.array_equal(y, want) if impl == FIXED else np.allclose(y.view(np.float32), want.view(np.float32), rtol=1e-4, atol=1e-4)
+                if not same:
+                    return None, "RESULT DIFFERS from the planner's own plan", None
+            for _ in range(300):
+                eng.run()
+            eng.sync()
+            best = min(eng.time_runs(5, steps, kernel=False)[0] / steps for _ in range(3)) * 1e3
+            plan = device.STREAM_FORMATS[st["stream_format"]] + ("/light" if st.get("light_kernel") else "") + f" x{st['col_slices']}"
+            return best, plan, y
+    except device.DeviceError as e:
+        return None, str(e)[:80], None
+
+
+def check(name, impl, m, steps=200, log=print):
+    csr = host.CSRMatrix.from_scipy(m)
+    rng = np.random.default_rng(99)
+    cols8 = (m.shape[1] + 7) // 8 * 8
+    x = rng.uniform(0.0, 2.0, cols8).astype(np.float32) if impl == FIXED else rng.normal(size=cols8).astype(np.float32)
+    xw = host.pack_vector(impl, x)
+    own_us, own_plan, y = time_plan(impl, csr, xw, {}, steps)
+    if own_us is None:
+        raise RuntimeError(f"{name}: the planner's own plan does not load: {own_plan}")
+    own_fmt, own_slices = own_plan.split(" x")[0], int(own_plan.split(" x")[1])
+    variants = {}
+    for f in FORMATS:
+        variants[f] = {"stream_format": f, "light": "0"}
+    if m.nnz <= 3_000_000:
+        variants["light"] = {"light": "1"}
+    base = own_fmt.split("/")[0]
+    for s in sorted({max(1, own_slices // 2), own_slices * 2, 1 if own_slices > 2 else own_slices} - {own_slices}):
+        if s <= 16:
+            variants[f"{base} x{s}"] = {"stream_format": base, "col_slices": str(s), "light": "0"}
+    rows = []
+    for tag, opts in variants.items():
+        us, plan, _ = time_plan(impl, csr, xw, opts, steps, want=y)
+        rows.append({"forced": tag, "us": None if us is None else round(us, 2), "plan": plan})
+    timed = [r for r in rows if r["us"] is not None and "DIFFERS" not in r["plan"]]
+    best = min(timed, key=lambda r: r["us"]) if timed else None
+    ratio = own_us / min(own_us, best["us"]) if best else 1.0
+    res = {"matrix": name, "impl": ["fixed", "float_pob", "float_stall"][impl], "shape": list(m.shape), "nnz": int(m.nnz), "planner": own_plan, "planner_us": round(own_us, 2),
+           "best_forced": best["plan"] if best else None, "best_forced_us": best["us"] if best else None, "planner_over_best": round(ratio, 3),
+           "wrong_results": [r["forced"] for r in rows if "DIFFERS" in r["plan"]], "variants": rows}
+    log(f"{name:30s} {res['impl']:11s} {m.shape[0]:>8d} x {m.shape[1]:<8d} nnz {m.nnz:>9d}  planner {own_plan:14s} {own_us:8.2f} us | best forced "
+        f"{(best['plan'] if best else '-'):14s} {(best['us'] if best else 0):8.2f} us | planner / best {ratio:5.3f}" + ("  WRONG RESULT: " + ",".join(res["wrong_results"]) if res["wrong_results"] else ""))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--steps", type=int, default=200)
+    a = ap.parse_args()
+    pick = set(a.only.split(",")) if a.only else set(QUICK) if a.quick else None
+    out = []
+    for name, impl, build in CASES:
+        if pick and name not in pick:
+            continue
+        t0 = time.perf_counter()
+        m = build()
+        out.append(check(name, impl, m, a.steps, log=lambda s: print(s, flush=True)))
+        out[-1]["build_s"] = round(time.perf_counter() - t0, 1)
+        for r in out[-1]["variants"]:
+            print(f"    {r['forced']:12s} {'-' if r['us'] is None else format(r['us'], '8.2f')}  {r['plan']}", flush=True)
+    worst = max(out, key=lambda r: r["planner_over_best"])
+    print(f"{len(out)} matrices: planner / best forced plan: worst {worst['planner_over_best']:.3f} ({worst['matrix']}), "
+          f"{sum(r['planner_over_best'] <= 1.10 for r in out)} within 10 %, median {sorted(r['planner_over_best'] for r in out)[len(out) // 2]:.3f}")
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
