@@ -28,10 +28,13 @@ Everything else a default run measures (the other BASELINE configurations, the r
 MALL-cold round-robin legs, the strong-scaling prediction: bench_extras.py) goes to `bench_details.json` next to this file and, one row
 per matrix, to stderr.  `--config NAME` measures only that configuration; `--quick` skips the extras.
 
-N > 1 (BASELINE.json configs[4]): mouse_gene, ONE matrix split into N row slabs by non-zero count (`--scaling strong`;
-hisparse_amd/sharding.py), every rank formats and loads its slab and holds all of x.  Timed = `value`: K slab SpMVs and ONE final
-all-gather of the y slabs over RCCL (`gather: final`, north_star's "a final RCCL gather over xGMI"; the reference too runs its NUM_RUNS
-launches and collects y once, sw/benchmark.cpp:318-346).  In the same line: the same K SpMVs with y left sharded (`compute_only`),
+N > 1, nothing named (the driver's series): `value` = the N = 1 workload carried to N GPUs the way the path shards -- WEAK scaling: every rank owns
+an ogbl-ppa-sized row slab (own seed) of a matrix N slabs tall and all of x (hisparse_amd/sharding.py), no collective inside the SpMV, K slab
+SpMVs and ONE final all-gather of the y slabs over RCCL (`gather: final`, north_star's "a final RCCL gather over xGMI"; the reference too runs
+its NUM_RUNS launches and collects y once, sw/benchmark.cpp:318-346); per-GPU work is fixed, so value(N) / (N x value(1)) reads as scaling
+efficiency.  In the same line under `baseline_config_4`: BASELINE.json configs[4] -- mouse_gene, ONE matrix split into N row slabs by non-zero
+count (strong), per-rank plans and the one-GPU prediction of its slabs beside the measured ones.  `--config NAME` / `--scale-matrix NAME`
+(+ `--scaling strong|weak`) measures that one workload instead.  Beside `value`: the same K SpMVs with y left sharded (`compute_only`),
 with an all-gather after EVERY SpMV (`exchange_every_step`) and with that gather done by peer stores (`exchange_push`).
 `--backend gloo --share-gpu` is the DRY RUN of that path on one GPU: N processes on GPU 0, the HIP engine, host-staged gloo collectives.
 The N-rank leg lives in bench_dist.py, the sweeps behind the details file in bench_extras.py.
@@ -422,7 +425,8 @@ def emit(out, details, rows, scaling=None):
     line = json.dumps(out)
     if len(line) > LINE_LIMIT:      # never again a line the driver's tail cannot hold: drop the optional keys, longest first
         for key in sorted((k for k in out if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                                                        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_vs_oracle")),
+                                                        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_vs_oracle", "baseline_config_4", "compute_only",
+                                                        "same_workload_on_one_gpu")),
                           key=lambda k: -len(json.dumps(out[k]))):
             del out[key]
             line = json.dumps(out)
@@ -482,7 +486,10 @@ def main():
                     help="N > 1: the matrix to shard, by name (same as --config; default mouse_gene = BASELINE.json configs[4]).  hollywood and "
                          "ogbn_products are the ones a curve can look right on: their 1/8 slabs are still 25-32 us of streaming (one-GPU prediction: "
                          "70 % / 79 % compute-only at 8 ways), where a 1/8 slab of mouse_gene is 3.6 us of bytes against a 3 us launch floor")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong", help="N > 1: split ONE matrix (default) or one matrix-sized slab per rank")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: strong = ONE matrix split N ways by non-zeros; weak = one matrix-sized row slab per rank (the matrix is N slabs tall).  Default: with "
+                         "a matrix named (--config / --scale-matrix) strong; with nothing named the driver's series -- ogbl_ppa weak as `value` (the N = 1 line's "
+                         "workload, per-GPU work fixed) AND mouse_gene strong (BASELINE.json configs[4]) in the same line under `baseline_config_4`")
     ap.add_argument("--gather", choices=["step", "final", "off"], default="final",
                     help="N > 1: what `value` times beside the K SpMVs: one all-gather of the y slabs at the end (default), one after every SpMV "
                          "(overlapped with the next), or none; the other patterns are reported alongside")
@@ -586,7 +593,7 @@ def main():
     out = {
         "metric": "SpMV GBPS (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346)",
         "value": res["value"], "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,      # (N = 1 of the weak series bench_dist.py continues: one ogbl-ppa-sized slab per GPU)
         "dtype": "u32 (Q8.24 fixed point, u64 row sums)" if impl == host.IMPL_FIXED else "f32",
         "data": "synthetic" if not args.npz else "file",
         "config": {"workload": res["workload"], "rows": res["rows"], "cols": res["cols"], "nnz": res["nnz"],

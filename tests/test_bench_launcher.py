@@ -57,6 +57,19 @@ def test_scale_matrix_names_the_matrix_to_shard():
     assert line["config"]["workload"].startswith("gplus, fixed IMPL") and line["config"]["nnz_total"] > 1.3e7
 
 
+def test_default_n_rank_run_is_the_weak_series_with_config_4_beside_it():
+    """nothing named: `value` = ogbl-ppa-sized slab per rank (weak: the N = 1 line's workload), BASELINE.json configs[4] -- mouse_gene split N ways -- in the same line"""
+    rc, line, text = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], {"HISPARSE_HIP_LIB": CPU_LIB}, timeout=1200)
+    assert rc == 0, text
+    assert line["scaling"] == "weak" and line["config"]["workload"].startswith("ogbl_ppa, fixed IMPL") and line["config"]["nnz_total"] > 8.4e7
+    assert line["same_workload_on_one_gpu"]["n_gpus"] == 1 and line["parity_vs_oracle"].startswith("bit-exact")
+    b4 = line["baseline_config_4"]
+    assert b4["scaling"] == "strong" and b4["workload"].startswith("mouse_gene, fixed IMPL") and b4["parity_vs_oracle"].startswith("bit-exact")
+    assert len(b4["per_rank"]) == 2 and b4["one_gpu_prediction"]["max_slab_us"] > 0 and b4["same_workload_on_one_gpu"]["n_gpus"] == 1
+    last = [l for l in text.splitlines() if l.startswith("{")][-1]
+    assert len(last) < 3400          # (N = 8 adds ~100 bytes per further rank: still inside bench.LINE_LIMIT)
+
+
 def test_gloo_backend_refuses_the_hip_library():
     rc, line, text = _bench(["--gpus", "2", "--backend", "gloo", "--config", "ppa_small", "--steps", "1", "--warmup", "0"])
     assert rc == 2, text
@@ -169,3 +182,18 @@ def test_n_rank_dry_run_on_one_gpu(n):
     assert push is not None and ("error" in push or push["equals_collective_on_every_rank"]), push
     last = [l for l in text.splitlines() if l.startswith("{")][-1]
     assert len(last) < 6000
+
+
+@__import__("pytest").mark.gpu
+def test_default_series_dry_run_on_one_gpu():
+    """the driver's own N-rank command line (nothing named) as a dry run at N = 2: ogbl-ppa-sized slab per rank (weak) as `value`, mouse_gene split
+    2 ways (BASELINE.json configs[4]) beside it -- HIP engine, stream binding, result binding, slab parity, gathered layout; only RCCL is left out"""
+    rc, line, text = _bench(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "20", "--warmup", "5"], timeout=1500)
+    assert rc == 0, "\n".join(l for l in text.splitlines() if "rank" in l.lower() or "error" in l.lower() or "Traceback" in l or l.startswith("  File"))[-6000:]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "DRY RUN" in line["backend"] and line["parity_vs_oracle"].startswith("bit-exact")
+    assert line["config"]["workload"].startswith("ogbl_ppa") and line["config"]["nnz_total"] > 8.4e7
+    assert 40 < line["same_workload_on_one_gpu"]["ms_per_step"] * 1e3 < 120          # one ogbl-ppa-sized slab on the one GPU it shares with the other rank
+    b4 = line["baseline_config_4"]
+    assert b4["scaling"] == "strong" and b4["parity_vs_oracle"].startswith("bit-exact") and len(b4["per_rank"]) == 2
+    last = [l for l in text.splitlines() if l.startswith("{")][-1]
+    assert len(last) < 4000
