@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <map>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -58,6 +60,77 @@ bool build_stream_tiles(const void* const channel[NUM_HBM_CHANNELS], const uint6
 }
 
 namespace {
+
+// ---- tile census (round 6) -------------------------------------------------------------------------------------------------------------
+// Until round 5 the plan was made from the rows' non-zero counts alone, i.e. as if every row range met every x sub-tile with the same number
+// of elements.  True enough for the scrambled power-law graphs and the Bernoulli layers the constants were measured on -- and wrong by
+// 2-6 x on anything with STRUCTURE (tools/planner_check.py, profiles/r06_planner_check_before.txt): a banded or block-diagonal matrix keeps a
+// row range's elements in two or three sub-tiles, so a plan of 51 row ranges x 5 column slices has 102 blocks that hold anything, on 102 of
+// 256 workgroups (banded 400 K: 56.9 us in the planner's 5 slices, 21.3 us in one).  The census is what the model lacked: non-zeros per
+// (fine row range, sub-tile) for `fine` ranges of equal non-zero count -- one more counting pass (the pass-1 kernel / walk with another row
+// map) -- from which every candidate plan's REAL units (the non-empty ones), block loads (sub-tiles dealt to slices the way the builder
+// deals them) and workgroup loads (heaviest block first, the way assign_workgroups balances) follow.
+struct TileCensus {
+    uint32_t fine = 0, tiles = 0;
+    std::vector<uint32_t> cnt;          // [fine][tiles]
+    double populated = 1.0;             // fraction of the (fine range, sub-tile) cells that hold anything
+    struct Eval { double nonempty_units, max_wg_load; };
+    // a plan of `plan_ranges` row ranges (equal non-zero count, in row order) x `cs` column slices on G workgroups
+    Eval evaluate(uint64_t plan_ranges, uint32_t cs, uint32_t G, uint64_t nnz) const {
+        plan_ranges = std::max<uint64_t>(1, plan_ranges);
+        if (cnt.empty() || !fine) {      // no census (matrix without non-zeros): the uniform picture
+            const double blocks = double(plan_ranges) * cs, per_wg = std::ceil(blocks / G);
+            return {double(plan_ranges) * tiles, double(nnz) / blocks * per_wg};
+        }
+        // more plan ranges than census rows: every census row stands for `split` plan ranges of 1 / split of its non-zeros
+        const uint64_t split = plan_ranges > fine ? (plan_ranges + fine - 1) / fine : 1;
+        const uint64_t groups = plan_ranges > fine ? fine : plan_ranges;
+        std::vector<double> t(tiles), block_load;
+        std::vector<uint32_t> order(tiles);
+        block_load.reserve(size_t(groups * split) * cs);
+        double nonempty = 0.0;
+        std::vector<double> slice_load(cs);
+        std::vector<uint32_t> slice_tiles(cs);
+        for (uint64_t j = 0; j < groups; ++j) {
+            const uint64_t lo = j * fine / groups, hi = (j + 1) * fine / groups;
+            std::fill(t.begin(), t.end(), 0.0);
+            for (uint64_t f = lo; f < hi; ++f)
+                for (uint32_t k = 0; k < tiles; ++k) t[k] += cnt[f * tiles + k];
+            uint32_t live = 0;
+            for (uint32_t k = 0; k < tiles; ++k) live += t[k] > 0.0;
+            nonempty += double(live) * double(split);
+            std::fill(slice_load.begin(), slice_load.end(), 0.0);
+            if (cs == 1) {
+                for (uint32_t k = 0; k < tiles; ++k) slice_load[0] += t[k];
+            } else {      // the builder's dealing: heaviest sub-tile first, each to the lightest slice so far (ties: the one with fewer sub-tiles)
+                std::iota(order.begin(), order.end(), 0u);
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t[a] > t[b]; });
+                std::fill(slice_tiles.begin(), slice_tiles.end(), 0u);
+                for (uint32_t k : order) {
+                    uint32_t best = 0;
+                    for (uint32_t c = 1; c < cs; ++c)
+                        if (slice_load[c] < slice_load[best] || (slice_load[c] == slice_load[best] && slice_tiles[c] < slice_tiles[best])) best = c;
+                    slice_load[best] += t[k];
+                    slice_tiles[best] += 1;
+                }
+            }
+            for (uint64_t rep = 0; rep < split; ++rep)
+                for (uint32_t c = 0; c < cs; ++c) block_load.push_back(slice_load[c] / double(split));
+        }
+        // heaviest block first, each to the workgroup with the least work so far (assign_workgroups)
+        std::sort(block_load.begin(), block_load.end(), std::greater<double>());
+        std::vector<double> wg(std::max<uint32_t>(1, G), 0.0);
+        std::make_heap(wg.begin(), wg.end(), std::greater<double>());
+        double worst = 0.0;
+        for (double b : block_load) {
+            std::pop_heap(wg.begin(), wg.end(), std::greater<double>());
+            wg.back() += b;
+            worst = std::max(worst, wg.back());
+            std::push_heap(wg.begin(), wg.end(), std::greater<double>());
+        }
+        return {std::max(1.0, nonempty), std::max(worst, double(nnz) / G)};
+    }
+};
 
 bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const uint64_t n_packets[NUM_HBM_CHANNELS],
                         const Geometry& geom, uint32_t num_rows, uint32_t num_cols, uint32_t num_row_partitions,
@@ -109,6 +182,47 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     }
 
     timer.lap("pass 0 (row counts)");
+    // ---- tile census (TileCensus above): non-zeros per (fine row range of equal non-zero count, x sub-tile) -----------------------------
+    TileCensus census;
+    census.tiles = CP * S;
+    {
+        const char* off = env_switch("HISPARSE_PLAN_CENSUS");      // 0: plan as rounds 1-5 did, from the row counts alone (A/B, tools/planner_check.py)
+        if (out.nnz && !(off && std::atoi(off) == 0)) {
+            census.fine = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>({512, (uint64_t(4) << 20) / std::max<uint32_t>(1, census.tiles), num_rows})));
+            std::vector<uint32_t> fine_of_row(num_rows);
+            uint64_t seen = 0;
+            for (uint32_t r = 0; r < num_rows; ++r) {
+                fine_of_row[r] = uint32_t(std::min<uint64_t>(census.fine - 1, seen * census.fine / out.nnz));
+                seen += row_nnz[r];
+            }
+            if (gpu) {
+                if (!gpu->count_tiles(fine_of_row, census.fine, census.cnt)) { error = gpu->error(); return false; }
+            } else {
+                const size_t cells = size_t(census.fine) * census.tiles;
+                std::unique_ptr<std::atomic<uint32_t>[]> cell(new std::atomic<uint32_t>[cells]);
+                for (size_t i = 0; i < cells; ++i) cell[i].store(0, std::memory_order_relaxed);
+                parallel_for(size_t(RP) * NUM_HBM_CHANNELS, [&](size_t w) {
+                    const uint32_t rp = uint32_t(w / NUM_HBM_CHANNELS), pc = uint32_t(w % NUM_HBM_CHANNELS);
+                    for (uint32_t cp = 0; cp < CP; ++cp)
+                        walk_channel_partition(L, chan(pc), n_packets[pc], pc, rp, cp, [&](uint32_t row, uint32_t col, uint32_t) {
+                            cell[size_t(fine_of_row[row]) * census.tiles + size_t(cp) * S + col / L.sub_width].fetch_add(1, std::memory_order_relaxed);
+                        });
+                });
+                census.cnt.resize(cells);
+                for (size_t i = 0; i < cells; ++i) census.cnt[i] = cell[i].load(std::memory_order_relaxed);
+            }
+            // (over the sub-tiles that exist: the last column partition's table ends where the matrix does)
+            size_t live = 0, existing = 0;
+            for (uint32_t cp = 0; cp < CP; ++cp)
+                for (uint32_t sub = 0; sub < S; ++sub) existing += uint64_t(sub) * L.sub_width < L.cols_in_part(cp);
+            existing *= census.fine;
+            for (uint32_t c : census.cnt) live += c != 0;
+            census.populated = existing ? std::min(1.0, std::max(1.0 / double(existing), double(live) / double(existing))) : 1.0;
+            if (env_switch("HISPARSE_PLAN_DEBUG"))
+                std::fprintf(stderr, "census: %u fine row ranges x %u sub-tiles, %.1f %% of the cells hold anything\n", census.fine, census.tiles, census.populated * 100.0);
+        }
+    }
+    timer.lap("tile census");
     bool prefer_sliced_delta = false, sliced_delta_possible = false;      // (decided in the BITMAP / LIGHT blocks below)
     double sliced_delta_us = 0.0;
     // ---- dense-row matrices (pruned-NN layers): BITMAP rows, their own builder and kernel (stream_tiles.h) --------------
@@ -133,7 +247,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             const uint32_t live_tiles = (num_cols + kSubTileCols - 1) / kSubTileCols;
             const double scale = 256.0 / std::max<uint32_t>(1, max_workgroups);
             sliced_delta_us = 5.8 + double(out.nnz) * 1.0e-6 * scale;
-            sliced_delta_possible = !is_float && live_tiles >= 2 && live_tiles <= kMaxColSlices && density >= 0.04 && num_cols >= kBitmapMinCols &&
+            sliced_delta_possible = !is_float && live_tiles >= 1 && live_tiles <= kMaxColSlices && density >= 0.04 && num_cols >= kBitmapMinCols &&
                                     double(out.nnz) * 7.0 < double(kCarryMaxImageBytes) && RP == 1 && out.nnz >= (1u << 20);      // (measured between 0.85 and 8.5 M non-zeros)
             const double bitmap_us = 5.0 + double(num_rows) * double((num_cols + kBitmapGroupCols - 1) / kBitmapGroupCols) / std::max<uint32_t>(1, max_workgroups) * 7.5e-3;
             if (bitmap && sliced_delta_possible && sliced_delta_us < 0.97 * bitmap_us && !env_switch("HISPARSE_STREAM_FORMAT")) {
@@ -180,9 +294,14 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         // 60.5 / 59.2, power-law squares 42.5 / 48, 86.6 / 99, 173 / 185), SWEEP's model within 3 %: hence the factor.  What the comparison
         // reproduces (stream_tiles.h, "SWEEP format", has the tables): pokec -> SWEEP, ogbn-products -> OWNER24, ogbn-products cut into 8
         // row slabs (same gap, a quarter of the row ranges: 59.2 -> 46.3 us) -> SWEEP.
-        const double gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 0.0;
+        // (the mean position gap INSIDE the (row range x sub-tile) cells that hold anything: a banded or block-diagonal matrix of 12 non-zeros per
+        //  row over a million columns is not hyper-sparse where its elements are -- banded 1 M x 1 M, float_stall: 63 us as the SWEEP image the
+        //  plain gap asked for, 27 us as a DELTA image)
+        const double gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) * census.populated : 0.0;
         bool sweep = false;
-        if (gap > kOwnerMinMeanGap && out.nnz >= kSweepMinNnz && uint64_t(num_cols) * 4 < (1ull << 32)) {
+        // (from kSweepMinNnz on; smaller matrices too where x is wider than the LIGHT plan's sixteen sub-tiles -- a quarter slab of a 100 K x 4 M
+        //  bipartite graph, 1.5 M non-zeros over 489 sub-tiles: 55.9 us as an OWNER24 image of 15 648 units, 11.2 us as a SWEEP image)
+        if (gap > kOwnerMinMeanGap && (out.nnz >= kSweepMinNnz || (out.nnz >= kSweepMinNnzWide && uint64_t(CP) * S > kLightMaxUnits)) && uint64_t(num_cols) * 4 < (1ull << 32)) {
             uint32_t cs = 1, rows_cap = 0;
             uint64_t want = 1;
             const double sweep_us = sweep_plan(L, out.nnz, max_workgroups, cs, want, rows_cap);
@@ -190,7 +309,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             uint64_t by_cap = 0;
             for (uint32_t rp = 0; rp < RP; ++rp) by_cap += (uint64_t(L.rows_in_part(rp)) + cap - 1) / cap;
             const double ranges = double(std::max<uint64_t>(by_cap, G / kMaxColSlices));
-            const double units = ranges * double(CP) * S, per_wg = units / G, unit_steps = double(out.nnz) / units / (kConsumerWaves * kWaveLanes);
+            const double units = std::max(1.0, ranges * double(CP) * S * census.populated), per_wg = units / G, unit_steps = double(out.nnz) / units / (kConsumerWaves * kWaveLanes);
             const double owner_slices = std::min<double>(kMaxColSlices, std::max(1.0, std::ceil(G / ranges)));
             const double owner_combine = owner_slices > 1.0 ? 2.0 + double(num_rows) * 4.0 * (owner_slices + 1.0) / 8e6 : 0.0;
             const double owner_us = 1.1 * (std::max(double(out.nnz) * 7.06 / 6.2e6, per_wg * (1.2 + 0.06 * unit_steps)) + 8.0 + owner_combine);
@@ -224,7 +343,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     }
     // ---- stream format (stream_tiles.h): DELTA for matrices that are sparse but not hyper-sparse; hyper-sparse float matrices: OWNER --
     {
-        const double mean_gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) : 1e30;
+        const double mean_gap = out.nnz ? double(num_rows) * double(num_cols) / double(out.nnz) * census.populated : 1e30;      // (inside the populated cells, see SWEEP above)
         out.format = (mean_gap >= kDeltaMinMeanGap && mean_gap <= kDeltaMaxMeanGap) ? kFormatDelta : kFormatPairs;
         // hyper-sparse matrices: OWNER, in its 7-byte record form (OWNER24) unless that turns out larger (decided after the sort).  Fixed
         // point too since round 3: saturating 32-bit accumulators (spmv_kernels.hip: OwnerOps) -- pokec in PAIRS, with 8-byte atomic
@@ -287,6 +406,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                                  {owner ? owner_max_block_rows(3) : (kMaxLdsBytes - 3 * kSubTileCols * 4) / kAccumulatorBytes - 1, 3}};   // 12287 / 8191 rows
         const Shape whole[1] = {{max_block_rows(false), kMaxXBuffers}};                                       // 4095 rows, ring 4
         const double sub_tiles = double(CP) * S;
+        std::map<uint64_t, TileCensus::Eval> census_memo;
         double best = 1e30;
         for (uint32_t cs = 1; cs <= (force_slices ? kMaxForcedColSlices : kMaxColSlices); ++cs) {
             // unforced: every count the cost model likes.  (Through round 4 only 1, 2, 4, 8 for matrices of more than sixteen sub-tiles -- everything
@@ -313,12 +433,17 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                 const uint64_t need = (uint64_t(num_rows) + cap - 1) / cap;
                 const double ranges = double(per_round * std::max<uint64_t>(1, (need + per_round - 1) / per_round));
                 const double blocks_per_wg = ranges * cs / G;
-                const double units_per_wg = std::max(1.0, ranges * sub_tiles / G);
+                // the plan's real units and loads (TileCensus): the non-empty (row range x sub-tile) cells, the heaviest workgroup's share
+                const uint64_t memo_key = (uint64_t(ranges) << 8) | cs;
+                auto found = census_memo.find(memo_key);
+                if (found == census_memo.end()) found = census_memo.emplace(memo_key, census.evaluate(uint64_t(ranges), cs, G, out.nnz)).first;
+                const TileCensus::Eval& real = found->second;
+                const double units_per_wg = std::max(1.0, real.nonempty_units / G);
                 const double unit_stream_us = double(out.nnz) * 8.0 / (units_per_wg * G) / 25e3;
                 // x pulled through a CU: 120 GB/s next to a DELTA / PAIRS stream (ogbl-ppa: 0.1 us per row range); OWNER's units are
                 // short and every one ends in a flush and a barrier, which also scale with the ranges: 1.34 us per range on
                 // ogbn-products = 29 GB/s (tools/slices_probe.sh)
-                const double volume_us = ranges * double(num_cols) * 4.0 / G / (owner ? 29e3 : 120e3);
+                const double volume_us = real.nonempty_units * double(L.sub_width) * 4.0 / G / (owner ? 29e3 : 120e3);      // (uniform matrix: ranges x num_cols x 4 bytes)
                 double latency_us = units_per_wg * std::max(0.0, 0.8 / (ring - 1) - unit_stream_us);
                 // Blocks of a few long rows (<= kDenseBlockRows) take the dense-row path: a wavefront sums a row in registers and pays a
                 // wavefront-wide reduction at every row change.  That is right for rows that fill many chunks of a sub-tile (pruned-NN
@@ -333,7 +458,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                 // 14 sub-tiles: 23.9 / 27.4 / 24.7 / 26.1 us in 5 / 6 / 7 / 8 slices)
                 if (!owner && cs > 1 && live_tiles <= 2 * kMaxColSlices)
                     latency_us += 0.75 * (double(out.nnz) * 8.0 / G / 25e3) * (double((live_tiles + cs - 1) / cs) * cs / live_tiles - 1.0);
-                const double rows_per_block = double(num_rows) / ranges, per_row_and_tile = double(out.nnz) / std::max(1.0, double(num_rows) * sub_tiles);
+                const double rows_per_block = double(num_rows) / ranges, per_row_and_tile = double(out.nnz) / std::max(1.0, double(num_rows) * sub_tiles * census.populated);
                 if (!owner && rows_per_block <= kDenseBlockRows && per_row_and_tile < 4.0 * kWaveLanes) latency_us += units_per_wg * 1.75;
                 // PAIRS deals a unit's elements, sorted by (row, column), to the lanes in consecutive runs: the 64 lanes of a step sit
                 // 1/896 of the unit apart, and when the block has fewer than 896 rows several of them are in the SAME row -- their
@@ -352,7 +477,13 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                 const double combine_us = cs > 1 ? (carried ? 1.0 : 3.5) + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
                 // workgroup slots that get no block (7 slices x 36 row ranges = 252 blocks on 256 workgroups): the stream they would have taken
                 // is the others' -- what tells 7 slices from 8 on mid-size wide matrices (profiles/r05_any_slice_count.txt)
-                const double idle_us = double(out.nnz) * 8.0 / 6.2e6 * (std::ceil(blocks_per_wg) / std::max(1e-9, blocks_per_wg) - 1.0);
+                // -- round 6: the heaviest workgroup's real share (TileCensus): the same term for a uniform matrix, and what makes column slices of a
+                // banded matrix as expensive as they are (most of its (row range x slice) blocks are empty)
+                // (charged beyond the uniform picture only where the real imbalance exceeds it by more than 15 %: the slice counts of the scrambled
+                //  graphs were settled by measurement to within a microsecond -- ogbl-ppa 5 slices, gplus 7 -- and the census rows are coarser than that)
+                const double uniform_load = double(out.nnz) / std::max(1.0, ranges * cs) * std::ceil(blocks_per_wg);
+                const double idle_us = double(out.nnz) * 8.0 / 6.2e6 * ((std::ceil(blocks_per_wg) / std::max(1e-9, blocks_per_wg) - 1.0) +
+                                                                     std::max(0.0, real.max_wg_load / std::max(1.0, uniform_load) - 1.15) * uniform_load / std::max(1.0, double(out.nnz) / G));
                 const double cost = volume_us + latency_us + conflict_us + 8.0 * blocks_per_wg + combine_us + idle_us;
                 if (detail::env_switch("HISPARSE_PLAN_DEBUG"))
                     std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f conflicts %.1f blocks/wg %.2f idle %.2f combine %.1f => %.2f us\n", cs, cap, ring, ranges,

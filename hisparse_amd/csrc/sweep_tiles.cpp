@@ -38,7 +38,16 @@ namespace {
 // Round 4, profiling builds on the real matrices (profiles/r04_sweep_ablations.txt): the gathers cost pokec 23 us with 20 K-row blocks and 11 us
 // with 40 K-row blocks (per line), ogbn-products 38 us either way -- a floor of ~12 clocks per gather instruction, 0.085 ns per element; and
 // every slice is another rows x 4 bytes of partial sums written by the kernel and read back by the combine pass (~4 TB/s + ~8 TB/s).
-constexpr double kSweepNsPerElement = 0.33, kSweepNsPerLine = 1.36, kSweepGatherNsPerElement = 0.085, kSweepBlockUs = 10.0;
+// Round 6: fitted again on the kernel of round 5 (ring depth 4, the epilogue, `sc1` streams for images that stay in the Infinity Cache), whole steps
+// of nine matrices the round-4 constants had never seen (tools/planner_check.py, profiles/r06_planner_check_before.txt; pokec, one rank's slabs of
+// hollywood / ogbn-products): the round-4 model (0.33 ns per element + max(1.36 ns per line, 0.085 ns per element) + 10 us per block) read 13 % high
+// on pokec and 40-75 % high on everything smaller -- an R-MAT graph of 24 M non-zeros modelled at 60 us and measured at 42.8 went to OWNER24 (58.7 us)
+// because of it.  Now, per block: 0.27 ns per element where the image stays in the cache (<= kResidentMaxImageBytes), 0.38 where it is streamed
+// from HBM every time, + 0.66 ns per 128-byte line of x in the block's slice, + 4.2 us; the combine pass as before.  Residuals on the nine: -7 ... +4 %
+// in fixed point, float modes up to 15 % slower than modelled.
+constexpr double kSweepNsPerElementResident = 0.27, kSweepNsPerElementStreamed = 0.38, kSweepNsPerLine = 0.66, kSweepBlockUs = 4.2;
+// the weights the slice borders are cut by (equal modelled cost per slice): the round-4 pair, kept -- the borders of the measured images do not move
+constexpr double kSweepCutNsPerElement = 0.33, kSweepCutNsPerLine = 1.36;
 
 struct Placed { uint64_t key; uint32_t value; };      // key = column << 16 | local row
 
@@ -70,7 +79,8 @@ double sweep_plan(const Layout& L, uint64_t nnz, uint32_t max_workgroups, uint32
         // (60 K elements per block) 46.2 -> 43.6 us in 16 slices, pokec (15 K per block) 22.2 -> 23.3: with so little in a block the x lines
         // it saves are not what the block waits for, and every slice is another set of partial rows.  So only where a block holds >= 32 K.
         if (cs > kMaxColSlices && !force_slices && double(nnz) / blocks < 32768.0) continue;
-        const double block_ns = double(nnz) / blocks * kSweepNsPerElement + std::max(double(lines) / cs * kSweepNsPerLine, double(nnz) / blocks * kSweepGatherNsPerElement);
+        const double per_element = double(nnz) * 8.1 <= double(kResidentMaxImageBytes) ? kSweepNsPerElementResident : kSweepNsPerElementStreamed;
+        const double block_ns = double(nnz) / blocks * per_element + double(lines) / cs * kSweepNsPerLine;
         const double combine_us = double(num_rows) * 4.0 * cs / 4e6 + (cs > 1 ? 2.0 + double(num_rows) * 4.0 * (cs + 1) / 8e6 : 0.0);
         const double cost = blocks_per_wg * (block_ns * 1e-3 + kSweepBlockUs) + combine_us;
         if (env_switch("HISPARSE_PLAN_DEBUG")) std::fprintf(stderr, "sweep plan cs %u: ranges %llu block %.1f us combine %.1f => %.1f us\n", cs, (unsigned long long)ranges, block_ns * 1e-3, combine_us, cost);
@@ -171,7 +181,7 @@ bool build_sweep_tiles(const Layout& L, const void* const channel[NUM_HBM_CHANNE
         });
         }
         std::vector<double> upto(lines + 1, 0.0);
-        for (uint32_t l = 0; l < lines; ++l) upto[l + 1] = upto[l] + double(line_nnz[l]) / std::max<uint32_t>(1, NR) * kSweepNsPerElement + kSweepNsPerLine;
+        for (uint32_t l = 0; l < lines; ++l) upto[l + 1] = upto[l] + double(line_nnz[l]) / std::max<uint32_t>(1, NR) * kSweepCutNsPerElement + kSweepCutNsPerLine;
         uint32_t line_before = 0;
         for (uint32_t k = 1; k < slices; ++k) {
             const uint32_t l = uint32_t(std::lower_bound(upto.begin(), upto.end(), upto[lines] * k / slices) - upto.begin());

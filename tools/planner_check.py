@@ -122,6 +122,22 @@ CASES = [
     ("slab4_of_bipartite_100k", POB, lambda: slab(uniform(100_000, 4_000_000, 60, 9, POB), 4, 2)),
     ("slab8_of_tall_2m", FIXED, lambda: slab(uniform(2_000_000, 50_000, 10, 10, FIXED), 8, 7)),
 ]
+
+
+def reference(name, impl_name=None):
+    """one of the seeded stand-ins of the reference's benchmark list (hisparse_amd/datasets.py): the matrices the planner's constants WERE measured on"""
+    import scipy.sparse as sp
+    from hisparse_amd import datasets
+    cfg, csr = datasets.load(name)
+    ip, ix, dv = csr.arrays()
+    return sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(csr.num_rows, csr.num_cols))
+
+
+# --reference: in-sample, for comparison (and to see that a planner change has not moved them)
+REFERENCE = [(f"ref_{n}", FIXED, (lambda n=n: reference(n))) for n in ("gplus", "ogbl_ppa", "pokec", "mouse_gene", "transformer_50", "transformer_60", "transformer_70", "transformer_80",
+                                                                        "transformer_90", "transformer_95", "ogbl_ppa_rmat", "mouse_gene_slab8", "mouse_gene_slab4", "mouse_gene_slab2", "hollywood")]
+REFERENCE += [("ref_ogbn_products_stall", STALL, lambda: reference("ogbn_products")), ("ref_mouse_gene_pob", POB, lambda: reference("mouse_gene")),
+              ("ref_pokec_pob", POB, lambda: reference("pokec")), ("ref_transformer_50_pob", POB, lambda: reference("transformer_50"))]
 QUICK = ("banded_400k_d40_w2k", "blockdiag_600k_b64_p50", "rmat19_45_15_15", "bipartite_20k_x_2m_200", "tall_3m_x_8k_6", "er_1500k_8",
          "dense_2048_x_8k_15", "slab8_of_rmat19", "slab4_of_bipartite_100k")
 FORMATS = ("pairs", "delta", "owner24", "sweep", "bitmap")
@@ -192,10 +208,11 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--json", default=None)
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--reference", action="store_true", help="the reference's own benchmark matrices (in-sample) instead of the out-of-sample cases")
     a = ap.parse_args()
     pick = set(a.only.split(",")) if a.only else set(QUICK) if a.quick else None
     out = []
-    for name, impl, build in CASES:
+    for name, impl, build in (REFERENCE if a.reference else CASES):
         if pick and name not in pick:
             continue
         t0 = time.perf_counter()
