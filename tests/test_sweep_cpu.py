@@ -132,11 +132,15 @@ def test_planner_takes_sweep_where_its_plan_is_modelled_faster(monkeypatch):
     slab of a matrix that stays OWNER24 as a whole (few row ranges: few lines of x to gather, while OWNER24's units cost what they cost)."""
     monkeypatch.delenv("HISPARSE_STREAM_FORMAT")
     sparse = host.CSRMatrix.generate("powerlaw", 1000000, 1000000, a=5.0e6, b=0.4, c=1.0, seed=3)          # mean position gap 200 K
-    denser = host.CSRMatrix.generate("powerlaw", 800000, 800000, a=2.0e7, b=0.4, c=1.0, seed=4)            # gap 32 K: OWNER24 ...
+    # gap 25 K and an image beyond the Infinity Cache (1 M x 1 M, 40 M non-zeros, 324 MB): OWNER24 (measured 62.4 us against 74.1 as a SWEEP image,
+    # profiles/r06_format_ab_sweep_owner24_border.txt) ...
+    denser = host.CSRMatrix.generate("powerlaw", 1000000, 1000000, a=4.0e7, b=0.35, c=1.0, seed=9)
     ip, ix, dv = denser.arrays()
     cut = int(np.searchsorted(ip, ip[-1] // 8))                                                           # ... its first eighth of the non-zeros as a slab: SWEEP
     slab = host.CSRMatrix.from_arrays(cut, denser.num_cols, ip[:cut + 1].copy(), ix[:ip[cut]].copy(), dv[:ip[cut]].copy())
-    for csr, want in ((sparse, "sweep"), (denser, "owner24"), (slab, "sweep")):
+    # ... and since round 6 (SWEEP model fitted again on the round-5 kernel) a gap-32 K matrix whose image stays in the cache: SWEEP (35.1 against 41.7 us)
+    resident = host.CSRMatrix.generate("powerlaw", 800000, 800000, a=2.0e7, b=0.4, c=1.0, seed=4)
+    for csr, want in ((sparse, "sweep"), (denser, "owner24"), (slab, "sweep"), (resident, "sweep")):
         cp = host.format_matrix(csr, 0, skip_empty_rows=True)
         t = build(cp, 0, 256)
         assert t["format"] == want, (csr.num_rows, csr.nnz, t["format"])

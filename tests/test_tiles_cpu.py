@@ -305,6 +305,13 @@ def test_bitmap_structure_and_parity(impl, rows, cols, density, wgs, monkeypatch
     _, cp = cases.formatted(m, impl, 4096, ob, True)
     xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 31, impl))
     t = build(cp, impl, wgs)
+    if t["format"] == "delta":
+        # round 6: a FIXED-point dense-row layer over ONE x sub-tile is a DELTA image by the planner's own rule (no refills, no unit barriers, per-lane
+        # row sums; until round 5 the rule needed two sub-tiles) -- 2048 x 8192 at 15 %: 6.7 us against 11.6 us as a BITMAP image
+        # (profiles/r06_planner_check_before.txt / _after.txt).  The BITMAP structure below is then checked on the forced image.
+        assert impl == 0 and cols <= 8192 and m.nnz >= (1 << 20) and t["col_slices"] == 1 and (rows, cols) == (3000, 2500)      # (where the fitted costs say so: stream_tiles.cpp)
+        monkeypatch.setenv("HISPARSE_STREAM_FORMAT", "bitmap")
+        t = build(cp, impl, wgs)
     assert t["format"] == "bitmap" and t["nnz"] == m.nnz and t["elements"] == m.nnz
     blocks, slices = t["blocks"], t["col_slices"]
     groups = (cp.num_cols + 63) // 64
