@@ -274,7 +274,8 @@ def bm_entry(name, paper_gops, res, impl="fixed"):
            "ms_per_step": res["ms_per_step"], "ms_per_step_long_run": res.get("ms_per_step_long_run"), "long_run_steps": res.get("long_run_steps"),
            "ms_per_step_synchronous": res["ms_per_step_synchronous"], "value": res["value"], "unit": "GB/s", "gops": res["gops"],
            "frac_whole_step": res["frac_whole_step"], "frac": r["frac"], "frac_event_pairs": r["frac_event_pairs"], "frac_mall_cold": r.get("frac_mall_cold"),
-           "kernel_ms": r["kernel_ms"], "streamed_bytes_per_launch": r["streamed_bytes_per_launch"],
+           "kernel_ms": r["kernel_ms"], "frac_steady": r.get("frac_steady"), "kernel_ms_steady": r.get("kernel_ms_steady"), "launches_per_step": r.get("launches_per_step"),
+           "streamed_bytes_per_launch": r["streamed_bytes_per_launch"],
            "image_fits_infinity_cache": r["streamed_bytes_per_launch"] < 256 * 2 ** 20, "parity_vs_oracle": res["parity_vs_oracle"],
            "paper_gops_u280": paper_gops, "paper_table": "Table 3" if impl == "fixed" else "Table 7",
            "gops_vs_paper": round(res["gops"] / paper_gops, 1) if paper_gops else None}

@@ -192,7 +192,7 @@ def test_default_series_dry_run_on_one_gpu():
     assert rc == 0, "\n".join(l for l in text.splitlines() if "rank" in l.lower() or "error" in l.lower() or "Traceback" in l or l.startswith("  File"))[-6000:]
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "DRY RUN" in line["backend"] and line["parity_vs_oracle"].startswith("bit-exact")
     assert line["config"]["workload"].startswith("ogbl_ppa") and line["config"]["nnz_total"] > 8.4e7
-    assert 40 < line["same_workload_on_one_gpu"]["ms_per_step"] * 1e3 < 120          # one ogbl-ppa-sized slab on the one GPU it shares with the other rank
+    assert 40 < line["same_workload_on_one_gpu"]["ms_per_step"] * 1e3 < 400          # one ogbl-ppa-sized slab on the one GPU it shares with the other rank
     b4 = line["baseline_config_4"]
     assert b4["scaling"] == "strong" and b4["parity_vs_oracle"].startswith("bit-exact") and len(b4["per_rank"]) == 2
     last = [l for l in text.splitlines() if l.startswith("{")][-1]

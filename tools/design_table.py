@@ -25,6 +25,7 @@ def line(key):
     r = e.get("roofline", e)
     frac, step, cold = r["frac"], e.get("frac_whole_step", r.get("frac_whole_step")), r.get("frac_mall_cold")
     kernel_us, step_us = r["kernel_ms"] * 1e3, e["ms_per_step"] * 1e3
+    steady = f" (steady {r['kernel_ms_steady'] * 1e3:.1f} µs = {pct(r['frac_steady'])} %)" if r.get("kernel_ms_steady") else ""      # round 6: `frac` = the all-launch average
     p = t.get(key[0])
     if p is not None and p.get("impl") is not None and int(p["impl"]) != ["fixed", "float_pob", "float_stall"].index(key[1]):
         p = None      # (profiled in another numeric mode)
@@ -39,7 +40,7 @@ def line(key):
     if e.get("ms_per_step_long_run"):      # K = 20 steps of a small matrix carry the final synchronisation: the same loop over thousands of steps beside it
         lus = e["ms_per_step_long_run"] * 1e3
         long_run = f" ({lus:.1f} µs = {8.0 * e['nnz'] / (lus * 1e-6) / 8e12 * 100:.1f} % over {e['long_run_steps']} steps)"
-    return f"| {key[0]} / {key[1]} | {fmt} | {kernel_us:.1f} µs = {pct(frac)} % | {step_us:.1f} µs = {pct(step)} %{long_run} | {pct(cold)} | {prof} | {traffic} | {parity} |"
+    return f"| {key[0]} / {key[1]} | {fmt} | {kernel_us:.1f} µs = {pct(frac)} %{steady} | {step_us:.1f} µs = {pct(step)} %{long_run} | {pct(cold)} | {prof} | {traffic} | {parity} |"
 
 
 order = [("ogbl_ppa", "fixed"), ("transformer_50", "float_pob"), ("ogbn_products", "float_stall"), ("mouse_gene", "fixed"), ("ogbl_ppa_rmat", "fixed"),
@@ -47,9 +48,9 @@ order = [("ogbl_ppa", "fixed"), ("transformer_50", "float_pob"), ("ogbn_products
          ("transformer_70", "fixed"), ("transformer_80", "fixed"), ("transformer_90", "fixed"), ("transformer_95", "fixed"),
          ("transformer_80", "float_pob"), ("transformer_80", "float_stall"), ("mouse_gene", "float_pob"), ("mouse_gene", "float_stall"),
          ("pokec", "float_pob"), ("pokec", "float_stall"), ("ogbn_products", "float_pob")]
-table = [f"**Round 5** (`profiles/{tag}_bench_n1.json` + `profiles/{tag}_bench_details.json` = ONE default `bench.py --gpus 1 --steps 20 --warmup 5` run, the driver's command line, one box, "
+table = [f"**Round {int(tag[1:])}** (`profiles/{tag}_bench_n1.json` + `profiles/{tag}_bench_details.json` = ONE default `bench.py --gpus 1 --steps 20 --warmup 5` run, the driver's command line, one box, "
          f"every row checked against the oracle in the same run; rocprofv3 column and HBM traffic: `profiles/{tag}_<config>_rocprofv3_summary.txt`, `profiles/hbm_traffic.json`, "
-         "another box of the same build — boxes differ by ± 2–3 %; one box in ~45 ran everything 8–35 % slower, `profiles/r05_slow_box_note.txt`).  The first five rows are BASELINE.json's configurations (+ the R-MAT stand-in), the rest the reference's sweep `sw/bm.sh` in all numeric modes:",
+         "another box of the same build — boxes differ by ± 2–3 %; one box in ~45 ran everything 8–35 % slower, `profiles/r05_slow_box_note.txt`; since round 6 the kernel column is the average over ALL launches of regions entered from an idle stream — what `rocprofv3 --stats` prints — with the steady state beside it).  The first five rows are BASELINE.json's configurations (+ the R-MAT stand-in), the rest the reference's sweep `sw/bm.sh` in all numeric modes:",
          "",
          "| matrix / IMPL | image | kernel alone (`roofline.frac`) | whole step (`value`) | whole step, MALL-cold % | rocprofv3 kernel avg / steady | HBM traffic vs 8·nnz | parity |",
          "|---|---|---|---|---|---|---|---|"]
@@ -75,7 +76,7 @@ if "--fill" in sys.argv:
         else:
             text = text.replace(marker.upper().replace("-", "_"), a + "\n" + body + "\n" + b)
 
-    put("round5-table", table_text)
+    put("bench-table" if "<!-- bench-table -->" in text else "round5-table", table_text)
     for name, marker in (("mouse_gene", "scaling-mouse"), ("hollywood", "scaling-hollywood"), ("ogbn_products", "scaling-ogbn")):
         if name in scal:
             a, b = f"<!-- {marker} -->", f"<!-- /{marker} -->"
