@@ -588,6 +588,16 @@ def main():
         if trace is not None:
             roofline["rocprofv3_live"] = {"kernel_avg_us": trace["avg_us"], "kernel_steady_median_us": trace["steady_median_us"], "dispatches": trace["calls"],
                                           "combine_avg_us": trace["combine_avg_us"], "frac": round(8.0 * res["nnz"] / (trace["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            # Two clocks for one kernel: the HIP-event figure is the launch-to-launch PERIOD of back-to-back launches (a launch's ramp overlaps its
+            # predecessor's tail), rocprofv3's is every dispatch's own begin-to-end duration and is what `--stats` averages.  `frac` is priced with the
+            # LONGER of the two, so that it can never read better than the committed rocprofv3 summaries ("whose average must agree").
+            if trace["avg_us"] * 1e-3 > roofline["kernel_ms"]:
+                roofline["kernel_ms_hip_events"], roofline["frac_hip_events"] = roofline["kernel_ms"], roofline["frac"]
+                roofline["kernel_ms"] = round(trace["avg_us"] * 1e-3, 5)
+                roofline["achieved"] = round(8.0 * res["nnz"] / (trace["avg_us"] * 1e-6) / 1e9, 2)
+                roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 4)
+                roofline["kernel_ms_from"] = (f"rocprofv3 --kernel-trace --stats run by this script: average over all {trace['calls']} dispatches (longer than the HIP-event period "
+                                              f"of back-to-back launches, kernel_ms_hip_events: a launch's ramp overlaps its predecessor's tail)")
         else:
             log(rank, f"{headline}: live rocprofv3 --stats pass not available ({how_trace})")
     out = {

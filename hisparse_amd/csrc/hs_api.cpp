@@ -543,7 +543,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
         // rank's slab of ogbn-products split 8 ways, 124 MB: 39.5 -> 32.0 us; pokec, 247 MB: 61.1 -> 59.6-60.8 fixed, 69.3-70.3 -> 66.3-67.7 float_pob).
         // Larger images keep `nt` (a plain read loop over 1 GiB: 7.1 TB/s with it, 6.0 without: profiles/r02_hbm_read_bench.txt).  `stream_resident` = 0 | 1 decides otherwise.
         // Round 6: the row-block kernels' PAIRS / DELTA streams too (spmv_kernels.hip: Ring<kRing | 4>), by their own rule (stream_tiles.h:
-        // kRowblockResidentMaxImageBytes): up to 1.25 x the cache where the blocks walk several units, tiny images whatever their shape; pure one-unit
+        // kRowblockResidentMaxImageBytes): up to the size of the cache where the blocks walk several units, tiny images whatever their shape; pure one-unit
         // streams and everything larger keep `nt` (hollywood: +13 % without it).  OWNER / OWNER24 / BITMAP / LIGHT images are not affected.
         const char* opt = ctx_option(ctx, "HISPARSE_STREAM_RESIDENT");
         const uint64_t image_bytes = image_on_device ? tiles.image_bytes : uint64_t(tiles.image.size());

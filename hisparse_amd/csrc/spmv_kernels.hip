@@ -101,13 +101,12 @@ __device__ __forceinline__ void dma_wait() {
 //   * the stream base is a loop-invariant SGPR pair, the per-step address a 32-bit vector offset (no 64-bit vector
 //     address arithmetic per step); s_nop 4 keeps 5 wait states between any scalar write of the base and its use;
 //   * `nt`: every element is read exactly once per SpMV, so it should not displace x in the L2 (measured: -8 %).
-//   * round 6: ... unless the image stays in the 256 MiB Infinity Cache from one SpMV to the next AND the blocks walk several (row range x
-//     sub-tile) units: then `sc1` without `nt` (the policy the SWEEP kernel takes for such images, spmv_sweep.hip) shortens the drained
-//     pipeline's refill at every unit border -- ogbl-ppa's 8-way slabs 16.8 -> 15.3 us, its 2-way slabs 34.8 -> 32.1, ogbl-ppa itself
-//     (313 MB) 54.2 -> 53.4, mouse_gene 33.8 -> 33.4, the sliced DELTA plans of the pruned-NN layers -2.5 % -- while a pure stream keeps `nt`:
-//     hollywood (872 MB) 137.5 -> 155 us without it, ogbn-products 203 -> 208, and the one-unit-per-block slabs of mouse_gene 12.4 -> 12.9 /
-//     20.0 -> 20.9 (profiles/r06_rowblock_stream_policy*.txt).  A plan-time choice (hs_api.cpp: stream_resident), a template parameter
-//     here: bit 2 of kRing.
+//   * round 6: ... unless the image FITS the 256 MiB Infinity Cache, i.e. stays there from one SpMV to the next, AND the blocks walk several (row range x
+//     sub-tile) units: then `sc1` without `nt` (the policy the SWEEP kernel takes for such images, spmv_sweep.hip) shortens the drained pipeline's
+//     refill at every unit border -- ogbl-ppa's 8-way slabs 16.8 -> 15.3 us, its 2-way slabs 34.8 -> 32.1, mouse_gene 33.8 -> 33.4, the sliced DELTA
+//     plans of the pruned-NN layers -2.5 % -- while a pure stream keeps `nt`: hollywood (872 MB) 137.5 -> 155 us without it, ogbn-products 203 -> 208, the
+//     headline matrix round-robin over three images 56 -> 65 us, and the one-unit-per-block slabs of mouse_gene 12.4 -> 12.9 / 20.0 -> 20.9
+//     (profiles/r06_rowblock_stream_policy*.txt).  A plan-time choice (hs_api.cpp: stream_resident), a template parameter here: bit 2 of kRing.
 #ifndef HS_ROWBLOCK_STREAM_POLICY
 #define HS_ROWBLOCK_STREAM_POLICY "nt"      // the stream loads of an image that is streamed from HBM every time
 #endif

@@ -89,11 +89,13 @@ constexpr uint32_t kMaxSweepSlices = 16;      // SWEEP images (round 5): a short
 // step in a run of hs_run calls); the planner prices the combine pass of such a plan at ~1 us instead of a launch of its own (3.5 us).
 constexpr uint64_t kCarryMaxImageBytes = 48ull << 20;
 constexpr uint64_t kResidentMaxImageBytes = 256ull << 20;   // SWEEP images up to the size of the Infinity Cache are streamed without the non-temporal hint (hs_api.cpp: stream_resident)
-// Row-block (PAIRS / DELTA) images, round 6 (profiles/r06_rowblock_stream_policy*.txt): without `nt` where the image (mostly) stays in the Infinity Cache
-// AND its blocks walk several units -- measured to gain up to 313 MB (ogbl-ppa: -1.5 %; its R-MAT stand-in, 292 MB: -0.7 %), to lose 13 % at 872 MB
-// (hollywood): 1.25 x the cache.  One-unit-per-block plans (a pure stream per block, no drained pipeline to refill) keep `nt` unless the whole image is a few
-// tens of MB, where the step is launch- and latency-bound (the sliced DELTA plans of the pruned-NN layers: -2.5 %; mouse_gene's 50 / 100 MB slabs: +4 %).
-constexpr uint64_t kRowblockResidentMaxImageBytes = 320ull << 20;
+// Row-block (PAIRS / DELTA) images, round 6 (profiles/r06_rowblock_stream_policy*.txt): without `nt` where the image fits the Infinity Cache AND its blocks walk
+// several units.  Measured to gain a little even above the cache (ogbl-ppa, 267 MiB: -1.5 % warm) -- but an image that does not fit is evicted between
+// steps anyway, and once a caller alternates between matrices the cacheable policy COSTS: the headline matrix round-robin over three images ran 65.4 us per SpMV
+// with `sc1` streams against 56 us with `nt` (bench.py's MALL-cold leg), hollywood (872 MB) 155 against 137 us.  So: the cache's own size, no more.
+// One-unit-per-block plans (a pure stream per block, no drained pipeline to refill) keep `nt` unless the whole image is a few tens of MB, where the
+// step is launch- and latency-bound (the sliced DELTA plans of the pruned-NN layers: -2.5 %; mouse_gene's 50 / 100 MB slabs: +4 %).
+constexpr uint64_t kRowblockResidentMaxImageBytes = 256ull << 20;
 constexpr uint64_t kRowblockResidentSmallImageBytes = 32ull << 20;
 constexpr uint32_t kMaxLdsBytes = 160 * 1024;
 // PAIRS format

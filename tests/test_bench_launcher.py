@@ -142,8 +142,9 @@ def test_default_single_gpu_run_fits_the_drivers_tail():
     # round 6: `frac` is the all-launch average (what rocprofv3 --stats prints), the steady state rides beside it, and the line says how many launches a step is
     assert r["frac"] <= r["frac_steady"] <= 1.0 and r["kernel_ms"] >= r["kernel_ms_steady"] and r["launches_per_step"] == (2 if line["config"]["col_slices"] > 1 else 1)
     live = r.get("rocprofv3_live")
-    if live:      # the live rocprofv3 --kernel-trace --stats pass agrees with the HIP-event average within 4 %
-        assert abs(live["kernel_avg_us"] - r["kernel_ms"] * 1e3) < 0.04 * live["kernel_avg_us"], (live, r["kernel_ms"])
+    if live:      # `frac` never reads better than the live rocprofv3 --stats average; the HIP-event period of back-to-back launches is within 8 % of it
+        assert r["kernel_ms"] * 1e3 >= live["kernel_avg_us"] * 0.999 and r["frac"] <= live["frac"] + 1e-4, (live, r["kernel_ms"])
+        assert abs(live["kernel_avg_us"] - r.get("kernel_ms_hip_events", r["kernel_ms"]) * 1e3) < 0.08 * live["kernel_avg_us"], (live, r)
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
     # one row per matrix of the sweep inside the stderr tail, and the details next to the script
     tail = p.stderr[-8000:]
