@@ -600,6 +600,7 @@ def main():
                                               f"of back-to-back launches, kernel_ms_hip_events: a launch's ramp overlaps its predecessor's tail)")
         else:
             log(rank, f"{headline}: live rocprofv3 --stats pass not available ({how_trace})")
+        res["roofline"].update({k: roofline[k] for k in ("achieved", "frac", "kernel_ms", "kernel_ms_from", "rocprofv3_live", "kernel_ms_hip_events", "frac_hip_events") if k in roofline})      # the details file says what the line says
     out = {
         "metric": "SpMV GBPS (8 B per non-zero per SpMV, sw/benchmark.cpp:312-346)",
         "value": res["value"], "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
