@@ -223,6 +223,22 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         }
     }
     timer.lap("tile census");
+    // ---- hub rows (round 6) ---------------------------------------------------------------------------------------------------------------
+    // A row that holds a large part of its row block puts most lanes of a step on ONE LDS accumulator: same-address ds_add serialises, and a
+    // matrix whose 50 hub rows hold 64 % of the non-zeros (tools/planner_check.py: hubs_500k) ran 89 us as the PAIRS image the mean gap
+    // picked, 94 us as a DELTA image -- and 44.9 us as a DELTA image whose lanes sum their runs in registers (kBlockDenseRows: one LDS add per
+    // lane and row change), which until now only blocks of uniformly long rows got.  So: (a) a DELTA block whose heaviest row holds an
+    // eighth of it is flagged for per-lane sums whatever its mean gap (below, "enumerate blocks"); (b) where rows heavy enough to fill a
+    // quarter of a workgroup's share hold >= 30 % of the matrix, the DELTA image is kept even if PAIRS would be smaller.  Forcing per-lane
+    // sums on every block costs an ordinary graph 20 % (rmat19: 32.0 -> 39.1 us), hence per block.
+    double hub_share = 0.0;
+    {
+        const uint64_t hub_min = std::max<uint64_t>(8192, out.nnz / (4ull * std::max<uint32_t>(1, max_workgroups)));
+        uint64_t in_hubs = 0;
+        for (uint32_t r = 0; r < num_rows; ++r) in_hubs += row_nnz[r] >= hub_min ? row_nnz[r] : 0u;
+        hub_share = out.nnz ? double(in_hubs) / double(out.nnz) : 0.0;
+    }
+    bool keep_delta_for_hubs = false;
     bool prefer_sliced_delta = false, sliced_delta_possible = false;      // (decided in the BITMAP / LIGHT blocks below)
     double sliced_delta_us = 0.0;
     // ---- dense-row matrices (pruned-NN layers): BITMAP rows, their own builder and kernel (stream_tiles.h) --------------
@@ -350,6 +366,9 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         // accumulators, 12287-row blocks and 26 600 units of 1 150 elements, ran at 24 % of the roofline
         if (mean_gap > kOwnerMinMeanGap && out.nnz >= 4096 && !g_no_owner) out.format = kFormatOwner24;
         if (prefer_sliced_delta) out.format = kFormatDelta;
+        if (out.format == kFormatDelta && hub_share >= 0.3 && !prefer_sliced_delta) keep_delta_for_hubs = true;      // (hub rows, above)
+        if (env_switch("HISPARSE_PLAN_DEBUG") && hub_share > 0.0)
+            std::fprintf(stderr, "format: %.1f %% of the non-zeros in hub rows%s\n", hub_share * 100.0, keep_delta_for_hubs ? " -> DELTA kept for its per-lane row sums" : "");
         if (const char* force = env_switch("HISPARSE_STREAM_FORMAT")) {
             const std::string f(force);
             if (f == "pairs") out.format = kFormatPairs;
@@ -378,119 +397,139 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
         if (light) out.format = kFormatPairs;
         out.light = light;
     }
-    bool delta = out.format == kFormatDelta;
-    const bool owner = out.format == kFormatOwner || out.format == kFormatOwner24;
-    bool owner24 = out.format == kFormatOwner24;      // may still fall back to the 8-byte form (below)
-    const bool format_forced = env_switch("HISPARSE_STREAM_FORMAT") != nullptr || prefer_sliced_delta;      // (the sliced DELTA plan of a dense-row layer is DELTA for its per-lane row sums, not for its bytes)
-    const uint32_t acc_bytes = owner ? kOwnerAccumulatorBytes : kAccumulatorBytes;
-    const uint32_t spare_rows = owner ? kConsumerWaves : 1u;     // accumulators behind the block's rows that padding elements aim at
+    // Round 6: the format family and the tile plan are decided TOGETHER where they depend on each other -- a float-mode matrix whose row-block plan
+    // comes out as ONE column slice of a PAIRS image (ds_add_f64 row sums, 4 095-row blocks) runs 10-30 % faster as an OWNER24 image (owned rows,
+    // plain read-modify-write on 4-byte sums, 24 561-row blocks) once it is large enough to amortise OWNER's longer prologue: banded 400 K 30.4 ->
+    // 23.5 us, block-diagonal 200 K 18.6 -> 15.0, 600 K 32.1 -> 22.3, tall 2 M x 50 K 31.1 -> 28.0, 3 M x 8 K 31.2 -> 25.8, in float_pob and
+    // float_stall alike; sliced plans are a wash (gplus, rmat19, er_300k: +-3 %) and small ones lose (a 4 M-non-zero slab 8.1 -> 9.4 us)
+    // (profiles/r06_float_pairs_vs_owner24.txt).  So: plan as before; if that gives float / PAIRS-family / one slice / >= kFloatOneSliceOwnerMinNnz
+    // non-zeros, plan again as OWNER24 and take it.
+    bool delta = false, owner = false, owner24 = false, format_forced = false;
+    uint32_t acc_bytes = kAccumulatorBytes, spare_rows = 1u, light_wgs = kLightWorkgroupsPerCu, G = 1, slices = 1, max_rows = 1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        delta = out.format == kFormatDelta;
+        owner = out.format == kFormatOwner || out.format == kFormatOwner24;
+        owner24 = out.format == kFormatOwner24;      // may still fall back to the 8-byte form (below)
+        format_forced = env_switch("HISPARSE_STREAM_FORMAT") != nullptr || prefer_sliced_delta || (keep_delta_for_hubs && out.format == kFormatDelta);      // (the sliced DELTA plan of a dense-row layer is DELTA for its per-lane row sums, not for its bytes)
+        acc_bytes = owner ? kOwnerAccumulatorBytes : kAccumulatorBytes;
+        spare_rows = owner ? kConsumerWaves : 1u;     // accumulators behind the block's rows that padding elements aim at
 
-    // ---- tile plan: column slices x (rows per block, x ring depth) ------------------------------------------------
-    // More column slices = longer row ranges = less x pulled through every CU, at the price of the combine pass; fewer
-    // rows per block = deeper x ring = refill latency hidden even when a (row range, sub-tile) unit holds only a few
-    // thousand non-zeros (hyper-sparse matrices).  Cost model in microseconds, constants measured on MI355X:
-    //   x volume through one CU at ~120 GB/s; a refill takes ~0.8 us to land, ring-1 of them overlap, a unit's stream
-    //   time (~25 GB/s per CU) hides the rest; ~8 us of prologue + epilogue per block; the combine kernel.
-    uint32_t light_wgs = kLightWorkgroupsPerCu;
-    if (const char* force = env_switch("HISPARSE_LIGHT_WGS")) light_wgs = std::min<uint32_t>(6u, std::max(1, std::atoi(force)));
-    const uint32_t G = std::max<uint32_t>(1, max_workgroups) * (light ? light_wgs : 1u);
-    uint32_t slices = 1, max_rows = light ? kLightMaxBlockRows : max_block_rows(false);
-    if (light) {
-        if (const char* force_rows = env_switch("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force_rows)));   // tests: chains of blocks
-    } else {
-        const char* force_slices = env_switch("HISPARSE_COL_SLICES");
-        const char* force_rows = env_switch("HISPARSE_MAX_ROWS");   // experiments
-        struct Shape { uint32_t cap, ring; };
-        // OWNER: 4-byte accumulators -> 24561 rows with a ring of 2, 16369 with a ring of 3, sliced or not
-        const Shape sliced[2] = {{owner ? owner_max_block_rows(2) : max_block_rows(true), 2},
-                                 {owner ? owner_max_block_rows(3) : (kMaxLdsBytes - 3 * kSubTileCols * 4) / kAccumulatorBytes - 1, 3}};   // 12287 / 8191 rows
-        const Shape whole[1] = {{max_block_rows(false), kMaxXBuffers}};                                       // 4095 rows, ring 4
-        const double sub_tiles = double(CP) * S;
-        std::map<uint64_t, TileCensus::Eval> census_memo;
-        double best = 1e30;
-        for (uint32_t cs = 1; cs <= (force_slices ? kMaxForcedColSlices : kMaxColSlices); ++cs) {
-            // unforced: every count the cost model likes.  (Through round 4 only 1, 2, 4, 8 for matrices of more than sixteen sub-tiles -- everything
-            // in between for OWNER, where the x volume decides: ogbn-products runs 241 us in 5 slices (102 ranges of 24 K rows, 2 blocks per
-            // workgroup) against 280 in 2 (127 ranges) and 275 in 4 -- because five slices had measured as a wash on ogbl-ppa and 3 us slower on
-            // its R-MAT stand-in, a PAIRS image then.  Measured again in round 5 (profiles/r05_any_slice_count.txt, whole step, alternating):
-            // ogbl-ppa 55.2-56.0 us in 4 slices, 54.0-54.5 in 5 (51 row ranges x 5 = 255 blocks: fewer, longer units); the R-MAT stand-in
-            // 58.4-59.0 -> 55.2-55.4; hollywood keeps 2, its slabs and ogbl-ppa's keep 8 (a 2-way slab takes 5 or 7: +-1 %).
-            // HISPARSE_POW2_SLICES=1 brings the old rule back for the A/B.)
-            // (a matrix of at most sixteen sub-tiles: a slice per sub-tile (or two) is the plan without x refills and
-            // unit barriers (gplus, 14 sub-tiles: 23.7 us in 7 slices, 26.1 in 8), and a power of two above the sub-tile count would leave
-            // whole slices, i.e. workgroups, empty)
-            const uint32_t live_tiles = (num_cols + kSubTileCols - 1) / kSubTileCols;
-            if (force_slices ? uint32_t(std::atoi(force_slices)) != cs : (!owner && (cs & (cs - 1)) != 0 && live_tiles > 2 * kMaxColSlices && env_switch("HISPARSE_POW2_SLICES"))) continue;
-            if (cs > 1 && uint64_t(CP) * S < cs) continue;                                    // fewer sub-tiles than slices
-            if (!force_slices && !owner && live_tiles <= kMaxColSlices && cs > live_tiles) continue;
-            for (const Shape& shape : (cs > 1 || owner) ? std::vector<Shape>(sliced, sliced + 2) : std::vector<Shape>(whole, whole + 1)) {
-                uint32_t cap = shape.cap, ring = shape.ring;
-                if (force_rows) {
-                    cap = std::min<uint32_t>(cap, std::max(1, std::atoi(force_rows)));
-                    ring = std::max(kMinXBuffers, std::min(kMaxXBuffers, (kMaxLdsBytes - (cap + spare_rows) * acc_bytes) / (kSubTileCols * 4u)));
+        // ---- tile plan: column slices x (rows per block, x ring depth) ------------------------------------------------
+        // More column slices = longer row ranges = less x pulled through every CU, at the price of the combine pass; fewer
+        // rows per block = deeper x ring = refill latency hidden even when a (row range, sub-tile) unit holds only a few
+        // thousand non-zeros (hyper-sparse matrices).  Cost model in microseconds, constants measured on MI355X:
+        //   x volume through one CU at ~120 GB/s; a refill takes ~0.8 us to land, ring-1 of them overlap, a unit's stream
+        //   time (~25 GB/s per CU) hides the rest; ~8 us of prologue + epilogue per block; the combine kernel.
+        light_wgs = kLightWorkgroupsPerCu;
+        if (const char* force = env_switch("HISPARSE_LIGHT_WGS")) light_wgs = std::min<uint32_t>(6u, std::max(1, std::atoi(force)));
+        G = std::max<uint32_t>(1, max_workgroups) * (light ? light_wgs : 1u);
+        slices = 1;
+        max_rows = light ? kLightMaxBlockRows : max_block_rows(false);
+        if (light) {
+            if (const char* force_rows = env_switch("HISPARSE_MAX_ROWS")) max_rows = std::min<uint32_t>(max_rows, std::max(1, std::atoi(force_rows)));   // tests: chains of blocks
+        } else {
+            const char* force_slices = env_switch("HISPARSE_COL_SLICES");
+            const char* force_rows = env_switch("HISPARSE_MAX_ROWS");   // experiments
+            struct Shape { uint32_t cap, ring; };
+            // OWNER: 4-byte accumulators -> 24561 rows with a ring of 2, 16369 with a ring of 3, sliced or not
+            const Shape sliced[2] = {{owner ? owner_max_block_rows(2) : max_block_rows(true), 2},
+                                     {owner ? owner_max_block_rows(3) : (kMaxLdsBytes - 3 * kSubTileCols * 4) / kAccumulatorBytes - 1, 3}};   // 12287 / 8191 rows
+            const Shape whole[1] = {{max_block_rows(false), kMaxXBuffers}};                                       // 4095 rows, ring 4
+            const double sub_tiles = double(CP) * S;
+            std::map<uint64_t, TileCensus::Eval> census_memo;
+            double best = 1e30;
+            for (uint32_t cs = 1; cs <= (force_slices ? kMaxForcedColSlices : kMaxColSlices); ++cs) {
+                // unforced: every count the cost model likes.  (Through round 4 only 1, 2, 4, 8 for matrices of more than sixteen sub-tiles -- everything
+                // in between for OWNER, where the x volume decides: ogbn-products runs 241 us in 5 slices (102 ranges of 24 K rows, 2 blocks per
+                // workgroup) against 280 in 2 (127 ranges) and 275 in 4 -- because five slices had measured as a wash on ogbl-ppa and 3 us slower on
+                // its R-MAT stand-in, a PAIRS image then.  Measured again in round 5 (profiles/r05_any_slice_count.txt, whole step, alternating):
+                // ogbl-ppa 55.2-56.0 us in 4 slices, 54.0-54.5 in 5 (51 row ranges x 5 = 255 blocks: fewer, longer units); the R-MAT stand-in
+                // 58.4-59.0 -> 55.2-55.4; hollywood keeps 2, its slabs and ogbl-ppa's keep 8 (a 2-way slab takes 5 or 7: +-1 %).
+                // HISPARSE_POW2_SLICES=1 brings the old rule back for the A/B.)
+                // (a matrix of at most sixteen sub-tiles: a slice per sub-tile (or two) is the plan without x refills and
+                // unit barriers (gplus, 14 sub-tiles: 23.7 us in 7 slices, 26.1 in 8), and a power of two above the sub-tile count would leave
+                // whole slices, i.e. workgroups, empty)
+                const uint32_t live_tiles = (num_cols + kSubTileCols - 1) / kSubTileCols;
+                if (force_slices ? uint32_t(std::atoi(force_slices)) != cs : (!owner && (cs & (cs - 1)) != 0 && live_tiles > 2 * kMaxColSlices && env_switch("HISPARSE_POW2_SLICES"))) continue;
+                if (cs > 1 && uint64_t(CP) * S < cs) continue;                                    // fewer sub-tiles than slices
+                if (!force_slices && !owner && live_tiles <= kMaxColSlices && cs > live_tiles) continue;
+                for (const Shape& shape : (cs > 1 || owner) ? std::vector<Shape>(sliced, sliced + 2) : std::vector<Shape>(whole, whole + 1)) {
+                    uint32_t cap = shape.cap, ring = shape.ring;
+                    if (force_rows) {
+                        cap = std::min<uint32_t>(cap, std::max(1, std::atoi(force_rows)));
+                        ring = std::max(kMinXBuffers, std::min(kMaxXBuffers, (kMaxLdsBytes - (cap + spare_rows) * acc_bytes) / (kSubTileCols * 4u)));
+                    }
+                    const uint64_t per_round = std::max<uint32_t>(1, G / cs);
+                    const uint64_t need = (uint64_t(num_rows) + cap - 1) / cap;
+                    const double ranges = double(per_round * std::max<uint64_t>(1, (need + per_round - 1) / per_round));
+                    const double blocks_per_wg = ranges * cs / G;
+                    // the plan's real units and loads (TileCensus): the non-empty (row range x sub-tile) cells, the heaviest workgroup's share
+                    const uint64_t memo_key = (uint64_t(ranges) << 8) | cs;
+                    auto found = census_memo.find(memo_key);
+                    if (found == census_memo.end()) found = census_memo.emplace(memo_key, census.evaluate(uint64_t(ranges), cs, G, out.nnz)).first;
+                    const TileCensus::Eval& real = found->second;
+                    const double units_per_wg = std::max(1.0, real.nonempty_units / G);
+                    const double unit_stream_us = double(out.nnz) * 8.0 / (units_per_wg * G) / 25e3;
+                    // x pulled through a CU: 120 GB/s next to a DELTA / PAIRS stream (ogbl-ppa: 0.1 us per row range); OWNER's units are
+                    // short and every one ends in a flush and a barrier, which also scale with the ranges: 1.34 us per range on
+                    // ogbn-products = 29 GB/s (tools/slices_probe.sh)
+                    const double volume_us = real.nonempty_units * double(L.sub_width) * 4.0 / G / (owner ? 29e3 : 120e3);      // (uniform matrix: ranges x num_cols x 4 bytes)
+                    double latency_us = units_per_wg * std::max(0.0, 0.8 / (ring - 1) - unit_stream_us);
+                    // Blocks of a few long rows (<= kDenseBlockRows) take the dense-row path: a wavefront sums a row in registers and pays a
+                    // wavefront-wide reduction at every row change.  That is right for rows that fill many chunks of a sub-tile (pruned-NN
+                    // layers: 16 K non-zeros per row) and slow when a (row, sub-tile) holds only a chunk or two -- one rank's slab of mouse_gene
+                    // split 8 ways (5632 rows x 45 K columns, 22-row blocks, 117 non-zeros per row and sub-tile) ran 2.5 us per unit, 22.7 us
+                    // for 29 MB; in 3 column slices (blocks of 66 rows, ordinary path) 11.5 us + the combine pass.  Price it.
+                    // an unsliced block walks ALL sub-tiles: every unit boundary costs it a head record per wavefront, a barrier and a refill
+                    // issue, ~0.3 us that the stream does not hide (gplus, 14 units per block: 28.6 us in one slice, 24.0 in seven, same
+                    // format; mouse_gene's 2-way slabs 21.9 -> 20.8) -- sliced plans have a fraction of the units and pay the combine pass instead
+                    if (!owner && cs == 1) latency_us += units_per_wg * 0.3;
+                    // few sub-tiles dealt to slices that do not divide them: the blocks of the slices with one sub-tile more set the time (gplus,
+                    // 14 sub-tiles: 23.9 / 27.4 / 24.7 / 26.1 us in 5 / 6 / 7 / 8 slices)
+                    if (!owner && cs > 1 && live_tiles <= 2 * kMaxColSlices)
+                        latency_us += 0.75 * (double(out.nnz) * 8.0 / G / 25e3) * (double((live_tiles + cs - 1) / cs) * cs / live_tiles - 1.0);
+                    const double rows_per_block = double(num_rows) / ranges, per_row_and_tile = double(out.nnz) / std::max(1.0, double(num_rows) * sub_tiles * census.populated);
+                    if (!owner && rows_per_block <= kDenseBlockRows && per_row_and_tile < 4.0 * kWaveLanes) latency_us += units_per_wg * 1.75;
+                    // PAIRS deals a unit's elements, sorted by (row, column), to the lanes in consecutive runs: the 64 lanes of a step sit
+                    // 1/896 of the unit apart, and when the block has fewer than 896 rows several of them are in the SAME row -- their
+                    // ds_add_u64 on one accumulator are serialised.  One rank's slab of mouse_gene split 4 ways (44-row blocks, ~20 lanes
+                    // per row): 15-26 us in one slice against 12.7-13.7 us in six (268-row blocks, one sub-tile each, combine pass included).
+                    // ~2 clocks per extra lane and wavefront step, all wavefronts of a workgroup through the one LDS.  (DELTA blocks of
+                    // long rows keep per-lane sums instead -- no atomics to collide.)
+                    const double lanes_per_row = std::min(64.0, 896.0 / std::max(1.0, rows_per_block));
+                    // (DELTA is still tentative here: below ~1.6 bytes saved per non-zero x nnz < the threshold it falls back to PAIRS, see "DELTA or PAIRS")
+                    const bool pairs_likely = !delta || (!format_forced && double(out.nnz) * 1.6 < double(is_float ? kDeltaMinSavedBytesFloat : kDeltaMinSavedBytes));
+                    const double conflict_us = (!owner && pairs_likely && lanes_per_row > 1.0 && per_row_and_tile >= 16.0)
+                                                   ? double(out.nnz) / G / kWaveLanes * (lanes_per_row - 1.0) * 2.0 / 2400.0 : 0.0;
+                    // the combine pass: a launch of its own (3.5 us) + its traffic -- or ~1 us of the NEXT step's kernel where the image is small
+                    // enough for the carried combine (hs_api.cpp; stream_tiles.h: kCarryMaxImageBytes)
+                    const bool carried = double(out.nnz) * 8.1 < double(kCarryMaxImageBytes);
+                    const double combine_us = cs > 1 ? (carried ? 1.0 : 3.5) + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
+                    // workgroup slots that get no block (7 slices x 36 row ranges = 252 blocks on 256 workgroups): the stream they would have taken
+                    // is the others' -- what tells 7 slices from 8 on mid-size wide matrices (profiles/r05_any_slice_count.txt)
+                    // -- round 6: the heaviest workgroup's real share (TileCensus): the same term for a uniform matrix, and what makes column slices of a
+                    // banded matrix as expensive as they are (most of its (row range x slice) blocks are empty)
+                    // (charged beyond the uniform picture only where the real imbalance exceeds it by more than 15 %: the slice counts of the scrambled
+                    //  graphs were settled by measurement to within a microsecond -- ogbl-ppa 5 slices, gplus 7 -- and the census rows are coarser than that)
+                    const double uniform_load = double(out.nnz) / std::max(1.0, ranges * cs) * std::ceil(blocks_per_wg);
+                    const double idle_us = double(out.nnz) * 8.0 / 6.2e6 * ((std::ceil(blocks_per_wg) / std::max(1e-9, blocks_per_wg) - 1.0) +
+                                                                         std::max(0.0, real.max_wg_load / std::max(1.0, uniform_load) - 1.15) * uniform_load / std::max(1.0, double(out.nnz) / G));
+                    const double cost = volume_us + latency_us + conflict_us + 8.0 * blocks_per_wg + combine_us + idle_us;
+                    if (detail::env_switch("HISPARSE_PLAN_DEBUG"))
+                        std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f conflicts %.1f blocks/wg %.2f idle %.2f combine %.1f => %.2f us\n", cs, cap, ring, ranges,
+                                     volume_us, latency_us, conflict_us, blocks_per_wg, idle_us, combine_us, cost);
+                    if (cost < best) { best = cost; slices = cs; max_rows = cap; }
                 }
-                const uint64_t per_round = std::max<uint32_t>(1, G / cs);
-                const uint64_t need = (uint64_t(num_rows) + cap - 1) / cap;
-                const double ranges = double(per_round * std::max<uint64_t>(1, (need + per_round - 1) / per_round));
-                const double blocks_per_wg = ranges * cs / G;
-                // the plan's real units and loads (TileCensus): the non-empty (row range x sub-tile) cells, the heaviest workgroup's share
-                const uint64_t memo_key = (uint64_t(ranges) << 8) | cs;
-                auto found = census_memo.find(memo_key);
-                if (found == census_memo.end()) found = census_memo.emplace(memo_key, census.evaluate(uint64_t(ranges), cs, G, out.nnz)).first;
-                const TileCensus::Eval& real = found->second;
-                const double units_per_wg = std::max(1.0, real.nonempty_units / G);
-                const double unit_stream_us = double(out.nnz) * 8.0 / (units_per_wg * G) / 25e3;
-                // x pulled through a CU: 120 GB/s next to a DELTA / PAIRS stream (ogbl-ppa: 0.1 us per row range); OWNER's units are
-                // short and every one ends in a flush and a barrier, which also scale with the ranges: 1.34 us per range on
-                // ogbn-products = 29 GB/s (tools/slices_probe.sh)
-                const double volume_us = real.nonempty_units * double(L.sub_width) * 4.0 / G / (owner ? 29e3 : 120e3);      // (uniform matrix: ranges x num_cols x 4 bytes)
-                double latency_us = units_per_wg * std::max(0.0, 0.8 / (ring - 1) - unit_stream_us);
-                // Blocks of a few long rows (<= kDenseBlockRows) take the dense-row path: a wavefront sums a row in registers and pays a
-                // wavefront-wide reduction at every row change.  That is right for rows that fill many chunks of a sub-tile (pruned-NN
-                // layers: 16 K non-zeros per row) and slow when a (row, sub-tile) holds only a chunk or two -- one rank's slab of mouse_gene
-                // split 8 ways (5632 rows x 45 K columns, 22-row blocks, 117 non-zeros per row and sub-tile) ran 2.5 us per unit, 22.7 us
-                // for 29 MB; in 3 column slices (blocks of 66 rows, ordinary path) 11.5 us + the combine pass.  Price it.
-                // an unsliced block walks ALL sub-tiles: every unit boundary costs it a head record per wavefront, a barrier and a refill
-                // issue, ~0.3 us that the stream does not hide (gplus, 14 units per block: 28.6 us in one slice, 24.0 in seven, same
-                // format; mouse_gene's 2-way slabs 21.9 -> 20.8) -- sliced plans have a fraction of the units and pay the combine pass instead
-                if (!owner && cs == 1) latency_us += units_per_wg * 0.3;
-                // few sub-tiles dealt to slices that do not divide them: the blocks of the slices with one sub-tile more set the time (gplus,
-                // 14 sub-tiles: 23.9 / 27.4 / 24.7 / 26.1 us in 5 / 6 / 7 / 8 slices)
-                if (!owner && cs > 1 && live_tiles <= 2 * kMaxColSlices)
-                    latency_us += 0.75 * (double(out.nnz) * 8.0 / G / 25e3) * (double((live_tiles + cs - 1) / cs) * cs / live_tiles - 1.0);
-                const double rows_per_block = double(num_rows) / ranges, per_row_and_tile = double(out.nnz) / std::max(1.0, double(num_rows) * sub_tiles * census.populated);
-                if (!owner && rows_per_block <= kDenseBlockRows && per_row_and_tile < 4.0 * kWaveLanes) latency_us += units_per_wg * 1.75;
-                // PAIRS deals a unit's elements, sorted by (row, column), to the lanes in consecutive runs: the 64 lanes of a step sit
-                // 1/896 of the unit apart, and when the block has fewer than 896 rows several of them are in the SAME row -- their
-                // ds_add_u64 on one accumulator are serialised.  One rank's slab of mouse_gene split 4 ways (44-row blocks, ~20 lanes
-                // per row): 15-26 us in one slice against 12.7-13.7 us in six (268-row blocks, one sub-tile each, combine pass included).
-                // ~2 clocks per extra lane and wavefront step, all wavefronts of a workgroup through the one LDS.  (DELTA blocks of
-                // long rows keep per-lane sums instead -- no atomics to collide.)
-                const double lanes_per_row = std::min(64.0, 896.0 / std::max(1.0, rows_per_block));
-                // (DELTA is still tentative here: below ~1.6 bytes saved per non-zero x nnz < the threshold it falls back to PAIRS, see "DELTA or PAIRS")
-                const bool pairs_likely = !delta || (!format_forced && double(out.nnz) * 1.6 < double(is_float ? kDeltaMinSavedBytesFloat : kDeltaMinSavedBytes));
-                const double conflict_us = (!owner && pairs_likely && lanes_per_row > 1.0 && per_row_and_tile >= 16.0)
-                                               ? double(out.nnz) / G / kWaveLanes * (lanes_per_row - 1.0) * 2.0 / 2400.0 : 0.0;
-                // the combine pass: a launch of its own (3.5 us) + its traffic -- or ~1 us of the NEXT step's kernel where the image is small
-                // enough for the carried combine (hs_api.cpp; stream_tiles.h: kCarryMaxImageBytes)
-                const bool carried = double(out.nnz) * 8.1 < double(kCarryMaxImageBytes);
-                const double combine_us = cs > 1 ? (carried ? 1.0 : 3.5) + double(num_rows) * 4.0 * (cs + 1) / 4e6 : 0.0;
-                // workgroup slots that get no block (7 slices x 36 row ranges = 252 blocks on 256 workgroups): the stream they would have taken
-                // is the others' -- what tells 7 slices from 8 on mid-size wide matrices (profiles/r05_any_slice_count.txt)
-                // -- round 6: the heaviest workgroup's real share (TileCensus): the same term for a uniform matrix, and what makes column slices of a
-                // banded matrix as expensive as they are (most of its (row range x slice) blocks are empty)
-                // (charged beyond the uniform picture only where the real imbalance exceeds it by more than 15 %: the slice counts of the scrambled
-                //  graphs were settled by measurement to within a microsecond -- ogbl-ppa 5 slices, gplus 7 -- and the census rows are coarser than that)
-                const double uniform_load = double(out.nnz) / std::max(1.0, ranges * cs) * std::ceil(blocks_per_wg);
-                const double idle_us = double(out.nnz) * 8.0 / 6.2e6 * ((std::ceil(blocks_per_wg) / std::max(1e-9, blocks_per_wg) - 1.0) +
-                                                                     std::max(0.0, real.max_wg_load / std::max(1.0, uniform_load) - 1.15) * uniform_load / std::max(1.0, double(out.nnz) / G));
-                const double cost = volume_us + latency_us + conflict_us + 8.0 * blocks_per_wg + combine_us + idle_us;
-                if (detail::env_switch("HISPARSE_PLAN_DEBUG"))
-                    std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f conflicts %.1f blocks/wg %.2f idle %.2f combine %.1f => %.2f us\n", cs, cap, ring, ranges,
-                                 volume_us, latency_us, conflict_us, blocks_per_wg, idle_us, combine_us, cost);
-                if (cost < best) { best = cost; slices = cs; max_rows = cap; }
             }
         }
+        const bool pairs_family = out.format == kFormatPairs || (out.format == kFormatDelta && double(out.nnz) * 1.6 < double(kDeltaMinSavedBytesFloat));
+        if (attempt == 0 && is_float && !owner && !light && !format_forced && !g_no_owner && pairs_family && slices == 1 && out.nnz >= kFloatOneSliceOwnerMinNnz &&
+            !env_switch("HISPARSE_COL_SLICES") && !env_switch("HISPARSE_MAX_ROWS")) {
+            if (env_switch("HISPARSE_PLAN_DEBUG")) std::fprintf(stderr, "format: float mode, one-slice PAIRS-family plan of %llu non-zeros -> planned again as OWNER24\n", (unsigned long long)out.nnz);
+            out.format = kFormatOwner24;
+            continue;
+        }
+        break;
     }
     if (uint64_t(slices) * num_rows > 0xffffffffull) {   // Block::out_offset = slice * num_rows + row0 is a 32-bit word offset
         while (slices > 1 && uint64_t(slices) * num_rows > 0xffffffffull) slices /= 2;
@@ -586,11 +625,16 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             blk.last_part = ranges[b].last_part;
             if (delta) {   // long rows: position gaps well inside a row (HISPARSE_ROW_RUNS=0|1 forces, for the tests)
                 // (over the rows that HAVE non-zeros: the padding rows at the end of a float_stall matrix would make the last block look sparse)
-                uint32_t live_rows = 0;
-                for (uint32_t r = 0; r < ranges[b].nrows; ++r) live_rows += row_nnz[ranges[b].row0 + r] != 0;
+                uint32_t live_rows = 0, heaviest = 0;
+                for (uint32_t r = 0; r < ranges[b].nrows; ++r) {
+                    live_rows += row_nnz[ranges[b].row0 + r] != 0;
+                    heaviest = std::max(heaviest, row_nnz[ranges[b].row0 + r]);
+                }
                 const double gap = range_nnz[b] ? double(live_rows) * double(num_cols) / double(range_nnz[b]) : 1e30;
+                // (a hub row: an eighth of the block in one row -- eight lanes of every step, more in the hub's own sub-tiles, would add to ONE accumulator; see "hub rows" above)
+                const bool hub_block = heaviest >= 4096 && uint64_t(heaviest) * 8 >= range_nnz[b];
                 const char* force = env_switch("HISPARSE_ROW_RUNS");
-                blk.flags = (force ? std::atoi(force) != 0 : gap < kDenseMeanGap) ? kBlockDenseRows : 0u;
+                blk.flags = (force ? std::atoi(force) != 0 : (gap < kDenseMeanGap || hub_block)) ? kBlockDenseRows : 0u;
             } else if (owner) {
                 blk.flags = 0;
             } else if (light) {

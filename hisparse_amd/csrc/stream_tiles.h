@@ -216,6 +216,7 @@ constexpr uint32_t kSweepColAlign = 32;                       // slices start on
 // float_pob; ogbn-products (48 K) stays OWNER24 (204 against 216 us).
 constexpr double kSweepSlabMinMeanGap = 8000.0;                // short, wide fixed-point slabs that fit the Infinity Cache take SWEEP from this mean gap on (stream_tiles.cpp)
 constexpr uint64_t kSweepMinNnz = (2u << 20) + 1;             // smaller matrices: the LIGHT plan's (when x is short) or the row-block kernel's
+constexpr uint64_t kFloatOneSliceOwnerMinNnz = 8u << 20;         // float modes: a one-slice PAIRS-family plan of at least this many non-zeros is planned again as OWNER24 (stream_tiles.cpp, round 6)
 constexpr uint64_t kSweepMinNnzWide = 256u << 10;             // ... unless x is wider than the LIGHT plan takes (kLightMaxUnits sub-tiles): SWEEP from here on (round 6)
 constexpr uint32_t kDenseBlockRows = 32;                      // blocks with at most this many rows use the dense-row layout
 constexpr uint32_t kBlockDenseRows = 1u;                      // Block::flags bit

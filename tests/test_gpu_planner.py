@@ -5,11 +5,11 @@ takes by itself must run within 10 % of the best plan that can be FORCED (every 
 and every forced plan must give the planner's y.  The reference's analogue is its design-space sweep
 (performance_model/design_space_exp.cpp:496-547).
 
-The full list (24 matrices; `python tools/planner_check.py`, profiles/r06_planner_check_after.txt) has four known misses, asserted here at
-their measured ratio + a margin so that they are SEEN, not hidden: a matrix whose 50 hub rows hold 64 % of the non-zeros (PAIRS: all lanes
-of a step on one LDS accumulator; SWEEP would be 1.9 x faster), a float block-diagonal matrix of 64 x 64 blocks (OWNER24 1.44 x), a 3 M x 8 K
-tall matrix of 6 non-zeros per row (OWNER24 1.17 x) and a 60 %-dense float layer (DELTA 1.13 x: the sliced-DELTA rule is fixed-point only).
-Before the tile census of round 6 the same list read: 14 of 24 within 10 %, six between 2.1 x and 5.9 x (profiles/r06_planner_check_before.txt)."""
+The full list (24 matrices; `python tools/planner_check.py`, profiles/r06_planner_check_after.txt): 23 within 10 %, median 1.016, one known miss asserted
+here at its measured ratio + a margin so that it is SEEN, not hidden: a 60 %-dense float layer of one sub-tile (DELTA 1.14 x: the sliced-DELTA rule is
+fixed-point only).  Before round 6 the same list read: 14 of 24 within 10 %, six between 2.1 x and 5.9 x (profiles/r06_planner_check_before.txt); what
+closed the gap: the tile census (banded / block-diagonal matrices and their slabs), the SWEEP model fitted again, SWEEP for small wide matrices, per-lane
+row sums for DELTA blocks with a hub row (a matrix whose 50 hub rows hold 52 % of the non-zeros: 89 -> 44.9 us), OWNER24 for one-slice float plans."""
 import os
 import sys
 
@@ -23,8 +23,9 @@ pytestmark = pytest.mark.gpu
 # (name, bound on planner time / best forced time).  A subset that builds in a few seconds each; the whole list: tools/planner_check.py.
 WITHIN_10_PERCENT = ["banded_400k_d40_w2k", "blockdiag_200k_b512_p10", "rmat19_45_15_15", "bipartite_20k_x_2m_200", "bipartite_100k_x_4m_60", "tall_2m_x_50k_10",
                      "er_300k_30", "er_1500k_8", "dense_2048_x_8k_15", "dense_256_x_64k_8", "slab8_of_rmat19", "slab4_of_banded_400k", "slab8_of_er_300k",
-                     "slab4_of_bipartite_100k", "slab8_of_tall_2m", "banded_1m_d12_w50k"]
-KNOWN_MISSES = {"tall_3m_x_8k_6": 1.30, "dense_4096_x_4k_60": 1.25}      # (+ hubs 1.93 and blockdiag_600k 1.44 in the full list: too slow to build here)
+                     "slab4_of_bipartite_100k", "slab8_of_tall_2m", "tall_3m_x_8k_6", "hubs_500k_15_plus_50x200k", "blockdiag_600k_b64_p50"]
+KNOWN_MISSES = {"dense_4096_x_4k_60": 1.25,
+                "banded_1m_d12_w50k": 1.16}      # (measured 1.02-1.09: OWNER24 in 4 slices where 2 would be 8 % faster -- inside 10 %, but too close to assert at 1.10)
 
 
 @pytest.mark.parametrize("name", WITHIN_10_PERCENT + sorted(KNOWN_MISSES))
