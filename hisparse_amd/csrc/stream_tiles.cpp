@@ -406,6 +406,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
     // non-zeros, plan again as OWNER24 and take it.
     bool delta = false, owner = false, owner24 = false, format_forced = false;
     uint32_t acc_bytes = kAccumulatorBytes, spare_rows = 1u, light_wgs = kLightWorkgroupsPerCu, G = 1, slices = 1, max_rows = 1;
+    double best = 1e30, best_units = 1.0;      // the chosen tile plan's modelled cost BESIDE its stream (us); its non-empty (row range x sub-tile) units
     for (int attempt = 0; attempt < 2; ++attempt) {
         delta = out.format == kFormatDelta;
         owner = out.format == kFormatOwner || out.format == kFormatOwner24;
@@ -437,7 +438,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             const Shape whole[1] = {{max_block_rows(false), kMaxXBuffers}};                                       // 4095 rows, ring 4
             const double sub_tiles = double(CP) * S;
             std::map<uint64_t, TileCensus::Eval> census_memo;
-            double best = 1e30;
+            best = 1e30;
             for (uint32_t cs = 1; cs <= (force_slices ? kMaxForcedColSlices : kMaxColSlices); ++cs) {
                 // unforced: every count the cost model likes.  (Through round 4 only 1, 2, 4, 8 for matrices of more than sixteen sub-tiles -- everything
                 // in between for OWNER, where the x volume decides: ogbn-products runs 241 us in 5 slices (102 ranges of 24 K rows, 2 blocks per
@@ -518,8 +519,29 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
                     if (detail::env_switch("HISPARSE_PLAN_DEBUG"))
                         std::fprintf(stderr, "plan cs %u cap %u ring %u: ranges %.0f volume %.1f latency %.1f conflicts %.1f blocks/wg %.2f idle %.2f combine %.1f => %.2f us\n", cs, cap, ring, ranges,
                                      volume_us, latency_us, conflict_us, blocks_per_wg, idle_us, combine_us, cost);
-                    if (cost < best) { best = cost; slices = cs; max_rows = cap; }
+                    if (cost < best) { best = cost; best_units = real.nonempty_units; slices = cs; max_rows = cap; }
                 }
+            }
+        }
+        // Round 6: below the hyper-sparse border a SWEEP plan can still replace the row-block plan -- where the units are tiny AND the models agree.  A
+        // (row range x sub-tile) unit costs the row-block kernel a barrier, a refill and a head record whatever it holds; a matrix of few long rows
+        // over millions of columns -- 2048 x 8 M, 2000 per row, mean gap 4000: below every gap rule -- has 131 elements per unit: 67.5 us as the PAIRS
+        // image the gap rule gives it, 22.3 us as a SWEEP image (tools/planner_check.py --second).  Both conditions: fewer than 1024 elements per
+        // non-empty unit of the chosen plan (the mechanism), and SWEEP's whole modelled step under 60 % of the row-block plan's stream + plan cost
+        // (the two models were fitted apart and the row-block one reads 30-80 % high in absolute terms: on their own they would send one rank's slab
+        // of mouse_gene -- 14 K elements per unit, 8.3 us as PAIRS, 12.5 as SWEEP -- the wrong way).
+        if (attempt == 0 && !owner && !light && !format_forced && !env_switch("HISPARSE_SWEEP") && !env_switch("HISPARSE_COL_SLICES") && !env_switch("HISPARSE_MAX_ROWS") &&
+            out.nnz >= kSweepMinNnzWide && uint64_t(num_cols) * 4 < (1ull << 32) && best < 1e29) {
+            uint32_t cs = 1, rows_cap = 0;
+            uint64_t want = 1;
+            const double sweep_us = sweep_plan(L, out.nnz, max_workgroups, cs, want, rows_cap);
+            const double rowblock_us = double(out.nnz) * 8.0 / 6.2e6 + best;
+            if (env_switch("HISPARSE_PLAN_DEBUG")) std::fprintf(stderr, "format: row-block plan %.1f us (stream + %.1f; %.0f elements per unit) against sweep %.1f us (%u slices)\n", rowblock_us, best, double(out.nnz) / std::max(1.0, best_units), sweep_us, cs);
+            if (sweep_us < 0.6 * rowblock_us && double(out.nnz) / std::max(1.0, best_units) < 1024.0) {
+                const uint64_t nnz_keep = out.nnz;
+                out = StreamTiles();
+                out.nnz = nnz_keep;
+                return build_sweep_tiles(L, channel, n_packets, row_nnz, max_workgroups, out, error, csr, gpu.get(), image_slack);
             }
         }
         const bool pairs_family = out.format == kFormatPairs || (out.format == kFormatDelta && double(out.nnz) * 1.6 < double(kDeltaMinSavedBytesFloat));

@@ -23,15 +23,17 @@ pytestmark = pytest.mark.gpu
 # (name, bound on planner time / best forced time).  A subset that builds in a few seconds each; the whole list: tools/planner_check.py.
 WITHIN_10_PERCENT = ["banded_400k_d40_w2k", "blockdiag_200k_b512_p10", "rmat19_45_15_15", "bipartite_20k_x_2m_200", "bipartite_100k_x_4m_60", "tall_2m_x_50k_10",
                      "er_300k_30", "er_1500k_8", "dense_2048_x_8k_15", "dense_256_x_64k_8", "slab8_of_rmat19", "slab4_of_banded_400k", "slab8_of_er_300k",
-                     "slab4_of_bipartite_100k", "slab8_of_tall_2m", "tall_3m_x_8k_6", "hubs_500k_15_plus_50x200k", "blockdiag_600k_b64_p50"]
-KNOWN_MISSES = {"dense_4096_x_4k_60": 1.25,
+                     "slab4_of_bipartite_100k", "slab8_of_tall_2m", "tall_3m_x_8k_6", "hubs_500k_15_plus_50x200k", "blockdiag_600k_b64_p50",
+                     # from the SECOND list (tools/planner_check.py --second: written after the rules were final; 9 of 12 within 10 %, profiles/r06_planner_check_second_list.txt)
+                     "wide_2k_x_8m_2000", "hubcols_500k_20_100x30", "stencil_1m_7x4"]
+KNOWN_MISSES = {"dense_4096_x_4k_60": 1.25, "stencil_300k_3x20": 1.45,      # (second list: a fixed-point one-slice plan that OWNER24 would run 1.31 x faster; no rule separates it from the ones it would slow down)
                 "banded_1m_d12_w50k": 1.16}      # (measured 1.02-1.09: OWNER24 in 4 slices where 2 would be 8 % faster -- inside 10 %, but too close to assert at 1.10)
 
 
 @pytest.mark.parametrize("name", WITHIN_10_PERCENT + sorted(KNOWN_MISSES))
 def test_planner_choice_against_the_best_forced_plan(name, record_property):
     import planner_check as pc
-    case = next(c for c in pc.CASES if c[0] == name)
+    case = next(c for c in pc.CASES + pc.SECOND if c[0] == name)
     res = pc.check(name, case[1], case[2](), steps=200, log=lambda s: None)
     record_property("planner", res["planner"])
     record_property("planner_us", res["planner_us"])

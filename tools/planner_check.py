@@ -124,6 +124,44 @@ CASES = [
 ]
 
 
+def hub_columns(n, per_row, hub_cols, share, seed, impl):
+    """`share` of every row's entries fall into `hub_cols` popular columns (a recommender / web graph's popular items), the rest anywhere"""
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(n, dtype=np.int64), per_row)
+    popular = rng.choice(n, hub_cols, replace=False)
+    c = np.where(rng.random(r.size) < share, popular[rng.integers(0, hub_cols, r.size)], rng.integers(0, n, r.size))
+    return _csr(n, n, r, c, seed, impl)
+
+
+def diagonals(n, offsets, width, per_band, seed, impl):
+    """FEM / stencil-like: `per_band` entries per row around each of the given diagonals (offset +- width)"""
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for off in offsets:
+        r = np.repeat(np.arange(n, dtype=np.int64), per_band)
+        rows.append(r)
+        cols.append(np.clip(r + off + rng.integers(-width, width + 1, r.size), 0, n - 1))
+    return _csr(n, n, np.concatenate(rows), np.concatenate(cols), seed, impl)
+
+
+# A SECOND list, written after the rules of round 6 were final and never used to adjust one (--second): road-network-like, stencil-like, popular
+# columns, very wide and short, tiny, moderately dense
+SECOND = [
+    ("road_2m_d3_w1k", FIXED, lambda: banded(2_000_000, 3, 1_000, 21, FIXED)),
+    ("road_4m_d3_w300k", STALL, lambda: banded(4_000_000, 3, 300_000, 22, STALL)),
+    ("stencil_300k_3x20", FIXED, lambda: diagonals(300_000, (-60_000, 0, 60_000), 40, 20, 23, FIXED)),
+    ("stencil_1m_7x4", POB, lambda: diagonals(1_000_000, (-10_000, -100, -1, 0, 1, 100, 10_000), 2, 4, 24, POB)),
+    ("hubcols_500k_20_100x30", FIXED, lambda: hub_columns(500_000, 20, 100, 0.30, 25, FIXED)),
+    ("hubcols_1m_12_1000x50", STALL, lambda: hub_columns(1_000_000, 12, 1000, 0.50, 26, STALL)),
+    ("wide_2k_x_8m_2000", FIXED, lambda: uniform(2_048, 8_000_000, 2000, 27, FIXED)),
+    ("tiny_5k_10", FIXED, lambda: uniform(5_000, 5_000, 10, 28, FIXED)),
+    ("tiny_20k_x_200k_5", POB, lambda: uniform(20_000, 200_000, 5, 29, POB)),
+    ("dense5_20k", FIXED, lambda: dense_rows(20_000, 20_000, 0.05, 30, FIXED)),
+    ("dense2_60k_x_30k", STALL, lambda: dense_rows(60_000, 30_000, 0.02, 31, STALL)),
+    ("rmat22_57_19_19", FIXED, lambda: rmat(22, 40_000_000, 0.57, 0.19, 0.19, 32, FIXED)),
+]
+
+
 def reference(name, impl_name=None):
     """one of the seeded stand-ins of the reference's benchmark list (hisparse_amd/datasets.py): the matrices the planner's constants WERE measured on"""
     import scipy.sparse as sp
@@ -193,6 +231,9 @@ def check(name, impl, m, steps=200, log=print):
         rows.append({"forced": tag, "us": None if us is None else round(us, 2), "plan": plan})
     timed = [r for r in rows if r["us"] is not None and "DIFFERS" not in r["plan"]]
     best = min(timed, key=lambda r: r["us"]) if timed else None
+    # a forced variant that comes out as the planner's OWN plan is the same image measured again: the planner's time is the best of those measurements
+    # (a 3-4 us step differs by 25 % from one measurement to the next)
+    own_us = min([own_us] + [r["us"] for r in timed if r["plan"] == own_plan])
     ratio = own_us / min(own_us, best["us"]) if best else 1.0
     res = {"matrix": name, "impl": ["fixed", "float_pob", "float_stall"][impl], "shape": list(m.shape), "nnz": int(m.nnz), "planner": own_plan, "planner_us": round(own_us, 2),
            "best_forced": best["plan"] if best else None, "best_forced_us": best["us"] if best else None, "planner_over_best": round(ratio, 3),
@@ -208,11 +249,12 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--json", default=None)
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--second", action="store_true", help="the second out-of-sample list (written after the planner's rules were final)")
     ap.add_argument("--reference", action="store_true", help="the reference's own benchmark matrices (in-sample) instead of the out-of-sample cases")
     a = ap.parse_args()
     pick = set(a.only.split(",")) if a.only else set(QUICK) if a.quick else None
     out = []
-    for name, impl, build in (REFERENCE if a.reference else CASES):
+    for name, impl, build in (REFERENCE if a.reference else SECOND if a.second else CASES):
         if pick and name not in pick:
             continue
         t0 = time.perf_counter()
