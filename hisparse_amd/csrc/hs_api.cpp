@@ -560,7 +560,7 @@ int load_matrix_impl(hs_context* ctx, const void* const* channel, const uint64_t
         // is a wash that depends on the box and the run (ogbl-ppa 55.4 -> 53.5 / 54.2 / 57.0 us, hollywood 137.0 -> 135.1 / 139.1, the R-MAT
         // stand-in 60.0 -> 57.8 / 62.0, ogbn-products 206 -> 204; pokec's SWEEP kernel 73.5 -> 76.0: 33 MB of partial rows in front of every
         // launch): the partial rows a workgroup adds up were written by OTHER XCDs and come back from the memory side while nothing else of
-        // the workgroup can start.  Hence: on by itself for images below 48 MiB, the launch-bound regime, and for OWNER images; `carry_combine` = 0 | 1 decides otherwise.
+        // the workgroup can start.  Hence: on by itself for images below 160 MiB (48 MiB until the middle was measured in round 6: stream_tiles.h, kCarryMaxImageBytes), the launch-bound regime, and for OWNER images; `carry_combine` = 0 | 1 decides otherwise.
         const char* opt = ctx_option(ctx, "HISPARSE_CARRY_COMBINE");
         const uint64_t image_bytes = image_on_device ? tiles.image_bytes : uint64_t(tiles.image.size());
         // (OWNER / OWNER24 images of any size too: ogbn-products gained 1-1.5 % in every one of four A/B pairs on two boxes (profiles/r05_carry_combine_ab.txt) -- its workgroups

@@ -264,7 +264,7 @@ bool build_stream_tiles_once(const void* const channel[NUM_HBM_CHANNELS], const 
             const double scale = 256.0 / std::max<uint32_t>(1, max_workgroups);
             sliced_delta_us = 5.8 + double(out.nnz) * 1.0e-6 * scale;
             sliced_delta_possible = !is_float && live_tiles >= 1 && live_tiles <= kMaxColSlices && density >= 0.04 && num_cols >= kBitmapMinCols &&
-                                    double(out.nnz) * 7.0 < double(kCarryMaxImageBytes) && RP == 1 && out.nnz >= (1u << 20);      // (measured between 0.85 and 8.5 M non-zeros)
+                                    double(out.nnz) * 7.0 < double(kSlicedDeltaMaxImageBytes) && RP == 1 && out.nnz >= (1u << 20);      // (measured between 0.85 and 8.5 M non-zeros)
             const double bitmap_us = 5.0 + double(num_rows) * double((num_cols + kBitmapGroupCols - 1) / kBitmapGroupCols) / std::max<uint32_t>(1, max_workgroups) * 7.5e-3;
             if (bitmap && sliced_delta_possible && sliced_delta_us < 0.97 * bitmap_us && !env_switch("HISPARSE_STREAM_FORMAT")) {
                 bitmap = false;

@@ -87,7 +87,11 @@ constexpr uint32_t kMaxForcedColSlices = 16;   // HISPARSE_COL_SLICES / col_slic
 constexpr uint32_t kMaxSweepSlices = 16;      // SWEEP images (round 5): a short, wide matrix -- one rank's slab -- wants few row ranges (every range sweeps all of x) and many slices
 // Column-sliced plans whose image stays below this carry the combine pass of a step into the next step's kernel (hs_api.cpp: one launch per
 // step in a run of hs_run calls); the planner prices the combine pass of such a plan at ~1 us instead of a launch of its own (3.5 us).
-constexpr uint64_t kCarryMaxImageBytes = 48ull << 20;
+// Round 5 set 48 MiB from two points (a 29 MB slab: 10.1 -> 8.6 us; ogbl-ppa, 280 MB: a wash; pokec's SWEEP image, 247 MB: 73.5 -> 76.0).  Round 6 measured the
+// middle (profiles/r06_carry_mid_size.txt, alternating runs): gplus (87 MB) 19.9 -> 19.3 us, one rank's slab of mouse_gene split 2 ways (89 MB) 20.2 -> 19.4,
+// of hollywood split 8 ways (SWEEP, 113 MB) 24.6 -> 24.1, of ogbl-ppa split 2 ways (155 MB) 32.2 -> 31.4: carried up to 160 MiB.
+constexpr uint64_t kCarryMaxImageBytes = 160ull << 20;
+constexpr uint64_t kSlicedDeltaMaxImageBytes = 48ull << 20;   // the sliced DELTA plan of fixed-point dense layers (stream_tiles.cpp): measured up to 8.5 M non-zeros, no further
 constexpr uint64_t kResidentMaxImageBytes = 256ull << 20;   // SWEEP images up to the size of the Infinity Cache are streamed without the non-temporal hint (hs_api.cpp: stream_resident)
 // Row-block (PAIRS / DELTA) images, round 6 (profiles/r06_rowblock_stream_policy*.txt): without `nt` where the image fits the Infinity Cache AND its blocks walk
 // several units.  Measured to gain a little even above the cache (ogbl-ppa, 267 MiB: -1.5 % warm) -- but an image that does not fit is evicted between

@@ -110,7 +110,7 @@ int hs_load_vector(hs_context* ctx, const void* packed_x, uint32_t num_cols);
  * stand-alone combine is launched only when something else follows -- every other entry point (hs_sync, hs_read_result, hs_feedback,
  * hs_run_partition, hs_bind_device_result with another target, hs_set_stream, ...) launches it first, so the order of effects on the
  * stream is exactly that of "kernel, combine" per call.  With a caller-owned stream (hs_set_stream), or once hs_get_stream has handed the
- * stream out, every call completes in itself.  Chosen per matrix at load time (hs_api.cpp: images below 48 MiB, where the second launch is a
+ * stream out, every call completes in itself.  Chosen per matrix at load time (hs_api.cpp: images below 160 MiB, where the second launch is a
  * large part of the step, and OWNER images); hs_set_option "carry_combine" = 0 | 1 decides otherwise.
  * CONSEQUENCE for callers that look at y through a device pointer (hs_device_result, hs_bind_device_result) on the library's own stream:
  * y of the last hs_run is complete only after an entry point of THIS library has settled it -- hs_sync, hs_read_result, hs_push_result,
