@@ -157,7 +157,7 @@ int hs_push_result(hs_context* ctx, void* const* dst, uint32_t n_dst, uint32_t n
  * (pairs|delta|owner|owner24|sweep|bitmap), col_slices, max_rows, cross_partitions (0: row blocks end at the reference's row-partition borders), spmm_vectors (4: plan the image for the four-column SpMM kernel, see hs_spmm), row_runs, delta_deal (wave: the dealing of DELTA runs of rounds 1-4), pow2_slices (1: column-slice counts 1, 2, 4, 8 only for matrices of more than sixteen sub-tiles, the rule of rounds 1-4), aux_bits, xcd_affinity, retile (host), bitmap_skew, bitmap_x_lds,
  * bitmap_build, walk_lanes, no_mfma_image, mfma_chunk, light (0|1: the small-matrix kernel), sweep (0|1: the
  * column-ordered format of very sparse matrices), plan_debug; call-time keys: spmm_fused, spmm_mfma,
- * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph, batch_graph (hs_run_batch); carry_combine (0|1, plan-time: see hs_run), stream_resident (0|1, plan-time: SWEEP and PAIRS / DELTA images streamed without the non-temporal hint; default: SWEEP images up to 256 MiB, the Infinity Cache; PAIRS / DELTA images up to 256 MiB whose blocks walk several units, or up to 32 MiB: hs_stats.stream_resident says what the plan took).  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
+ * spmspv (sparse|auto|dense), spmspv_crossover, iterate_graph, batch_graph (hs_run_batch); carry_combine (0|1, plan-time: see hs_run), stream_resident (0|1, plan-time: SWEEP and PAIRS / DELTA images streamed without the non-temporal hint; default: SWEEP images up to 256 MiB, the Infinity Cache; PAIRS / DELTA images up to 256 MiB whose blocks walk several units, or up to 32 MiB: hs_stats.stream_resident says what the plan took).  autotune (0|1, plan-time, round 6: the load builds the planner's own image AND every other element format the matrix can take, times a few SpMVs of each on a zero vector and keeps the fastest -- a handful of extra loads of tens of milliseconds each, for callers that run one matrix thousands of times; a forced stream_format switches it off; hs_get_stats says what was kept), plan_census (0: plan from the rows' non-zero counts alone, as rounds 1-5 did).  value NULL or "" clears the option.  An unknown key is HS_ERR_BAD_ARG.
  * Options set here win over the environment variable of the same name, which stays as the fallback for tools and tests.  None of them
  * changes WHAT is computed.  The switches that do (HISPARSE_ABLATE, HISPARSE_DEPTH: profiling builds with parts of the work removed) are
  * not options: they exist only in libhisparse_hip_prof.so, and this library refuses to run (HS_ERR_BAD_ARG from hs_run, hs_run_partition,

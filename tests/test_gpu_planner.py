@@ -44,3 +44,42 @@ def test_planner_choice_against_the_best_forced_plan(name, record_property):
     bound = KNOWN_MISSES.get(name, 1.10)
     assert res["planner_over_best"] <= bound, (f"{name}: planner {res['planner']} {res['planner_us']} us, best forced {res['best_forced']} {res['best_forced_us']} us "
                                                f"= {res['planner_over_best']:.3f} x (bound {bound})")
+
+
+@pytest.mark.parametrize("name,impl_want", [("stencil_300k_3x20", "owner24"), ("rmat19_45_15_15", None), ("dense_2048_x_8k_15", None)])
+def test_autotune_keeps_the_fastest_measured_plan(name, impl_want):
+    """hs_set_option "autotune" = 1 (round 6, opt-in): the load measures the planner's own image against every other element format and keeps the fastest.  On the
+    known close call of the second list (a fixed-point one-slice plan that OWNER24 runs 1.3 x faster) it must switch; elsewhere it must end within 3 % of the
+    planner's plan or better; the result is the oracle's either way, and the caller's options are as they were."""
+    import numpy as np
+    import planner_check as pc
+    from hisparse_amd import device, host
+    from oracle import oracle as orc
+    import cases
+    case = next(c for c in pc.CASES + pc.SECOND if c[0] == name)
+    impl, m = case[1], case[2]()
+    csr = host.CSRMatrix.from_scipy(m)
+    cp = host.format_matrix(csr, impl, skip_empty_rows=True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 3, impl))
+    want = orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+    times = {}
+    for tune in ("0", "1"):
+        with device.SpmvEngine(impl) as eng:
+            eng.set_option("autotune", tune)
+            eng.set_option("light", "0")                     # a caller's own option must survive the tuning loads
+            eng.load_matrix(cp)
+            st = eng.stats()
+            eng.load_vector(xw)
+            eng.run()
+            got = eng.read_result()
+            assert np.array_equal(got, want) if impl == 0 else cases.float_close(got, want)
+            for _ in range(300):
+                eng.run()
+            eng.sync()
+            times[tune] = (min(eng.time_runs(5, 200, kernel=False)[0] / 200 for _ in range(3)) * 1e3, device.STREAM_FORMATS[st["stream_format"]])
+            eng.load_matrix(cp)                              # ... and the next load tunes again from a clean option state
+            assert device.STREAM_FORMATS[eng.stats()["stream_format"]] == times[tune][1]
+    (plain_us, plain_fmt), (tuned_us, tuned_fmt) = times["0"], times["1"]
+    if impl_want:
+        assert tuned_fmt == impl_want and tuned_us < 0.9 * plain_us, times
+    assert tuned_us <= 1.04 * plain_us, times
