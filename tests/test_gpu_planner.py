@@ -77,8 +77,10 @@ def test_autotune_keeps_the_fastest_measured_plan(name, impl_want):
                 eng.run()
             eng.sync()
             times[tune] = (min(eng.time_runs(5, 200, kernel=False)[0] / 200 for _ in range(3)) * 1e3, device.STREAM_FORMATS[st["stream_format"]])
-            eng.load_matrix(cp)                              # ... and the next load tunes again from a clean option state
-            assert device.STREAM_FORMATS[eng.stats()["stream_format"]] == times[tune][1]
+            eng.set_option("autotune", "0")                  # ... and the tuning loads left no forced format behind: without the option the next load is
+            eng.load_matrix(cp)                              # the planner's own plan again (two formats within 3 % of each other may swap between tuned loads)
+            planner_fmt = device.STREAM_FORMATS[eng.stats()["stream_format"]]
+            assert planner_fmt == times.get("0", (None, planner_fmt))[1]
     (plain_us, plain_fmt), (tuned_us, tuned_fmt) = times["0"], times["1"]
     if impl_want:
         assert tuned_fmt == impl_want and tuned_us < 0.9 * plain_us, times
