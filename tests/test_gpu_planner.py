@@ -85,3 +85,49 @@ def test_autotune_keeps_the_fastest_measured_plan(name, impl_want):
     if impl_want:
         assert tuned_fmt == impl_want and tuned_us < 0.9 * plain_us, times
     assert tuned_us <= 1.08 * plain_us, times      # (ties within 3 % go to the planner's plan; a wrong pick at that margin costs no more than this)
+
+
+STRUCTURED = [("banded", lambda impl: __import__("planner_check").banded(150_000, 16, 800, 41, impl)),
+              ("block_diagonal", lambda impl: __import__("planner_check").block_diagonal(90_000, 256, 0.12, 42, impl)),
+              ("hub_rows", lambda impl: __import__("planner_check").hubs(150_000, 10, 20, 70_000, 43, impl)),
+              ("few_long_rows_over_4m_columns", lambda impl: __import__("planner_check").uniform(2_048, 4_000_000, 600, 44, impl)),
+              ("float_one_slice", lambda impl: __import__("planner_check").block_diagonal(360_000, 64, 0.5, 45, impl)),
+              ("stencil", lambda impl: __import__("planner_check").diagonals(200_000, (-40_000, 0, 40_000), 30, 12, 46, impl))]
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("kind", [k for k, _ in STRUCTURED])
+def test_structured_matrices_match_the_oracle_under_the_planners_own_plan(kind, impl):
+    """The plans round 6 added (one-slice plans from the census, per-lane sums for hub-row blocks, SWEEP for tiny units, OWNER24 for one-slice float plans)
+    against oracle/cpu_ref.c: whole run, a burst (the carried combine) and the reference's partition-by-partition loop -- bit-exact in fixed point,
+    1e-4 in the float modes."""
+    import numpy as np
+    from hisparse_amd import device, host
+    from oracle import oracle as orc
+    import cases
+    m = dict(STRUCTURED)[kind](impl)
+    if impl != 0:
+        m.data *= np.float32(0.25)
+    cp = host.format_matrix(host.CSRMatrix.from_scipy(m), impl, skip_empty_rows=True)
+    xw = host.pack_vector(impl, cases.random_x(cp.num_cols, 7, impl))
+    want = orc.spmv(impl, [cp.channel_ptr(c)[0] for c in range(16)], xw, cp.num_rows, cp.num_cols, cp.num_row_partitions, cp.num_col_partitions, cp.ob_bank, cp.vb_bank)
+    with device.SpmvEngine(impl) as eng:
+        eng.load_matrix(cp)
+        st = eng.stats()
+        eng.load_vector(xw)
+        eng.run()
+        one = eng.read_result()
+        eng.run_batch(3)
+        burst = eng.read_result()
+        for j in range(cp.num_row_partitions):
+            eng.run_partition(j, cp.part_len(j))
+        parts = eng.read_result()
+    for y in (one, burst, parts):
+        assert np.array_equal(y, want) if impl == 0 else cases.float_close(y, want), (kind, device.STREAM_FORMATS[st["stream_format"]], st["col_slices"])
+    fmt = device.STREAM_FORMATS[st["stream_format"]]
+    if kind in ("banded", "block_diagonal"):
+        assert st["col_slices"] == 1 or fmt in ("owner24", "sweep"), (fmt, st["col_slices"])
+    if kind == "few_long_rows_over_4m_columns":
+        assert fmt == "sweep"
+    if kind == "float_one_slice" and impl != 0:
+        assert fmt == "owner24"
