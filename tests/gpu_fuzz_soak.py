@@ -1,5 +1,5 @@
 """Long seeded fuzz on one GPU: random shapes / densities / bank sizes / numeric modes / stream formats, every result compared
-with the oracle; prints the parameters of any failing case.  usage: [FUZZ_PROFILE=dense|large] python tests/gpu_fuzz_soak.py [cases] [seed]"""
+with the oracle; prints the parameters of any failing case.  usage: [FUZZ_PROFILE=dense|large|structured] python tests/gpu_fuzz_soak.py [cases] [seed]"""
 import os, sys, time
 import numpy as np
 import scipy.sparse as sp
@@ -21,6 +21,9 @@ def run(n_cases=200, seed=1, profile=None, verbose=True):
         if profile == "dense":      # few long rows: heavy same-accumulator traffic
             rows = int(rng.integers(1, 2000)); cols = int(rng.integers(64, 5000))
             density = float(rng.choice([0.1, 0.3, 0.6]))
+        elif profile == "structured":   # round 6: banded / block-diagonal / hub rows / few long rows over many columns -- the plans the tile census, the hub-row
+            rows = int(rng.integers(2000, 90000)); cols = int(rng.integers(2000, 90000))      # rule and the tiny-unit rule pick, under random banks (several row / column
+            density = float(rng.choice([0.0003, 0.002, 0.01]))                                # partitions), slices and formats, device image against the host builder's
         elif profile == "large":    # several row blocks per workgroup, column slices, bridges
             rows = int(rng.integers(20000, 120000)); cols = int(rng.integers(20000, 120000))
             density = float(rng.choice([0.00002, 0.0001, 0.0005]))
@@ -48,6 +51,33 @@ def run(n_cases=200, seed=1, profile=None, verbose=True):
             ip, ix, dv = csr.arrays()
             m = sp.csr_matrix((dv, ix.astype(np.int64), ip.astype(np.int64)), shape=(rows, cols))
             cp = host.format_matrix(csr, impl, vb_bank=vb, ob_bank=ob, skip_empty_rows=skip)
+        elif profile == "structured":
+            srng = np.random.default_rng(seed)
+            kind = str(srng.choice(["banded", "blockdiag", "hubs", "wide"]))
+            per_row = max(1, int(density * cols))
+            if kind == "wide":
+                rows = int(srng.integers(8, 600)); cols = int(srng.integers(200000, 1500000)); per_row = int(srng.integers(50, 800))
+            r = np.repeat(np.arange(rows, dtype=np.int64), per_row)
+            if kind == "banded":
+                half = int(srng.integers(8, max(9, cols // 8)))
+                c = np.clip(r * cols // max(1, rows) + srng.integers(-half, half + 1, r.size), 0, cols - 1)
+            elif kind == "blockdiag":
+                blk = int(srng.choice([32, 64, 256, 1024]))
+                c = np.minimum((r * cols // max(1, rows)) // blk * blk + srng.integers(0, blk, r.size), cols - 1)
+            else:
+                c = srng.integers(0, cols, r.size)
+            if kind == "hubs":
+                hub = np.repeat(srng.choice(rows, int(srng.integers(1, 6)), replace=False), int(srng.integers(2000, min(cols, 40000))))
+                r = np.concatenate([r, hub]); c = np.concatenate([c, srng.integers(0, cols, hub.size)])
+            key = np.unique(r * cols + c)
+            vals = (srng.uniform(0.0, 1.0, key.size) if impl == 0 else srng.normal(size=key.size) * 0.5).astype(np.float32)
+            m = sp.csr_matrix((vals, (key // cols, key % cols)), shape=(rows, cols))
+            m.sort_indices()
+            if kind == "wide":
+                vb, ob = host.default_banks(impl)
+            else:      # (bank sizes that keep the partition grid of a 90 K-column matrix in the thousands)
+                vb = int(srng.choice([16, 64, 4096])); ob = int(srng.choice([2, 8, 64])) * (8 if impl == 2 else 1)
+            _, cp = cases.formatted(m, impl, vb, ob, skip)
         else:
             m = cases.random_csr(rows, cols, density, seed, impl)
             _, cp = cases.formatted(m, impl, vb, ob, skip)
